@@ -1,0 +1,33 @@
+# Top-level build: HIP library (gfx950), drop-in executables, oracle (test infrastructure).
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+ARCH    ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude
+LIB      = ebwt2snp_amd/libe2s_hip.so
+CSRC     = ebwt2snp_amd/csrc
+HOST     = ebwt2snp_amd/host
+
+all: lib bins oracle
+
+lib: $(LIB)
+
+$(LIB): $(CSRC)/e2s_kernels.hip $(CSRC)/e2s_capi.hip $(CSRC)/e2s_internal.h $(CSRC)/e2s_swar.h $(HOST)/snp_tail.cpp include/e2s_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/e2s_kernels.hip $(CSRC)/e2s_capi.hip $(HOST)/snp_tail.cpp
+
+bins: bin/ebwt2clust bin/clust2snp
+
+bin/%: $(HOST)/%_main.cpp $(HOST)/egsa_files.hpp $(LIB)
+	@mkdir -p bin
+	$(CXX) -O2 -std=c++17 -Wall -Iinclude -o $@ $< -Lebwt2snp_amd -le2s_hip -Wl,-rpath,'$$ORIGIN/../ebwt2snp_amd'
+
+oracle:
+	$(MAKE) -C oracle
+
+asm: $(CSRC)/e2s_kernels.hip
+	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build_kernels.s $(CSRC)/e2s_kernels.hip -Rpass-analysis=kernel-resource-usage
+
+clean:
+	rm -rf $(LIB) bin build_kernels.s
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib bins oracle asm clean

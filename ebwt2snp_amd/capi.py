@@ -1,0 +1,280 @@
+"""ctypes binding of libe2s_hip.so (include/e2s_hip.h).  Plumbing only: every compute call goes to
+the HIP library; there is no Python or CPU fallback -- without the library or without a GPU the
+calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libe2s_hip.so")
+
+E2S_NONE = (1 << 64) - 1
+MAX_CLUST_LEN = 150
+
+ERR = {0: "OK", 1: "ERR_ARG", 2: "ERR_HIP", 3: "ERR_STATE", 4: "ERR_CAPACITY", 5: "ERR_SPIN_TIMEOUT",
+       6: "ERR_INPUT", 7: "ERR_REF_CRASH", 8: "ERR_IO"}
+
+
+class E2SError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR.get(code, code), msg))
+        self.code = code
+
+
+class ShardDesc(C.Structure):
+    _fields_ = [("global_offset", C.c_uint64), ("n_entries", C.c_uint64), ("n_total", C.c_uint64),
+                ("halo_left", C.c_uint32), ("halo_right", C.c_uint32),
+                ("lcp_bytes", C.c_int32), ("da_bytes", C.c_int32), ("pos_bytes", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Boundary(C.Structure):
+    _fields_ = [("n_ends", C.c_uint64), ("open_start", C.c_uint64), ("last_end_start", C.c_uint64),
+                ("begins_inside", C.c_uint32), ("open_after", C.c_uint32), ("pass_through", C.c_uint32),
+                ("end_before_last", C.c_uint32), ("first_end_low16", C.c_uint32), ("tail_lcp", C.c_uint32),
+                ("tail_prev_lcp", C.c_uint32), ("tail_bwt", C.c_uint32), ("reserved", C.c_uint64 * 2)]
+
+
+class StitchPlan(C.Structure):
+    _fields_ = [("patch_first", C.c_uint32), ("n_tail", C.c_uint32), ("first_start", C.c_uint64),
+                ("tail_start", C.c_uint64 * 2), ("first_len", C.c_uint16), ("tail_len", C.c_uint16 * 2),
+                ("reserved16", C.c_uint16), ("phantom_lcp", C.c_uint32), ("reserved32", C.c_uint32)]
+
+
+class Hist(C.Structure):
+    _fields_ = [("freq", C.c_uint64 * (MAX_CLUST_LEN + 1)), ("n_records", C.c_uint64), ("n_bases", C.c_uint64),
+                ("last_len", C.c_uint64)]
+
+
+class C2SParams(C.Structure):
+    _fields_ = [("nr_reads1", C.c_uint64), ("k_left", C.c_int32), ("k_right", C.c_int32), ("mcov_out", C.c_int32),
+                ("consensus_reads", C.c_int32), ("max_clust_length", C.c_int32), ("min_len", C.c_int32)]
+
+
+class CandHeader(C.Structure):
+    _fields_ = [("record_index", C.c_uint64), ("pair_index", C.c_uint32), ("n0", C.c_uint32), ("n1", C.c_uint32),
+                ("right_idx", C.c_uint32), ("right_pos", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class TailParams(C.Structure):
+    _fields_ = [("k_left", C.c_int32), ("k_right", C.c_int32), ("max_gap", C.c_int32), ("max_err", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("scan_ms", C.c_float), ("scan_main_ms", C.c_float), ("hist_ms", C.c_float), ("cand_ms", C.c_float),
+                ("cand_main_ms", C.c_float), ("upload_ms", C.c_float),
+                ("scan_bytes_read", C.c_uint64), ("scan_bytes_written", C.c_uint64),
+                ("cand_bytes_read", C.c_uint64), ("cand_bytes_written", C.c_uint64)]
+
+
+# every symbol include/e2s_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
+           "e2s_attach_soa", "e2s_upload_lcp", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
+           "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_load_clusters", "e2s_cluster_hist",
+           "e2s_auto_max_clust_length", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates",
+           "e2s_snp_from_candidates", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP extension not built: %s missing (run `make lib` or __graft_entry__.build())" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.e2s_create.argtypes = [C.c_int, C.POINTER(H)]
+    L.e2s_destroy.argtypes = [H]
+    L.e2s_last_error.argtypes = [H]
+    L.e2s_last_error.restype = C.c_char_p
+    L.e2s_version.restype = C.c_char_p
+    L.e2s_upload_bcr.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.e2s_upload_gesa.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p]
+    L.e2s_attach_soa.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.e2s_upload_lcp.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_uint8]
+    L.e2s_cluster_scan.argtypes = [H, C.c_int, C.c_int, C.c_int]
+    L.e2s_boundary_desc.argtypes = [H, C.POINTER(Boundary)]
+    L.e2s_stitch.argtypes = [H, C.POINTER(Boundary), C.c_int, C.c_int]
+    L.e2s_stitch_plan.argtypes = [C.POINTER(Boundary), C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(StitchPlan)]
+    L.e2s_cluster_counts.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_fetch_clusters.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.e2s_load_clusters.argtypes = [H, C.c_void_p, C.c_uint64]
+    L.e2s_cluster_hist.argtypes = [H, C.POINTER(Hist)]
+    L.e2s_auto_max_clust_length.argtypes = [C.POINTER(Hist), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_find_candidates.argtypes = [H, C.POINTER(C2SParams), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.e2s_candidate_stride.argtypes = [H, C.POINTER(C2SParams), C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
+    L.e2s_fetch_candidates.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.e2s_snp_from_candidates.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p,
+                                          C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_last_timing.argtypes = [H, C.POINTER(Timing)]
+    L.e2s_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    L.e2s_synchronize.argtypes = [H]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    """host numpy array or integer device pointer -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))
+
+
+class Handle:
+    """One GPU, one EGSA shard.  Thin object wrapper over the C ABI."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.e2s_create(device, C.byref(self.h))
+        if rc:
+            raise E2SError(rc, self.L.e2s_last_error(None).decode())
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.e2s_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise E2SError(rc, self.L.e2s_last_error(self.h).decode())
+
+    @staticmethod
+    def desc(n_total, offset=0, n_entries=None, halo_left=0, halo_right=0, x=1, y=4, z=1):
+        return ShardDesc(offset, n_total if n_entries is None else n_entries, n_total, halo_left, halo_right, x, y, z, 0)
+
+    def upload_bcr(self, d, bwt, lcp, pairsa):
+        self._ck(self.L.e2s_upload_bcr(self.h, C.byref(d), _ptr(bwt), _ptr(lcp), _ptr(pairsa)))
+
+    def upload_gesa(self, d, aos):
+        self._ck(self.L.e2s_upload_gesa(self.h, C.byref(d), _ptr(aos)))
+
+    def upload_lcp(self, d, lcp, tail_bwt):
+        self._ck(self.L.e2s_upload_lcp(self.h, C.byref(d), _ptr(lcp), int(tail_bwt)))
+
+    def attach_soa(self, d, d_bwt, d_lcp, d_pos, d_da, keep=()):
+        self._keep = list(keep)
+        self._ck(self.L.e2s_attach_soa(self.h, C.byref(d), _ptr(d_bwt), _ptr(d_lcp), _ptr(d_pos), _ptr(d_da)))
+
+    def cluster_scan(self, k=16, min_len=2, scan_mode=0):
+        self._ck(self.L.e2s_cluster_scan(self.h, k, min_len, scan_mode))
+
+    def boundary(self):
+        b = Boundary()
+        self._ck(self.L.e2s_boundary_desc(self.h, C.byref(b)))
+        return b
+
+    def stitch(self, all_b, rank):
+        arr = (Boundary * len(all_b))(*all_b)
+        self._ck(self.L.e2s_stitch(self.h, arr, len(all_b), rank))
+
+    def scan_single(self, k=16, min_len=2, scan_mode=0):
+        """scan + the (trivial) one-rank stitch"""
+        self.cluster_scan(k, min_len, scan_mode)
+        self.stitch([self.boundary()], 0)
+
+    def counts(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.e2s_cluster_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def fetch_clusters(self):
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_fetch_clusters(self.h, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1) * 10, dtype=np.uint8)
+        self._ck(self.L.e2s_fetch_clusters(self.h, _ptr(buf), n.value, C.byref(n)))
+        return buf[:n.value * 10]
+
+    def load_clusters(self, packed):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        self._ck(self.L.e2s_load_clusters(self.h, _ptr(packed), packed.size // 10))
+
+    def hist(self):
+        hs = Hist()
+        self._ck(self.L.e2s_cluster_hist(self.h, C.byref(hs)))
+        return hs
+
+    def find_candidates(self, params, record_index_base=0):
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_find_candidates(self.h, C.byref(params), record_index_base, C.byref(n)))
+        return n.value
+
+    def fetch_candidates(self, params):
+        cap, stride = C.c_uint32(0), C.c_size_t(0)
+        self._ck(self.L.e2s_candidate_stride(self.h, C.byref(params), C.byref(cap), C.byref(stride)))
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_fetch_candidates(self.h, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1) * stride.value, dtype=np.uint8)
+        self._ck(self.L.e2s_fetch_candidates(self.h, _ptr(buf), n.value, C.byref(n)))
+        return buf[:n.value * stride.value], n.value, cap.value, stride.value
+
+    def timing(self):
+        t = Timing()
+        self._ck(self.L.e2s_last_timing(self.h, C.byref(t)))
+        return t
+
+    def stream(self):
+        s = C.c_void_p()
+        self._ck(self.L.e2s_stream(self.h, C.byref(s)))
+        return s.value
+
+    def synchronize(self):
+        self._ck(self.L.e2s_synchronize(self.h))
+
+
+def stitch_plan(all_b, rank, n_total, k=16, lcp_bytes=1):
+    """Host-only: what `rank` must patch/append once it holds every shard's boundary descriptor."""
+    arr = (Boundary * len(all_b))(*all_b)
+    pl = StitchPlan()
+    rc = lib().e2s_stitch_plan(arr, len(all_b), rank, n_total, k, lcp_bytes, C.byref(pl))
+    if rc:
+        raise E2SError(rc, "e2s_stitch_plan: inconsistent boundary descriptors")
+    return pl
+
+
+def auto_max_clust_length(hists, mcov_out=5, pval=0.99):
+    """Host-only: statistics() of clust2snp.cpp:877-966 over per-shard partial histograms."""
+    arr = (Hist * len(hists))(*hists)
+    mcl, nc, nb = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+    rc = lib().e2s_auto_max_clust_length(arr, len(hists), mcov_out, pval, C.byref(mcl), C.byref(nc), C.byref(nb))
+    if rc:
+        raise E2SError(rc, "statistics(): the reference crashes on this input")
+    return mcl.value, nc.value, nb.value
+
+
+def snp_from_candidates(cands, n_cand, list_cap, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2):
+    p = TailParams(k_left, k_right, max_gap, max_err)
+    nv, ne = C.c_uint64(0), C.c_uint64(0)
+    cands = np.ascontiguousarray(cands, dtype=np.uint8)
+    rc = lib().e2s_snp_from_candidates(_ptr(cands), n_cand, list_cap, C.byref(p), fasta_path.encode(), out_path.encode(),
+                                       C.byref(nv), C.byref(ne))
+    if rc:
+        raise E2SError(rc, "e2s_snp_from_candidates")
+    return nv.value, ne.value
+
+
+def parse_candidates(buf, n_cand, list_cap, stride):
+    """fetch_candidates bytes -> list of dicts (same shape as tests/oracle_lib.candidates)."""
+    out = []
+    hs = C.sizeof(CandHeader)
+    for c in range(n_cand):
+        rec = buf[c * stride:(c + 1) * stride]
+        h = CandHeader.from_buffer_copy(rec[:hs].tobytes())
+        l = rec[hs:].view(np.uint32)
+        out.append(dict(record_index=h.record_index, pair_index=h.pair_index, right_idx=h.right_idx, right_pos=h.right_pos,
+                        idx0=l[0:h.n0].tolist(), pos0=l[list_cap:list_cap + h.n0].tolist(),
+                        idx1=l[2 * list_cap:2 * list_cap + h.n1].tolist(), pos1=l[3 * list_cap:3 * list_cap + h.n1].tolist()))
+    return out

@@ -1,0 +1,750 @@
+// e2s_capi.hip -- the C ABI of include/e2s_hip.h: handle, residency, launches, stitching.
+// Host code only (compiled by hipcc for the HIP runtime API); kernels live in e2s_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/e2s_hip.h"
+#include "e2s_internal.h"
+
+static_assert(sizeof(CandHeader) == sizeof(e2s_cand_header), "candidate header layout");
+static_assert(E2S_MAX_CLUST_LEN == E2S_MAX_CLUST_LEN_K, "max cluster length");
+
+static std::string g_create_error;
+
+struct e2s_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // shard
+    bool have_shard = false, attached = false;
+    e2s_shard_desc d{};
+    int layout = 0;                              // 0: BCR field order, 1: .gesa field order (EOF phantom model)
+    uint8_t* bwt = nullptr; void* lcp = nullptr; void* pos = nullptr; void* da = nullptr;
+    int xb = 1, yb = 4, zb = 1;                  // device widths (8-byte file fields are held as 4)
+    uint64_t n_prov = 0, prov_lo = 0;
+    std::vector<void*> owned;
+    // scan state
+    uint64_t* d_starts = nullptr; uint16_t* d_lens = nullptr; uint64_t cap = 0;
+    uint64_t* d_tile_state = nullptr; uint64_t* d_tile_fix = nullptr; uint32_t* d_tile_count = nullptr; uint64_t* d_tile_prefix = nullptr;
+    uint64_t tiles_cap = 0;
+    uint64_t* d_scalars = nullptr;               // [0] total_ends  [1] cand_count  [2..] hist (153)
+    uint32_t* d_words = nullptr;                 // [0] tile_counter [1] err [2,3] flags [4,5] tailv
+    bool scanned = false, stitched = false, records_from_file = false;
+    int k = 16, min_len = 2;
+    uint64_t n_ends = 0, n_rec = 0, n_closed = 0;
+    uint32_t begins_inside = 0, open_after = 0, end_before_last = 0;
+    uint32_t tail_lcp = 0, tail_prev_lcp = 0, tail_bwt = 0;
+    uint16_t first_len_prov = 0;
+    uint64_t open_start = E2S_NONE, last_end_start = E2S_NONE;
+    // candidates
+    uint8_t* d_cand = nullptr; uint64_t cand_cap = 0, cand_bytes = 0; uint32_t cand_stride = 0, list_cap = 0; uint64_t n_cand = 0;
+    bool tail_bwt_given = false; uint8_t tail_bwt_arg = 0;
+    // timing
+    hipEvent_t ev[8] = {};
+    e2s_timing tm{};
+};
+
+#define CK(call)                                                                                         \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);                                  \
+            return E2S_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+
+static int fail(e2s_handle h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
+
+extern "C" const char* e2s_version(void) { return "ebwt2snp_amd 0.1 (gfx950)"; }
+
+extern "C" const char* e2s_last_error(e2s_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int e2s_create(int device_id, e2s_handle* out) {
+    if (!out) return E2S_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e) +
+                         " (this library has no CPU path)";
+        return E2S_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) { g_create_error = "device id out of range"; return E2S_ERR_ARG; }
+    e2s_ctx* h = new e2s_ctx();
+    h->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice/hipStreamCreate: ") + hipGetErrorString(e);
+        delete h;
+        return E2S_ERR_HIP;
+    }
+    for (auto& ev : h->ev) hipEventCreate(&ev);
+    if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess) {
+        g_create_error = "hipMalloc failed";
+        delete h;
+        return E2S_ERR_HIP;
+    }
+    *out = h;
+    return E2S_OK;
+}
+
+static void release_shard(e2s_ctx* h) {
+    for (void* p : h->owned) hipFree(p);
+    h->owned.clear();
+    h->bwt = nullptr; h->lcp = h->pos = h->da = nullptr;
+    h->have_shard = false; h->attached = false; h->scanned = h->stitched = false; h->records_from_file = false;
+    h->tail_bwt_given = false;
+}
+
+extern "C" int e2s_destroy(e2s_handle h) {
+    if (!h) return E2S_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    release_shard(h);
+    hipFree(h->d_starts); hipFree(h->d_lens); hipFree(h->d_tile_state); hipFree(h->d_tile_fix);
+    hipFree(h->d_tile_count); hipFree(h->d_tile_prefix); hipFree(h->d_scalars); hipFree(h->d_words); hipFree(h->d_cand);
+    for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return E2S_OK;
+}
+
+extern "C" int e2s_stream(e2s_handle h, void** stream) { if (!h || !stream) return E2S_ERR_ARG; *stream = (void*)h->stream; return E2S_OK; }
+extern "C" int e2s_synchronize(e2s_handle h) { if (!h) return E2S_ERR_ARG; CK(hipSetDevice(h->device)); CK(hipStreamSynchronize(h->stream)); return E2S_OK; }
+
+static bool width_ok(int w) { return w == 1 || w == 2 || w == 4 || w == 8; }
+
+static int check_desc(e2s_handle h, const e2s_shard_desc* d) {
+    if (!h || !d) return E2S_ERR_ARG;
+    if (!width_ok(d->lcp_bytes) || !width_ok(d->da_bytes) || !width_ok(d->pos_bytes))
+        return fail(h, E2S_ERR_ARG, "byte widths must be 1, 2, 4 or 8 (the reference leaves other widths uninitialised)");
+    if (d->n_total == 0 || d->n_entries == 0) return fail(h, E2S_ERR_ARG, "empty EGSA (the reference reads uninitialised memory here)");
+    if (d->global_offset + d->n_entries > d->n_total) return fail(h, E2S_ERR_ARG, "shard exceeds the EGSA");
+    if (d->halo_left > d->global_offset) return fail(h, E2S_ERR_ARG, "halo_left reaches before the array start");
+    if (d->global_offset + d->n_entries + d->halo_right > d->n_total) return fail(h, E2S_ERR_ARG, "halo_right reaches past the array end");
+    const uint64_t need_l = std::min<uint64_t>(d->global_offset, E2S_MAX_CLUST_LEN + 2);
+    const uint64_t need_r = std::min<uint64_t>(d->n_total - d->global_offset - d->n_entries, 1);
+    if (d->halo_left < need_l || d->halo_right < need_r)
+        return fail(h, E2S_ERR_ARG, "halo too small: need min(offset, 152) entries on the left and 1 on the right");
+    return E2S_OK;
+}
+
+static void set_shard_common(e2s_ctx* h, const e2s_shard_desc* d) {
+    h->d = *d;
+    h->n_prov = (uint64_t)d->halo_left + d->n_entries + d->halo_right;
+    h->prov_lo = d->global_offset - d->halo_left;
+    h->xb = std::min(d->lcp_bytes, 4); h->yb = std::min(d->da_bytes, 4); h->zb = std::min(d->pos_bytes, 4);
+    h->have_shard = true;
+    h->scanned = h->stitched = false; h->records_from_file = false;
+}
+
+static int dev_alloc(e2s_ctx* h, void** p, size_t bytes) {
+    CK(hipMalloc(p, bytes + 256));
+    h->owned.push_back(*p);
+    return E2S_OK;
+}
+
+extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa) {
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if (!bwt || !lcp || !pairsa) return fail(h, E2S_ERR_ARG, "null source pointer");
+    CK(hipSetDevice(h->device));
+    release_shard(h);
+    set_shard_common(h, d);
+    h->layout = 0;
+    const uint64_t n = h->n_prov;
+    CK(hipEventRecord(h->ev[0], h->stream));
+    if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
+    if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
+    if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
+    if ((rc = dev_alloc(h, &h->da, n * h->yb))) return rc;
+    CK(hipMemcpyAsync(h->bwt, bwt, n, hipMemcpyHostToDevice, h->stream));
+    void* stage = nullptr;
+    if (d->lcp_bytes == 8) {
+        CK(hipMalloc(&stage, n * 8));
+        CK(hipMemcpyAsync(stage, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        e2s_launch_narrow8((const uint8_t*)stage, n, (uint32_t*)h->lcp, h->stream);
+        CK(hipStreamSynchronize(h->stream));
+        CK(hipFree(stage));
+    } else {
+        CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
+    }
+    const size_t rec = (size_t)d->pos_bytes + d->da_bytes;
+    CK(hipMalloc(&stage, n * rec + 16));
+    CK(hipMemcpyAsync(stage, pairsa, n * rec, hipMemcpyHostToDevice, h->stream));
+    e2s_launch_unpack_pairsa((const uint8_t*)stage, n, d->pos_bytes, d->da_bytes, h->pos, h->zb, h->da, h->yb, h->stream);
+    CK(hipEventRecord(h->ev[1], h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipFree(stage));
+    CK(hipGetLastError());
+    hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    return E2S_OK;
+}
+
+extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void* aos) {
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if (!aos) return fail(h, E2S_ERR_ARG, "null source pointer");
+    CK(hipSetDevice(h->device));
+    release_shard(h);
+    set_shard_common(h, d);
+    h->layout = 1;
+    const uint64_t n = h->n_prov;
+    CK(hipEventRecord(h->ev[0], h->stream));
+    if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
+    if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
+    if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
+    if ((rc = dev_alloc(h, &h->da, n * h->yb))) return rc;
+    const size_t rec = (size_t)d->da_bytes + d->pos_bytes + d->lcp_bytes + 1;
+    void* stage = nullptr;
+    CK(hipMalloc(&stage, n * rec + 16));
+    CK(hipMemcpyAsync(stage, aos, n * rec, hipMemcpyHostToDevice, h->stream));
+    e2s_launch_unpack_gesa((const uint8_t*)stage, n, d->da_bytes, d->pos_bytes, d->lcp_bytes, h->bwt, h->lcp, h->xb, h->pos, h->zb,
+                           h->da, h->yb, h->stream);
+    CK(hipEventRecord(h->ev[1], h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipFree(stage));
+    CK(hipGetLastError());
+    hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    return E2S_OK;
+}
+
+extern "C" int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, const void* d_lcp, const void* d_pos,
+                              const void* d_da) {
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if (d->lcp_bytes == 8 || d->da_bytes == 8 || d->pos_bytes == 8) return fail(h, E2S_ERR_ARG, "attach: 8-byte fields must be narrowed first");
+    if (!d_lcp) return fail(h, E2S_ERR_ARG, "null lcp pointer");
+    if (((uintptr_t)d_lcp & 15u) != 0) return fail(h, E2S_ERR_ARG, "attach: the LCP array must be 16-byte aligned");
+    CK(hipSetDevice(h->device));
+    release_shard(h);
+    set_shard_common(h, d);
+    h->layout = 0;
+    h->attached = true;
+    h->bwt = (uint8_t*)d_bwt; h->lcp = (void*)d_lcp; h->pos = (void*)d_pos; h->da = (void*)d_da;
+    return E2S_OK;
+}
+
+extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void* lcp, uint8_t tail_bwt) {
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if (!lcp) return fail(h, E2S_ERR_ARG, "null source pointer");
+    CK(hipSetDevice(h->device));
+    release_shard(h);
+    set_shard_common(h, d);
+    h->layout = 0;
+    h->tail_bwt_given = true; h->tail_bwt_arg = tail_bwt;
+    const uint64_t n = h->n_prov;
+    CK(hipEventRecord(h->ev[0], h->stream));
+    if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
+    if (d->lcp_bytes == 8) {
+        void* stage = nullptr;
+        CK(hipMalloc(&stage, n * 8));
+        CK(hipMemcpyAsync(stage, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        e2s_launch_narrow8((const uint8_t*)stage, n, (uint32_t*)h->lcp, h->stream);
+        CK(hipStreamSynchronize(h->stream));
+        CK(hipFree(stage));
+    } else {
+        CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
+    }
+    CK(hipEventRecord(h->ev[1], h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipGetLastError());
+    hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    return E2S_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ebwt2clust: scan
+// ---------------------------------------------------------------------------------------------
+static int ensure_records(e2s_ctx* h, uint64_t cap) {
+    if (cap <= h->cap && h->d_starts) return E2S_OK;
+    hipFree(h->d_starts); hipFree(h->d_lens);
+    h->d_starts = nullptr; h->d_lens = nullptr; h->cap = 0;
+    CK(hipMalloc((void**)&h->d_starts, (cap + 8) * sizeof(uint64_t)));
+    CK(hipMalloc((void**)&h->d_lens, (cap + 8) * sizeof(uint16_t) + 64));
+    h->cap = cap;
+    return E2S_OK;
+}
+
+static int ensure_tiles(e2s_ctx* h, uint64_t n_tiles) {
+    if (n_tiles <= h->tiles_cap) return E2S_OK;
+    hipFree(h->d_tile_state); hipFree(h->d_tile_fix); hipFree(h->d_tile_count); hipFree(h->d_tile_prefix);
+    h->tiles_cap = 0;
+    CK(hipMalloc((void**)&h->d_tile_state, n_tiles * 8));
+    CK(hipMalloc((void**)&h->d_tile_fix, n_tiles * 8));
+    CK(hipMalloc((void**)&h->d_tile_count, n_tiles * 4));
+    CK(hipMalloc((void**)&h->d_tile_prefix, n_tiles * 8));
+    h->tiles_cap = n_tiles;
+    return E2S_OK;
+}
+
+extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode) {
+    if (!h) return E2S_ERR_ARG;
+    if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
+    if (scan_mode != 0 && scan_mode != 1) return fail(h, E2S_ERR_ARG, "scan_mode must be 0 or 1");
+    CK(hipSetDevice(h->device));
+    const e2s_shard_desc& d = h->d;
+    h->k = k; h->min_len = min_len;
+    h->scanned = h->stitched = false; h->records_from_file = false;
+
+    ScanArgs a{};
+    a.lcp = h->lcp; a.n_prov = h->n_prov; a.prov_lo = h->prov_lo; a.prov_is_global0 = h->prov_lo == 0;
+    a.own_lo = d.halo_left;
+    a.start_hi = (uint64_t)d.halo_left + d.n_entries;
+    // the end test of global position n_total-1 needs the EOF phantom: resolved in e2s_stitch
+    const uint64_t last_end_global = d.n_total - 1;                       // exclusive bound on j for end(j)
+    a.end_hi = std::min<uint64_t>(a.start_hi, last_end_global > h->prov_lo ? last_end_global - h->prov_lo : 0);
+    if (a.end_hi < a.own_lo) a.end_hi = a.own_lo;
+    a.k_u32 = (uint32_t)k;
+    const uint64_t lane_max = h->xb == 1 ? 0xFFull : h->xb == 2 ? 0xFFFFull : 0xFFFFFFFFull;
+    const uint32_t H = h->xb == 1 ? 0x80808080u : h->xb == 2 ? 0x80008000u : 0x80000000u;
+    a.hge = ((uint64_t)a.k_u32 > lane_max) ? 0u : H;
+    a.kb = h->xb == 1 ? (a.k_u32 & 0xFF) * 0x01010101u : h->xb == 2 ? (a.k_u32 & 0xFFFF) * 0x00010001u : a.k_u32;
+    const uint64_t tile_entries = (uint64_t)E2S_SCAN_ROWS * E2S_SCAN_BLOCK * (16 / h->xb);
+    a.n_tiles = (h->n_prov + tile_entries - 1) / tile_entries;
+    if (a.n_tiles > 0x7FFFFFFFull) return fail(h, E2S_ERR_ARG, "shard too large for one launch");
+    int rc = ensure_tiles(h, a.n_tiles);
+    if (rc) return rc;
+    uint64_t want = std::max<uint64_t>(h->cap, d.n_entries / 8 + 4096);
+    a.spin_limit = 1u << 22;
+    a.total_ends = h->d_scalars + 0;
+    a.tile_fix = h->d_tile_fix; a.tile_state = h->d_tile_state; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
+    a.tile_counter = h->d_words + 0; a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = ensure_records(h, want))) return rc;
+        a.starts = h->d_starts; a.lens = h->d_lens; a.cap = h->cap;
+        CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
+        CK(hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+        CK(hipMemsetAsync(h->d_tile_fix, 0xFF, a.n_tiles * 8, h->stream));
+        e2s_launch_shard_flags(a, h->xb, h->stream);
+        CK(hipEventRecord(h->ev[0], h->stream));
+        if (scan_mode == 0) {
+            CK(hipMemsetAsync(h->d_tile_state, 0, a.n_tiles * 8, h->stream));
+            CK(hipEventRecord(h->ev[2], h->stream));
+            e2s_launch_scan(a, h->xb, 0, h->stream);
+            CK(hipEventRecord(h->ev[3], h->stream));
+        } else {
+            CK(hipEventRecord(h->ev[2], h->stream));
+            e2s_launch_scan(a, h->xb, 1, h->stream);
+            e2s_launch_tile_scan(h->d_tile_count, (unsigned long long*)h->d_tile_prefix, a.n_tiles, h->stream);
+            e2s_launch_scan(a, h->xb, 2, h->stream);
+            CK(hipEventRecord(h->ev[3], h->stream));
+        }
+        e2s_launch_scan_fix(a.n_tiles, (const unsigned long long*)h->d_tile_fix, (const unsigned long long*)h->d_starts, h->d_lens,
+                            h->cap, a.flags, h->stream);
+        CK(hipEventRecord(h->ev[1], h->stream));
+        uint32_t words[16];
+        uint64_t total = 0;
+        CK(hipMemcpyAsync(words, h->d_words, sizeof(words), hipMemcpyDeviceToHost, h->stream));
+        CK(hipMemcpyAsync(&total, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+        CK(hipGetLastError());
+        h->begins_inside = words[2]; h->open_after = words[3]; h->end_before_last = words[4];
+        if (words[1] & E2S_DEVERR_SPIN) return fail(h, E2S_ERR_SPIN_TIMEOUT, "look-back wait expired");
+        h->tail_lcp = words[8]; h->tail_prev_lcp = words[9];
+        h->n_ends = total;
+        if (total + 4 <= h->cap) break;
+        if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow");
+        want = total + 4096;                                       // rare: rerun with the exact size
+    }
+    hipEventElapsedTime(&h->tm.scan_ms, h->ev[0], h->ev[1]);
+    hipEventElapsedTime(&h->tm.scan_main_ms, h->ev[2], h->ev[3]);
+    h->tm.scan_bytes_read = d.n_entries * (uint64_t)d.lcp_bytes;
+    h->tm.scan_bytes_written = h->n_ends * 10;
+
+    // the few values the boundary descriptor and the EOF phantom need
+    h->open_start = E2S_NONE; h->last_end_start = E2S_NONE; h->first_len_prov = 0;
+    const bool own_start_open = h->open_after && !(h->n_ends == 0 && h->begins_inside);
+    if (own_start_open) CK(hipMemcpy(&h->open_start, h->d_starts + h->n_ends, 8, hipMemcpyDeviceToHost));
+    if (h->n_ends > 0) {
+        if (!(h->n_ends == 1 && h->begins_inside)) CK(hipMemcpy(&h->last_end_start, h->d_starts + h->n_ends - 1, 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&h->first_len_prov, h->d_lens, 2, hipMemcpyDeviceToHost));
+    }
+    h->tail_bwt = 0;
+    const bool last_rank = d.global_offset + d.n_entries == d.n_total;
+    if (last_rank) {
+        if (h->tail_bwt_given) h->tail_bwt = h->tail_bwt_arg;
+        else if (h->bwt) {
+            uint8_t b = 0;
+            CK(hipMemcpy(&b, h->bwt + (h->n_prov - 1), 1, hipMemcpyDeviceToHost));
+            h->tail_bwt = b;
+        } else return fail(h, E2S_ERR_STATE, "the last shard needs the BWT column (or e2s_upload_lcp's tail_bwt) for the EOF rule");
+        if (h->end_before_last && d.n_entries < 2 && d.global_offset > 0)
+            return fail(h, E2S_ERR_ARG, "the last shard must own at least two entries");
+    }
+    h->scanned = true;
+    return E2S_OK;
+}
+
+extern "C" int e2s_boundary_desc(e2s_handle h, e2s_boundary* out) {
+    if (!h || !out) return E2S_ERR_ARG;
+    if (!h->scanned) return fail(h, E2S_ERR_STATE, "e2s_cluster_scan has not run");
+    memset(out, 0, sizeof(*out));
+    out->n_ends = h->n_ends;
+    out->open_start = h->open_start;
+    out->last_end_start = h->last_end_start;
+    out->begins_inside = h->begins_inside;
+    out->open_after = h->open_after;
+    out->pass_through = (h->n_ends == 0 && h->begins_inside && h->open_after) ? 1u : 0u;
+    out->end_before_last = h->end_before_last;
+    out->first_end_low16 = h->first_len_prov;
+    out->tail_lcp = h->tail_lcp;
+    out->tail_prev_lcp = h->tail_prev_lcp;
+    out->tail_bwt = h->tail_bwt;
+    return E2S_OK;
+}
+
+// start of the cluster that is open when rank r begins (walk back over pass-through shards)
+static uint64_t incoming_start(const e2s_boundary* all, int r) {
+    for (int q = r - 1; q >= 0; --q) {
+        if (all[q].open_start != E2S_NONE) return all[q].open_start;
+        if (!all[q].pass_through) return E2S_NONE;
+    }
+    return E2S_NONE;
+}
+
+extern "C" int e2s_stitch_plan(const e2s_boundary* all, int nranks, int rank, uint64_t n, int k, int lcp_bytes,
+                               e2s_stitch_plan_t* out) {
+    if (!all || !out || nranks < 1 || rank < 0 || rank >= nranks) return E2S_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    const e2s_boundary& me = all[rank];
+    const uint32_t ku = (uint32_t)k;
+    uint64_t inc = E2S_NONE;
+    if (me.begins_inside) {
+        inc = incoming_start(all, rank);
+        if (inc == E2S_NONE) return E2S_ERR_INPUT;               // descriptors do not fit together
+        if (me.n_ends > 0) {
+            out->patch_first = 1;
+            out->first_start = inc;
+            out->first_len = (uint16_t)((me.first_end_low16 - (uint32_t)(inc & 0xFFFF)) & 0xFFFF);
+        }
+    }
+    if (rank != nranks - 1) return E2S_OK;
+    // ---- last rank: the reference's EOF phantom (hazard H1; slot model, see oracle/e2s_oracle.c) ----
+    const uint64_t xmask = lcp_bytes >= 8 ? ~0ull : ((1ull << (8 * lcp_bytes)) - 1ull);
+    uint64_t slot = (((uint64_t)me.tail_lcp) & ~0xFFull) | (uint64_t)(me.tail_bwt & 0xFF);
+    if (n >= 3 && me.end_before_last) {
+        // append_entry ran right before the phantom read: the slot holds that cluster's start
+        uint64_t s = me.last_end_start;
+        if (s == E2S_NONE) s = inc;                              // it was this shard's only end and began earlier
+        if (s == E2S_NONE) return E2S_ERR_INPUT;
+        slot = s;
+    }
+    const uint32_t P = (uint32_t)(slot & xmask);
+    out->phantom_lcp = P;
+    const bool open_last = me.open_after != 0;                   // open(n-1)
+    uint64_t cur = E2S_NONE;
+    if (open_last) cur = (me.open_start != E2S_NONE) ? me.open_start : incoming_start(all, rank);
+    int nt = 0;
+    if (n == 1) {
+        // no loop iteration: start = ge(0) ? 0 : (P >= k ? 1 : null); tail flush with i = 1 (ebwt2clust.cpp:83-84,127-131)
+        if (open_last) { out->tail_start[nt] = 0; out->tail_len[nt++] = 2; }
+        else if (P >= ku) { out->tail_start[nt] = 1; out->tail_len[nt++] = 1; }
+    } else if (open_last) {
+        if (cur == E2S_NONE) return E2S_ERR_INPUT;
+        const bool gt = me.tail_prev_lcp > me.tail_lcp;
+        if ((gt && me.tail_lcp <= P) || P < ku) {                // the cluster ends at n-1 (ebwt2clust.cpp:98-106)
+            out->tail_start[nt] = cur; out->tail_len[nt++] = (uint16_t)((n - 1 - cur + 1) & 0xFFFF);
+            if (P >= ku) { out->tail_start[nt] = n; out->tail_len[nt++] = 1; }     // the phantom opens (n,1) (:116-118)
+        } else {                                                 // still open after the loop: the flush includes index n
+            out->tail_start[nt] = cur; out->tail_len[nt++] = (uint16_t)((n - cur + 1) & 0xFFFF);
+        }
+    } else if (P >= ku) { out->tail_start[nt] = n; out->tail_len[nt++] = 1; }
+    out->n_tail = (uint32_t)nt;
+    return E2S_OK;
+}
+
+extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int rank) {
+    if (!h || !all || nranks < 1 || rank < 0 || rank >= nranks) return E2S_ERR_ARG;
+    if (!h->scanned) return fail(h, E2S_ERR_STATE, "e2s_cluster_scan has not run");
+    CK(hipSetDevice(h->device));
+    const e2s_shard_desc& d = h->d;
+    const bool last_rank = d.global_offset + d.n_entries == d.n_total;
+    if (last_rank != (rank == nranks - 1)) return fail(h, E2S_ERR_ARG, "rank order must be SA order: only the last rank may hold the EGSA's end");
+    e2s_stitch_plan_t pl;
+    int rc = e2s_stitch_plan(all, nranks, rank, d.n_total, h->k, d.lcp_bytes, &pl);
+    if (rc) return fail(h, rc, "inconsistent boundary descriptors");
+    if (pl.patch_first) {
+        CK(hipMemcpy(h->d_starts, &pl.first_start, 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(h->d_lens, &pl.first_len, 2, hipMemcpyHostToDevice));
+    }
+    h->n_rec = h->n_ends;
+    h->n_closed = h->n_ends;
+    if (pl.n_tail) {
+        if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
+        CK(hipMemcpy(h->d_starts + h->n_rec, pl.tail_start, 8 * pl.n_tail, hipMemcpyHostToDevice));
+        CK(hipMemcpy(h->d_lens + h->n_rec, pl.tail_len, 2 * pl.n_tail, hipMemcpyHostToDevice));
+        h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
+    }
+    h->stitched = true;
+    return E2S_OK;
+}
+
+extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_records) {
+    if (!h) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
+    if (n_closed) *n_closed = h->n_closed;
+    if (n_records) {
+        e2s_hist hs;
+        int rc = e2s_cluster_hist(h, &hs);
+        if (rc) return rc;
+        *n_records = hs.n_records;
+    }
+    return E2S_OK;
+}
+
+extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records, uint64_t* n_records) {
+    if (!h || !n_records) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
+    CK(hipSetDevice(h->device));
+    std::vector<uint64_t> s(h->n_rec);
+    std::vector<uint16_t> l(h->n_rec);
+    if (h->n_rec) {
+        CK(hipMemcpy(s.data(), h->d_starts, h->n_rec * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(l.data(), h->d_lens, h->n_rec * 2, hipMemcpyDeviceToHost));
+    }
+    uint64_t w = 0;
+    uint8_t* o = (uint8_t*)out;
+    for (uint64_t i = 0; i < h->n_rec; ++i) {
+        if ((int)l[i] >= h->min_len) {                              // append_entry, ebwt2clust.cpp:56
+            if (o && w < cap_records) { memcpy(o + w * 10, &s[i], 8); memcpy(o + w * 10 + 8, &l[i], 2); }
+            ++w;
+        }
+    }
+    *n_records = w;
+    return (o && w > cap_records) ? E2S_ERR_CAPACITY : E2S_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// clust2snp: records from a .clusters file, histogram, candidates
+// ---------------------------------------------------------------------------------------------
+extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_records) {
+    if (!h || (!recs && n_records)) return E2S_ERR_ARG;
+    if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
+    CK(hipSetDevice(h->device));
+    int rc = ensure_records(h, n_records + 8);
+    if (rc) return rc;
+    std::vector<uint64_t> s(n_records);
+    std::vector<uint16_t> l(n_records);
+    const uint8_t* p = (const uint8_t*)recs;
+    uint64_t prev_end = 0;
+    for (uint64_t i = 0; i < n_records; ++i) {
+        memcpy(&s[i], p + i * 10, 8); memcpy(&l[i], p + i * 10 + 8, 2);
+        if (i && s[i] < prev_end) return fail(h, E2S_ERR_INPUT, ".clusters records must be ascending and non-overlapping (H16)");
+        prev_end = s[i] + l[i];
+    }
+    if (n_records) {
+        CK(hipMemcpy(h->d_starts, s.data(), n_records * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(h->d_lens, l.data(), n_records * 2, hipMemcpyHostToDevice));
+    }
+    h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;
+    h->min_len = 0;
+    h->scanned = true; h->stitched = true; h->records_from_file = true;
+    return E2S_OK;
+}
+
+extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
+    if (!h || !out) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
+    CK(hipSetDevice(h->device));
+    memset(out, 0, sizeof(*out));
+    uint64_t* dh = h->d_scalars + 8;
+    CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 3) * 8, h->stream));
+    CK(hipEventRecord(h->ev[4], h->stream));
+    if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
+    CK(hipEventRecord(h->ev[5], h->stream));
+    uint64_t buf[E2S_MAX_CLUST_LEN + 3];
+    CK(hipMemcpyAsync(buf, dh, sizeof(buf), hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    CK(hipGetLastError());
+    hipEventElapsedTime(&h->tm.hist_ms, h->ev[4], h->ev[5]);
+    memcpy(out->freq, buf, (E2S_MAX_CLUST_LEN + 1) * 8);
+    out->n_records = buf[E2S_MAX_CLUST_LEN + 1];
+    out->n_bases = buf[E2S_MAX_CLUST_LEN + 2];
+    // length of the last record that survives the min_len filter (the one the reference counts twice, H4)
+    out->last_len = 0;
+    if (out->n_records) {
+        uint64_t hi = h->n_rec;
+        std::vector<uint16_t> chunk;
+        while (hi > 0) {
+            const uint64_t lo = hi > 4096 ? hi - 4096 : 0;
+            chunk.resize(hi - lo);
+            CK(hipMemcpy(chunk.data(), h->d_lens + lo, (hi - lo) * 2, hipMemcpyDeviceToHost));
+            bool found = false;
+            for (uint64_t i = hi - lo; i-- > 0;)
+                if ((int)chunk[i] >= h->min_len) { out->last_len = chunk[i]; found = true; break; }
+            if (found) break;
+            hi = lo;
+        }
+    }
+    return E2S_OK;
+}
+
+// statistics(), clust2snp.cpp:877-966, host part.  The oracle build (-Ofast) divides in the first test
+// and multiplies by the hoisted reciprocal inside the loop; reproduced here (H19).
+extern "C" int e2s_auto_max_clust_length(const e2s_hist* parts, int nparts, int mcov_out, double pval,
+                                         int* max_clust_length, uint64_t* n_clust, uint64_t* n_bases) {
+    if (!parts || nparts < 1 || !max_clust_length) return E2S_ERR_ARG;
+    uint64_t freq[E2S_MAX_CLUST_LEN + 1] = {0};
+    uint64_t nrec = 0, nb = 0, last_len = 0;
+    for (int p = 0; p < nparts; ++p) {
+        for (int i = 0; i <= E2S_MAX_CLUST_LEN; ++i) freq[i] += parts[p].freq[i];
+        nrec += parts[p].n_records; nb += parts[p].n_bases;
+        if (parts[p].n_records) last_len = parts[p].last_len;
+    }
+    if (nrec == 0) return E2S_ERR_REF_CRASH;                       // empty .clusters: SIGFPE in the reference (H6)
+    // H4: `while(not clusters.eof())` counts the last record twice
+    if (last_len <= E2S_MAX_CLUST_LEN) freq[last_len]++;
+    nrec += 1; nb += last_len;
+    uint64_t mx = 0;
+    for (uint64_t i = 1; i <= E2S_MAX_CLUST_LEN; ++i) mx = std::max(mx, freq[i] * i);
+    if (mx == 0) return E2S_ERR_REF_CRASH;                         // clust2snp.cpp:921 divides by max
+    int mcl = 2 * mcov_out;
+    if (mcl < 0 || mcl > E2S_MAX_CLUST_LEN) return E2S_ERR_REF_CRASH;
+    uint64_t cum = freq[mcl] * (uint64_t)mcl;
+    const double dnb = (double)nb;
+    if ((double)cum / dnb < pval) {
+        const double r = 1.0 / dnb;
+        uint64_t c = (uint64_t)mcl;
+        while (c < E2S_MAX_CLUST_LEN) {
+            ++c;
+            cum += freq[c] * c;
+            if (!((double)cum * r < pval)) break;
+        }
+        mcl = (int)c;
+    }
+    *max_clust_length = mcl;
+    if (n_clust) *n_clust = nrec;
+    if (n_bases) *n_bases = nb;
+    return E2S_OK;
+}
+
+static uint32_t list_cap_of(const e2s_c2s_params* p) {
+    // `left_idx.size() < consensus_reads`: size_t vs int, a negative int converts to a huge bound
+    if (p->consensus_reads < 0) return E2S_MAX_CLUST_LEN;
+    return (uint32_t)std::min(p->consensus_reads, (int)E2S_MAX_CLUST_LEN);
+}
+
+extern "C" int e2s_candidate_stride(e2s_handle h, const e2s_c2s_params* p, uint32_t* list_cap, size_t* stride_bytes) {
+    (void)h;
+    if (!p) return E2S_ERR_ARG;
+    const uint32_t c = list_cap_of(p);
+    if (list_cap) *list_cap = c;
+    if (stride_bytes) *stride_bytes = sizeof(e2s_cand_header) + (size_t)4 * c * sizeof(uint32_t);
+    return E2S_OK;
+}
+
+// The entry read_el returns past EOF inside clust2snp (slot model; oracle/e2s_oracle.c).
+static void phantom_entry(const e2s_ctx* h, uint32_t text, uint32_t suff, uint32_t lcp, uint32_t bwt,
+                          uint32_t* pt, uint32_t* ps, uint32_t* pl, uint32_t* pb) {
+    uint8_t slot[8] = {0};
+    auto put = [&](uint32_t v, int w) { for (int i = 0; i < std::min(w, 4); ++i) slot[i] = (uint8_t)(v >> (8 * i)); if (w == 8) for (int i = 4; i < 8; ++i) slot[i] = 0; };
+    const int x = h->d.lcp_bytes, y = h->d.da_bytes, z = h->d.pos_bytes;
+    if (h->layout == 1) { put(text, y); put(suff, z); } else { put(suff, z); put(text, y); }
+    put(lcp, x); put(bwt, 1);
+    auto get = [&](int w) { uint32_t v = 0; for (int i = 0; i < std::min(w, 4); ++i) v |= (uint32_t)slot[i] << (8 * i); return v; };
+    *pt = get(y); *ps = get(z); *pl = get(x); *pb = slot[0];
+}
+
+extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand) {
+    if (!h || !p) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
+    if (!h->bwt || !h->pos || !h->da) return fail(h, E2S_ERR_STATE, "the per-cluster pass needs all four EGSA arrays");
+    CK(hipSetDevice(h->device));
+    const e2s_shard_desc& d = h->d;
+    CandArgs a{};
+    a.bwt = h->bwt; a.lcp = h->lcp; a.pos = h->pos; a.da = h->da; a.xb = h->xb; a.yb = h->yb; a.zb = h->zb;
+    a.prov_lo = h->prov_lo; a.prov_hi = h->prov_lo + h->n_prov; a.n_total = d.n_total;
+    if (a.prov_hi == d.n_total) {
+        uint32_t t = 0, s = 0, l = 0; uint8_t b = 0;
+        const uint64_t i = h->n_prov - 1;
+        CK(hipMemcpy(&t, (const uint8_t*)h->da + i * h->yb, h->yb, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&s, (const uint8_t*)h->pos + i * h->zb, h->zb, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&l, (const uint8_t*)h->lcp + i * h->xb, h->xb, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&b, h->bwt + i, 1, hipMemcpyDeviceToHost));
+        phantom_entry(h, t, s, l, b, &a.ph_text, &a.ph_suff, &a.ph_lcp, &a.ph_bwt);
+    }
+    a.starts = h->d_starts; a.lens = h->d_lens; a.n_rec = h->n_rec;
+    a.rec_per_wave = 8;
+    a.nr_reads1 = p->nr_reads1;
+    a.k_left_u = (uint64_t)(int64_t)p->k_left; a.k_right_u = (uint64_t)(int64_t)p->k_right;   // uint64_t vs int compares
+    a.k_left_lo = (uint32_t)p->k_left; a.mcov_u = (uint32_t)p->mcov_out;
+    // `length >= mcov_out*2 and length <= max_clust_length` (int compares), plus append_entry's filter
+    const long long lo2 = 2LL * p->mcov_out;
+    a.len_lo = (int)std::max<long long>(std::max<long long>(lo2, (long long)p->min_len), -1LL);
+    a.len_hi = std::min(p->max_clust_length, (int)E2S_MAX_CLUST_LEN);
+    a.list_cap = list_cap_of(p);
+    a.stride = (uint32_t)(sizeof(e2s_cand_header) + (size_t)4 * a.list_cap * sizeof(uint32_t));
+    a.cand_count = (unsigned long long*)(h->d_scalars + 1);
+    a.record_index_base = record_index_base;
+    a.err = h->d_words + 1;
+    h->list_cap = a.list_cap; h->cand_stride = a.stride;
+    uint64_t want = std::max<uint64_t>(4096, h->n_rec / 256);
+    uint64_t count = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!h->d_cand || want * a.stride > h->cand_bytes) {
+            hipFree(h->d_cand); h->d_cand = nullptr; h->cand_bytes = 0;
+            CK(hipMalloc((void**)&h->d_cand, (size_t)want * a.stride + 256));
+            h->cand_bytes = want * a.stride;
+        }
+        h->cand_cap = h->cand_bytes / a.stride;
+        a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap;
+        CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
+        CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
+        CK(hipEventRecord(h->ev[6], h->stream));
+        if (h->n_rec) e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
+        CK(hipEventRecord(h->ev[7], h->stream));
+        uint32_t err = 0;
+        CK(hipMemcpyAsync(&count, h->d_scalars + 1, 8, hipMemcpyDeviceToHost, h->stream));
+        CK(hipMemcpyAsync(&err, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+        CK(hipGetLastError());
+        if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
+        if (count <= h->cand_cap) break;
+        if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "candidate buffer overflow");
+        want = count + 1024;
+    }
+    h->n_cand = count;
+    hipEventElapsedTime(&h->tm.cand_ms, h->ev[6], h->ev[7]);
+    h->tm.cand_main_ms = h->tm.cand_ms;
+    h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
+    h->tm.cand_bytes_written = count * a.stride;
+    if (n_cand) *n_cand = count;
+    return E2S_OK;
+}
+
+extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand) {
+    if (!h || !n_cand) return E2S_ERR_ARG;
+    CK(hipSetDevice(h->device));
+    *n_cand = h->n_cand;
+    if (!out) return E2S_OK;
+    if (cap_cand < h->n_cand) return fail(h, E2S_ERR_CAPACITY, "candidate output too small");
+    if (!h->n_cand) return E2S_OK;
+    const size_t st = h->cand_stride;
+    std::vector<uint8_t> raw((size_t)h->n_cand * st);
+    CK(hipMemcpy(raw.data(), h->d_cand, raw.size(), hipMemcpyDeviceToHost));
+    // slots were claimed with an atomic counter: restore SA order (record, then (c0,c1) loop order)
+    std::vector<uint64_t> order(h->n_cand);
+    for (uint64_t i = 0; i < h->n_cand; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+        const e2s_cand_header* a = (const e2s_cand_header*)(raw.data() + x * st);
+        const e2s_cand_header* b = (const e2s_cand_header*)(raw.data() + y * st);
+        if (a->record_index != b->record_index) return a->record_index < b->record_index;
+        return a->pair_index < b->pair_index;
+    });
+    uint8_t* o = (uint8_t*)out;
+    for (uint64_t i = 0; i < h->n_cand; ++i) memcpy(o + i * st, raw.data() + order[i] * st, st);
+    return E2S_OK;
+}
+
+extern "C" int e2s_last_timing(e2s_handle h, e2s_timing* out) {
+    if (!h || !out) return E2S_ERR_ARG;
+    *out = h->tm;
+    return E2S_OK;
+}

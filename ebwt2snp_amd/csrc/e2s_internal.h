@@ -1,0 +1,84 @@
+// e2s_internal.h -- shared between the kernels (e2s_kernels.hip) and the C-ABI layer (e2s_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define E2S_SCAN_BLOCK 256
+#define E2S_SCAN_ROWS 4
+#define E2S_MAX_CLUST_LEN_K 150
+
+// device-side error bits
+#define E2S_DEVERR_SPIN   1u   // look-back wait expired
+#define E2S_DEVERR_REMOTE 2u   // a cluster's entries are not resident in this shard
+
+// a.flags[] slots written by k_shard_flags
+#define E2S_FLAG_BEGINS_INSIDE 0
+#define E2S_FLAG_OPEN_AFTER 1
+#define E2S_FLAG_END_BEFORE_LAST 2
+
+struct ScanArgs {
+    const void* lcp;          // first provided entry
+    uint64_t n_prov;          // provided entries
+    uint64_t prov_lo;         // global SA index of the first provided entry
+    uint32_t prov_is_global0; // prov_lo == 0
+    uint64_t own_lo;          // local index of the first owned entry
+    uint64_t end_hi;          // ends are emitted for local indices [own_lo, end_hi)   (global j <= n_total-2)
+    uint64_t start_hi;        // starts for [own_lo, start_hi)                          (= local end of owned range)
+    uint32_t k_u32;           // (uint32_t)k
+    uint32_t kb;              // k broadcast to every X-byte lane of a word
+    uint32_t hge;             // Swar<X>::H, or 0 if k exceeds the lane range (never >= k)
+    uint64_t n_tiles;
+    // outputs
+    uint64_t* starts;         // [cap + 1]
+    uint16_t* lens;           // [cap + 1]
+    uint64_t cap;
+    uint64_t* total_ends;
+    uint64_t* tile_fix;       // [n_tiles], preset to ~0
+    // look-back workspace (MODE 0)
+    uint64_t* tile_state;     // [n_tiles], preset to 0
+    uint32_t* tile_counter;   // preset to 0
+    uint32_t spin_limit;
+    // MODE 1 / 2
+    uint32_t* tile_count;
+    const uint64_t* tile_prefix;
+    uint32_t* err;
+    uint32_t* flags;
+    uint32_t* tailv;
+};
+
+struct CandHeader {           // == e2s_cand_header
+    uint64_t record_index;
+    uint32_t pair_index;
+    uint32_t n0, n1;
+    uint32_t right_idx, right_pos;
+    uint32_t reserved;
+};
+
+struct CandArgs {
+    const uint8_t* bwt; const void* lcp; const void* pos; const void* da;   // first provided entry
+    int xb, yb, zb;
+    uint64_t prov_lo, prov_hi, n_total;
+    uint32_t ph_text, ph_suff, ph_lcp, ph_bwt;      // the EOF phantom entry (global index n_total)
+    const uint64_t* starts; const uint16_t* lens; uint64_t n_rec;
+    uint32_t rec_per_wave;
+    uint64_t nr_reads1, k_left_u, k_right_u;
+    uint32_t k_left_lo, mcov_u;
+    int len_lo, len_hi;
+    uint32_t list_cap;
+    uint8_t* cand_buf; uint64_t cand_cap; uint32_t stride;
+    unsigned long long* cand_count;
+    uint64_t record_index_base;
+    uint32_t* err;
+};
+
+void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
+void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);
+void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* starts,
+                         uint16_t* lens, unsigned long long cap, const uint32_t* flags, hipStream_t st);
+void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st);
+void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
+void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);
+void e2s_launch_unpack_pairsa(const uint8_t* src, unsigned long long n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st);
+void e2s_launch_narrow8(const uint8_t* src, unsigned long long n, uint32_t* dst, hipStream_t st);
+void e2s_launch_unpack_gesa(const uint8_t* src, unsigned long long n, int yf, int zf, int xf, uint8_t* bwt, void* lcp, int xb,
+                            void* pos, int zb, void* da, int yb, hipStream_t st);

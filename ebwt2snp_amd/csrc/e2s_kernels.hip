@@ -1,0 +1,620 @@
+// e2s_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ebwt2snp hot path.
+//
+//   K1  k_scan<X,MODE>      cluster-boundary scan over the LCP array   (cluster_lm, ebwt2clust.cpp:68-139)
+//   K1f k_scan_fix          resolves the <=1 cross-tile cluster per tile
+//   KH  k_hist              cluster-length histogram                    (statistics, clust2snp.cpp:889-909)
+//   K2  k_candidates<DEF>   per-cluster allele counts, filters, lists   (find_variants, clust2snp.cpp:367-500)
+//   KU  k_unpack_*          BCR pairSA / .gesa AoS -> SoA in HBM         (read_el, include.hpp:120-199)
+//
+// Integer streaming only: no MFMA.  Layout, roofline and byte counts are in DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "e2s_internal.h"
+#include "e2s_swar.h"
+
+// ----------------------------------------------------------------------------------------------
+// wave64 helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// inclusive add-scan across the 64 lanes of a wave (DPP row shifts + row broadcasts)
+__device__ __forceinline__ u32 wave_incl_scan(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return x;
+}
+__device__ __forceinline__ u32 wave_bcast_last(u32 x) { return (u32)__builtin_amdgcn_readlane((int)x, 63); }
+
+// alignbyte, bfi, Swar<X>, row_flags<X>: e2s_swar.h
+
+// mask (lane-MSB form) of entries b of the row with lo <= b < hi
+template <int X> __device__ __forceinline__ void range_mask(int lo, int hi, u32* m) {
+    constexpr int EPW = Swar<X>::EPW;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        u32 v = 0;
+#pragma unroll
+        for (int e = 0; e < EPW; ++e) {
+            const int b = w * EPW + e;
+            if (b >= lo && b < hi) v |= 1u << (e * 8 * X + 8 * X - 1);
+        }
+        m[w] = v;
+    }
+}
+
+constexpr int SCAN_BLK = E2S_SCAN_BLOCK;
+constexpr int SCAN_ROWS = E2S_SCAN_ROWS;
+constexpr u32 CARRY_CLOSED = 0xFFFFFFFFu;   // last event of the thread-row was an end
+constexpr u32 CARRY_NOEVENT = 0xFFFFFFFEu;  // no event: pass the predecessor's carry through
+constexpr u32 CARRY_UNKNOWN = 0xFFFFFFFDu;  // the open start lies before this tile
+
+constexpr u64 ST_FLAG_A = 1ull << 62;       // tile aggregate published
+constexpr u64 ST_FLAG_P = 2ull << 62;       // inclusive prefix published
+constexpr u64 ST_VALUE = (1ull << 62) - 1;
+
+// MODE 0: single pass, decoupled look-back.  MODE 1: count only.  MODE 2: emit with given prefixes.
+template <int X, int MODE>
+__global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
+    constexpr int EPT = 16 / X;                     // entries per thread-row
+    constexpr int ROW_ENTRIES = SCAN_BLK * EPT;
+    constexpr int TILE = SCAN_ROWS * ROW_ENTRIES;
+    constexpr int PRE = (X == 4) ? 2 : 1;
+    constexpr int LB = Swar<X>::LB;                 // log2(bits per entry lane)
+    constexpr int EPW = Swar<X>::EPW;
+    constexpr int NWAVES = SCAN_BLK / 64;
+
+    __shared__ u32 s_tile;
+    __shared__ u32 s_wtot[SCAN_ROWS][NWAVES];
+    __shared__ u32 s_wcarry[SCAN_ROWS][NWAVES];
+    __shared__ u64 s_prefix;
+
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63u, wave = tid >> 6;
+
+    u64 tile;
+    if (MODE == 0) {
+        if (tid == 0) s_tile = atomicAdd(a.tile_counter, 1u);    // dispatch-order ticket: predecessors have started
+        __syncthreads();
+        tile = s_tile;
+    } else {
+        tile = blockIdx.x;
+    }
+    const int64_t tile_lo = (int64_t)tile * TILE;                // local entry index (0 = first provided entry)
+    const uint8_t* base = (const uint8_t*)a.lcp;
+    const int64_t n_prov = (int64_t)a.n_prov;
+
+    // owned window in local indices: ends for [own_lo, end_hi), starts for [own_lo, start_hi)
+    const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
+
+    RowFlags F[SCAN_ROWS];
+    u32 cnt[SCAN_ROWS];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; ++r) {
+        const int64_t i0 = tile_lo + (int64_t)r * ROW_ENTRIES + (int64_t)tid * EPT;
+        u32 W[PRE + 5];
+        if (i0 >= PRE * EPW && i0 + EPT + EPW <= n_prov) {
+            // interior: one 16-B load plus the two edge words (L1/L2 hits: neighbours load the same lines)
+            const uint4 v = *(const uint4*)(base + i0 * X);
+            W[PRE + 0] = v.x; W[PRE + 1] = v.y; W[PRE + 2] = v.z; W[PRE + 3] = v.w;
+#pragma unroll
+            for (int p = 0; p < PRE; ++p) W[p] = *(const u32*)(base + i0 * X - 4 * (PRE - p));
+            W[PRE + 4] = *(const u32*)(base + i0 * X + 16);
+        } else {
+            // array edges: byte-guarded loads, zeros outside the provided range (LCP 0 < k: "not open")
+#pragma unroll
+            for (int w = 0; w < PRE + 5; ++w) {
+                u32 v = 0;
+#pragma unroll
+                for (int bt = 0; bt < 4; ++bt) {
+                    const int64_t byte = i0 * X + (int64_t)(w - PRE) * 4 + bt;
+                    if (byte >= 0 && byte < n_prov * X) v |= (u32)base[byte] << (8 * bt);
+                }
+                W[w] = v;
+            }
+        }
+        row_flags<X>(W, a.kb, a.hge, F[r]);
+        // the j = 0,1 rules of ebwt2clust.cpp:83-84 (only the thread-row holding global index 0):
+        // with L[0] >= k the cluster opened at 0 swallows entry 1 whatever L[1] is, and j = 0 is never tested
+        if (a.prov_is_global0 && i0 == 0) {
+            constexpr u32 B0 = 1u << (8 * X - 1);
+            constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
+            constexpr int w1 = (X == 4) ? 1 : 0;
+            constexpr u32 B1 = (X == 4) ? B0 : (B0 << (8 * (X & 3)));
+            constexpr int w2 = (X == 4) ? 2 : (X == 2 ? 1 : 0);
+            constexpr u32 B2 = (X == 1) ? (B0 << 16) : B0;
+            const u32 e0v = W[PRE] & LM;
+            const u32 e1v = (X == 4) ? W[PRE + 1] : ((W[PRE] >> (8 * (X & 3))) & LM);
+            const u32 e2v = (X == 4) ? W[PRE + 2] : (X == 2 ? (W[PRE + 1] & LM) : ((W[PRE] >> 16) & LM));
+            const u32 k = a.k_u32;
+            F[r].end[0] &= ~B0;
+            if (a.hge != 0 && e0v >= k) {
+                const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < k);
+                F[r].start[w1] &= ~B1;
+                if (end1) F[r].end[w1] |= B1; else F[r].end[w1] &= ~B1;
+                if (e2v >= k) { if (end1) F[r].start[w2] |= B2; else F[r].start[w2] &= ~B2; }
+            }
+        }
+        // restrict to the owned window
+        if (!(i0 >= own_lo && i0 + EPT <= end_hi)) {
+            u32 m[4];
+            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, end_hi - i0)), m);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) F[r].end[w] &= m[w];
+        }
+        if (!(i0 >= own_lo && i0 + EPT <= start_hi)) {
+            u32 m[4];
+            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, start_hi - i0)), m);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) F[r].start[w] &= m[w];
+        }
+        cnt[r] = __popc(F[r].end[0]) + __popc(F[r].end[1]) + __popc(F[r].end[2]) + __popc(F[r].end[3]);
+    }
+
+    // ---- block-level exclusive scan of end counts in row-major order ----
+    u32 excl[SCAN_ROWS];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; ++r) {
+        const u32 inc = wave_incl_scan(cnt[r]);
+        excl[r] = inc - cnt[r];
+        if (lane == 63) s_wtot[r][wave] = inc;
+    }
+    __syncthreads();
+    u32 tile_total = 0;
+    {
+        u32 run = 0;
+#pragma unroll
+        for (int r = 0; r < SCAN_ROWS; ++r) {
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) {
+                const u32 v = s_wtot[r][w];
+                if (w == (int)wave) excl[r] += run;
+                run += v;
+            }
+        }
+        tile_total = run;
+    }
+
+    if (MODE == 1) {
+        if (tid == 0) a.tile_count[tile] = tile_total;
+        return;
+    }
+
+    // ---- tile prefix ----
+    u64 prefix;
+    if (MODE == 0) {
+        if (wave == 0) {
+            if (lane == 0) {
+                const u64 v = (tile == 0 ? ST_FLAG_P : ST_FLAG_A) | (u64)tile_total;
+                __hip_atomic_store(&a.tile_state[tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            u64 run = 0;
+            if (tile > 0) {
+                int64_t look = (int64_t)tile - 1 - (int64_t)lane;
+                bool done = false;
+                u32 spins = 0;
+                while (!done) {
+                    u64 v = ST_FLAG_P;                                   // before tile 0: prefix 0
+                    if (look >= 0) v = __hip_atomic_load(&a.tile_state[look], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 ready = __ballot((v >> 62) != 0);
+                    const u64 isp = __ballot((v >> 62) == 2);
+                    // usable window: lanes 0..p where p = nearest predecessor holding an inclusive prefix,
+                    // provided every lane below it is ready
+                    u64 need = isp ? ((isp & (0 - isp)) << 1) - 1 : ~0ull;   // lanes up to and including first P
+                    if ((ready & need) == need) {
+                        u32 lo = (u32)(v & 0xFFFFFFFFull), hi = (u32)((v & ST_VALUE) >> 32);
+                        const bool use = ((need >> lane) & 1ull) != 0;
+                        lo = use ? lo : 0; hi = use ? hi : 0;
+                        // 64-bit wave sum of the used lanes (values < 2^62, counts fit comfortably)
+                        u64 s = ((u64)hi << 32) | lo;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                        run += s;
+                        if (isp) done = true; else look -= 64;
+                        spins = 0;
+                    } else {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > a.spin_limit) { if (lane == 0) atomicOr(a.err, E2S_DEVERR_SPIN); done = true; }
+                    }
+                }
+                if (lane == 0)
+                    __hip_atomic_store(&a.tile_state[tile], ST_FLAG_P | ((run + tile_total) & ST_VALUE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) s_prefix = run;
+        }
+        __syncthreads();
+        prefix = s_prefix;
+    } else {
+        prefix = a.tile_prefix[tile];
+    }
+    if (tile == a.n_tiles - 1 && tid == 0) *a.total_ends = prefix + tile_total;
+
+    // ---- carries: the open start each thread-row inherits from the rows before it in the tile ----
+    u32 carry_out[SCAN_ROWS], carry_in[SCAN_ROWS];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; ++r) {
+        const int64_t row_lo = (int64_t)r * ROW_ENTRIES + (int64_t)tid * EPT;    // tile-local entry offset
+        u32 co = CARRY_NOEVENT;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 ev = F[r].end[w] | F[r].start[w];
+            if (ev) {
+                const int top = 31 - __clz(ev);
+                // at one position the start precedes the end, so a set end bit means the last event is an end
+                if ((F[r].end[w] >> top) & 1u) co = CARRY_CLOSED;
+                else co = (u32)(row_lo + w * EPW + (top >> LB));
+            }
+        }
+        carry_out[r] = co;
+        const u64 evm = __ballot(co != CARRY_NOEVENT);
+        const u64 below = evm & ((1ull << lane) - 1ull);
+        // every lane takes part in the permute (an inactive source lane would read as 0)
+        const u32 got = (u32)__shfl((int)co, below ? 63 - __clzll(below) : (int)lane);
+        carry_in[r] = below ? got : CARRY_NOEVENT;
+        const u32 wlast = evm ? (u32)__builtin_amdgcn_readlane((int)co, 63 - __clzll(evm)) : CARRY_NOEVENT;
+        if (lane == 0) s_wcarry[r][wave] = wlast;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; ++r) {
+        if (carry_in[r] == CARRY_NOEVENT) {
+            u32 ci = CARRY_UNKNOWN;
+            for (int q = r * NWAVES + (int)wave - 1; q >= 0; --q) {
+                const u32 c = s_wcarry[q / NWAVES][q % NWAVES];
+                if (c != CARRY_NOEVENT) { ci = c; break; }
+            }
+            carry_in[r] = ci;
+        }
+    }
+
+    // ---- emit: walk the events of each thread-row in order (start before end at one position) ----
+    const u64 g_tile = a.prov_lo + (u64)tile_lo;                 // global SA index of the tile's first entry
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; ++r) {
+        u64 rk = prefix + excl[r];
+        u32 pend = carry_in[r];
+        const u32 row_lo = (u32)(r * ROW_ENTRIES) + tid * EPT;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            u32 ev = F[r].end[w] | F[r].start[w];
+            while (ev) {
+                const int bit = __ffs(ev) - 1;
+                ev &= ev - 1;
+                const u32 off = row_lo + w * EPW + (bit >> LB);
+                if ((F[r].start[w] >> bit) & 1u) {
+                    if (rk < a.cap) a.starts[rk] = g_tile + off;
+                    pend = off;
+                }
+                if ((F[r].end[w] >> bit) & 1u) {
+                    if (rk < a.cap) {
+                        if (pend < CARRY_UNKNOWN) a.lens[rk] = (uint16_t)(off - pend + 1);
+                        else { a.lens[rk] = (uint16_t)((g_tile + off + 1) & 0xFFFFull); a.tile_fix[tile] = rk; }
+                    }
+                    ++rk;
+                    pend = CARRY_CLOSED;
+                }
+            }
+        }
+    }
+}
+
+// one thread per tile: finish the record whose start lies in an earlier tile
+__global__ void k_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* starts, uint16_t* lens, u64 cap, const u32* flags) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const u64 r = tile_fix[t];
+    if (r == ~0ull || r >= cap) return;
+    if (r == 0 && flags[E2S_FLAG_BEGINS_INSIDE]) return;        // start lives in an earlier shard: e2s_stitch
+    lens[r] = (uint16_t)((lens[r] - (uint16_t)(starts[r] & 0xFFFFull)) & 0xFFFFu);
+}
+
+// exclusive scan of per-tile counts (MODE 1 -> MODE 2), single block
+__global__ __launch_bounds__(1024) void k_tile_scan(const u32* cnt, u64* prefix, u64 n) {
+    __shared__ u64 s_part[1024];
+    const u32 tid = threadIdx.x;
+    const u64 per = (n + 1023) / 1024;
+    const u64 lo = min(n, per * tid), hi = min(n, lo + per);
+    u64 s = 0;
+    for (u64 i = lo; i < hi; ++i) s += cnt[i];
+    s_part[tid] = s;
+    __syncthreads();
+    if (tid == 0) { u64 run = 0; for (int i = 0; i < 1024; ++i) { const u64 v = s_part[i]; s_part[i] = run; run += v; } }
+    __syncthreads();
+    u64 run = s_part[tid];
+    for (u64 i = lo; i < hi; ++i) { prefix[i] = run; run += cnt[i]; }
+}
+
+// shard descriptors: begins_inside / open_after, evaluated scalar-ly on the two boundary entries
+__global__ void k_shard_flags(ScanArgs a, u32 xb) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto L = [&](int64_t i) -> u32 {            // local index -> LCP, 0 outside the provided range
+        if (i < 0 || i >= (int64_t)a.n_prov) return 0u;
+        const uint8_t* p = (const uint8_t*)a.lcp + i * xb;
+        return xb == 1 ? (u32)p[0] : xb == 2 ? (u32)*(const uint16_t*)p : *(const u32*)p;
+    };
+    const u32 k = a.k_u32;
+    const bool never = a.hge == 0;
+    auto ge = [&](int64_t i) { return !never && L(i) >= k; };
+    auto gidx = [&](int64_t i) { return (int64_t)a.prov_lo + i; };
+    auto open = [&](int64_t i) -> bool {       // ebwt2clust.cpp:83-84,116
+        const int64_t g = gidx(i);
+        if (g < 0) return false;
+        if (g == 1) return ge(i - 1) || ge(i);
+        return ge(i);
+    };
+    auto endf = [&](int64_t i) -> bool {       // ebwt2clust.cpp:98-102 (never evaluated for j = 0)
+        const int64_t g = gidx(i);
+        if (g <= 0) return false;
+        return open(i) && ((L(i - 1) > L(i) && L(i) <= L(i + 1)) || !ge(i + 1));
+    };
+    auto startf = [&](int64_t i) -> bool {
+        const int64_t g = gidx(i);
+        if (!open(i)) return false;
+        if (g == 0) return true;
+        return !open(i - 1) || endf(i - 1);
+    };
+    const int64_t lo = (int64_t)a.own_lo, last = (int64_t)a.start_hi - 1;   // last owned entry
+    u32 begins_inside = 0, open_after = 0, end_before_last = 0;
+    if (a.start_hi > a.own_lo) {
+        begins_inside = (open(lo) && !startf(lo)) ? 1u : 0u;
+        // the end test of the very last entry of the EGSA needs the EOF phantom: left to e2s_stitch
+        const bool last_is_eof = (last >= (int64_t)a.end_hi);
+        open_after = (open(last) && (last_is_eof || !endf(last))) ? 1u : 0u;
+        // did a cluster close at n_total-2, i.e. did append_entry run in the reference's last real iteration?
+        if (last_is_eof) end_before_last = endf(last - 1) ? 1u : 0u;
+    }
+    a.flags[E2S_FLAG_BEGINS_INSIDE] = begins_inside;
+    a.flags[E2S_FLAG_OPEN_AFTER] = open_after;
+    a.flags[E2S_FLAG_END_BEFORE_LAST] = end_before_last;
+    a.tailv[0] = L(last);
+    a.tailv[1] = L(last - 1);
+}
+
+// ----------------------------------------------------------------------------------------------
+// KH: histogram of cluster lengths (statistics(), clust2snp.cpp:889-909; H4 applied on the host)
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int min_len, u64* out /*151 freq, n_rec, n_bases*/) {
+    __shared__ u32 s_freq[E2S_MAX_CLUST_LEN_K + 1];
+    __shared__ u64 s_acc[2];
+    for (int i = threadIdx.x; i <= E2S_MAX_CLUST_LEN_K; i += blockDim.x) s_freq[i] = 0;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    u64 nrec = 0, nb = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const int l = lens[i];
+        if (l >= min_len) {                                   // append_entry's filter, ebwt2clust.cpp:56
+            nrec++; nb += (u64)l;
+            if (l <= E2S_MAX_CLUST_LEN_K) atomicAdd(&s_freq[l], 1u);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nrec += __shfl_xor(nrec, o); nb += __shfl_xor(nb, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd((u64*)&s_acc[0], nrec); atomicAdd((u64*)&s_acc[1], nb); }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= E2S_MAX_CLUST_LEN_K; i += blockDim.x) if (s_freq[i]) atomicAdd(&out[i], (u64)s_freq[i]);
+    if (threadIdx.x == 0) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K2: per-cluster pass.  One wave per cluster record, lane i <-> entry start+i (clusters are
+// at most 150 entries: three 64-entry chunks).  find_variants, clust2snp.cpp:367-500.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 load_w(const void* p, int w, int64_t i) {
+    return w == 1 ? (u32)((const uint8_t*)p)[i] : w == 2 ? (u32)((const uint16_t*)p)[i] : ((const u32*)p)[i];
+}
+
+// include.hpp:265-279 (N/n: the reference draws rand()%4; we map to 0 deterministically)
+__device__ __forceinline__ u32 base_to_int(u32 c) {
+    c &= ~0x20u;                                   // fold case: 'a'..'t' -> 'A'..'T'
+    return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+}
+
+constexpr int CAND_WAVES = 4;
+constexpr int MAXCH = 3;                           // ceil(150/64)
+
+template <bool DEF>                                // DEF: widths (x,y,z) = (1,4,1)
+__global__ __launch_bounds__(CAND_WAVES * 64) void k_candidates(CandArgs a) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 gw = ((u64)blockIdx.x * CAND_WAVES) + (threadIdx.x >> 6);
+    const u64 r0 = gw * a.rec_per_wave;
+    for (u32 q = 0; q < a.rec_per_wave; ++q) {
+        const u64 r = r0 + q;
+        if (r >= a.n_rec) return;
+        const int len = (int)a.lens[r];
+        if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 (+ append_entry's filter)
+        const u64 s = a.starts[r];
+        // entries must be resident: [s, s+len) within the provided range, index n_total being the EOF phantom
+        if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull)) {
+            if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
+            continue;
+        }
+        const int nch = (len + 63) >> 6;
+        u32 text[MAXCH], suff[MAXCH], lcp[MAXCH], bwt[MAXCH];
+        bool valid[MAXCH];
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            valid[c] = false; text[c] = suff[c] = lcp[c] = bwt[c] = 0;
+            if (c < nch) {
+                const int o = c * 64 + (int)lane;
+                valid[c] = o < len;
+                if (valid[c]) {
+                    const u64 g = s + (u64)o;
+                    if (g == a.n_total) { text[c] = a.ph_text; suff[c] = a.ph_suff; lcp[c] = a.ph_lcp; bwt[c] = a.ph_bwt; }
+                    else {
+                        const int64_t i = (int64_t)(g - a.prov_lo);
+                        bwt[c] = a.bwt[i];
+                        if (DEF) { lcp[c] = ((const uint8_t*)a.lcp)[i]; suff[c] = ((const uint8_t*)a.pos)[i]; text[c] = ((const u32*)a.da)[i]; }
+                        else { lcp[c] = load_w(a.lcp, a.xb, i); suff[c] = load_w(a.pos, a.zb, i); text[c] = load_w(a.da, a.yb, i); }
+                    }
+                }
+            }
+        }
+        // counts[sample][base] and the first entry with the strictly largest LCP (clust2snp.cpp:377-393)
+        u32 cnt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        u32 best_lcp = 0, best_text = 0, best_suff = 0;
+        u32 smp[MAXCH], bas[MAXCH];
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            if (c < nch) {
+                smp[c] = ((u64)text[c] < a.nr_reads1) ? 0u : 1u;            // uint32 text vs uint64 nr_reads1
+                bas[c] = base_to_int(bwt[c]);
+#pragma unroll
+                for (int sb = 0; sb < 8; ++sb)
+                    cnt[sb >> 2][sb & 3] += (u32)__popcll(__ballot(valid[c] && smp[c] == (u32)(sb >> 2) && bas[c] == (u32)(sb & 3)));
+                u32 m = valid[c] ? lcp[c] : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
+                if (m > best_lcp) {                                          // strictly greater: earlier chunk wins ties
+                    const u64 who = __ballot(valid[c] && lcp[c] == m);
+                    const int src = __ffsll((long long)who) - 1;
+                    best_lcp = m;
+                    best_text = (u32)__shfl((int)text[c], src);
+                    best_suff = (u32)__shfl((int)suff[c], src);
+                }
+            }
+        }
+        if ((u64)best_lcp < a.k_right_u) continue;                          // clust2snp.cpp:396
+        u32 f0 = 0, f1 = 0;                                                  // frequent characters, :402-407
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { if (cnt[0][b] >= a.mcov_u) f0 |= 1u << b; if (cnt[1][b] >= a.mcov_u) f1 |= 1u << b; }
+        if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) continue;   // :419-429
+        u32 pair = 0;
+        for (int b0 = 0; b0 < 4; ++b0) {
+            if (!((f0 >> b0) & 1u)) continue;
+            for (int b1 = 0; b1 < 4; ++b1) {
+                if (!((f1 >> b1) & 1u) || b0 == b1) continue;
+                const u32 c0 = "ACGT"[b0], c1 = "ACGT"[b1];                  // int_to_base, raw compare ch == c (:455,466)
+                // membership and rank in SA order (:446-476)
+                u32 n0 = 0, n1 = 0, rk0[MAXCH], rk1[MAXCH];
+                bool m0[MAXCH], m1[MAXCH];
+#pragma unroll
+                for (int c = 0; c < MAXCH; ++c) {
+                    m0[c] = m1[c] = false; rk0[c] = rk1[c] = 0;
+                    if (c < nch) {
+                        const bool okc = valid[c] && (u64)suff[c] >= a.k_left_u && (u64)lcp[c] >= a.k_right_u;
+                        m0[c] = okc && bwt[c] == c0 && smp[c] == 0;
+                        m1[c] = okc && bwt[c] == c1 && smp[c] == 1;
+                        const u64 b0m = __ballot(m0[c]), b1m = __ballot(m1[c]);
+                        const u64 lt = (1ull << lane) - 1ull;
+                        rk0[c] = n0 + (u32)__popcll(b0m & lt);
+                        rk1[c] = n1 + (u32)__popcll(b1m & lt);
+                        n0 += (u32)__popcll(b0m); n1 += (u32)__popcll(b1m);
+                    }
+                }
+                const u32 e0 = min(n0, a.list_cap), e1 = min(n1, a.list_cap);  // size() < consensus_reads (:458,469)
+                if (e0 > 0 && e1 > 0) {                                        // :478
+                    u64 slot = 0;
+                    if (lane == 0) slot = atomicAdd(a.cand_count, 1ull);
+                    slot = __shfl(slot, 0);
+                    if (slot < a.cand_cap) {
+                        uint8_t* rec = a.cand_buf + slot * a.stride;
+                        if (lane == 0) {
+                            CandHeader* h = (CandHeader*)rec;
+                            h->record_index = a.record_index_base + r;
+                            h->pair_index = pair; h->n0 = e0; h->n1 = e1;
+                            h->right_idx = best_text; h->right_pos = best_suff; h->reserved = 0;
+                        }
+                        u32* l = (u32*)(rec + sizeof(CandHeader));
+#pragma unroll
+                        for (int c = 0; c < MAXCH; ++c) {
+                            if (c < nch) {
+                                if (m0[c] && rk0[c] < a.list_cap) { l[rk0[c]] = text[c]; l[a.list_cap + rk0[c]] = suff[c] - a.k_left_lo; }
+                                if (m1[c] && rk1[c] < a.list_cap) { l[2 * a.list_cap + rk1[c]] = text[c]; l[3 * a.list_cap + rk1[c]] = suff[c] - a.k_left_lo; }
+                            }
+                        }
+                    }
+                }
+                ++pair;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// KU: file layouts -> struct-of-arrays in HBM (8-byte fields truncated to 32 bits like t_GSA)
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 rd_le(const uint8_t* p, int w) {
+    u32 v = 0;
+    const int m = w < 4 ? w : 4;
+    for (int i = 0; i < m; ++i) v |= (u32)p[i] << (8 * i);
+    return v;
+}
+__device__ __forceinline__ void wr_le(void* base, int w, u64 i, u32 v) {
+    if (w == 1) ((uint8_t*)base)[i] = (uint8_t)v; else if (w == 2) ((uint16_t*)base)[i] = (uint16_t)v; else ((u32*)base)[i] = v;
+}
+
+// pairSA = [pos:z][da:y] per entry (include.hpp:159-175)
+__global__ void k_unpack_pairsa(const uint8_t* src, u64 n, int zb_file, int yb_file, void* pos, int zb, void* da, int yb) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = src + i * (u64)(zb_file + yb_file);
+    wr_le(pos, zb, i, rd_le(p, zb_file));
+    wr_le(da, yb, i, rd_le(p + zb_file, yb_file));
+}
+// narrow an 8-byte little-endian column to 4 bytes (LCP file with -x 8)
+__global__ void k_narrow8(const uint8_t* src, u64 n, u32* dst) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = rd_le(src + i * 8, 4);
+}
+// .gesa = [da:y][pos:z][lcp:x][bwt:1] per entry (include.hpp:126-155)
+__global__ void k_unpack_gesa(const uint8_t* src, u64 n, int yb_file, int zb_file, int xb_file,
+                              uint8_t* bwt, void* lcp, int xb, void* pos, int zb, void* da, int yb) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = src + i * (u64)(yb_file + zb_file + xb_file + 1);
+    wr_le(da, yb, i, rd_le(p, yb_file));
+    wr_le(pos, zb, i, rd_le(p + yb_file, zb_file));
+    wr_le(lcp, xb, i, rd_le(p + yb_file + zb_file, xb_file));
+    bwt[i] = p[yb_file + zb_file + xb_file];
+}
+
+// ----------------------------------------------------------------------------------------------
+// launchers (called from e2s_capi.cpp through e2s_internal.h)
+// ----------------------------------------------------------------------------------------------
+template <int X> static void launch_scan_x(const ScanArgs& a, int mode, hipStream_t st) {
+    const dim3 grid((unsigned)a.n_tiles), blk(SCAN_BLK);
+    if (mode == 0) hipLaunchKernelGGL((k_scan<X, 0>), grid, blk, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_scan<X, 1>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_scan<X, 2>), grid, blk, 0, st, a);
+}
+void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st) {
+    if (xb == 1) launch_scan_x<1>(a, mode, st); else if (xb == 2) launch_scan_x<2>(a, mode, st); else launch_scan_x<4>(a, mode, st);
+}
+void e2s_launch_tile_scan(const u32* cnt, u64* prefix, u64 n, hipStream_t st) {
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, n);
+}
+void e2s_launch_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* starts, uint16_t* lens, u64 cap, const u32* flags, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_fix, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, tile_fix, starts, lens, cap, flags);
+}
+void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st) {
+    hipLaunchKernelGGL(k_shard_flags, dim3(1), dim3(64), 0, st, a, (u32)xb);
+}
+void e2s_launch_hist(const uint16_t* lens, u64 n, int min_len, u64* out, hipStream_t st) {
+    u64 blocks = (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)blocks), dim3(256), 0, st, lens, n, min_len, out);
+}
+void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st) {
+    const u64 waves = (a.n_rec + a.rec_per_wave - 1) / a.rec_per_wave;
+    const u64 blocks = (waves + CAND_WAVES - 1) / CAND_WAVES;
+    if (blocks == 0) return;
+    if (def_widths) hipLaunchKernelGGL((k_candidates<true>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
+    else hipLaunchKernelGGL((k_candidates<false>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
+}
+void e2s_launch_unpack_pairsa(const uint8_t* src, u64 n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_unpack_pairsa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, n, zf, yf, pos, zb, da, yb);
+}
+void e2s_launch_narrow8(const uint8_t* src, u64 n, u32* dst, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_narrow8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, n, dst);
+}
+void e2s_launch_unpack_gesa(const uint8_t* src, u64 n, int yf, int zf, int xf, uint8_t* bwt, void* lcp, int xb, void* pos, int zb, void* da, int yb, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_unpack_gesa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, n, yf, zf, xf, bwt, lcp, xb, pos, zb, da, yb);
+}

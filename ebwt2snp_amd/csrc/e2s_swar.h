@@ -1,0 +1,90 @@
+// e2s_swar.h -- the SWAR stencil of the cluster-boundary scan (cluster_lm, ebwt2clust.cpp:68-139).
+// Pure 32-bit integer code shared by the gfx950 kernel (e2s_kernels.hip) and a host-compiled
+// check (tests/swar_check.cpp) that compares it with the sequential definition.
+#pragma once
+#include <stdint.h>
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+#if defined(__HIPCC__)
+#define E2S_HD __host__ __device__ __forceinline__
+#else
+#define E2S_HD inline
+#endif
+// ({hi,lo} >> 8*sh) & 0xffffffff, sh in 0..3 -- v_alignbyte_b32 on the GPU
+E2S_HD u32 alignbyte(u32 hi, u32 lo, u32 sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    return (u32)(((((u64)hi) << 32) | lo) >> (8 * (sh & 3)));
+#endif
+}
+// (m & a) | (~m & b)
+E2S_HD u32 bfi(u32 m, u32 a, u32 b) { return (m & a) | (~m & b); }
+
+// ----------------------------------------------------------------------------------------------
+// K1: boundary scan.  One thread-row = 16 bytes of LCP = EPT entries; a tile = ROWS x 256 thread-rows,
+// row-major (thread t of row r holds bytes [r*4096 + t*16, +16) of the tile), so every wave
+// instruction loads 1 KiB contiguous.  Flags are computed SWAR in "lane-MSB form": one flag per
+// X-byte lane of a 32-bit word, held in that lane's top bit.
+// ----------------------------------------------------------------------------------------------
+template <int X> struct Swar;
+template <> struct Swar<1> { static constexpr u32 H = 0x80808080u; static constexpr int EPW = 4; static constexpr int LB = 3; };
+template <> struct Swar<2> { static constexpr u32 H = 0x80008000u; static constexpr int EPW = 2; static constexpr int LB = 4; };
+template <> struct Swar<4> { static constexpr u32 H = 0x80000000u; static constexpr int EPW = 1; static constexpr int LB = 5; };
+
+// previous-entry / next-entry views of a word stream
+template <int X> E2S_HD u32 prev_elems(u32 cur, u32 before) {
+    if (X == 4) return before;
+    return alignbyte(cur, before, 4 - X);            // ({cur,before} >> 8*(4-X))
+}
+template <int X> E2S_HD u32 next_elems(u32 after, u32 cur) {
+    if (X == 4) return after;
+    return alignbyte(after, cur, X);                 // ({after,cur} >> 8*X)
+}
+
+struct RowFlags { u32 end[4]; u32 start[4]; };
+
+// W[0..PRE-1]: words before the row, W[PRE..PRE+3]: the row, W[PRE+4]: the word after.
+// Returns END/START flags (lane-MSB form) for the 16 bytes of the row, before range masking.
+template <int X>
+E2S_HD void row_flags(const u32* W, u32 kb, u32 hge, RowFlags& f) {
+    constexpr u32 H = Swar<X>::H;
+    constexpr int PRE = (X == 4) ? 2 : 1;
+    constexpr int NW = PRE + 5;
+    u32 ge[NW], nle[NW];                       // ge: L>=k ; nle: (L[j] >= L[j-1]) i.e. NOT gt(j)
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const u32 x = W[w];
+        const u32 xh = x | H;
+        // lane-wise x >= k: where the top bits of x and k differ x's top bit decides, else the
+        // borrow-free subtract of the low bits does
+        const u32 t = xh - (kb & ~H);
+        ge[w] = bfi(x ^ kb, x, t) & hge;
+        const u32 y = (w == 0) ? prev_elems<X>(x, 0u) : prev_elems<X>(x, W[w - 1]);
+        const u32 t2 = xh - (y & ~H);
+        nle[w] = bfi(x ^ y, x, t2);           // top bit: x >= y  (garbage elsewhere, masked at the end)
+    }
+    // end(j)   = ge(j) & ((gt(j) & !gt(j+1)) | !ge(j+1))          ebwt2clust.cpp:98-102
+    // start(j) = ge(j) & (!ge(j-1) | end(j-1))                    ebwt2clust.cpp:108,116-120
+    u32 endw[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int w = PRE - 1 + i;             // the word before the row, then the row
+        const u32 nle_n = next_elems<X>(nle[w + 1], nle[w]);
+        const u32 ge_n = next_elems<X>(ge[w + 1], ge[w]);
+        const u32 locmin = ~nle[w] & nle_n;    // gt(j) & !gt(j+1)
+        const u32 t = ~locmin & ge_n;
+        endw[i] = ~t & ge[w] & H;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int w = PRE + i;
+        const u32 ge_p = prev_elems<X>(ge[w], ge[w - 1]);
+        const u32 end_p = prev_elems<X>(endw[i + 1], endw[i]);
+        f.end[i] = endw[i + 1];
+        f.start[i] = ge[w] & ~(ge_p & ~end_p) & H;
+    }
+}
+

@@ -1,0 +1,61 @@
+// egsa_files.hpp -- file side of the drop-in executables: locate and map the EGSA index files the way
+// egsa_stream's constructor does (include.hpp:42-81): <input>.gesa first, else the BCR triple
+// <input>.out / .out.lcp / .out.pairSA, else "Error: missing index files." and exit(1).
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "e2s_hip.h"
+
+struct MappedFile {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    bool open(const std::string& path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        if (n == 0) { p = (const uint8_t*)""; return true; }
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (const uint8_t*)m;
+        return true;
+    }
+    ~MappedFile() { if (p && n) munmap((void*)p, n); if (fd >= 0) ::close(fd); }
+};
+
+struct EgsaFiles {
+    bool gesa = false;
+    MappedFile aos, bwt, lcp, pairsa;
+    uint64_t n = 0;
+    // exits like the reference when nothing is found
+    void open_or_die(const std::string& input, int x, int y, int z) {
+        if (aos.open(input + ".gesa")) {
+            gesa = true;
+            n = aos.n / (size_t)(x + y + z + 1);
+            return;
+        }
+        if (lcp.open(input + ".out.lcp") && bwt.open(input + ".out") && pairsa.open(input + ".out.pairSA")) {
+            n = lcp.n / (size_t)x;
+            return;
+        }
+        std::cout << "Error: missing index files." << std::endl;
+        exit(1);
+    }
+};
+
+inline void die_on(int rc, e2s_handle h, const char* what) {
+    if (rc == E2S_OK) return;
+    std::cerr << what << " failed (" << rc << "): " << e2s_last_error(h) << std::endl;
+    exit(2);
+}

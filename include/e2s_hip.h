@@ -1,0 +1,212 @@
+/*
+ * e2s_hip.h -- C ABI of the MI355X (gfx950) implementation of ebwt2snp's eBWT
+ * positional-clustering hot path.
+ *
+ * The reference (nicolaprezza/ebwt2snp) has no FFI or plugin interface: the hot
+ * path is reachable only through the two executables ebwt2clust / clust2snp and
+ * their on-disk formats.  The entry points below are therefore cut at the
+ * reference's internal seams, each one replacing the function(s) cited:
+ *
+ *   e2s_upload_* / e2s_attach_soa   egsa_stream::read_el           include.hpp:120-199
+ *   e2s_cluster_scan                cluster_lm                     ebwt2clust.cpp:68-139
+ *   e2s_stitch / e2s_fetch_clusters append_entry + tail flush      ebwt2clust.cpp:54-63,127-135
+ *   e2s_cluster_hist                statistics (histogram pass)    clust2snp.cpp:877-909
+ *   e2s_auto_max_clust_length       statistics (auto max length)   clust2snp.cpp:936-946
+ *   e2s_find_candidates             find_events + find_variants    clust2snp.cpp:788-857,367-500
+ *   e2s_snp_from_candidates         extract_variants + to_file     clust2snp.cpp:505-780
+ *
+ * Conventions: one handle per GPU; the caller is single-threaded per handle; no
+ * exceptions cross the boundary; every call returns E2S_OK (0) or an error code
+ * (e2s_last_error gives text); the caller owns every host buffer it passes, the
+ * library owns device buffers unless attached.  Plain pointers and sizes only.
+ * All file-format integers are little-endian.
+ */
+#ifndef E2S_HIP_H
+#define E2S_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2S_OK               0
+#define E2S_ERR_ARG          1   /* bad argument / unsupported byte width */
+#define E2S_ERR_HIP          2   /* a HIP runtime call failed (no GPU, OOM, ...) */
+#define E2S_ERR_STATE        3   /* call out of order (e.g. scan before upload) */
+#define E2S_ERR_CAPACITY     4   /* output buffer too small; required count returned */
+#define E2S_ERR_SPIN_TIMEOUT 5   /* bounded in-kernel wait expired (look-back chain) */
+#define E2S_ERR_INPUT        6   /* malformed input (.clusters not ascending / past EOF) */
+#define E2S_ERR_REF_CRASH    7   /* the reference crashes on this input (H6); nothing written */
+#define E2S_ERR_IO           8
+
+#define E2S_NONE (~(uint64_t)0)
+#define E2S_MAX_CLUST_LEN 150    /* max_clust_length_def, clust2snp.cpp:32; -M is unparseable (H5) */
+
+typedef struct e2s_ctx* e2s_handle;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int  e2s_create(int device_id, e2s_handle* out);
+int  e2s_destroy(e2s_handle h);
+const char* e2s_last_error(e2s_handle h);   /* h may be NULL: last creation error */
+const char* e2s_version(void);
+
+/* ---- EGSA shard ---------------------------------------------------------------------------
+ * A handle holds one contiguous suffix-array range [global_offset, global_offset+n_entries)
+ * of an EGSA with n_total entries, plus halos: halo_left entries before (>= E2S_MAX_CLUST_LEN+2,
+ * or up to the array start: a cluster is handled by the shard that holds its END) and halo_right
+ * entries after (>= 1, or none at the array end).
+ * Source pointers address the FIRST PROVIDED entry, i.e. global index global_offset-halo_left.
+ * Byte widths follow -x/-y/-z of the reference (1,2,4,8); 8-byte fields are truncated to
+ * 32 bits exactly as t_GSA does (include.hpp:131,140,149).                                     */
+typedef struct {
+    uint64_t global_offset;
+    uint64_t n_entries;
+    uint64_t n_total;
+    uint32_t halo_left;
+    uint32_t halo_right;
+    int32_t  lcp_bytes;   /* -x */
+    int32_t  da_bytes;    /* -y */
+    int32_t  pos_bytes;   /* -z */
+    int32_t  reserved;
+} e2s_shard_desc;
+
+/* BCR triple (include.hpp:159-188): bwt = <f>.out (1 B/entry), lcp = <f>.out.lcp (x B),
+ * pairsa = <f>.out.pairSA ([pos:z][da:y] per entry).  Host pointers; copied to HBM and
+ * de-interleaved there. */
+int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa);
+/* .gesa array-of-structs (include.hpp:126-155): [da:y][pos:z][lcp:x][bwt:1] per entry. */
+int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void* aos);
+/* Struct-of-arrays already in HBM (device pointers, widths as in d, 8-byte widths not allowed);
+ * zero-copy: the caller keeps ownership and must keep them alive until detach/destroy. */
+int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, const void* d_lcp,
+                   const void* d_pos, const void* d_da);
+/* LCP column only (host pointer, x bytes per entry) -- all ebwt2clust needs: cluster_lm reads and
+ * discards the other fields.  tail_bwt = BWT byte of the shard's last owned entry (it feeds the
+ * reference's EOF phantom on the last rank; ignored elsewhere). */
+int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void* lcp, uint8_t tail_bwt);
+
+/* ---- ebwt2clust: cluster boundaries ------------------------------------------------------- */
+/* scan_mode: 0 = single-pass decoupled look-back (default), 1 = three-kernel count/scan/emit. */
+int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode);
+
+/* What one shard tells the others (fixed size; exchanged with ONE all-gather). */
+typedef struct {
+    uint64_t n_ends;           /* clusters that END in this shard (before the EOF tail is resolved)        */
+    uint64_t open_start;       /* start of the cluster still open at the shard's end, if it began in this
+                                  shard; E2S_NONE otherwise                                                 */
+    uint64_t last_end_start;   /* start of the cluster closed by the shard's last end (E2S_NONE: none, or
+                                  it began in an earlier shard)                                             */
+    uint32_t begins_inside;    /* the first owned entry continues a cluster opened in an earlier shard       */
+    uint32_t open_after;       /* a cluster is open after the last owned entry                               */
+    uint32_t pass_through;     /* no start and no end at all, and inside a cluster throughout                */
+    uint32_t end_before_last;  /* last rank only: a cluster ends at SA position n_total-2 (EOF phantom rule) */
+    uint32_t first_end_low16;  /* ((position of the first end)+1) & 0xFFFF: lets the owner of the end finish
+                                  the u16 length once the start is known                                     */
+    uint32_t tail_lcp;         /* LCP of the last owned entry                                                */
+    uint32_t tail_prev_lcp;    /* LCP of the entry before it                                                 */
+    uint32_t tail_bwt;         /* BWT byte of the last owned entry                                           */
+    uint64_t reserved[2];
+} e2s_boundary;
+
+int e2s_boundary_desc(e2s_handle h, e2s_boundary* out);
+
+/* What rank `rank` must do to its own record list once it has everybody's descriptor. */
+typedef struct {
+    uint32_t patch_first;      /* 1: this shard's record 0 becomes (first_start, first_len)          */
+    uint32_t n_tail;           /* last rank: 0..2 records appended after its n_ends records           */
+    uint64_t first_start;
+    uint64_t tail_start[2];
+    uint16_t first_len;
+    uint16_t tail_len[2];
+    uint16_t reserved16;
+    uint32_t phantom_lcp;      /* last rank: the EOF phantom LCP of the reference (hazard H1)         */
+    uint32_t reserved32;
+} e2s_stitch_plan_t;
+/* Host-only, pure function of the gathered descriptors (all[nranks], rank order = SA order). */
+int e2s_stitch_plan(const e2s_boundary* all, int nranks, int rank, uint64_t n_total, int k, int lcp_bytes,
+                    e2s_stitch_plan_t* out);
+/* e2s_stitch_plan + apply it to the device-resident records of this shard. */
+int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int rank);
+
+/* After e2s_stitch: n_closed = this shard's share of the count ebwt2clust prints
+ * (ebwt2clust.cpp:137, before the min_len filter); n_records = records it writes. */
+int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_records);
+/* Packed 10-byte {u64 start; u16 length} records of this shard (ebwt2clust.cpp:58-59), ascending. */
+int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records, uint64_t* n_records);
+
+/* ---- clust2snp: per-cluster pass ---------------------------------------------------------- */
+/* Use a .clusters file instead of the device-resident scan result (stand-alone clust2snp).
+ * recs: packed 10-byte records whose start lies in this shard, ascending, non-overlapping. */
+int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_records);
+
+/* Partial statistics of this shard's records (clust2snp.cpp:889-909 without the H4 double count). */
+typedef struct {
+    uint64_t freq[E2S_MAX_CLUST_LEN + 1];
+    uint64_t n_records;
+    uint64_t n_bases;
+    uint64_t last_len;        /* length of this shard's last record (valid if n_records > 0) */
+} e2s_hist;
+int e2s_cluster_hist(e2s_handle h, e2s_hist* out);
+
+/* Host-only: merge per-rank partials in rank order, apply the reference's double count of the
+ * last record (H4) and its auto-detection loop incl. the -Ofast arithmetic (H19).
+ * Returns E2S_ERR_REF_CRASH where the reference divides by zero (no record / no length<=150). */
+int e2s_auto_max_clust_length(const e2s_hist* parts, int nparts, int mcov_out, double pval,
+                              int* max_clust_length, uint64_t* n_clust, uint64_t* n_bases);
+
+typedef struct {
+    uint64_t nr_reads1;        /* -n as the reference stores it: (uint64_t)atoi(arg)            */
+    int32_t  k_left;           /* -L (31) */
+    int32_t  k_right;          /* -R (30) */
+    int32_t  mcov_out;         /* -m (5)  */
+    int32_t  consensus_reads;  /* -c (20) */
+    int32_t  max_clust_length; /* from e2s_auto_max_clust_length */
+    int32_t  min_len;          /* ebwt2clust -m when records come from e2s_cluster_scan; 0 for a .clusters file */
+} e2s_c2s_params;
+
+/* Fixed-size candidate (clust2snp.cpp:101-117).  Lists keep SA order, at most `cap` entries. */
+typedef struct {
+    uint64_t record_index;     /* global index of the cluster record it came from */
+    uint32_t pair_index;       /* position in the (c0,c1) loop order of clust2snp.cpp:431-435 */
+    uint32_t n0, n1;
+    uint32_t right_idx, right_pos;
+    uint32_t reserved;
+} e2s_cand_header;
+/* out layout: n_cand blocks of [e2s_cand_header][u32 idx0[cap]][u32 pos0[cap]][u32 idx1[cap]][u32 pos1[cap]] */
+int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand);
+int e2s_candidate_stride(e2s_handle h, const e2s_c2s_params* p, uint32_t* list_cap, size_t* stride_bytes);
+int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand);  /* sorted in SA order */
+
+/* ---- host tail: candidates -> KisSNP2 text (extract_variants + distance + to_file) -------- */
+typedef struct {
+    int32_t k_left, k_right, max_gap, max_err;   /* -L -R -g -e */
+} e2s_tail_params;
+/* cands: e2s_fetch_candidates layout (all ranks concatenated in rank order).  fasta_path is the
+ * reads file; out_path the .snp to write.  Host only (no GPU work). */
+int e2s_snp_from_candidates(const void* cands, uint64_t n_cand, uint32_t list_cap, const e2s_tail_params* p,
+                            const char* fasta_path, const char* out_path,
+                            uint64_t* n_variants, uint64_t* n_events);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+typedef struct {
+    float scan_ms;        /* e2s_cluster_scan kernels (HIP events on the handle's stream) */
+    float scan_main_ms;   /* the dominant scan kernel alone */
+    float hist_ms;
+    float cand_ms;        /* e2s_find_candidates kernels */
+    float cand_main_ms;   /* the dominant per-cluster kernel alone */
+    float upload_ms;
+    uint64_t scan_bytes_read, scan_bytes_written;   /* algorithmic bytes of the last call */
+    uint64_t cand_bytes_read, cand_bytes_written;
+} e2s_timing;
+int e2s_last_timing(e2s_handle h, e2s_timing* out);
+/* The HIP stream the handle launches on (hipStream_t as void*), for callers that bracket calls
+ * with their own events. */
+int e2s_stream(e2s_handle h, void** stream);
+int e2s_synchronize(e2s_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+// tests/swar_check.cpp -- host-compiled check of the SWAR stencil the gfx950 scan kernel uses
+// (ebwt2snp_amd/csrc/e2s_swar.h) against the per-entry definition of cluster_lm's tests
+// (ebwt2clust.cpp:98-102,116).  Built and run by tests/test_swar_host.py; no GPU needed.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../ebwt2snp_amd/csrc/e2s_swar.h"
+
+template <int X> static int run(unsigned seed, int iters) {
+    constexpr int PRE = (X == 4) ? 2 : 1;
+    constexpr int EPT = 16 / X;
+    constexpr int EPW = 4 / X;
+    constexpr u32 H = Swar<X>::H;
+    const u64 lane_max = X == 1 ? 0xFFull : X == 2 ? 0xFFFFull : 0xFFFFFFFFull;
+    srand(seed);
+    int bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        // entries -PRE*EPW .. EPT+EPW-1 around one thread-row
+        const int lo = -PRE * EPW, hi = EPT + EPW;
+        std::vector<u64> L(hi - lo);
+        const u64 kchoices[] = {16, 1, 0, 127, 128, 129, 200, 255, 256, 40000, 65535, 65536, 0x80000000ull, 0xFFFFFFFFull};
+        u64 k = kchoices[rand() % 14];
+        const int mode = rand() % 4;
+        for (auto& v : L) {
+            u64 r;
+            if (mode == 0) r = (u64)(rand() % 4) + (k > 2 ? k - 2 : 0);
+            else if (mode == 1) r = ((u64)rand() << 16 ^ (u64)rand());
+            else if (mode == 2) r = (u64)(rand() % 300);
+            else r = (rand() & 1) ? lane_max - (u64)(rand() % 3) : (u64)(rand() % 3);
+            v = r & lane_max;
+        }
+        u32 W[PRE + 5];
+        memset(W, 0, sizeof(W));
+        for (int e = lo; e < hi; ++e) {
+            const int idx = e - lo;                       // entry idx in stream
+            const int w = idx / EPW, l = idx % EPW;
+            W[w] |= (u32)(L[idx] << (8 * X * l) & 0xFFFFFFFFull) ;
+        }
+        const u32 k32 = (u32)k;
+        const u32 hge = (k > lane_max) ? 0u : H;
+        const u32 kb = X == 1 ? (k32 & 0xFF) * 0x01010101u : X == 2 ? (k32 & 0xFFFF) * 0x00010001u : k32;
+        RowFlags f;
+        row_flags<X>(W, kb, hge, f);
+        auto Lx = [&](int e) -> u64 { return L[e - lo]; };
+        auto ge = [&](int e) { return hge != 0 && Lx(e) >= k; };
+        auto endf = [&](int e) { return ge(e) && ((Lx(e - 1) > Lx(e) && Lx(e) <= Lx(e + 1)) || !ge(e + 1)); };
+        for (int e = 0; e < EPT; ++e) {
+            const bool want_end = endf(e);
+            const bool want_start = ge(e) && (!ge(e - 1) || endf(e - 1));
+            const int w = e / EPW, l = e % EPW;
+            const u32 bit = 1u << (8 * X * l + 8 * X - 1);
+            const bool got_end = (f.end[w] & bit) != 0, got_start = (f.start[w] & bit) != 0;
+            if (want_end != got_end || want_start != got_start) {
+                if (bad < 5) fprintf(stderr, "X=%d it=%d e=%d k=%llu end %d/%d start %d/%d\n", X, it, e, (unsigned long long)k, want_end, got_end, want_start, got_start);
+                ++bad;
+            }
+        }
+        // no stray bits outside the lane-MSB positions
+        for (int w = 0; w < 4; ++w) if ((f.end[w] | f.start[w]) & ~H) { if (bad < 5) fprintf(stderr, "stray bits X=%d\n", X); ++bad; }
+    }
+    return bad;
+}
+
+int main() {
+    int bad = run<1>(1, 200000) + run<2>(2, 200000) + run<4>(3, 200000);
+    printf("swar_check: %s (%d mismatches)\n", bad ? "FAIL" : "OK", bad);
+    return bad ? 1 : 0;
+}

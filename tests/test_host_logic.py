@@ -1,0 +1,220 @@
+"""CPU-only tests of the product's host-side pieces (everything in libe2s_hip.so that needs no GPU)
+and of the kernel's SWAR stencil compiled for the host."""
+import ctypes as C
+import os
+import random
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import goldens
+import oracle_lib as O
+import shard_emul as SE
+from ebwt2snp_amd import capi
+from ebwt2snp_amd import egsa_io as IO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = capi.lib()
+    hdr = open(os.path.join(ROOT, "include", "e2s_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(e2s_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    assert sorted(capi.SYMBOLS) == declared
+    for s in declared:
+        assert hasattr(L, s), s
+    assert b"gfx950" in L.e2s_version()
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.E2SError) as ei:
+        capi.Handle(0)
+    assert "no CPU path" in str(ei.value)
+
+
+def test_swar_stencil_host_build(tmp_path):
+    exe = str(tmp_path / "swar_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "swar_check.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _stitch_all(L, bwt, cuts, k, m, x):
+    """records of the whole EGSA assembled from emulated shards + the product's e2s_stitch_plan"""
+    n = len(L)
+    bounds = [0] + list(cuts) + [n]
+    shards = [SE.shard_scan(L, bwt, bounds[i], bounds[i + 1], k) for i in range(len(bounds) - 1)]
+    allb = [s[2] for s in shards]
+    S, Ln, closed = [], [], 0
+    for r, (st, ln, _) in enumerate(shards):
+        plan = capi.stitch_plan(allb, r, n, k, x)
+        st2, ln2 = SE.apply_plan(st, ln, plan)
+        S.append(st2)
+        Ln.append(ln2)
+        closed += st2.size
+    S = np.concatenate(S)
+    Ln = np.concatenate(Ln)
+    keep = Ln.astype(np.int64) >= m
+    return S[keep], Ln[keep], closed
+
+
+def test_stencil_and_stitch_plan_against_golden_table():
+    rnd = random.Random(5)
+    for c in goldens.e2c_table():
+        L = c["lcp"]
+        n = len(L)
+        if n < 1:
+            continue
+        x = c.get("x", 1)
+        k = c.get("k", 0) or 16
+        m = c.get("m", 0) or 2
+        bwt = c.get("bwt", [65] * n)
+        for nsh in (1, 2, 3):
+            if nsh > 1 and n < 2 * nsh + 2:
+                continue
+            cuts = sorted(rnd.sample(range(1, n - 1), nsh - 1)) if nsh > 1 else []
+            if nsh > 1 and n - cuts[-1] < 2:
+                continue
+            S, Ln, closed = _stitch_all(L, bwt, cuts, k, m, x)
+            assert closed == c["expect"]["n_printed"], (c.get("k"), nsh, cuts)
+            assert S.tolist() == c["expect"]["starts"] and Ln.tolist() == c["expect"]["lens"], (nsh, cuts)
+
+
+def test_stitch_plan_random_long_clusters():
+    """clusters spanning whole shards (pass-through) and u16 wrap across a cut"""
+    rnd = np.random.RandomState(3)
+    for it in range(60):
+        n = int(rnd.randint(50, 4000))
+        L = np.where(rnd.rand(n) < 0.02, rnd.randint(0, 16, n), rnd.randint(16, 40, n)).astype(np.uint32)
+        if it % 3 == 0:
+            L[:] = 20
+            L[0] = 0
+        bwt = rnd.choice([36, 65, 67, 71, 84], n).astype(np.uint8)
+        ph = O.phantom_lcp_for_scan(L, bwt, 16, 1)
+        es, el, ec = O.cluster_lm_mem(L, ph, 16, 2)
+        nsh = int(rnd.randint(1, 6))
+        cuts = sorted(set(rnd.randint(1, n - 2, nsh - 1).tolist())) if nsh > 1 else []
+        S, Ln, closed = _stitch_all(L, bwt, cuts, 16, 2, 1)
+        assert closed == ec
+        assert S.tolist() == es.tolist() and Ln.tolist() == el.tolist()
+
+
+def test_auto_max_clust_length_matches_reference_statistics():
+    for meta in goldens.e2e_cases():
+        if "clusters_file" not in meta:
+            continue
+        s, l = IO.read_clusters(os.path.join(goldens.GOLD, meta["clusters_file"]))
+        hs = capi.Hist()
+        for v in l:
+            if v <= 150:
+                hs.freq[int(v)] += 1
+        hs.n_records = len(l)
+        hs.n_bases = int(l.astype(np.int64).sum())
+        hs.last_len = int(l[-1])
+        mcl, nc, nb = capi.auto_max_clust_length([hs], meta["c2s"].get("m", 0) or 5, meta["c2s"].get("p", 0) or 0.99)
+        assert mcl == meta["max_clust_length"] and nc == meta["n_records"] + 1
+        # split into two partial histograms (what two shards would report)
+        h1, h2 = capi.Hist(), capi.Hist()
+        half = len(l) // 2
+        for hh, part in ((h1, l[:half]), (h2, l[half:])):
+            for v in part:
+                if v <= 150:
+                    hh.freq[int(v)] += 1
+            hh.n_records = len(part)
+            hh.n_bases = int(part.astype(np.int64).sum())
+            hh.last_len = int(part[-1])
+        assert capi.auto_max_clust_length([h1, h2], 5, 0.99)[0] == mcl
+    # empty .clusters: the reference dies with SIGFPE (H6)
+    with pytest.raises(capi.E2SError):
+        capi.auto_max_clust_length([capi.Hist()], 5, 0.99)
+
+
+def _pack_candidates(cands, cap):
+    hs = C.sizeof(capi.CandHeader)
+    stride = hs + 16 * cap
+    buf = np.zeros(len(cands) * stride, dtype=np.uint8)
+    for i, c in enumerate(cands):
+        h = capi.CandHeader(i, 0, len(c["idx0"]), len(c["idx1"]), c["right_idx"], c["right_pos"], 0)
+        buf[i * stride:i * stride + hs] = np.frombuffer(bytes(h), dtype=np.uint8)
+        l = buf[i * stride + hs:(i + 1) * stride].view(np.uint32)
+        l[0:len(c["idx0"])] = c["idx0"]
+        l[cap:cap + len(c["pos0"])] = c["pos0"]
+        l[2 * cap:2 * cap + len(c["idx1"])] = c["idx1"]
+        l[3 * cap:3 * cap + len(c["pos1"])] = c["pos1"]
+    return buf
+
+
+@pytest.mark.parametrize("meta", [m for m in goldens.e2e_cases() if m["name"] in ("tiny_bcr", "c1_bcr", "opts_bcr", "w282_bcr", "indel_bcr")],
+                         ids=lambda m: m["name"])
+def test_host_tail_on_oracle_candidates(meta, tmp_path):
+    """product host tail (extract_variants + distance + to_file) fed with the oracle's candidates
+    must reproduce the reference's .snp byte for byte"""
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    x, y, z = meta["xyz"]
+    assert O.ebwt2clust(p, meta["e2c"].get("k", 0), meta["e2c"].get("m", 0), x, y, z)[0] == 0
+    a = meta["c2s"]
+    opts = O.c2s_opts(n1, L=a.get("L", 0), R=a.get("R", 0), g=a.get("g", 0), c=a.get("c", 0), e=a.get("e", 0),
+                      m=a.get("m", 0), p=a.get("p", 0.0), x=x, y=y, z=z)
+    rc, cands, mcl = O.candidates(p, opts)
+    assert rc == 0 and len(cands) == meta["n_candidates"]
+    cap = a.get("c", 0) or 20
+    out = str(tmp_path / "product.snp")
+    nv, ne = capi.snp_from_candidates(_pack_candidates(cands, cap), len(cands), cap, p, out,
+                                      a.get("L", 0) or 31, a.get("R", 0) or 30, a.get("g", 0) or 10, a.get("e", 0) or 2)
+    assert open(out, "rb").read() == goldens.golden_snp(meta)
+    assert ne == meta["n_events"]
+
+
+def test_host_tail_crafted(tmp_path):
+    g = goldens.crafted()
+    for c in g["cases"]:
+        d = tmp_path / c["name"]
+        d.mkdir()
+        p = str(d / "v.fasta")
+        IO.write_fasta(p, g["reads"])
+        x, y, z = c["xyz"]
+        ent = np.asarray(c["entries"])
+        (IO.write_gesa if c["gesa"] else IO.write_bcr)(p, ent[:, 0], ent[:, 1], ent[:, 2], ent[:, 3], x, y, z)
+        IO.write_clusters(p + ".clusters", [s for s, _ in c["clusters"]], [l for _, l in c["clusters"]])
+        a = c["args"]
+        opts = O.c2s_opts(c["n1"], L=a.get("L", 0), R=a.get("R", 0), g=a.get("g", 0), c=a.get("c", 0),
+                          e=a.get("e", 0), m=a.get("m", 0), p=a.get("p", 0.0), x=x, y=y, z=z)
+        rc, cands, _ = O.candidates(p, opts)
+        assert rc == 0
+        cap = a.get("c", 0) or 20
+        out = str(d / "product.snp")
+        capi.snp_from_candidates(_pack_candidates(cands, cap), len(cands), cap, p, out,
+                                 a.get("L", 0) or 31, a.get("R", 0) or 30, a.get("g", 0) or 10, a.get("e", 0) or 2)
+        assert open(out).read() == c["expected_snp"], c["name"]
+
+
+def test_host_tail_fasta_layouts(tmp_path):
+    """multi-line FASTA records and a missing final newline parse like the reference's get_reads"""
+    meta = [m for m in goldens.e2e_cases() if m["name"] == "tiny_bcr"][0]
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    assert O.ebwt2clust(p)[0] == 0
+    rc, cands, _ = O.candidates(p, O.c2s_opts(n1))
+    for variant in ("wrapped", "nonl"):
+        q = str(tmp_path / (variant + ".fasta"))
+        rl = [bytes(r).decode() for r in reads]
+        if variant == "wrapped":
+            IO.write_fasta(q, rl, width=37)
+        else:
+            IO.write_fasta(q, rl)
+            data = open(q, "rb").read()
+            open(q, "wb").write(data[:-1])
+        # the oracle on the same layout
+        for ext in (".out", ".out.lcp", ".out.pairSA", ".clusters"):
+            os.link(p + ext, q + ext)
+        assert O.clust2snp(q, O.c2s_opts(n1))[0] == 0
+        out = str(tmp_path / (variant + ".product.snp"))
+        capi.snp_from_candidates(_pack_candidates(cands, 20), len(cands), 20, q, out)
+        assert open(out, "rb").read() == open(IO.snp_out_path(q), "rb").read() == goldens.golden_snp(meta)
