@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- EGSA entries/sec through ebwt2clust+clust2snp on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over a synthetic EGSA that is already resident in HBM:
+  cluster-boundary scan (ebwt2clust) -> boundary stitch -> cluster-length statistics ->
+  per-cluster allele-count/candidate pass (clust2snp) -> candidates copied to the host.
+The host tail (consensus / distance / KisSNP2 text for the ~1-per-12k-entries candidates) is outside the
+step; DESIGN.md quotes it separately.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+N > 1: weak scaling.  The global EGSA is N copies of the block; rank r owns a contiguous SA range whose
+cuts fall INSIDE clusters, so the stitch is real: ONE all-gather of the 88-byte boundary descriptors
+(plus one of the 1.2 KB histogram partials for the statistics step), RCCL over xGMI.
+"""
+import argparse
+import ctypes
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from ebwt2snp_amd import capi, synth
+from ebwt2snp_amd import egsa_io as IO
+
+WORKLOADS = {
+    # name: (reads per individual, read length)  -- BASELINE.json configs
+    "c1": (1000, 100),            # 2x1k x100bp, 2.02e5 entries (the reference's own CPU-runnable case)
+    "c2": (1000000, 100),         # 2x1M x100bp, 2.02e8 entries  <- the metric's 1-GPU configuration
+    "c2s": (250000, 100),         # quarter-size c2 for quick checks
+}
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def build_block(R, L, device):
+    reads, n1, e = synth.synth_case(R, L, seed=1, device=device, tail_lcp0=True)
+    bwt = e["bwt"].contiguous()
+    lcp = e["lcp"].to(torch.uint8).contiguous()
+    pos = e["suff"].to(torch.uint8).contiguous()
+    da = e["text"].to(torch.int32).contiguous()
+    return reads, n1, dict(bwt=bwt, lcp=lcp, pos=pos, da=da)
+
+
+def pick_cut(lcp, approx):
+    """an SA position near `approx` that lies strictly inside a cluster (both neighbours share >= 16)"""
+    w = lcp[approx:approx + 100000].to(torch.int32)
+    # c-1, c, c+1 all >= 16 and c-1 not a local minimum: the cluster runs through the cut
+    inside = (w[1:-2] >= 16) & (w[2:-1] >= 16) & (w[3:] >= 16) & (w[1:-2] >= w[:-3])
+    idx = torch.nonzero(inside)[0].item()
+    return approx + idx + 2
+
+
+def shard_arrays(blk, m, rank, world):
+    """rank's slice of the N-block global EGSA: [rank*m + d_r, (rank+1)*m + d_{r+1}) plus halos"""
+    cuts = [0] * (world + 1)
+    for r in range(1, world):
+        cuts[r] = pick_cut(blk["lcp"], m // 3 + 1000 * r)
+    lo_in, hi_in = cuts[rank], cuts[rank + 1]
+    hl = min(152, lo_in) if rank > 0 else 0
+    hr = 1 if rank < world - 1 else 0
+    out = {}
+    for k, v in blk.items():
+        parts = [v[lo_in - hl:]]
+        if hi_in + hr > 0:
+            parts.append(v[:hi_in + hr])
+        out[k] = torch.cat(parts).contiguous()
+    g0 = rank * m + lo_in
+    n_own = (m - lo_in) + hi_in
+    return out, g0, n_own, hl, hr
+
+
+def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2):
+    h.cluster_scan(k, min_len, 0)
+    b = h.boundary()
+    if world > 1:
+        t = torch.frombuffer(bytearray(bytes(b)), dtype=torch.uint8).to(dev)
+        allt = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allt, t)                       # the boundary stitch: ONE all-gather
+        raw = allt.cpu().numpy().tobytes()
+        sz = ctypes.sizeof(capi.Boundary)
+        allb = [capi.Boundary.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(world)]
+    else:
+        allb = [b]
+    h.stitch(allb, rank)
+    hs = h.hist()
+    if world > 1:
+        t = torch.frombuffer(bytearray(bytes(hs)), dtype=torch.uint8).to(dev)
+        allt = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allt, t)
+        raw = allt.cpu().numpy().tobytes()
+        sz = ctypes.sizeof(capi.Hist)
+        hists = [capi.Hist.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(world)]
+    else:
+        hists = [hs]
+    mcl, n_clust, _ = capi.auto_max_clust_length(hists, prm_base["m"], 0.99)
+    prm = capi.C2SParams(prm_base["n1"], 31, 30, prm_base["m"], 20, mcl, min_len)
+    ncand = h.find_candidates(prm, rank << 40)
+    buf, ncand, cap, stride = h.fetch_candidates(prm)
+    return dict(n_ends=b.n_ends, n_cand=ncand, mcl=mcl, n_clust=n_clust)
+
+
+def cpu_baseline(blk, reads, n1, sample_entries):
+    """the reference's own executables (oracle/_ref) -- or, without them, the C restatement -- timed on
+    one host core over the first `sample_entries` entries of the same EGSA, through files like the
+    reference works (BCR triple + FASTA)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n = int(min(sample_entries, blk["lcp"].numel()))
+    d = tempfile.mkdtemp(prefix="e2s_cpu_")
+    try:
+        p = os.path.join(d, "reads.fasta")
+        IO.write_fasta_fast(p, reads.cpu().numpy())
+        lcp = blk["lcp"][:n].cpu().numpy().copy()
+        lcp[-1] = 0
+        IO.write_bcr(p, blk["da"][:n].cpu().numpy(), blk["pos"][:n].cpu().numpy(), lcp, blk["bwt"][:n].cpu().numpy())
+        if O.have_ref():
+            kind = "reference"
+            t0 = time.time()
+            rc, out = O.ref_ebwt2clust(p)
+            t1 = time.time()
+            assert rc == 0, out[-300:]
+            rc, out = O.ref_clust2snp(p, n1)
+            t2 = time.time()
+            assert rc == 0, out[-300:]
+        else:
+            kind = "port"
+            O.build()
+            t0 = time.time()
+            rc, _ = O.ebwt2clust(p)
+            t1 = time.time()
+            assert rc == 0
+            rc, _ = O.clust2snp(p, O.c2s_opts(n1))
+            t2 = time.time()
+            assert rc == 0
+        return dict(value=n / (t2 - t0), unit="EGSA entries/s", cores=1, kind=kind,
+                    sample="first %d entries of the same EGSA (BCR triple + FASTA on local disk): ebwt2clust %.2f s + clust2snp %.2f s"
+                           % (n, t1 - t0, t2 - t1))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=100000000, help="entries of the CPU baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and a.gpus > 1:
+        # not launched by torch.distributed.run: start it as a child (one rank per GPU) before touching the GPU
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    R, L = WORKLOADS[a.workload]
+    t0 = time.time()
+    reads, n1, blk = build_block(R, L, dev)
+    m = blk["lcp"].numel()
+    arrs, g0, n_own, hl, hr = shard_arrays(blk, m, rank, world)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    n_total = m * world
+
+    h = capi.Handle(local)
+    d = capi.Handle.desc(n_total, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr)
+    h.attach_soa(d, arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(), arrs["pos"].data_ptr(), arrs["da"].data_ptr(),
+                 keep=tuple(arrs.values()))
+    prm_base = dict(n1=n1, m=5)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    info = None
+    for _ in range(a.warmup):
+        info = run_step(h, prm_base, world, rank, dist, dev)
+    scan_ms, cand_ms, scan_all_ms, hist_ms = [], [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        info = run_step(h, prm_base, world, rank, dist, dev)
+        tm = h.timing()
+        scan_ms.append(tm.scan_main_ms); cand_ms.append(tm.cand_main_ms); scan_all_ms.append(tm.scan_ms); hist_ms.append(tm.hist_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([info["n_ends"], info["n_cand"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        tot_ends, tot_cand = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        tot_ends, tot_cand = info["n_ends"], info["n_cand"]
+
+    if rank == 0:
+        tm = h.timing()
+        ms_step = elapsed / a.steps * 1e3
+        value = n_total * a.steps / elapsed
+        # dominant kernel: the per-cluster pass (k_candidates).  Algorithmic bytes per launch:
+        # 7 B/entry (bwt 1 + lcp 1 + pos 1 + da 4) over the owned entries + 10 B per cluster record read.
+        cand_avg_ms = float(np.mean(cand_ms))
+        cand_bytes = n_own * 7 + info["n_ends"] * 10
+        cand_gbs = cand_bytes / (cand_avg_ms * 1e-3) / 1e9
+        scan_avg_ms = float(np.mean(scan_ms))
+        scan_bytes = n_own * 1 + info["n_ends"] * 10          # LCP read + 10 B/record written
+        scan_gbs = scan_bytes / (scan_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": value, "unit": "EGSA entries/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s: 2x%d reads x %dbp synthetic EGSA per GPU, %d entries/GPU, BCR widths 1/4/1"
+                                   % (a.workload, R, L, m), "entries_total": n_total, "k": 16, "min_len": 2,
+                       "parallelism": "sa-range x%d" % world, "cluster_records": tot_ends, "candidates": tot_cand,
+                       "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_candidates", "achieved": cand_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": cand_gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": cand_avg_ms, "algorithmic_bytes": cand_bytes},
+            "roofline_scan": {"bound": "hbm", "kernel": "k_scan", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": scan_gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": scan_avg_ms,
+                              "algorithmic_bytes": scan_bytes, "scan_all_kernels_ms": float(np.mean(scan_all_ms)),
+                              "hist_ms": float(np.mean(hist_ms))},
+        }
+        if world == 1 and a.cpu_sample > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(blk, reads, n1, a.cpu_sample)
+            except Exception as ex:           # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "EGSA entries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

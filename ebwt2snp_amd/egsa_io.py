@@ -84,6 +84,20 @@ def write_fasta(path, reads, width=None):
                     f.write(r + b"\n")
 
 
+def write_fasta_fast(path, reads):
+    """reads: uint8 [R, L] ASCII.  Fixed-width headers so the whole file is one array write."""
+    R, L = reads.shape
+    hdr = np.char.zfill(np.arange(R).astype(str), 9)
+    rec = np.empty((R, 2 + 9 + 1 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord(">")
+    rec[:, 1] = ord("r")
+    rec[:, 2:11] = np.frombuffer("".join(hdr.tolist()).encode(), dtype=np.uint8).reshape(R, 9)
+    rec[:, 11] = 10
+    rec[:, 12:12 + L] = reads
+    rec[:, 12 + L] = 10
+    rec.tofile(path)
+
+
 def snp_out_path(input_path):
     """clust2snp.cpp:1074-1076: input.substr(0, rfind(".fast")) + ".snp"."""
     p = input_path.rfind(".fast")
