@@ -30,7 +30,11 @@ struct e2s_ctx {
     std::vector<void*> owned;
     // scan state
     uint64_t* d_starts = nullptr; uint16_t* d_lens = nullptr; uint64_t cap = 0;
-    uint64_t* d_tile_state = nullptr; uint64_t* d_tile_fix = nullptr; uint32_t* d_tile_count = nullptr; uint64_t* d_tile_prefix = nullptr;
+    uint64_t* d_tile_state = nullptr; uint64_t* d_tile_fix = nullptr; uint64_t* d_tile_fix_end = nullptr; uint32_t* d_tile_count = nullptr; uint64_t* d_tile_prefix = nullptr;
+    uint64_t* d_wrap = nullptr;                  // [E2S_WRAP_CAP] ranks of records whose true length wrapped the u16
+    std::vector<uint64_t> wrap_ranks; bool wrap_overflow = false;
+    uint64_t first_end_pos = E2S_NONE; bool first_wrapped = false;
+    uint64_t* d_fl_starts = nullptr; uint16_t* d_fl_lens = nullptr; uint64_t fl_cap = 0;
     uint64_t tiles_cap = 0;
     uint64_t* d_scalars = nullptr;               // [0] total_ends  [1] cand_count  [2..] hist (153)
     uint32_t* d_words = nullptr;                 // [0] tile_counter [1] err [2,3] flags [4,5] tailv
@@ -83,7 +87,8 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
         return E2S_ERR_HIP;
     }
     for (auto& ev : h->ev) hipEventCreate(&ev);
-    if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess) {
+    if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         delete h;
         return E2S_ERR_HIP;
@@ -107,6 +112,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     release_shard(h);
     hipFree(h->d_starts); hipFree(h->d_lens); hipFree(h->d_tile_state); hipFree(h->d_tile_fix);
     hipFree(h->d_tile_count); hipFree(h->d_tile_prefix); hipFree(h->d_scalars); hipFree(h->d_words); hipFree(h->d_cand);
+    hipFree(h->d_tile_fix_end); hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(h->stream);
     delete h;
@@ -273,10 +279,11 @@ static int ensure_records(e2s_ctx* h, uint64_t cap) {
 
 static int ensure_tiles(e2s_ctx* h, uint64_t n_tiles) {
     if (n_tiles <= h->tiles_cap) return E2S_OK;
-    hipFree(h->d_tile_state); hipFree(h->d_tile_fix); hipFree(h->d_tile_count); hipFree(h->d_tile_prefix);
+    hipFree(h->d_tile_state); hipFree(h->d_tile_fix); hipFree(h->d_tile_fix_end); hipFree(h->d_tile_count); hipFree(h->d_tile_prefix);
     h->tiles_cap = 0;
     CK(hipMalloc((void**)&h->d_tile_state, n_tiles * 8));
     CK(hipMalloc((void**)&h->d_tile_fix, n_tiles * 8));
+    CK(hipMalloc((void**)&h->d_tile_fix_end, n_tiles * 8));
     CK(hipMalloc((void**)&h->d_tile_count, n_tiles * 4));
     CK(hipMalloc((void**)&h->d_tile_prefix, n_tiles * 8));
     h->tiles_cap = n_tiles;
@@ -313,14 +320,17 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     uint64_t want = std::max<uint64_t>(h->cap, d.n_entries / 8 + 4096);
     a.spin_limit = 1u << 22;
     a.total_ends = h->d_scalars + 0;
-    a.tile_fix = h->d_tile_fix; a.tile_state = h->d_tile_state; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
+    a.tile_fix = h->d_tile_fix; a.tile_fix_end = h->d_tile_fix_end; a.tile_state = h->d_tile_state; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
+    a.first_end_pos = h->d_scalars + 3;
     a.tile_counter = h->d_words + 0; a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
 
+    uint32_t wrap_n = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = ensure_records(h, want))) return rc;
         a.starts = h->d_starts; a.lens = h->d_lens; a.cap = h->cap;
         CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
         CK(hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+        CK(hipMemsetAsync(h->d_scalars + 3, 0xFF, 8, h->stream));
         CK(hipMemsetAsync(h->d_tile_fix, 0xFF, a.n_tiles * 8, h->stream));
         e2s_launch_shard_flags(a, h->xb, h->stream);
         CK(hipEventRecord(h->ev[0], h->stream));
@@ -336,8 +346,9 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             e2s_launch_scan(a, h->xb, 2, h->stream);
             CK(hipEventRecord(h->ev[3], h->stream));
         }
-        e2s_launch_scan_fix(a.n_tiles, (const unsigned long long*)h->d_tile_fix, (const unsigned long long*)h->d_starts, h->d_lens,
-                            h->cap, a.flags, h->stream);
+        e2s_launch_scan_fix(a.n_tiles, (const unsigned long long*)h->d_tile_fix, (const unsigned long long*)h->d_tile_fix_end,
+                            (const unsigned long long*)h->d_starts, h->d_lens, h->cap, a.flags, (unsigned long long*)h->d_wrap,
+                            h->d_words + 12, h->stream);
         CK(hipEventRecord(h->ev[1], h->stream));
         uint32_t words[16];
         uint64_t total = 0;
@@ -346,6 +357,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
         h->begins_inside = words[2]; h->open_after = words[3]; h->end_before_last = words[4];
+        wrap_n = words[12];
         if (words[1] & E2S_DEVERR_SPIN) return fail(h, E2S_ERR_SPIN_TIMEOUT, "look-back wait expired");
         h->tail_lcp = words[8]; h->tail_prev_lcp = words[9];
         h->n_ends = total;
@@ -358,6 +370,14 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     h->tm.scan_bytes_read = d.n_entries * (uint64_t)d.lcp_bytes;
     h->tm.scan_bytes_written = h->n_ends * 10;
 
+    // records whose uint16_t length wrapped: the per-cluster pass must take them from the record list
+    h->wrap_ranks.clear(); h->wrap_overflow = wrap_n > E2S_WRAP_CAP; h->first_wrapped = false;
+    if (wrap_n && !h->wrap_overflow) {
+        h->wrap_ranks.resize(wrap_n);
+        CK(hipMemcpy(h->wrap_ranks.data(), h->d_wrap, wrap_n * 8, hipMemcpyDeviceToHost));
+    }
+    h->first_end_pos = E2S_NONE;
+    if (h->n_ends) CK(hipMemcpy(&h->first_end_pos, h->d_scalars + 3, 8, hipMemcpyDeviceToHost));
     // the few values the boundary descriptor and the EOF phantom need
     h->open_start = E2S_NONE; h->last_end_start = E2S_NONE; h->first_len_prov = 0;
     const bool own_start_open = h->open_after && !(h->n_ends == 0 && h->begins_inside);
@@ -473,6 +493,7 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     if (pl.patch_first) {
         CK(hipMemcpy(h->d_starts, &pl.first_start, 8, hipMemcpyHostToDevice));
         CK(hipMemcpy(h->d_lens, &pl.first_len, 2, hipMemcpyHostToDevice));
+        h->first_wrapped = h->first_end_pos != E2S_NONE && h->first_end_pos - pl.first_start + 1 >= 65536;
     }
     h->n_rec = h->n_ends;
     h->n_closed = h->n_ends;
@@ -652,6 +673,16 @@ static void phantom_entry(const e2s_ctx* h, uint32_t text, uint32_t suff, uint32
     *pt = get(y); *ps = get(z); *pl = get(x); *pb = slot[0];
 }
 
+static int ensure_flagged(e2s_ctx* h, uint64_t cap) {
+    if (cap <= h->fl_cap && h->d_fl_starts) return E2S_OK;
+    hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
+    h->d_fl_starts = nullptr; h->d_fl_lens = nullptr; h->fl_cap = 0;
+    CK(hipMalloc((void**)&h->d_fl_starts, (cap + 8) * 8));
+    CK(hipMalloc((void**)&h->d_fl_lens, (cap + 8) * 2 + 64));
+    h->fl_cap = cap;
+    return E2S_OK;
+}
+
 extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand) {
     if (!h || !p) return E2S_ERR_ARG;
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
@@ -670,8 +701,6 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         CK(hipMemcpy(&b, h->bwt + i, 1, hipMemcpyDeviceToHost));
         phantom_entry(h, t, s, l, b, &a.ph_text, &a.ph_suff, &a.ph_lcp, &a.ph_bwt);
     }
-    a.starts = h->d_starts; a.lens = h->d_lens; a.n_rec = h->n_rec;
-    a.rec_per_wave = 8;
     a.nr_reads1 = p->nr_reads1;
     a.k_left_u = (uint64_t)(int64_t)p->k_left; a.k_right_u = (uint64_t)(int64_t)p->k_right;   // uint64_t vs int compares
     a.k_left_lo = (uint32_t)p->k_left; a.mcov_u = (uint32_t)p->mcov_out;
@@ -685,9 +714,16 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     a.record_index_base = record_index_base;
     a.err = h->d_words + 1;
     h->list_cap = a.list_cap; h->cand_stride = a.stride;
+
+    // Streaming path: boundaries recomputed from the LCP inside the kernel.  Needs the records to be the
+    // scan's own (same k), default field widths for what it reads, 16-byte aligned columns.
+    const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt | (uintptr_t)h->da) & 15u) == 0;
+    bool streaming = !h->records_from_file && d.lcp_bytes == 1 && d.da_bytes == 4 && aligned && !h->wrap_overflow;
+
     uint64_t want = std::max<uint64_t>(4096, h->n_rec / 256);
     uint64_t count = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    bool done = false;
+    for (int attempt = 0; attempt < 5 && !done; ++attempt) {
         if (!h->d_cand || want * a.stride > h->cand_bytes) {
             hipFree(h->d_cand); h->d_cand = nullptr; h->cand_bytes = 0;
             CK(hipMalloc((void**)&h->d_cand, (size_t)want * a.stride + 256));
@@ -697,22 +733,81 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap;
         CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
         CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
-        CK(hipEventRecord(h->ev[6], h->stream));
-        if (h->n_rec) e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
-        CK(hipEventRecord(h->ev[7], h->stream));
+        uint64_t flagged = 0;
+        if (streaming) {
+            int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096));
+            if (rc) return rc;
+            // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
+            std::vector<uint64_t> seed_r;
+            for (uint64_t r = h->n_ends; r < h->n_rec; ++r) seed_r.push_back(r);
+            for (uint64_t r : h->wrap_ranks) seed_r.push_back(r);
+            if (h->first_wrapped) seed_r.push_back(0);
+            std::vector<uint64_t> ss; std::vector<uint16_t> sl;
+            for (uint64_t r : seed_r) {
+                uint64_t st = 0; uint16_t ln = 0;
+                CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(&ln, h->d_lens + r, 2, hipMemcpyDeviceToHost));
+                if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); }
+            }
+            const uint64_t nseed = ss.size();
+            if (nseed) {
+                CK(hipMemcpyAsync(h->d_fl_starts, ss.data(), nseed * 8, hipMemcpyHostToDevice, h->stream));
+                CK(hipMemcpyAsync(h->d_fl_lens, sl.data(), nseed * 2, hipMemcpyHostToDevice, h->stream));
+            }
+            CK(hipMemcpyAsync(h->d_scalars + 2, &nseed, 8, hipMemcpyHostToDevice, h->stream));
+            FilterArgs f{};
+            f.bwt = h->bwt; f.lcp = (const uint8_t*)h->lcp; f.da = (const uint32_t*)h->da;
+            f.n_prov = h->n_prov; f.prov_lo = h->prov_lo; f.prov_is_global0 = h->prov_lo == 0;
+            f.own_lo = d.halo_left;
+            const uint64_t own_hi = (uint64_t)d.halo_left + d.n_entries;
+            const uint64_t last_end_global = d.n_total - 1;
+            f.end_hi = std::min<uint64_t>(own_hi, last_end_global > h->prov_lo ? last_end_global - h->prov_lo : 0);
+            if (f.end_hi < f.own_lo) f.end_hi = f.own_lo;
+            f.k_u32 = (uint32_t)h->k;
+            f.hge = ((uint64_t)f.k_u32 > 0xFFull) ? 0u : 0x80808080u;
+            f.kb = (f.k_u32 & 0xFF) * 0x01010101u;
+            f.kr_hge = (a.k_right_u > 0xFFull) ? 0u : 0x80808080u;
+            f.krb = (uint32_t)(a.k_right_u & 0xFF) * 0x01010101u;
+            f.nr_reads1 = a.nr_reads1; f.mcov_u = a.mcov_u; f.len_lo = a.len_lo; f.len_hi = a.len_hi;
+            f.n_tiles = (h->n_prov + 3935) / 3936;
+            f.fl_starts = h->d_fl_starts; f.fl_lens = h->d_fl_lens; f.fl_cap = h->fl_cap;
+            f.fl_count = (unsigned long long*)(h->d_scalars + 2);
+            f.err = h->d_words + 1;
+            CK(hipEventRecord(h->ev[6], h->stream));
+            e2s_launch_cluster_filter(f, h->stream);
+            CK(hipEventRecord(h->ev[4], h->stream));
+            a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap;
+            a.n_rec_dev = (const unsigned long long*)(h->d_scalars + 2);
+            a.key_is_start = 1;
+            e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
+            CK(hipEventRecord(h->ev[7], h->stream));
+        } else {
+            a.starts = h->d_starts; a.lens = h->d_lens; a.n_rec = h->n_rec; a.n_rec_dev = nullptr; a.key_is_start = 0;
+            CK(hipEventRecord(h->ev[6], h->stream));
+            if (h->n_rec) e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
+            CK(hipEventRecord(h->ev[4], h->stream));
+            CK(hipEventRecord(h->ev[7], h->stream));
+        }
         uint32_t err = 0;
         CK(hipMemcpyAsync(&count, h->d_scalars + 1, 8, hipMemcpyDeviceToHost, h->stream));
+        CK(hipMemcpyAsync(&flagged, h->d_scalars + 2, 8, hipMemcpyDeviceToHost, h->stream));
         CK(hipMemcpyAsync(&err, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
-        if (count <= h->cand_cap) break;
-        if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "candidate buffer overflow");
+        if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
+        if (streaming && flagged > h->fl_cap) {
+            int rc = ensure_flagged(h, flagged + 4096);
+            if (rc) return rc;
+            continue;
+        }
+        if (count <= h->cand_cap) { done = true; break; }
         want = count + 1024;
     }
+    if (!done) return fail(h, E2S_ERR_CAPACITY, "candidate / flagged buffer overflow");
     h->n_cand = count;
     hipEventElapsedTime(&h->tm.cand_ms, h->ev[6], h->ev[7]);
-    h->tm.cand_main_ms = h->tm.cand_ms;
+    hipEventElapsedTime(&h->tm.cand_main_ms, h->ev[6], h->ev[4]);
     h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
     h->tm.cand_bytes_written = count * a.stride;
     if (n_cand) *n_cand = count;

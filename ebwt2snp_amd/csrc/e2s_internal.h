@@ -10,6 +10,7 @@
 // device-side error bits
 #define E2S_DEVERR_SPIN   1u   // look-back wait expired
 #define E2S_DEVERR_REMOTE 2u   // a cluster's entries are not resident in this shard
+#define E2S_DEVERR_DENSE  4u   // a 4096-entry window holds more clusters than the LDS slots (fall back)
 
 // a.flags[] slots written by k_shard_flags
 #define E2S_FLAG_BEGINS_INSIDE 0
@@ -33,7 +34,9 @@ struct ScanArgs {
     uint16_t* lens;           // [cap + 1]
     uint64_t cap;
     uint64_t* total_ends;
-    uint64_t* tile_fix;       // [n_tiles], preset to ~0
+    uint64_t* tile_fix;       // [n_tiles], preset to ~0: rank of the tile's record whose start lies in an earlier tile
+    uint64_t* tile_fix_end;   // [n_tiles]: that record's end position
+    uint64_t* first_end_pos;  // SA position of the shard's first end (preset ~0)
     // look-back workspace (MODE 0)
     uint64_t* tile_state;     // [n_tiles], preset to 0
     uint32_t* tile_counter;   // preset to 0
@@ -60,6 +63,8 @@ struct CandArgs {
     uint64_t prov_lo, prov_hi, n_total;
     uint32_t ph_text, ph_suff, ph_lcp, ph_bwt;      // the EOF phantom entry (global index n_total)
     const uint64_t* starts; const uint16_t* lens; uint64_t n_rec;
+    const unsigned long long* n_rec_dev;            // if set: the record count lives on the device (flagged list)
+    uint32_t key_is_start;                          // order key of a candidate = its cluster's start position
     uint32_t rec_per_wave;
     uint64_t nr_reads1, k_left_u, k_right_u;
     uint32_t k_left_lo, mcov_u;
@@ -71,10 +76,29 @@ struct CandArgs {
     uint32_t* err;
 };
 
+struct FilterArgs {
+    const uint8_t* bwt; const uint8_t* lcp; const uint32_t* da;     // first provided entry, 16-byte aligned
+    uint64_t n_prov, prov_lo;
+    uint32_t prov_is_global0;
+    uint64_t own_lo, end_hi;                                        // a cluster is handled where its END is owned
+    uint32_t k_u32, kb, hge;                                        // scan threshold (as in ScanArgs)
+    uint32_t krb, kr_hge;                                           // k_right broadcast / 0 if it exceeds a byte
+    uint64_t nr_reads1;
+    uint32_t mcov_u;
+    int len_lo, len_hi;
+    uint64_t n_tiles;
+    uint64_t* fl_starts; uint16_t* fl_lens; uint64_t fl_cap;
+    unsigned long long* fl_count;
+    uint32_t* err;
+};
+
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
+void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);
-void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* starts,
-                         uint16_t* lens, unsigned long long cap, const uint32_t* flags, hipStream_t st);
+#define E2S_WRAP_CAP 1024
+void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* tile_fix_end,
+                         const unsigned long long* starts, uint16_t* lens, unsigned long long cap, const uint32_t* flags,
+                         unsigned long long* wrap_list, uint32_t* wrap_count, hipStream_t st);
 void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
 void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);

@@ -47,6 +47,29 @@ template <int X> __device__ __forceinline__ void range_mask(int lo, int hi, u32*
     }
 }
 
+// The j = 0,1 rules of ebwt2clust.cpp:83-84, applied to the thread-row that holds global index 0:
+// with L[0] >= k the cluster opened at 0 swallows entry 1 whatever L[1] is, and j = 0 is never tested.
+template <int X>
+__device__ __forceinline__ void patch_global0(const u32* W, u32 k, u32 hge, RowFlags& f) {
+    constexpr int PRE = (X == 4) ? 2 : 1;
+    constexpr u32 B0 = 1u << (8 * X - 1);
+    constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
+    constexpr int w1 = (X == 4) ? 1 : 0;
+    constexpr u32 B1 = (X == 4) ? B0 : (B0 << (8 * (X & 3)));
+    constexpr int w2 = (X == 4) ? 2 : (X == 2 ? 1 : 0);
+    constexpr u32 B2 = (X == 1) ? (B0 << 16) : B0;
+    const u32 e0v = W[PRE] & LM;
+    const u32 e1v = (X == 4) ? W[PRE + 1] : ((W[PRE] >> (8 * (X & 3))) & LM);
+    const u32 e2v = (X == 4) ? W[PRE + 2] : (X == 2 ? (W[PRE + 1] & LM) : ((W[PRE] >> 16) & LM));
+    f.end[0] &= ~B0;
+    if (hge != 0 && e0v >= k) {
+        const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < k);
+        f.start[w1] &= ~B1;
+        if (end1) f.end[w1] |= B1; else f.end[w1] &= ~B1;
+        if (e2v >= k) { if (end1) f.start[w2] |= B2; else f.start[w2] &= ~B2; }
+    }
+}
+
 constexpr int SCAN_BLK = E2S_SCAN_BLOCK;
 constexpr int SCAN_ROWS = E2S_SCAN_ROWS;
 constexpr u32 CARRY_CLOSED = 0xFFFFFFFFu;   // last event of the thread-row was an end
@@ -118,27 +141,7 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
             }
         }
         row_flags<X>(W, a.kb, a.hge, F[r]);
-        // the j = 0,1 rules of ebwt2clust.cpp:83-84 (only the thread-row holding global index 0):
-        // with L[0] >= k the cluster opened at 0 swallows entry 1 whatever L[1] is, and j = 0 is never tested
-        if (a.prov_is_global0 && i0 == 0) {
-            constexpr u32 B0 = 1u << (8 * X - 1);
-            constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
-            constexpr int w1 = (X == 4) ? 1 : 0;
-            constexpr u32 B1 = (X == 4) ? B0 : (B0 << (8 * (X & 3)));
-            constexpr int w2 = (X == 4) ? 2 : (X == 2 ? 1 : 0);
-            constexpr u32 B2 = (X == 1) ? (B0 << 16) : B0;
-            const u32 e0v = W[PRE] & LM;
-            const u32 e1v = (X == 4) ? W[PRE + 1] : ((W[PRE] >> (8 * (X & 3))) & LM);
-            const u32 e2v = (X == 4) ? W[PRE + 2] : (X == 2 ? (W[PRE + 1] & LM) : ((W[PRE] >> 16) & LM));
-            const u32 k = a.k_u32;
-            F[r].end[0] &= ~B0;
-            if (a.hge != 0 && e0v >= k) {
-                const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < k);
-                F[r].start[w1] &= ~B1;
-                if (end1) F[r].end[w1] |= B1; else F[r].end[w1] &= ~B1;
-                if (e2v >= k) { if (end1) F[r].start[w2] |= B2; else F[r].start[w2] &= ~B2; }
-            }
-        }
+        if (a.prov_is_global0 && i0 == 0) patch_global0<X>(W, a.k_u32, a.hge, F[r]);
         // restrict to the owned window
         if (!(i0 >= own_lo && i0 + EPT <= end_hi)) {
             u32 m[4];
@@ -292,8 +295,9 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
                 if ((F[r].end[w] >> bit) & 1u) {
                     if (rk < a.cap) {
                         if (pend < CARRY_UNKNOWN) a.lens[rk] = (uint16_t)(off - pend + 1);
-                        else { a.lens[rk] = (uint16_t)((g_tile + off + 1) & 0xFFFFull); a.tile_fix[tile] = rk; }
+                        else { a.lens[rk] = (uint16_t)((g_tile + off + 1) & 0xFFFFull); a.tile_fix[tile] = rk; a.tile_fix_end[tile] = g_tile + off; }
                     }
+                    if (rk == 0) *a.first_end_pos = g_tile + off;
                     ++rk;
                     pend = CARRY_CLOSED;
                 }
@@ -302,14 +306,21 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
     }
 }
 
-// one thread per tile: finish the record whose start lies in an earlier tile
-__global__ void k_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* starts, uint16_t* lens, u64 cap, const u32* flags) {
+// one thread per tile: finish the record whose start lies in an earlier tile.  Records whose true length
+// reaches 65536 (the reference's uint16_t length wraps, ebwt2clust.cpp:104) are listed for the per-cluster pass.
+__global__ void k_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* tile_fix_end, const u64* starts, uint16_t* lens, u64 cap,
+                           const u32* flags, u64* wrap_list, u32* wrap_count) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const u64 r = tile_fix[t];
     if (r == ~0ull || r >= cap) return;
     if (r == 0 && flags[E2S_FLAG_BEGINS_INSIDE]) return;        // start lives in an earlier shard: e2s_stitch
-    lens[r] = (uint16_t)((lens[r] - (uint16_t)(starts[r] & 0xFFFFull)) & 0xFFFFu);
+    const u64 true_len = tile_fix_end[t] - starts[r] + 1;
+    lens[r] = (uint16_t)(true_len & 0xFFFFull);
+    if (true_len >= 65536ull) {
+        const u32 i = atomicAdd(wrap_count, 1u);
+        if (i < E2S_WRAP_CAP) wrap_list[i] = r;
+    }
 }
 
 // exclusive scan of per-tile counts (MODE 1 -> MODE 2), single block
@@ -400,6 +411,189 @@ __global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int m
 }
 
 // ----------------------------------------------------------------------------------------------
+// K2a: streaming per-cluster allele counts + filters (phase A of find_events/find_variants,
+// clust2snp.cpp:816,377-429).  Entry-parallel: a thread-row is 16 consecutive entries; a block walks
+// windows of 4096 entries that overlap the previous window by 160, so every cluster of <= 150
+// entries that ENDS in the window's new part lies inside the window.  Cluster boundaries are
+// recomputed from the LCP with the same SWAR stencil as K1; per-cluster counts[2][4] are reduced in
+// LDS (packed 4 x 8-bit counters, one slot per cluster of the window).  Clusters that pass the
+// reference's filters are appended to a short list for K2b (lists, clust2snp.cpp:431-496).
+// Default widths only (lcp 1 B, da 4 B); bytes read per entry: lcp 1 + bwt 1 + da 4.
+// ----------------------------------------------------------------------------------------------
+constexpr int FW_WIN = 4096;                 // window = 256 thread-rows of 16 entries
+constexpr int FW_HALO = 160;                 // >= E2S_MAX_CLUST_LEN + margin, multiple of 16
+constexpr int FW_NEW = FW_WIN - FW_HALO;     // 3936
+constexpr int FW_SLOTS = 2048;               // clusters per window held in LDS; denser windows raise E2S_DEVERR_DENSE
+constexpr u32 SE_ENDED = 1u << 24, SE_KR = 1u << 25;
+
+// lane-MSB mask (clean: only the top bit of each byte) -> 4-bit compact mask
+__device__ __forceinline__ u32 msb_compact(u32 m) { return (m * 0x00204081u) >> 28; }
+__device__ __forceinline__ u32 compact16(const u32* m) {
+    return msb_compact(m[0]) | (msb_compact(m[1]) << 4) | (msb_compact(m[2]) << 8) | (msb_compact(m[3]) << 12);
+}
+// lane-wise x == K (K broadcast): top bit of each byte
+__device__ __forceinline__ u32 swar_eq(u32 x, u32 kb) {
+    const u32 y = x ^ kb;
+    const u32 z = ((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y;       // top bit set iff byte != 0
+    return ~z & 0x80808080u;
+}
+
+__global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
+    __shared__ u32 s_all[FW_SLOTS];          // C | G<<8 | T<<16 | n<<24 over both samples
+    __shared__ u32 s_s1[FW_SLOTS];           // the same for sample 1
+    __shared__ u32 s_se[FW_SLOTS];           // start offset | end offset << 12 | SE_ENDED | SE_KR
+    __shared__ u32 s_wtot[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int64_t n_prov = (int64_t)a.n_prov;
+    const uint8_t* lcpb = a.lcp;
+    const uint8_t* bwtb = a.bwt;
+
+    for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;       // local index of the window's first entry
+        const int64_t i0 = win_lo + (int64_t)tid * 16;
+        // ---- loads: lcp row + edge words, bwt row, da in coalesced order ----
+        u32 W[6], B[4];
+        if (i0 >= 4 && i0 + 20 <= n_prov) {
+            const uint4 v = *(const uint4*)(lcpb + i0);
+            W[1] = v.x; W[2] = v.y; W[3] = v.z; W[4] = v.w;
+            W[0] = *(const u32*)(lcpb + i0 - 4);
+            W[5] = *(const u32*)(lcpb + i0 + 16);
+            const uint4 b = *(const uint4*)(bwtb + i0);
+            B[0] = b.x; B[1] = b.y; B[2] = b.z; B[3] = b.w;
+        } else {
+#pragma unroll
+            for (int w = 0; w < 6; ++w) {
+                u32 v = 0, vb = 0;
+#pragma unroll
+                for (int bt = 0; bt < 4; ++bt) {
+                    const int64_t e = i0 + (int64_t)(w - 1) * 4 + bt;
+                    if (e >= 0 && e < n_prov) { v |= (u32)lcpb[e] << (8 * bt); vb |= (u32)bwtb[e] << (8 * bt); }
+                }
+                W[w] = v;
+                if (w >= 1 && w <= 4) B[w - 1] = vb;
+            }
+        }
+        // sample bit of every entry: lane i of load q holds entries wave*1024 + q*256 + 4i .. +3
+        u32 snib = 0;
+        {
+            const int64_t wbase = win_lo + (int64_t)wave * 1024;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t e = wbase + q * 256 + (int64_t)lane * 4;
+                u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                if (e >= 0 && e + 4 <= n_prov) {
+                    const uint4 v = *(const uint4*)(a.da + e);
+                    t0 = v.x; t1 = v.y; t2 = v.z; t3 = v.w;
+                } else {
+                    if (e + 0 >= 0 && e + 0 < n_prov) t0 = a.da[e + 0];
+                    if (e + 1 >= 0 && e + 1 < n_prov) t1 = a.da[e + 1];
+                    if (e + 2 >= 0 && e + 2 < n_prov) t2 = a.da[e + 2];
+                    if (e + 3 >= 0 && e + 3 < n_prov) t3 = a.da[e + 3];
+                }
+                // sample = !(text < nr_reads1), uint32 text against uint64 nr_reads1 (clust2snp.cpp:390)
+                const u32 nib = ((u64)t0 >= a.nr_reads1 ? 1u : 0u) | ((u64)t1 >= a.nr_reads1 ? 2u : 0u) |
+                                ((u64)t2 >= a.nr_reads1 ? 4u : 0u) | ((u64)t3 >= a.nr_reads1 ? 8u : 0u);
+                snib |= nib << (4 * q);
+            }
+        }
+        // owner lane L = 16q + j gathers nibble q of lanes 4j .. 4j+3
+        u32 S1;
+        {
+            const int q4 = (int)(lane >> 4) * 4, j4 = (int)(lane & 15u) * 4;
+            const u32 x0 = (u32)__shfl((int)snib, j4 + 0), x1 = (u32)__shfl((int)snib, j4 + 1);
+            const u32 x2 = (u32)__shfl((int)snib, j4 + 2), x3 = (u32)__shfl((int)snib, j4 + 3);
+            S1 = ((x0 >> q4) & 15u) | (((x1 >> q4) & 15u) << 4) | (((x2 >> q4) & 15u) << 8) | (((x3 >> q4) & 15u) << 12);
+        }
+        // ---- cluster boundaries (same stencil as the scan) ----
+        RowFlags F;
+        row_flags<1>(W, a.kb, a.hge, F);
+        if (a.prov_is_global0 && i0 == 0) patch_global0<1>(W, a.k_u32, a.hge, F);
+        const u32 END = compact16(F.end), ST = compact16(F.start);
+        const bool in0 = (a.hge != 0) && ((W[1] & 0xFFu) >= a.k_u32) && !(ST & 1u);
+        // ---- per-entry classes, compact 16-bit masks ----
+        u32 mC[4], mG[4], mT[4], mK[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 x = B[w] & 0xDFDFDFDFu;                       // fold case (include.hpp:269-272)
+            mC[w] = swar_eq(x, 0x43434343u);
+            mG[w] = swar_eq(x, 0x47474747u);
+            mT[w] = swar_eq(x, 0x54545454u);
+            const u32 xh = W[w + 1] | 0x80808080u;
+            mK[w] = bfi(W[w + 1] ^ a.krb, W[w + 1], xh - (a.krb & 0x7f7f7f7fu)) & a.kr_hge;    // lcp >= k_right
+        }
+        const u32 isC = compact16(mC), isG = compact16(mG), isT = compact16(mT), KR = compact16(mK);
+
+        // ---- slot numbering: exclusive count of cluster starts before this thread-row ----
+        const u32 nst = (u32)__popc(ST);
+        const u32 inc = wave_incl_scan(nst);
+        if (lane == 63) s_wtot[wave] = inc;
+        __syncthreads();                                             // also: previous window fully evaluated
+        u32 sbase = inc - nst, nslots = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const u32 v = s_wtot[w]; if (w < (int)wave) sbase += v; nslots += v; }
+        const bool dense = nslots > FW_SLOTS;
+        if (dense) { if (tid == 0) atomicOr(a.err, E2S_DEVERR_DENSE); nslots = FW_SLOTS; }
+        for (u32 s2 = tid; s2 < nslots; s2 += 256) { s_all[s2] = 0; s_s1[s2] = 0; s_se[s2] = 0; }
+        __syncthreads();
+
+        // ---- walk the events of the thread-row, flush each piece of a cluster into its slot ----
+        {
+            int slot = (int)sbase - 1;                                // cluster open at the row's first entry (-1: began before the window)
+            bool in = in0;
+            int lo = 0;
+            const u32 row_off = tid * 16;
+            auto flush = [&](int hi, bool ended) {
+                if (slot < 0 || slot >= FW_SLOTS) return;
+                const u32 rm = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+                const u32 r1 = rm & S1;
+                const u32 all = (u32)__popc(isC & rm) | ((u32)__popc(isG & rm) << 8) | ((u32)__popc(isT & rm) << 16) | ((u32)__popc(rm) << 24);
+                const u32 s1v = (u32)__popc(isC & r1) | ((u32)__popc(isG & r1) << 8) | ((u32)__popc(isT & r1) << 16) | ((u32)__popc(r1) << 24);
+                atomicAdd(&s_all[slot], all);
+                atomicAdd(&s_s1[slot], s1v);
+                u32 se = (KR & rm) ? SE_KR : 0u;
+                if (ended) se |= SE_ENDED | ((row_off + (u32)hi) << 12);
+                if (se) atomicOr(&s_se[slot], se);
+            };
+            u32 ev = END | ST;
+            while (ev) {
+                const int b = __ffs(ev) - 1;
+                ev &= ev - 1;
+                if ((ST >> b) & 1u) {                                 // a start precedes an end at the same position
+                    ++slot; lo = b; in = true;
+                    if (slot < FW_SLOTS) atomicOr(&s_se[slot], row_off + (u32)b);
+                }
+                if ((END >> b) & 1u) { flush(b, true); in = false; }
+            }
+            if (in) flush(15, false);                                 // the cluster continues in the next thread-row
+        }
+        __syncthreads();
+
+        // ---- evaluate the clusters that END in the new part of the window ----
+        const int64_t new_lo = (int64_t)tile * FW_NEW;
+        const int64_t e_lo = max(new_lo, (int64_t)a.own_lo), e_hi = min(new_lo + FW_NEW, (int64_t)a.end_hi);
+        for (u32 s2 = tid; s2 < nslots; s2 += 256) {
+            const u32 se = s_se[s2];
+            if (!(se & SE_ENDED) || !(se & SE_KR)) continue;          // no end here, or max LCP < k_right (:396)
+            const int so = (int)(se & 0xFFFu), eo = (int)((se >> 12) & 0xFFFu);
+            const int64_t epos = win_lo + eo;
+            if (epos < e_lo || epos >= e_hi) continue;
+            const int len = eo - so + 1;
+            if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 + append_entry's filter
+            const u32 all = s_all[s2], s1v = s_s1[s2];
+            const u32 c1C = s1v & 0xFFu, c1G = (s1v >> 8) & 0xFFu, c1T = (s1v >> 16) & 0xFFu, n1 = s1v >> 24;
+            const u32 c0C = (all & 0xFFu) - c1C, c0G = ((all >> 8) & 0xFFu) - c1G, c0T = ((all >> 16) & 0xFFu) - c1T, n0 = (all >> 24) - n1;
+            const u32 c0A = n0 - c0C - c0G - c0T, c1A = n1 - c1C - c1G - c1T;
+            u32 f0 = 0, f1 = 0;
+            if (c0A >= a.mcov_u) f0 |= 1u; if (c0C >= a.mcov_u) f0 |= 2u; if (c0G >= a.mcov_u) f0 |= 4u; if (c0T >= a.mcov_u) f0 |= 8u;
+            if (c1A >= a.mcov_u) f1 |= 1u; if (c1C >= a.mcov_u) f1 |= 2u; if (c1G >= a.mcov_u) f1 |= 4u; if (c1T >= a.mcov_u) f1 |= 8u;
+            if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) continue;   // :419-429
+            const u64 idx = atomicAdd(a.fl_count, 1ull);
+            if (idx < a.fl_cap) { a.fl_starts[idx] = a.prov_lo + (u64)(win_lo + so); a.fl_lens[idx] = (uint16_t)len; }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // K2: per-cluster pass.  One wave per cluster record, lane i <-> entry start+i (clusters are
 // at most 150 entries: three 64-entry chunks).  find_variants, clust2snp.cpp:367-500.
 // ----------------------------------------------------------------------------------------------
@@ -420,10 +614,10 @@ template <bool DEF>                                // DEF: widths (x,y,z) = (1,4
 __global__ __launch_bounds__(CAND_WAVES * 64) void k_candidates(CandArgs a) {
     const u32 lane = threadIdx.x & 63u;
     const u64 gw = ((u64)blockIdx.x * CAND_WAVES) + (threadIdx.x >> 6);
-    const u64 r0 = gw * a.rec_per_wave;
-    for (u32 q = 0; q < a.rec_per_wave; ++q) {
-        const u64 r = r0 + q;
-        if (r >= a.n_rec) return;
+    const u64 n_waves = (u64)gridDim.x * CAND_WAVES;
+    const u64 n_rec = a.n_rec_dev ? min((u64)*a.n_rec_dev, a.n_rec) : a.n_rec;
+    // consecutive records to consecutive waves of a block: neighbouring clusters share cache lines
+    for (u64 r = gw; r < n_rec; r += n_waves) {
         const int len = (int)a.lens[r];
         if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 (+ append_entry's filter)
         const u64 s = a.starts[r];
@@ -514,7 +708,7 @@ __global__ __launch_bounds__(CAND_WAVES * 64) void k_candidates(CandArgs a) {
                         uint8_t* rec = a.cand_buf + slot * a.stride;
                         if (lane == 0) {
                             CandHeader* h = (CandHeader*)rec;
-                            h->record_index = a.record_index_base + r;
+                            h->record_index = a.key_is_start ? s : a.record_index_base + r;
                             h->pair_index = pair; h->n0 = e0; h->n1 = e1;
                             h->right_idx = best_text; h->right_pos = best_suff; h->reserved = 0;
                         }
@@ -587,8 +781,10 @@ void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st) {
 void e2s_launch_tile_scan(const u32* cnt, u64* prefix, u64 n, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, n);
 }
-void e2s_launch_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* starts, uint16_t* lens, u64 cap, const u32* flags, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_fix, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, tile_fix, starts, lens, cap, flags);
+void e2s_launch_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* tile_fix_end, const u64* starts, uint16_t* lens, u64 cap,
+                         const u32* flags, u64* wrap_list, u32* wrap_count, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_fix, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, tile_fix, tile_fix_end, starts, lens, cap,
+                       flags, wrap_list, wrap_count);
 }
 void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st) {
     hipLaunchKernelGGL(k_shard_flags, dim3(1), dim3(64), 0, st, a, (u32)xb);
@@ -600,11 +796,16 @@ void e2s_launch_hist(const uint16_t* lens, u64 n, int min_len, u64* out, hipStre
     hipLaunchKernelGGL(k_hist, dim3((unsigned)blocks), dim3(256), 0, st, lens, n, min_len, out);
 }
 void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st) {
-    const u64 waves = (a.n_rec + a.rec_per_wave - 1) / a.rec_per_wave;
-    const u64 blocks = (waves + CAND_WAVES - 1) / CAND_WAVES;
+    u64 blocks = (a.n_rec + CAND_WAVES - 1) / CAND_WAVES;
+    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;              // grid-stride beyond that
     if (blocks == 0) return;
     if (def_widths) hipLaunchKernelGGL((k_candidates<true>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
     else hipLaunchKernelGGL((k_candidates<false>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
+}
+void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st) {
+    u64 blocks = a.n_tiles < 1280 ? a.n_tiles : 1280;            // persistent: 256 CUs x 5 blocks
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_cluster_filter, dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 void e2s_launch_unpack_pairsa(const uint8_t* src, u64 n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st) {
     if (!n) return;

@@ -286,3 +286,123 @@ def test_drop_in_executables(tmp_path):
     assert r.returncode == 0 and "clust2snp [options]" in r.stdout
     r = subprocess.run([e2c, "-i", str(tmp_path / "nonexistent.fa")], capture_output=True, text=True)
     assert r.returncode == 1 and "Error: missing index files." in r.stdout
+
+
+def _fused_candidates(h, en, n1, k=16, m=2, mcov=5, L=31, R=30, c=20, p=0.99, xyz=(1, 4, 1)):
+    """scan -> stitch -> hist -> candidates on one handle (records stay on the device: streaming pass)"""
+    x, y, z = xyz
+    n = en["lcp"].size
+    d = capi.Handle.desc(n, x=x, y=y, z=z)
+    psa = np.zeros(n, dtype=np.dtype([("s", IO._DT[z]), ("t", IO._DT[y])]))
+    psa["s"] = en["suff"]
+    psa["t"] = en["text"]
+    h.upload_bcr(d, en["bwt"], en["lcp"].astype(IO._DT[x]).view(np.uint8), psa.view(np.uint8))
+    h.scan_single(k, m, 0)
+    mcl, _, _ = capi.auto_max_clust_length([h.hist()], mcov, p)
+    prm = capi.C2SParams(n1 & ((1 << 64) - 1), L, R, mcov, c, mcl, m)
+    h.find_candidates(prm)
+    buf, nc, cap, stride = h.fetch_candidates(prm)
+    return capi.parse_candidates(buf, nc, cap, stride), mcl
+
+
+def _oracle_candidates(tmp_path, reads, en, n1, k=0, m=0, mcov=0, L=0, R=0, c=0, p=0.0, xyz=(1, 4, 1), tag="o"):
+    x, y, z = xyz
+    q = str(tmp_path / (tag + ".fasta"))
+    IO.write_fasta(q, reads)
+    IO.write_bcr(q, en["text"], en["suff"], en["lcp"], en["bwt"], x, y, z)
+    assert O.ebwt2clust(q, k, m, x, y, z)[0] == 0
+    rc, oc, omcl = O.candidates(q, O.c2s_opts(n1, L=L, R=R, c=c, m=mcov, p=p, x=x, y=y, z=z))
+    assert rc in (0, 5)
+    return oc, omcl
+
+
+@pytest.mark.parametrize("case", [
+    dict(seed=51, R=3000, L=100),
+    dict(seed=52, R=1200, L=150, k=20, m=4),
+    dict(seed=53, R=2000, L=100, mcov=3, Lc=25, Rc=20, c=6, p=0.9),
+    dict(seed=54, R=2000, L=100, tail=False),
+    dict(seed=55, R=1500, L=100, xyz=(1, 4, 2)),
+    dict(seed=56, R=1500, L=100, xyz=(2, 4, 1)),      # wide LCP: record-driven pass
+    dict(seed=57, R=1500, L=100, n1_shift=-700),     # different sample split
+], ids=lambda c: "seed%d" % c["seed"])
+def test_fused_streaming_candidates_equal_oracle(H, tmp_path, case):
+    reads, n1, e = synth.synth_case(case["R"], case["L"], seed=case["seed"], tail_lcp0=case.get("tail", True))
+    xyz = case.get("xyz", (1, 4, 1))
+    en = synth.egsa_to_numpy(e, *xyz)
+    n1 = n1 + case.get("n1_shift", 0)
+    kw = dict(k=case.get("k", 0), m=case.get("m", 0), mcov=case.get("mcov", 0), L=case.get("Lc", 0), R=case.get("Rc", 0),
+              c=case.get("c", 0), p=case.get("p", 0.0))
+    oc, omcl = _oracle_candidates(tmp_path, reads.numpy(), en, n1, xyz=xyz, **kw)
+    got, mcl = _fused_candidates(H, en, n1, k=kw["k"] or 16, m=kw["m"] or 2, mcov=kw["mcov"] or 5, L=kw["L"] or 31,
+                                 R=kw["R"] or 30, c=kw["c"] or 20, p=kw["p"] or 0.99, xyz=xyz)
+    assert mcl == omcl and len(got) == len(oc) and len(oc) > 0
+    for a, b in zip(got, oc):
+        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+            assert a[key] == b[key]
+
+
+def test_fused_streaming_adversarial(H, tmp_path):
+    """hand-built EGSA columns: a candidate cluster whose u16 length wrapped (true length 65536+24), clusters
+    straddling the 3936-entry window seams, a dense stretch (> 2048 clusters per window: fallback), lower-case
+    and '$' BWT symbols, clusters of exactly 2*mcov and max length"""
+    rnd = np.random.RandomState(9)
+    n = 400000
+    lcp = np.zeros(n, dtype=np.uint8)
+    bwt = rnd.choice([65, 67, 71, 84, 36, 99, 116], n).astype(np.uint8)
+    text = rnd.randint(0, 2000, n).astype(np.uint32)
+    suff = rnd.randint(0, 100, n).astype(np.uint8)
+    pos = 10
+
+    def cluster(length, lv=40, alleles=(67, 71)):
+        nonlocal pos
+        s = pos
+        lcp[s:s + length] = lv
+        lcp[s] = 0 if s else lcp[s]
+        half = length // 2
+        bwt[s:s + half] = alleles[0]
+        bwt[s + half:s + length] = alleles[1]
+        text[s:s + half] = rnd.randint(0, 1000, half)
+        text[s + half:s + length] = rnd.randint(1000, 2000, length - half)
+        suff[s:s + length] = rnd.randint(31, 100, length)
+        pos = s + length + 3
+        return s
+    # ordinary candidate clusters placed across window seams (multiples of 3936) and tile seams (16384)
+    for seam in (3936, 2 * 3936, 16384, 5 * 3936, 32768, 49152):
+        pos = seam - 17
+        cluster(30)
+    pos = 60000
+    for length in (10, 11, 150, 151, 9):
+        cluster(length)
+    # a long run: one cluster of 65536+24 entries (no local minimum, flat LCP): the reference sees length 24
+    pos = 70000
+    s_long = pos
+    cluster(65536 + 24, lv=50)
+    # first 24 entries of it form a candidate
+    bwt[s_long + 1:s_long + 13] = 67; text[s_long + 1:s_long + 13] = rnd.randint(0, 1000, 12)
+    bwt[s_long + 13:s_long + 25] = 71; text[s_long + 13:s_long + 25] = rnd.randint(1000, 2000, 12)
+    suff[s_long:s_long + 25] = 60
+    # dense stretch: cluster of length 2 every 3 entries -> > 2048 clusters per 4096-entry window
+    pos = 200000
+    base = np.arange(200000, 230000)
+    lcp[base] = np.where(base % 3 == 0, 0, 20)
+    pos = 240000
+    for _ in range(200):
+        cluster(int(rnd.randint(10, 151)))
+    lcp[-1] = 0
+    en = dict(text=text, suff=suff, lcp=lcp, bwt=bwt)
+    reads = np.full((2000, 100), 65, dtype=np.uint8)
+    oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000)
+    got, mcl = _fused_candidates(H, en, 1000)
+    assert mcl == omcl and len(oc) > 150
+    assert len(got) == len(oc)
+    for a, b in zip(got, oc):
+        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+            assert a[key] == b[key]
+    # the same without the dense stretch: stays on the streaming pass
+    lcp[200000:230000] = 0
+    oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000, tag="o2")
+    got, mcl = _fused_candidates(H, en, 1000)
+    assert mcl == omcl and len(got) == len(oc) > 150
+    for a, b in zip(got, oc):
+        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+            assert a[key] == b[key]
