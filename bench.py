@@ -80,8 +80,19 @@ def shard_arrays(blk, m, rank, world):
     return out, g0, n_own, hl, hr
 
 
+PHASES = {}
+
+
+def _tick(name, t0):
+    t1 = time.perf_counter()
+    PHASES[name] = PHASES.get(name, 0.0) + (t1 - t0)
+    return t1
+
+
 def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2):
+    t = time.perf_counter()
     h.cluster_scan(k, min_len, 0)
+    t = _tick("scan", t)
     b = h.boundary()
     if world > 1:
         t = torch.frombuffer(bytearray(bytes(b)), dtype=torch.uint8).to(dev)
@@ -93,7 +104,9 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2):
     else:
         allb = [b]
     h.stitch(allb, rank)
+    t = _tick("stitch", t)
     hs = h.hist()
+    t = _tick("hist", t)
     if world > 1:
         t = torch.frombuffer(bytearray(bytes(hs)), dtype=torch.uint8).to(dev)
         allt = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
@@ -105,8 +118,11 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2):
         hists = [hs]
     mcl, n_clust, _ = capi.auto_max_clust_length(hists, prm_base["m"], 0.99)
     prm = capi.C2SParams(prm_base["n1"], 31, 30, prm_base["m"], 20, mcl, min_len)
+    t = _tick("stats", t)
     ncand = h.find_candidates(prm, rank << 40)
+    t = _tick("candidates", t)
     buf, ncand, cap, stride = h.fetch_candidates(prm)
+    t = _tick("fetch", t)
     return dict(n_ends=b.n_ends, n_cand=ncand, mcl=mcl, n_clust=n_clust)
 
 
@@ -202,6 +218,7 @@ def main():
         info = run_step(h, prm_base, world, rank, dist, dev)
     scan_ms, cand_ms, scan_all_ms, hist_ms = [], [], [], []
     barrier()
+    PHASES.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         info = run_step(h, prm_base, world, rank, dist, dev)
@@ -238,7 +255,8 @@ def main():
             "config": {"workload": "%s: 2x%d reads x %dbp synthetic EGSA per GPU, %d entries/GPU, BCR widths 1/4/1"
                                    % (a.workload, R, L, m), "entries_total": n_total, "k": 16, "min_len": 2,
                        "parallelism": "sa-range x%d" % world, "cluster_records": tot_ends, "candidates": tot_cand,
-                       "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2)},
+                       "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2),
+                       "host_phase_ms": {k2: round(v / a.steps * 1e3, 4) for k2, v in PHASES.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_candidates", "achieved": cand_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": cand_gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": cand_avg_ms, "algorithmic_bytes": cand_bytes},
             "roofline_scan": {"bound": "hbm", "kernel": "k_scan", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

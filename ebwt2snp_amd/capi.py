@@ -136,6 +136,7 @@ class Handle:
         if rc:
             raise E2SError(rc, self.L.e2s_last_error(None).decode())
         self._keep = []
+        self._cbuf = None
 
     def close(self):
         if self.h:
@@ -217,9 +218,11 @@ class Handle:
         self._ck(self.L.e2s_candidate_stride(self.h, C.byref(params), C.byref(cap), C.byref(stride)))
         n = C.c_uint64(0)
         self._ck(self.L.e2s_fetch_candidates(self.h, None, 0, C.byref(n)))
-        buf = np.zeros(max(n.value, 1) * stride.value, dtype=np.uint8)
-        self._ck(self.L.e2s_fetch_candidates(self.h, _ptr(buf), n.value, C.byref(n)))
-        return buf[:n.value * stride.value], n.value, cap.value, stride.value
+        need = max(n.value, 1) * stride.value
+        if self._cbuf is None or self._cbuf.size < need:
+            self._cbuf = np.empty(need + need // 4, dtype=np.uint8)
+        self._ck(self.L.e2s_fetch_candidates(self.h, _ptr(self._cbuf), n.value, C.byref(n)))
+        return self._cbuf[:n.value * stride.value], n.value, cap.value, stride.value
 
     def timing(self):
         t = Timing()

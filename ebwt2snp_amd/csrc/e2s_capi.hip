@@ -48,6 +48,7 @@ struct e2s_ctx {
     // candidates
     uint8_t* d_cand = nullptr; uint64_t cand_cap = 0, cand_bytes = 0; uint32_t cand_stride = 0, list_cap = 0; uint64_t n_cand = 0;
     bool tail_bwt_given = false; uint8_t tail_bwt_arg = 0;
+    uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging for candidate download
     // timing
     hipEvent_t ev[8] = {};
     e2s_timing tm{};
@@ -113,6 +114,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipFree(h->d_starts); hipFree(h->d_lens); hipFree(h->d_tile_state); hipFree(h->d_tile_fix);
     hipFree(h->d_tile_count); hipFree(h->d_tile_prefix); hipFree(h->d_scalars); hipFree(h->d_words); hipFree(h->d_cand);
     hipFree(h->d_tile_fix_end); hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
+    if (h->pin_cand) hipHostFree(h->pin_cand);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(h->stream);
     delete h;
@@ -733,10 +735,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap;
         CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
         CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
-        uint64_t flagged = 0;
         if (streaming) {
-            int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096));
-            if (rc) return rc;
             // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
             std::vector<uint64_t> seed_r;
             for (uint64_t r = h->n_ends; r < h->n_rec; ++r) seed_r.push_back(r);
@@ -750,11 +749,6 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); }
             }
             const uint64_t nseed = ss.size();
-            if (nseed) {
-                CK(hipMemcpyAsync(h->d_fl_starts, ss.data(), nseed * 8, hipMemcpyHostToDevice, h->stream));
-                CK(hipMemcpyAsync(h->d_fl_lens, sl.data(), nseed * 2, hipMemcpyHostToDevice, h->stream));
-            }
-            CK(hipMemcpyAsync(h->d_scalars + 2, &nseed, 8, hipMemcpyHostToDevice, h->stream));
             FilterArgs f{};
             f.bwt = h->bwt; f.lcp = (const uint8_t*)h->lcp; f.da = (const uint32_t*)h->da;
             f.n_prov = h->n_prov; f.prov_lo = h->prov_lo; f.prov_is_global0 = h->prov_lo == 0;
@@ -770,19 +764,24 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             f.krb = (uint32_t)(a.k_right_u & 0xFF) * 0x01010101u;
             f.nr_reads1 = a.nr_reads1; f.mcov_u = a.mcov_u; f.len_lo = a.len_lo; f.len_hi = a.len_hi;
             f.n_tiles = (h->n_prov + 3935) / 3936;
-            f.fl_starts = h->d_fl_starts; f.fl_lens = h->d_fl_lens; f.fl_cap = h->fl_cap;
-            f.fl_count = (unsigned long long*)(h->d_scalars + 2);
             f.err = h->d_words + 1;
-            CK(hipEventRecord(h->ev[6], h->stream));
-            e2s_launch_cluster_filter(f, h->stream);
-            CK(hipEventRecord(h->ev[4], h->stream));
-            a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap;
-            a.n_rec_dev = (const unsigned long long*)(h->d_scalars + 2);
             a.key_is_start = 1;
-            e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
+            f.c = a;
+            CK(hipEventRecord(h->ev[6], h->stream));
+            e2s_launch_cluster_filter(f, d.pos_bytes == 1, h->stream);
+            CK(hipEventRecord(h->ev[4], h->stream));
+            if (nseed) {
+                int rc = ensure_flagged(h, nseed + 8);
+                if (rc) return rc;
+                CK(hipMemcpyAsync(h->d_fl_starts, ss.data(), nseed * 8, hipMemcpyHostToDevice, h->stream));
+                CK(hipMemcpyAsync(h->d_fl_lens, sl.data(), nseed * 2, hipMemcpyHostToDevice, h->stream));
+                a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = nseed;
+                e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
+                CK(hipStreamSynchronize(h->stream));              // ss/sl are stack-owned
+            }
             CK(hipEventRecord(h->ev[7], h->stream));
         } else {
-            a.starts = h->d_starts; a.lens = h->d_lens; a.n_rec = h->n_rec; a.n_rec_dev = nullptr; a.key_is_start = 0;
+            a.starts = h->d_starts; a.lens = h->d_lens; a.n_rec = h->n_rec; a.key_is_start = 0;
             CK(hipEventRecord(h->ev[6], h->stream));
             if (h->n_rec) e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
             CK(hipEventRecord(h->ev[4], h->stream));
@@ -790,17 +789,11 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         }
         uint32_t err = 0;
         CK(hipMemcpyAsync(&count, h->d_scalars + 1, 8, hipMemcpyDeviceToHost, h->stream));
-        CK(hipMemcpyAsync(&flagged, h->d_scalars + 2, 8, hipMemcpyDeviceToHost, h->stream));
         CK(hipMemcpyAsync(&err, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
         if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
-        if (streaming && flagged > h->fl_cap) {
-            int rc = ensure_flagged(h, flagged + 4096);
-            if (rc) return rc;
-            continue;
-        }
         if (count <= h->cand_cap) { done = true; break; }
         want = count + 1024;
     }
@@ -814,6 +807,25 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     return E2S_OK;
 }
 
+// ascending order of 64-bit keys: LSD radix, 11-bit digits (a few tens of thousands of candidates)
+static void radix_order(const std::vector<uint64_t>& key, std::vector<uint32_t>& order) {
+    const size_t n = key.size();
+    order.resize(n);
+    std::vector<uint32_t> tmp(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    uint64_t mx = 0;
+    for (uint64_t k : key) mx |= k;
+    uint32_t cnt[2048];
+    for (int shift = 0; shift < 64 && (mx >> shift) != 0; shift += 11) {
+        memset(cnt, 0, sizeof(cnt));
+        for (size_t i = 0; i < n; ++i) cnt[(key[order[i]] >> shift) & 2047]++;
+        uint32_t run = 0;
+        for (int d = 0; d < 2048; ++d) { const uint32_t c = cnt[d]; cnt[d] = run; run += c; }
+        for (size_t i = 0; i < n; ++i) tmp[cnt[(key[order[i]] >> shift) & 2047]++] = order[i];
+        order.swap(tmp);
+    }
+}
+
 extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand) {
     if (!h || !n_cand) return E2S_ERR_ARG;
     CK(hipSetDevice(h->device));
@@ -822,19 +834,38 @@ extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, 
     if (cap_cand < h->n_cand) return fail(h, E2S_ERR_CAPACITY, "candidate output too small");
     if (!h->n_cand) return E2S_OK;
     const size_t st = h->cand_stride;
-    std::vector<uint8_t> raw((size_t)h->n_cand * st);
-    CK(hipMemcpy(raw.data(), h->d_cand, raw.size(), hipMemcpyDeviceToHost));
-    // slots were claimed with an atomic counter: restore SA order (record, then (c0,c1) loop order)
-    std::vector<uint64_t> order(h->n_cand);
-    for (uint64_t i = 0; i < h->n_cand; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
-        const e2s_cand_header* a = (const e2s_cand_header*)(raw.data() + x * st);
-        const e2s_cand_header* b = (const e2s_cand_header*)(raw.data() + y * st);
-        if (a->record_index != b->record_index) return a->record_index < b->record_index;
-        return a->pair_index < b->pair_index;
-    });
+    const size_t bytes = (size_t)h->n_cand * st;
+    if (bytes > h->pin_cand_bytes) {                                // pinned staging: the copy runs at link rate
+        if (h->pin_cand) hipHostFree(h->pin_cand);
+        h->pin_cand = nullptr; h->pin_cand_bytes = 0;
+        CK(hipHostMalloc((void**)&h->pin_cand, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        h->pin_cand_bytes = bytes + bytes / 4 + 4096;
+    }
+    CK(hipMemcpyAsync(h->pin_cand, h->d_cand, bytes, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    // slots were claimed with atomic counters: restore SA order (cluster, then the (c0,c1) loop order)
+    const uint8_t* raw = h->pin_cand;
+    std::vector<uint64_t> key(h->n_cand);
+    bool small = true;
+    for (uint64_t i = 0; i < h->n_cand; ++i) {
+        const e2s_cand_header* c = (const e2s_cand_header*)(raw + i * st);
+        if (c->record_index >> 61) small = false;
+        key[i] = (c->record_index << 2) | (c->pair_index & 3u);
+    }
+    std::vector<uint32_t> order;
+    if (small) radix_order(key, order);
+    else {
+        order.resize(h->n_cand);
+        for (uint64_t i = 0; i < h->n_cand; ++i) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const e2s_cand_header* a = (const e2s_cand_header*)(raw + (size_t)x * st);
+            const e2s_cand_header* b = (const e2s_cand_header*)(raw + (size_t)y * st);
+            if (a->record_index != b->record_index) return a->record_index < b->record_index;
+            return a->pair_index < b->pair_index;
+        });
+    }
     uint8_t* o = (uint8_t*)out;
-    for (uint64_t i = 0; i < h->n_cand; ++i) memcpy(o + i * st, raw.data() + order[i] * st, st);
+    for (uint64_t i = 0; i < h->n_cand; ++i) memcpy(o + i * st, raw + (size_t)order[i] * st, st);
     return E2S_OK;
 }
 

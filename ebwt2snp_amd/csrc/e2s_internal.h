@@ -63,7 +63,6 @@ struct CandArgs {
     uint64_t prov_lo, prov_hi, n_total;
     uint32_t ph_text, ph_suff, ph_lcp, ph_bwt;      // the EOF phantom entry (global index n_total)
     const uint64_t* starts; const uint16_t* lens; uint64_t n_rec;
-    const unsigned long long* n_rec_dev;            // if set: the record count lives on the device (flagged list)
     uint32_t key_is_start;                          // order key of a candidate = its cluster's start position
     uint32_t rec_per_wave;
     uint64_t nr_reads1, k_left_u, k_right_u;
@@ -76,6 +75,7 @@ struct CandArgs {
     uint32_t* err;
 };
 
+
 struct FilterArgs {
     const uint8_t* bwt; const uint8_t* lcp; const uint32_t* da;     // first provided entry, 16-byte aligned
     uint64_t n_prov, prov_lo;
@@ -87,13 +87,12 @@ struct FilterArgs {
     uint32_t mcov_u;
     int len_lo, len_hi;
     uint64_t n_tiles;
-    uint64_t* fl_starts; uint16_t* fl_lens; uint64_t fl_cap;
-    unsigned long long* fl_count;
     uint32_t* err;
+    CandArgs c;                                                     // list extraction for the clusters that pass
 };
 
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
-void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
+void e2s_launch_cluster_filter(const FilterArgs& a, bool def_pos, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);
 #define E2S_WRAP_CAP 1024
 void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* tile_fix_end,

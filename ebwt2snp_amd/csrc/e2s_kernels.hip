@@ -411,6 +411,153 @@ __global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int m
 }
 
 // ----------------------------------------------------------------------------------------------
+// K2: per-cluster pass.  One wave per cluster record, lane i <-> entry start+i (clusters are
+// at most 150 entries: three 64-entry chunks).  find_variants, clust2snp.cpp:367-500.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 load_w(const void* p, int w, int64_t i) {
+    return w == 1 ? (u32)((const uint8_t*)p)[i] : w == 2 ? (u32)((const uint16_t*)p)[i] : ((const u32*)p)[i];
+}
+
+// include.hpp:265-279 (N/n: the reference draws rand()%4; we map to 0 deterministically, see DESIGN.md)
+__device__ __forceinline__ u32 base_to_int(u32 c) {
+    c &= ~0x20u;                                   // fold case: 'a'..'t' -> 'A'..'T'
+    return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+}
+
+constexpr int CAND_WAVES = 4;
+constexpr int MAXCH = 3;                           // ceil(150/64)
+
+// One cluster record [s, s+len) handled by one wave: lane i <-> entry s+i (three 64-entry chunks cover
+// the 150-entry maximum).  `alloc(lane)` hands out the memory of the next candidate (wave-uniform).
+template <bool DEF, typename Alloc>                // DEF: widths (x,y,z) = (1,4,1)
+__device__ __forceinline__ void cluster_record(const CandArgs& a, const u64 s, const int len, const u64 key, const u32 lane, Alloc alloc) {
+    const int nch = (len + 63) >> 6;
+    u32 text[MAXCH], suff[MAXCH], lcp[MAXCH], bwt[MAXCH];
+    bool valid[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        valid[c] = false; text[c] = suff[c] = lcp[c] = bwt[c] = 0;
+        if (c < nch) {
+            const int o = c * 64 + (int)lane;
+            valid[c] = o < len;
+            if (valid[c]) {
+                const u64 g = s + (u64)o;
+                if (g == a.n_total) { text[c] = a.ph_text; suff[c] = a.ph_suff; lcp[c] = a.ph_lcp; bwt[c] = a.ph_bwt; }
+                else {
+                    const int64_t i = (int64_t)(g - a.prov_lo);
+                    bwt[c] = a.bwt[i];
+                    if (DEF) { lcp[c] = ((const uint8_t*)a.lcp)[i]; suff[c] = ((const uint8_t*)a.pos)[i]; text[c] = ((const u32*)a.da)[i]; }
+                    else { lcp[c] = load_w(a.lcp, a.xb, i); suff[c] = load_w(a.pos, a.zb, i); text[c] = load_w(a.da, a.yb, i); }
+                }
+            }
+        }
+    }
+    // counts[sample][base] and the first entry with the strictly largest LCP (clust2snp.cpp:377-393)
+    u32 cnt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    u32 best_lcp = 0, best_text = 0, best_suff = 0;
+    u32 smp[MAXCH], bas[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        if (c < nch) {
+            smp[c] = ((u64)text[c] < a.nr_reads1) ? 0u : 1u;            // uint32 text vs uint64 nr_reads1
+            bas[c] = base_to_int(bwt[c]);
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb)
+                cnt[sb >> 2][sb & 3] += (u32)__popcll(__ballot(valid[c] && smp[c] == (u32)(sb >> 2) && bas[c] == (u32)(sb & 3)));
+            u32 m = valid[c] ? lcp[c] : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
+            if (m > best_lcp) {                                          // strictly greater: earlier chunk wins ties
+                const u64 who = __ballot(valid[c] && lcp[c] == m);
+                const int src = __ffsll((long long)who) - 1;
+                best_lcp = m;
+                best_text = (u32)__shfl((int)text[c], src);
+                best_suff = (u32)__shfl((int)suff[c], src);
+            }
+        }
+    }
+    if ((u64)best_lcp < a.k_right_u) return;                            // clust2snp.cpp:396
+    u32 f0 = 0, f1 = 0;                                                  // frequent characters, :402-407
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { if (cnt[0][b] >= a.mcov_u) f0 |= 1u << b; if (cnt[1][b] >= a.mcov_u) f1 |= 1u << b; }
+    if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) return;   // :419-429
+    u32 pair = 0;
+    for (int b0 = 0; b0 < 4; ++b0) {
+        if (!((f0 >> b0) & 1u)) continue;
+        for (int b1 = 0; b1 < 4; ++b1) {
+            if (!((f1 >> b1) & 1u) || b0 == b1) continue;
+            const u32 c0 = "ACGT"[b0], c1 = "ACGT"[b1];                  // int_to_base, raw compare ch == c (:455,466)
+            // membership and rank in SA order (:446-476)
+            u32 n0 = 0, n1 = 0, rk0[MAXCH], rk1[MAXCH];
+            bool m0[MAXCH], m1[MAXCH];
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                m0[c] = m1[c] = false; rk0[c] = rk1[c] = 0;
+                if (c < nch) {
+                    const bool okc = valid[c] && (u64)suff[c] >= a.k_left_u && (u64)lcp[c] >= a.k_right_u;
+                    m0[c] = okc && bwt[c] == c0 && smp[c] == 0;
+                    m1[c] = okc && bwt[c] == c1 && smp[c] == 1;
+                    const u64 b0m = __ballot(m0[c]), b1m = __ballot(m1[c]);
+                    const u64 lt = (1ull << lane) - 1ull;
+                    rk0[c] = n0 + (u32)__popcll(b0m & lt);
+                    rk1[c] = n1 + (u32)__popcll(b1m & lt);
+                    n0 += (u32)__popcll(b0m); n1 += (u32)__popcll(b1m);
+                }
+            }
+            const u32 e0 = min(n0, a.list_cap), e1 = min(n1, a.list_cap);  // size() < consensus_reads (:458,469)
+            if (e0 > 0 && e1 > 0) {                                        // :478
+                uint8_t* rec = alloc(lane);
+                if (rec) {
+                    if (lane == 0) {
+                        CandHeader* h = (CandHeader*)rec;
+                        h->record_index = key;
+                        h->pair_index = pair; h->n0 = e0; h->n1 = e1;
+                        h->right_idx = best_text; h->right_pos = best_suff; h->reserved = 0;
+                    }
+                    u32* l = (u32*)(rec + sizeof(CandHeader));
+#pragma unroll
+                    for (int c = 0; c < MAXCH; ++c) {
+                        if (c < nch) {
+                            if (m0[c] && rk0[c] < a.list_cap) { l[rk0[c]] = text[c]; l[a.list_cap + rk0[c]] = suff[c] - a.k_left_lo; }
+                            if (m1[c] && rk1[c] < a.list_cap) { l[2 * a.list_cap + rk1[c]] = text[c]; l[3 * a.list_cap + rk1[c]] = suff[c] - a.k_left_lo; }
+                        }
+                    }
+                }
+            }
+            ++pair;
+        }
+    }
+}
+
+struct GlobalAlloc {
+    const CandArgs& a;
+    __device__ __forceinline__ uint8_t* operator()(u32 lane) const {
+        u64 slot = 0;
+        if (lane == 0) slot = atomicAdd(a.cand_count, 1ull);
+        slot = __shfl(slot, 0);
+        return slot < a.cand_cap ? a.cand_buf + slot * a.stride : nullptr;
+    }
+};
+
+template <bool DEF>
+__global__ __launch_bounds__(CAND_WAVES * 64) void k_candidates(CandArgs a) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 gw = ((u64)blockIdx.x * CAND_WAVES) + (threadIdx.x >> 6);
+    const u64 n_waves = (u64)gridDim.x * CAND_WAVES;
+    for (u64 r = gw; r < a.n_rec; r += n_waves) {
+        const int len = (int)a.lens[r];
+        if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 (+ append_entry's filter)
+        const u64 s = a.starts[r];
+        // entries must be resident: [s, s+len) within the provided range, index n_total being the EOF phantom
+        if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull)) {
+            if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
+            continue;
+        }
+        cluster_record<DEF>(a, s, len, a.key_is_start ? s : a.record_index_base + r, lane, GlobalAlloc{a});
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // K2a: streaming per-cluster allele counts + filters (phase A of find_events/find_variants,
 // clust2snp.cpp:816,377-429).  Entry-parallel: a thread-row is 16 consecutive entries; a block walks
 // windows of 4096 entries that overlap the previous window by 160, so every cluster of <= 150
@@ -438,11 +585,48 @@ __device__ __forceinline__ u32 swar_eq(u32 x, u32 kb) {
     return ~z & 0x80808080u;
 }
 
+constexpr int FW_FLMAX = 64;                 // flagged clusters per window (more: E2S_DEVERR_DENSE -> record-driven pass)
+constexpr int FW_STAGE = 32;                 // candidates staged in LDS before one global slot reservation
+
+struct StageAlloc {
+    uint8_t* stage; u32* n; u32 stride;
+    __device__ __forceinline__ uint8_t* operator()(u32 lane) const {
+        u32 slot = 0;
+        if (lane == 0) slot = atomicAdd(n, 1u);
+        slot = (u32)__shfl((int)slot, 0);
+        return slot < FW_STAGE ? stage + (size_t)slot * stride : nullptr;
+    }
+};
+
+extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // FW_STAGE candidate records
+
+template <bool DEFPOS>
 __global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
     __shared__ u32 s_all[FW_SLOTS];          // C | G<<8 | T<<16 | n<<24 over both samples
     __shared__ u32 s_s1[FW_SLOTS];           // the same for sample 1
     __shared__ u32 s_se[FW_SLOTS];           // start offset | end offset << 12 | SE_ENDED | SE_KR
+    __shared__ u32 s_fl[FW_FLMAX];           // flagged clusters of the window: start offset | len << 16
     __shared__ u32 s_wtot[4];
+    __shared__ u32 s_nfl, s_nstage;
+    __shared__ u64 s_gbase;
+    if (threadIdx.x == 0) { s_nfl = 0; s_nstage = 0; }
+    // one global slot reservation for everything staged so far, then a cooperative copy (all threads call)
+    auto stage_flush = [&]() {
+        const u32 n = min(s_nstage, (u32)FW_STAGE);
+        if (n) {
+            if (threadIdx.x == 0) s_gbase = atomicAdd(a.c.cand_count, (unsigned long long)n);
+            __syncthreads();
+            const u64 gbase = s_gbase;
+            const u32 q = a.c.stride / 16;
+            for (u32 i = threadIdx.x; i < n * q; i += 256) {
+                const u64 slot = gbase + i / q;
+                if (slot < a.c.cand_cap) ((uint4*)(a.c.cand_buf + slot * a.c.stride))[i % q] = ((const uint4*)s_stage)[i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_nstage = 0;
+        __syncthreads();
+    };
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int64_t n_prov = (int64_t)a.n_prov;
     const uint8_t* lcpb = a.lcp;
@@ -587,145 +771,27 @@ __global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
             if (c0A >= a.mcov_u) f0 |= 1u; if (c0C >= a.mcov_u) f0 |= 2u; if (c0G >= a.mcov_u) f0 |= 4u; if (c0T >= a.mcov_u) f0 |= 8u;
             if (c1A >= a.mcov_u) f1 |= 1u; if (c1C >= a.mcov_u) f1 |= 2u; if (c1G >= a.mcov_u) f1 |= 4u; if (c1T >= a.mcov_u) f1 |= 8u;
             if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) continue;   // :419-429
-            const u64 idx = atomicAdd(a.fl_count, 1ull);
-            if (idx < a.fl_cap) { a.fl_starts[idx] = a.prov_lo + (u64)(win_lo + so); a.fl_lens[idx] = (uint16_t)len; }
+            const u32 idx = atomicAdd(&s_nfl, 1u);
+            if (idx < FW_FLMAX) s_fl[idx] = (u32)so | ((u32)len << 16);
+            else atomicOr(a.err, E2S_DEVERR_DENSE);
         }
+        __syncthreads();
+        // ---- the rare clusters that passed: lists and candidate records (clust2snp.cpp:431-496), one wave each ----
+        const u32 nfl = min(s_nfl, (u32)FW_FLMAX);
+        for (u32 base = 0; base < nfl; base += 4) {
+            if (s_nstage > FW_STAGE - 16) stage_flush();            // every round adds at most 4 x 4 candidates
+            const u32 i = base + wave;
+            if (i < nfl) {
+                const u32 v = s_fl[i];
+                const u64 gs = a.prov_lo + (u64)(win_lo + (int64_t)(v & 0xFFFFu));
+                cluster_record<DEFPOS>(a.c, gs, (int)(v >> 16), gs, lane, StageAlloc{s_stage, &s_nstage, a.c.stride});
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_nfl = 0;
     }
-}
-
-// ----------------------------------------------------------------------------------------------
-// K2: per-cluster pass.  One wave per cluster record, lane i <-> entry start+i (clusters are
-// at most 150 entries: three 64-entry chunks).  find_variants, clust2snp.cpp:367-500.
-// ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 load_w(const void* p, int w, int64_t i) {
-    return w == 1 ? (u32)((const uint8_t*)p)[i] : w == 2 ? (u32)((const uint16_t*)p)[i] : ((const u32*)p)[i];
-}
-
-// include.hpp:265-279 (N/n: the reference draws rand()%4; we map to 0 deterministically, see DESIGN.md)
-__device__ __forceinline__ u32 base_to_int(u32 c) {
-    c &= ~0x20u;                                   // fold case: 'a'..'t' -> 'A'..'T'
-    return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
-}
-
-constexpr int CAND_WAVES = 4;
-constexpr int MAXCH = 3;                           // ceil(150/64)
-
-template <bool DEF>                                // DEF: widths (x,y,z) = (1,4,1)
-__global__ __launch_bounds__(CAND_WAVES * 64) void k_candidates(CandArgs a) {
-    const u32 lane = threadIdx.x & 63u;
-    const u64 gw = ((u64)blockIdx.x * CAND_WAVES) + (threadIdx.x >> 6);
-    const u64 n_waves = (u64)gridDim.x * CAND_WAVES;
-    const u64 n_rec = a.n_rec_dev ? min((u64)*a.n_rec_dev, a.n_rec) : a.n_rec;
-    // consecutive records to consecutive waves of a block: neighbouring clusters share cache lines
-    for (u64 r = gw; r < n_rec; r += n_waves) {
-        const int len = (int)a.lens[r];
-        if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 (+ append_entry's filter)
-        const u64 s = a.starts[r];
-        // entries must be resident: [s, s+len) within the provided range, index n_total being the EOF phantom
-        if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull)) {
-            if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
-            continue;
-        }
-        const int nch = (len + 63) >> 6;
-        u32 text[MAXCH], suff[MAXCH], lcp[MAXCH], bwt[MAXCH];
-        bool valid[MAXCH];
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            valid[c] = false; text[c] = suff[c] = lcp[c] = bwt[c] = 0;
-            if (c < nch) {
-                const int o = c * 64 + (int)lane;
-                valid[c] = o < len;
-                if (valid[c]) {
-                    const u64 g = s + (u64)o;
-                    if (g == a.n_total) { text[c] = a.ph_text; suff[c] = a.ph_suff; lcp[c] = a.ph_lcp; bwt[c] = a.ph_bwt; }
-                    else {
-                        const int64_t i = (int64_t)(g - a.prov_lo);
-                        bwt[c] = a.bwt[i];
-                        if (DEF) { lcp[c] = ((const uint8_t*)a.lcp)[i]; suff[c] = ((const uint8_t*)a.pos)[i]; text[c] = ((const u32*)a.da)[i]; }
-                        else { lcp[c] = load_w(a.lcp, a.xb, i); suff[c] = load_w(a.pos, a.zb, i); text[c] = load_w(a.da, a.yb, i); }
-                    }
-                }
-            }
-        }
-        // counts[sample][base] and the first entry with the strictly largest LCP (clust2snp.cpp:377-393)
-        u32 cnt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        u32 best_lcp = 0, best_text = 0, best_suff = 0;
-        u32 smp[MAXCH], bas[MAXCH];
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            if (c < nch) {
-                smp[c] = ((u64)text[c] < a.nr_reads1) ? 0u : 1u;            // uint32 text vs uint64 nr_reads1
-                bas[c] = base_to_int(bwt[c]);
-#pragma unroll
-                for (int sb = 0; sb < 8; ++sb)
-                    cnt[sb >> 2][sb & 3] += (u32)__popcll(__ballot(valid[c] && smp[c] == (u32)(sb >> 2) && bas[c] == (u32)(sb & 3)));
-                u32 m = valid[c] ? lcp[c] : 0u;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
-                if (m > best_lcp) {                                          // strictly greater: earlier chunk wins ties
-                    const u64 who = __ballot(valid[c] && lcp[c] == m);
-                    const int src = __ffsll((long long)who) - 1;
-                    best_lcp = m;
-                    best_text = (u32)__shfl((int)text[c], src);
-                    best_suff = (u32)__shfl((int)suff[c], src);
-                }
-            }
-        }
-        if ((u64)best_lcp < a.k_right_u) continue;                          // clust2snp.cpp:396
-        u32 f0 = 0, f1 = 0;                                                  // frequent characters, :402-407
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { if (cnt[0][b] >= a.mcov_u) f0 |= 1u << b; if (cnt[1][b] >= a.mcov_u) f1 |= 1u << b; }
-        if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) continue;   // :419-429
-        u32 pair = 0;
-        for (int b0 = 0; b0 < 4; ++b0) {
-            if (!((f0 >> b0) & 1u)) continue;
-            for (int b1 = 0; b1 < 4; ++b1) {
-                if (!((f1 >> b1) & 1u) || b0 == b1) continue;
-                const u32 c0 = "ACGT"[b0], c1 = "ACGT"[b1];                  // int_to_base, raw compare ch == c (:455,466)
-                // membership and rank in SA order (:446-476)
-                u32 n0 = 0, n1 = 0, rk0[MAXCH], rk1[MAXCH];
-                bool m0[MAXCH], m1[MAXCH];
-#pragma unroll
-                for (int c = 0; c < MAXCH; ++c) {
-                    m0[c] = m1[c] = false; rk0[c] = rk1[c] = 0;
-                    if (c < nch) {
-                        const bool okc = valid[c] && (u64)suff[c] >= a.k_left_u && (u64)lcp[c] >= a.k_right_u;
-                        m0[c] = okc && bwt[c] == c0 && smp[c] == 0;
-                        m1[c] = okc && bwt[c] == c1 && smp[c] == 1;
-                        const u64 b0m = __ballot(m0[c]), b1m = __ballot(m1[c]);
-                        const u64 lt = (1ull << lane) - 1ull;
-                        rk0[c] = n0 + (u32)__popcll(b0m & lt);
-                        rk1[c] = n1 + (u32)__popcll(b1m & lt);
-                        n0 += (u32)__popcll(b0m); n1 += (u32)__popcll(b1m);
-                    }
-                }
-                const u32 e0 = min(n0, a.list_cap), e1 = min(n1, a.list_cap);  // size() < consensus_reads (:458,469)
-                if (e0 > 0 && e1 > 0) {                                        // :478
-                    u64 slot = 0;
-                    if (lane == 0) slot = atomicAdd(a.cand_count, 1ull);
-                    slot = __shfl(slot, 0);
-                    if (slot < a.cand_cap) {
-                        uint8_t* rec = a.cand_buf + slot * a.stride;
-                        if (lane == 0) {
-                            CandHeader* h = (CandHeader*)rec;
-                            h->record_index = a.key_is_start ? s : a.record_index_base + r;
-                            h->pair_index = pair; h->n0 = e0; h->n1 = e1;
-                            h->right_idx = best_text; h->right_pos = best_suff; h->reserved = 0;
-                        }
-                        u32* l = (u32*)(rec + sizeof(CandHeader));
-#pragma unroll
-                        for (int c = 0; c < MAXCH; ++c) {
-                            if (c < nch) {
-                                if (m0[c] && rk0[c] < a.list_cap) { l[rk0[c]] = text[c]; l[a.list_cap + rk0[c]] = suff[c] - a.k_left_lo; }
-                                if (m1[c] && rk1[c] < a.list_cap) { l[2 * a.list_cap + rk1[c]] = text[c]; l[3 * a.list_cap + rk1[c]] = suff[c] - a.k_left_lo; }
-                            }
-                        }
-                    }
-                }
-                ++pair;
-            }
-        }
-    }
+    __syncthreads();
+    stage_flush();
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -802,10 +868,12 @@ void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st) {
     if (def_widths) hipLaunchKernelGGL((k_candidates<true>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
     else hipLaunchKernelGGL((k_candidates<false>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
 }
-void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st) {
+void e2s_launch_cluster_filter(const FilterArgs& a, bool def_pos, hipStream_t st) {
     u64 blocks = a.n_tiles < 1280 ? a.n_tiles : 1280;            // persistent: 256 CUs x 5 blocks
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_cluster_filter, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    const size_t dyn = (size_t)FW_STAGE * a.c.stride;
+    if (def_pos) hipLaunchKernelGGL((k_cluster_filter<true>), dim3((unsigned)blocks), dim3(256), dyn, st, a);
+    else hipLaunchKernelGGL((k_cluster_filter<false>), dim3((unsigned)blocks), dim3(256), dyn, st, a);
 }
 void e2s_launch_unpack_pairsa(const uint8_t* src, u64 n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st) {
     if (!n) return;
