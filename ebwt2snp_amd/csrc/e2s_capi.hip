@@ -34,7 +34,7 @@ struct e2s_ctx {
     uint64_t* d_wrap = nullptr;                  // [E2S_WRAP_CAP] ranks of records whose true length wrapped the u16
     std::vector<uint64_t> wrap_ranks; bool wrap_overflow = false;
     uint64_t first_end_pos = E2S_NONE; bool first_wrapped = false;
-    uint64_t* d_fl_starts = nullptr; uint16_t* d_fl_lens = nullptr; uint64_t fl_cap = 0;
+    uint64_t* d_fl_starts = nullptr; uint16_t* d_fl_lens = nullptr; uint64_t fl_cap = 0; uint64_t n_flagged = 0;
     uint64_t tiles_cap = 0;
     uint64_t* d_scalars = nullptr;               // [0] total_ends  [1] cand_count  [2..] hist (153)
     uint32_t* d_words = nullptr;                 // [0] tile_counter [1] err [2,3] flags [4,5] tailv
@@ -749,6 +749,13 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); }
             }
             const uint64_t nseed = ss.size();
+            int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096 + nseed));
+            if (rc) return rc;
+            if (nseed) {
+                CK(hipMemcpy(h->d_fl_starts, ss.data(), nseed * 8, hipMemcpyHostToDevice));
+                CK(hipMemcpy(h->d_fl_lens, sl.data(), nseed * 2, hipMemcpyHostToDevice));
+            }
+            CK(hipMemcpyAsync(h->d_scalars + 2, &nseed, 8, hipMemcpyHostToDevice, h->stream));
             FilterArgs f{};
             f.bwt = h->bwt; f.lcp = (const uint8_t*)h->lcp; f.da = (const uint32_t*)h->da;
             f.n_prov = h->n_prov; f.prov_lo = h->prov_lo; f.prov_is_global0 = h->prov_lo == 0;
@@ -765,20 +772,13 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             f.nr_reads1 = a.nr_reads1; f.mcov_u = a.mcov_u; f.len_lo = a.len_lo; f.len_hi = a.len_hi;
             f.n_tiles = (h->n_prov + 3935) / 3936;
             f.err = h->d_words + 1;
-            a.key_is_start = 1;
-            f.c = a;
+            f.fl_starts = h->d_fl_starts; f.fl_lens = h->d_fl_lens; f.fl_cap = h->fl_cap;
+            f.fl_count = (unsigned long long*)(h->d_scalars + 2);
             CK(hipEventRecord(h->ev[6], h->stream));
-            e2s_launch_cluster_filter(f, d.pos_bytes == 1, h->stream);
+            e2s_launch_cluster_filter(f, h->stream);
             CK(hipEventRecord(h->ev[4], h->stream));
-            if (nseed) {
-                int rc = ensure_flagged(h, nseed + 8);
-                if (rc) return rc;
-                CK(hipMemcpyAsync(h->d_fl_starts, ss.data(), nseed * 8, hipMemcpyHostToDevice, h->stream));
-                CK(hipMemcpyAsync(h->d_fl_lens, sl.data(), nseed * 2, hipMemcpyHostToDevice, h->stream));
-                a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = nseed;
-                e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
-                CK(hipStreamSynchronize(h->stream));              // ss/sl are stack-owned
-            }
+            a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
+            e2s_launch_flagged_lists(a, (const unsigned long long*)(h->d_scalars + 2), d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
             CK(hipEventRecord(h->ev[7], h->stream));
         } else {
             a.starts = h->d_starts; a.lens = h->d_lens; a.n_rec = h->n_rec; a.key_is_start = 0;
@@ -788,12 +788,20 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             CK(hipEventRecord(h->ev[7], h->stream));
         }
         uint32_t err = 0;
+        uint64_t flagged = 0;
+        CK(hipMemcpyAsync(&flagged, h->d_scalars + 2, 8, hipMemcpyDeviceToHost, h->stream));
         CK(hipMemcpyAsync(&count, h->d_scalars + 1, 8, hipMemcpyDeviceToHost, h->stream));
         CK(hipMemcpyAsync(&err, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
         if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
+        if (streaming && flagged > h->fl_cap) {
+            int rc = ensure_flagged(h, flagged + 4096);
+            if (rc) return rc;
+            continue;
+        }
+        h->n_flagged = flagged;
         if (count <= h->cand_cap) { done = true; break; }
         want = count + 1024;
     }

@@ -88,11 +88,13 @@ struct FilterArgs {
     int len_lo, len_hi;
     uint64_t n_tiles;
     uint32_t* err;
-    CandArgs c;                                                     // list extraction for the clusters that pass
+    uint64_t* fl_starts; uint16_t* fl_lens; uint64_t fl_cap;        // clusters that pass, for k_flagged_lists
+    unsigned long long* fl_count;
 };
 
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
-void e2s_launch_cluster_filter(const FilterArgs& a, bool def_pos, hipStream_t st);
+void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
+void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);
 #define E2S_WRAP_CAP 1024
 void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* tile_fix_end,

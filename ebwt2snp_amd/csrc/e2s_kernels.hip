@@ -585,7 +585,7 @@ __device__ __forceinline__ u32 swar_eq(u32 x, u32 kb) {
     return ~z & 0x80808080u;
 }
 
-constexpr int FW_FLMAX = 64;                 // flagged clusters per window (more: E2S_DEVERR_DENSE -> record-driven pass)
+constexpr int FW_FLQ = 128;                  // flagged clusters queued in LDS before one global reservation
 constexpr int FW_STAGE = 32;                 // candidates staged in LDS before one global slot reservation
 
 struct StageAlloc {
@@ -598,33 +598,31 @@ struct StageAlloc {
     }
 };
 
-extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // FW_STAGE candidate records
+extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // FW_STAGE candidate records (k_flagged_lists)
 
-template <bool DEFPOS>
 __global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
     __shared__ u32 s_all[FW_SLOTS];          // C | G<<8 | T<<16 | n<<24 over both samples
     __shared__ u32 s_s1[FW_SLOTS];           // the same for sample 1
     __shared__ u32 s_se[FW_SLOTS];           // start offset | end offset << 12 | SE_ENDED | SE_KR
-    __shared__ u32 s_fl[FW_FLMAX];           // flagged clusters of the window: start offset | len << 16
+    __shared__ u64 s_flq[FW_FLQ];            // flagged clusters waiting for a global reservation: start | len << 48
     __shared__ u32 s_wtot[4];
-    __shared__ u32 s_nfl, s_nstage;
+    __shared__ u32 s_nfl;
     __shared__ u64 s_gbase;
-    if (threadIdx.x == 0) { s_nfl = 0; s_nstage = 0; }
-    // one global slot reservation for everything staged so far, then a cooperative copy (all threads call)
-    auto stage_flush = [&]() {
-        const u32 n = min(s_nstage, (u32)FW_STAGE);
+    if (threadIdx.x == 0) s_nfl = 0;
+    // one global reservation for the whole queue (the single-word atomic rate is ~88/us: never per cluster)
+    auto queue_flush = [&]() {
+        const u32 n = min(s_nfl, (u32)FW_FLQ);
         if (n) {
-            if (threadIdx.x == 0) s_gbase = atomicAdd(a.c.cand_count, (unsigned long long)n);
+            if (threadIdx.x == 0) s_gbase = atomicAdd(a.fl_count, (unsigned long long)n);
             __syncthreads();
             const u64 gbase = s_gbase;
-            const u32 q = a.c.stride / 16;
-            for (u32 i = threadIdx.x; i < n * q; i += 256) {
-                const u64 slot = gbase + i / q;
-                if (slot < a.c.cand_cap) ((uint4*)(a.c.cand_buf + slot * a.c.stride))[i % q] = ((const uint4*)s_stage)[i];
+            for (u32 i = threadIdx.x; i < n; i += 256) {
+                const u64 v = s_flq[i];
+                if (gbase + i < a.fl_cap) { a.fl_starts[gbase + i] = v & 0xFFFFFFFFFFFFull; a.fl_lens[gbase + i] = (uint16_t)(v >> 48); }
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_nstage = 0;
+        if (threadIdx.x == 0) s_nfl = 0;
         __syncthreads();
     };
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -772,25 +770,52 @@ __global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
             if (c1A >= a.mcov_u) f1 |= 1u; if (c1C >= a.mcov_u) f1 |= 2u; if (c1G >= a.mcov_u) f1 |= 4u; if (c1T >= a.mcov_u) f1 |= 8u;
             if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) continue;   // :419-429
             const u32 idx = atomicAdd(&s_nfl, 1u);
-            if (idx < FW_FLMAX) s_fl[idx] = (u32)so | ((u32)len << 16);
+            if (idx < FW_FLQ) s_flq[idx] = (a.prov_lo + (u64)(win_lo + so)) | ((u64)len << 48);
             else atomicOr(a.err, E2S_DEVERR_DENSE);
         }
         __syncthreads();
-        // ---- the rare clusters that passed: lists and candidate records (clust2snp.cpp:431-496), one wave each ----
-        const u32 nfl = min(s_nfl, (u32)FW_FLMAX);
-        for (u32 base = 0; base < nfl; base += 4) {
-            if (s_nstage > FW_STAGE - 16) stage_flush();            // every round adds at most 4 x 4 candidates
-            const u32 i = base + wave;
-            if (i < nfl) {
-                const u32 v = s_fl[i];
-                const u64 gs = a.prov_lo + (u64)(win_lo + (int64_t)(v & 0xFFFFu));
-                cluster_record<DEFPOS>(a.c, gs, (int)(v >> 16), gs, lane, StageAlloc{s_stage, &s_nstage, a.c.stride});
-            }
-            __syncthreads();
-        }
-        if (tid == 0) s_nfl = 0;
+        if (s_nfl > FW_FLQ / 2) queue_flush();                      // uniform: s_nfl is stable after the barrier
     }
     __syncthreads();
+    queue_flush();
+}
+
+// K2b: lists and candidate records (clust2snp.cpp:431-496) for the few clusters K2a let through.  Persistent
+// blocks, one wave per cluster, candidates staged in LDS so that a block reserves output slots ~once per 32.
+template <bool DEF>
+__global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigned long long* n_dev) {
+    __shared__ u32 s_nstage;
+    __shared__ u64 s_gbase;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_nstage = 0;
+    __syncthreads();
+    auto stage_flush = [&]() {
+        const u32 n = min(s_nstage, (u32)FW_STAGE);
+        if (n) {
+            if (tid == 0) s_gbase = atomicAdd(a.cand_count, (unsigned long long)n);
+            __syncthreads();
+            const u64 gbase = s_gbase;
+            const u32 q = a.stride / 16;
+            for (u32 i = tid; i < n * q; i += 256) {
+                const u64 slot = gbase + i / q;
+                if (slot < a.cand_cap) ((uint4*)(a.cand_buf + slot * a.stride))[i % q] = ((const uint4*)s_stage)[i];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_nstage = 0;
+        __syncthreads();
+    };
+    const u64 n = min((u64)*n_dev, a.n_rec);
+    const u64 per_round = (u64)gridDim.x * 4;
+    for (u64 base = (u64)blockIdx.x * 4; base < n; base += per_round) {
+        if (s_nstage > FW_STAGE - 16) stage_flush();                // a round adds at most 4 x 4 candidates
+        const u64 r = base + wave;
+        if (r < n) {
+            const u64 s = a.starts[r];
+            cluster_record<DEF>(a, s, (int)a.lens[r], s, lane, StageAlloc{s_stage, &s_nstage, a.stride});
+        }
+        __syncthreads();
+    }
     stage_flush();
 }
 
@@ -868,12 +893,26 @@ void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st) {
     if (def_widths) hipLaunchKernelGGL((k_candidates<true>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
     else hipLaunchKernelGGL((k_candidates<false>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
 }
-void e2s_launch_cluster_filter(const FilterArgs& a, bool def_pos, hipStream_t st) {
-    u64 blocks = a.n_tiles < 1280 ? a.n_tiles : 1280;            // persistent: 256 CUs x 5 blocks
+// persistent grids: exactly the blocks that can be resident (a larger static-stride grid would run in two rounds)
+static int resident_blocks(const void* fn, int threads, size_t dyn_lds) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 2;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    return per_cu * cus;
+}
+void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st) {
+    static int resident = 0;
+    if (!resident) resident = resident_blocks((const void*)k_cluster_filter, 256, 0);
+    u64 blocks = a.n_tiles < (u64)resident ? a.n_tiles : (u64)resident;
     if (blocks == 0) return;
-    const size_t dyn = (size_t)FW_STAGE * a.c.stride;
-    if (def_pos) hipLaunchKernelGGL((k_cluster_filter<true>), dim3((unsigned)blocks), dim3(256), dyn, st, a);
-    else hipLaunchKernelGGL((k_cluster_filter<false>), dim3((unsigned)blocks), dim3(256), dyn, st, a);
+    hipLaunchKernelGGL(k_cluster_filter, dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
+    const size_t dyn = (size_t)FW_STAGE * a.stride;
+    const unsigned blocks = 1024;
+    if (def_widths) hipLaunchKernelGGL((k_flagged_lists<true>), dim3(blocks), dim3(256), dyn, st, a, n_dev);
+    else hipLaunchKernelGGL((k_flagged_lists<false>), dim3(blocks), dim3(256), dyn, st, a, n_dev);
 }
 void e2s_launch_unpack_pairsa(const uint8_t* src, u64 n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st) {
     if (!n) return;
