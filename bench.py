@@ -121,8 +121,8 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2):
     t = _tick("stats", t)
     ncand = h.find_candidates(prm, rank << 40)
     t = _tick("candidates", t)
-    buf, ncand, cap, stride = h.fetch_candidates(prm)
-    t = _tick("fetch", t)
+    recs, order, ncand, cap, stride = h.candidates_view()      # pinned host memory, SA order via `order`
+    t = _tick("view", t)
     return dict(n_ends=b.n_ends, n_cand=ncand, mcl=mcl, n_clust=n_clust)
 
 

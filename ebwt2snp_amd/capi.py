@@ -71,7 +71,7 @@ class Timing(C.Structure):
 SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
            "e2s_attach_soa", "e2s_upload_lcp", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_load_clusters", "e2s_cluster_hist",
-           "e2s_auto_max_clust_length", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates",
+           "e2s_auto_max_clust_length", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_snp_from_candidates", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
 
 _lib = None
@@ -107,7 +107,9 @@ def lib():
     L.e2s_find_candidates.argtypes = [H, C.POINTER(C2SParams), C.c_uint64, C.POINTER(C.c_uint64)]
     L.e2s_candidate_stride.argtypes = [H, C.POINTER(C2SParams), C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
     L.e2s_fetch_candidates.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
-    L.e2s_snp_from_candidates.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p,
+    L.e2s_candidates_view.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
+    L.e2s_snp_from_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p,
                                           C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_last_timing.argtypes = [H, C.POINTER(Timing)]
     L.e2s_stream.argtypes = [H, C.POINTER(C.c_void_p)]
@@ -224,6 +226,17 @@ class Handle:
         self._ck(self.L.e2s_fetch_candidates(self.h, _ptr(self._cbuf), n.value, C.byref(n)))
         return self._cbuf[:n.value * stride.value], n.value, cap.value, stride.value
 
+    def candidates_view(self):
+        """zero-copy: (records uint8 view into the library's pinned buffer, order uint32 view, n, list_cap, stride)"""
+        recs, order = C.c_void_p(), C.c_void_p()
+        n, cap, stride = C.c_uint64(0), C.c_uint32(0), C.c_size_t(0)
+        self._ck(self.L.e2s_candidates_view(self.h, C.byref(recs), C.byref(order), C.byref(n), C.byref(cap), C.byref(stride)))
+        if not n.value:
+            return np.zeros(0, np.uint8), np.zeros(0, np.uint32), 0, cap.value, stride.value
+        r = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint8)), shape=(n.value * stride.value,))
+        o = np.ctypeslib.as_array(C.cast(order, C.POINTER(C.c_uint32)), shape=(n.value,))
+        return r, o, n.value, cap.value, stride.value
+
     def timing(self):
         t = Timing()
         self._ck(self.L.e2s_last_timing(self.h, C.byref(t)))
@@ -258,12 +271,15 @@ def auto_max_clust_length(hists, mcov_out=5, pval=0.99):
     return mcl.value, nc.value, nb.value
 
 
-def snp_from_candidates(cands, n_cand, list_cap, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2):
+def snp_from_candidates(cands, n_cand, list_cap, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2,
+                        order=None):
     p = TailParams(k_left, k_right, max_gap, max_err)
     nv, ne = C.c_uint64(0), C.c_uint64(0)
     cands = np.ascontiguousarray(cands, dtype=np.uint8)
-    rc = lib().e2s_snp_from_candidates(_ptr(cands), n_cand, list_cap, C.byref(p), fasta_path.encode(), out_path.encode(),
-                                       C.byref(nv), C.byref(ne))
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+    rc = lib().e2s_snp_from_candidates(_ptr(cands), _ptr(order), n_cand, list_cap, C.byref(p), fasta_path.encode(),
+                                       out_path.encode(), C.byref(nv), C.byref(ne))
     if rc:
         raise E2SError(rc, "e2s_snp_from_candidates")
     return nv.value, ne.value

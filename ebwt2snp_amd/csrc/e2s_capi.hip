@@ -48,7 +48,14 @@ struct e2s_ctx {
     // candidates
     uint8_t* d_cand = nullptr; uint64_t cand_cap = 0, cand_bytes = 0; uint32_t cand_stride = 0, list_cap = 0; uint64_t n_cand = 0;
     bool tail_bwt_given = false; uint8_t tail_bwt_arg = 0;
-    uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging for candidate download
+    uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
+    uint32_t* pin_order = nullptr;
+    uint32_t* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;
+    bool cand_downloaded = false;
+    uint8_t* pin_mail = nullptr;                 // 4 KB pinned mailbox for small downloads / uploads
+    ScanMail* d_mail = nullptr;
+    uint32_t last_text = 0, last_suff = 0, last_lcp = 0, last_bwt = 0; bool last_known = false;
+    e2s_stitch_plan_t plan{};
     // timing
     hipEvent_t ev[8] = {};
     e2s_timing tm{};
@@ -89,7 +96,8 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     }
     for (auto& ev : h->ev) hipEventCreate(&ev);
     if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess) {
+        hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, sizeof(ScanMail)) != hipSuccess ||
+        hipHostMalloc((void**)&h->pin_mail, 4096, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         delete h;
         return E2S_ERR_HIP;
@@ -103,7 +111,7 @@ static void release_shard(e2s_ctx* h) {
     h->owned.clear();
     h->bwt = nullptr; h->lcp = h->pos = h->da = nullptr;
     h->have_shard = false; h->attached = false; h->scanned = h->stitched = false; h->records_from_file = false;
-    h->tail_bwt_given = false;
+    h->tail_bwt_given = false; h->last_known = false;
 }
 
 extern "C" int e2s_destroy(e2s_handle h) {
@@ -115,6 +123,9 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipFree(h->d_tile_count); hipFree(h->d_tile_prefix); hipFree(h->d_scalars); hipFree(h->d_words); hipFree(h->d_cand);
     hipFree(h->d_tile_fix_end); hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
     if (h->pin_cand) hipHostFree(h->pin_cand);
+    if (h->pin_mail) hipHostFree(h->pin_mail);
+    hipFree(h->d_mail);
+    hipFree(h->d_rank); hipFree(h->d_order);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(h->stream);
     delete h;
@@ -326,7 +337,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     a.first_end_pos = h->d_scalars + 3;
     a.tile_counter = h->d_words + 0; a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
 
-    uint32_t wrap_n = 0;
+    ScanMail mail{};
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = ensure_records(h, want))) return rc;
         a.starts = h->d_starts; a.lens = h->d_lens; a.cap = h->cap;
@@ -352,21 +363,20 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
                             (const unsigned long long*)h->d_starts, h->d_lens, h->cap, a.flags, (unsigned long long*)h->d_wrap,
                             h->d_words + 12, h->stream);
         CK(hipEventRecord(h->ev[1], h->stream));
-        uint32_t words[16];
-        uint64_t total = 0;
-        CK(hipMemcpyAsync(words, h->d_words, sizeof(words), hipMemcpyDeviceToHost, h->stream));
-        CK(hipMemcpyAsync(&total, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+        e2s_launch_scan_mail(a, h->d_words, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, h->stream);
+        CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
-        h->begins_inside = words[2]; h->open_after = words[3]; h->end_before_last = words[4];
-        wrap_n = words[12];
-        if (words[1] & E2S_DEVERR_SPIN) return fail(h, E2S_ERR_SPIN_TIMEOUT, "look-back wait expired");
-        h->tail_lcp = words[8]; h->tail_prev_lcp = words[9];
-        h->n_ends = total;
-        if (total + 4 <= h->cap) break;
+        mail = *(const ScanMail*)h->pin_mail;
+        if (mail.err & E2S_DEVERR_SPIN) return fail(h, E2S_ERR_SPIN_TIMEOUT, "look-back wait expired");
+        h->n_ends = mail.total_ends;
+        if (mail.total_ends + 4 <= h->cap) break;
         if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow");
-        want = total + 4096;                                       // rare: rerun with the exact size
+        want = mail.total_ends + 4096;                             // rare: rerun with the exact size
     }
+    h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
+    h->tail_lcp = mail.tail_lcp; h->tail_prev_lcp = mail.tail_prev_lcp;
+    const uint32_t wrap_n = mail.wrap_count;
     hipEventElapsedTime(&h->tm.scan_ms, h->ev[0], h->ev[1]);
     hipEventElapsedTime(&h->tm.scan_main_ms, h->ev[2], h->ev[3]);
     h->tm.scan_bytes_read = d.n_entries * (uint64_t)d.lcp_bytes;
@@ -378,25 +388,16 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         h->wrap_ranks.resize(wrap_n);
         CK(hipMemcpy(h->wrap_ranks.data(), h->d_wrap, wrap_n * 8, hipMemcpyDeviceToHost));
     }
-    h->first_end_pos = E2S_NONE;
-    if (h->n_ends) CK(hipMemcpy(&h->first_end_pos, h->d_scalars + 3, 8, hipMemcpyDeviceToHost));
-    // the few values the boundary descriptor and the EOF phantom need
-    h->open_start = E2S_NONE; h->last_end_start = E2S_NONE; h->first_len_prov = 0;
-    const bool own_start_open = h->open_after && !(h->n_ends == 0 && h->begins_inside);
-    if (own_start_open) CK(hipMemcpy(&h->open_start, h->d_starts + h->n_ends, 8, hipMemcpyDeviceToHost));
-    if (h->n_ends > 0) {
-        if (!(h->n_ends == 1 && h->begins_inside)) CK(hipMemcpy(&h->last_end_start, h->d_starts + h->n_ends - 1, 8, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(&h->first_len_prov, h->d_lens, 2, hipMemcpyDeviceToHost));
-    }
+    h->first_end_pos = h->n_ends ? mail.first_end_pos : E2S_NONE;
+    h->open_start = mail.open_start; h->last_end_start = mail.last_end_start; h->first_len_prov = (uint16_t)mail.first_len_prov;
+    h->last_text = mail.last_text; h->last_suff = mail.last_suff; h->last_lcp = mail.last_lcp; h->last_bwt = mail.last_bwt;
+    h->last_known = h->bwt && h->pos && h->da;
     h->tail_bwt = 0;
     const bool last_rank = d.global_offset + d.n_entries == d.n_total;
     if (last_rank) {
         if (h->tail_bwt_given) h->tail_bwt = h->tail_bwt_arg;
-        else if (h->bwt) {
-            uint8_t b = 0;
-            CK(hipMemcpy(&b, h->bwt + (h->n_prov - 1), 1, hipMemcpyDeviceToHost));
-            h->tail_bwt = b;
-        } else return fail(h, E2S_ERR_STATE, "the last shard needs the BWT column (or e2s_upload_lcp's tail_bwt) for the EOF rule");
+        else if (h->bwt) h->tail_bwt = mail.last_bwt & 0xFF;
+        else return fail(h, E2S_ERR_STATE, "the last shard needs the BWT column (or e2s_upload_lcp's tail_bwt) for the EOF rule");
         if (h->end_before_last && d.n_entries < 2 && d.global_offset > 0)
             return fail(h, E2S_ERR_ARG, "the last shard must own at least two entries");
     }
@@ -492,19 +493,15 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     e2s_stitch_plan_t pl;
     int rc = e2s_stitch_plan(all, nranks, rank, d.n_total, h->k, d.lcp_bytes, &pl);
     if (rc) return fail(h, rc, "inconsistent boundary descriptors");
-    if (pl.patch_first) {
-        CK(hipMemcpy(h->d_starts, &pl.first_start, 8, hipMemcpyHostToDevice));
-        CK(hipMemcpy(h->d_lens, &pl.first_len, 2, hipMemcpyHostToDevice));
-        h->first_wrapped = h->first_end_pos != E2S_NONE && h->first_end_pos - pl.first_start + 1 >= 65536;
-    }
+    if (pl.patch_first) h->first_wrapped = h->first_end_pos != E2S_NONE && h->first_end_pos - pl.first_start + 1 >= 65536;
     h->n_rec = h->n_ends;
     h->n_closed = h->n_ends;
-    if (pl.n_tail) {
-        if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
-        CK(hipMemcpy(h->d_starts + h->n_rec, pl.tail_start, 8 * pl.n_tail, hipMemcpyHostToDevice));
-        CK(hipMemcpy(h->d_lens + h->n_rec, pl.tail_len, 2 * pl.n_tail, hipMemcpyHostToDevice));
-        h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
-    }
+    if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
+    if (pl.patch_first || pl.n_tail)
+        e2s_launch_apply_plan((unsigned long long*)h->d_starts, h->d_lens, pl.patch_first, pl.first_start, pl.first_len, h->n_ends,
+                              pl.n_tail, pl.tail_start[0], pl.tail_len[0], pl.tail_start[1], pl.tail_len[1], h->stream);
+    h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
+    h->plan = pl;
     h->stitched = true;
     return E2S_OK;
 }
@@ -578,34 +575,20 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     CK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
     uint64_t* dh = h->d_scalars + 8;
-    CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 3) * 8, h->stream));
+    CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 4) * 8, h->stream));
     CK(hipEventRecord(h->ev[4], h->stream));
     if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
     CK(hipEventRecord(h->ev[5], h->stream));
-    uint64_t buf[E2S_MAX_CLUST_LEN + 3];
-    CK(hipMemcpyAsync(buf, dh, sizeof(buf), hipMemcpyDeviceToHost, h->stream));
+    if (h->n_rec) e2s_launch_hist_tail(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
+    uint64_t* buf = (uint64_t*)(h->pin_mail + 256);
+    CK(hipMemcpyAsync(buf, dh, (E2S_MAX_CLUST_LEN + 4) * 8, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
     CK(hipGetLastError());
     hipEventElapsedTime(&h->tm.hist_ms, h->ev[4], h->ev[5]);
     memcpy(out->freq, buf, (E2S_MAX_CLUST_LEN + 1) * 8);
     out->n_records = buf[E2S_MAX_CLUST_LEN + 1];
     out->n_bases = buf[E2S_MAX_CLUST_LEN + 2];
-    // length of the last record that survives the min_len filter (the one the reference counts twice, H4)
-    out->last_len = 0;
-    if (out->n_records) {
-        uint64_t hi = h->n_rec;
-        std::vector<uint16_t> chunk;
-        while (hi > 0) {
-            const uint64_t lo = hi > 4096 ? hi - 4096 : 0;
-            chunk.resize(hi - lo);
-            CK(hipMemcpy(chunk.data(), h->d_lens + lo, (hi - lo) * 2, hipMemcpyDeviceToHost));
-            bool found = false;
-            for (uint64_t i = hi - lo; i-- > 0;)
-                if ((int)chunk[i] >= h->min_len) { out->last_len = chunk[i]; found = true; break; }
-            if (found) break;
-            hi = lo;
-        }
-    }
+    out->last_len = out->n_records ? buf[E2S_MAX_CLUST_LEN + 3] : 0;      // the record the reference counts twice (H4)
     return E2S_OK;
 }
 
@@ -695,13 +678,16 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     a.bwt = h->bwt; a.lcp = h->lcp; a.pos = h->pos; a.da = h->da; a.xb = h->xb; a.yb = h->yb; a.zb = h->zb;
     a.prov_lo = h->prov_lo; a.prov_hi = h->prov_lo + h->n_prov; a.n_total = d.n_total;
     if (a.prov_hi == d.n_total) {
-        uint32_t t = 0, s = 0, l = 0; uint8_t b = 0;
-        const uint64_t i = h->n_prov - 1;
-        CK(hipMemcpy(&t, (const uint8_t*)h->da + i * h->yb, h->yb, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(&s, (const uint8_t*)h->pos + i * h->zb, h->zb, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(&l, (const uint8_t*)h->lcp + i * h->xb, h->xb, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(&b, h->bwt + i, 1, hipMemcpyDeviceToHost));
-        phantom_entry(h, t, s, l, b, &a.ph_text, &a.ph_suff, &a.ph_lcp, &a.ph_bwt);
+        if (!h->last_known) {                       // records came from a file: no scan has looked at the last entry yet
+            uint32_t t = 0, s = 0, l = 0; uint8_t b = 0;
+            const uint64_t i = h->n_prov - 1;
+            CK(hipMemcpy(&t, (const uint8_t*)h->da + i * h->yb, h->yb, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(&s, (const uint8_t*)h->pos + i * h->zb, h->zb, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(&l, (const uint8_t*)h->lcp + i * h->xb, h->xb, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(&b, h->bwt + i, 1, hipMemcpyDeviceToHost));
+            h->last_text = t; h->last_suff = s; h->last_lcp = l; h->last_bwt = b; h->last_known = true;
+        }
+        phantom_entry(h, h->last_text, h->last_suff, h->last_lcp, h->last_bwt, &a.ph_text, &a.ph_suff, &a.ph_lcp, &a.ph_bwt);
     }
     a.nr_reads1 = p->nr_reads1;
     a.k_left_u = (uint64_t)(int64_t)p->k_left; a.k_right_u = (uint64_t)(int64_t)p->k_right;   // uint64_t vs int compares
@@ -737,25 +723,31 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
         if (streaming) {
             // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
-            std::vector<uint64_t> seed_r;
-            for (uint64_t r = h->n_ends; r < h->n_rec; ++r) seed_r.push_back(r);
-            for (uint64_t r : h->wrap_ranks) seed_r.push_back(r);
-            if (h->first_wrapped) seed_r.push_back(0);
             std::vector<uint64_t> ss; std::vector<uint16_t> sl;
-            for (uint64_t r : seed_r) {
+            auto seed = [&](uint64_t st, uint16_t ln) { if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); } };
+            for (uint32_t t = 0; t < h->plan.n_tail; ++t) seed(h->plan.tail_start[t], h->plan.tail_len[t]);
+            if (h->first_wrapped) seed(h->plan.first_start, h->plan.first_len);
+            for (uint64_t r : h->wrap_ranks) {                       // rare: a cluster of 65536+ entries
                 uint64_t st = 0; uint16_t ln = 0;
                 CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
                 CK(hipMemcpy(&ln, h->d_lens + r, 2, hipMemcpyDeviceToHost));
-                if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); }
+                seed(st, ln);
             }
             const uint64_t nseed = ss.size();
             int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096 + nseed));
             if (rc) return rc;
-            if (nseed) {
-                CK(hipMemcpy(h->d_fl_starts, ss.data(), nseed * 8, hipMemcpyHostToDevice));
-                CK(hipMemcpy(h->d_fl_lens, sl.data(), nseed * 2, hipMemcpyHostToDevice));
+            if (nseed > 64) return fail(h, E2S_ERR_INPUT, "too many clusters with wrapped length");
+            {   // seeds travel through the pinned mailbox (asynchronous copies)
+                uint64_t* ms = (uint64_t*)(h->pin_mail + 2048); uint16_t* ml = (uint16_t*)(h->pin_mail + 2048 + 64 * 8);
+                uint64_t* mc = (uint64_t*)(h->pin_mail + 2048 + 64 * 8 + 64 * 2);
+                for (uint64_t t = 0; t < nseed; ++t) { ms[t] = ss[t]; ml[t] = sl[t]; }
+                *mc = nseed;
+                if (nseed) {
+                    CK(hipMemcpyAsync(h->d_fl_starts, ms, nseed * 8, hipMemcpyHostToDevice, h->stream));
+                    CK(hipMemcpyAsync(h->d_fl_lens, ml, nseed * 2, hipMemcpyHostToDevice, h->stream));
+                }
+                CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, h->stream));
             }
-            CK(hipMemcpyAsync(h->d_scalars + 2, &nseed, 8, hipMemcpyHostToDevice, h->stream));
             FilterArgs f{};
             f.bwt = h->bwt; f.lcp = (const uint8_t*)h->lcp; f.da = (const uint32_t*)h->da;
             f.n_prov = h->n_prov; f.prov_lo = h->prov_lo; f.prov_is_global0 = h->prov_lo == 0;
@@ -787,13 +779,14 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             CK(hipEventRecord(h->ev[4], h->stream));
             CK(hipEventRecord(h->ev[7], h->stream));
         }
-        uint32_t err = 0;
-        uint64_t flagged = 0;
-        CK(hipMemcpyAsync(&flagged, h->d_scalars + 2, 8, hipMemcpyDeviceToHost, h->stream));
-        CK(hipMemcpyAsync(&count, h->d_scalars + 1, 8, hipMemcpyDeviceToHost, h->stream));
-        CK(hipMemcpyAsync(&err, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
+        uint64_t* mb = (uint64_t*)(h->pin_mail + 1024);
+        CK(hipMemcpyAsync(mb, h->d_scalars + 1, 16, hipMemcpyDeviceToHost, h->stream));        // cand_count, flagged
+        CK(hipMemcpyAsync(mb + 2, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
+        count = mb[0];
+        const uint64_t flagged = mb[1];
+        const uint32_t err = *(const uint32_t*)(mb + 2);
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
         if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
         if (streaming && flagged > h->fl_cap) {
@@ -807,6 +800,33 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     }
     if (!done) return fail(h, E2S_ERR_CAPACITY, "candidate / flagged buffer overflow");
     h->n_cand = count;
+    h->cand_downloaded = false;
+    if (count) {
+        // SA order on the GPU, then ONE download of records + permutation into pinned memory
+        if (count > h->order_cap) {
+            hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
+            const uint64_t c2 = count + count / 4 + 1024;
+            CK(hipMalloc((void**)&h->d_rank, c2 * 4));
+            CK(hipMalloc((void**)&h->d_order, c2 * 4));
+            h->order_cap = c2;
+        }
+        const size_t rec_bytes = (size_t)count * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
+        const size_t need = ord_off + (size_t)count * 4;
+        if (need > h->pin_cand_bytes) {
+            if (h->pin_cand) hipHostFree(h->pin_cand);
+            h->pin_cand = nullptr; h->pin_cand_bytes = 0;
+            CK(hipHostMalloc((void**)&h->pin_cand, need + need / 4 + 4096, hipHostMallocDefault));
+            h->pin_cand_bytes = need + need / 4 + 4096;
+        }
+        h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
+        CK(hipEventRecord(h->ev[2], h->stream));
+        e2s_launch_cand_order(h->d_cand, a.stride, count, h->d_rank, h->d_order, h->stream);
+        CK(hipMemcpyAsync(h->pin_cand, h->d_cand, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+        CK(hipMemcpyAsync(h->pin_order, h->d_order, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+        CK(hipGetLastError());
+        h->cand_downloaded = true;
+    }
     hipEventElapsedTime(&h->tm.cand_ms, h->ev[6], h->ev[7]);
     hipEventElapsedTime(&h->tm.cand_main_ms, h->ev[6], h->ev[4]);
     h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
@@ -815,65 +835,28 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     return E2S_OK;
 }
 
-// ascending order of 64-bit keys: LSD radix, 11-bit digits (a few tens of thousands of candidates)
-static void radix_order(const std::vector<uint64_t>& key, std::vector<uint32_t>& order) {
-    const size_t n = key.size();
-    order.resize(n);
-    std::vector<uint32_t> tmp(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-    uint64_t mx = 0;
-    for (uint64_t k : key) mx |= k;
-    uint32_t cnt[2048];
-    for (int shift = 0; shift < 64 && (mx >> shift) != 0; shift += 11) {
-        memset(cnt, 0, sizeof(cnt));
-        for (size_t i = 0; i < n; ++i) cnt[(key[order[i]] >> shift) & 2047]++;
-        uint32_t run = 0;
-        for (int d = 0; d < 2048; ++d) { const uint32_t c = cnt[d]; cnt[d] = run; run += c; }
-        for (size_t i = 0; i < n; ++i) tmp[cnt[(key[order[i]] >> shift) & 2047]++] = order[i];
-        order.swap(tmp);
-    }
-}
-
 extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand) {
     if (!h || !n_cand) return E2S_ERR_ARG;
-    CK(hipSetDevice(h->device));
     *n_cand = h->n_cand;
     if (!out) return E2S_OK;
     if (cap_cand < h->n_cand) return fail(h, E2S_ERR_CAPACITY, "candidate output too small");
     if (!h->n_cand) return E2S_OK;
+    if (!h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
     const size_t st = h->cand_stride;
-    const size_t bytes = (size_t)h->n_cand * st;
-    if (bytes > h->pin_cand_bytes) {                                // pinned staging: the copy runs at link rate
-        if (h->pin_cand) hipHostFree(h->pin_cand);
-        h->pin_cand = nullptr; h->pin_cand_bytes = 0;
-        CK(hipHostMalloc((void**)&h->pin_cand, bytes + bytes / 4 + 4096, hipHostMallocDefault));
-        h->pin_cand_bytes = bytes + bytes / 4 + 4096;
-    }
-    CK(hipMemcpyAsync(h->pin_cand, h->d_cand, bytes, hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
-    // slots were claimed with atomic counters: restore SA order (cluster, then the (c0,c1) loop order)
-    const uint8_t* raw = h->pin_cand;
-    std::vector<uint64_t> key(h->n_cand);
-    bool small = true;
-    for (uint64_t i = 0; i < h->n_cand; ++i) {
-        const e2s_cand_header* c = (const e2s_cand_header*)(raw + i * st);
-        if (c->record_index >> 61) small = false;
-        key[i] = (c->record_index << 2) | (c->pair_index & 3u);
-    }
-    std::vector<uint32_t> order;
-    if (small) radix_order(key, order);
-    else {
-        order.resize(h->n_cand);
-        for (uint64_t i = 0; i < h->n_cand; ++i) order[i] = (uint32_t)i;
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            const e2s_cand_header* a = (const e2s_cand_header*)(raw + (size_t)x * st);
-            const e2s_cand_header* b = (const e2s_cand_header*)(raw + (size_t)y * st);
-            if (a->record_index != b->record_index) return a->record_index < b->record_index;
-            return a->pair_index < b->pair_index;
-        });
-    }
     uint8_t* o = (uint8_t*)out;
-    for (uint64_t i = 0; i < h->n_cand; ++i) memcpy(o + i * st, raw + (size_t)order[i] * st, st);
+    for (uint64_t i = 0; i < h->n_cand; ++i) memcpy(o + i * st, h->pin_cand + (size_t)h->pin_order[i] * st, st);
+    return E2S_OK;
+}
+
+extern "C" int e2s_candidates_view(e2s_handle h, const void** recs, const uint32_t** order, uint64_t* n_cand,
+                                   uint32_t* list_cap, size_t* stride_bytes) {
+    if (!h) return E2S_ERR_ARG;
+    if (h->n_cand && !h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
+    if (recs) *recs = h->n_cand ? h->pin_cand : nullptr;
+    if (order) *order = h->n_cand ? h->pin_order : nullptr;
+    if (n_cand) *n_cand = h->n_cand;
+    if (list_cap) *list_cap = h->list_cap;
+    if (stride_bytes) *stride_bytes = h->cand_stride;
     return E2S_OK;
 }
 

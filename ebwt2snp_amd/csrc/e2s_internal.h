@@ -49,6 +49,14 @@ struct ScanArgs {
     uint32_t* tailv;
 };
 
+// everything the host needs after a scan, gathered by k_scan_mail so that ONE small download suffices
+struct ScanMail {
+    uint64_t total_ends, first_end_pos, open_start, last_end_start;
+    uint32_t begins_inside, open_after, end_before_last, err;
+    uint32_t wrap_count, first_len_prov, tail_lcp, tail_prev_lcp;
+    uint32_t last_text, last_suff, last_lcp, last_bwt;      // the last provided entry (EOF phantom model)
+};
+
 struct CandHeader {           // == e2s_cand_header
     uint64_t record_index;
     uint32_t pair_index;
@@ -101,6 +109,13 @@ void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* t
                          const unsigned long long* starts, uint16_t* lens, unsigned long long cap, const uint32_t* flags,
                          unsigned long long* wrap_list, uint32_t* wrap_count, hipStream_t st);
 void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st);
+void e2s_launch_scan_mail(const ScanArgs& a, const uint32_t* words, const uint8_t* bwt, const void* pos, const void* da,
+                          int xb, int yb, int zb, ScanMail* out, hipStream_t st);
+void e2s_launch_apply_plan(unsigned long long* starts, uint16_t* lens, uint32_t patch_first, unsigned long long first_start,
+                           uint16_t first_len, unsigned long long n_ends, uint32_t n_tail, unsigned long long t0, uint16_t l0,
+                           unsigned long long t1, uint16_t l1, hipStream_t st);
+void e2s_launch_hist_tail(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out_last_len, hipStream_t st);
+void e2s_launch_cand_order(const uint8_t* cand, uint32_t stride, unsigned long long n, uint32_t* rank, uint32_t* order, hipStream_t st);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
 void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);
 void e2s_launch_unpack_pairsa(const uint8_t* src, unsigned long long n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st);

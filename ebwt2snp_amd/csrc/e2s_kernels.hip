@@ -385,6 +385,52 @@ __global__ void k_shard_flags(ScanArgs a, u32 xb) {
     a.tailv[1] = L(last - 1);
 }
 
+// one thread: collect what the host needs after a scan into one struct (one download instead of many)
+__global__ void k_scan_mail(ScanArgs a, const u32* words, const uint8_t* bwt, const void* pos, const void* da,
+                            int xb, int yb, int zb, ScanMail* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ScanMail m;
+    m.total_ends = *a.total_ends;
+    m.first_end_pos = *a.first_end_pos;
+    m.begins_inside = a.flags[E2S_FLAG_BEGINS_INSIDE];
+    m.open_after = a.flags[E2S_FLAG_OPEN_AFTER];
+    m.end_before_last = a.flags[E2S_FLAG_END_BEFORE_LAST];
+    m.err = *a.err;
+    m.wrap_count = words[12];
+    m.tail_lcp = a.tailv[0];
+    m.tail_prev_lcp = a.tailv[1];
+    const u64 ne = m.total_ends;
+    const bool fits = ne + 1 < a.cap;
+    const bool own_open = m.open_after && !(ne == 0 && m.begins_inside);
+    m.open_start = (own_open && fits) ? a.starts[ne] : ~0ull;
+    m.last_end_start = (ne > 0 && fits && !(ne == 1 && m.begins_inside)) ? a.starts[ne - 1] : ~0ull;
+    m.first_len_prov = (ne > 0 && fits) ? a.lens[0] : 0u;
+    const u64 li = a.n_prov - 1;
+    auto ld = [&](const void* p, int w) -> u32 {
+        if (!p) return 0u;
+        return w == 1 ? (u32)((const uint8_t*)p)[li] : w == 2 ? (u32)((const uint16_t*)p)[li] : ((const u32*)p)[li];
+    };
+    m.last_text = ld(da, yb); m.last_suff = ld(pos, zb); m.last_lcp = ld(a.lcp, xb); m.last_bwt = bwt ? (u32)bwt[li] : 0u;
+    *out = m;
+}
+
+// apply e2s_stitch_plan to the device-resident records (values travel as kernel arguments)
+__global__ void k_apply_plan(u64* starts, uint16_t* lens, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_ends, u32 n_tail,
+                             u64 t0, uint16_t l0, u64 t1, uint16_t l1) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (patch_first) { starts[0] = first_start; lens[0] = first_len; }
+    if (n_tail > 0) { starts[n_ends] = t0; lens[n_ends] = l0; }
+    if (n_tail > 1) { starts[n_ends + 1] = t1; lens[n_ends + 1] = l1; }
+}
+
+// length of the last record that survives the min_len filter (the reference counts it twice, H4)
+__global__ void k_hist_tail(const uint16_t* lens, u64 n, int min_len, u64* out_last_len) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u64 v = 0;
+    for (u64 i = n; i-- > 0;) if ((int)lens[i] >= min_len) { v = lens[i]; break; }
+    *out_last_len = v;
+}
+
 // ----------------------------------------------------------------------------------------------
 // KH: histogram of cluster lengths (statistics(), clust2snp.cpp:889-909; H4 applied on the host)
 // ----------------------------------------------------------------------------------------------
@@ -820,6 +866,41 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
 }
 
 // ----------------------------------------------------------------------------------------------
+// KO: SA order of the candidates.  Output slots are claimed with atomics, so the order of the buffer is
+// arbitrary; the reference emits candidates in SA order (cluster, then the (c0,c1) loop order).  Keys are
+// unique, a few 10^4 per GPU: rank by counting (n^2/4096 block-steps), then scatter the permutation.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 cand_key(const uint8_t* cand, u32 stride, u64 i) {
+    const CandHeader* h = (const CandHeader*)(cand + i * stride);
+    return (h->record_index << 2) | (u64)(h->pair_index & 3u);
+}
+constexpr int KO_CHUNK = 4096;
+__global__ __launch_bounds__(256) void k_cand_rank(const uint8_t* cand, u32 stride, u64 n, u32* rank) {
+    __shared__ u64 s_keys[KO_CHUNK];
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 jbase = (u64)blockIdx.y * KO_CHUNK;
+    const u64 jn = min((u64)KO_CHUNK, n - jbase);
+    for (u32 t = threadIdx.x; t < jn; t += 256) s_keys[t] = cand_key(cand, stride, jbase + t);
+    __syncthreads();
+    if (i >= n) return;
+    const u64 mine = cand_key(cand, stride, i);
+    u32 r = 0;
+    for (u32 t = 0; t < jn; ++t) r += s_keys[t] < mine ? 1u : 0u;
+    if (r) atomicAdd(&rank[i], r);
+}
+__global__ void k_cand_scatter(const u32* rank, u64 n, u32* order) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[rank[i]] = (u32)i;
+}
+void e2s_launch_cand_order(const uint8_t* cand, u32 stride, u64 n, u32* rank, u32* order, hipStream_t st) {
+    if (!n) return;
+    hipMemsetAsync(rank, 0, n * 4, st);
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n + KO_CHUNK - 1) / KO_CHUNK));
+    hipLaunchKernelGGL(k_cand_rank, grid, dim3(256), 0, st, cand, stride, n, rank);
+    hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)rank, n, order);
+}
+
+// ----------------------------------------------------------------------------------------------
 // KU: file layouts -> struct-of-arrays in HBM (8-byte fields truncated to 32 bits like t_GSA)
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 rd_le(const uint8_t* p, int w) {
@@ -879,6 +960,17 @@ void e2s_launch_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* tile_fix_e
 }
 void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st) {
     hipLaunchKernelGGL(k_shard_flags, dim3(1), dim3(64), 0, st, a, (u32)xb);
+}
+void e2s_launch_scan_mail(const ScanArgs& a, const u32* words, const uint8_t* bwt, const void* pos, const void* da,
+                          int xb, int yb, int zb, ScanMail* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_mail, dim3(1), dim3(64), 0, st, a, words, bwt, pos, da, xb, yb, zb, out);
+}
+void e2s_launch_apply_plan(u64* starts, uint16_t* lens, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_ends, u32 n_tail,
+                           u64 t0, uint16_t l0, u64 t1, uint16_t l1, hipStream_t st) {
+    hipLaunchKernelGGL(k_apply_plan, dim3(1), dim3(64), 0, st, starts, lens, patch_first, first_start, first_len, n_ends, n_tail, t0, l0, t1, l1);
+}
+void e2s_launch_hist_tail(const uint16_t* lens, u64 n, int min_len, u64* out_last_len, hipStream_t st) {
+    hipLaunchKernelGGL(k_hist_tail, dim3(1), dim3(64), 0, st, lens, n, min_len, out_last_len);
 }
 void e2s_launch_hist(const uint16_t* lens, u64 n, int min_len, u64* out, hipStream_t st) {
     u64 blocks = (n + 256 * 8 - 1) / (256 * 8);

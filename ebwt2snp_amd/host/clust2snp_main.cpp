@@ -158,7 +158,7 @@ int main(int argc, char** argv) {
     std::cout << "(4/4) Computing edit distances and saving SNPs/indels to file ... " << std::endl;
     e2s_tail_params tp{k_left, k_right, max_gap, max_err};
     uint64_t nv = 0, ne = 0;
-    rc = e2s_snp_from_candidates(cands.data(), n_cand, cap, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
+    rc = e2s_snp_from_candidates(cands.data(), nullptr, n_cand, cap, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
     if (rc == E2S_ERR_REF_CRASH) {
         std::cerr << "no candidate variant: the reference crashes here (SIGSEGV, clust2snp.cpp:531); no .snp written" << std::endl;
         return 139;

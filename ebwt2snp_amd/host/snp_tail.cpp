@@ -132,8 +132,9 @@ struct Variant { std::string left0, left1, right; int s0, s1; };
 
 }  // namespace
 
-extern "C" int e2s_snp_from_candidates(const void* cands, uint64_t n_cand, uint32_t list_cap, const e2s_tail_params* p,
-                                       const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events) {
+extern "C" int e2s_snp_from_candidates(const void* cands, const uint32_t* order, uint64_t n_cand, uint32_t list_cap,
+                                       const e2s_tail_params* p, const char* fasta_path, const char* out_path,
+                                       uint64_t* n_variants, uint64_t* n_events) {
     if (!p || !fasta_path || !out_path || (!cands && n_cand)) return E2S_ERR_ARG;
     if (n_variants) *n_variants = 0;
     if (n_events) *n_events = 0;
@@ -141,8 +142,9 @@ extern "C" int e2s_snp_from_candidates(const void* cands, uint64_t n_cand, uint3
     if (n_cand == 0) return E2S_ERR_REF_CRASH;
     const size_t stride = sizeof(e2s_cand_header) + (size_t)4 * list_cap * sizeof(uint32_t);
     const uint8_t* base = (const uint8_t*)cands;
-    auto hdr = [&](uint64_t c) { return (const e2s_cand_header*)(base + c * stride); };
-    auto lists = [&](uint64_t c) { return (const uint32_t*)(base + c * stride + sizeof(e2s_cand_header)); };
+    auto at_rec = [&](uint64_t c) { return base + (size_t)(order ? order[c] : c) * stride; };     // SA order
+    auto hdr = [&](uint64_t c) { return (const e2s_cand_header*)at_rec(c); };
+    auto lists = [&](uint64_t c) { return (const uint32_t*)(at_rec(c) + sizeof(e2s_cand_header)); };
 
     // all read ranks any candidate touches, ascending and unique (clust2snp.cpp:512-523)
     std::vector<uint64_t> ranks;

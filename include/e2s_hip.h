@@ -177,16 +177,22 @@ typedef struct {
 /* out layout: n_cand blocks of [e2s_cand_header][u32 idx0[cap]][u32 pos0[cap]][u32 idx1[cap]][u32 pos1[cap]] */
 int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand);
 int e2s_candidate_stride(e2s_handle h, const e2s_c2s_params* p, uint32_t* list_cap, size_t* stride_bytes);
-int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand);  /* sorted in SA order */
+int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand);  /* copied out in SA order */
+/* Zero-copy: the candidates as e2s_find_candidates left them in the library's pinned host buffer (arbitrary
+ * order) plus the permutation that puts them in SA order: the i-th candidate is recs[order[i]].  Valid until
+ * the next e2s_find_candidates / e2s_destroy on this handle. */
+int e2s_candidates_view(e2s_handle h, const void** recs, const uint32_t** order, uint64_t* n_cand,
+                        uint32_t* list_cap, size_t* stride_bytes);
 
 /* ---- host tail: candidates -> KisSNP2 text (extract_variants + distance + to_file) -------- */
 typedef struct {
     int32_t k_left, k_right, max_gap, max_err;   /* -L -R -g -e */
 } e2s_tail_params;
-/* cands: e2s_fetch_candidates layout (all ranks concatenated in rank order).  fasta_path is the
- * reads file; out_path the .snp to write.  Host only (no GPU work). */
-int e2s_snp_from_candidates(const void* cands, uint64_t n_cand, uint32_t list_cap, const e2s_tail_params* p,
-                            const char* fasta_path, const char* out_path,
+/* cands: e2s_fetch_candidates layout (all ranks concatenated in rank order); order: NULL, or the
+ * permutation of e2s_candidates_view.  fasta_path is the reads file; out_path the .snp to write.
+ * Host only (no GPU work). */
+int e2s_snp_from_candidates(const void* cands, const uint32_t* order, uint64_t n_cand, uint32_t list_cap,
+                            const e2s_tail_params* p, const char* fasta_path, const char* out_path,
                             uint64_t* n_variants, uint64_t* n_events);
 
 /* ---- measurement --------------------------------------------------------------------------- */
