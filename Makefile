@@ -2,7 +2,8 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude
+EXTRA   ?=
+HIPFLAGS = $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude
 LIB      = ebwt2snp_amd/libe2s_hip.so
 CSRC     = ebwt2snp_amd/csrc
 HOST     = ebwt2snp_amd/host

@@ -646,7 +646,10 @@ struct StageAlloc {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // FW_STAGE candidate records (k_flagged_lists)
 
-__global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
+#ifndef FW_LB_WAVES
+#define FW_LB_WAVES 3
+#endif
+__global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs a) {
     __shared__ u32 s_all[FW_SLOTS];          // C | G<<8 | T<<16 | n<<24 over both samples
     __shared__ u32 s_s1[FW_SLOTS];           // the same for sample 1
     __shared__ u32 s_se[FW_SLOTS];           // start offset | end offset << 12 | SE_ENDED | SE_KR
@@ -676,18 +679,19 @@ __global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
     const uint8_t* lcpb = a.lcp;
     const uint8_t* bwtb = a.bwt;
 
-    for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;       // local index of the window's first entry
+    // one window's worth of loads: lcp row + edge words, bwt row, da in coalesced order
+    // (lane i of load q holds entries wave*1024 + q*256 + 4i .. +3)
+    struct FwRegs { u32 W[6]; u32 B[4]; uint4 T[4]; };
+    auto fw_load = [&](u64 tile, FwRegs& r) {
+        const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;
         const int64_t i0 = win_lo + (int64_t)tid * 16;
-        // ---- loads: lcp row + edge words, bwt row, da in coalesced order ----
-        u32 W[6], B[4];
         if (i0 >= 4 && i0 + 20 <= n_prov) {
             const uint4 v = *(const uint4*)(lcpb + i0);
-            W[1] = v.x; W[2] = v.y; W[3] = v.z; W[4] = v.w;
-            W[0] = *(const u32*)(lcpb + i0 - 4);
-            W[5] = *(const u32*)(lcpb + i0 + 16);
+            r.W[1] = v.x; r.W[2] = v.y; r.W[3] = v.z; r.W[4] = v.w;
+            r.W[0] = *(const u32*)(lcpb + i0 - 4);
+            r.W[5] = *(const u32*)(lcpb + i0 + 16);
             const uint4 b = *(const uint4*)(bwtb + i0);
-            B[0] = b.x; B[1] = b.y; B[2] = b.z; B[3] = b.w;
+            r.B[0] = b.x; r.B[1] = b.y; r.B[2] = b.z; r.B[3] = b.w;
         } else {
 #pragma unroll
             for (int w = 0; w < 6; ++w) {
@@ -697,32 +701,46 @@ __global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
                     const int64_t e = i0 + (int64_t)(w - 1) * 4 + bt;
                     if (e >= 0 && e < n_prov) { v |= (u32)lcpb[e] << (8 * bt); vb |= (u32)bwtb[e] << (8 * bt); }
                 }
-                W[w] = v;
-                if (w >= 1 && w <= 4) B[w - 1] = vb;
+                r.W[w] = v;
+                if (w >= 1 && w <= 4) r.B[w - 1] = vb;
             }
         }
-        // sample bit of every entry: lane i of load q holds entries wave*1024 + q*256 + 4i .. +3
-        u32 snib = 0;
-        {
-            const int64_t wbase = win_lo + (int64_t)wave * 1024;
+        const int64_t wbase = win_lo + (int64_t)wave * 1024;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t e = wbase + q * 256 + (int64_t)lane * 4;
-                u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-                if (e >= 0 && e + 4 <= n_prov) {
-                    const uint4 v = *(const uint4*)(a.da + e);
-                    t0 = v.x; t1 = v.y; t2 = v.z; t3 = v.w;
-                } else {
-                    if (e + 0 >= 0 && e + 0 < n_prov) t0 = a.da[e + 0];
-                    if (e + 1 >= 0 && e + 1 < n_prov) t1 = a.da[e + 1];
-                    if (e + 2 >= 0 && e + 2 < n_prov) t2 = a.da[e + 2];
-                    if (e + 3 >= 0 && e + 3 < n_prov) t3 = a.da[e + 3];
-                }
-                // sample = !(text < nr_reads1), uint32 text against uint64 nr_reads1 (clust2snp.cpp:390)
-                const u32 nib = ((u64)t0 >= a.nr_reads1 ? 1u : 0u) | ((u64)t1 >= a.nr_reads1 ? 2u : 0u) |
-                                ((u64)t2 >= a.nr_reads1 ? 4u : 0u) | ((u64)t3 >= a.nr_reads1 ? 8u : 0u);
-                snib |= nib << (4 * q);
+        for (int q = 0; q < 4; ++q) {
+            const int64_t e = wbase + q * 256 + (int64_t)lane * 4;
+            if (e >= 0 && e + 4 <= n_prov) r.T[q] = *(const uint4*)(a.da + e);
+            else {
+                uint4 t = make_uint4(0, 0, 0, 0);
+                if (e + 0 >= 0 && e + 0 < n_prov) t.x = a.da[e + 0];
+                if (e + 1 >= 0 && e + 1 < n_prov) t.y = a.da[e + 1];
+                if (e + 2 >= 0 && e + 2 < n_prov) t.z = a.da[e + 2];
+                if (e + 3 >= 0 && e + 3 < n_prov) t.w = a.da[e + 3];
+                r.T[q] = t;
             }
+        }
+    };
+
+    FwRegs cur, nxt;
+    if (blockIdx.x < a.n_tiles) fw_load(blockIdx.x, cur);
+    for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        // software pipeline: the next window's loads are in flight while this one is processed
+        if (tile + gridDim.x < a.n_tiles) fw_load(tile + gridDim.x, nxt);
+        const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;       // local index of the window's first entry
+        const int64_t i0 = win_lo + (int64_t)tid * 16;
+        u32 W[6], B[4];
+#pragma unroll
+        for (int w = 0; w < 6; ++w) W[w] = cur.W[w];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) B[w] = cur.B[w];
+        // sample = !(text < nr_reads1), uint32 text against uint64 nr_reads1 (clust2snp.cpp:390)
+        u32 snib = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 t = cur.T[q];
+            const u32 nib = ((u64)t.x >= a.nr_reads1 ? 1u : 0u) | ((u64)t.y >= a.nr_reads1 ? 2u : 0u) |
+                            ((u64)t.z >= a.nr_reads1 ? 4u : 0u) | ((u64)t.w >= a.nr_reads1 ? 8u : 0u);
+            snib |= nib << (4 * q);
         }
         // owner lane L = 16q + j gathers nibble q of lanes 4j .. 4j+3
         u32 S1;
@@ -821,6 +839,7 @@ __global__ __launch_bounds__(256) void k_cluster_filter(FilterArgs a) {
         }
         __syncthreads();
         if (s_nfl > FW_FLQ / 2) queue_flush();                      // uniform: s_nfl is stable after the barrier
+        cur = nxt;
     }
     __syncthreads();
     queue_flush();
