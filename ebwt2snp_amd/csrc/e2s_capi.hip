@@ -52,6 +52,11 @@ struct e2s_ctx {
     uint32_t* pin_order = nullptr;
     uint32_t* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;
     bool cand_downloaded = false;
+    // segmented record storage (scan_mode 0): segment b = d_starts/d_lens[b*seg_cap ...), SegDesc per block
+    bool segmented = false; uint32_t seg_cap = 0, seg_blocks = 0; SegDesc* d_seg_desc = nullptr; uint64_t* d_seg_off = nullptr;
+    uint32_t seg_blocks_cap = 0;
+    uint64_t first_rec_addr = E2S_NONE;
+    uint64_t* d_cstarts = nullptr; uint16_t* d_clens = nullptr; uint64_t ccap = 0; bool compact_valid = false;   // contiguous copy, on demand
     uint8_t* pin_mail = nullptr;                 // 4 KB pinned mailbox for small downloads / uploads
     ScanMail* d_mail = nullptr;
     uint32_t last_text = 0, last_suff = 0, last_lcp = 0, last_bwt = 0; bool last_known = false;
@@ -124,7 +129,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipFree(h->d_tile_fix_end); hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
     if (h->pin_cand) hipHostFree(h->pin_cand);
     if (h->pin_mail) hipHostFree(h->pin_mail);
-    hipFree(h->d_mail);
+    hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
     hipFree(h->d_rank); hipFree(h->d_order);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(h->stream);
@@ -303,6 +308,31 @@ static int ensure_tiles(e2s_ctx* h, uint64_t n_tiles) {
     return E2S_OK;
 }
 
+// contiguous record arrays for consumers that index records by rank (file output, record-driven pass).
+// scan_mode 0 keeps records in per-block segments; this gathers them once, on demand, tail records included.
+static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_t** lens) {
+    if (!h->segmented) { *starts = h->d_starts; *lens = h->d_lens; return E2S_OK; }
+    if (!h->compact_valid) {
+        if (h->n_rec + 8 > h->ccap) {
+            hipFree(h->d_cstarts); hipFree(h->d_clens); h->d_cstarts = nullptr; h->d_clens = nullptr; h->ccap = 0;
+            CK(hipMalloc((void**)&h->d_cstarts, (h->n_rec + 8) * 8));
+            CK(hipMalloc((void**)&h->d_clens, (h->n_rec + 8) * 2 + 64));
+            h->ccap = h->n_rec + 8;
+        }
+        SegArgs sa{};
+        sa.starts = h->d_starts; sa.lens = h->d_lens; sa.seg_cap = h->seg_cap; sa.desc = h->d_seg_desc; sa.n_blocks = h->seg_blocks;
+        if (h->n_ends) e2s_launch_seg_compact(sa, (const unsigned long long*)h->d_seg_off, (unsigned long long*)h->d_cstarts, h->d_clens, h->stream);
+        if (h->stitched && h->plan.n_tail)
+            e2s_launch_apply_plan((unsigned long long*)h->d_cstarts, h->d_clens, 0, 0, 0, h->n_ends, h->plan.n_tail, h->plan.tail_start[0],
+                                  h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], h->stream);
+        CK(hipStreamSynchronize(h->stream));
+        CK(hipGetLastError());
+        h->compact_valid = true;
+    }
+    *starts = h->d_cstarts; *lens = h->d_clens;
+    return E2S_OK;
+}
+
 extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode) {
     if (!h) return E2S_ERR_ARG;
     if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
@@ -310,7 +340,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     CK(hipSetDevice(h->device));
     const e2s_shard_desc& d = h->d;
     h->k = k; h->min_len = min_len;
-    h->scanned = h->stitched = false; h->records_from_file = false;
+    h->scanned = h->stitched = false; h->records_from_file = false; h->compact_valid = false;
 
     ScanArgs a{};
     a.lcp = h->lcp; a.n_prov = h->n_prov; a.prov_lo = h->prov_lo; a.prov_is_global0 = h->prov_lo == 0;
@@ -325,54 +355,97 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     const uint32_t H = h->xb == 1 ? 0x80808080u : h->xb == 2 ? 0x80008000u : 0x80000000u;
     a.hge = ((uint64_t)a.k_u32 > lane_max) ? 0u : H;
     a.kb = h->xb == 1 ? (a.k_u32 & 0xFF) * 0x01010101u : h->xb == 2 ? (a.k_u32 & 0xFFFF) * 0x00010001u : a.k_u32;
-    const uint64_t tile_entries = (uint64_t)E2S_SCAN_ROWS * E2S_SCAN_BLOCK * (16 / h->xb);
-    a.n_tiles = (h->n_prov + tile_entries - 1) / tile_entries;
-    if (a.n_tiles > 0x7FFFFFFFull) return fail(h, E2S_ERR_ARG, "shard too large for one launch");
-    int rc = ensure_tiles(h, a.n_tiles);
-    if (rc) return rc;
-    uint64_t want = std::max<uint64_t>(h->cap, d.n_entries / 8 + 4096);
-    a.spin_limit = 1u << 22;
     a.total_ends = h->d_scalars + 0;
-    a.tile_fix = h->d_tile_fix; a.tile_fix_end = h->d_tile_fix_end; a.tile_state = h->d_tile_state; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
     a.first_end_pos = h->d_scalars + 3;
     a.tile_counter = h->d_words + 0; a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
-
+    int rc;
     ScanMail mail{};
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if ((rc = ensure_records(h, want))) return rc;
-        a.starts = h->d_starts; a.lens = h->d_lens; a.cap = h->cap;
-        CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
-        CK(hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-        CK(hipMemsetAsync(h->d_scalars + 3, 0xFF, 8, h->stream));
-        CK(hipMemsetAsync(h->d_tile_fix, 0xFF, a.n_tiles * 8, h->stream));
-        e2s_launch_shard_flags(a, h->xb, h->stream);
-        CK(hipEventRecord(h->ev[0], h->stream));
-        if (scan_mode == 0) {
-            CK(hipMemsetAsync(h->d_tile_state, 0, a.n_tiles * 8, h->stream));
+
+    if (scan_mode == 0) {
+        // ---- segmented single-pass scan: persistent blocks over contiguous tile ranges ----
+        const uint64_t row_entries = (uint64_t)E2S_SCAN_BLOCK * (16 / h->xb);
+        SegArgs sa{};
+        sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
+        sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;
+        sa.k_u32 = a.k_u32; sa.kb = a.kb; sa.hge = a.hge;
+        sa.n_tiles = (h->n_prov + row_entries - 1) / row_entries;
+        static int resident[5] = {0, 0, 0, 0, 0};
+        if (!resident[h->xb]) resident[h->xb] = e2s_scan_seg_resident_blocks(h->xb);
+        uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
+        sa.tiles_per_block = (uint32_t)((sa.n_tiles + nb - 1) / nb);
+        nb = (sa.n_tiles + sa.tiles_per_block - 1) / sa.tiles_per_block;
+        sa.n_blocks = (uint32_t)nb;
+        if (nb + 1 > h->seg_blocks_cap) {
+            hipFree(h->d_seg_desc); hipFree(h->d_seg_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->seg_blocks_cap = 0;
+            CK(hipMalloc((void**)&h->d_seg_desc, (nb + 1) * sizeof(SegDesc)));
+            CK(hipMalloc((void**)&h->d_seg_off, (nb + 2) * 8));
+            h->seg_blocks_cap = (uint32_t)(nb + 1);
+        }
+        const uint64_t range_entries = (uint64_t)sa.tiles_per_block * row_entries;
+        uint64_t seg_cap = range_entries / 8 + 256;                 // typical density is ~0.03 records per entry
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
+            if ((rc = ensure_records(h, nb * seg_cap))) return rc;
+            sa.seg_cap = (uint32_t)seg_cap; sa.starts = h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
+            sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
+            CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
+            e2s_launch_shard_flags(a, h->xb, h->stream);
+            CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
-            e2s_launch_scan(a, h->xb, 0, h->stream);
+            e2s_launch_scan_seg(sa, h->xb, h->stream);
             CK(hipEventRecord(h->ev[3], h->stream));
-        } else {
+            e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb,
+                               h->d_mail, h->stream);
+            CK(hipEventRecord(h->ev[1], h->stream));
+            CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
+            CK(hipStreamSynchronize(h->stream));
+            CK(hipGetLastError());
+            mail = *(const ScanMail*)h->pin_mail;
+            if (!(mail.err & E2S_DEVERR_SEGFULL)) break;
+            if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record segment overflow");
+            seg_cap = range_entries + 16;                           // worst case: rerun with room for everything
+        }
+        h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
+        h->first_rec_addr = mail.first_rec_addr;
+        h->n_ends = mail.total_ends;
+    } else {
+        // ---- three-kernel count / scan / emit into contiguous arrays ----
+        h->segmented = false; h->first_rec_addr = 0;
+        const uint64_t tile_entries = (uint64_t)E2S_SCAN_ROWS * E2S_SCAN_BLOCK * (16 / h->xb);
+        a.n_tiles = (h->n_prov + tile_entries - 1) / tile_entries;
+        if (a.n_tiles > 0x7FFFFFFFull) return fail(h, E2S_ERR_ARG, "shard too large for one launch");
+        if ((rc = ensure_tiles(h, a.n_tiles))) return rc;
+        uint64_t want = std::max<uint64_t>(h->cap, d.n_entries / 8 + 4096);
+        a.spin_limit = 1u << 22;
+        a.tile_fix = h->d_tile_fix; a.tile_fix_end = h->d_tile_fix_end; a.tile_state = h->d_tile_state; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = ensure_records(h, want))) return rc;
+            a.starts = h->d_starts; a.lens = h->d_lens; a.cap = h->cap;
+            CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
+            CK(hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+            CK(hipMemsetAsync(h->d_scalars + 3, 0xFF, 8, h->stream));
+            CK(hipMemsetAsync(h->d_tile_fix, 0xFF, a.n_tiles * 8, h->stream));
+            e2s_launch_shard_flags(a, h->xb, h->stream);
+            CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
             e2s_launch_scan(a, h->xb, 1, h->stream);
             e2s_launch_tile_scan(h->d_tile_count, (unsigned long long*)h->d_tile_prefix, a.n_tiles, h->stream);
             e2s_launch_scan(a, h->xb, 2, h->stream);
             CK(hipEventRecord(h->ev[3], h->stream));
+            e2s_launch_scan_fix(a.n_tiles, (const unsigned long long*)h->d_tile_fix, (const unsigned long long*)h->d_tile_fix_end,
+                                (const unsigned long long*)h->d_starts, h->d_lens, h->cap, a.flags, (unsigned long long*)h->d_wrap,
+                                h->d_words + 12, h->stream);
+            CK(hipEventRecord(h->ev[1], h->stream));
+            e2s_launch_scan_mail(a, h->d_words, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, h->stream);
+            CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
+            CK(hipStreamSynchronize(h->stream));
+            CK(hipGetLastError());
+            mail = *(const ScanMail*)h->pin_mail;
+            h->n_ends = mail.total_ends;
+            if (mail.total_ends + 4 <= h->cap) break;
+            if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow");
+            want = mail.total_ends + 4096;                             // rare: rerun with the exact size
         }
-        e2s_launch_scan_fix(a.n_tiles, (const unsigned long long*)h->d_tile_fix, (const unsigned long long*)h->d_tile_fix_end,
-                            (const unsigned long long*)h->d_starts, h->d_lens, h->cap, a.flags, (unsigned long long*)h->d_wrap,
-                            h->d_words + 12, h->stream);
-        CK(hipEventRecord(h->ev[1], h->stream));
-        e2s_launch_scan_mail(a, h->d_words, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, h->stream);
-        CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
-        CK(hipStreamSynchronize(h->stream));
-        CK(hipGetLastError());
-        mail = *(const ScanMail*)h->pin_mail;
-        if (mail.err & E2S_DEVERR_SPIN) return fail(h, E2S_ERR_SPIN_TIMEOUT, "look-back wait expired");
-        h->n_ends = mail.total_ends;
-        if (mail.total_ends + 4 <= h->cap) break;
-        if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow");
-        want = mail.total_ends + 4096;                             // rare: rerun with the exact size
     }
     h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
     h->tail_lcp = mail.tail_lcp; h->tail_prev_lcp = mail.tail_prev_lcp;
@@ -383,6 +456,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     h->tm.scan_bytes_written = h->n_ends * 10;
 
     // records whose uint16_t length wrapped: the per-cluster pass must take them from the record list
+    // (addresses into d_starts/d_lens: ranks for the contiguous layout, segment slots for the segmented one)
     h->wrap_ranks.clear(); h->wrap_overflow = wrap_n > E2S_WRAP_CAP; h->first_wrapped = false;
     if (wrap_n && !h->wrap_overflow) {
         h->wrap_ranks.resize(wrap_n);
@@ -496,10 +570,19 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     if (pl.patch_first) h->first_wrapped = h->first_end_pos != E2S_NONE && h->first_end_pos - pl.first_start + 1 >= 65536;
     h->n_rec = h->n_ends;
     h->n_closed = h->n_ends;
-    if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
-    if (pl.patch_first || pl.n_tail)
-        e2s_launch_apply_plan((unsigned long long*)h->d_starts, h->d_lens, pl.patch_first, pl.first_start, pl.first_len, h->n_ends,
-                              pl.n_tail, pl.tail_start[0], pl.tail_len[0], pl.tail_start[1], pl.tail_len[1], h->stream);
+    if (h->segmented) {
+        // record 0 lives at the head of the first non-empty segment; the tail records stay on the host
+        // (hist and the per-cluster pass take them from the plan, records_contiguous() appends them)
+        if (pl.patch_first && h->first_rec_addr != E2S_NONE)
+            e2s_launch_apply_plan((unsigned long long*)h->d_starts + h->first_rec_addr, h->d_lens + h->first_rec_addr, 1, pl.first_start,
+                                  pl.first_len, 0, 0, 0, 0, 0, 0, h->stream);
+        h->compact_valid = false;
+    } else {
+        if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
+        if (pl.patch_first || pl.n_tail)
+            e2s_launch_apply_plan((unsigned long long*)h->d_starts, h->d_lens, pl.patch_first, pl.first_start, pl.first_len, h->n_ends,
+                                  pl.n_tail, pl.tail_start[0], pl.tail_len[0], pl.tail_start[1], pl.tail_len[1], h->stream);
+    }
     h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
     h->plan = pl;
     h->stitched = true;
@@ -526,8 +609,11 @@ extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records,
     std::vector<uint64_t> s(h->n_rec);
     std::vector<uint16_t> l(h->n_rec);
     if (h->n_rec) {
-        CK(hipMemcpy(s.data(), h->d_starts, h->n_rec * 8, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(l.data(), h->d_lens, h->n_rec * 2, hipMemcpyDeviceToHost));
+        const uint64_t* ds; const uint16_t* dl;
+        int rc = records_contiguous(h, &ds, &dl);
+        if (rc) return rc;
+        CK(hipMemcpy(s.data(), ds, h->n_rec * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(l.data(), dl, h->n_rec * 2, hipMemcpyDeviceToHost));
     }
     uint64_t w = 0;
     uint8_t* o = (uint8_t*)out;
@@ -564,7 +650,8 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
         CK(hipMemcpy(h->d_lens, l.data(), n_records * 2, hipMemcpyHostToDevice));
     }
     h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;
-    h->min_len = 0;
+    h->min_len = 0; h->segmented = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};
+    h->wrap_ranks.clear(); h->wrap_overflow = false; h->first_wrapped = false;
     h->scanned = true; h->stitched = true; h->records_from_file = true;
     return E2S_OK;
 }
@@ -577,9 +664,16 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     uint64_t* dh = h->d_scalars + 8;
     CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 4) * 8, h->stream));
     CK(hipEventRecord(h->ev[4], h->stream));
-    if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
-    CK(hipEventRecord(h->ev[5], h->stream));
-    if (h->n_rec) e2s_launch_hist_tail(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
+    if (h->segmented) {
+        if (h->n_ends) e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, (unsigned long long*)dh, h->stream);
+        CK(hipEventRecord(h->ev[5], h->stream));
+        if (h->n_ends) e2s_launch_hist_tail_seg(h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len,
+                                                (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
+    } else {
+        if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
+        CK(hipEventRecord(h->ev[5], h->stream));
+        if (h->n_rec) e2s_launch_hist_tail(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
+    }
     uint64_t* buf = (uint64_t*)(h->pin_mail + 256);
     CK(hipMemcpyAsync(buf, dh, (E2S_MAX_CLUST_LEN + 4) * 8, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
@@ -589,6 +683,15 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     out->n_records = buf[E2S_MAX_CLUST_LEN + 1];
     out->n_bases = buf[E2S_MAX_CLUST_LEN + 2];
     out->last_len = out->n_records ? buf[E2S_MAX_CLUST_LEN + 3] : 0;      // the record the reference counts twice (H4)
+    if (h->segmented) {                                                     // the EOF tail records live in the stitch plan
+        for (uint32_t t = 0; t < h->plan.n_tail; ++t) {
+            const int l = h->plan.tail_len[t];
+            if (l >= h->min_len) {
+                out->n_records++; out->n_bases += (uint64_t)l; out->last_len = (uint64_t)l;
+                if (l <= E2S_MAX_CLUST_LEN) out->freq[l]++;
+            }
+        }
+    }
     return E2S_OK;
 }
 
@@ -773,7 +876,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             e2s_launch_flagged_lists(a, (const unsigned long long*)(h->d_scalars + 2), d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
             CK(hipEventRecord(h->ev[7], h->stream));
         } else {
-            a.starts = h->d_starts; a.lens = h->d_lens; a.n_rec = h->n_rec; a.key_is_start = 0;
+            { const uint64_t* ds; const uint16_t* dl; int rc = records_contiguous(h, &ds, &dl); if (rc) return rc; a.starts = ds; a.lens = dl; }
+            a.n_rec = h->n_rec; a.key_is_start = 0;
             CK(hipEventRecord(h->ev[6], h->stream));
             if (h->n_rec) e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
             CK(hipEventRecord(h->ev[4], h->stream));

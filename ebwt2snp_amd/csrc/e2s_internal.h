@@ -10,6 +10,7 @@
 // device-side error bits
 #define E2S_DEVERR_SPIN   1u   // look-back wait expired
 #define E2S_DEVERR_REMOTE 2u   // a cluster's entries are not resident in this shard
+#define E2S_DEVERR_SEGFULL 8u  // an output segment of the segmented scan overflowed (rerun with larger segments)
 #define E2S_DEVERR_DENSE  4u   // a 4096-entry window holds more clusters than the LDS slots (fall back)
 
 // a.flags[] slots written by k_shard_flags
@@ -49,9 +50,31 @@ struct ScanArgs {
     uint32_t* tailv;
 };
 
+// ---- segmented scan (scan_mode 0): each persistent block owns a contiguous range of tiles and writes the
+// records that END in it into its own output segment; nothing is exchanged between blocks during the scan.
+struct SegDesc {                 // per block, written by k_scan_seg
+    uint32_t count;              // records in the segment
+    uint32_t first_unknown;      // record 0's start lies before the block's range (cluster continues from earlier)
+    uint32_t open_after;         // a cluster is open after the block's last entry
+    uint32_t overflow;           // the segment was too small
+    uint64_t open_start;         // its start if it lies in this block's range, else ~0
+    uint64_t first_end_pos;      // SA position of the block's first end (valid if count > 0)
+};
+
+struct SegArgs {
+    const void* lcp; uint64_t n_prov, prov_lo; uint32_t prov_is_global0;
+    uint64_t own_lo, end_hi, start_hi;
+    uint32_t k_u32, kb, hge;
+    uint64_t n_tiles; uint32_t tiles_per_block; uint32_t n_blocks;
+    uint64_t* starts; uint16_t* lens; uint32_t seg_cap;        // segment b = [b*seg_cap, (b+1)*seg_cap)
+    SegDesc* desc;
+    unsigned long long* wrap_list; uint32_t* wrap_count;        // addresses (b*seg_cap + i) of records with true length >= 65536
+};
+
 // everything the host needs after a scan, gathered by k_scan_mail so that ONE small download suffices
 struct ScanMail {
     uint64_t total_ends, first_end_pos, open_start, last_end_start;
+    uint64_t first_rec_addr, last_rec_addr;                  // where record 0 / the last record live (segmented storage)
     uint32_t begins_inside, open_after, end_before_last, err;
     uint32_t wrap_count, first_len_prov, tail_lcp, tail_prev_lcp;
     uint32_t last_text, last_suff, last_lcp, last_bwt;      // the last provided entry (EOF phantom model)
@@ -109,6 +132,14 @@ void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* t
                          const unsigned long long* starts, uint16_t* lens, unsigned long long cap, const uint32_t* flags,
                          unsigned long long* wrap_list, uint32_t* wrap_count, hipStream_t st);
 void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st);
+int  e2s_scan_seg_resident_blocks(int xb);
+void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st);
+void e2s_launch_seg_fix(const SegArgs& a, const uint32_t* flags, const uint32_t* tailv, unsigned long long* seg_off, uint32_t* err,
+                        const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, hipStream_t st);
+void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, unsigned long long* out_starts, uint16_t* out_lens, hipStream_t st);
+void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out, hipStream_t st);
+void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len,
+                              unsigned long long* out_last_len, hipStream_t st);
 void e2s_launch_scan_mail(const ScanArgs& a, const uint32_t* words, const uint8_t* bwt, const void* pos, const void* da,
                           int xb, int yb, int zb, ScanMail* out, hipStream_t st);
 void e2s_launch_apply_plan(unsigned long long* starts, uint16_t* lens, uint32_t patch_first, unsigned long long first_start,

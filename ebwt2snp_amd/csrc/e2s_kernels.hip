@@ -306,6 +306,234 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// K1 (scan_mode 0): segmented single-pass scan.  A persistent block owns a CONTIGUOUS range of tiles
+// (one tile = 256 thread-rows = 4 KiB of LCP), walks it front to back carrying its running record count
+// and its open cluster start, and writes the records that END in its range into its own output segment.
+// No block ever waits for another one: the segments are tied together afterwards by k_seg_fix
+// (<= ~1300 descriptors, one thread).  One barrier per tile; the next tile's loads are in flight meanwhile.
+// ----------------------------------------------------------------------------------------------
+constexpr u32 SEG_CLOSED = 0xFFFFFFFFu, SEG_NOEVENT = 0xFFFFFFFEu, SEG_UNKNOWN = 0xFFFFFFFDu;
+
+// clean lane-MSB mask of one 16-byte row -> (16/X)-bit compact mask, bit e = entry e
+template <int X> __device__ __forceinline__ u32 row_compact(const u32* m) {
+    if (X == 1) {
+        u32 r = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) r |= ((((m[w] >> 7) | (m[w] >> 14)) | ((m[w] >> 21) | (m[w] >> 28))) & 15u) << (4 * w);
+        return r;
+    } else if (X == 2) {
+        u32 r = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) r |= (((m[w] >> 15) & 1u) | ((m[w] >> 30) & 2u)) << (2 * w);
+        return r;
+    } else {
+        return (m[0] >> 31) | ((m[1] >> 31) << 1) | ((m[2] >> 31) << 2) | ((m[3] >> 31) << 3);
+    }
+}
+
+template <int X>
+__global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
+    constexpr int EPT = 16 / X;
+    constexpr int TILE = 256 * EPT;
+    constexpr int PRE = (X == 4) ? 2 : 1;
+    constexpr int EPW = Swar<X>::EPW;
+    constexpr int NW = PRE + 5;
+    __shared__ u32 s_wtot[2][4], s_wcarry[2][4];
+    __shared__ u32 s_run[2], s_open[2];
+    __shared__ u32 s_in0, s_unknown;
+    __shared__ u64 s_first_end;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 b = blockIdx.x;
+    const u64 t0 = (u64)b * a.tiles_per_block;
+    const u64 t1 = min(t0 + (u64)a.tiles_per_block, a.n_tiles);
+    const uint8_t* base = (const uint8_t*)a.lcp;
+    const int64_t n_prov = (int64_t)a.n_prov;
+    const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
+    const u64 g_range = a.prov_lo + t0 * TILE;                  // SA position of the range's first entry
+    const u64 seg = (u64)b * a.seg_cap;
+
+    auto seg_load = [&](u64 tile, u32* W) {
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * EPT;
+        if (i0 >= PRE * EPW && i0 + EPT + EPW <= n_prov) {
+            const uint4 v = *(const uint4*)(base + i0 * X);
+            W[PRE + 0] = v.x; W[PRE + 1] = v.y; W[PRE + 2] = v.z; W[PRE + 3] = v.w;
+#pragma unroll
+            for (int p = 0; p < PRE; ++p) W[p] = *(const u32*)(base + i0 * X - 4 * (PRE - p));
+            W[PRE + 4] = *(const u32*)(base + i0 * X + 16);
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                u32 v = 0;
+#pragma unroll
+                for (int bt = 0; bt < 4; ++bt) {
+                    const int64_t byte = i0 * X + (int64_t)(w - PRE) * 4 + bt;
+                    if (byte >= 0 && byte < n_prov * X) v |= (u32)base[byte] << (8 * bt);
+                }
+                W[w] = v;
+            }
+        }
+    };
+
+    if (tid == 0) { s_run[0] = 0; s_open[0] = SEG_UNKNOWN; s_in0 = 0; s_unknown = 0; s_first_end = ~0ull; }
+    u32 W[NW], Wn[NW];
+    if (t0 < t1) seg_load(t0, W);
+    u32 par = 0;
+    for (u64 tile = t0; tile < t1; ++tile, par ^= 1u) {
+        if (tile + 1 < t1) seg_load(tile + 1, Wn);              // in flight while this tile is processed
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * EPT;
+        RowFlags F;
+        row_flags<X>(W, a.kb, a.hge, F);
+        if (a.prov_is_global0 && i0 == 0) patch_global0<X>(W, a.k_u32, a.hge, F);
+        if (!(i0 >= own_lo && i0 + EPT <= end_hi)) {
+            u32 m[4];
+            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, end_hi - i0)), m);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) F.end[w] &= m[w];
+        }
+        if (!(i0 >= own_lo && i0 + EPT <= start_hi)) {
+            u32 m[4];
+            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, start_hi - i0)), m);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) F.start[w] &= m[w];
+        }
+        const u32 END = row_compact<X>(F.end), ST = row_compact<X>(F.start);
+        if (tile == t0 && tid == 0) {
+            // does the range begin inside a cluster?  open(first) && !start(first)
+            constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
+            const bool ge0 = a.hge != 0 && (W[PRE] & LM) >= a.k_u32;
+            s_in0 = (ge0 && !(ST & 1u)) ? 1u : 0u;
+        }
+        const u32 cnt = (u32)__popc(END);
+        const u32 inc = wave_incl_scan(cnt);
+        u32 ev = END | ST;
+        const u32 base_off = (u32)((tile - t0) * TILE) + tid * EPT;   // offset from the range's first entry
+        // the open start this thread-row hands on: its last event (a start precedes an end at one position)
+        u32 co = SEG_NOEVENT;
+        if (ev) {
+            const int top = 31 - __clz(ev);
+            co = ((END >> top) & 1u) ? SEG_CLOSED : base_off + (u32)top;
+        }
+        const u64 evm = __ballot(ev != 0);
+        const u64 below = evm & ((1ull << lane) - 1ull);
+        const u32 got = (u32)__shfl((int)co, below ? 63 - __clzll(below) : (int)lane);   // all lanes take part
+        u32 ci = below ? got : SEG_NOEVENT;
+        const u32 wlast = evm ? (u32)__builtin_amdgcn_readlane((int)co, 63 - __clzll(evm)) : SEG_NOEVENT;
+        if (lane == 63) s_wtot[par][wave] = inc;
+        if (lane == 0) s_wcarry[par][wave] = wlast;
+        __syncthreads();
+        u32 pre = inc - cnt, tile_total = 0, tile_carry = SEG_NOEVENT, wave_ci = SEG_NOEVENT;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 v = s_wtot[par][w], c = s_wcarry[par][w];
+            if (w < (int)wave) { pre += v; if (c != SEG_NOEVENT) wave_ci = c; }
+            tile_total += v;
+            if (c != SEG_NOEVENT) tile_carry = c;
+        }
+        const u32 run = s_run[par], open_in = s_open[par];
+        if (ci == SEG_NOEVENT) ci = (wave_ci != SEG_NOEVENT) ? wave_ci : open_in;
+        if (tid == 0) { s_run[par ^ 1u] = run + tile_total; s_open[par ^ 1u] = (tile_carry != SEG_NOEVENT) ? tile_carry : open_in; }
+        // emit
+        u32 rk = run + pre, pend = ci;
+        while (ev) {
+            const int bit = __ffs(ev) - 1;
+            ev &= ev - 1;
+            const u32 off = base_off + (u32)bit;
+            if ((ST >> bit) & 1u) {
+                if (rk < a.seg_cap) a.starts[seg + rk] = g_range + off;
+                pend = off;
+            }
+            if ((END >> bit) & 1u) {
+                if (rk < a.seg_cap) {
+                    if (pend < SEG_UNKNOWN) {
+                        const u32 len = off - pend + 1u;
+                        a.lens[seg + rk] = (uint16_t)len;
+                        if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
+                    } else {
+                        a.lens[seg + rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
+                        s_unknown = 1;
+                    }
+                }
+                if (rk == 0) s_first_end = g_range + off;
+                ++rk;
+                pend = SEG_CLOSED;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) W[w] = Wn[w];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const u32 count = s_run[par], open = s_open[par];
+        SegDesc d;
+        d.count = min(count, a.seg_cap);
+        d.overflow = count > a.seg_cap ? 1u : 0u;
+        d.first_unknown = s_unknown;
+        d.first_end_pos = s_first_end;
+        if (open == SEG_UNKNOWN) { d.open_after = (t0 < t1) ? s_in0 : 0u; d.open_start = ~0ull; }   // no event at all
+        else if (open == SEG_CLOSED) { d.open_after = 0; d.open_start = ~0ull; }
+        else { d.open_after = 1; d.open_start = g_range + open; }
+        a.desc[b] = d;
+    }
+}
+
+// One thread ties the segments together: record offsets, the records whose start lies in an earlier block,
+// and the ScanMail the host downloads.
+__global__ void k_seg_fix(SegArgs a, const u32* flags, const u32* tailv, u64* seg_off, u32* err,
+                          const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ScanMail m;
+    u64 run = 0, carry = ~0ull, first_addr = ~0ull, last_addr = ~0ull, first_end = ~0ull;
+    u32 e = 0;
+    for (u32 b = 0; b < a.n_blocks; ++b) {
+        const SegDesc d = a.desc[b];
+        seg_off[b] = run;
+        if (d.overflow) e |= E2S_DEVERR_SEGFULL;
+        const u64 seg = (u64)b * a.seg_cap;
+        if (d.count) {
+            if (first_addr == ~0ull) { first_addr = seg; first_end = d.first_end_pos; }
+            last_addr = seg + d.count - 1;
+            if (d.first_unknown && carry != ~0ull) {              // the cluster began in an earlier block of this shard
+                const u64 true_len = d.first_end_pos - carry + 1;
+                a.starts[seg] = carry;
+                a.lens[seg] = (uint16_t)(true_len & 0xFFFFull);
+                if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
+            }
+        }
+        if (!d.open_after) carry = ~0ull;
+        else if (d.open_start != ~0ull) carry = d.open_start;     // else: inside one cluster throughout, carry passes through
+        run += d.count;
+    }
+    seg_off[a.n_blocks] = run;
+    m.total_ends = run;
+    m.first_end_pos = first_end;
+    m.first_rec_addr = first_addr; m.last_rec_addr = last_addr;
+    m.begins_inside = flags[E2S_FLAG_BEGINS_INSIDE];
+    m.open_after = flags[E2S_FLAG_OPEN_AFTER];
+    m.end_before_last = flags[E2S_FLAG_END_BEFORE_LAST];
+    m.err = e | *err;
+    m.wrap_count = *a.wrap_count;
+    m.tail_lcp = tailv[0]; m.tail_prev_lcp = tailv[1];
+    m.open_start = (m.open_after && carry != ~0ull) ? carry : ~0ull;
+    m.last_end_start = (run > 0 && !(run == 1 && m.begins_inside)) ? a.starts[last_addr] : ~0ull;
+    m.first_len_prov = run > 0 ? a.lens[first_addr] : 0u;
+    const u64 li = a.n_prov - 1;
+    auto ld = [&](const void* p, int w) -> u32 {
+        if (!p) return 0u;
+        return w == 1 ? (u32)((const uint8_t*)p)[li] : w == 2 ? (u32)((const uint16_t*)p)[li] : ((const u32*)p)[li];
+    };
+    m.last_text = ld(da, yb); m.last_suff = ld(pos, zb); m.last_lcp = ld(a.lcp, xb); m.last_bwt = bwt ? (u32)bwt[li] : 0u;
+    *out = m;
+}
+
+// segments -> contiguous record arrays (only for consumers that index records by rank)
+__global__ __launch_bounds__(256) void k_seg_compact(SegArgs a, const u64* seg_off, u64* out_starts, uint16_t* out_lens) {
+    const u32 b = blockIdx.x;
+    const u32 n = a.desc[b].count;
+    const u64 src = (u64)b * a.seg_cap, dst = seg_off[b];
+    for (u32 i = threadIdx.x; i < n; i += 256) { out_starts[dst + i] = a.starts[src + i]; out_lens[dst + i] = a.lens[src + i]; }
+}
+
 // one thread per tile: finish the record whose start lies in an earlier tile.  Records whose true length
 // reaches 65536 (the reference's uint16_t length wraps, ebwt2clust.cpp:104) are listed for the per-cluster pass.
 __global__ void k_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* tile_fix_end, const u64* starts, uint16_t* lens, u64 cap,
@@ -454,6 +682,44 @@ __global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int m
     __syncthreads();
     for (int i = threadIdx.x; i <= E2S_MAX_CLUST_LEN_K; i += blockDim.x) if (s_freq[i]) atomicAdd(&out[i], (u64)s_freq[i]);
     if (threadIdx.x == 0) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
+}
+
+// the same over the segmented record storage of scan_mode 0 (one block per segment, 32 histogram replicas in
+// LDS: cluster lengths concentrate on a few values, a single copy serialises on the hot bins)
+__global__ __launch_bounds__(256) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, int min_len, u64* out) {
+    constexpr int REP = 32, NB = E2S_MAX_CLUST_LEN_K + 1;
+    __shared__ u32 s_freq[REP][NB + 1];
+    __shared__ u64 s_acc[2];
+    for (int i = threadIdx.x; i < REP * (NB + 1); i += 256) (&s_freq[0][0])[i] = 0;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 b = blockIdx.x, n = desc[b].count, rep = threadIdx.x & (REP - 1);
+    const uint16_t* p = lens + (u64)b * seg_cap;
+    u64 nrec = 0, nb = 0;
+    for (u32 i = threadIdx.x; i < n; i += 256) {
+        const int l = p[i];
+        if (l >= min_len) { nrec++; nb += (u64)l; if (l <= E2S_MAX_CLUST_LEN_K) atomicAdd(&s_freq[rep][l], 1u); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nrec += __shfl_xor(nrec, o); nb += __shfl_xor(nb, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd((u64*)&s_acc[0], nrec); atomicAdd((u64*)&s_acc[1], nb); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += 256) {
+        u32 v = 0;
+#pragma unroll
+        for (int r = 0; r < REP; ++r) v += s_freq[r][i];
+        if (v) atomicAdd(&out[i], (u64)v);
+    }
+    if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
+}
+__global__ void k_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u64 v = 0; bool found = false;
+    for (u32 b = n_blocks; b-- > 0 && !found;) {
+        const uint16_t* p = lens + (u64)b * seg_cap;
+        for (u32 i = desc[b].count; i-- > 0;) if ((int)p[i] >= min_len) { v = p[i]; found = true; break; }
+    }
+    *out_last_len = v;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -960,6 +1226,7 @@ __global__ void k_unpack_gesa(const uint8_t* src, u64 n, int yb_file, int zb_fil
 // ----------------------------------------------------------------------------------------------
 // launchers (called from e2s_capi.cpp through e2s_internal.h)
 // ----------------------------------------------------------------------------------------------
+static int resident_blocks(const void* fn, int threads, size_t dyn_lds);
 template <int X> static void launch_scan_x(const ScanArgs& a, int mode, hipStream_t st) {
     const dim3 grid((unsigned)a.n_tiles), blk(SCAN_BLK);
     if (mode == 0) hipLaunchKernelGGL((k_scan<X, 0>), grid, blk, 0, st, a);
@@ -968,6 +1235,29 @@ template <int X> static void launch_scan_x(const ScanArgs& a, int mode, hipStrea
 }
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st) {
     if (xb == 1) launch_scan_x<1>(a, mode, st); else if (xb == 2) launch_scan_x<2>(a, mode, st); else launch_scan_x<4>(a, mode, st);
+}
+int e2s_scan_seg_resident_blocks(int xb) {
+    const void* fn = xb == 1 ? (const void*)k_scan_seg<1> : xb == 2 ? (const void*)k_scan_seg<2> : (const void*)k_scan_seg<4>;
+    return resident_blocks(fn, 256, 0);
+}
+void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
+    const dim3 grid(a.n_blocks), blk(256);
+    if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1>), grid, blk, 0, st, a);
+    else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_scan_seg<4>), grid, blk, 0, st, a);
+}
+void e2s_launch_seg_fix(const SegArgs& a, const u32* flags, const u32* tailv, u64* seg_off, u32* err, const uint8_t* bwt, const void* pos,
+                        const void* da, int xb, int yb, int zb, ScanMail* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(64), 0, st, a, flags, tailv, seg_off, err, bwt, pos, da, xb, yb, zb, out);
+}
+void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_starts, uint16_t* out_lens, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, out_starts, out_lens);
+}
+void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_hist_seg, dim3(n_blocks), dim3(256), 0, st, lens, desc, seg_cap, min_len, out);
+}
+void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len, hipStream_t st) {
+    hipLaunchKernelGGL(k_hist_tail_seg, dim3(1), dim3(64), 0, st, lens, desc, seg_cap, n_blocks, min_len, out_last_len);
 }
 void e2s_launch_tile_scan(const u32* cnt, u64* prefix, u64 n, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, n);
