@@ -374,6 +374,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
         sa.tiles_per_block = (uint32_t)((sa.n_tiles + nb - 1) / nb);
         nb = (sa.n_tiles + sa.tiles_per_block - 1) / sa.tiles_per_block;
+        if (nb > 4096) return fail(h, E2S_ERR_STATE, "more persistent blocks than k_seg_fix handles");
         sa.n_blocks = (uint32_t)nb;
         if (nb + 1 > h->seg_blocks_cap) {
             hipFree(h->d_seg_desc); hipFree(h->d_seg_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->seg_blocks_cap = 0;

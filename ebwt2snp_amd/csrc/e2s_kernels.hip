@@ -477,53 +477,94 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
     }
 }
 
-// One thread ties the segments together: record offsets, the records whose start lies in an earlier block,
-// and the ScanMail the host downloads.
-__global__ void k_seg_fix(SegArgs a, const u32* flags, const u32* tailv, u64* seg_off, u32* err,
-                          const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    ScanMail m;
-    u64 run = 0, carry = ~0ull, first_addr = ~0ull, last_addr = ~0ull, first_end = ~0ull;
-    u32 e = 0;
-    for (u32 b = 0; b < a.n_blocks; ++b) {
+// One block ties the segments together: record offsets (exclusive scan of the per-block counts), the records
+// whose start lies in an earlier block, and the ScanMail the host downloads.
+constexpr int SEGFIX_MAX = 4096;             // persistent blocks of the scan (256 CUs x <= 8): far below
+__global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, const u32* tailv, u64* seg_off, u32* err,
+                                                  const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out) {
+    __shared__ u32 s_cnt[SEGFIX_MAX];
+    __shared__ u64 s_open[SEGFIX_MAX];       // open_start | PASS (inside one cluster throughout) | NONE (closed after the block)
+    __shared__ u32 s_part[1024];
+    __shared__ u32 s_first, s_last, s_err;
+    const u64 NONE = ~0ull, PASS = ~0ull - 1;
+    const u32 tid = threadIdx.x, nb = a.n_blocks;
+    if (tid == 0) { s_first = 0xFFFFFFFFu; s_last = 0; s_err = 0; }
+    __syncthreads();
+    for (u32 b = tid; b < nb; b += 1024) {
         const SegDesc d = a.desc[b];
-        seg_off[b] = run;
-        if (d.overflow) e |= E2S_DEVERR_SEGFULL;
-        const u64 seg = (u64)b * a.seg_cap;
-        if (d.count) {
-            if (first_addr == ~0ull) { first_addr = seg; first_end = d.first_end_pos; }
-            last_addr = seg + d.count - 1;
-            if (d.first_unknown && carry != ~0ull) {              // the cluster began in an earlier block of this shard
-                const u64 true_len = d.first_end_pos - carry + 1;
-                a.starts[seg] = carry;
-                a.lens[seg] = (uint16_t)(true_len & 0xFFFFull);
-                if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
-            }
-        }
-        if (!d.open_after) carry = ~0ull;
-        else if (d.open_start != ~0ull) carry = d.open_start;     // else: inside one cluster throughout, carry passes through
-        run += d.count;
+        s_cnt[b] = d.count;
+        s_open[b] = !d.open_after ? NONE : (d.open_start != NONE ? d.open_start : PASS);
+        if (d.overflow) atomicOr(&s_err, E2S_DEVERR_SEGFULL);
+        if (d.count) { atomicMin(&s_first, b); atomicMax(&s_last, b); }
     }
-    seg_off[a.n_blocks] = run;
-    m.total_ends = run;
-    m.first_end_pos = first_end;
-    m.first_rec_addr = first_addr; m.last_rec_addr = last_addr;
-    m.begins_inside = flags[E2S_FLAG_BEGINS_INSIDE];
-    m.open_after = flags[E2S_FLAG_OPEN_AFTER];
-    m.end_before_last = flags[E2S_FLAG_END_BEFORE_LAST];
-    m.err = e | *err;
-    m.wrap_count = *a.wrap_count;
-    m.tail_lcp = tailv[0]; m.tail_prev_lcp = tailv[1];
-    m.open_start = (m.open_after && carry != ~0ull) ? carry : ~0ull;
-    m.last_end_start = (run > 0 && !(run == 1 && m.begins_inside)) ? a.starts[last_addr] : ~0ull;
-    m.first_len_prov = run > 0 ? a.lens[first_addr] : 0u;
-    const u64 li = a.n_prov - 1;
-    auto ld = [&](const void* p, int w) -> u32 {
-        if (!p) return 0u;
-        return w == 1 ? (u32)((const uint8_t*)p)[li] : w == 2 ? (u32)((const uint16_t*)p)[li] : ((const u32*)p)[li];
+    __syncthreads();
+    // exclusive scan of the counts: each thread owns a contiguous chunk
+    const u32 per = (nb + 1023) / 1024, lo = min(nb, tid * per), hi = min(nb, lo + per);
+    u32 sum = 0;
+    for (u32 b = lo; b < hi; ++b) sum += s_cnt[b];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid < 64) {                           // 1024 partials: 16 per lane, wave scan
+        u32 loc = 0;
+        for (int i = 0; i < 16; ++i) loc += s_part[tid * 16 + i];
+        const u32 inc = wave_incl_scan(loc);
+        u32 run = inc - loc;
+        for (int i = 0; i < 16; ++i) { const u32 v = s_part[tid * 16 + i]; s_part[tid * 16 + i] = run; run += v; }
+    }
+    __syncthreads();
+    u64 run = s_part[tid];
+    for (u32 b = lo; b < hi; ++b) {
+        seg_off[b] = run;
+        run += s_cnt[b];
+    }
+    if (hi == nb && lo < nb) seg_off[nb] = run;
+    if (nb == 0 && tid == 0) seg_off[0] = 0;
+    // the open start a block inherits: nearest earlier block that is not inside one cluster throughout
+    auto carry_into = [&](u32 b) -> u64 {
+        for (u32 q = b; q-- > 0;) { const u64 v = s_open[q]; if (v != PASS) return v; }
+        return NONE;
     };
-    m.last_text = ld(da, yb); m.last_suff = ld(pos, zb); m.last_lcp = ld(a.lcp, xb); m.last_bwt = bwt ? (u32)bwt[li] : 0u;
-    *out = m;
+    for (u32 b = tid; b < nb; b += 1024) {
+        if (!s_cnt[b]) continue;
+        const SegDesc d = a.desc[b];
+        if (!d.first_unknown) continue;
+        const u64 carry = carry_into(b);
+        if (carry == NONE) continue;                                // begins in an earlier shard: e2s_stitch
+        const u64 seg = (u64)b * a.seg_cap;
+        const u64 true_len = d.first_end_pos - carry + 1;
+        a.starts[seg] = carry;
+        a.lens[seg] = (uint16_t)(true_len & 0xFFFFull);
+        if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ScanMail m;
+        u64 total = 0;
+        if (nb) total = seg_off[nb];
+        const bool any = s_first != 0xFFFFFFFFu;
+        const u64 first_addr = any ? (u64)s_first * a.seg_cap : NONE;
+        const u64 last_addr = any ? (u64)s_last * a.seg_cap + s_cnt[s_last] - 1 : NONE;
+        m.total_ends = total;
+        m.first_end_pos = any ? a.desc[s_first].first_end_pos : NONE;
+        m.first_rec_addr = first_addr; m.last_rec_addr = last_addr;
+        m.begins_inside = flags[E2S_FLAG_BEGINS_INSIDE];
+        m.open_after = flags[E2S_FLAG_OPEN_AFTER];
+        m.end_before_last = flags[E2S_FLAG_END_BEFORE_LAST];
+        m.err = s_err | *err;
+        m.wrap_count = *a.wrap_count;
+        m.tail_lcp = tailv[0]; m.tail_prev_lcp = tailv[1];
+        const u64 carry = carry_into(nb);
+        m.open_start = (m.open_after && carry != NONE) ? carry : NONE;
+        m.last_end_start = (total > 0 && !(total == 1 && m.begins_inside)) ? a.starts[last_addr] : NONE;
+        m.first_len_prov = total > 0 ? a.lens[first_addr] : 0u;
+        const u64 li = a.n_prov - 1;
+        auto ld = [&](const void* p, int w) -> u32 {
+            if (!p) return 0u;
+            return w == 1 ? (u32)((const uint8_t*)p)[li] : w == 2 ? (u32)((const uint16_t*)p)[li] : ((const u32*)p)[li];
+        };
+        m.last_text = ld(da, yb); m.last_suff = ld(pos, zb); m.last_lcp = ld(a.lcp, xb); m.last_bwt = bwt ? (u32)bwt[li] : 0u;
+        *out = m;
+    }
 }
 
 // segments -> contiguous record arrays (only for consumers that index records by rank)
@@ -1248,7 +1289,7 @@ void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
 }
 void e2s_launch_seg_fix(const SegArgs& a, const u32* flags, const u32* tailv, u64* seg_off, u32* err, const uint8_t* bwt, const void* pos,
                         const void* da, int xb, int yb, int zb, ScanMail* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(64), 0, st, a, flags, tailv, seg_off, err, bwt, pos, da, xb, yb, zb, out);
+    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, err, bwt, pos, da, xb, yb, zb, out);
 }
 void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_starts, uint16_t* out_lens, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, out_starts, out_lens);
