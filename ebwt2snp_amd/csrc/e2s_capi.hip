@@ -363,7 +363,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
 
     if (scan_mode == 0) {
         // ---- segmented single-pass scan: persistent blocks over contiguous tile ranges ----
-        const uint64_t row_entries = (uint64_t)E2S_SCAN_BLOCK * (16 / h->xb);
+        const uint64_t row_entries = (uint64_t)E2S_SCAN_BLOCK * (E2S_SPAN_BYTES / h->xb);   // entries per tile
         SegArgs sa{};
         sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
         sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;

@@ -5,6 +5,7 @@
 
 #define E2S_SCAN_BLOCK 256
 #define E2S_SCAN_ROWS 4
+#define E2S_SPAN_BYTES 64        // bytes of LCP per thread and tile in the segmented scan
 #define E2S_MAX_CLUST_LEN_K 150
 
 // device-side error bits

@@ -315,30 +315,27 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
 // ----------------------------------------------------------------------------------------------
 constexpr u32 SEG_CLOSED = 0xFFFFFFFFu, SEG_NOEVENT = 0xFFFFFFFEu, SEG_UNKNOWN = 0xFFFFFFFDu;
 
-// clean lane-MSB mask of one 16-byte row -> (16/X)-bit compact mask, bit e = entry e
-template <int X> __device__ __forceinline__ u32 row_compact(const u32* m) {
-    if (X == 1) {
-        u32 r = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) r |= ((((m[w] >> 7) | (m[w] >> 14)) | ((m[w] >> 21) | (m[w] >> 28))) & 15u) << (4 * w);
-        return r;
-    } else if (X == 2) {
-        u32 r = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) r |= (((m[w] >> 15) & 1u) | ((m[w] >> 30) & 2u)) << (2 * w);
-        return r;
-    } else {
-        return (m[0] >> 31) | ((m[1] >> 31) << 1) | ((m[2] >> 31) << 2) | ((m[3] >> 31) << 3);
-    }
+// Events of a span in compact form: 2 bits per entry (bit 0 = a cluster starts here, bit 1 = one ends here),
+// 16 entries per 32-bit word.  Built from the clean lane-MSB masks of the span's words.
+template <int X> __device__ __forceinline__ u32 word_events(u32 endm, u32 startm) {
+    const u32 c = endm | (startm >> 1);                     // per lane: top bit = end, next bit = start
+    if (X == 1) return __builtin_amdgcn_ubfe((((c >> 6) & 0x03030303u) * 0x00041041u), 18, 8);   // 4 entries -> 8 bits
+    if (X == 2) return ((c >> 14) & 3u) | ((c >> 28) & 0xCu);                                  // 2 entries -> 4 bits
+    return c >> 30;                                                                             // 1 entry  -> 2 bits
 }
+
+constexpr int SPAN_WORDS = E2S_SPAN_BYTES / 4;               // 16 words = 64 B of LCP per thread and tile
 
 template <int X>
 __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
-    constexpr int EPT = 16 / X;
-    constexpr int TILE = 256 * EPT;
+    constexpr int NR = SPAN_WORDS;
+    constexpr int ES = 4 * NR / X;                           // entries per thread span
+    constexpr int TILE = 256 * ES;
     constexpr int PRE = (X == 4) ? 2 : 1;
     constexpr int EPW = Swar<X>::EPW;
-    constexpr int NW = PRE + 5;
+    constexpr int NW = PRE + NR + 1;
+    constexpr int FB = 2 * EPW;                              // event bits per span word
+    constexpr int NEV = (NR * FB + 31) / 32;                 // event words per span
     __shared__ u32 s_wtot[2][4], s_wcarry[2][4];
     __shared__ u32 s_run[2], s_open[2];
     __shared__ u32 s_in0, s_unknown;
@@ -353,14 +350,20 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
     const u64 g_range = a.prov_lo + t0 * TILE;                  // SA position of the range's first entry
     const u64 seg = (u64)b * a.seg_cap;
 
+    // a thread reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of a wave
+    // cover one 4 KiB stretch between them) plus the words just before and after its span
     auto seg_load = [&](u64 tile, u32* W) {
-        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * EPT;
-        if (i0 >= PRE * EPW && i0 + EPT + EPW <= n_prov) {
-            const uint4 v = *(const uint4*)(base + i0 * X);
-            W[PRE + 0] = v.x; W[PRE + 1] = v.y; W[PRE + 2] = v.z; W[PRE + 3] = v.w;
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * ES;
+        if (i0 >= PRE * EPW && i0 + ES + EPW <= n_prov) {
+            const uint8_t* p = base + i0 * X;
 #pragma unroll
-            for (int p = 0; p < PRE; ++p) W[p] = *(const u32*)(base + i0 * X - 4 * (PRE - p));
-            W[PRE + 4] = *(const u32*)(base + i0 * X + 16);
+            for (int q = 0; q < NR / 4; ++q) {
+                const uint4 v = *(const uint4*)(p + 16 * q);
+                W[PRE + 4 * q + 0] = v.x; W[PRE + 4 * q + 1] = v.y; W[PRE + 4 * q + 2] = v.z; W[PRE + 4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) W[q] = *(const u32*)(p - 4 * (PRE - q));
+            W[PRE + NR] = *(const u32*)(p + 4 * NR);
         } else {
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -381,40 +384,58 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
     u32 par = 0;
     for (u64 tile = t0; tile < t1; ++tile, par ^= 1u) {
         if (tile + 1 < t1) seg_load(tile + 1, Wn);              // in flight while this tile is processed
-        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * EPT;
-        RowFlags F;
-        row_flags<X>(W, a.kb, a.hge, F);
-        if (a.prov_is_global0 && i0 == 0) patch_global0<X>(W, a.k_u32, a.hge, F);
-        if (!(i0 >= own_lo && i0 + EPT <= end_hi)) {
-            u32 m[4];
-            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, end_hi - i0)), m);
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * ES;
+        u32 EV[NEV];
+        {
+            u32 endm[NR], startm[NR];
+            span_flags<X, NR>(W, a.kb, a.hge, endm, startm);
+            if (a.prov_is_global0 && i0 == 0) {
+                RowFlags f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) F.end[w] &= m[w];
-        }
-        if (!(i0 >= own_lo && i0 + EPT <= start_hi)) {
-            u32 m[4];
-            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, start_hi - i0)), m);
+                for (int w = 0; w < 4; ++w) { f.end[w] = endm[w]; f.start[w] = startm[w]; }
+                patch_global0<X>(W, a.k_u32, a.hge, f);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) F.start[w] &= m[w];
+                for (int w = 0; w < 4; ++w) { endm[w] = f.end[w]; startm[w] = f.start[w]; }
+            }
+#pragma unroll
+            for (int g = 0; g < NEV; ++g) EV[g] = 0;
+#pragma unroll
+            for (int w = 0; w < NR; ++w) EV[(w * FB) / 32] |= word_events<X>(endm[w], startm[w]) << ((w * FB) % 32);
         }
-        const u32 END = row_compact<X>(F.end), ST = row_compact<X>(F.start);
+        // restrict to the owned window (only spans that straddle its edges)
+        if (!(i0 >= own_lo && i0 + ES <= end_hi && i0 + ES <= start_hi)) {
+#pragma unroll
+            for (int g = 0; g < NEV; ++g) {
+                u32 keep = 0;
+                for (int f = 0; f < 16; ++f) {
+                    const int64_t e = i0 + g * 16 + f;
+                    if (e >= own_lo && e < start_hi) keep |= 1u << (2 * f);
+                    if (e >= own_lo && e < end_hi) keep |= 2u << (2 * f);
+                }
+                EV[g] &= keep;
+            }
+        }
         if (tile == t0 && tid == 0) {
             // does the range begin inside a cluster?  open(first) && !start(first)
             constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
             const bool ge0 = a.hge != 0 && (W[PRE] & LM) >= a.k_u32;
-            s_in0 = (ge0 && !(ST & 1u)) ? 1u : 0u;
+            s_in0 = (ge0 && !(EV[0] & 1u)) ? 1u : 0u;
         }
-        const u32 cnt = (u32)__popc(END);
+        u32 cnt = 0;
+#pragma unroll
+        for (int g = 0; g < NEV; ++g) cnt += (u32)__popc(EV[g] & 0xAAAAAAAAu);
         const u32 inc = wave_incl_scan(cnt);
-        u32 ev = END | ST;
-        const u32 base_off = (u32)((tile - t0) * TILE) + tid * EPT;   // offset from the range's first entry
-        // the open start this thread-row hands on: its last event (a start precedes an end at one position)
+        const u32 base_off = (u32)((tile - t0) * TILE) + tid * ES;   // offset from the range's first entry
+        // the open start this span hands on: its last event (a start precedes an end at one position)
         u32 co = SEG_NOEVENT;
-        if (ev) {
-            const int top = 31 - __clz(ev);
-            co = ((END >> top) & 1u) ? SEG_CLOSED : base_off + (u32)top;
+#pragma unroll
+        for (int g = 0; g < NEV; ++g) {
+            if (EV[g]) {
+                const int top = 31 - __clz(EV[g]);
+                co = (top & 1) ? SEG_CLOSED : base_off + (u32)(g * 16 + (top >> 1));
+            }
         }
-        const u64 evm = __ballot(ev != 0);
+        const u64 evm = __ballot(co != SEG_NOEVENT);
         const u64 below = evm & ((1ull << lane) - 1ull);
         const u32 got = (u32)__shfl((int)co, below ? 63 - __clzll(below) : (int)lane);   // all lanes take part
         u32 ci = below ? got : SEG_NOEVENT;
@@ -433,30 +454,33 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
         const u32 run = s_run[par], open_in = s_open[par];
         if (ci == SEG_NOEVENT) ci = (wave_ci != SEG_NOEVENT) ? wave_ci : open_in;
         if (tid == 0) { s_run[par ^ 1u] = run + tile_total; s_open[par ^ 1u] = (tile_carry != SEG_NOEVENT) ? tile_carry : open_in; }
-        // emit
+        // emit: one event per iteration, in order
         u32 rk = run + pre, pend = ci;
-        while (ev) {
-            const int bit = __ffs(ev) - 1;
-            ev &= ev - 1;
-            const u32 off = base_off + (u32)bit;
-            if ((ST >> bit) & 1u) {
-                if (rk < a.seg_cap) a.starts[seg + rk] = g_range + off;
-                pend = off;
-            }
-            if ((END >> bit) & 1u) {
-                if (rk < a.seg_cap) {
-                    if (pend < SEG_UNKNOWN) {
-                        const u32 len = off - pend + 1u;
-                        a.lens[seg + rk] = (uint16_t)len;
-                        if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
-                    } else {
-                        a.lens[seg + rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
-                        s_unknown = 1;
+#pragma unroll
+        for (int g = 0; g < NEV; ++g) {
+            u32 ev = EV[g];
+            while (ev) {
+                const int bit = __ffs(ev) - 1;
+                ev &= ev - 1;
+                const u32 off = base_off + (u32)(g * 16 + (bit >> 1));
+                if (!(bit & 1)) {                                   // start
+                    if (rk < a.seg_cap) a.starts[seg + rk] = g_range + off;
+                    pend = off;
+                } else {                                            // end
+                    if (rk < a.seg_cap) {
+                        if (pend < SEG_UNKNOWN) {
+                            const u32 len = off - pend + 1u;
+                            a.lens[seg + rk] = (uint16_t)len;
+                            if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
+                        } else {
+                            a.lens[seg + rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
+                            s_unknown = 1;
+                        }
                     }
+                    if (rk == 0) s_first_end = g_range + off;
+                    ++rk;
+                    pend = SEG_CLOSED;
                 }
-                if (rk == 0) s_first_end = g_range + off;
-                ++rk;
-                pend = SEG_CLOSED;
             }
         }
 #pragma unroll

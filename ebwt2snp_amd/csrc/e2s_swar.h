@@ -44,15 +44,13 @@ template <int X> E2S_HD u32 next_elems(u32 after, u32 cur) {
     return alignbyte(after, cur, X);                 // ({after,cur} >> 8*X)
 }
 
-struct RowFlags { u32 end[4]; u32 start[4]; };
-
-// W[0..PRE-1]: words before the row, W[PRE..PRE+3]: the row, W[PRE+4]: the word after.
-// Returns END/START flags (lane-MSB form) for the 16 bytes of the row, before range masking.
-template <int X>
-E2S_HD void row_flags(const u32* W, u32 kb, u32 hge, RowFlags& f) {
+// W[0..PRE-1]: words before the span, W[PRE..PRE+NR-1]: the span (NR words), W[PRE+NR]: the word after.
+// Returns END/START flags (lane-MSB form) for the span, before range masking.
+template <int X, int NR>
+E2S_HD void span_flags(const u32* W, u32 kb, u32 hge, u32* end, u32* start) {
     constexpr u32 H = Swar<X>::H;
     constexpr int PRE = (X == 4) ? 2 : 1;
-    constexpr int NW = PRE + 5;
+    constexpr int NW = PRE + NR + 1;
     u32 ge[NW], nle[NW];                       // ge: L>=k ; nle: (L[j] >= L[j-1]) i.e. NOT gt(j)
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -68,10 +66,10 @@ E2S_HD void row_flags(const u32* W, u32 kb, u32 hge, RowFlags& f) {
     }
     // end(j)   = ge(j) & ((gt(j) & !gt(j+1)) | !ge(j+1))          ebwt2clust.cpp:98-102
     // start(j) = ge(j) & (!ge(j-1) | end(j-1))                    ebwt2clust.cpp:108,116-120
-    u32 endw[5];
+    u32 endw[NR + 1];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int w = PRE - 1 + i;             // the word before the row, then the row
+    for (int i = 0; i < NR + 1; ++i) {
+        const int w = PRE - 1 + i;             // the word before the span, then the span
         const u32 nle_n = next_elems<X>(nle[w + 1], nle[w]);
         const u32 ge_n = next_elems<X>(ge[w + 1], ge[w]);
         const u32 locmin = ~nle[w] & nle_n;    // gt(j) & !gt(j+1)
@@ -79,12 +77,14 @@ E2S_HD void row_flags(const u32* W, u32 kb, u32 hge, RowFlags& f) {
         endw[i] = ~t & ge[w] & H;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int w = PRE + i;
         const u32 ge_p = prev_elems<X>(ge[w], ge[w - 1]);
         const u32 end_p = prev_elems<X>(endw[i + 1], endw[i]);
-        f.end[i] = endw[i + 1];
-        f.start[i] = ge[w] & ~(ge_p & ~end_p) & H;
+        end[i] = endw[i + 1];
+        start[i] = ge[w] & ~(ge_p & ~end_p) & H;
     }
 }
 
+struct RowFlags { u32 end[4]; u32 start[4]; };
+template <int X> E2S_HD void row_flags(const u32* W, u32 kb, u32 hge, RowFlags& f) { span_flags<X, 4>(W, kb, hge, f.end, f.start); }

@@ -8,9 +8,9 @@
 
 #include "../ebwt2snp_amd/csrc/e2s_swar.h"
 
-template <int X> static int run(unsigned seed, int iters) {
+template <int X, int NR> static int run(unsigned seed, int iters) {
     constexpr int PRE = (X == 4) ? 2 : 1;
-    constexpr int EPT = 16 / X;
+    constexpr int EPT = 4 * NR / X;
     constexpr int EPW = 4 / X;
     constexpr u32 H = Swar<X>::H;
     const u64 lane_max = X == 1 ? 0xFFull : X == 2 ? 0xFFFFull : 0xFFFFFFFFull;
@@ -31,7 +31,7 @@ template <int X> static int run(unsigned seed, int iters) {
             else r = (rand() & 1) ? lane_max - (u64)(rand() % 3) : (u64)(rand() % 3);
             v = r & lane_max;
         }
-        u32 W[PRE + 5];
+        u32 W[PRE + NR + 1];
         memset(W, 0, sizeof(W));
         for (int e = lo; e < hi; ++e) {
             const int idx = e - lo;                       // entry idx in stream
@@ -41,8 +41,8 @@ template <int X> static int run(unsigned seed, int iters) {
         const u32 k32 = (u32)k;
         const u32 hge = (k > lane_max) ? 0u : H;
         const u32 kb = X == 1 ? (k32 & 0xFF) * 0x01010101u : X == 2 ? (k32 & 0xFFFF) * 0x00010001u : k32;
-        RowFlags f;
-        row_flags<X>(W, kb, hge, f);
+        struct { u32 end[NR]; u32 start[NR]; } f;
+        span_flags<X, NR>(W, kb, hge, f.end, f.start);
         auto Lx = [&](int e) -> u64 { return L[e - lo]; };
         auto ge = [&](int e) { return hge != 0 && Lx(e) >= k; };
         auto endf = [&](int e) { return ge(e) && ((Lx(e - 1) > Lx(e) && Lx(e) <= Lx(e + 1)) || !ge(e + 1)); };
@@ -58,13 +58,14 @@ template <int X> static int run(unsigned seed, int iters) {
             }
         }
         // no stray bits outside the lane-MSB positions
-        for (int w = 0; w < 4; ++w) if ((f.end[w] | f.start[w]) & ~H) { if (bad < 5) fprintf(stderr, "stray bits X=%d\n", X); ++bad; }
+        for (int w = 0; w < NR; ++w) if ((f.end[w] | f.start[w]) & ~H) { if (bad < 5) fprintf(stderr, "stray bits X=%d\n", X); ++bad; }
     }
     return bad;
 }
 
 int main() {
-    int bad = run<1>(1, 200000) + run<2>(2, 200000) + run<4>(3, 200000);
+    int bad = run<1, 4>(1, 200000) + run<2, 4>(2, 200000) + run<4, 4>(3, 200000) +
+              run<1, 16>(4, 60000) + run<2, 16>(5, 60000) + run<4, 16>(6, 60000);
     printf("swar_check: %s (%d mismatches)\n", bad ? "FAIL" : "OK", bad);
     return bad ? 1 : 0;
 }
