@@ -319,7 +319,7 @@ constexpr u32 SEG_CLOSED = 0xFFFFFFFFu, SEG_NOEVENT = 0xFFFFFFFEu, SEG_UNKNOWN =
 // 16 entries per 32-bit word.  Built from the clean lane-MSB masks of the span's words.
 template <int X> __device__ __forceinline__ u32 word_events(u32 endm, u32 startm) {
     const u32 c = endm | (startm >> 1);                     // per lane: top bit = end, next bit = start
-    if (X == 1) return __builtin_amdgcn_ubfe((((c >> 6) & 0x03030303u) * 0x00041041u), 18, 8);   // 4 entries -> 8 bits
+    if (X == 1) return __builtin_amdgcn_udot4((c >> 6) & 0x03030303u, 0x40100401u, 0u, false);   // 4 entries -> 8 bits (v_dot4_u32_u8)
     if (X == 2) return ((c >> 14) & 3u) | ((c >> 28) & 0xCu);                                  // 2 entries -> 4 bits
     return c >> 30;                                                                             // 1 entry  -> 2 bits
 }
@@ -353,28 +353,31 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
     // a thread reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of a wave
     // cover one 4 KiB stretch between them) plus the words just before and after its span
     auto seg_load = [&](u64 tile, u32* W) {
-        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * ES;
-        if (i0 >= PRE * EPW && i0 + ES + EPW <= n_prov) {
-            const uint8_t* p = base + i0 * X;
+        const int64_t tl = (int64_t)tile * TILE;
+        if (tl >= PRE * EPW && tl + TILE + EPW <= n_prov) {
+            // interior tile (uniform test): scalar base + 32-bit lane offset
+            const uint8_t* p = base + tl * X;
+            const u32 o = tid * (u32)(4 * NR);
 #pragma unroll
             for (int q = 0; q < NR / 4; ++q) {
-                const uint4 v = *(const uint4*)(p + 16 * q);
+                const uint4 v = *(const uint4*)(p + o + 16 * q);
                 W[PRE + 4 * q + 0] = v.x; W[PRE + 4 * q + 1] = v.y; W[PRE + 4 * q + 2] = v.z; W[PRE + 4 * q + 3] = v.w;
             }
 #pragma unroll
-            for (int q = 0; q < PRE; ++q) W[q] = *(const u32*)(p - 4 * (PRE - q));
-            W[PRE + NR] = *(const u32*)(p + 4 * NR);
-        } else {
+            for (int q = 0; q < PRE; ++q) W[q] = *(const u32*)(p + o - 4 * (PRE - q));
+            W[PRE + NR] = *(const u32*)(p + o + 4 * NR);
+            return;
+        }
+        const int64_t i0 = tl + (int64_t)tid * ES;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                u32 v = 0;
+        for (int w = 0; w < NW; ++w) {                                  // (static indices: the array stays in registers)
+            u32 v = 0;
 #pragma unroll
-                for (int bt = 0; bt < 4; ++bt) {
-                    const int64_t byte = i0 * X + (int64_t)(w - PRE) * 4 + bt;
-                    if (byte >= 0 && byte < n_prov * X) v |= (u32)base[byte] << (8 * bt);
-                }
-                W[w] = v;
+            for (int bt = 0; bt < 4; ++bt) {
+                const int64_t byte = i0 * X + (int64_t)(w - PRE) * 4 + bt;
+                if (byte >= 0 && byte < n_prov * X) v |= (u32)base[byte] << (8 * bt);
             }
+            W[w] = v;
         }
     };
 
@@ -950,10 +953,12 @@ constexpr int FW_NEW = FW_WIN - FW_HALO;     // 3936
 constexpr int FW_SLOTS = 2048;               // clusters per window held in LDS; denser windows raise E2S_DEVERR_DENSE
 constexpr u32 SE_ENDED = 1u << 24, SE_KR = 1u << 25;
 
-// lane-MSB mask (clean: only the top bit of each byte) -> 4-bit compact mask
-__device__ __forceinline__ u32 msb_compact(u32 m) { return (m * 0x00204081u) >> 28; }
+// clean lane-MSB masks of a 16-byte row (bytes are 0x80 or 0) -> 16-bit compact mask, bit e = entry e.
+// v_dot4_u32_u8 with weights 1,2,4,8 | 16,32,64,128 sums 128 * (the 8 mask bits of two words): four dot4 + two ops.
 __device__ __forceinline__ u32 compact16(const u32* m) {
-    return msb_compact(m[0]) | (msb_compact(m[1]) << 4) | (msb_compact(m[2]) << 8) | (msb_compact(m[3]) << 12);
+    const u32 lo = __builtin_amdgcn_udot4(m[1], 0x80402010u, __builtin_amdgcn_udot4(m[0], 0x08040201u, 0u, false), false);
+    const u32 hi = __builtin_amdgcn_udot4(m[3], 0x80402010u, __builtin_amdgcn_udot4(m[2], 0x08040201u, 0u, false), false);
+    return ((hi << 8) | lo) >> 7;
 }
 // lane-wise x == K (K broadcast): top bit of each byte
 __device__ __forceinline__ u32 swar_eq(u32 x, u32 kb) {
@@ -1013,45 +1018,52 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
     // one window's worth of loads: lcp row + edge words, bwt row, da in coalesced order
     // (lane i of load q holds entries wave*1024 + q*256 + 4i .. +3)
     struct FwRegs { u32 W[6]; u32 B[4]; uint4 T[4]; };
+    const u32 wave_u = (u32)__builtin_amdgcn_readfirstlane((int)wave);      // wave-uniform in an SGPR
     auto fw_load = [&](u64 tile, FwRegs& r) {
         const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;
-        const int64_t i0 = win_lo + (int64_t)tid * 16;
-        if (i0 >= 4 && i0 + 20 <= n_prov) {
-            const uint4 v = *(const uint4*)(lcpb + i0);
+        if (win_lo >= 4 && win_lo + FW_WIN + 4 <= n_prov) {
+            // interior window (uniform test): scalar base + 32-bit lane offset for every load
+            const uint8_t* lp = lcpb + win_lo;
+            const uint8_t* bp = bwtb + win_lo;
+            const u32 o = tid * 16u;
+            const uint4 v = *(const uint4*)(lp + o);
             r.W[1] = v.x; r.W[2] = v.y; r.W[3] = v.z; r.W[4] = v.w;
-            r.W[0] = *(const u32*)(lcpb + i0 - 4);
-            r.W[5] = *(const u32*)(lcpb + i0 + 16);
-            const uint4 b = *(const uint4*)(bwtb + i0);
+            r.W[0] = *(const u32*)(lp + o - 4);
+            r.W[5] = *(const u32*)(lp + o + 16);
+            const uint4 b = *(const uint4*)(bp + o);
             r.B[0] = b.x; r.B[1] = b.y; r.B[2] = b.z; r.B[3] = b.w;
-        } else {
+            const u32* tp = a.da + win_lo + (int64_t)wave_u * 1024;
 #pragma unroll
-            for (int w = 0; w < 6; ++w) {
-                u32 v = 0, vb = 0;
+            for (int q = 0; q < 4; ++q) r.T[q] = *(const uint4*)(tp + (u32)(q * 256) + lane * 4u);
+            return;
+        }
+        const int64_t i0 = win_lo + (int64_t)tid * 16;
 #pragma unroll
-                for (int bt = 0; bt < 4; ++bt) {
-                    const int64_t e = i0 + (int64_t)(w - 1) * 4 + bt;
-                    if (e >= 0 && e < n_prov) { v |= (u32)lcpb[e] << (8 * bt); vb |= (u32)bwtb[e] << (8 * bt); }
-                }
-                r.W[w] = v;
-                if (w >= 1 && w <= 4) r.B[w - 1] = vb;
+        for (int w = 0; w < 6; ++w) {                                   // (static indices: the arrays stay in registers)
+            u32 v = 0, vb = 0;
+#pragma unroll
+            for (int bt = 0; bt < 4; ++bt) {
+                const int64_t e = i0 + (int64_t)(w - 1) * 4 + bt;
+                if (e >= 0 && e < n_prov) { v |= (u32)lcpb[e] << (8 * bt); vb |= (u32)bwtb[e] << (8 * bt); }
             }
+            r.W[w] = v;
+            if (w >= 1 && w <= 4) r.B[w - 1] = vb;
         }
         const int64_t wbase = win_lo + (int64_t)wave * 1024;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t e = wbase + q * 256 + (int64_t)lane * 4;
-            if (e >= 0 && e + 4 <= n_prov) r.T[q] = *(const uint4*)(a.da + e);
-            else {
-                uint4 t = make_uint4(0, 0, 0, 0);
-                if (e + 0 >= 0 && e + 0 < n_prov) t.x = a.da[e + 0];
-                if (e + 1 >= 0 && e + 1 < n_prov) t.y = a.da[e + 1];
-                if (e + 2 >= 0 && e + 2 < n_prov) t.z = a.da[e + 2];
-                if (e + 3 >= 0 && e + 3 < n_prov) t.w = a.da[e + 3];
-                r.T[q] = t;
-            }
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (e + 0 >= 0 && e + 0 < n_prov) t.x = a.da[e + 0];
+            if (e + 1 >= 0 && e + 1 < n_prov) t.y = a.da[e + 1];
+            if (e + 2 >= 0 && e + 2 < n_prov) t.z = a.da[e + 2];
+            if (e + 3 >= 0 && e + 3 < n_prov) t.w = a.da[e + 3];
+            r.T[q] = t;
         }
     };
 
+    const u32 thr32 = a.nr_reads1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)a.nr_reads1;
+    const u32 s1_ok = a.nr_reads1 > 0xFFFFFFFFull ? 0u : 15u;
     FwRegs cur, nxt;
     if (blockIdx.x < a.n_tiles) fw_load(blockIdx.x, cur);
     for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -1069,9 +1081,9 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint4 t = cur.T[q];
-            const u32 nib = ((u64)t.x >= a.nr_reads1 ? 1u : 0u) | ((u64)t.y >= a.nr_reads1 ? 2u : 0u) |
-                            ((u64)t.z >= a.nr_reads1 ? 4u : 0u) | ((u64)t.w >= a.nr_reads1 ? 8u : 0u);
-            snib |= nib << (4 * q);
+            // 32-bit compare against min(nr_reads1, 2^32-1); s1_ok = 0 when nr_reads1 exceeds every uint32 text
+            const u32 nib = (t.x >= thr32 ? 1u : 0u) | (t.y >= thr32 ? 2u : 0u) | (t.z >= thr32 ? 4u : 0u) | (t.w >= thr32 ? 8u : 0u);
+            snib |= (nib & s1_ok) << (4 * q);
         }
         // owner lane L = 16q + j gathers nibble q of lanes 4j .. 4j+3
         u32 S1;
