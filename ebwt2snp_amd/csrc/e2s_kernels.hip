@@ -315,15 +315,6 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
 // ----------------------------------------------------------------------------------------------
 constexpr u32 SEG_CLOSED = 0xFFFFFFFFu, SEG_NOEVENT = 0xFFFFFFFEu, SEG_UNKNOWN = 0xFFFFFFFDu;
 
-// Events of a span in compact form: 2 bits per entry (bit 0 = a cluster starts here, bit 1 = one ends here),
-// 16 entries per 32-bit word.  Built from the clean lane-MSB masks of the span's words.
-template <int X> __device__ __forceinline__ u32 word_events(u32 endm, u32 startm) {
-    const u32 c = endm | (startm >> 1);                     // per lane: top bit = end, next bit = start
-    if (X == 1) return __builtin_amdgcn_udot4((c >> 6) & 0x03030303u, 0x40100401u, 0u, false);   // 4 entries -> 8 bits (v_dot4_u32_u8)
-    if (X == 2) return ((c >> 14) & 3u) | ((c >> 28) & 0xCu);                                  // 2 entries -> 4 bits
-    return c >> 30;                                                                             // 1 entry  -> 2 bits
-}
-
 constexpr int SPAN_WORDS = E2S_SPAN_BYTES / 4;               // 16 words = 64 B of LCP per thread and tile
 
 template <int X>
@@ -349,6 +340,8 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
     const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
     const u64 g_range = a.prov_lo + t0 * TILE;                  // SA position of the range's first entry
     const u64 seg = (u64)b * a.seg_cap;
+    uint64_t* const seg_starts = a.starts + seg;                   // block-uniform bases: stores use a 32-bit record offset
+    uint16_t* const seg_lens = a.lens + seg;
 
     // a thread reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of a wave
     // cover one 4 KiB stretch between them) plus the words just before and after its span
@@ -388,22 +381,23 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
     for (u64 tile = t0; tile < t1; ++tile, par ^= 1u) {
         if (tile + 1 < t1) seg_load(tile + 1, Wn);              // in flight while this tile is processed
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * ES;
+        // ---- events of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
         u32 EV[NEV];
-        {
-            u32 endm[NR], startm[NR];
-            span_flags<X, NR>(W, a.kb, a.hge, endm, startm);
-            if (a.prov_is_global0 && i0 == 0) {
-                RowFlags f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { f.end[w] = endm[w]; f.start[w] = startm[w]; }
-                patch_global0<X>(W, a.k_u32, a.hge, f);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { endm[w] = f.end[w]; startm[w] = f.start[w]; }
+        span_events<X, NR>(W, a.kb, a.hge, EV);
+        if (a.prov_is_global0 && i0 == 0) {
+            // the j = 0,1 rules of ebwt2clust.cpp:83-84 on the compact stream (bit 2e = start(e), bit 2e+1 = end(e)):
+            // with L[0] >= k the cluster opened at 0 swallows entry 1 whatever L[1] is, and j = 0 is never tested
+            constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
+            const u32 e0v = W[PRE] & LM;
+            const u32 e1v = (X == 4) ? W[PRE + 1] : ((W[PRE] >> (8 * (X & 3))) & LM);
+            const u32 e2v = (X == 4) ? W[PRE + 2] : (X == 2 ? (W[PRE + 1] & LM) : ((W[PRE] >> 16) & LM));
+            EV[0] &= ~2u;
+            if (a.hge != 0 && e0v >= a.k_u32) {
+                const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < a.k_u32);
+                EV[0] &= ~4u;
+                EV[0] = end1 ? (EV[0] | 8u) : (EV[0] & ~8u);
+                if (e2v >= a.k_u32) EV[0] = end1 ? (EV[0] | 16u) : (EV[0] & ~16u);
             }
-#pragma unroll
-            for (int g = 0; g < NEV; ++g) EV[g] = 0;
-#pragma unroll
-            for (int w = 0; w < NR; ++w) EV[(w * FB) / 32] |= word_events<X>(endm[w], startm[w]) << ((w * FB) % 32);
         }
         // restrict to the owned window (only spans that straddle its edges)
         if (!(i0 >= own_lo && i0 + ES <= end_hi && i0 + ES <= start_hi)) {
@@ -467,16 +461,16 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
                 ev &= ev - 1;
                 const u32 off = base_off + (u32)(g * 16 + (bit >> 1));
                 if (!(bit & 1)) {                                   // start
-                    if (rk < a.seg_cap) a.starts[seg + rk] = g_range + off;
+                    if (rk < a.seg_cap) seg_starts[rk] = g_range + off;
                     pend = off;
                 } else {                                            // end
                     if (rk < a.seg_cap) {
                         if (pend < SEG_UNKNOWN) {
                             const u32 len = off - pend + 1u;
-                            a.lens[seg + rk] = (uint16_t)len;
+                            seg_lens[rk] = (uint16_t)len;
                             if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
                         } else {
-                            a.lens[seg + rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
+                            seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
                             s_unknown = 1;
                         }
                     }

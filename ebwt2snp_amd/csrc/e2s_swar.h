@@ -88,3 +88,53 @@ E2S_HD void span_flags(const u32* W, u32 kb, u32 hge, u32* end, u32* start) {
 
 struct RowFlags { u32 end[4]; u32 start[4]; };
 template <int X> E2S_HD void row_flags(const u32* W, u32 kb, u32 hge, RowFlags& f) { span_flags<X, 4>(W, kb, hge, f.end, f.start); }
+
+// ---- compact event stream of a span: 2 bits per entry (bit 2e = a cluster starts at entry e, bit 2e+1 = one ends
+// there), 16 entries per 32-bit word.  Same stencil as span_flags, but streamed word by word so that only the
+// running state (~10 registers) is live, and packed on the fly.
+template <int X> E2S_HD u32 word_events(u32 endm, u32 startm) {
+    const u32 c = endm | (startm >> 1);                     // per lane: top bit = end, next bit = start
+    if (X == 1) {                                           // 4 entries -> 8 bits
+        const u32 f = (c >> 6) & 0x03030303u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_udot4(f, 0x40100401u, 0u, false);          // v_dot4_u32_u8: sum of field_i * 4^i
+#else
+        return (f & 3u) | (((f >> 8) & 3u) << 2) | (((f >> 16) & 3u) << 4) | (((f >> 24) & 3u) << 6);
+#endif
+    }
+    if (X == 2) return ((c >> 14) & 3u) | ((c >> 28) & 0xCu);                // 2 entries -> 4 bits
+    return c >> 30;                                                          // 1 entry  -> 2 bits
+}
+
+template <int X, int NR>
+E2S_HD void span_events(const u32* W, u32 kb, u32 hge, u32* EV) {
+    constexpr u32 H = Swar<X>::H;
+    constexpr int PRE = (X == 4) ? 2 : 1;
+    constexpr int NW = PRE + NR + 1;
+    constexpr int FB = 2 * Swar<X>::EPW;                    // event bits per span word
+    constexpr int NEV = (NR * FB + 31) / 32;
+#pragma unroll
+    for (int g = 0; g < NEV; ++g) EV[g] = 0;
+    u32 ge1 = 0, ge2 = 0, nle1 = 0, end2 = 0;               // ge/nle of word w-1, ge/end of word w-2
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const u32 x = W[w];
+        const u32 xh = x | H;
+        const u32 ge0 = bfi(x ^ kb, x, xh - (kb & ~H)) & hge;                              // L >= k
+        const u32 y = (w == 0) ? prev_elems<X>(x, 0u) : prev_elems<X>(x, W[w - 1]);
+        const u32 nle0 = bfi(x ^ y, x, xh - (y & ~H));                                     // top bit: L[j] >= L[j-1]
+        if (w >= 1) {
+            // end(j) = ge(j) & ((gt(j) & !gt(j+1)) | !ge(j+1)) for the entries of word w-1       (ebwt2clust.cpp:98-102)
+            const u32 locmin = ~nle1 & next_elems<X>(nle0, nle1);
+            const u32 end1 = ~(~locmin & next_elems<X>(ge0, ge1)) & ge1 & H;
+            if (w - 1 >= PRE) {
+                // start(j) = ge(j) & (!ge(j-1) | end(j-1))                                       (:108,116-120)
+                const u32 start1 = ge1 & ~(prev_elems<X>(ge1, ge2) & ~prev_elems<X>(end1, end2)) & H;
+                const int i = w - 1 - PRE;
+                EV[(i * FB) / 32] |= word_events<X>(end1, start1) << ((i * FB) % 32);
+            }
+            end2 = end1;
+        }
+        ge2 = ge1; ge1 = ge0; nle1 = nle0;
+    }
+}

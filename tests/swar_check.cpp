@@ -57,6 +57,17 @@ template <int X, int NR> static int run(unsigned seed, int iters) {
                 ++bad;
             }
         }
+        // the streamed, packed form must say the same (bit 2e = start, bit 2e+1 = end, 16 entries per word)
+        {
+            u32 EV[(NR * 2 * EPW + 31) / 32];
+            span_events<X, NR>(W, kb, hge, EV);
+            for (int e = 0; e < EPT; ++e) {
+                const bool gs = (EV[e / 16] >> (2 * (e % 16))) & 1u, gen = (EV[e / 16] >> (2 * (e % 16) + 1)) & 1u;
+                const bool want_end = endf(e);
+                const bool want_start = ge(e) && (!ge(e - 1) || endf(e - 1));
+                if (gs != want_start || gen != want_end) { if (bad < 5) fprintf(stderr, "span_events X=%d e=%d\n", X, e); ++bad; }
+            }
+        }
         // no stray bits outside the lane-MSB positions
         for (int w = 0; w < NR; ++w) if ((f.end[w] | f.start[w]) & ~H) { if (bad < 5) fprintf(stderr, "stray bits X=%d\n", X); ++bad; }
     }
