@@ -399,11 +399,14 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
                 if (e2v >= a.k_u32) EV[0] = end1 ? (EV[0] | 16u) : (EV[0] & ~16u);
             }
         }
-        // restrict to the owned window (only spans that straddle its edges)
-        if (!(i0 >= own_lo && i0 + ES <= end_hi && i0 + ES <= start_hi)) {
+        // restrict to the owned window: only the tiles that straddle its edges (tile-uniform test, a scalar branch --
+        // left per-thread the compiler if-converts the 64-bit compares into ~300 always-executed instructions)
+        const int64_t tl = (int64_t)tile * TILE;
+        if (!(tl >= own_lo && tl + TILE <= end_hi && tl + TILE <= start_hi)) {
 #pragma unroll
             for (int g = 0; g < NEV; ++g) {
                 u32 keep = 0;
+#pragma unroll 1
                 for (int f = 0; f < 16; ++f) {
                     const int64_t e = i0 + g * 16 + f;
                     if (e >= own_lo && e < start_hi) keep |= 1u << (2 * f);
