@@ -5,7 +5,9 @@
 
 #define E2S_SCAN_BLOCK 256
 #define E2S_SCAN_ROWS 4
+#ifndef E2S_SPAN_BYTES
 #define E2S_SPAN_BYTES 64        // bytes of LCP per thread and tile in the segmented scan
+#endif
 #define E2S_MAX_CLUST_LEN_K 150
 
 // device-side error bits

@@ -317,8 +317,14 @@ constexpr u32 SEG_CLOSED = 0xFFFFFFFFu, SEG_NOEVENT = 0xFFFFFFFEu, SEG_UNKNOWN =
 
 constexpr int SPAN_WORDS = E2S_SPAN_BYTES / 4;               // 16 words = 64 B of LCP per thread and tile
 
+#ifndef E2S_SCAN_PREFETCH
+#define E2S_SCAN_PREFETCH 1
+#endif
+#ifndef E2S_SCAN_WAVES
+#define E2S_SCAN_WAVES 1
+#endif
 template <int X>
-__global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
+__global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     constexpr int NR = SPAN_WORDS;
     constexpr int ES = 4 * NR / X;                           // entries per thread span
     constexpr int TILE = 256 * ES;
@@ -375,11 +381,19 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
     };
 
     if (tid == 0) { s_run[0] = 0; s_open[0] = SEG_UNKNOWN; s_in0 = 0; s_unknown = 0; s_first_end = ~0ull; }
+#if E2S_SCAN_PREFETCH
     u32 W[NW], Wn[NW];
     if (t0 < t1) seg_load(t0, W);
+#else
+    u32 W[NW];
+#endif
     u32 par = 0;
     for (u64 tile = t0; tile < t1; ++tile, par ^= 1u) {
+#if E2S_SCAN_PREFETCH
         if (tile + 1 < t1) seg_load(tile + 1, Wn);              // in flight while this tile is processed
+#else
+        seg_load(tile, W);                                      // latency is hidden by the other waves of the SIMD
+#endif
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * ES;
         // ---- events of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
         u32 EV[NEV];
@@ -456,9 +470,15 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
         if (tid == 0) { s_run[par ^ 1u] = run + tile_total; s_open[par ^ 1u] = (tile_carry != SEG_NOEVENT) ? tile_carry : open_in; }
         // emit: one event per iteration, in order
         u32 rk = run + pre, pend = ci;
+#ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loop
+        asm volatile("" :: "v"(rk), "v"(pend), "v"(EV[0]));
+        const bool do_emit = rk == 0xFFFFFFFFu;
+#else
+        const bool do_emit = true;
+#endif
 #pragma unroll
         for (int g = 0; g < NEV; ++g) {
-            u32 ev = EV[g];
+            u32 ev = do_emit ? EV[g] : 0u;
             while (ev) {
                 const int bit = __ffs(ev) - 1;
                 ev &= ev - 1;
@@ -483,8 +503,10 @@ __global__ __launch_bounds__(256) void k_scan_seg(SegArgs a) {
                 }
             }
         }
+#if E2S_SCAN_PREFETCH
 #pragma unroll
         for (int w = 0; w < NW; ++w) W[w] = Wn[w];
+#endif
     }
     __syncthreads();
     if (tid == 0) {
