@@ -395,59 +395,51 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         seg_load(tile, W);                                      // latency is hidden by the other waves of the SIMD
 #endif
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * ES;
-        // ---- events of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
-        u32 EV[NEV];
-        span_events<X, NR>(W, a.kb, a.hge, EV);
+        // ---- start / end planes of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
+        u64 S, E;                                               // bit e: a cluster starts / ends at entry e of the span
+        span_planes<X, NR>(W, a.kb, a.hge, S, E);
         if (a.prov_is_global0 && i0 == 0) {
-            // the j = 0,1 rules of ebwt2clust.cpp:83-84 on the compact stream (bit 2e = start(e), bit 2e+1 = end(e)):
-            // with L[0] >= k the cluster opened at 0 swallows entry 1 whatever L[1] is, and j = 0 is never tested
+            // the j = 0,1 rules of ebwt2clust.cpp:83-84: with L[0] >= k the cluster opened at 0 swallows entry 1
+            // whatever L[1] is, and j = 0 is never tested
             constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
             const u32 e0v = W[PRE] & LM;
             const u32 e1v = (X == 4) ? W[PRE + 1] : ((W[PRE] >> (8 * (X & 3))) & LM);
             const u32 e2v = (X == 4) ? W[PRE + 2] : (X == 2 ? (W[PRE + 1] & LM) : ((W[PRE] >> 16) & LM));
-            EV[0] &= ~2u;
+            E &= ~1ull;
             if (a.hge != 0 && e0v >= a.k_u32) {
                 const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < a.k_u32);
-                EV[0] &= ~4u;
-                EV[0] = end1 ? (EV[0] | 8u) : (EV[0] & ~8u);
-                if (e2v >= a.k_u32) EV[0] = end1 ? (EV[0] | 16u) : (EV[0] & ~16u);
+                S &= ~2ull;
+                E = end1 ? (E | 2ull) : (E & ~2ull);
+                if (e2v >= a.k_u32) S = end1 ? (S | 4ull) : (S & ~4ull);
             }
         }
         // restrict to the owned window: only the tiles that straddle its edges (tile-uniform test, a scalar branch --
         // left per-thread the compiler if-converts the 64-bit compares into ~300 always-executed instructions)
         const int64_t tl = (int64_t)tile * TILE;
         if (!(tl >= own_lo && tl + TILE <= end_hi && tl + TILE <= start_hi)) {
-#pragma unroll
-            for (int g = 0; g < NEV; ++g) {
-                u32 keep = 0;
+            u64 ks = 0, ke = 0;
 #pragma unroll 1
-                for (int f = 0; f < 16; ++f) {
-                    const int64_t e = i0 + g * 16 + f;
-                    if (e >= own_lo && e < start_hi) keep |= 1u << (2 * f);
-                    if (e >= own_lo && e < end_hi) keep |= 2u << (2 * f);
-                }
-                EV[g] &= keep;
+            for (int f = 0; f < ES; ++f) {
+                const int64_t e = i0 + f;
+                if (e >= own_lo && e < start_hi) ks |= 1ull << f;
+                if (e >= own_lo && e < end_hi) ke |= 1ull << f;
             }
+            S &= ks; E &= ke;
         }
         if (tile == t0 && tid == 0) {
             // does the range begin inside a cluster?  open(first) && !start(first)
             constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
             const bool ge0 = a.hge != 0 && (W[PRE] & LM) >= a.k_u32;
-            s_in0 = (ge0 && !(EV[0] & 1u)) ? 1u : 0u;
+            s_in0 = (ge0 && !(S & 1ull)) ? 1u : 0u;
         }
-        u32 cnt = 0;
-#pragma unroll
-        for (int g = 0; g < NEV; ++g) cnt += (u32)__popc(EV[g] & 0xAAAAAAAAu);
+        const u32 cnt = (u32)__popcll(E);
         const u32 inc = wave_incl_scan(cnt);
         const u32 base_off = (u32)((tile - t0) * TILE) + tid * ES;   // offset from the range's first entry
         // the open start this span hands on: its last event (a start precedes an end at one position)
         u32 co = SEG_NOEVENT;
-#pragma unroll
-        for (int g = 0; g < NEV; ++g) {
-            if (EV[g]) {
-                const int top = 31 - __clz(EV[g]);
-                co = (top & 1) ? SEG_CLOSED : base_off + (u32)(g * 16 + (top >> 1));
-            }
+        if (S | E) {
+            const int ms = S ? 63 - __clzll(S) : -1, me = E ? 63 - __clzll(E) : -1;
+            co = (ms > me) ? base_off + (u32)ms : SEG_CLOSED;
         }
         const u64 evm = __ballot(co != SEG_NOEVENT);
         const u64 below = evm & ((1ull << lane) - 1ull);
@@ -468,39 +460,37 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         const u32 run = s_run[par], open_in = s_open[par];
         if (ci == SEG_NOEVENT) ci = (wave_ci != SEG_NOEVENT) ? wave_ci : open_in;
         if (tid == 0) { s_run[par ^ 1u] = run + tile_total; s_open[par ^ 1u] = (tile_carry != SEG_NOEVENT) ? tile_carry : open_in; }
-        // emit: one event per iteration, in order
-        u32 rk = run + pre, pend = ci;
+        // emit: one record per iteration, written whole by the thread that owns its END.  Its start is the one
+        // start bit between the previous end and this end, or -- if there is none -- the open start carried in.
+        {
+            u32 rk = run + pre;
+            u64 done = 0;                                       // entries up to and including the previous end
 #ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loop
-        asm volatile("" :: "v"(rk), "v"(pend), "v"(EV[0]));
-        const bool do_emit = rk == 0xFFFFFFFFu;
-#else
-        const bool do_emit = true;
+            asm volatile("" :: "v"(rk), "v"(ci));
+            if (rk == 0xFFFFFFFFu)
 #endif
-#pragma unroll
-        for (int g = 0; g < NEV; ++g) {
-            u32 ev = do_emit ? EV[g] : 0u;
-            while (ev) {
-                const int bit = __ffs(ev) - 1;
-                ev &= ev - 1;
-                const u32 off = base_off + (u32)(g * 16 + (bit >> 1));
-                if (!(bit & 1)) {                                   // start
-                    if (rk < a.seg_cap) seg_starts[rk] = g_range + off;
-                    pend = off;
-                } else {                                            // end
-                    if (rk < a.seg_cap) {
-                        if (pend < SEG_UNKNOWN) {
-                            const u32 len = off - pend + 1u;
-                            seg_lens[rk] = (uint16_t)len;
-                            if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
-                        } else {
-                            seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
-                            s_unknown = 1;
-                        }
+            while (E) {
+                const int e = __ffsll((long long)E) - 1;
+                E &= E - 1;
+                const u64 upto = (2ull << e) - 1ull;
+                const u64 sc = S & upto & ~done;
+                done = upto;
+                const u32 off = base_off + (u32)e;
+                const u32 st = sc ? base_off + (u32)(63 - __clzll(sc)) : ci;
+                if (rk < a.seg_cap) {
+                    if (st < SEG_UNKNOWN) {
+                        const u32 len = off - st + 1u;
+                        seg_starts[rk] = g_range + st;
+                        seg_lens[rk] = (uint16_t)len;
+                        if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
+                    } else {
+                        seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
+                        s_unknown = 1;
                     }
-                    if (rk == 0) s_first_end = g_range + off;
-                    ++rk;
-                    pend = SEG_CLOSED;
                 }
+                if (rk == 0) s_first_end = g_range + off;
+                ++rk;
+                ci = SEG_CLOSED;
             }
         }
 #if E2S_SCAN_PREFETCH

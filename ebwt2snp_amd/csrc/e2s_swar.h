@@ -138,3 +138,62 @@ E2S_HD void span_events(const u32* W, u32 kb, u32 hge, u32* EV) {
         ge2 = ge1; ge1 = ge0; nle1 = nle0;
     }
 }
+
+// ---- start / end planes of a span: bit e of S = a cluster starts at entry e, bit e of E = one ends there
+// (4*NR/X entries, at most 64).  Same streamed stencil; the clean lane-MSB masks are packed with v_dot4_u32_u8:
+// bytes are 0x80 or 0, so dot4 with weights 1,2,4,8 | 16,32,64,128 over two words gives 128 * (8 mask bits).
+E2S_HD u32 e2s_udot4(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    return c + (a & 0xFF) * (b & 0xFF) + ((a >> 8) & 0xFF) * ((b >> 8) & 0xFF) + ((a >> 16) & 0xFF) * ((b >> 16) & 0xFF) + (a >> 24) * (b >> 24);
+#endif
+}
+
+template <int X, int NR>
+E2S_HD void span_planes(const u32* W, u32 kb, u32 hge, u64& S, u64& E) {
+    constexpr u32 H = Swar<X>::H;
+    constexpr int PRE = (X == 4) ? 2 : 1;
+    constexpr int NW = PRE + NR + 1;
+    constexpr int EPW = Swar<X>::EPW;
+    static_assert(NR * EPW <= 64 && NR % 2 == 0, "span too long for one 64-bit plane");
+    u32 sp[NR / 2], ep[NR / 2];                              // X = 1: 128 * (8 bits) per word pair; else bits of a word pair
+    u32 ge1 = 0, ge2 = 0, nle1 = 0, end2 = 0;               // ge/nle of word w-1, ge/end of word w-2
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const u32 x = W[w];
+        const u32 xh = x | H;
+        const u32 ge0 = bfi(x ^ kb, x, xh - (kb & ~H)) & hge;                              // L >= k
+        const u32 y = (w == 0) ? prev_elems<X>(x, 0u) : prev_elems<X>(x, W[w - 1]);
+        const u32 nle0 = bfi(x ^ y, x, xh - (y & ~H));                                     // top bit: L[j] >= L[j-1]
+        if (w >= 1) {
+            const u32 locmin = ~nle1 & next_elems<X>(nle0, nle1);                          // ebwt2clust.cpp:98-102
+            const u32 end1 = ~(~locmin & next_elems<X>(ge0, ge1)) & ge1 & H;
+            if (w - 1 >= PRE) {
+                const u32 start1 = ge1 & ~(prev_elems<X>(ge1, ge2) & ~prev_elems<X>(end1, end2)) & H;   // :108,116-120
+                const int i = w - 1 - PRE;
+                if (X == 1) {
+                    if (i % 2 == 0) { sp[i / 2] = e2s_udot4(start1, 0x08040201u, 0u); ep[i / 2] = e2s_udot4(end1, 0x08040201u, 0u); }
+                    else { sp[i / 2] = e2s_udot4(start1, 0x80402010u, sp[i / 2]); ep[i / 2] = e2s_udot4(end1, 0x80402010u, ep[i / 2]); }
+                } else if (X == 2) {
+                    const u32 sb = ((start1 >> 15) & 1u) | ((start1 >> 30) & 2u), eb = ((end1 >> 15) & 1u) | ((end1 >> 30) & 2u);
+                    if (i % 2 == 0) { sp[i / 2] = sb; ep[i / 2] = eb; } else { sp[i / 2] |= sb << 2; ep[i / 2] |= eb << 2; }
+                } else {
+                    if (i % 2 == 0) { sp[i / 2] = start1 >> 31; ep[i / 2] = end1 >> 31; } else { sp[i / 2] |= (start1 >> 31) << 1; ep[i / 2] |= (end1 >> 31) << 1; }
+                }
+            }
+            end2 = end1;
+        }
+        ge2 = ge1; ge1 = ge0; nle1 = nle0;
+    }
+    // assemble: word pair j holds 2*EPW entries
+    constexpr int PB = 2 * EPW;                              // bits per pair
+    u64 s = 0, e = 0;
+#pragma unroll
+    for (int j = 0; j < NR / 2; ++j) {
+        const u64 sv = (X == 1) ? (u64)(sp[j] >> 7) : (u64)sp[j];
+        const u64 ev = (X == 1) ? (u64)(ep[j] >> 7) : (u64)ep[j];
+        s |= sv << (j * PB); e |= ev << (j * PB);
+    }
+    S = s; E = e;
+}

@@ -68,6 +68,17 @@ template <int X, int NR> static int run(unsigned seed, int iters) {
                 if (gs != want_start || gen != want_end) { if (bad < 5) fprintf(stderr, "span_events X=%d e=%d\n", X, e); ++bad; }
             }
         }
+        // and the start / end planes
+        {
+            u64 S, E;
+            span_planes<X, NR>(W, kb, hge, S, E);
+            for (int e = 0; e < EPT; ++e) {
+                const bool want_end = endf(e);
+                const bool want_start = ge(e) && (!ge(e - 1) || endf(e - 1));
+                if ((bool)((S >> e) & 1) != want_start || (bool)((E >> e) & 1) != want_end) { if (bad < 5) fprintf(stderr, "span_planes X=%d e=%d\n", X, e); ++bad; }
+            }
+            if (EPT < 64 && ((S | E) >> (EPT & 63))) { if (bad < 5) fprintf(stderr, "span_planes stray X=%d\n", X); ++bad; }
+        }
         // no stray bits outside the lane-MSB positions
         for (int w = 0; w < NR; ++w) if ((f.end[w] | f.start[w]) & ~H) { if (bad < 5) fprintf(stderr, "stray bits X=%d\n", X); ++bad; }
     }
