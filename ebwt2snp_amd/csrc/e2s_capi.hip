@@ -363,7 +363,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
 
     if (scan_mode == 0) {
         // ---- segmented single-pass scan: persistent blocks over contiguous tile ranges ----
-        const uint64_t row_entries = (uint64_t)E2S_SCAN_BLOCK * (E2S_SPAN_BYTES / h->xb);   // entries per tile
+        const uint64_t row_entries = (uint64_t)64 * (E2S_SPAN_BYTES / h->xb);   // entries per wave-tile (64 lanes x 64 B)
         SegArgs sa{};
         sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
         sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;
@@ -374,7 +374,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
         sa.tiles_per_block = (uint32_t)((sa.n_tiles + nb - 1) / nb);
         nb = (sa.n_tiles + sa.tiles_per_block - 1) / sa.tiles_per_block;
-        if (nb > 4096) return fail(h, E2S_ERR_STATE, "more persistent blocks than k_seg_fix handles");
+        if (nb > 8192) return fail(h, E2S_ERR_STATE, "more scan workers than k_seg_fix handles");
         sa.n_blocks = (uint32_t)nb;
         if (nb + 1 > h->seg_blocks_cap) {
             hipFree(h->d_seg_desc); hipFree(h->d_seg_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->seg_blocks_cap = 0;

@@ -323,22 +323,20 @@ constexpr int SPAN_WORDS = E2S_SPAN_BYTES / 4;               // 16 words = 64 B 
 #ifndef E2S_SCAN_WAVES
 #define E2S_SCAN_WAVES 1
 #endif
+// Every WAVE is its own worker: it owns a contiguous range of wave-tiles (64 lanes x 64 B = 4 KiB of LCP), carries
+// its running record count and its open cluster start in registers and writes into its own output segment.  No
+// LDS, no barrier, nothing shared between waves: the scheduler interleaves them freely.
 template <int X>
 __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     constexpr int NR = SPAN_WORDS;
     constexpr int ES = 4 * NR / X;                           // entries per thread span
-    constexpr int TILE = 256 * ES;
+    constexpr int TILE = 64 * ES;                            // entries per wave-tile
     constexpr int PRE = (X == 4) ? 2 : 1;
     constexpr int EPW = Swar<X>::EPW;
     constexpr int NW = PRE + NR + 1;
-    constexpr int FB = 2 * EPW;                              // event bits per span word
-    constexpr int NEV = (NR * FB + 31) / 32;                 // event words per span
-    __shared__ u32 s_wtot[2][4], s_wcarry[2][4];
-    __shared__ u32 s_run[2], s_open[2];
-    __shared__ u32 s_in0, s_unknown;
-    __shared__ u64 s_first_end;
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u32 b = blockIdx.x;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // worker (= segment) index
+    if (b >= a.n_blocks) return;
     const u64 t0 = (u64)b * a.tiles_per_block;
     const u64 t1 = min(t0 + (u64)a.tiles_per_block, a.n_tiles);
     const uint8_t* base = (const uint8_t*)a.lcp;
@@ -346,17 +344,17 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
     const u64 g_range = a.prov_lo + t0 * TILE;                  // SA position of the range's first entry
     const u64 seg = (u64)b * a.seg_cap;
-    uint64_t* const seg_starts = a.starts + seg;                   // block-uniform bases: stores use a 32-bit record offset
+    uint64_t* const seg_starts = a.starts + seg;                // worker-uniform bases: stores use a 32-bit record offset
     uint16_t* const seg_lens = a.lens + seg;
 
-    // a thread reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of a wave
+    // a lane reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of the wave
     // cover one 4 KiB stretch between them) plus the words just before and after its span
     auto seg_load = [&](u64 tile, u32* W) {
         const int64_t tl = (int64_t)tile * TILE;
         if (tl >= PRE * EPW && tl + TILE + EPW <= n_prov) {
             // interior tile (uniform test): scalar base + 32-bit lane offset
             const uint8_t* p = base + tl * X;
-            const u32 o = tid * (u32)(4 * NR);
+            const u32 o = lane * (u32)(4 * NR);
 #pragma unroll
             for (int q = 0; q < NR / 4; ++q) {
                 const uint4 v = *(const uint4*)(p + o + 16 * q);
@@ -367,7 +365,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
             W[PRE + NR] = *(const u32*)(p + o + 4 * NR);
             return;
         }
-        const int64_t i0 = tl + (int64_t)tid * ES;
+        const int64_t i0 = tl + (int64_t)lane * ES;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {                                  // (static indices: the array stays in registers)
             u32 v = 0;
@@ -380,21 +378,23 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         }
     };
 
-    if (tid == 0) { s_run[0] = 0; s_open[0] = SEG_UNKNOWN; s_in0 = 0; s_unknown = 0; s_first_end = ~0ull; }
+    u32 run = 0;                                                // records written so far (wave-uniform)
+    u32 open = SEG_UNKNOWN;                                     // open start: offset from the range start | CLOSED | UNKNOWN
+    u32 in0 = 0, unknown = 0;
+    u64 first_end = ~0ull;
 #if E2S_SCAN_PREFETCH
     u32 W[NW], Wn[NW];
     if (t0 < t1) seg_load(t0, W);
 #else
     u32 W[NW];
 #endif
-    u32 par = 0;
-    for (u64 tile = t0; tile < t1; ++tile, par ^= 1u) {
+    for (u64 tile = t0; tile < t1; ++tile) {
 #if E2S_SCAN_PREFETCH
         if (tile + 1 < t1) seg_load(tile + 1, Wn);              // in flight while this tile is processed
 #else
         seg_load(tile, W);                                      // latency is hidden by the other waves of the SIMD
 #endif
-        const int64_t i0 = (int64_t)tile * TILE + (int64_t)tid * ES;
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
         // ---- start / end planes of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
         u64 S, E;                                               // bit e: a cluster starts / ends at entry e of the span
         span_planes<X, NR>(W, a.kb, a.hge, S, E);
@@ -426,15 +426,16 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
             }
             S &= ks; E &= ke;
         }
-        if (tile == t0 && tid == 0) {
-            // does the range begin inside a cluster?  open(first) && !start(first)
+        if (tile == t0) {
+            // does the range begin inside a cluster?  open(first) && !start(first)   (lane 0 holds the first entry)
             constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
             const bool ge0 = a.hge != 0 && (W[PRE] & LM) >= a.k_u32;
-            s_in0 = (ge0 && !(S & 1ull)) ? 1u : 0u;
+            in0 = (u32)__builtin_amdgcn_readfirstlane((ge0 && !(S & 1ull)) ? 1 : 0);
         }
         const u32 cnt = (u32)__popcll(E);
         const u32 inc = wave_incl_scan(cnt);
-        const u32 base_off = (u32)((tile - t0) * TILE) + tid * ES;   // offset from the range's first entry
+        const u32 tile_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        const u32 base_off = (u32)((tile - t0) * TILE) + lane * ES;   // offset from the range's first entry
         // the open start this span hands on: its last event (a start precedes an end at one position)
         u32 co = SEG_NOEVENT;
         if (S | E) {
@@ -444,26 +445,12 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         const u64 evm = __ballot(co != SEG_NOEVENT);
         const u64 below = evm & ((1ull << lane) - 1ull);
         const u32 got = (u32)__shfl((int)co, below ? 63 - __clzll(below) : (int)lane);   // all lanes take part
-        u32 ci = below ? got : SEG_NOEVENT;
+        u32 ci = below ? got : open;
         const u32 wlast = evm ? (u32)__builtin_amdgcn_readlane((int)co, 63 - __clzll(evm)) : SEG_NOEVENT;
-        if (lane == 63) s_wtot[par][wave] = inc;
-        if (lane == 0) s_wcarry[par][wave] = wlast;
-        __syncthreads();
-        u32 pre = inc - cnt, tile_total = 0, tile_carry = SEG_NOEVENT, wave_ci = SEG_NOEVENT;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const u32 v = s_wtot[par][w], c = s_wcarry[par][w];
-            if (w < (int)wave) { pre += v; if (c != SEG_NOEVENT) wave_ci = c; }
-            tile_total += v;
-            if (c != SEG_NOEVENT) tile_carry = c;
-        }
-        const u32 run = s_run[par], open_in = s_open[par];
-        if (ci == SEG_NOEVENT) ci = (wave_ci != SEG_NOEVENT) ? wave_ci : open_in;
-        if (tid == 0) { s_run[par ^ 1u] = run + tile_total; s_open[par ^ 1u] = (tile_carry != SEG_NOEVENT) ? tile_carry : open_in; }
-        // emit: one record per iteration, written whole by the thread that owns its END.  Its start is the one
+        // emit: one record per iteration, written whole by the lane that owns its END.  Its start is the one
         // start bit between the previous end and this end, or -- if there is none -- the open start carried in.
         {
-            u32 rk = run + pre;
+            u32 rk = run + inc - cnt;
             u64 done = 0;                                       // entries up to and including the previous end
 #ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loop
             asm volatile("" :: "v"(rk), "v"(ci));
@@ -485,28 +472,32 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
                         if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
                     } else {
                         seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
-                        s_unknown = 1;
+                        unknown = 1;
                     }
                 }
-                if (rk == 0) s_first_end = g_range + off;
+                if (rk == 0) first_end = g_range + off;
                 ++rk;
                 ci = SEG_CLOSED;
             }
         }
+        run += tile_total;
+        if (wlast != SEG_NOEVENT) open = wlast;
 #if E2S_SCAN_PREFETCH
 #pragma unroll
         for (int w = 0; w < NW; ++w) W[w] = Wn[w];
 #endif
     }
-    __syncthreads();
-    if (tid == 0) {
-        const u32 count = s_run[par], open = s_open[par];
+    // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
+    const u64 unk_m = __ballot(unknown != 0);
+    const u64 fe_m = __ballot(first_end != ~0ull);
+    const u64 fe = __shfl(first_end, fe_m ? __ffsll((long long)fe_m) - 1 : 0);
+    if (lane == 0) {
         SegDesc d;
-        d.count = min(count, a.seg_cap);
-        d.overflow = count > a.seg_cap ? 1u : 0u;
-        d.first_unknown = s_unknown;
-        d.first_end_pos = s_first_end;
-        if (open == SEG_UNKNOWN) { d.open_after = (t0 < t1) ? s_in0 : 0u; d.open_start = ~0ull; }   // no event at all
+        d.count = min(run, a.seg_cap);
+        d.overflow = run > a.seg_cap ? 1u : 0u;
+        d.first_unknown = unk_m ? 1u : 0u;
+        d.first_end_pos = fe_m ? fe : ~0ull;
+        if (open == SEG_UNKNOWN) { d.open_after = (t0 < t1) ? in0 : 0u; d.open_start = ~0ull; }   // no event at all
         else if (open == SEG_CLOSED) { d.open_after = 0; d.open_start = ~0ull; }
         else { d.open_after = 1; d.open_start = g_range + open; }
         a.desc[b] = d;
@@ -515,7 +506,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
 
 // One block ties the segments together: record offsets (exclusive scan of the per-block counts), the records
 // whose start lies in an earlier block, and the ScanMail the host downloads.
-constexpr int SEGFIX_MAX = 4096;             // persistent blocks of the scan (256 CUs x <= 8): far below
+constexpr int SEGFIX_MAX = 8192;             // scan workers (= resident waves: 256 CUs x <= 32)
 __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, const u32* tailv, u64* seg_off, u32* err,
                                                   const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out) {
     __shared__ u32 s_cnt[SEGFIX_MAX];
@@ -1322,12 +1313,12 @@ template <int X> static void launch_scan_x(const ScanArgs& a, int mode, hipStrea
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st) {
     if (xb == 1) launch_scan_x<1>(a, mode, st); else if (xb == 2) launch_scan_x<2>(a, mode, st); else launch_scan_x<4>(a, mode, st);
 }
-int e2s_scan_seg_resident_blocks(int xb) {
+int e2s_scan_seg_resident_blocks(int xb) {                   // resident WORKERS (waves)
     const void* fn = xb == 1 ? (const void*)k_scan_seg<1> : xb == 2 ? (const void*)k_scan_seg<2> : (const void*)k_scan_seg<4>;
-    return resident_blocks(fn, 256, 0);
+    return 4 * resident_blocks(fn, 256, 0);
 }
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
-    const dim3 grid(a.n_blocks), blk(256);
+    const dim3 grid((a.n_blocks + 3) / 4), blk(256);           // four independent workers (waves) per block
     if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1>), grid, blk, 0, st, a);
     else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((k_scan_seg<4>), grid, blk, 0, st, a);
