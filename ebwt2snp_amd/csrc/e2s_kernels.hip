@@ -397,7 +397,14 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
         // ---- start / end planes of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
         u64 S, E;                                               // bit e: a cluster starts / ends at entry e of the span
+#ifdef E2S_ABL_NOSWAR                                           // diagnostic build: loads + scan + emit skeleton without the stencil
+        { u32 x = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) x ^= W[w];
+          S = (x == 0x12345678u) ? 1ull : 0ull; E = (x == 0x87654321u) ? 2ull : 0ull; }
+#else
         span_planes<X, NR>(W, a.kb, a.hge, S, E);
+#endif
         if (a.prov_is_global0 && i0 == 0) {
             // the j = 0,1 rules of ebwt2clust.cpp:83-84: with L[0] >= k the cluster opened at 0 swallows entry 1
             // whatever L[1] is, and j = 0 is never tested
@@ -447,6 +454,13 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         const u32 got = (u32)__shfl((int)co, below ? 63 - __clzll(below) : (int)lane);   // all lanes take part
         u32 ci = below ? got : open;
         const u32 wlast = evm ? (u32)__builtin_amdgcn_readlane((int)co, 63 - __clzll(evm)) : SEG_NOEVENT;
+        // Take the prefetched words NOW, before the record stores: vmcnt counts loads and stores together and in order,
+        // so waiting for the next tile's loads after a data-dependent number of stores would mean waiting for every
+        // store to land (vmcnt(0)) once per tile.  This way the stores drain under the next tile's stencil.
+#if E2S_SCAN_PREFETCH
+#pragma unroll
+        for (int w = 0; w < NW; ++w) W[w] = Wn[w];
+#endif
         // emit: one record per iteration, written whole by the lane that owns its END.  Its start is the one
         // start bit between the previous end and this end, or -- if there is none -- the open start carried in.
         {
@@ -482,10 +496,6 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         }
         run += tile_total;
         if (wlast != SEG_NOEVENT) open = wlast;
-#if E2S_SCAN_PREFETCH
-#pragma unroll
-        for (int w = 0; w < NW; ++w) W[w] = Wn[w];
-#endif
     }
     // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
     const u64 unk_m = __ballot(unknown != 0);
