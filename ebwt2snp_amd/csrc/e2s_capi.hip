@@ -51,6 +51,7 @@ struct e2s_ctx {
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
     uint32_t* pin_order = nullptr;
     uint32_t* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;
+    uint64_t* d_keys = nullptr; uint64_t keys_cap = 0;
     bool cand_downloaded = false;
     // segmented record storage (scan_mode 0): segment b = d_starts/d_lens[b*seg_cap ...), SegDesc per block
     bool segmented = false; uint32_t seg_cap = 0, seg_blocks = 0; SegDesc* d_seg_desc = nullptr; uint64_t* d_seg_off = nullptr;
@@ -130,7 +131,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->pin_cand) hipHostFree(h->pin_cand);
     if (h->pin_mail) hipHostFree(h->pin_mail);
     hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
-    hipFree(h->d_rank); hipFree(h->d_order);
+    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     hipStreamDestroy(h->stream);
     delete h;
@@ -822,7 +823,12 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             h->cand_bytes = want * a.stride;
         }
         h->cand_cap = h->cand_bytes / a.stride;
-        a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap;
+        if (h->cand_cap > h->keys_cap) {
+            hipFree(h->d_keys); h->d_keys = nullptr; h->keys_cap = 0;
+            CK(hipMalloc((void**)&h->d_keys, (h->cand_cap + 8) * 8));
+            h->keys_cap = h->cand_cap;
+        }
+        a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap; a.cand_keys = (unsigned long long*)h->d_keys;
         CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
         CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
         if (streaming) {
@@ -904,12 +910,13 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         want = count + 1024;
     }
     if (!done) return fail(h, E2S_ERR_CAPACITY, "candidate / flagged buffer overflow");
+    const bool streaming_done = streaming;
     h->n_cand = count;
     h->cand_downloaded = false;
     if (count) {
         // SA order on the GPU, then ONE download of records + permutation into pinned memory
         if (count > h->order_cap) {
-            hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
+            hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
             const uint64_t c2 = count + count / 4 + 1024;
             CK(hipMalloc((void**)&h->d_rank, c2 * 4));
             CK(hipMalloc((void**)&h->d_order, c2 * 4));
@@ -925,7 +932,9 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         }
         h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
         CK(hipEventRecord(h->ev[2], h->stream));
-        e2s_launch_cand_order(h->d_cand, a.stride, count, h->d_rank, h->d_order, h->stream);
+        // k_flagged_lists leaves the SA-order keys next to the records; the record-driven pass builds them from the headers
+        if (!streaming_done) e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
+        e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, h->d_rank, h->d_order, h->stream);
         CK(hipMemcpyAsync(h->pin_cand, h->d_cand, rec_bytes, hipMemcpyDeviceToHost, h->stream));
         CK(hipMemcpyAsync(h->pin_order, h->d_order, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));

@@ -104,6 +104,7 @@ struct CandArgs {
     int len_lo, len_hi;
     uint32_t list_cap;
     uint8_t* cand_buf; uint64_t cand_cap; uint32_t stride;
+    unsigned long long* cand_keys;                  // [cand_cap] SA-order key of every candidate slot
     unsigned long long* cand_count;
     uint64_t record_index_base;
     uint32_t* err;
@@ -149,7 +150,8 @@ void e2s_launch_apply_plan(unsigned long long* starts, uint16_t* lens, uint32_t 
                            uint16_t first_len, unsigned long long n_ends, uint32_t n_tail, unsigned long long t0, uint16_t l0,
                            unsigned long long t1, uint16_t l1, hipStream_t st);
 void e2s_launch_hist_tail(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out_last_len, hipStream_t st);
-void e2s_launch_cand_order(const uint8_t* cand, uint32_t stride, unsigned long long n, uint32_t* rank, uint32_t* order, hipStream_t st);
+void e2s_launch_cand_keys(const uint8_t* cand, uint32_t stride, unsigned long long n, unsigned long long* keys, hipStream_t st);
+void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, uint32_t* rank, uint32_t* order, hipStream_t st);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
 void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);
 void e2s_launch_unpack_pairsa(const uint8_t* src, unsigned long long n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st);

@@ -576,30 +576,35 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, c
     __syncthreads();
     if (tid == 0) {
         ScanMail m;
-        u64 total = 0;
-        if (nb) total = seg_off[nb];
         const bool any = s_first != 0xFFFFFFFFu;
         const u64 first_addr = any ? (u64)s_first * a.seg_cap : NONE;
         const u64 last_addr = any ? (u64)s_last * a.seg_cap + s_cnt[s_last] - 1 : NONE;
-        m.total_ends = total;
-        m.first_end_pos = any ? a.desc[s_first].first_end_pos : NONE;
-        m.first_rec_addr = first_addr; m.last_rec_addr = last_addr;
-        m.begins_inside = flags[E2S_FLAG_BEGINS_INSIDE];
-        m.open_after = flags[E2S_FLAG_OPEN_AFTER];
-        m.end_before_last = flags[E2S_FLAG_END_BEFORE_LAST];
-        m.err = s_err | *err;
-        m.wrap_count = *a.wrap_count;
-        m.tail_lcp = tailv[0]; m.tail_prev_lcp = tailv[1];
-        const u64 carry = carry_into(nb);
-        m.open_start = (m.open_after && carry != NONE) ? carry : NONE;
-        m.last_end_start = (total > 0 && !(total == 1 && m.begins_inside)) ? a.starts[last_addr] : NONE;
-        m.first_len_prov = total > 0 ? a.lens[first_addr] : 0u;
+        // every global value the mail needs is loaded unconditionally (clamped addresses) so that the loads are all
+        // in flight together instead of queueing behind one another's branches
         const u64 li = a.n_prov - 1;
-        auto ld = [&](const void* p, int w) -> u32 {
-            if (!p) return 0u;
-            return w == 1 ? (u32)((const uint8_t*)p)[li] : w == 2 ? (u32)((const uint16_t*)p)[li] : ((const u32*)p)[li];
-        };
-        m.last_text = ld(da, yb); m.last_suff = ld(pos, zb); m.last_lcp = ld(a.lcp, xb); m.last_bwt = bwt ? (u32)bwt[li] : 0u;
+        const u64 total = nb ? seg_off[nb] : 0;                      // written above by the thread that owns the last chunk
+        const u64 v_first_end = a.desc[any ? s_first : 0].first_end_pos;
+        const u64 v_last_start = a.starts[any ? last_addr : 0];
+        const u32 v_first_len = a.lens[any ? first_addr : 0];
+        const u32 v_text = da ? (yb == 1 ? (u32)((const uint8_t*)da)[li] : yb == 2 ? (u32)((const uint16_t*)da)[li] : ((const u32*)da)[li]) : 0u;
+        const u32 v_suff = pos ? (zb == 1 ? (u32)((const uint8_t*)pos)[li] : zb == 2 ? (u32)((const uint16_t*)pos)[li] : ((const u32*)pos)[li]) : 0u;
+        const u32 v_lcp = xb == 1 ? (u32)((const uint8_t*)a.lcp)[li] : xb == 2 ? (u32)((const uint16_t*)a.lcp)[li] : ((const u32*)a.lcp)[li];
+        const u32 v_bwt = bwt ? (u32)bwt[li] : 0u;
+        const u32 v_wrap = *a.wrap_count, v_err = *err;
+        const u32 f0 = flags[E2S_FLAG_BEGINS_INSIDE], f1 = flags[E2S_FLAG_OPEN_AFTER], f2 = flags[E2S_FLAG_END_BEFORE_LAST];
+        const u32 tv0 = tailv[0], tv1 = tailv[1];
+        m.total_ends = total;
+        m.first_end_pos = any ? v_first_end : NONE;
+        m.first_rec_addr = first_addr; m.last_rec_addr = last_addr;
+        m.begins_inside = f0; m.open_after = f1; m.end_before_last = f2;
+        m.err = s_err | v_err;
+        m.wrap_count = v_wrap;
+        m.tail_lcp = tv0; m.tail_prev_lcp = tv1;
+        const u64 carry = carry_into(nb);
+        m.open_start = (f1 && carry != NONE) ? carry : NONE;
+        m.last_end_start = (total > 0 && !(total == 1 && f0)) ? v_last_start : NONE;
+        m.first_len_prov = total > 0 ? v_first_len : 0u;
+        m.last_text = v_text; m.last_suff = v_suff; m.last_lcp = v_lcp; m.last_bwt = v_bwt;
         *out = m;
     }
 }
@@ -764,19 +769,22 @@ __global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int m
 
 // the same over the segmented record storage of scan_mode 0 (one block per segment, 32 histogram replicas in
 // LDS: cluster lengths concentrate on a few values, a single copy serialises on the hot bins)
-__global__ __launch_bounds__(256) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, int min_len, u64* out) {
+__global__ __launch_bounds__(256) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u64* out) {
     constexpr int REP = 32, NB = E2S_MAX_CLUST_LEN_K + 1;
     __shared__ u32 s_freq[REP][NB + 1];
     __shared__ u64 s_acc[2];
     for (int i = threadIdx.x; i < REP * (NB + 1); i += 256) (&s_freq[0][0])[i] = 0;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
-    const u32 b = blockIdx.x, n = desc[b].count, rep = threadIdx.x & (REP - 1);
-    const uint16_t* p = lens + (u64)b * seg_cap;
+    const u32 rep = threadIdx.x & (REP - 1);
     u64 nrec = 0, nb = 0;
-    for (u32 i = threadIdx.x; i < n; i += 256) {
-        const int l = p[i];
-        if (l >= min_len) { nrec++; nb += (u64)l; if (l <= E2S_MAX_CLUST_LEN_K) atomicAdd(&s_freq[rep][l], 1u); }
+    for (u32 b = blockIdx.x; b < n_seg; b += gridDim.x) {
+        const u32 n = desc[b].count;
+        const uint16_t* p = lens + (u64)b * seg_cap;
+        for (u32 i = threadIdx.x; i < n; i += 256) {
+            const int l = p[i];
+            if (l >= min_len) { nrec++; nb += (u64)l; if (l <= E2S_MAX_CLUST_LEN_K) atomicAdd(&s_freq[rep][l], 1u); }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { nrec += __shfl_xor(nrec, o); nb += __shfl_xor(nb, o); }
@@ -1218,6 +1226,10 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
                 const u64 slot = gbase + i / q;
                 if (slot < a.cand_cap) ((uint4*)(a.cand_buf + slot * a.stride))[i % q] = ((const uint4*)s_stage)[i];
             }
+            for (u32 i = tid; i < n; i += 256) {                    // SA-order key of each slot, contiguous for the ordering pass
+                const CandHeader* hd = (const CandHeader*)(s_stage + (size_t)i * a.stride);
+                if (gbase + i < a.cand_cap) a.cand_keys[gbase + i] = (hd->record_index << 2) | (u64)(hd->pair_index & 3u);
+            }
         }
         __syncthreads();
         if (tid == 0) s_nstage = 0;
@@ -1242,33 +1254,45 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
 // arbitrary; the reference emits candidates in SA order (cluster, then the (c0,c1) loop order).  Keys are
 // unique, a few 10^4 per GPU: rank by counting (n^2/4096 block-steps), then scatter the permutation.
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 cand_key(const uint8_t* cand, u32 stride, u64 i) {
-    const CandHeader* h = (const CandHeader*)(cand + i * stride);
-    return (h->record_index << 2) | (u64)(h->pair_index & 3u);
-}
-constexpr int KO_CHUNK = 4096;
-__global__ __launch_bounds__(256) void k_cand_rank(const uint8_t* cand, u32 stride, u64 n, u32* rank) {
-    __shared__ u64 s_keys[KO_CHUNK];
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    const u64 jbase = (u64)blockIdx.y * KO_CHUNK;
-    const u64 jn = min((u64)KO_CHUNK, n - jbase);
-    for (u32 t = threadIdx.x; t < jn; t += 256) s_keys[t] = cand_key(cand, stride, jbase + t);
-    __syncthreads();
+__global__ void k_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u64 mine = cand_key(cand, stride, i);
-    u32 r = 0;
-    for (u32 t = 0; t < jn; ++t) r += s_keys[t] < mine ? 1u : 0u;
-    if (r) atomicAdd(&rank[i], r);
+    const CandHeader* h = (const CandHeader*)(cand + i * stride);
+    keys[i] = (h->record_index << 2) | (u64)(h->pair_index & 3u);
+}
+constexpr int KO_CHUNK = 2048;               // keys compared per block (LDS), KO_KPT keys ranked per thread
+constexpr int KO_KPT = 4;
+__global__ __launch_bounds__(256) void k_cand_rank(const u64* keys, u64 n, u32* rank) {
+    __shared__ __attribute__((aligned(16))) u64 s_keys[KO_CHUNK];
+    const u64 jbase = (u64)blockIdx.y * KO_CHUNK;
+    const u32 jn = (u32)min((u64)KO_CHUNK, n - jbase);
+    for (u32 t = threadIdx.x; t < KO_CHUNK; t += 256) s_keys[t] = t < jn ? keys[jbase + t] : ~0ull;   // pad: never smaller
+    __syncthreads();
+    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * KO_KPT;
+    u64 mine[KO_KPT]; u32 r[KO_KPT];
+#pragma unroll
+    for (int q = 0; q < KO_KPT; ++q) { mine[q] = i0 + q < n ? keys[i0 + q] : 0ull; r[q] = 0; }
+    for (u32 t = 0; t < KO_CHUNK; t += 2) {
+        const ulonglong2 kk = *(const ulonglong2*)&s_keys[t];         // one ds_read_b128 (broadcast) per two keys
+#pragma unroll
+        for (int q = 0; q < KO_KPT; ++q) r[q] += (kk.x < mine[q] ? 1u : 0u) + (kk.y < mine[q] ? 1u : 0u);
+    }
+#pragma unroll
+    for (int q = 0; q < KO_KPT; ++q) if (i0 + q < n && r[q]) atomicAdd(&rank[i0 + q], r[q]);
 }
 __global__ void k_cand_scatter(const u32* rank, u64 n, u32* order) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) order[rank[i]] = (u32)i;
 }
-void e2s_launch_cand_order(const uint8_t* cand, u32 stride, u64 n, u32* rank, u32* order, hipStream_t st) {
+void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_cand_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cand, stride, n, keys);
+}
+void e2s_launch_cand_order(const u64* keys, u64 n, u32* rank, u32* order, hipStream_t st) {
     if (!n) return;
     hipMemsetAsync(rank, 0, n * 4, st);
-    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n + KO_CHUNK - 1) / KO_CHUNK));
-    hipLaunchKernelGGL(k_cand_rank, grid, dim3(256), 0, st, cand, stride, n, rank);
+    const dim3 grid((unsigned)((n + 256 * KO_KPT - 1) / (256 * KO_KPT)), (unsigned)((n + KO_CHUNK - 1) / KO_CHUNK));
+    hipLaunchKernelGGL(k_cand_rank, grid, dim3(256), 0, st, keys, n, rank);
     hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)rank, n, order);
 }
 
@@ -1341,7 +1365,7 @@ void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_start
     hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, out_starts, out_lens);
 }
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_hist_seg, dim3(n_blocks), dim3(256), 0, st, lens, desc, seg_cap, min_len, out);
+    hipLaunchKernelGGL(k_hist_seg, dim3(n_blocks < 512u ? n_blocks : 512u), dim3(256), 0, st, lens, desc, seg_cap, n_blocks, min_len, out);
 }
 void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len, hipStream_t st) {
     hipLaunchKernelGGL(k_hist_tail_seg, dim3(1), dim3(64), 0, st, lens, desc, seg_cap, n_blocks, min_len, out_last_len);
