@@ -78,11 +78,30 @@ struct e2s_ctx {
 
 static int fail(e2s_handle h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
 
+// E2S_DEBUG_SYNC=1: synchronise and check after every launch, naming the one that failed (development aid)
+static bool debug_sync() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_DEBUG_SYNC"); v = (e && *e == '1') ? 1 : 0; } return v == 1; }
+static void dbg_entry(const char* name) {
+    if (!debug_sync()) return;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "[e2s debug] stale HIP error on entry of %s: %s\n", name, hipGetErrorString(e));
+}
+#define LCHK(name)                                                                                       \
+    do {                                                                                                 \
+        if (debug_sync()) {                                                                              \
+            hipError_t e1_ = hipStreamSynchronize(h->stream), e2_ = hipGetLastError();                    \
+            if (e1_ != hipSuccess || e2_ != hipSuccess) {                                                \
+                h->err = std::string("after ") + name + ": " + hipGetErrorString(e1_ != hipSuccess ? e1_ : e2_); \
+                return E2S_ERR_HIP;                                                                      \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
 extern "C" const char* e2s_version(void) { return "ebwt2snp_amd 0.1 (gfx950)"; }
 
 extern "C" const char* e2s_last_error(e2s_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int e2s_create(int device_id, e2s_handle* out) {
+    dbg_entry("e2s_create");
     if (!out) return E2S_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -121,6 +140,7 @@ static void release_shard(e2s_ctx* h) {
 }
 
 extern "C" int e2s_destroy(e2s_handle h) {
+    dbg_entry("e2s_destroy");
     if (!h) return E2S_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
@@ -138,8 +158,10 @@ extern "C" int e2s_destroy(e2s_handle h) {
     return E2S_OK;
 }
 
-extern "C" int e2s_stream(e2s_handle h, void** stream) { if (!h || !stream) return E2S_ERR_ARG; *stream = (void*)h->stream; return E2S_OK; }
-extern "C" int e2s_synchronize(e2s_handle h) { if (!h) return E2S_ERR_ARG; CK(hipSetDevice(h->device)); CK(hipStreamSynchronize(h->stream)); return E2S_OK; }
+extern "C" int e2s_stream(e2s_handle h, void** stream) {
+    dbg_entry("e2s_stream"); if (!h || !stream) return E2S_ERR_ARG; *stream = (void*)h->stream; return E2S_OK; }
+extern "C" int e2s_synchronize(e2s_handle h) {
+    dbg_entry("e2s_synchronize"); if (!h) return E2S_ERR_ARG; CK(hipSetDevice(h->device)); CK(hipStreamSynchronize(h->stream)); return E2S_OK; }
 
 static bool width_ok(int w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 
@@ -174,6 +196,7 @@ static int dev_alloc(e2s_ctx* h, void** p, size_t bytes) {
 }
 
 extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa) {
+    dbg_entry("e2s_upload_bcr");
     int rc = check_desc(h, d);
     if (rc) return rc;
     if (!bwt || !lcp || !pairsa) return fail(h, E2S_ERR_ARG, "null source pointer");
@@ -193,6 +216,7 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
         CK(hipMalloc(&stage, n * 8));
         CK(hipMemcpyAsync(stage, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
         e2s_launch_narrow8((const uint8_t*)stage, n, (uint32_t*)h->lcp, h->stream);
+        LCHK("e2s_launch_narrow8");
         CK(hipStreamSynchronize(h->stream));
         CK(hipFree(stage));
     } else {
@@ -202,6 +226,7 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     CK(hipMalloc(&stage, n * rec + 16));
     CK(hipMemcpyAsync(stage, pairsa, n * rec, hipMemcpyHostToDevice, h->stream));
     e2s_launch_unpack_pairsa((const uint8_t*)stage, n, d->pos_bytes, d->da_bytes, h->pos, h->zb, h->da, h->yb, h->stream);
+    LCHK("e2s_launch_unpack_pairsa");
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
     CK(hipFree(stage));
@@ -211,6 +236,7 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
 }
 
 extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void* aos) {
+    dbg_entry("e2s_upload_gesa");
     int rc = check_desc(h, d);
     if (rc) return rc;
     if (!aos) return fail(h, E2S_ERR_ARG, "null source pointer");
@@ -230,6 +256,7 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     CK(hipMemcpyAsync(stage, aos, n * rec, hipMemcpyHostToDevice, h->stream));
     e2s_launch_unpack_gesa((const uint8_t*)stage, n, d->da_bytes, d->pos_bytes, d->lcp_bytes, h->bwt, h->lcp, h->xb, h->pos, h->zb,
                            h->da, h->yb, h->stream);
+    LCHK("e2s_launch_unpack_gesa");
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
     CK(hipFree(stage));
@@ -240,6 +267,7 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
 
 extern "C" int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, const void* d_lcp, const void* d_pos,
                               const void* d_da) {
+    dbg_entry("e2s_attach_soa");
     int rc = check_desc(h, d);
     if (rc) return rc;
     if (d->lcp_bytes == 8 || d->da_bytes == 8 || d->pos_bytes == 8) return fail(h, E2S_ERR_ARG, "attach: 8-byte fields must be narrowed first");
@@ -255,6 +283,7 @@ extern "C" int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void*
 }
 
 extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void* lcp, uint8_t tail_bwt) {
+    dbg_entry("e2s_upload_lcp");
     int rc = check_desc(h, d);
     if (rc) return rc;
     if (!lcp) return fail(h, E2S_ERR_ARG, "null source pointer");
@@ -271,6 +300,7 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
         CK(hipMalloc(&stage, n * 8));
         CK(hipMemcpyAsync(stage, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
         e2s_launch_narrow8((const uint8_t*)stage, n, (uint32_t*)h->lcp, h->stream);
+        LCHK("e2s_launch_narrow8");
         CK(hipStreamSynchronize(h->stream));
         CK(hipFree(stage));
     } else {
@@ -326,6 +356,7 @@ static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_
         if (h->stitched && h->plan.n_tail)
             e2s_launch_apply_plan((unsigned long long*)h->d_cstarts, h->d_clens, 0, 0, 0, h->n_ends, h->plan.n_tail, h->plan.tail_start[0],
                                   h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], h->stream);
+            LCHK("e2s_launch_apply_plan");
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
         h->compact_valid = true;
@@ -335,6 +366,7 @@ static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_
 }
 
 extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode) {
+    dbg_entry("e2s_cluster_scan");
     if (!h) return E2S_ERR_ARG;
     if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
     if (scan_mode != 0 && scan_mode != 1) return fail(h, E2S_ERR_ARG, "scan_mode must be 0 or 1");
@@ -392,12 +424,15 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
             CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
             e2s_launch_shard_flags(a, h->xb, h->stream);
+            LCHK("e2s_launch_shard_flags");
             CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
             e2s_launch_scan_seg(sa, h->xb, h->stream);
+            LCHK("e2s_launch_scan_seg");
             CK(hipEventRecord(h->ev[3], h->stream));
             e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb,
                                h->d_mail, h->stream);
+            LCHK("e2s_launch_seg_fix");
             CK(hipEventRecord(h->ev[1], h->stream));
             CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
             CK(hipStreamSynchronize(h->stream));
@@ -428,17 +463,23 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             CK(hipMemsetAsync(h->d_scalars + 3, 0xFF, 8, h->stream));
             CK(hipMemsetAsync(h->d_tile_fix, 0xFF, a.n_tiles * 8, h->stream));
             e2s_launch_shard_flags(a, h->xb, h->stream);
+            LCHK("e2s_launch_shard_flags");
             CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
             e2s_launch_scan(a, h->xb, 1, h->stream);
+            LCHK("e2s_launch_scan");
             e2s_launch_tile_scan(h->d_tile_count, (unsigned long long*)h->d_tile_prefix, a.n_tiles, h->stream);
+            LCHK("e2s_launch_tile_scan");
             e2s_launch_scan(a, h->xb, 2, h->stream);
+            LCHK("e2s_launch_scan");
             CK(hipEventRecord(h->ev[3], h->stream));
             e2s_launch_scan_fix(a.n_tiles, (const unsigned long long*)h->d_tile_fix, (const unsigned long long*)h->d_tile_fix_end,
                                 (const unsigned long long*)h->d_starts, h->d_lens, h->cap, a.flags, (unsigned long long*)h->d_wrap,
                                 h->d_words + 12, h->stream);
+            LCHK("e2s_launch_scan_fix");
             CK(hipEventRecord(h->ev[1], h->stream));
             e2s_launch_scan_mail(a, h->d_words, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, h->stream);
+            LCHK("e2s_launch_scan_mail");
             CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
             CK(hipStreamSynchronize(h->stream));
             CK(hipGetLastError());
@@ -482,6 +523,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
 }
 
 extern "C" int e2s_boundary_desc(e2s_handle h, e2s_boundary* out) {
+    dbg_entry("e2s_boundary_desc");
     if (!h || !out) return E2S_ERR_ARG;
     if (!h->scanned) return fail(h, E2S_ERR_STATE, "e2s_cluster_scan has not run");
     memset(out, 0, sizeof(*out));
@@ -510,6 +552,7 @@ static uint64_t incoming_start(const e2s_boundary* all, int r) {
 
 extern "C" int e2s_stitch_plan(const e2s_boundary* all, int nranks, int rank, uint64_t n, int k, int lcp_bytes,
                                e2s_stitch_plan_t* out) {
+    dbg_entry("e2s_stitch_plan");
     if (!all || !out || nranks < 1 || rank < 0 || rank >= nranks) return E2S_ERR_ARG;
     memset(out, 0, sizeof(*out));
     const e2s_boundary& me = all[rank];
@@ -560,6 +603,7 @@ extern "C" int e2s_stitch_plan(const e2s_boundary* all, int nranks, int rank, ui
 }
 
 extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int rank) {
+    dbg_entry("e2s_stitch");
     if (!h || !all || nranks < 1 || rank < 0 || rank >= nranks) return E2S_ERR_ARG;
     if (!h->scanned) return fail(h, E2S_ERR_STATE, "e2s_cluster_scan has not run");
     CK(hipSetDevice(h->device));
@@ -578,12 +622,14 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
         if (pl.patch_first && h->first_rec_addr != E2S_NONE)
             e2s_launch_apply_plan((unsigned long long*)h->d_starts + h->first_rec_addr, h->d_lens + h->first_rec_addr, 1, pl.first_start,
                                   pl.first_len, 0, 0, 0, 0, 0, 0, h->stream);
+            LCHK("e2s_launch_apply_plan");
         h->compact_valid = false;
     } else {
         if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
         if (pl.patch_first || pl.n_tail)
             e2s_launch_apply_plan((unsigned long long*)h->d_starts, h->d_lens, pl.patch_first, pl.first_start, pl.first_len, h->n_ends,
                                   pl.n_tail, pl.tail_start[0], pl.tail_len[0], pl.tail_start[1], pl.tail_len[1], h->stream);
+            LCHK("e2s_launch_apply_plan");
     }
     h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
     h->plan = pl;
@@ -592,6 +638,7 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
 }
 
 extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_records) {
+    dbg_entry("e2s_cluster_counts");
     if (!h) return E2S_ERR_ARG;
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
     if (n_closed) *n_closed = h->n_closed;
@@ -605,6 +652,7 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 }
 
 extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records, uint64_t* n_records) {
+    dbg_entry("e2s_fetch_clusters");
     if (!h || !n_records) return E2S_ERR_ARG;
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
     CK(hipSetDevice(h->device));
@@ -633,6 +681,7 @@ extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records,
 // clust2snp: records from a .clusters file, histogram, candidates
 // ---------------------------------------------------------------------------------------------
 extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_records) {
+    dbg_entry("e2s_load_clusters");
     if (!h || (!recs && n_records)) return E2S_ERR_ARG;
     if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
     CK(hipSetDevice(h->device));
@@ -659,6 +708,7 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
 }
 
 extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
+    dbg_entry("e2s_cluster_hist");
     if (!h || !out) return E2S_ERR_ARG;
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
     CK(hipSetDevice(h->device));
@@ -701,6 +751,7 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
 // and multiplies by the hoisted reciprocal inside the loop; reproduced here (H19).
 extern "C" int e2s_auto_max_clust_length(const e2s_hist* parts, int nparts, int mcov_out, double pval,
                                          int* max_clust_length, uint64_t* n_clust, uint64_t* n_bases) {
+    dbg_entry("e2s_auto_max_clust_length");
     if (!parts || nparts < 1 || !max_clust_length) return E2S_ERR_ARG;
     uint64_t freq[E2S_MAX_CLUST_LEN + 1] = {0};
     uint64_t nrec = 0, nb = 0, last_len = 0;
@@ -743,6 +794,7 @@ static uint32_t list_cap_of(const e2s_c2s_params* p) {
 }
 
 extern "C" int e2s_candidate_stride(e2s_handle h, const e2s_c2s_params* p, uint32_t* list_cap, size_t* stride_bytes) {
+    dbg_entry("e2s_candidate_stride");
     (void)h;
     if (!p) return E2S_ERR_ARG;
     const uint32_t c = list_cap_of(p);
@@ -774,6 +826,7 @@ static int ensure_flagged(e2s_ctx* h, uint64_t cap) {
 }
 
 extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand) {
+    dbg_entry("e2s_find_candidates");
     if (!h || !p) return E2S_ERR_ARG;
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
     if (!h->bwt || !h->pos || !h->da) return fail(h, E2S_ERR_STATE, "the per-cluster pass needs all four EGSA arrays");
@@ -878,9 +931,11 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             f.fl_count = (unsigned long long*)(h->d_scalars + 2);
             CK(hipEventRecord(h->ev[6], h->stream));
             e2s_launch_cluster_filter(f, h->stream);
+            LCHK("e2s_launch_cluster_filter");
             CK(hipEventRecord(h->ev[4], h->stream));
             a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
             e2s_launch_flagged_lists(a, (const unsigned long long*)(h->d_scalars + 2), d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
+            LCHK("e2s_launch_flagged_lists");
             CK(hipEventRecord(h->ev[7], h->stream));
         } else {
             { const uint64_t* ds; const uint16_t* dl; int rc = records_contiguous(h, &ds, &dl); if (rc) return rc; a.starts = ds; a.lens = dl; }
@@ -916,7 +971,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     if (count) {
         // SA order on the GPU, then ONE download of records + permutation into pinned memory
         if (count > h->order_cap) {
-            hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
+            hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
             const uint64_t c2 = count + count / 4 + 1024;
             CK(hipMalloc((void**)&h->d_rank, c2 * 4));
             CK(hipMalloc((void**)&h->d_order, c2 * 4));
@@ -935,6 +990,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         // k_flagged_lists leaves the SA-order keys next to the records; the record-driven pass builds them from the headers
         if (!streaming_done) e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
         e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, h->d_rank, h->d_order, h->stream);
+        LCHK("e2s_launch_cand_order");
         CK(hipMemcpyAsync(h->pin_cand, h->d_cand, rec_bytes, hipMemcpyDeviceToHost, h->stream));
         CK(hipMemcpyAsync(h->pin_order, h->d_order, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
@@ -950,6 +1006,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
 }
 
 extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand) {
+    dbg_entry("e2s_fetch_candidates");
     if (!h || !n_cand) return E2S_ERR_ARG;
     *n_cand = h->n_cand;
     if (!out) return E2S_OK;
@@ -964,6 +1021,7 @@ extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, 
 
 extern "C" int e2s_candidates_view(e2s_handle h, const void** recs, const uint32_t** order, uint64_t* n_cand,
                                    uint32_t* list_cap, size_t* stride_bytes) {
+    dbg_entry("e2s_candidates_view");
     if (!h) return E2S_ERR_ARG;
     if (h->n_cand && !h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
     if (recs) *recs = h->n_cand ? h->pin_cand : nullptr;
@@ -975,6 +1033,7 @@ extern "C" int e2s_candidates_view(e2s_handle h, const void** recs, const uint32
 }
 
 extern "C" int e2s_last_timing(e2s_handle h, e2s_timing* out) {
+    dbg_entry("e2s_last_timing");
     if (!h || !out) return E2S_ERR_ARG;
     *out = h->tm;
     return E2S_OK;
