@@ -166,6 +166,22 @@ def cpu_baseline(blk, reads, n1, sample_entries):
         shutil.rmtree(d, ignore_errors=True)
 
 
+PMC_FILE = "profiles/round1_final_pmc_traffic.json"
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE; collected by
+    tools/profile.sh in separate --pmc runs of this same command, summarised by tools/profile_summary.py).  None when the
+    committed profile is of another workload -- counters cannot be read from inside the timed run."""
+    try:
+        j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)))
+        if j.get("workload") != workload:
+            return None
+        return float(j["kernels"][kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,7 +256,7 @@ def main():
         tm = h.timing()
         ms_step = elapsed / a.steps * 1e3
         value = n_total * a.steps / elapsed
-        # dominant kernel: the per-cluster pass (k_candidates).  Algorithmic bytes per launch:
+        # dominant kernel: the streaming per-cluster filter (k_cluster_filter).  Algorithmic bytes per launch:
         # 7 B/entry (bwt 1 + lcp 1 + pos 1 + da 4) over the owned entries + 10 B per cluster record read.
         cand_avg_ms = float(np.mean(cand_ms))
         cand_bytes = n_own * 7 + info["n_ends"] * 10
@@ -248,6 +264,7 @@ def main():
         scan_avg_ms = float(np.mean(scan_ms))
         scan_bytes = n_own * 1 + info["n_ends"] * 10          # LCP read + 10 B/record written
         scan_gbs = scan_bytes / (scan_avg_ms * 1e-3) / 1e9
+        k2_traffic, k1_traffic = pmc_traffic(a.workload, "k_cluster_filter"), pmc_traffic(a.workload, "k_scan_seg<1>")
         out = {
             "metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": value, "unit": "EGSA entries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -257,10 +274,11 @@ def main():
                        "parallelism": "sa-range x%d" % world, "cluster_records": tot_ends, "candidates": tot_cand,
                        "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2),
                        "host_phase_ms": {k2: round(v / a.steps * 1e3, 4) for k2, v in PHASES.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_candidates", "achieved": cand_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": cand_gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": cand_avg_ms, "algorithmic_bytes": cand_bytes},
-            "roofline_scan": {"bound": "hbm", "kernel": "k_scan", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": scan_gbs / HBM_PEAK_GBS, "traffic": None, "launch_ms": scan_avg_ms,
+            "roofline": {"bound": "hbm", "kernel": "k_cluster_filter", "achieved": cand_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": cand_gbs / HBM_PEAK_GBS, "traffic": k2_traffic, "launch_ms": cand_avg_ms, "algorithmic_bytes": cand_bytes,
+                         "traffic_source": PMC_FILE if k2_traffic else None},
+            "roofline_scan": {"bound": "hbm", "kernel": "k_scan_seg", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": scan_gbs / HBM_PEAK_GBS, "traffic": k1_traffic, "launch_ms": scan_avg_ms,
                               "algorithmic_bytes": scan_bytes, "scan_all_kernels_ms": float(np.mean(scan_all_ms)),
                               "hist_ms": float(np.mean(hist_ms))},
         }

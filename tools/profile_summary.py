@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh run into profiles/:
+   <round>_kernel_stats.csv  -- this repo's kernels from rocprofv3 --kernel-trace --stats
+   <round>_pmc_traffic.json  -- FETCH_SIZE / WRITE_SIZE per launch per kernel, with the gfx950 correction
+                                (FETCH_SIZE doubled, MI355X_MICROARCH.md "HBM"; the counters are in KiB)
+usage: tools/profile_summary.py gpurun_out/<tag> profiles/<round>"""
+import csv, glob, json, os, sys
+
+OURS = ("k_scan", "k_seg", "k_hist", "k_cluster_filter", "k_flagged", "k_cand", "k_candidates", "k_shard", "k_apply",
+        "k_tile", "k_unpack")
+
+
+def ours(name):
+    return any(name.startswith(p) or (" " + p) in name for p in OURS)
+
+
+def short(name):
+    return name.replace("void ", "").split("(")[0]
+
+
+def main(src, dst):
+    st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(st)) if ours(r["Name"])]
+    with open(dst + "_kernel_stats.csv", "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0   (MI355X, workload c2: 2.02e8 entries)\n")
+        f.write("# only this repo's kernels are listed; the rest of the trace is torch building the synthetic EGSA\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+        for r in rows:
+            f.write('"%s",%s,%s,%s,%s,%s,%s,%s\n' % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                                                     r["MinNs"], r["MaxNs"], r["StdDev"]))
+    pmc = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        fs = glob.glob(os.path.join(src, c, "**", "*counter_collection.csv"), recursive=True)
+        if not fs:
+            continue
+        acc = {}
+        for r in csv.DictReader(open(fs[0])):
+            if r["Counter_Name"] != c or not ours(r["Kernel_Name"]):
+                continue
+            acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            kib = sum(v) / len(v)
+            b = kib * 1024.0 * (2.0 if c == "FETCH_SIZE" else 1.0)
+            pmc.setdefault(k, {})[c + "_raw_KiB_per_launch"] = kib
+            pmc[k][("fetch" if c == "FETCH_SIZE" else "write") + "_bytes_per_launch"] = b
+            pmc[k]["launches"] = len(v)
+    for k, v in pmc.items():
+        v["hbm_bytes_per_launch"] = v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0",
+               "corrections": "counter unit KiB; FETCH_SIZE doubled on gfx950 (128-B requests tallied at 64 B)",
+               "workload": "c2", "kernels": pmc}, open(dst + "_pmc_traffic.json", "w"), indent=1)
+    bj = os.path.join(src, "bench_under_rocprof.json")
+    if os.path.exists(bj) and os.path.getsize(bj):
+        open(dst + "_bench_under_rocprof.json", "w").write(open(bj).read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
