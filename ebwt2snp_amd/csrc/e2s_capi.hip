@@ -50,7 +50,8 @@ struct e2s_ctx {
     bool tail_bwt_given = false; uint8_t tail_bwt_arg = 0;
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
     uint32_t* pin_order = nullptr;
-    uint32_t* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;
+    void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
+    hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
     uint64_t* d_keys = nullptr; uint64_t keys_cap = 0;
     bool cand_downloaded = false;
     // segmented record storage (scan_mode 0): segment b = d_starts/d_lens[b*seg_cap ...), SegDesc per block
@@ -120,6 +121,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
         return E2S_ERR_HIP;
     }
     for (auto& ev : h->ev) hipEventCreate(&ev);
+    hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, sizeof(ScanMail)) != hipSuccess ||
         hipHostMalloc((void**)&h->pin_mail, 4096, hipHostMallocDefault) != hipSuccess) {
@@ -153,6 +155,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
     hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
+    if (h->stream2) hipStreamDestroy(h->stream2);
     hipStreamDestroy(h->stream);
     delete h;
     return E2S_OK;
@@ -973,7 +976,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         if (count > h->order_cap) {
             hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
             const uint64_t c2 = count + count / 4 + 1024;
-            CK(hipMalloc((void**)&h->d_rank, c2 * 4));
+            CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(c2)));
             CK(hipMalloc((void**)&h->d_order, c2 * 4));
             h->order_cap = c2;
         }
@@ -986,14 +989,18 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             h->pin_cand_bytes = need + need / 4 + 4096;
         }
         h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
-        CK(hipEventRecord(h->ev[2], h->stream));
+        // the records are final (the stream was synchronised above): they travel on the second stream while the
+        // first one computes the SA order
+        CK(hipMemcpyAsync(h->pin_cand, h->d_cand, rec_bytes, hipMemcpyDeviceToHost, h->stream2));
         // k_flagged_lists leaves the SA-order keys next to the records; the record-driven pass builds them from the headers
         if (!streaming_done) e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
-        e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, h->d_rank, h->d_order, h->stream);
+        const uint64_t key_lo = (streaming_done ? h->prov_lo : record_index_base) << 2;
+        const uint64_t key_span = ((streaming_done ? h->n_prov : h->n_rec) + 1) << 2;
+        e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, key_lo, key_span, h->d_rank, h->d_order, h->stream);
         LCHK("e2s_launch_cand_order");
-        CK(hipMemcpyAsync(h->pin_cand, h->d_cand, rec_bytes, hipMemcpyDeviceToHost, h->stream));
         CK(hipMemcpyAsync(h->pin_order, h->d_order, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
+        CK(hipStreamSynchronize(h->stream2));
         CK(hipGetLastError());
         h->cand_downloaded = true;
     }

@@ -151,7 +151,10 @@ void e2s_launch_apply_plan(unsigned long long* starts, uint16_t* lens, uint32_t 
                            unsigned long long t1, uint16_t l1, hipStream_t st);
 void e2s_launch_hist_tail(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out_last_len, hipStream_t st);
 void e2s_launch_cand_keys(const uint8_t* cand, uint32_t stride, unsigned long long n, unsigned long long* keys, hipStream_t st);
-void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, uint32_t* rank, uint32_t* order, hipStream_t st);
+constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
+size_t e2s_cand_order_scratch_bytes(unsigned long long n);
+void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, unsigned long long key_lo, unsigned long long key_span,
+                           void* scratch, uint32_t* order, hipStream_t st);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
 void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);
 void e2s_launch_unpack_pairsa(const uint8_t* src, unsigned long long n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st);

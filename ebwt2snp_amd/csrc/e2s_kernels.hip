@@ -382,6 +382,17 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     u32 open = SEG_UNKNOWN;                                     // open start: offset from the range start | CLOSED | UNKNOWN
     u32 in0 = 0, unknown = 0;
     u64 first_end = ~0ull;
+#if E2S_SCAN_PREFETCH == 2
+    // two tiles ahead: W = the tile being processed, PA / PB = the next two, filled alternately (static register
+    // roles: the loop body is instantiated twice).  A wave keeps 4-8 KiB of loads in flight at all times, also
+    // while it computes and while it emits -- with one tile ahead the waves of a SIMD fall into step (all wait,
+    // then all compute) and neither HBM nor the VALU is busy half of the time.
+    u32 W[NW], PA[NW], PB[NW];
+    if (t0 < t1) seg_load(t0, W);
+    if (t0 + 1 < t1) seg_load(t0 + 1, PB);
+    auto body = [&](const u64 tile, u32* Pfree, u32* Wn) {
+        if (tile + 2 < t1) seg_load(tile + 2, Pfree);
+#else
 #if E2S_SCAN_PREFETCH
     u32 W[NW], Wn[NW];
     if (t0 < t1) seg_load(t0, W);
@@ -393,6 +404,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         if (tile + 1 < t1) seg_load(tile + 1, Wn);              // in flight while this tile is processed
 #else
         seg_load(tile, W);                                      // latency is hidden by the other waves of the SIMD
+#endif
 #endif
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
         // ---- start / end planes of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
@@ -496,7 +508,15 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         }
         run += tile_total;
         if (wlast != SEG_NOEVENT) open = wlast;
+#if E2S_SCAN_PREFETCH == 2
+    };
+    for (u64 tile = t0; tile < t1; tile += 2) {
+        body(tile, PA, PB);
+        if (tile + 1 < t1) body(tile + 1, PB, PA);
     }
+#else
+    }
+#endif
     // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
     const u64 unk_m = __ballot(unknown != 0);
     const u64 fe_m = __ballot(first_end != ~0ull);
@@ -1252,7 +1272,10 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
 // ----------------------------------------------------------------------------------------------
 // KO: SA order of the candidates.  Output slots are claimed with atomics, so the order of the buffer is
 // arbitrary; the reference emits candidates in SA order (cluster, then the (c0,c1) loop order).  Keys are
-// unique, a few 10^4 per GPU: rank by counting (n^2/4096 block-steps), then scatter the permutation.
+// unique and spread over the shard's SA range, so they are ranked by bucket: count per bucket of the key
+// range (~2 keys per bucket), exclusive scan of the counts, group the keys by bucket, rank inside the
+// bucket.  O(n) work for evenly spread keys (the first version ranked by counting all pairs: 54 us for
+// 1.7x10^4 keys and quadratic beyond).
 // ----------------------------------------------------------------------------------------------
 __global__ void k_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1260,40 +1283,71 @@ __global__ void k_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys) {
     const CandHeader* h = (const CandHeader*)(cand + i * stride);
     keys[i] = (h->record_index << 2) | (u64)(h->pair_index & 3u);
 }
-constexpr int KO_CHUNK = 2048;               // keys compared per block (LDS), KO_KPT keys ranked per thread
-constexpr int KO_KPT = 4;
-__global__ __launch_bounds__(256) void k_cand_rank(const u64* keys, u64 n, u32* rank) {
-    __shared__ __attribute__((aligned(16))) u64 s_keys[KO_CHUNK];
-    const u64 jbase = (u64)blockIdx.y * KO_CHUNK;
-    const u32 jn = (u32)min((u64)KO_CHUNK, n - jbase);
-    for (u32 t = threadIdx.x; t < KO_CHUNK; t += 256) s_keys[t] = t < jn ? keys[jbase + t] : ~0ull;   // pad: never smaller
-    __syncthreads();
-    const u64 i0 = ((u64)blockIdx.x * 256 + threadIdx.x) * KO_KPT;
-    u64 mine[KO_KPT]; u32 r[KO_KPT];
-#pragma unroll
-    for (int q = 0; q < KO_KPT; ++q) { mine[q] = i0 + q < n ? keys[i0 + q] : 0ull; r[q] = 0; }
-    for (u32 t = 0; t < KO_CHUNK; t += 2) {
-        const ulonglong2 kk = *(const ulonglong2*)&s_keys[t];         // one ds_read_b128 (broadcast) per two keys
-#pragma unroll
-        for (int q = 0; q < KO_KPT; ++q) r[q] += (kk.x < mine[q] ? 1u : 0u) + (kk.y < mine[q] ? 1u : 0u);
-    }
-#pragma unroll
-    for (int q = 0; q < KO_KPT; ++q) if (i0 + q < n && r[q]) atomicAdd(&rank[i0 + q], r[q]);
+__device__ __forceinline__ u32 ko_bucket(u64 key, u64 key_lo, u32 shift, u32 nb) {
+    const u64 d = key >= key_lo ? key - key_lo : 0ull;
+    const u64 b = d >> shift;
+    return b < nb ? (u32)b : nb - 1u;
 }
-__global__ void k_cand_scatter(const u32* rank, u64 n, u32* order) {
+__global__ void k_ko_count(const u64* keys, u64 n, u64 key_lo, u32 shift, u32 nb, u32* cnt, u32* slot) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[rank[i]] = (u32)i;
+    if (i < n) slot[i] = atomicAdd(&cnt[ko_bucket(keys[i], key_lo, shift, nb)], 1u);
+}
+// exclusive scan of cnt[0..nb) in place (one block; nb <= 2^18)
+__global__ __launch_bounds__(1024) void k_ko_scan(u32* cnt, u32 nb) {
+    __shared__ u32 s_part[1024];
+    const u32 tid = threadIdx.x, per = (nb + 1023u) / 1024u, lo = min(nb, tid * per), hi = min(nb, lo + per);
+    u32 sum = 0;
+    for (u32 b = lo; b < hi; ++b) sum += cnt[b];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        const u32 v = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = s_part[tid] - sum;
+    for (u32 b = lo; b < hi; ++b) { const u32 c = cnt[b]; cnt[b] = run; run += c; }
+    if (tid == 1023) cnt[nb] = s_part[1023];
+}
+__global__ void k_ko_place(const u64* keys, u64 n, u64 key_lo, u32 shift, u32 nb, const u32* off, const u32* slot, u64* gkeys, u32* gidx) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = keys[i];
+    const u32 at = off[ko_bucket(k, key_lo, shift, nb)] + slot[i];
+    gkeys[at] = k; gidx[at] = (u32)i;
+}
+__global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, u64 key_lo, u32 shift, u32 nb, const u32* off, u32* order) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u64 k = gkeys[j];
+    const u32 b = ko_bucket(k, key_lo, shift, nb), lo = off[b], hi = off[b + 1];
+    u32 r = lo;
+    for (u32 t = lo; t < hi; ++t) r += gkeys[t] < k ? 1u : 0u;
+    order[r] = gidx[j];
 }
 void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(k_cand_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cand, stride, n, keys);
 }
-void e2s_launch_cand_order(const u64* keys, u64 n, u32* rank, u32* order, hipStream_t st) {
+// scratch layout (u32 words): cnt[nb + 1] | slot[n] | gidx[n] | (8-byte aligned) gkeys[n]
+size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
+void e2s_launch_cand_order(const u64* keys, u64 n, u64 key_lo, u64 key_span, void* scratch, u32* order, hipStream_t st) {
     if (!n) return;
-    hipMemsetAsync(rank, 0, n * 4, st);
-    const dim3 grid((unsigned)((n + 256 * KO_KPT - 1) / (256 * KO_KPT)), (unsigned)((n + KO_CHUNK - 1) / KO_CHUNK));
-    hipLaunchKernelGGL(k_cand_rank, grid, dim3(256), 0, st, keys, n, rank);
-    hipLaunchKernelGGL(k_cand_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)rank, n, order);
+    u32 nb = 256;
+    while (nb < E2S_KO_MAX_BUCKETS && (u64)nb * 2 < n) nb <<= 1;
+    u32 shift = 0;
+    while (shift < 63 && (key_span >> shift) >= (u64)nb) ++shift;           // (key - key_lo) >> shift < nb for key - key_lo < key_span
+    u32* cnt = (u32*)scratch;
+    u32* slot = cnt + E2S_KO_MAX_BUCKETS + 2;
+    u32* gidx = slot + n;
+    u64* gkeys = (u64*)(((uintptr_t)(gidx + n) + 7) & ~(uintptr_t)7);
+    hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, st);
+    const dim3 g((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_ko_count, g, blk, 0, st, keys, n, key_lo, shift, nb, cnt, slot);
+    hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, cnt, nb);
+    hipLaunchKernelGGL(k_ko_place, g, blk, 0, st, keys, n, key_lo, shift, nb, (const u32*)cnt, (const u32*)slot, gkeys, gidx);
+    hipLaunchKernelGGL(k_ko_rank, g, blk, 0, st, (const u64*)gkeys, (const u32*)gidx, n, key_lo, shift, nb, (const u32*)cnt, order);
 }
 
 // ----------------------------------------------------------------------------------------------

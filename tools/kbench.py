@@ -14,8 +14,13 @@ torch.cuda.synchronize()
 n = blk["lcp"].numel()
 h = capi.Handle(0)
 h.attach_soa(capi.Handle.desc(n), blk["bwt"].data_ptr(), blk["lcp"].data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr())
-ts = []
-for i in range(25):
-    h.cluster_scan(16, 2, 0)
-    ts.append(h.timing().scan_main_ms)
-print("scan_main_ms median %.4f min %.4f  (%.0f GB/s LCP)" % (np.median(ts[3:]), min(ts[3:]), n / np.median(ts[3:]) / 1e6))
+flush = torch.zeros(1 << 30, dtype=torch.uint8, device=dev)       # > Infinity Cache: evicts the LCP between scans, as a full step does
+for mode in ("warm (LCP may sit in the 256 MiB Infinity Cache)", "cold (1 GiB written in between)"):
+    ts = []
+    for i in range(25):
+        if mode.startswith("cold"):
+            flush.add_(1)
+            torch.cuda.synchronize()
+        h.cluster_scan(16, 2, 0)
+        ts.append(h.timing().scan_main_ms)
+    print("scan_main_ms median %.4f min %.4f  (%.0f GB/s LCP)  %s" % (np.median(ts[3:]), min(ts[3:]), n / np.median(ts[3:]) / 1e6, mode))
