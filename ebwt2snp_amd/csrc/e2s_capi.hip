@@ -174,6 +174,7 @@ static int check_desc(e2s_handle h, const e2s_shard_desc* d) {
         return fail(h, E2S_ERR_ARG, "byte widths must be 1, 2, 4 or 8 (the reference leaves other widths uninitialised)");
     if (d->n_total == 0 || d->n_entries == 0) return fail(h, E2S_ERR_ARG, "empty EGSA (the reference reads uninitialised memory here)");
     if (d->global_offset + d->n_entries > d->n_total) return fail(h, E2S_ERR_ARG, "shard exceeds the EGSA");
+    if (d->n_total >= (1ull << 47)) return fail(h, E2S_ERR_ARG, "EGSA of 2^47 entries or more");     // SA positions are packed into 48 bits
     if (d->halo_left > d->global_offset) return fail(h, E2S_ERR_ARG, "halo_left reaches before the array start");
     if (d->global_offset + d->n_entries + d->halo_right > d->n_total) return fail(h, E2S_ERR_ARG, "halo_right reaches past the array end");
     const uint64_t need_l = std::min<uint64_t>(d->global_offset, E2S_MAX_CLUST_LEN + 2);
@@ -406,10 +407,19 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         sa.k_u32 = a.k_u32; sa.kb = a.kb; sa.hge = a.hge;
         sa.n_tiles = (h->n_prov + row_entries - 1) / row_entries;
         static int resident[5] = {0, 0, 0, 0, 0};
-        if (!resident[h->xb]) resident[h->xb] = e2s_scan_seg_resident_blocks(h->xb);
+        if (!resident[h->xb]) {
+            resident[h->xb] = e2s_scan_seg_resident_blocks(h->xb);
+            if (const char* ev = getenv("E2S_SCAN_WORKERS")) {        // tuning aid: cap the number of scan workers
+                const int cap = atoi(ev);
+                if (cap > 0 && cap < resident[h->xb]) resident[h->xb] = cap;
+            }
+        }
+        // as many workers as waves fit on the chip (a whole number per SIMD), tiles dealt out evenly: the kernel is
+        // VALU bound, so a SIMD holding one worker more, or workers one tile longer, finishes that much later
         uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
-        sa.tiles_per_block = (uint32_t)((sa.n_tiles + nb - 1) / nb);
-        nb = (sa.n_tiles + sa.tiles_per_block - 1) / sa.tiles_per_block;
+        if (nb == 0) nb = 1;
+        sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
+        sa.tiles_rem = (uint32_t)(sa.n_tiles % nb);
         if (nb > 8192) return fail(h, E2S_ERR_STATE, "more scan workers than k_seg_fix handles");
         sa.n_blocks = (uint32_t)nb;
         if (nb + 1 > h->seg_blocks_cap) {
@@ -418,8 +428,8 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             CK(hipMalloc((void**)&h->d_seg_off, (nb + 2) * 8));
             h->seg_blocks_cap = (uint32_t)(nb + 1);
         }
-        const uint64_t range_entries = (uint64_t)sa.tiles_per_block * row_entries;
-        uint64_t seg_cap = range_entries / 8 + 256;                 // typical density is ~0.03 records per entry
+        const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
+        uint64_t seg_cap = (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
             if ((rc = ensure_records(h, nb * seg_cap))) return rc;

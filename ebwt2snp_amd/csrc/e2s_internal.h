@@ -68,7 +68,8 @@ struct SegArgs {
     const void* lcp; uint64_t n_prov, prov_lo; uint32_t prov_is_global0;
     uint64_t own_lo, end_hi, start_hi;
     uint32_t k_u32, kb, hge;
-    uint64_t n_tiles; uint32_t tiles_per_block; uint32_t n_blocks;
+    uint64_t n_tiles; uint32_t tiles_per_block; uint32_t n_blocks;   // worker b owns tiles_per_block tiles, +1 for b < tiles_rem
+    uint32_t tiles_rem;
     uint64_t* starts; uint16_t* lens; uint32_t seg_cap;        // segment b = [b*seg_cap, (b+1)*seg_cap)
     SegDesc* desc;
     unsigned long long* wrap_list; uint32_t* wrap_count;        // addresses (b*seg_cap + i) of records with true length >= 65536

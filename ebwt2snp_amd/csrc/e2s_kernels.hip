@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "e2s_internal.h"
+#include <type_traits>
 #include "e2s_swar.h"
 
 // ----------------------------------------------------------------------------------------------
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
 // ----------------------------------------------------------------------------------------------
 constexpr u32 SEG_CLOSED = 0xFFFFFFFFu, SEG_NOEVENT = 0xFFFFFFFEu, SEG_UNKNOWN = 0xFFFFFFFDu;
 
+constexpr int SEG_STAGE = 256;                              // records of one wave-tile staged in LDS (more: written directly)
 constexpr int SPAN_WORDS = E2S_SPAN_BYTES / 4;               // 16 words = 64 B of LCP per thread and tile
 
 #ifndef E2S_SCAN_PREFETCH
@@ -326,19 +328,41 @@ constexpr int SPAN_WORDS = E2S_SPAN_BYTES / 4;               // 16 words = 64 B 
 // Every WAVE is its own worker: it owns a contiguous range of wave-tiles (64 lanes x 64 B = 4 KiB of LCP), carries
 // its running record count and its open cluster start in registers and writes into its own output segment.  No
 // LDS, no barrier, nothing shared between waves: the scheduler interleaves them freely.
+//
+// The kernel is VALU-issue bound (tools/valu_rate.hip: ~4.5 cycles per wave-instruction and SIMD for the integer
+// ops used here, whatever the occupancy), so the design rule is instruction count per tile:
+//   * per word only the two predicates (L >= k, L[j] >= L[j-1]) are evaluated SWAR and packed into 64-bit planes
+//     with v_dot4; the start/end stencil runs on the planes (e2s_swar.h, span_pred / plane_end / plane_start);
+//     the one bit pair a lane needs from its left neighbour travels by DPP wave_shr:1;
+//   * the open start a lane inherits is a DPP max-scan of "last start at or below this lane";
+//   * records are emitted per 32-bit half plane (half the instructions per record of a 64-bit walk).
+__device__ __forceinline__ u32 wave_incl_max(u32 x) {
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));   // row_shr:4
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));   // row_shr:8
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+    x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
+    return x;
+}
+// value of lane-1 (lane 0 receives `first`)
+__device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
+    return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xf, 0xf, false);    // wave_shr:1
+}
+
 template <int X>
 __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     constexpr int NR = SPAN_WORDS;
     constexpr int ES = 4 * NR / X;                           // entries per thread span
     constexpr int TILE = 64 * ES;                            // entries per wave-tile
-    constexpr int PRE = (X == 4) ? 2 : 1;
     constexpr int EPW = Swar<X>::EPW;
-    constexpr int NW = PRE + NR + 1;
+    constexpr int NW = NR + 2;                               // [word before][span][word after]
+    constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
     const u32 lane = threadIdx.x & 63u;
     const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // worker (= segment) index
     if (b >= a.n_blocks) return;
-    const u64 t0 = (u64)b * a.tiles_per_block;
-    const u64 t1 = min(t0 + (u64)a.tiles_per_block, a.n_tiles);
+    const u64 t0 = (u64)b * a.tiles_per_block + min(b, a.tiles_rem);
+    const u64 t1 = min(t0 + (u64)a.tiles_per_block + (b < a.tiles_rem ? 1u : 0u), a.n_tiles);
     const uint8_t* base = (const uint8_t*)a.lcp;
     const int64_t n_prov = (int64_t)a.n_prov;
     const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
@@ -349,81 +373,95 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
 
     // a lane reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of the wave
     // cover one 4 KiB stretch between them) plus the words just before and after its span
-    auto seg_load = [&](u64 tile, u32* W) {
+    // interior tile: all of its words, the word before and the word after lie inside the provided range
+    auto load_fast = [&](u64 tile, u32* W) {
         const int64_t tl = (int64_t)tile * TILE;
-        if (tl >= PRE * EPW && tl + TILE + EPW <= n_prov) {
-            // interior tile (uniform test): scalar base + 32-bit lane offset
-            const uint8_t* p = base + tl * X;
-            const u32 o = lane * (u32)(4 * NR);
+#ifdef E2S_ABL_NOLOAD                                            // diagnostic build: no memory reads, synthetic words (results are wrong)
+        {
+            u32 x = (u32)tile * 2654435761u + lane * 40503u;
 #pragma unroll
-            for (int q = 0; q < NR / 4; ++q) {
-                const uint4 v = *(const uint4*)(p + o + 16 * q);
-                W[PRE + 4 * q + 0] = v.x; W[PRE + 4 * q + 1] = v.y; W[PRE + 4 * q + 2] = v.z; W[PRE + 4 * q + 3] = v.w;
-            }
-#pragma unroll
-            for (int q = 0; q < PRE; ++q) W[q] = *(const u32*)(p + o - 4 * (PRE - q));
-            W[PRE + NR] = *(const u32*)(p + o + 4 * NR);
+            for (int w = 0; w < NW; ++w) { x = x * 1664525u + 1013904223u; W[w] = (x >> 3) & 0x1F1F1F1Fu; }
             return;
         }
-        const int64_t i0 = tl + (int64_t)lane * ES;
+#endif
+        const uint8_t* p = base + tl * X;                           // scalar base + 32-bit lane offset
+        const u32 o = lane * (u32)(4 * NR);
+#pragma unroll
+        for (int q = 0; q < NR / 4; ++q) {
+            const uint4 v = *(const uint4*)(p + o + 16 * q);
+            W[1 + 4 * q + 0] = v.x; W[1 + 4 * q + 1] = v.y; W[1 + 4 * q + 2] = v.z; W[1 + 4 * q + 3] = v.w;
+        }
+        W[0] = *(const u32*)(p + o - 4);
+        W[NR + 1] = *(const u32*)(p + o + 4 * NR);
+    };
+    // the first tile of the shard and the tiles around its end: byte by byte, zero outside the provided range
+    auto load_slow = [&](u64 tile, u32* W) {
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {                                  // (static indices: the array stays in registers)
             u32 v = 0;
 #pragma unroll
             for (int bt = 0; bt < 4; ++bt) {
-                const int64_t byte = i0 * X + (int64_t)(w - PRE) * 4 + bt;
+                const int64_t byte = i0 * X + (int64_t)(w - 1) * 4 + bt;
                 if (byte >= 0 && byte < n_prov * X) v |= (u32)base[byte] << (8 * bt);
             }
             W[w] = v;
         }
     };
+    // one entry (0 outside the provided range), the same value in every lane
+    auto entry_at = [&](int64_t i) -> u32 {
+        u32 v = 0;
+        if (i >= 0 && i < n_prov) {
+#pragma unroll
+            for (int bt = 0; bt < X; ++bt) v |= (u32)base[i * X + bt] << (8 * bt);
+        }
+        return v;
+    };
+
+    // records of a tile are staged in LDS by the lanes that own their ENDs and written out in rank order, 64 per
+    // store: a sparse store per record costs ~55 SIMD cycles on this chip whatever the number of active lanes (the
+    // per-record stores were 16 of the kernel's 68 us)
+    __shared__ uint64_t s_stage[4][SEG_STAGE];
+    uint64_t* const st_rec = s_stage[threadIdx.x >> 6];
 
     u32 run = 0;                                                // records written so far (wave-uniform)
-    u32 open = SEG_UNKNOWN;                                     // open start: offset from the range start | CLOSED | UNKNOWN
+    u32 open1 = 0;                                              // 1 + offset of the last start seen in the range (0: none yet)
+    u32 state = 0;                                              // last event of the range so far: 0 none, 1 an end, 2 a start
     u32 in0 = 0, unknown = 0;
     u64 first_end = ~0ull;
-#if E2S_SCAN_PREFETCH == 2
-    // two tiles ahead: W = the tile being processed, PA / PB = the next two, filled alternately (static register
-    // roles: the loop body is instantiated twice).  A wave keeps 4-8 KiB of loads in flight at all times, also
-    // while it computes and while it emits -- with one tile ahead the waves of a SIMD fall into step (all wait,
-    // then all compute) and neither HBM nor the VALU is busy half of the time.
-    u32 W[NW], PA[NW], PB[NW];
-    if (t0 < t1) seg_load(t0, W);
-    if (t0 + 1 < t1) seg_load(t0 + 1, PB);
-    auto body = [&](const u64 tile, u32* Pfree, u32* Wn) {
-        if (tile + 2 < t1) seg_load(tile + 2, Pfree);
-#else
-#if E2S_SCAN_PREFETCH
-    u32 W[NW], Wn[NW];
-    if (t0 < t1) seg_load(t0, W);
-#else
-    u32 W[NW];
-#endif
-    for (u64 tile = t0; tile < t1; ++tile) {
-#if E2S_SCAN_PREFETCH
-        if (tile + 1 < t1) seg_load(tile + 1, Wn);              // in flight while this tile is processed
-#else
-        seg_load(tile, W);                                      // latency is hidden by the other waves of the SIMD
-#endif
-#endif
+    // GE / end of the entry just before the range (bit 0 / bit 1): what lane 0 of the first tile inherits
+    u32 cb;
+    {
+        const int64_t r0 = (int64_t)t0 * TILE;
+        const u32 lm2 = entry_at(r0 - 2), lm1 = entry_at(r0 - 1), l0 = entry_at(r0);
+        const bool gm1 = a.hge != 0 && lm1 >= a.k_u32, g0 = a.hge != 0 && l0 >= a.k_u32;
+        const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
+        cb = (u32)__builtin_amdgcn_readfirstlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)));
+    }
+    // Two register sets that swap roles from tile to tile (the loop body is instantiated twice): W = the tile
+    // being processed, Wn = the next one, in flight meanwhile.
+    u32 WA[NW], WB[NW];
+    auto body = [&](const u64 tile, u32* W, u32* Wn, auto prefetch) {
+        constexpr bool PF = decltype(prefetch)::value;
+        if (PF) load_fast(tile + 1, Wn);                        // in flight while this tile is processed
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
-        // ---- start / end planes of the span (e2s_swar.h: streamed word by word, ~10 live registers) ----
+        // ---- start / end planes of the span ----
         u64 S, E;                                               // bit e: a cluster starts / ends at entry e of the span
-#ifdef E2S_ABL_NOSWAR                                           // diagnostic build: loads + scan + emit skeleton without the stencil
-        { u32 x = 0;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) x ^= W[w];
-          S = (x == 0x12345678u) ? 1ull : 0ull; E = (x == 0x87654321u) ? 2ull : 0ull; }
-#else
-        span_planes<X, NR>(W, a.kb, a.hge, S, E);
-#endif
+        {
+            u64 GE, NLE; u32 after;
+            span_pred<X, NR>(W, a.kb, a.hge, GE, NLE, after);
+            E = plane_end<ES>(GE, NLE, after);
+            const u32 top = (u32)((GE >> (ES - 1)) & 1ull) | ((u32)((E >> (ES - 1)) & 1ull) << 1);
+            const u32 before = wave_shr1(top, cb);
+            S = plane_start<ES>(GE, E, before);
+            cb = (u32)__builtin_amdgcn_readlane((int)top, 63);
+        }
         if (a.prov_is_global0 && i0 == 0) {
             // the j = 0,1 rules of ebwt2clust.cpp:83-84: with L[0] >= k the cluster opened at 0 swallows entry 1
             // whatever L[1] is, and j = 0 is never tested
-            constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
-            const u32 e0v = W[PRE] & LM;
-            const u32 e1v = (X == 4) ? W[PRE + 1] : ((W[PRE] >> (8 * (X & 3))) & LM);
-            const u32 e2v = (X == 4) ? W[PRE + 2] : (X == 2 ? (W[PRE + 1] & LM) : ((W[PRE] >> 16) & LM));
+            const u32 e0v = W[1] & LM;
+            const u32 e1v = (X == 4) ? W[2] : ((W[1] >> (8 * (X & 3))) & LM);
+            const u32 e2v = (X == 4) ? W[3] : (X == 2 ? (W[2] & LM) : ((W[1] >> 16) & LM));
             E &= ~1ull;
             if (a.hge != 0 && e0v >= a.k_u32) {
                 const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < a.k_u32);
@@ -447,76 +485,142 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         }
         if (tile == t0) {
             // does the range begin inside a cluster?  open(first) && !start(first)   (lane 0 holds the first entry)
-            constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
-            const bool ge0 = a.hge != 0 && (W[PRE] & LM) >= a.k_u32;
+            const bool ge0 = a.hge != 0 && (W[1] & LM) >= a.k_u32;
             in0 = (u32)__builtin_amdgcn_readfirstlane((ge0 && !(S & 1ull)) ? 1 : 0);
         }
         const u32 cnt = (u32)__popcll(E);
         const u32 inc = wave_incl_scan(cnt);
         const u32 tile_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
         const u32 base_off = (u32)((tile - t0) * TILE) + lane * ES;   // offset from the range's first entry
-        // the open start this span hands on: its last event (a start precedes an end at one position)
-        u32 co = SEG_NOEVENT;
-        if (S | E) {
-            const int ms = S ? 63 - __clzll(S) : -1, me = E ? 63 - __clzll(E) : -1;
-            co = (ms > me) ? base_off + (u32)ms : SEG_CLOSED;
+        // the start an END without a start of its own in the lane belongs to: the last start below the lane
+        const u32 ls1 = S ? base_off + (u32)(64 - __clzll(S)) : 0u;   // 1 + offset of the lane's last start
+        const u32 mx = wave_incl_max(ls1);
+        u32 cur1 = max(wave_shr1(mx, 0u), open1);
+        // the last event of the tile decides what the range hands on
+        const u64 evm = __ballot((S | E) != 0ull);
+        if (evm) {
+            const int ll = 63 - __clzll(evm);
+            const u32 slo = (u32)__builtin_amdgcn_readlane((int)(u32)S, ll), shi = (u32)__builtin_amdgcn_readlane((int)(u32)(S >> 32), ll);
+            const u32 elo = (u32)__builtin_amdgcn_readlane((int)(u32)E, ll), ehi = (u32)__builtin_amdgcn_readlane((int)(u32)(E >> 32), ll);
+            const u64 sS = ((u64)shi << 32) | slo, sE = ((u64)ehi << 32) | elo;
+            const int ms = sS ? 63 - __clzll(sS) : -1, me = sE ? 63 - __clzll(sE) : -1;   // a start precedes an end at one position
+            state = ms > me ? 2u : 1u;
         }
-        const u64 evm = __ballot(co != SEG_NOEVENT);
-        const u64 below = evm & ((1ull << lane) - 1ull);
-        const u32 got = (u32)__shfl((int)co, below ? 63 - __clzll(below) : (int)lane);   // all lanes take part
-        u32 ci = below ? got : open;
-        const u32 wlast = evm ? (u32)__builtin_amdgcn_readlane((int)co, 63 - __clzll(evm)) : SEG_NOEVENT;
-        // Take the prefetched words NOW, before the record stores: vmcnt counts loads and stores together and in order,
-        // so waiting for the next tile's loads after a data-dependent number of stores would mean waiting for every
-        // store to land (vmcnt(0)) once per tile.  This way the stores drain under the next tile's stencil.
-#if E2S_SCAN_PREFETCH
-#pragma unroll
-        for (int w = 0; w < NW; ++w) W[w] = Wn[w];
-#endif
-        // emit: one record per iteration, written whole by the lane that owns its END.  Its start is the one
-        // start bit between the previous end and this end, or -- if there is none -- the open start carried in.
+        const u32 tile_last1 = (u32)__builtin_amdgcn_readlane((int)mx, 63);
+        // Wait for the prefetched words NOW, before the record stores: vmcnt counts loads and stores together and in
+        // order, so waiting for the next tile's loads after a data-dependent number of stores would mean waiting for
+        // every store to land (vmcnt(0)) once per tile.  The empty asm "uses and redefines" the registers: the compiler
+        // places the wait here and the stores drain under the next tile's stencil.  No instruction is emitted.
+        static_assert(NW == 18, "operand list below");
+        if (PF)
+        asm volatile("" : "+v"(Wn[0]), "+v"(Wn[1]), "+v"(Wn[2]), "+v"(Wn[3]), "+v"(Wn[4]), "+v"(Wn[5]), "+v"(Wn[6]), "+v"(Wn[7]), "+v"(Wn[8]),
+                          "+v"(Wn[9]), "+v"(Wn[10]), "+v"(Wn[11]), "+v"(Wn[12]), "+v"(Wn[13]), "+v"(Wn[14]), "+v"(Wn[15]), "+v"(Wn[16]), "+v"(Wn[17]));
+        if (run == 0 && tile_total != 0) {                      // the range's first end (once per worker)
+            if (cnt != 0 && inc == cnt) first_end = g_range + base_off + (u32)(__ffsll((long long)E) - 1);
+        }
+        // emit: one record per iteration, staged by the lane that owns its END, half plane by half plane.  Its start
+        // is the start bit between the previous end and this end, or -- if there is none -- the last start before
+        // (cur1; 0 = not seen in this range: the record is finished by k_seg_fix / e2s_stitch).  Almost every tile
+        // takes the plain loop: no cluster can be 65536 long (every start used is at or after the last one seen
+        // before the tile), the segment and the staging buffer have room -- tile-uniform tests instead of per-record
+        // ones.  Staged word: (1 + SA position of the start) | length << 48.
         {
-            u32 rk = run + inc - cnt;
-            u64 done = 0;                                       // entries up to and including the previous end
-#ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loop
-            asm volatile("" :: "v"(rk), "v"(ci));
-            if (rk == 0xFFFFFFFFu)
+            const u32 rk0 = run + inc - cnt;
+            const u32 tile_end1 = (u32)((tile - t0 + 1) * TILE);
+            const bool plain = run + tile_total <= a.seg_cap && tile_end1 + 2u - open1 < 65536u && tile_total <= (u32)SEG_STAGE;
+            auto emit_half = [&](u32 Eh, const u32 Sh, const u32 hbase, u32& rk, auto mode) {
+                constexpr int MODE = decltype(mode)::value;     // 0 plain, 1 every per-record check
+                u32 done = 0;                                   // entries of the half up to and including the previous end
+                while (Eh) {
+                    const u32 e = (u32)__builtin_ctz(Eh);
+                    const u32 upto = (2u << e) - 1u;
+                    const u32 sc = Sh & upto & ~done;
+                    done = upto;
+                    Eh &= ~upto;
+                    const u32 off = hbase + e;
+                    const u32 st1 = sc ? hbase + (32u - (u32)__builtin_clz(sc)) : cur1;      // 1 + offset of the start
+                    if (MODE == 0) {
+#ifdef E2S_ABL_NOSTORE                                          // diagnostic build: the plain loop without its stores
+                        asm volatile("" :: "v"(st1), "v"(off), "v"(rk));
+#else
+                        st_rec[rk - run] = (g_range + st1) | ((u64)((off + 2u - st1) << 16) << 32);      // tile-local rank
 #endif
-            while (E) {
-                const int e = __ffsll((long long)E) - 1;
-                E &= E - 1;
-                const u64 upto = (2ull << e) - 1ull;
-                const u64 sc = S & upto & ~done;
-                done = upto;
-                const u32 off = base_off + (u32)e;
-                const u32 st = sc ? base_off + (u32)(63 - __clzll(sc)) : ci;
-                if (rk < a.seg_cap) {
-                    if (st < SEG_UNKNOWN) {
-                        const u32 len = off - st + 1u;
-                        seg_starts[rk] = g_range + st;
-                        seg_lens[rk] = (uint16_t)len;
-                        if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
-                    } else {
-                        seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
-                        unknown = 1;
+                    } else if (rk < a.seg_cap) {
+                        if (st1 != 0u) {
+                            const u32 len = off + 2u - st1;
+                            seg_starts[rk] = g_range + (st1 - 1u);
+                            seg_lens[rk] = (uint16_t)len;
+                            if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
+                        } else {
+                            seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);       // finished by k_seg_fix / e2s_stitch
+                            unknown = 1;
+                        }
+                    }
+                    ++rk;
+                }
+                // a start after the half's last end is what a later half's first end belongs to
+                const u32 pend = Sh & ~done;
+                if (pend) cur1 = hbase + (32u - (u32)__builtin_clz(pend));
+            };
+            auto emit_all = [&](auto mode) {
+                u32 rk = rk0;
+                emit_half((u32)E, (u32)S, base_off, rk, mode);
+                if (ES > 32) emit_half((u32)(E >> 32), (u32)(S >> 32), base_off + 32u, rk, mode);
+            };
+#ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loop
+            asm volatile("" :: "v"(rk0), "v"(cur1));
+            if (rk0 == 0xFFFFFFFFu)
+#endif
+            if (plain) {
+                emit_all(std::integral_constant<int, 0>{});
+#ifndef E2S_ABL_NOSTORE
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                constexpr u64 M48 = (1ull << 48) - 1ull;
+                if (open1 != 0u) {
+                    for (u32 r = lane; r < tile_total; r += 64u) {          // dense, rank-ordered stores
+                        const u64 v = st_rec[r];
+                        seg_starts[run + r] = (v & M48) - 1ull;
+                        seg_lens[run + r] = (uint16_t)(v >> 48);
+                    }
+                } else {                                                    // no start seen in the range before this tile
+                    for (u32 r = lane; r < tile_total; r += 64u) {
+                        const u64 v = st_rec[r];
+                        if ((v & M48) != g_range) {
+                            seg_starts[run + r] = (v & M48) - 1ull;
+                            seg_lens[run + r] = (uint16_t)(v >> 48);
+                        } else {                                            // staged length = offset of the end + 2
+                            seg_lens[run + r] = (uint16_t)((u32)(v >> 48) - 1u + (u32)g_range);
+                            unknown = 1;
+                        }
                     }
                 }
-                if (rk == 0) first_end = g_range + off;
-                ++rk;
-                ci = SEG_CLOSED;
-            }
+                __builtin_amdgcn_wave_barrier();
+#endif
+            } else emit_all(std::integral_constant<int, 1>{});
         }
         run += tile_total;
-        if (wlast != SEG_NOEVENT) open = wlast;
-#if E2S_SCAN_PREFETCH == 2
+        open1 = max(open1, tile_last1);
     };
-    for (u64 tile = t0; tile < t1; tile += 2) {
-        body(tile, PA, PB);
-        if (tile + 1 < t1) body(tile + 1, PB, PA);
+    // The hot loop runs over interior tiles only, two per trip (static register roles), and contains nothing but the
+    // fast loader: with the byte-wise loader of the edge tiles inlined next to it the compiler's wait-count
+    // analysis gave up at the join and waited for the prefetch it had just issued (vmcnt(0)) on every other tile.
+    {
+        const std::true_type P1{}; const std::false_type P0{};
+        u64 tile = t0;
+        // interior tiles are [1, tfe): tile 0 has no word before it, the last ones no word after
+        const u64 tfe = n_prov >= (int64_t)(TILE + EPW) ? (u64)((n_prov - EPW) / TILE) : 0ull;
+        const u64 tf = min(t1, tfe);
+        auto slow_run = [&](u64 upto) { for (; tile < upto; ++tile) { load_slow(tile, WA); body(tile, WA, WB, P0); } };
+        slow_run(min(t1, (u64)1));
+        if (tile < tf) {
+            load_fast(tile, WA);
+            while (tile + 3 <= tf) { body(tile, WA, WB, P1); body(tile + 1, WB, WA, P1); tile += 2; }
+            if (tile + 2 == tf) { body(tile, WA, WB, P1); body(tile + 1, WB, WA, P0); tile += 2; }
+            else { body(tile, WA, WB, P0); tile += 1; }
+        }
+        slow_run(t1);
     }
-#else
-    }
-#endif
     // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
     const u64 unk_m = __ballot(unknown != 0);
     const u64 fe_m = __ballot(first_end != ~0ull);
@@ -527,9 +631,9 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         d.overflow = run > a.seg_cap ? 1u : 0u;
         d.first_unknown = unk_m ? 1u : 0u;
         d.first_end_pos = fe_m ? fe : ~0ull;
-        if (open == SEG_UNKNOWN) { d.open_after = (t0 < t1) ? in0 : 0u; d.open_start = ~0ull; }   // no event at all
-        else if (open == SEG_CLOSED) { d.open_after = 0; d.open_start = ~0ull; }
-        else { d.open_after = 1; d.open_start = g_range + open; }
+        if (state == 0u) { d.open_after = (t0 < t1) ? in0 : 0u; d.open_start = ~0ull; }         // no event at all
+        else if (state == 1u) { d.open_after = 0; d.open_start = ~0ull; }
+        else { d.open_after = 1; d.open_start = g_range + (open1 - 1u); }
         a.desc[b] = d;
     }
 }
@@ -547,12 +651,22 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, c
     const u32 tid = threadIdx.x, nb = a.n_blocks;
     if (tid == 0) { s_first = 0xFFFFFFFFu; s_last = 0; s_err = 0; }
     __syncthreads();
-    for (u32 b = tid; b < nb; b += 1024) {
-        const SegDesc d = a.desc[b];
-        s_cnt[b] = d.count;
-        s_open[b] = !d.open_after ? NONE : (d.open_start != NONE ? d.open_start : PASS);
-        if (d.overflow) atomicOr(&s_err, E2S_DEVERR_SEGFULL);
-        if (d.count) { atomicMin(&s_first, b); atomicMax(&s_last, b); }
+    // every descriptor this thread looks at is loaded up front (<= 8, all in flight together: the loop used to pay
+    // one global-memory latency per trip, twice)
+    constexpr int DPT = SEGFIX_MAX / 1024;
+    u32 d_cnt[DPT], d_unk[DPT]; u64 d_fend[DPT];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+        const u32 b = tid + (u32)q * 1024u;
+        SegDesc d{};
+        if (b < nb) d = a.desc[b];
+        d_cnt[q] = d.count; d_unk[q] = d.first_unknown; d_fend[q] = d.first_end_pos;
+        if (b < nb) {
+            s_cnt[b] = d.count;
+            s_open[b] = !d.open_after ? NONE : (d.open_start != NONE ? d.open_start : PASS);
+            if (d.overflow) atomicOr(&s_err, E2S_DEVERR_SEGFULL);
+            if (d.count) { atomicMin(&s_first, b); atomicMax(&s_last, b); }
+        }
     }
     __syncthreads();
     // exclusive scan of the counts: each thread owns a contiguous chunk
@@ -581,14 +695,14 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, c
         for (u32 q = b; q-- > 0;) { const u64 v = s_open[q]; if (v != PASS) return v; }
         return NONE;
     };
-    for (u32 b = tid; b < nb; b += 1024) {
-        if (!s_cnt[b]) continue;
-        const SegDesc d = a.desc[b];
-        if (!d.first_unknown) continue;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+        const u32 b = tid + (u32)q * 1024u;
+        if (b >= nb || !d_cnt[q] || !d_unk[q]) continue;
         const u64 carry = carry_into(b);
         if (carry == NONE) continue;                                // begins in an earlier shard: e2s_stitch
         const u64 seg = (u64)b * a.seg_cap;
-        const u64 true_len = d.first_end_pos - carry + 1;
+        const u64 true_len = d_fend[q] - carry + 1;
         a.starts[seg] = carry;
         a.lens[seg] = (uint16_t)(true_len & 0xFFFFull);
         if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
@@ -787,33 +901,42 @@ __global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int m
     if (threadIdx.x == 0) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
 }
 
-// the same over the segmented record storage of scan_mode 0 (one block per segment, 32 histogram replicas in
-// LDS: cluster lengths concentrate on a few values, a single copy serialises on the hot bins)
-__global__ __launch_bounds__(256) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u64* out) {
-    constexpr int REP = 32, NB = E2S_MAX_CLUST_LEN_K + 1;
-    __shared__ u32 s_freq[REP][NB + 1];
+// the same over the segmented record storage of scan_mode 0.  A segment holds only ~10^3 lengths, so a wave takes
+// a whole segment with 16-byte loads (8 lengths per lane) and the 16 waves of a block keep as many segments in
+// flight: the first version walked the segments block by block, one global-memory latency each (31 us for 13 MB).
+// Per wave 4 histogram replicas in LDS (lengths concentrate on a few values).  Segments are 16-byte aligned
+// (seg_cap is a multiple of 8).
+__global__ __launch_bounds__(1024) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u64* out) {
+    constexpr int REP = 4, NB = E2S_MAX_CLUST_LEN_K + 1, NWV = 16;
+    __shared__ u32 s_freq[NWV * REP][NB + 1];
     __shared__ u64 s_acc[2];
-    for (int i = threadIdx.x; i < REP * (NB + 1); i += 256) (&s_freq[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < NWV * REP * (NB + 1); i += 1024) (&s_freq[0][0])[i] = 0;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
-    const u32 rep = threadIdx.x & (REP - 1);
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32* const my = s_freq[wave * REP + (lane & (REP - 1))];
     u64 nrec = 0, nb = 0;
-    for (u32 b = blockIdx.x; b < n_seg; b += gridDim.x) {
+    auto take = [&](u32 l) { if ((int)l >= min_len) { nrec++; nb += (u64)l; if (l <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&my[l], 1u); } };
+    for (u32 b = blockIdx.x * NWV + wave; b < n_seg; b += gridDim.x * NWV) {
         const u32 n = desc[b].count;
         const uint16_t* p = lens + (u64)b * seg_cap;
-        for (u32 i = threadIdx.x; i < n; i += 256) {
-            const int l = p[i];
-            if (l >= min_len) { nrec++; nb += (u64)l; if (l <= E2S_MAX_CLUST_LEN_K) atomicAdd(&s_freq[rep][l], 1u); }
+        const u32 nv = n >> 3;                                   // whole groups of 8 lengths
+        for (u32 i = lane; i < nv; i += 64u) {
+            const uint4 v = *(const uint4*)(p + 8u * i);
+            take(v.x & 0xFFFFu); take(v.x >> 16); take(v.y & 0xFFFFu); take(v.y >> 16);
+            take(v.z & 0xFFFFu); take(v.z >> 16); take(v.w & 0xFFFFu); take(v.w >> 16);
         }
+        const u32 r = (nv << 3) + lane;
+        if (r < n) take((u32)p[r]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { nrec += __shfl_xor(nrec, o); nb += __shfl_xor(nb, o); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd((u64*)&s_acc[0], nrec); atomicAdd((u64*)&s_acc[1], nb); }
+    if (lane == 0) { atomicAdd((u64*)&s_acc[0], nrec); atomicAdd((u64*)&s_acc[1], nb); }
     __syncthreads();
-    for (int i = threadIdx.x; i < NB; i += 256) {
+    for (int i = threadIdx.x; i < NB; i += 1024) {
         u32 v = 0;
-#pragma unroll
-        for (int r = 0; r < REP; ++r) v += s_freq[r][i];
+#pragma unroll 8
+        for (int r = 0; r < NWV * REP; ++r) v += s_freq[r][i];
         if (v) atomicAdd(&out[i], (u64)v);
     }
     if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
@@ -1419,7 +1542,8 @@ void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_start
     hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, out_starts, out_lens);
 }
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_hist_seg, dim3(n_blocks < 512u ? n_blocks : 512u), dim3(256), 0, st, lens, desc, seg_cap, n_blocks, min_len, out);
+    const unsigned want = (n_blocks + 15u) / 16u;                 // 16 waves per block, a segment per wave and trip
+    hipLaunchKernelGGL(k_hist_seg, dim3(want < 256u ? (want ? want : 1u) : 256u), dim3(1024), 0, st, lens, desc, seg_cap, n_blocks, min_len, out);
 }
 void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len, hipStream_t st) {
     hipLaunchKernelGGL(k_hist_tail_seg, dim3(1), dim3(64), 0, st, lens, desc, seg_cap, n_blocks, min_len, out_last_len);

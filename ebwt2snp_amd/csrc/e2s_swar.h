@@ -197,3 +197,86 @@ E2S_HD void span_planes(const u32* W, u32 kb, u32 hge, u64& S, u64& E) {
     }
     S = s; E = e;
 }
+
+// ---- second formulation (K1 from round 1b on): per word only the two PREDICATES are evaluated SWAR and packed
+// into bit planes -- GE: L[e] >= k, NLE: L[e] >= L[e-1] -- and the stencil itself runs on the 64-bit planes
+// (a handful of instructions per span instead of ~10 per word):
+//     end(e)   = GE(e) & ((~NLE(e) & NLE(e+1)) | ~GE(e+1))                       ebwt2clust.cpp:98-102
+//     start(e) = GE(e) & ~(GE(e-1) & ~end(e-1))                                  ebwt2clust.cpp:108,116-120
+// W2 = [word before the span][NR span words][word after the span].  `after`: bit 0 = GE, bit 1 = NLE of the first
+// entry after the span.  `before` (plane_start): bit 0 = GE(-1), bit 1 = end(-1), i.e. the top GE / E bits of
+// the span before this one (the previous lane on the GPU).
+// per byte (a + b + (c & 1)) >> 1 -- v_lerp_u8.  With b = ~y and c = 1 the top bit of each byte is a >= y:
+// (a - y + 256) >> 1 >= 128  <=>  a >= y.  One instruction per unsigned byte compare of four entries.
+E2S_HD u32 e2s_lerp_u8(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_lerp(a, b, c);
+#else
+    u32 r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const u32 v = (((a >> (8 * i)) & 0xFFu) + ((b >> (8 * i)) & 0xFFu) + ((c >> (8 * i)) & 1u)) >> 1;
+        r |= (v & 0xFFu) << (8 * i);
+    }
+    return r;
+#endif
+}
+
+template <int X, int NR>
+E2S_HD void span_pred(const u32* W2, u32 kb, u32 hge, u64& GE, u64& NLE, u32& after) {
+    constexpr u32 H = Swar<X>::H;
+    constexpr int EPW = Swar<X>::EPW;
+    static_assert(NR * EPW <= 64 && NR % 2 == 0, "span too long for one 64-bit plane");
+    const u32 kl = kb & ~H;
+    u32 gs[NR / 2], ns[NR / 2];                               // X = 1: 128 * (8 plane bits) per word pair
+    u64 g64 = 0, n64 = 0;
+#pragma unroll
+    for (int i = 0; i <= NR; ++i) {                           // i = NR: the word after the span (first entry only)
+        const u32 x = W2[1 + i];
+        u32 ge, nle;                                          // clean lane-MSB masks
+        if (X == 1) {
+            const u32 ny = alignbyte(~x, ~W2[i], 3);          // ~(previous entries)
+            ge = e2s_lerp_u8(x, ~kb, 0x01010101u) & hge;
+            nle = e2s_lerp_u8(x, ny, 0x01010101u) & H;
+        } else {
+            const u32 xh = x | H;
+            const u32 y = prev_elems<X>(x, W2[i]);
+            ge = bfi(x ^ kb, x, xh - kl) & hge;
+            nle = bfi(x ^ y, x, xh - (y & ~H)) & H;
+        }
+        if (i == NR) { after = ((ge >> (8 * X - 1)) & 1u) | (((nle >> (8 * X - 1)) & 1u) << 1); break; }
+        if (X == 1) {
+            if (i % 2 == 0) { gs[i / 2] = e2s_udot4(ge, 0x08040201u, 0u); ns[i / 2] = e2s_udot4(nle, 0x08040201u, 0u); }
+            else { gs[i / 2] = e2s_udot4(ge, 0x80402010u, gs[i / 2]); ns[i / 2] = e2s_udot4(nle, 0x80402010u, ns[i / 2]); }
+        } else if (X == 2) {
+            g64 |= (u64)(((ge >> 15) & 1u) | (ge >> 30)) << (2 * i);
+            n64 |= (u64)(((nle >> 15) & 1u) | (nle >> 30)) << (2 * i);
+        } else {
+            g64 |= (u64)(ge >> 31) << i;
+            n64 |= (u64)(nle >> 31) << i;
+        }
+    }
+    if (X == 1) {
+        // s = 128 * v (v = 8 plane bits): v << 8j = s << (8j - 7)
+        u32 gw[2] = {0, 0}, nw[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < NR / 2; ++j) {
+            const int h = j / 4, q = j % 4;
+            if (q == 0) { gw[h] = gs[j] >> 7; nw[h] = ns[j] >> 7; }
+            else { gw[h] |= gs[j] << (8 * q - 7); nw[h] |= ns[j] << (8 * q - 7); }
+        }
+        g64 = (u64)gw[0] | ((u64)gw[1] << 32);
+        n64 = (u64)nw[0] | ((u64)nw[1] << 32);
+    }
+    GE = g64; NLE = n64;
+}
+template <int ES> E2S_HD u64 plane_end(u64 GE, u64 NLE, u32 after) {
+    const u64 gn = (GE >> 1) | ((u64)(after & 1u) << (ES - 1));
+    const u64 nn = (NLE >> 1) | ((u64)((after >> 1) & 1u) << (ES - 1));
+    return GE & ((~NLE & nn) | ~gn);
+}
+template <int ES> E2S_HD u64 plane_start(u64 GE, u64 E, u32 before) {
+    const u64 gp = (GE << 1) | (u64)(before & 1u);
+    const u64 ep = (E << 1) | (u64)((before >> 1) & 1u);
+    const u64 s = GE & ~(gp & ~ep);
+    return ES == 64 ? s : (s & ((1ull << (ES & 63)) - 1ull));
+}

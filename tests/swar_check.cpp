@@ -79,6 +79,24 @@ template <int X, int NR> static int run(unsigned seed, int iters) {
             }
             if (EPT < 64 && ((S | E) >> (EPT & 63))) { if (bad < 5) fprintf(stderr, "span_planes stray X=%d\n", X); ++bad; }
         }
+        // second formulation: predicate planes + plane-level stencil
+        {
+            u32 W2[NR + 2];
+            for (int w = 0; w < NR + 2; ++w) W2[w] = W[PRE - 1 + w];
+            u64 GE, NLE, S, E; u32 after;
+            span_pred<X, NR>(W2, kb, hge, GE, NLE, after);
+            E = plane_end<EPT>(GE, NLE, after);
+            const u32 before = (ge(-1) ? 1u : 0u) | (endf(-1) ? 2u : 0u);
+            S = plane_start<EPT>(GE, E, before);
+            for (int e = 0; e < EPT; ++e) {
+                const bool want_end = endf(e);
+                const bool want_start = ge(e) && (!ge(e - 1) || endf(e - 1));
+                if ((bool)((GE >> e) & 1) != ge(e) || (bool)((NLE >> e) & 1) != (Lx(e) >= Lx(e - 1)) ||
+                    (bool)((S >> e) & 1) != want_start || (bool)((E >> e) & 1) != want_end) { if (bad < 5) fprintf(stderr, "span_pred X=%d NR=%d e=%d k=%llu\n", X, NR, e, (unsigned long long)k); ++bad; }
+            }
+            if (after != ((ge(EPT) ? 1u : 0u) | (Lx(EPT) >= Lx(EPT - 1) ? 2u : 0u))) { if (bad < 5) fprintf(stderr, "span_pred after X=%d\n", X); ++bad; }
+            if (EPT < 64 && ((S | E | GE | NLE) >> (EPT & 63))) { if (bad < 5) fprintf(stderr, "span_pred stray X=%d\n", X); ++bad; }
+        }
         // no stray bits outside the lane-MSB positions
         for (int w = 0; w < NR; ++w) if ((f.end[w] | f.start[w]) & ~H) { if (bad < 5) fprintf(stderr, "stray bits X=%d\n", X); ++bad; }
     }
