@@ -655,17 +655,32 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, c
     // one global-memory latency per trip, twice)
     constexpr int DPT = SEGFIX_MAX / 1024;
     u32 d_cnt[DPT], d_unk[DPT]; u64 d_fend[DPT];
+    {
+        SegDesc d[DPT];
 #pragma unroll
-    for (int q = 0; q < DPT; ++q) {
-        const u32 b = tid + (u32)q * 1024u;
-        SegDesc d{};
-        if (b < nb) d = a.desc[b];
-        d_cnt[q] = d.count; d_unk[q] = d.first_unknown; d_fend[q] = d.first_end_pos;
-        if (b < nb) {
-            s_cnt[b] = d.count;
-            s_open[b] = !d.open_after ? NONE : (d.open_start != NONE ? d.open_start : PASS);
-            if (d.overflow) atomicOr(&s_err, E2S_DEVERR_SEGFULL);
-            if (d.count) { atomicMin(&s_first, b); atomicMax(&s_last, b); }
+        for (int q = 0; q < DPT; ++q) {                         // unconditional (clamped) loads: one basic block, all in flight
+            const u32 b = tid + (u32)q * 1024u;
+            d[q] = a.desc[b < nb ? b : (nb ? nb - 1u : 0u)];
+        }
+        u32 fmin = 0xFFFFFFFFu, fmax = 0u, ferr = 0u;
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const u32 b = tid + (u32)q * 1024u;
+            const bool in = b < nb;
+            d_cnt[q] = in ? d[q].count : 0u; d_unk[q] = d[q].first_unknown; d_fend[q] = d[q].first_end_pos;
+            if (in) {
+                s_cnt[b] = d[q].count;
+                s_open[b] = !d[q].open_after ? NONE : (d[q].open_start != NONE ? d[q].open_start : PASS);
+                if (d[q].overflow) ferr = E2S_DEVERR_SEGFULL;
+                if (d[q].count) { fmin = min(fmin, b); fmax = max(fmax, b); }
+            }
+        }
+        // wave-level reduction first: one LDS atomic per wave instead of one per descriptor on a single address
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { fmin = min(fmin, (u32)__shfl_xor((int)fmin, o)); fmax = max(fmax, (u32)__shfl_xor((int)fmax, o)); ferr |= (u32)__shfl_xor((int)ferr, o); }
+        if ((tid & 63u) == 0) {
+            if (fmin != 0xFFFFFFFFu) { atomicMin(&s_first, fmin); atomicMax(&s_last, fmax); }
+            if (ferr) atomicOr(&s_err, ferr);
         }
     }
     __syncthreads();
@@ -1415,23 +1430,54 @@ __global__ void k_ko_count(const u64* keys, u64 n, u64 key_lo, u32 shift, u32 nb
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slot[i] = atomicAdd(&cnt[ko_bucket(keys[i], key_lo, shift, nb)], 1u);
 }
-// exclusive scan of cnt[0..nb) in place (one block; nb <= 2^18)
+// exclusive scan of cnt[0..nb) in place (one block; nb a power of two, 256 <= nb <= 2^18).  A thread owns `per`
+// consecutive counts and moves them 16 at a time (four 16-byte loads in flight), not one global round trip each.
 __global__ __launch_bounds__(1024) void k_ko_scan(u32* cnt, u32 nb) {
     __shared__ u32 s_part[1024];
-    const u32 tid = threadIdx.x, per = (nb + 1023u) / 1024u, lo = min(nb, tid * per), hi = min(nb, lo + per);
+    const u32 tid = threadIdx.x;
+    const u32 per = nb >= 1024u ? nb / 1024u : 1u;             // power of two
+    const u32 lo = tid * per;
+    const bool act = lo < nb;
     u32 sum = 0;
-    for (u32 b = lo; b < hi; ++b) sum += cnt[b];
+    if (act) {
+        if (per >= 4u) {
+            for (u32 i = 0; i < per; i += 16u) {
+                uint4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (i + 4u * q < per) ? *(const uint4*)(cnt + lo + i + 4u * q) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum += v[q].x + v[q].y + v[q].z + v[q].w;
+            }
+        } else for (u32 i = 0; i < per; ++i) sum += cnt[lo + i];
+    }
     s_part[tid] = sum;
     __syncthreads();
-    for (u32 d = 1; d < 1024; d <<= 1) {
-        const u32 v = tid >= d ? s_part[tid - d] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    if (tid < 64) {                           // 1024 partials: 16 per lane, wave scan
+        u32 loc = 0;
+        for (int i = 0; i < 16; ++i) loc += s_part[tid * 16 + i];
+        const u32 inc = wave_incl_scan(loc);
+        u32 run = inc - loc;
+        for (int i = 0; i < 16; ++i) { const u32 v = s_part[tid * 16 + i]; s_part[tid * 16 + i] = run; run += v; }
+        if (tid == 63) cnt[nb] = run;
     }
-    u32 run = s_part[tid] - sum;
-    for (u32 b = lo; b < hi; ++b) { const u32 c = cnt[b]; cnt[b] = run; run += c; }
-    if (tid == 1023) cnt[nb] = s_part[1023];
+    __syncthreads();
+    if (!act) return;
+    u32 run = s_part[tid];
+    if (per >= 4u) {
+        for (u32 i = 0; i < per; i += 16u) {
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (i + 4u * q < per) ? *(const uint4*)(cnt + lo + i + 4u * q) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i + 4u * q < per) {
+                    uint4 o;
+                    o.x = run; run += v[q].x; o.y = run; run += v[q].y; o.z = run; run += v[q].z; o.w = run; run += v[q].w;
+                    *(uint4*)(cnt + lo + i + 4u * q) = o;
+                }
+            }
+        }
+    } else for (u32 i = 0; i < per; ++i) { const u32 c = cnt[lo + i]; cnt[lo + i] = run; run += c; }
 }
 __global__ void k_ko_place(const u64* keys, u64 n, u64 key_lo, u32 shift, u32 nb, const u32* off, const u32* slot, u64* gkeys, u32* gidx) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
