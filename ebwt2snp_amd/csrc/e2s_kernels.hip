@@ -314,7 +314,6 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
 // No block ever waits for another one: the segments are tied together afterwards by k_seg_fix
 // (<= ~1300 descriptors, one thread).  One barrier per tile; the next tile's loads are in flight meanwhile.
 // ----------------------------------------------------------------------------------------------
-constexpr u32 SEG_CLOSED = 0xFFFFFFFFu, SEG_NOEVENT = 0xFFFFFFFEu, SEG_UNKNOWN = 0xFFFFFFFDu;
 
 constexpr int SEG_STAGE = 256;                              // records of one wave-tile staged in LDS (more: written directly)
 constexpr int SPAN_WORDS = E2S_SPAN_BYTES / 4;               // 16 words = 64 B of LCP per thread and tile
@@ -1114,14 +1113,17 @@ __global__ __launch_bounds__(CAND_WAVES * 64) void k_candidates(CandArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// K2a: streaming per-cluster allele counts + filters (phase A of find_events/find_variants,
-// clust2snp.cpp:816,377-429).  Entry-parallel: a thread-row is 16 consecutive entries; a block walks
-// windows of 4096 entries that overlap the previous window by 160, so every cluster of <= 150
-// entries that ENDS in the window's new part lies inside the window.  Cluster boundaries are
-// recomputed from the LCP with the same SWAR stencil as K1; per-cluster counts[2][4] are reduced in
-// LDS (packed 4 x 8-bit counters, one slot per cluster of the window).  Clusters that pass the
-// reference's filters are appended to a short list for K2b (lists, clust2snp.cpp:431-496).
-// Default widths only (lcp 1 B, da 4 B); bytes read per entry: lcp 1 + bwt 1 + da 4.
+// K2a: streaming per-cluster PRE-filter (phase A of find_events/find_variants, clust2snp.cpp:816,377-429).
+// Entry-parallel: a thread-row is 16 consecutive entries; a block walks windows of 4096 entries that overlap
+// the previous window by 160, so every cluster of <= 150 entries that ENDS in the window's new part lies inside
+// the window.  Cluster boundaries are recomputed from the LCP with the same SWAR stencil as the scan; per-cluster
+// base counts are reduced in LDS (packed 4 x 8-bit counters, one slot per cluster of the window).
+// What it keeps is a SUPERSET of the clusters the reference accepts, decided without the document array:
+// a cluster passes clust2snp.cpp:419-429 only if the two samples' sets of frequent bases are non-empty and
+// different, so at least two different bases occur >= mcov_out times in the cluster as a whole.  That test
+// needs the BWT only; `da` (4 of the 7 bytes of an entry) is read by K2b for the ~0.3 % of the clusters that
+// survive, where the exact per-sample test of the reference is applied.  Bytes read per entry: lcp 1 + bwt 1.
+// Default LCP width only (1 B).
 // ----------------------------------------------------------------------------------------------
 constexpr int FW_WIN = 4096;                 // window = 256 thread-rows of 16 entries
 constexpr int FW_HALO = 160;                 // >= E2S_MAX_CLUST_LEN + margin, multiple of 16
@@ -1163,7 +1165,6 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // FW_STAGE 
 #endif
 __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs a) {
     __shared__ u32 s_all[FW_SLOTS];          // C | G<<8 | T<<16 | n<<24 over both samples
-    __shared__ u32 s_s1[FW_SLOTS];           // the same for sample 1
     __shared__ u32 s_se[FW_SLOTS];           // start offset | end offset << 12 | SE_ENDED | SE_KR
     __shared__ u64 s_flq[FW_FLQ];            // flagged clusters waiting for a global reservation: start | len << 48
     __shared__ u32 s_wtot[4];
@@ -1193,8 +1194,7 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
 
     // one window's worth of loads: lcp row + edge words, bwt row, da in coalesced order
     // (lane i of load q holds entries wave*1024 + q*256 + 4i .. +3)
-    struct FwRegs { u32 W[6]; u32 B[4]; uint4 T[4]; };
-    const u32 wave_u = (u32)__builtin_amdgcn_readfirstlane((int)wave);      // wave-uniform in an SGPR
+    struct FwRegs { u32 W[6]; u32 B[4]; };
     auto fw_load = [&](u64 tile, FwRegs& r) {
         const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;
         if (win_lo >= 4 && win_lo + FW_WIN + 4 <= n_prov) {
@@ -1208,9 +1208,6 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
             r.W[5] = *(const u32*)(lp + o + 16);
             const uint4 b = *(const uint4*)(bp + o);
             r.B[0] = b.x; r.B[1] = b.y; r.B[2] = b.z; r.B[3] = b.w;
-            const u32* tp = a.da + win_lo + (int64_t)wave_u * 1024;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r.T[q] = *(const uint4*)(tp + (u32)(q * 256) + lane * 4u);
             return;
         }
         const int64_t i0 = win_lo + (int64_t)tid * 16;
@@ -1225,21 +1222,8 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
             r.W[w] = v;
             if (w >= 1 && w <= 4) r.B[w - 1] = vb;
         }
-        const int64_t wbase = win_lo + (int64_t)wave * 1024;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t e = wbase + q * 256 + (int64_t)lane * 4;
-            uint4 t = make_uint4(0, 0, 0, 0);
-            if (e + 0 >= 0 && e + 0 < n_prov) t.x = a.da[e + 0];
-            if (e + 1 >= 0 && e + 1 < n_prov) t.y = a.da[e + 1];
-            if (e + 2 >= 0 && e + 2 < n_prov) t.z = a.da[e + 2];
-            if (e + 3 >= 0 && e + 3 < n_prov) t.w = a.da[e + 3];
-            r.T[q] = t;
-        }
     };
 
-    const u32 thr32 = a.nr_reads1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)a.nr_reads1;
-    const u32 s1_ok = a.nr_reads1 > 0xFFFFFFFFull ? 0u : 15u;
     FwRegs cur, nxt;
     if (blockIdx.x < a.n_tiles) fw_load(blockIdx.x, cur);
     for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -1252,23 +1236,6 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
         for (int w = 0; w < 6; ++w) W[w] = cur.W[w];
 #pragma unroll
         for (int w = 0; w < 4; ++w) B[w] = cur.B[w];
-        // sample = !(text < nr_reads1), uint32 text against uint64 nr_reads1 (clust2snp.cpp:390)
-        u32 snib = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint4 t = cur.T[q];
-            // 32-bit compare against min(nr_reads1, 2^32-1); s1_ok = 0 when nr_reads1 exceeds every uint32 text
-            const u32 nib = (t.x >= thr32 ? 1u : 0u) | (t.y >= thr32 ? 2u : 0u) | (t.z >= thr32 ? 4u : 0u) | (t.w >= thr32 ? 8u : 0u);
-            snib |= (nib & s1_ok) << (4 * q);
-        }
-        // owner lane L = 16q + j gathers nibble q of lanes 4j .. 4j+3
-        u32 S1;
-        {
-            const int q4 = (int)(lane >> 4) * 4, j4 = (int)(lane & 15u) * 4;
-            const u32 x0 = (u32)__shfl((int)snib, j4 + 0), x1 = (u32)__shfl((int)snib, j4 + 1);
-            const u32 x2 = (u32)__shfl((int)snib, j4 + 2), x3 = (u32)__shfl((int)snib, j4 + 3);
-            S1 = ((x0 >> q4) & 15u) | (((x1 >> q4) & 15u) << 4) | (((x2 >> q4) & 15u) << 8) | (((x3 >> q4) & 15u) << 12);
-        }
         // ---- cluster boundaries (same stencil as the scan) ----
         RowFlags F;
         row_flags<1>(W, a.kb, a.hge, F);
@@ -1298,7 +1265,7 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
         for (int w = 0; w < 4; ++w) { const u32 v = s_wtot[w]; if (w < (int)wave) sbase += v; nslots += v; }
         const bool dense = nslots > FW_SLOTS;
         if (dense) { if (tid == 0) atomicOr(a.err, E2S_DEVERR_DENSE); nslots = FW_SLOTS; }
-        for (u32 s2 = tid; s2 < nslots; s2 += 256) { s_all[s2] = 0; s_s1[s2] = 0; s_se[s2] = 0; }
+        for (u32 s2 = tid; s2 < nslots; s2 += 256) { s_all[s2] = 0; s_se[s2] = 0; }
         __syncthreads();
 
         // ---- walk the events of the thread-row, flush each piece of a cluster into its slot ----
@@ -1310,11 +1277,8 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
             auto flush = [&](int hi, bool ended) {
                 if (slot < 0 || slot >= FW_SLOTS) return;
                 const u32 rm = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
-                const u32 r1 = rm & S1;
                 const u32 all = (u32)__popc(isC & rm) | ((u32)__popc(isG & rm) << 8) | ((u32)__popc(isT & rm) << 16) | ((u32)__popc(rm) << 24);
-                const u32 s1v = (u32)__popc(isC & r1) | ((u32)__popc(isG & r1) << 8) | ((u32)__popc(isT & r1) << 16) | ((u32)__popc(r1) << 24);
                 atomicAdd(&s_all[slot], all);
-                atomicAdd(&s_s1[slot], s1v);
                 u32 se = (KR & rm) ? SE_KR : 0u;
                 if (ended) se |= SE_ENDED | ((row_off + (u32)hi) << 12);
                 if (se) atomicOr(&s_se[slot], se);
@@ -1344,14 +1308,11 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
             if (epos < e_lo || epos >= e_hi) continue;
             const int len = eo - so + 1;
             if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 + append_entry's filter
-            const u32 all = s_all[s2], s1v = s_s1[s2];
-            const u32 c1C = s1v & 0xFFu, c1G = (s1v >> 8) & 0xFFu, c1T = (s1v >> 16) & 0xFFu, n1 = s1v >> 24;
-            const u32 c0C = (all & 0xFFu) - c1C, c0G = ((all >> 8) & 0xFFu) - c1G, c0T = ((all >> 16) & 0xFFu) - c1T, n0 = (all >> 24) - n1;
-            const u32 c0A = n0 - c0C - c0G - c0T, c1A = n1 - c1C - c1G - c1T;
-            u32 f0 = 0, f1 = 0;
-            if (c0A >= a.mcov_u) f0 |= 1u; if (c0C >= a.mcov_u) f0 |= 2u; if (c0G >= a.mcov_u) f0 |= 4u; if (c0T >= a.mcov_u) f0 |= 8u;
-            if (c1A >= a.mcov_u) f1 |= 1u; if (c1C >= a.mcov_u) f1 |= 2u; if (c1G >= a.mcov_u) f1 |= 4u; if (c1T >= a.mcov_u) f1 |= 8u;
-            if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) continue;   // :419-429
+            // at least two different bases with >= mcov_out occurrences over both samples (necessary for :419-429)
+            const u32 all = s_all[s2];
+            const u32 cC = all & 0xFFu, cG = (all >> 8) & 0xFFu, cT = (all >> 16) & 0xFFu, cA = (all >> 24) - cC - cG - cT;
+            const u32 nfreq = (cA >= a.mcov_u ? 1u : 0u) + (cC >= a.mcov_u ? 1u : 0u) + (cG >= a.mcov_u ? 1u : 0u) + (cT >= a.mcov_u ? 1u : 0u);
+            if (nfreq < 2u) continue;
             const u32 idx = atomicAdd(&s_nfl, 1u);
             if (idx < FW_FLQ) s_flq[idx] = (a.prov_lo + (u64)(win_lo + so)) | ((u64)len << 48);
             else atomicOr(a.err, E2S_DEVERR_DENSE);
