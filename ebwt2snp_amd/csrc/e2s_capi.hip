@@ -943,7 +943,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             f.fl_starts = h->d_fl_starts; f.fl_lens = h->d_fl_lens; f.fl_cap = h->fl_cap;
             f.fl_count = (unsigned long long*)(h->d_scalars + 2);
             CK(hipEventRecord(h->ev[6], h->stream));
-            e2s_launch_cluster_filter(f, h->stream);
+            static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;   // the first formulation, kept for cross-checks
+            if (filter_v1) e2s_launch_cluster_filter(f, h->stream); else e2s_launch_cluster_filter2(f, h->stream);
             LCHK("e2s_launch_cluster_filter");
             CK(hipEventRecord(h->ev[4], h->stream));
             a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;

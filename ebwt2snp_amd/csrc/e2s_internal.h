@@ -126,10 +126,13 @@ struct FilterArgs {
     uint32_t* err;
     uint64_t* fl_starts; uint16_t* fl_lens; uint64_t fl_cap;        // clusters that pass, for k_flagged_lists
     unsigned long long* fl_count;
+    // k_cluster_filter2: wave workers over 4096-entry tiles (worker b owns w_per tiles, +1 for b < w_rem)
+    uint64_t w_tiles; uint32_t w_per, w_rem, w_blocks;
 };
 
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
 void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
+void e2s_launch_cluster_filter2(FilterArgs a, hipStream_t st);
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);
 #define E2S_WRAP_CAP 1024

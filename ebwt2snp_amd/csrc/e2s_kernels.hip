@@ -9,6 +9,7 @@
 // Integer streaming only: no MFMA.  Layout, roofline and byte counts are in DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "e2s_internal.h"
 #include <type_traits>
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     // Two register sets that swap roles from tile to tile (the loop body is instantiated twice): W = the tile
     // being processed, Wn = the next one, in flight meanwhile.
     u32 WA[NW], WB[NW];
-    auto body = [&](const u64 tile, u32* W, u32* Wn, auto prefetch) {
+    auto body = [&](const u64 tile, u32* W, u32* Wn, auto prefetch) __attribute__((always_inline)) {
         constexpr bool PF = decltype(prefetch)::value;
         if (PF) load_fast(tile + 1, Wn);                        // in flight while this tile is processed
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
@@ -1325,6 +1326,225 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
     queue_flush();
 }
 
+// ----------------------------------------------------------------------------------------------
+// K2a, second formulation: the same pre-filter built like the scan kernel.  Every wave is a worker over a
+// contiguous range of 4096-entry tiles (a lane owns 64 entries); everything is a 64-bit plane per lane: cluster
+// starts / ends (the scan's stencil), LCP >= k_right, BWT = C / G / T.  A cluster is evaluated by the lane that
+// holds its END: its own piece [start or span begin, end] by population counts of the class planes, plus -- if
+// the cluster began in an earlier lane -- a carry (packed counts + flags) handed from lane to lane with DPP
+// wave_shr:1 (three rounds cover every cluster of <= 150 entries) and from tile to tile in an SGPR.  No LDS
+// slots, no atomics, no barrier.  Only ENDs of clusters that contain two different bases at all are walked
+// (bit-parallel: a carry-propagating add over the interior of the runs); a worker first runs the tile before
+// its range without evaluating anything, to pick up the cluster that reaches into its range.
+// ----------------------------------------------------------------------------------------------
+constexpr int F2_Q = 64;                     // flagged clusters a wave queues in LDS between global reservations
+
+__global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
+    constexpr int NR = 16, ES = 64, TILE = 4096, NW = NR + 2;
+    __shared__ u64 s_q[4][F2_Q];
+    u64* const q = s_q[threadIdx.x >> 6];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if (b >= a.w_blocks) return;
+    const u64 t0 = (u64)b * a.w_per + min(b, a.w_rem);
+    const u64 t1 = min(t0 + (u64)a.w_per + (b < a.w_rem ? 1u : 0u), a.w_tiles);
+    const u64 torg = t0 > 0 ? t0 - 1 : t0;                      // first tile processed (warm-up tile before the range)
+    const uint8_t* base = a.lcp;
+    const uint8_t* bwtb = a.bwt;
+    const int64_t n_prov = (int64_t)a.n_prov;
+    const int64_t e_lo = (int64_t)a.own_lo, e_hi = (int64_t)a.end_hi;
+    const u64 g_org = a.prov_lo + torg * TILE;                  // SA position of offset 0
+
+    auto load_fast = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
+        const int64_t tl = (int64_t)tile * TILE;
+        const uint8_t* p = base + tl;
+        const uint8_t* pb = bwtb + tl;
+        const u32 o = lane * 64u;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const uint4 v = *(const uint4*)(p + o + 16 * qd);
+            W[1 + 4 * qd + 0] = v.x; W[1 + 4 * qd + 1] = v.y; W[1 + 4 * qd + 2] = v.z; W[1 + 4 * qd + 3] = v.w;
+            const uint4 w = *(const uint4*)(pb + o + 16 * qd);
+            B[4 * qd + 0] = w.x; B[4 * qd + 1] = w.y; B[4 * qd + 2] = w.z; B[4 * qd + 3] = w.w;
+        }
+        W[0] = *(const u32*)(p + o - 4);
+        W[NR + 1] = *(const u32*)(p + o + 64);
+    };
+    auto load_slow = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            u32 v = 0, vb = 0;
+#pragma unroll
+            for (int bt = 0; bt < 4; ++bt) {
+                const int64_t e = i0 + (int64_t)(w - 1) * 4 + bt;
+                if (e >= 0 && e < n_prov) { v |= (u32)base[e] << (8 * bt); vb |= (u32)bwtb[e] << (8 * bt); }
+            }
+            W[w] = v;
+            if (w >= 1 && w <= NR) B[w - 1] = vb;
+        }
+    };
+    auto entry_at = [&](int64_t i) -> u32 { return (i >= 0 && i < n_prov) ? (u32)base[i] : 0u; };
+
+    u32 open1 = 0;                                              // 1 + offset of the last start seen (0: none yet)
+    u32 cin0 = 0;                                               // carry into lane 0 of the next tile: counts | flags << 24
+    u32 ccarry = 0;                                             // class code of the entry before the tile (2 bits)
+    u32 qn = 0;                                                 // queued flagged clusters (wave-uniform)
+    u32 cb;                                                     // GE / end of the entry before the first tile
+    {
+        const int64_t r0 = (int64_t)torg * TILE;
+        const u32 lm2 = entry_at(r0 - 2), lm1 = entry_at(r0 - 1), l0 = entry_at(r0);
+        const bool gm1 = a.hge != 0 && lm1 >= a.k_u32, g0 = a.hge != 0 && l0 >= a.k_u32;
+        const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
+        cb = (u32)__builtin_amdgcn_readfirstlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)));
+        // (the class of the entry before the first tile only matters for a cluster that is rejected for its length)
+    }
+    auto queue_flush = [&]() {
+        if (qn) {
+            u64 gbase = 0;
+            if (lane == 0) gbase = atomicAdd(a.fl_count, (unsigned long long)qn);
+            gbase = __shfl(gbase, 0);
+            if (lane < qn) {
+                const u64 v = q[lane];
+                if (gbase + lane < a.fl_cap) { a.fl_starts[gbase + lane] = v & 0xFFFFFFFFFFFFull; a.fl_lens[gbase + lane] = (uint16_t)(v >> 48); }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        qn = 0;
+    };
+
+    u32 WA[NW], WB[NW], BA[NR], BB[NR];
+    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch, auto warmup) __attribute__((always_inline)) {
+        constexpr bool PF = decltype(prefetch)::value, WARM = decltype(warmup)::value;
+        if (PF) load_fast(tile + 1, Wn, Bn);
+        const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
+        u64 S, E, GE;
+        {
+            u64 NLE; u32 after;
+            span_pred<1, NR>(W, a.kb, a.hge, GE, NLE, after);
+            E = plane_end<ES>(GE, NLE, after);
+            const u32 top = (u32)((GE >> (ES - 1)) & 1ull) | ((u32)((E >> (ES - 1)) & 1ull) << 1);
+            const u32 before = wave_shr1(top, cb);
+            S = plane_start<ES>(GE, E, before);
+            cb = (u32)__builtin_amdgcn_readlane((int)top, 63);
+        }
+        u64 IN = GE;                                            // entry lies in a cluster
+        if (a.prov_is_global0 && i0 == 0) {                     // the j = 0,1 rules (see k_scan_seg)
+            const u32 e0v = W[1] & 0xFFu, e1v = (W[1] >> 8) & 0xFFu, e2v = (W[1] >> 16) & 0xFFu;
+            E &= ~1ull;
+            if (a.hge != 0 && e0v >= a.k_u32) {
+                const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < a.k_u32);
+                S &= ~2ull;
+                E = end1 ? (E | 2ull) : (E & ~2ull);
+                if (e2v >= a.k_u32) S = end1 ? (S | 4ull) : (S & ~4ull);
+                IN |= 2ull;                                     // entry 1 belongs to the cluster opened at 0 whatever L[1] is
+            }
+        }
+        u64 C, G, T;
+        span_bwt_classes<NR>(B, C, G, T);
+        const u64 KR = span_ge_plane<NR>(W + 1, a.krb, a.kr_hge);
+        // class changes inside clusters: F(e) = class(e) != class(e-1), e in a cluster and not its first entry
+        const u64 c0 = C | T, c1 = G | T;
+        const u32 ctop = (u32)(c0 >> 63) | ((u32)(c1 >> 63) << 1);
+        const u32 cprev = wave_shr1(ctop, ccarry);
+        ccarry = (u32)__builtin_amdgcn_readlane((int)ctop, 63);
+        const u64 F = ((c0 ^ ((c0 << 1) | (u64)(cprev & 1u))) | (c1 ^ ((c1 << 1) | (u64)((cprev >> 1) & 1u)))) & IN & ~S;
+        // what the lane hands on: counts and flags from its last start (or, without a start, its whole span) to its end
+        const bool hasS = S != 0ull;
+        const int msbS = 63 - __clzll(S | 1ull);
+        const u64 tm = hasS ? ~((1ull << msbS) - 1ull) : ~0ull;
+        auto packed = [&](u64 m) -> u32 {
+            return (u32)__popcll(C & m) | ((u32)__popcll(G & m) << 8) | ((u32)__popcll(T & m) << 16) | ((KR & m) ? (1u << 24) : 0u) | ((F & m) ? (1u << 25) : 0u);
+        };
+        const u32 local = packed(tm);
+        auto merge = [](u32 x, u32 y) -> u32 { return (((x & 0xFFFFFFu) + (y & 0xFFFFFFu)) & 0xFFFFFFu) | ((x | y) & 0xFF000000u); };
+        u32 out = local;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const u32 in = wave_shr1(out, cin0);
+            out = hasS ? local : merge(local, in);
+        }
+        const u32 cin = wave_shr1(out, cin0);                   // carry into this lane
+        cin0 = (u32)__builtin_amdgcn_readlane((int)out, 63);
+        // last start at or below each lane (as in the scan)
+        const u32 base_off = (u32)((tile - torg) * TILE) + lane * ES;
+        const u32 ls1 = hasS ? base_off + (u32)msbS + 1u : 0u;
+        const u32 mx = wave_incl_max(ls1);
+        const u32 cur1 = max(wave_shr1(mx, 0u), open1);
+        open1 = max(open1, (u32)__builtin_amdgcn_readlane((int)mx, 63));
+        if (PF) {
+            static_assert(NW == 18 && NR == 16, "operand lists below");
+            asm volatile("" : "+v"(Wn[0]), "+v"(Wn[1]), "+v"(Wn[2]), "+v"(Wn[3]), "+v"(Wn[4]), "+v"(Wn[5]), "+v"(Wn[6]), "+v"(Wn[7]), "+v"(Wn[8]),
+                              "+v"(Wn[9]), "+v"(Wn[10]), "+v"(Wn[11]), "+v"(Wn[12]), "+v"(Wn[13]), "+v"(Wn[14]), "+v"(Wn[15]), "+v"(Wn[16]), "+v"(Wn[17]));
+            asm volatile("" : "+v"(Bn[0]), "+v"(Bn[1]), "+v"(Bn[2]), "+v"(Bn[3]), "+v"(Bn[4]), "+v"(Bn[5]), "+v"(Bn[6]), "+v"(Bn[7]),
+                              "+v"(Bn[8]), "+v"(Bn[9]), "+v"(Bn[10]), "+v"(Bn[11]), "+v"(Bn[12]), "+v"(Bn[13]), "+v"(Bn[14]), "+v"(Bn[15]));
+        }
+        if (WARM) return;
+        // ENDs to evaluate: owned, and of clusters with a class change somewhere (incoming flag: bit 25 of the carry)
+        u64 Ev = E;
+        const int64_t tl = (int64_t)tile * TILE;
+        if (!(tl >= e_lo && tl + TILE <= e_hi)) {
+            u64 ke = 0;
+#pragma unroll 1
+            for (int f = 0; f < ES; ++f) { const int64_t e = i0 + f; if (e >= e_lo && e < e_hi) ke |= 1ull << f; }
+            Ev &= ke;
+        }
+        const u64 Fin = F | ((((cin >> 25) & 1u) && (IN & ~S & 1ull)) ? 1ull : 0ull);
+        const u64 R = IN & ~E;
+        u64 Ei = Ev & (((R + (Fin & R)) & E) | (Fin & E));
+        if (qn > (u32)(F2_Q / 2)) queue_flush();
+        // wave-uniform loop (every lane stays until the last one is done): the queue position is wave state
+        while (__ballot(Ei != 0ull)) {
+            const bool act = Ei != 0ull;
+            const int e = act ? __ffsll((long long)Ei) - 1 : 0;
+            Ei &= Ei - 1;
+            const u64 upto = (2ull << e) - 1ull;
+            const u64 sc = S & upto;
+            const bool have = sc != 0ull;
+            const int ms = 63 - __clzll(sc | 1ull);
+            const u64 rm = have ? (upto & ~((1ull << ms) - 1ull)) : upto;
+            u32 pk = (u32)__popcll(C & rm) | ((u32)__popcll(G & rm) << 8) | ((u32)__popcll(T & rm) << 16);
+            bool kr = (KR & rm) != 0ull;
+            if (!have) { pk = merge(pk, cin) & 0xFFFFFFu; kr = kr || ((cin >> 24) & 1u); }
+            const u32 st1 = have ? base_off + (u32)ms + 1u : cur1;
+            const u32 len = base_off + (u32)e + 2u - st1;
+            const u32 cC = pk & 0xFFu, cG = (pk >> 8) & 0xFFu, cT = (pk >> 16) & 0xFFu, cA = len - cC - cG - cT;
+            const u32 nfreq = (cA >= a.mcov_u ? 1u : 0u) + (cC >= a.mcov_u ? 1u : 0u) + (cG >= a.mcov_u ? 1u : 0u) + (cT >= a.mcov_u ? 1u : 0u);
+            // st1 == 0: the cluster began before the warm-up tile, i.e. it is longer than a tile and fails the length test
+            const bool pass = act && st1 != 0u && (int)len >= a.len_lo && (int)len <= a.len_hi && kr && nfreq >= 2u;
+            const u64 pm = __ballot(pass);
+            if (pass) {
+                const u32 idx = qn + (u32)__popcll(pm & ((1ull << lane) - 1ull));
+                if (idx < (u32)F2_Q) q[idx] = (g_org + (u64)(st1 - 1u)) | ((u64)len << 48);
+                else atomicOr(a.err, E2S_DEVERR_DENSE);
+            }
+            qn = min(qn + (u32)__popcll(pm), (u32)F2_Q);
+        }
+    };
+    {
+        const std::true_type Y{}; const std::false_type N{};
+        u64 tile = torg;
+        const u64 tfe = n_prov >= (int64_t)(TILE + 4) ? (u64)((n_prov - 4) / TILE) : 0ull;   // interior tiles are [1, tfe)
+        const u64 tf = min(t1, tfe);
+        // the warm-up tile (evaluates nothing), then tile 0 of the shard if it is ours: byte-wise loads
+        if (tile < t0) {
+            if (tile >= 1 && tile < tfe) load_fast(tile, WA, BA); else load_slow(tile, WA, BA);
+            body(tile, WA, BA, WB, BB, N, Y);
+            ++tile;
+        }
+        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, N, N); } };
+        slow_run(min(t1, (u64)1));
+        if (tile < tf) {
+            load_fast(tile, WA, BA);
+            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, Y, N); body(tile + 1, WB, BB, WA, BA, Y, N); tile += 2; }
+            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, Y, N); body(tile + 1, WB, BB, WA, BA, N, N); tile += 2; }
+            else { body(tile, WA, BA, WB, BB, N, N); tile += 1; }
+        }
+        slow_run(t1);
+    }
+    queue_flush();
+}
+
 // K2b: lists and candidate records (clust2snp.cpp:431-496) for the few clusters K2a let through.  Persistent
 // blocks, one wave per cluster, candidates staged in LDS so that a block reserves output slots ~once per 32.
 template <bool DEF>
@@ -1361,7 +1581,11 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
         const u64 r = base + wave;
         if (r < n) {
             const u64 s = a.starts[r];
-            cluster_record<DEF>(a, s, (int)a.lens[r], s, lane, StageAlloc{s_stage, &s_nstage, a.stride});
+            const int len = (int)a.lens[r];
+            // entries must be resident (index n_total being the EOF phantom): a record from a broken list must not fault
+            if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull) || len < 1 || len > 3 * 64) {
+                if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
+            } else cluster_record<DEF>(a, s, len, s, lane, StageAlloc{s_stage, &s_nstage, a.stride});
         }
         __syncthreads();
     }
@@ -1604,6 +1828,18 @@ void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st) {
     u64 blocks = a.n_tiles < (u64)resident ? a.n_tiles : (u64)resident;
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_cluster_filter, dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+void e2s_launch_cluster_filter2(FilterArgs a, hipStream_t st) {
+    static int resident = 0;
+    if (!resident) {
+        resident = 4 * resident_blocks((const void*)k_cluster_filter2, 256, 0);
+        if (const char* ev = getenv("E2S_FILTER_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < resident) resident = cap; }
+    }
+    a.w_tiles = (a.n_prov + 4095) / 4096;
+    uint64_t nb = a.w_tiles < (uint64_t)resident ? a.w_tiles : (uint64_t)resident;
+    if (nb == 0) return;
+    a.w_per = (uint32_t)(a.w_tiles / nb); a.w_rem = (uint32_t)(a.w_tiles % nb); a.w_blocks = (uint32_t)nb;
+    hipLaunchKernelGGL(k_cluster_filter2, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, a);
 }
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
     const size_t dyn = (size_t)FW_STAGE * a.stride;

@@ -280,3 +280,47 @@ template <int ES> E2S_HD u64 plane_start(u64 GE, u64 E, u32 before) {
     const u64 s = GE & ~(gp & ~ep);
     return ES == 64 ? s : (s & ((1ull << (ES & 63)) - 1ull));
 }
+
+// ---- K2a planes (1-byte entries): which entries of a 64-entry span hold C / G / T (case folded, include.hpp:265-279;
+// every other byte counts as A), and which have LCP >= k_right.  byte == K  <=>  byte >= K and not byte >= K+1:
+// two v_lerp_u8 and one bit-op per word and class.
+E2S_HD u32 e2s_pack8(u32 lo4, u32 hi4) { return e2s_udot4(hi4, 0x80402010u, e2s_udot4(lo4, 0x08040201u, 0u)); }   // 128 * (8 bits)
+template <int NR>
+E2S_HD void span_assemble(const u32* s, u64& out) {          // s[j] = 128 * (plane bits 8j .. 8j+7)
+    u32 w[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < NR / 2; ++j) {
+        const int h = j / 4, q = j % 4;
+        if (q == 0) w[h] = s[j] >> 7; else w[h] |= s[j] << (8 * q - 7);
+    }
+    out = (u64)w[0] | ((u64)w[1] << 32);
+}
+template <int NR>
+E2S_HD void span_bwt_classes(const u32* B, u64& C, u64& G, u64& T) {
+    constexpr u32 H = 0x80808080u, ONE = 0x01010101u;
+    static_assert(NR == 16, "one 64-bit plane per class");
+    u32 sc[NR / 2], sg[NR / 2], st[NR / 2];
+#pragma unroll
+    for (int j = 0; j < NR / 2; ++j) {
+        u32 mc[2], mg[2], mt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32 x = B[2 * j + i] & 0xDFDFDFDFu;         // fold case
+            mc[i] = e2s_lerp_u8(x, ~0x43434343u, ONE) & ~e2s_lerp_u8(x, ~0x44444444u, ONE) & H;
+            mg[i] = e2s_lerp_u8(x, ~0x47474747u, ONE) & ~e2s_lerp_u8(x, ~0x48484848u, ONE) & H;
+            mt[i] = e2s_lerp_u8(x, ~0x54545454u, ONE) & ~e2s_lerp_u8(x, ~0x55555555u, ONE) & H;
+        }
+        sc[j] = e2s_pack8(mc[0], mc[1]); sg[j] = e2s_pack8(mg[0], mg[1]); st[j] = e2s_pack8(mt[0], mt[1]);
+    }
+    span_assemble<NR>(sc, C); span_assemble<NR>(sg, G); span_assemble<NR>(st, T);
+}
+template <int NR>
+E2S_HD u64 span_ge_plane(const u32* W /* the NR span words */, u32 kb, u32 hge) {
+    static_assert(NR == 16, "one 64-bit plane");
+    u32 sk[NR / 2];
+#pragma unroll
+    for (int j = 0; j < NR / 2; ++j)
+        sk[j] = e2s_pack8(e2s_lerp_u8(W[2 * j], ~kb, 0x01010101u) & hge, e2s_lerp_u8(W[2 * j + 1], ~kb, 0x01010101u) & hge);
+    u64 out; span_assemble<NR>(sk, out);
+    return out;
+}

@@ -103,9 +103,36 @@ template <int X, int NR> static int run(unsigned seed, int iters) {
     return bad;
 }
 
+// K2a planes: classes of BWT bytes and LCP >= k_right over a 64-entry span
+static int run_classes(unsigned seed, int iters) {
+    srand(seed);
+    int bad = 0;
+    const unsigned char pool[] = {'A', 'C', 'G', 'T', 'a', 'c', 'g', 't', 'N', '$', 'n', 0x42, 0x44, 0x46, 0x48, 0x53, 0x55, 0x63 ^ 0x80, 0xC3, 0xFF, 0x00, 0x23, 0x67 | 0x80};
+    for (int it = 0; it < iters; ++it) {
+        unsigned char b[64], l[64];
+        for (int i = 0; i < 64; ++i) { b[i] = (rand() % 3) ? pool[rand() % sizeof(pool)] : (unsigned char)rand(); l[i] = (unsigned char)rand(); }
+        u32 B[16], W[16];
+        memcpy(B, b, 64); memcpy(W, l, 64);
+        u64 C, G, T;
+        span_bwt_classes<16>(B, C, G, T);
+        const u64 kr = (u64)(rand() % 300);
+        const u32 hge = kr > 0xFF ? 0u : 0x80808080u, kb = (u32)(kr & 0xFF) * 0x01010101u;
+        const u64 K = span_ge_plane<16>(W, kb, hge);
+        for (int i = 0; i < 64; ++i) {
+            const unsigned char f = b[i] & 0xDF;
+            const bool wc = f == 'C', wg = f == 'G', wt = f == 'T', wk = hge != 0 && (u64)l[i] >= kr;
+            if ((bool)((C >> i) & 1) != wc || (bool)((G >> i) & 1) != wg || (bool)((T >> i) & 1) != wt || (bool)((K >> i) & 1) != wk) {
+                if (bad < 5) fprintf(stderr, "classes i=%d byte=%02x\n", i, b[i]);
+                ++bad;
+            }
+        }
+    }
+    return bad;
+}
+
 int main() {
     int bad = run<1, 4>(1, 200000) + run<2, 4>(2, 200000) + run<4, 4>(3, 200000) +
-              run<1, 16>(4, 60000) + run<2, 16>(5, 60000) + run<4, 16>(6, 60000);
+              run<1, 16>(4, 60000) + run<2, 16>(5, 60000) + run<4, 16>(6, 60000) + run_classes(7, 40000);
     printf("swar_check: %s (%d mismatches)\n", bad ? "FAIL" : "OK", bad);
     return bad ? 1 : 0;
 }
