@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --cpu-sample 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" $ARGS > "$out/stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d "$out/$c" -o run -- python3 "$root/bench.py" --steps 3 --warmup 1 --cpu-sample 0 > "$out/$c.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-include-regex "^(void )?k_" --output-format csv -d "$out/$c" -o run -- python3 "$root/bench.py" --steps 3 --warmup 1 --cpu-sample 0 > "$out/$c.log" 2>&1
 done
 find "$out" -name "*.db" -delete; find "$out" -name "*kernel_trace.csv" -size +20M -delete
 du -sh "$out" "$out"/* | tail -8

@@ -7,7 +7,7 @@ usage: tools/profile_summary.py gpurun_out/<tag> profiles/<round>"""
 import csv, glob, json, os, sys
 
 OURS = ("k_scan", "k_seg", "k_hist", "k_cluster_filter", "k_flagged", "k_cand", "k_candidates", "k_shard", "k_apply",
-        "k_tile", "k_unpack")
+        "k_tile", "k_unpack", "k_ko")
 
 
 def ours(name):
