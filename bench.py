@@ -89,33 +89,55 @@ def _tick(name, t0):
     return t1
 
 
-def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2):
+_XCHG = {}
+# E2S_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the N-rank logic (shards, single
+# exchange, stitch plans, merged statistics) on a one-GPU box; not a measurement
+REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
+
+
+def _exchange(blob, world, dist, dev):
+    """ONE all-gather (RCCL) of a small fixed-size blob per rank; persistent pinned / device buffers."""
+    n = len(blob)
+    x = _XCHG.get(n)
+    if x is None:
+        x = dict(src=torch.empty(n, dtype=torch.uint8).pin_memory(), dst=torch.empty(world * n, dtype=torch.uint8).pin_memory(),
+                 d_src=torch.empty(n, dtype=torch.uint8, device=dev), d_dst=torch.empty(world * n, dtype=torch.uint8, device=dev))
+        _XCHG[n] = x
+    x["src"].numpy()[:] = np.frombuffer(blob, dtype=np.uint8)
+    if REHEARSAL:                                                  # gloo: host tensors
+        dist.all_gather_into_tensor(x["dst"], x["src"])
+        raw = x["dst"].numpy().tobytes()
+        return [raw[i * n:(i + 1) * n] for i in range(world)]
+    x["d_src"].copy_(x["src"], non_blocking=True)
+    dist.all_gather_into_tensor(x["d_dst"], x["d_src"])
+    x["dst"].copy_(x["d_dst"], non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    raw = x["dst"].numpy().tobytes()
+    return [raw[i * n:(i + 1) * n] for i in range(world)]
+
+
+def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None):
     t = time.perf_counter()
-    h.cluster_scan(k, min_len, 0)
+    h.cluster_scan(k, min_len, 0)                                  # scan + statistics of the shard's own records
     t = _tick("scan", t)
     b = h.boundary()
     if world > 1:
-        t = torch.frombuffer(bytearray(bytes(b)), dtype=torch.uint8).to(dev)
-        allt = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(allt, t)                       # the boundary stitch: ONE all-gather
-        raw = allt.cpu().numpy().tobytes()
-        sz = ctypes.sizeof(capi.Boundary)
-        allb = [capi.Boundary.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(world)]
+        # the boundary stitch: ONE all-gather carries descriptor + statistics of every rank
+        st = h.scan_stats()
+        sb, ss = ctypes.sizeof(capi.Boundary), ctypes.sizeof(capi.ScanStats)
+        parts = _exchange(bytes(b) + bytes(st), world, dist, dev)
+        allb = [capi.Boundary.from_buffer_copy(p[:sb]) for p in parts]
+        alls = [capi.ScanStats.from_buffer_copy(p[sb:sb + ss]) for p in parts]
     else:
         allb = [b]
     h.stitch(allb, rank)
     t = _tick("stitch", t)
-    hs = h.hist()
-    t = _tick("hist", t)
     if world > 1:
-        t = torch.frombuffer(bytearray(bytes(hs)), dtype=torch.uint8).to(dev)
-        allt = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(allt, t)
-        raw = allt.cpu().numpy().tobytes()
-        sz = ctypes.sizeof(capi.Hist)
-        hists = [capi.Hist.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(world)]
+        # every rank applies every rank's stitch plan to that rank's statistics (pure host functions)
+        hists = [capi.hist_after_stitch(alls[r], allb[r], capi.stitch_plan(allb, r, n_total, k, 1)) for r in range(world)]
     else:
-        hists = [hs]
+        hists = [h.hist()]
+    t = _tick("hist", t)
     mcl, n_clust, _ = capi.auto_max_clust_length(hists, prm_base["m"], 0.99)
     prm = capi.C2SParams(prm_base["n1"], 31, 30, prm_base["m"], 20, mcl, min_len)
     t = _tick("stats", t)
@@ -204,8 +226,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if REHEARSAL:
+            local = 0
+            import faulthandler
+            faulthandler.dump_traceback_later(600, exit=True)     # a rehearsal that stalls says where
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the box's hostname may not resolve
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -231,22 +260,23 @@ def main():
 
     info = None
     for _ in range(a.warmup):
-        info = run_step(h, prm_base, world, rank, dist, dev)
+        info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total)
     scan_ms, cand_ms, scan_all_ms, hist_ms = [], [], [], []
     barrier()
     PHASES.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        info = run_step(h, prm_base, world, rank, dist, dev)
+        info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total)
         tm = h.timing()
         scan_ms.append(tm.scan_main_ms); cand_ms.append(tm.cand_main_ms); scan_all_ms.append(tm.scan_ms); hist_ms.append(tm.hist_ms)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if REHEARSAL else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([info["n_ends"], info["n_cand"]], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([info["n_ends"], info["n_cand"]], dtype=torch.int64, device=rdev)
         dist.all_reduce(cnt)
         tot_ends, tot_cand = int(cnt[0].item()), int(cnt[1].item())
     else:

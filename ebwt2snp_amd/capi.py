@@ -46,6 +46,11 @@ class Hist(C.Structure):
                 ("last_len", C.c_uint64)]
 
 
+class ScanStats(C.Structure):
+    _fields_ = [("hist", Hist), ("last_is_first", C.c_uint32), ("last_none", C.c_uint32), ("min_len", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+
 class C2SParams(C.Structure):
     _fields_ = [("nr_reads1", C.c_uint64), ("k_left", C.c_int32), ("k_right", C.c_int32), ("mcov_out", C.c_int32),
                 ("consensus_reads", C.c_int32), ("max_clust_length", C.c_int32), ("min_len", C.c_int32)]
@@ -70,7 +75,8 @@ class Timing(C.Structure):
 # every symbol include/e2s_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
            "e2s_attach_soa", "e2s_upload_lcp", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
-           "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_load_clusters", "e2s_cluster_hist",
+           "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
+           "e2s_hist_after_stitch",
            "e2s_auto_max_clust_length", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_snp_from_candidates", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
 
@@ -102,6 +108,8 @@ def lib():
     L.e2s_fetch_clusters.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.e2s_load_clusters.argtypes = [H, C.c_void_p, C.c_uint64]
     L.e2s_cluster_hist.argtypes = [H, C.POINTER(Hist)]
+    L.e2s_scan_stats_desc.argtypes = [H, C.POINTER(ScanStats)]
+    L.e2s_hist_after_stitch.argtypes = [C.POINTER(ScanStats), C.POINTER(Boundary), C.POINTER(StitchPlan), C.POINTER(Hist)]
     L.e2s_auto_max_clust_length.argtypes = [C.POINTER(Hist), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_find_candidates.argtypes = [H, C.POINTER(C2SParams), C.c_uint64, C.POINTER(C.c_uint64)]
@@ -210,6 +218,12 @@ class Handle:
         self._ck(self.L.e2s_cluster_hist(self.h, C.byref(hs)))
         return hs
 
+    def scan_stats(self):
+        """statistics of the scan's own records, available right after cluster_scan (no GPU work)"""
+        st = ScanStats()
+        self._ck(self.L.e2s_scan_stats_desc(self.h, C.byref(st)))
+        return st
+
     def find_candidates(self, params, record_index_base=0):
         n = C.c_uint64(0)
         self._ck(self.L.e2s_find_candidates(self.h, C.byref(params), record_index_base, C.byref(n)))
@@ -259,6 +273,15 @@ def stitch_plan(all_b, rank, n_total, k=16, lcp_bytes=1):
     if rc:
         raise E2SError(rc, "e2s_stitch_plan: inconsistent boundary descriptors")
     return pl
+
+
+def hist_after_stitch(raw, boundary, plan):
+    """Host-only: a rank's statistics once its stitch plan is applied (what Handle.hist() returns after stitch)."""
+    hs = Hist()
+    rc = lib().e2s_hist_after_stitch(C.byref(raw), C.byref(boundary), C.byref(plan), C.byref(hs))
+    if rc:
+        raise E2SError(rc, "e2s_hist_after_stitch")
+    return hs
 
 
 def auto_max_clust_length(hists, mcov_out=5, pval=0.99):

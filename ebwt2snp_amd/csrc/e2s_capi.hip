@@ -51,6 +51,7 @@ struct e2s_ctx {
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
     uint32_t* pin_order = nullptr;
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
+    e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
     uint64_t* d_keys = nullptr; uint64_t keys_cap = 0;
     bool cand_downloaded = false;
@@ -137,7 +138,7 @@ static void release_shard(e2s_ctx* h) {
     for (void* p : h->owned) hipFree(p);
     h->owned.clear();
     h->bwt = nullptr; h->lcp = h->pos = h->da = nullptr;
-    h->have_shard = false; h->attached = false; h->scanned = h->stitched = false; h->records_from_file = false;
+    h->have_shard = false; h->attached = false; h->scanned = h->stitched = false; h->records_from_file = false; h->raw_stats_valid = false;
     h->tail_bwt_given = false; h->last_known = false;
 }
 
@@ -447,7 +448,16 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
                                h->d_mail, h->stream);
             LCHK("e2s_launch_seg_fix");
             CK(hipEventRecord(h->ev[1], h->stream));
+            // statistics of the records in the same phase (no second round trip): e2s_scan_stats_desc / e2s_cluster_hist
+            uint64_t* dh = h->d_scalars + 8;
+            CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 5) * 8, h->stream));
+            CK(hipEventRecord(h->ev[4], h->stream));
+            e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)dh, h->stream);
+            CK(hipEventRecord(h->ev[5], h->stream));
+            e2s_launch_hist_tail_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
+            LCHK("e2s_launch_hist_seg");
             CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
+            CK(hipMemcpyAsync(h->pin_mail + 256, dh, (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));
             CK(hipStreamSynchronize(h->stream));
             CK(hipGetLastError());
             mail = *(const ScanMail*)h->pin_mail;
@@ -458,9 +468,24 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
         h->first_rec_addr = mail.first_rec_addr;
         h->n_ends = mail.total_ends;
+        {
+            const uint64_t* buf = (const uint64_t*)(h->pin_mail + 256);
+            e2s_scan_stats& rs = h->raw_stats;
+            memset(&rs, 0, sizeof(rs));
+            memcpy(rs.hist.freq, buf, (E2S_MAX_CLUST_LEN + 1) * 8);
+            rs.hist.n_records = buf[E2S_MAX_CLUST_LEN + 1];
+            rs.hist.n_bases = buf[E2S_MAX_CLUST_LEN + 2];
+            const uint64_t at = buf[E2S_MAX_CLUST_LEN + 4];
+            rs.last_none = at == ~0ull ? 1u : 0u;
+            rs.last_is_first = (!rs.last_none && at == mail.first_rec_addr) ? 1u : 0u;
+            rs.hist.last_len = rs.last_none ? 0 : buf[E2S_MAX_CLUST_LEN + 3];
+            rs.min_len = min_len;
+            h->raw_stats_valid = true;
+            hipEventElapsedTime(&h->tm.hist_ms, h->ev[4], h->ev[5]);
+        }
     } else {
         // ---- three-kernel count / scan / emit into contiguous arrays ----
-        h->segmented = false; h->first_rec_addr = 0;
+        h->segmented = false; h->first_rec_addr = 0; h->raw_stats_valid = false;
         const uint64_t tile_entries = (uint64_t)E2S_SCAN_ROWS * E2S_SCAN_BLOCK * (16 / h->xb);
         a.n_tiles = (h->n_prov + tile_entries - 1) / tile_entries;
         if (a.n_tiles > 0x7FFFFFFFull) return fail(h, E2S_ERR_ARG, "shard too large for one launch");
@@ -724,10 +749,16 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     dbg_entry("e2s_cluster_hist");
     if (!h || !out) return E2S_ERR_ARG;
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
+    if (h->segmented && h->raw_stats_valid && !h->records_from_file) {      // computed by the scan: apply the stitch plan on the host
+        e2s_boundary b;
+        int rc = e2s_boundary_desc(h, &b);
+        if (rc) return rc;
+        return e2s_hist_after_stitch(&h->raw_stats, &b, &h->plan, out);
+    }
     CK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
     uint64_t* dh = h->d_scalars + 8;
-    CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 4) * 8, h->stream));
+    CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 5) * 8, h->stream));
     CK(hipEventRecord(h->ev[4], h->stream));
     if (h->segmented) {
         if (h->n_ends) e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, (unsigned long long*)dh, h->stream);
@@ -757,6 +788,36 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
             }
         }
     }
+    return E2S_OK;
+}
+
+extern "C" int e2s_scan_stats_desc(e2s_handle h, e2s_scan_stats* out) {
+    if (!h || !out) return E2S_ERR_ARG;
+    if (!h->scanned || !h->segmented || !h->raw_stats_valid) return fail(h, E2S_ERR_STATE, "no scan statistics (e2s_cluster_scan with scan_mode 0 has not run)");
+    *out = h->raw_stats;
+    return E2S_OK;
+}
+
+extern "C" int e2s_hist_after_stitch(const e2s_scan_stats* raw, const e2s_boundary* b, const e2s_stitch_plan_t* plan, e2s_hist* out) {
+    if (!raw || !b || !plan || !out) return E2S_ERR_ARG;
+    *out = raw->hist;
+    const int min_len = raw->min_len;
+    auto add = [&](int l, int sign) {
+        if (l < min_len) return;
+        out->n_records += (uint64_t)(int64_t)sign; out->n_bases += (uint64_t)((int64_t)sign * l);
+        if (l <= E2S_MAX_CLUST_LEN) out->freq[l] += (uint64_t)(int64_t)sign;
+    };
+    if (plan->patch_first) {                                     // record 0: provisional length out, stitched length in
+        const int oldl = (int)(b->first_end_low16 & 0xFFFFu), newl = (int)plan->first_len;
+        add(oldl, -1);
+        add(newl, +1);
+        if (raw->last_none || raw->last_is_first) out->last_len = newl >= min_len ? (uint64_t)newl : 0;
+    }
+    for (uint32_t t = 0; t < plan->n_tail; ++t) {                // the EOF tail records live in the stitch plan
+        const int l = plan->tail_len[t];
+        if (l >= min_len) { add(l, +1); out->last_len = (uint64_t)l; }
+    }
+    if (!out->n_records) out->last_len = 0;
     return E2S_OK;
 }
 

@@ -958,12 +958,13 @@ __global__ __launch_bounds__(1024) void k_hist_seg(const uint16_t* lens, const S
 }
 __global__ void k_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 v = 0; bool found = false;
+    u64 v = 0, at = ~0ull; bool found = false;
     for (u32 b = n_blocks; b-- > 0 && !found;) {
         const uint16_t* p = lens + (u64)b * seg_cap;
-        for (u32 i = desc[b].count; i-- > 0;) if ((int)p[i] >= min_len) { v = p[i]; found = true; break; }
+        for (u32 i = desc[b].count; i-- > 0;) if ((int)p[i] >= min_len) { v = p[i]; at = (u64)b * seg_cap + i; found = true; break; }
     }
-    *out_last_len = v;
+    out_last_len[0] = v;
+    out_last_len[1] = at;                                        // where that record lives (~0: none qualifies)
 }
 
 // ----------------------------------------------------------------------------------------------

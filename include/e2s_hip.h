@@ -150,6 +150,22 @@ typedef struct {
 } e2s_hist;
 int e2s_cluster_hist(e2s_handle h, e2s_hist* out);
 
+/* The same statistics as the scan left them, available right after e2s_cluster_scan (the scan computes them in
+ * the same phase, no further GPU work): together with e2s_boundary this is everything a rank has to publish, so
+ * descriptor and statistics travel in ONE all-gather.  `hist` counts the shard's own n_ends records with the
+ * lengths as stored before e2s_stitch (record 0 provisional if the shard begins inside a cluster). */
+typedef struct {
+    e2s_hist hist;
+    uint32_t last_is_first;   /* hist.last_len was taken from record 0                                 */
+    uint32_t last_none;       /* no record reaches min_len                                              */
+    int32_t  min_len;         /* the -m the scan ran with                                               */
+    uint32_t reserved;
+} e2s_scan_stats;
+int e2s_scan_stats_desc(e2s_handle h, e2s_scan_stats* out);
+/* Host-only, pure: rank's statistics once its stitch plan (e2s_stitch_plan) is applied -- what e2s_cluster_hist
+ * returns after e2s_stitch.  b = the rank's own descriptor. */
+int e2s_hist_after_stitch(const e2s_scan_stats* raw, const e2s_boundary* b, const e2s_stitch_plan_t* plan, e2s_hist* out);
+
 /* Host-only: merge per-rank partials in rank order, apply the reference's double count of the
  * last record (H4) and its auto-detection loop incl. the -Ofast arithmetic (H19).
  * Returns E2S_ERR_REF_CRASH where the reference divides by zero (no record / no length<=150). */

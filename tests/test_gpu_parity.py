@@ -184,12 +184,23 @@ def test_sharded_scan_and_candidates_on_one_gpu(tmp_path):
         closed = 0
         recs = []
         hists = []
+        raws = [h.scan_stats() for h in hs]                     # before the stitch: what a rank publishes with its descriptor
         for r, h in enumerate(hs):
             h.stitch(allb, r)
             c, _ = h.counts()
             closed += c
             recs.append(h.fetch_clusters())
             hists.append(h.hist())
+            # the statistics of the scan phase + the stitch plan (pure host functions, any rank can evaluate them for
+            # any other rank) must equal the statistics of the records the shard finally holds
+            pure = capi.hist_after_stitch(raws[r], allb[r], capi.stitch_plan(allb, r, n, 16, 1))
+            ln = np.frombuffer(recs[-1], dtype=IO.CLUSTER_DTYPE)["length"].astype(np.int64)
+            keep = ln[ln >= 2]
+            want_freq = np.bincount(keep[keep <= capi.MAX_CLUST_LEN], minlength=capi.MAX_CLUST_LEN + 1)
+            for hh in (hists[-1], pure):
+                assert list(hh.freq) == want_freq.tolist()
+                assert hh.n_records == keep.size and hh.n_bases == int(keep.sum())
+                assert hh.last_len == (int(keep[-1]) if keep.size else 0)
         assert closed == ocnt
         assert np.concatenate(recs).tobytes() == ocl
         mcl, _, _ = capi.auto_max_clust_length(hists, 5, 0.99)
