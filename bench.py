@@ -143,7 +143,7 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None)
     t = _tick("stats", t)
     ncand = h.find_candidates(prm, rank << 40)
     t = _tick("candidates", t)
-    recs, order, ncand, cap, stride = h.candidates_view()      # pinned host memory, SA order via `order`
+    stream, off8, ncand = h.candidates_packed()                  # pinned host memory, packed, SA order (what the host tail consumes)
     t = _tick("view", t)
     return dict(n_ends=b.n_ends, n_cand=ncand, mcl=mcl, n_clust=n_clust)
 

@@ -78,7 +78,7 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
            "e2s_hist_after_stitch",
            "e2s_auto_max_clust_length", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
-           "e2s_snp_from_candidates", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
+           "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
 
 _lib = None
 
@@ -119,6 +119,9 @@ def lib():
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
     L.e2s_snp_from_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p,
                                           C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_candidates_packed.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_snp_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(TailParams), C.c_char_p, C.c_char_p,
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_last_timing.argtypes = [H, C.POINTER(Timing)]
     L.e2s_stream.argtypes = [H, C.POINTER(C.c_void_p)]
     L.e2s_synchronize.argtypes = [H]
@@ -251,6 +254,17 @@ class Handle:
         o = np.ctypeslib.as_array(C.cast(order, C.POINTER(C.c_uint32)), shape=(n.value,))
         return r, o, n.value, cap.value, stride.value
 
+    def candidates_packed(self):
+        """zero-copy: (packed stream uint8 view into the handle's pinned buffer, offsets8 uint32 view with n + 1 entries, n)"""
+        st, off = C.c_void_p(), C.c_void_p()
+        n, nbytes = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.e2s_candidates_packed(self.h, C.byref(st), C.byref(off), C.byref(n), C.byref(nbytes)))
+        if not n.value:
+            return np.zeros(0, np.uint8), np.zeros(1, np.uint32), 0
+        r = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint8)), shape=(nbytes.value,))
+        o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint32)), shape=(n.value + 1,))
+        return r, o, n.value
+
     def timing(self):
         t = Timing()
         self._ck(self.L.e2s_last_timing(self.h, C.byref(t)))
@@ -305,6 +319,16 @@ def snp_from_candidates(cands, n_cand, list_cap, fasta_path, out_path, k_left=31
                                        out_path.encode(), C.byref(nv), C.byref(ne))
     if rc:
         raise E2SError(rc, "e2s_snp_from_candidates")
+    return nv.value, ne.value
+
+
+def snp_from_packed(stream, offsets8, n_cand, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2):
+    p = TailParams(k_left, k_right, max_gap, max_err)
+    nv, ne = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().e2s_snp_from_packed(_ptr(stream), _ptr(offsets8), n_cand, C.byref(p), fasta_path.encode(), out_path.encode(),
+                                   C.byref(nv), C.byref(ne))
+    if rc:
+        raise E2SError(rc, "e2s_snp_from_packed")
     return nv.value, ne.value
 
 

@@ -49,7 +49,9 @@ struct e2s_ctx {
     uint8_t* d_cand = nullptr; uint64_t cand_cap = 0, cand_bytes = 0; uint32_t cand_stride = 0, list_cap = 0; uint64_t n_cand = 0;
     bool tail_bwt_given = false; uint8_t tail_bwt_arg = 0;
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
-    uint32_t* pin_order = nullptr;
+    uint32_t* pin_order = nullptr;                                // offsets (8-byte units) of the packed candidates, n_cand + 1 entries
+    uint32_t* d_size8 = nullptr; uint64_t size8_cap = 0;          // pack scratch
+    std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
@@ -154,7 +156,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->pin_cand) hipHostFree(h->pin_cand);
     if (h->pin_mail) hipHostFree(h->pin_mail);
     hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
-    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys);
+    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_size8);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     if (h->stream2) hipStreamDestroy(h->stream2);
     hipStreamDestroy(h->stream);
@@ -1042,7 +1044,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     if (!done) return fail(h, E2S_ERR_CAPACITY, "candidate / flagged buffer overflow");
     const bool streaming_done = streaming;
     h->n_cand = count;
-    h->cand_downloaded = false;
+    h->cand_downloaded = false; h->host_fixed_valid = false;
     if (count) {
         // SA order on the GPU, then ONE download of records + permutation into pinned memory
         if (count > h->order_cap) {
@@ -1052,8 +1054,9 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             CK(hipMalloc((void**)&h->d_order, c2 * 4));
             h->order_cap = c2;
         }
+        // pinned host buffer: the packed stream can not exceed the fixed-stride size; offsets follow it
         const size_t rec_bytes = (size_t)count * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
-        const size_t need = ord_off + (size_t)count * 4;
+        const size_t need = ord_off + ((size_t)count + 1) * 4;
         if (need > h->pin_cand_bytes) {
             if (h->pin_cand) hipHostFree(h->pin_cand);
             h->pin_cand = nullptr; h->pin_cand_bytes = 0;
@@ -1061,18 +1064,25 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             h->pin_cand_bytes = need + need / 4 + 4096;
         }
         h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
-        // the records are final (the stream was synchronised above): they travel on the second stream while the
-        // first one computes the SA order
-        CK(hipMemcpyAsync(h->pin_cand, h->d_cand, rec_bytes, hipMemcpyDeviceToHost, h->stream2));
+        const uint64_t n_pad = (count + 4095) & ~4095ull;
+        if (n_pad + 1 > h->size8_cap) {
+            hipFree(h->d_size8); h->d_size8 = nullptr; h->size8_cap = 0;
+            CK(hipMalloc((void**)&h->d_size8, (n_pad + 4096 + 1) * 4));
+            h->size8_cap = n_pad + 4096 + 1;
+        }
         // k_flagged_lists leaves the SA-order keys next to the records; the record-driven pass builds them from the headers
         if (!streaming_done) e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
         const uint64_t key_lo = (streaming_done ? h->prov_lo : record_index_base) << 2;
         const uint64_t key_span = ((streaming_done ? h->n_prov : h->n_rec) + 1) << 2;
         e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, key_lo, key_span, h->d_rank, h->d_order, h->stream);
         LCHK("e2s_launch_cand_order");
-        CK(hipMemcpyAsync(h->pin_order, h->d_order, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+        // SA order, packed, straight into the pinned buffer (the GPU writes host memory: no copy, no second wait)
+        void* dev_pin = nullptr;
+        CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
+        e2s_launch_cand_pack(h->d_cand, a.stride, a.list_cap, h->d_order, count, h->d_size8, n_pad, (uint8_t*)dev_pin,
+                             (uint32_t*)((uint8_t*)dev_pin + ord_off), h->stream);
+        LCHK("e2s_launch_cand_pack");
         CK(hipStreamSynchronize(h->stream));
-        CK(hipStreamSynchronize(h->stream2));
         CK(hipGetLastError());
         h->cand_downloaded = true;
     }
@@ -1084,6 +1094,27 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     return E2S_OK;
 }
 
+// the fixed-stride layout of include/e2s_hip.h, in SA order, rebuilt on the host from the packed stream
+static void expand_fixed(e2s_ctx* h) {
+    if (h->host_fixed_valid) return;
+    const size_t st = h->cand_stride; const uint32_t cap = h->list_cap;
+    h->host_fixed.assign((size_t)h->n_cand * st, 0);
+    h->host_ident.resize(h->n_cand);
+    for (uint64_t i = 0; i < h->n_cand; ++i) {
+        const uint8_t* r = h->pin_cand + (size_t)h->pin_order[i] * 8;
+        const e2s_cand_header* hd = (const e2s_cand_header*)r;
+        const uint32_t* l = (const uint32_t*)(r + sizeof(e2s_cand_header));
+        uint8_t* o = h->host_fixed.data() + i * st;
+        memcpy(o, hd, sizeof(e2s_cand_header));
+        uint32_t* ol = (uint32_t*)(o + sizeof(e2s_cand_header));
+        memcpy(ol, l, (size_t)hd->n0 * 4); memcpy(ol + cap, l + hd->n0, (size_t)hd->n0 * 4);
+        memcpy(ol + 2 * (size_t)cap, l + 2 * (size_t)hd->n0, (size_t)hd->n1 * 4);
+        memcpy(ol + 3 * (size_t)cap, l + 2 * (size_t)hd->n0 + hd->n1, (size_t)hd->n1 * 4);
+        h->host_ident[i] = (uint32_t)i;
+    }
+    h->host_fixed_valid = true;
+}
+
 extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand) {
     dbg_entry("e2s_fetch_candidates");
     if (!h || !n_cand) return E2S_ERR_ARG;
@@ -1092,9 +1123,8 @@ extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, 
     if (cap_cand < h->n_cand) return fail(h, E2S_ERR_CAPACITY, "candidate output too small");
     if (!h->n_cand) return E2S_OK;
     if (!h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
-    const size_t st = h->cand_stride;
-    uint8_t* o = (uint8_t*)out;
-    for (uint64_t i = 0; i < h->n_cand; ++i) memcpy(o + i * st, h->pin_cand + (size_t)h->pin_order[i] * st, st);
+    expand_fixed(h);
+    memcpy(out, h->host_fixed.data(), h->host_fixed.size());
     return E2S_OK;
 }
 
@@ -1103,11 +1133,23 @@ extern "C" int e2s_candidates_view(e2s_handle h, const void** recs, const uint32
     dbg_entry("e2s_candidates_view");
     if (!h) return E2S_ERR_ARG;
     if (h->n_cand && !h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
-    if (recs) *recs = h->n_cand ? h->pin_cand : nullptr;
-    if (order) *order = h->n_cand ? h->pin_order : nullptr;
+    if (h->n_cand) expand_fixed(h);
+    if (recs) *recs = h->n_cand ? h->host_fixed.data() : nullptr;
+    if (order) *order = h->n_cand ? h->host_ident.data() : nullptr;
     if (n_cand) *n_cand = h->n_cand;
     if (list_cap) *list_cap = h->list_cap;
     if (stride_bytes) *stride_bytes = h->cand_stride;
+    return E2S_OK;
+}
+
+extern "C" int e2s_candidates_packed(e2s_handle h, const void** stream, const uint32_t** offsets8, uint64_t* n_cand, uint64_t* stream_bytes) {
+    dbg_entry("e2s_candidates_packed");
+    if (!h) return E2S_ERR_ARG;
+    if (h->n_cand && !h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
+    if (stream) *stream = h->n_cand ? h->pin_cand : nullptr;
+    if (offsets8) *offsets8 = h->n_cand ? h->pin_order : nullptr;
+    if (n_cand) *n_cand = h->n_cand;
+    if (stream_bytes) *stream_bytes = h->n_cand ? (uint64_t)h->pin_order[h->n_cand] * 8 : 0;
     return E2S_OK;
 }
 

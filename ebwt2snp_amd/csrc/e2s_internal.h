@@ -157,6 +157,8 @@ void e2s_launch_hist_tail(const uint16_t* lens, unsigned long long n, int min_le
 void e2s_launch_cand_keys(const uint8_t* cand, uint32_t stride, unsigned long long n, unsigned long long* keys, hipStream_t st);
 constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
 size_t e2s_cand_order_scratch_bytes(unsigned long long n);
+void e2s_launch_cand_pack(const uint8_t* cand, uint32_t stride, uint32_t list_cap, const uint32_t* order, unsigned long long n, uint32_t* size8,
+                          unsigned long long n_pad, uint8_t* stream, uint32_t* off_out, hipStream_t st);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, unsigned long long key_lo, unsigned long long key_span,
                            void* scratch, uint32_t* order, hipStream_t st);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);

@@ -1616,7 +1616,7 @@ __global__ void k_ko_count(const u64* keys, u64 n, u64 key_lo, u32 shift, u32 nb
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slot[i] = atomicAdd(&cnt[ko_bucket(keys[i], key_lo, shift, nb)], 1u);
 }
-// exclusive scan of cnt[0..nb) in place (one block; nb a power of two, 256 <= nb <= 2^18).  A thread owns `per`
+// exclusive scan of cnt[0..nb) in place, total at cnt[nb] (one block; nb a power of two >= 256, or a multiple of 4096).  A thread owns `per`
 // consecutive counts and moves them 16 at a time (four 16-byte loads in flight), not one global round trip each.
 __global__ __launch_bounds__(1024) void k_ko_scan(u32* cnt, u32 nb) {
     __shared__ u32 s_part[1024];
@@ -1680,6 +1680,57 @@ __global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, u64 key_lo, 
     u32 r = lo;
     for (u32 t = lo; t < hi; ++t) r += gkeys[t] < k ? 1u : 0u;
     order[r] = gidx[j];
+}
+// ---- candidates for the host: packed, in SA order.  Records are fixed-stride in HBM (lists of <= list_cap, on
+// average a third full); what crosses PCIe is [header][idx0[n0]][pos0[n0]][idx1[n1]][pos1[n1]] per candidate, written
+// by the GPU straight into pinned host memory in SA order, plus the offsets (units of 8 bytes).
+__global__ void k_cand_sizes(const uint8_t* cand, u32 stride, const u32* order, u64 n, u64 n_pad, u32* size8) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    u32 v = 0;
+    if (i < n) {
+        const CandHeader* h = (const CandHeader*)(cand + (u64)order[i] * stride);
+        v = (u32)(sizeof(CandHeader) / 8) + h->n0 + h->n1;       // 8 bytes per (idx, pos) pair
+    }
+    size8[i] = v;
+}
+__global__ __launch_bounds__(256) void k_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, const u32* order, const u32* off8, u64 n,
+                                                   uint8_t* stream, u32* off_out) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 gw = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+    for (u64 i = gw; i < n; i += nw) {
+        const uint8_t* src = cand + (u64)order[i] * stride;
+        const CandHeader* h = (const CandHeader*)src;
+        const u32 n0 = h->n0, n1 = h->n1, o8 = off8[i];
+        u32* dst = (u32*)(stream + (u64)o8 * 8);
+        const u32* hs = (const u32*)src;
+        const u32* l = hs + sizeof(CandHeader) / 4;
+        constexpr u32 HW = sizeof(CandHeader) / 4;
+        const u32 total = HW + 2u * (n0 + n1);
+        for (u32 w = lane; w < total; w += 64u) {
+            u32 v;
+            if (w < HW) v = hs[w];
+            else {
+                const u32 t = w - HW;
+                if (t < n0) v = l[t];
+                else if (t < 2u * n0) v = l[list_cap + (t - n0)];
+                else if (t < 2u * n0 + n1) v = l[2u * list_cap + (t - 2u * n0)];
+                else v = l[3u * list_cap + (t - 2u * n0 - n1)];
+            }
+            dst[w] = v;
+        }
+        if (lane == 0) { off_out[i] = o8; if (i == n - 1) off_out[n] = o8 + total / 2u; }   // total words / 2 = 8-byte units
+    }
+}
+// exclusive scan of size8[0..n_pad) in place + total at size8[n_pad]; n_pad a multiple of 4096
+void e2s_launch_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, const u32* order, u64 n, u32* size8 /* n_pad + 1 */, u64 n_pad,
+                          uint8_t* stream, u32* off_out, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_cand_sizes, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, cand, stride, order, n, n_pad, size8);
+    hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, size8, (u32)n_pad);
+    const u64 blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(k_cand_pack, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, cand, stride, list_cap, order, (const u32*)size8, n,
+                       stream, off_out);
 }
 void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hipStream_t st) {
     if (!n) return;

@@ -147,18 +147,17 @@ int main(int argc, char** argv) {
     die_on(e2s_find_candidates(h, &prm, 0, &n_cand), h, "find candidates");
     std::cout << " 100% done." << std::endl;
     std::cout << "Done. " << n_cand << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
-    uint32_t cap = 0; size_t stride = 0;
-    e2s_candidate_stride(h, &prm, &cap, &stride);
-    std::vector<uint8_t> cands((size_t)n_cand * stride + 16);
-    die_on(e2s_fetch_candidates(h, cands.data(), n_cand, &n_cand), h, "fetch candidates");
-    e2s_destroy(h);
+    // the candidates arrive packed and in SA order in the handle's pinned buffer; the tail reads them in place
+    const void* cstream = nullptr; const uint32_t* coff = nullptr; uint64_t cbytes = 0;
+    die_on(e2s_candidates_packed(h, &cstream, &coff, &n_cand, &cbytes), h, "candidates");
 
     std::cout << "(2/4) Extracting reads from fasta file ..." << std::endl;
     std::cout << "(3/4) Filtering " << n_cand << " candidates and computing consensus of left-contexts ... " << std::endl;
     std::cout << "(4/4) Computing edit distances and saving SNPs/indels to file ... " << std::endl;
     e2s_tail_params tp{k_left, k_right, max_gap, max_err};
     uint64_t nv = 0, ne = 0;
-    rc = e2s_snp_from_candidates(cands.data(), nullptr, n_cand, cap, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
+    rc = e2s_snp_from_packed(cstream, coff, n_cand, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
+    e2s_destroy(h);
     if (rc == E2S_ERR_REF_CRASH) {
         std::cerr << "no candidate variant: the reference crashes here (SIGSEGV, clust2snp.cpp:531); no .snp written" << std::endl;
         return 139;

@@ -132,30 +132,26 @@ struct Variant { std::string left0, left1, right; int s0, s1; };
 
 }  // namespace
 
-extern "C" int e2s_snp_from_candidates(const void* cands, const uint32_t* order, uint64_t n_cand, uint32_t list_cap,
-                                       const e2s_tail_params* p, const char* fasta_path, const char* out_path,
-                                       uint64_t* n_variants, uint64_t* n_events) {
-    if (!p || !fasta_path || !out_path || (!cands && n_cand)) return E2S_ERR_ARG;
+// one candidate, wherever it is stored
+struct CandView { const e2s_cand_header* h; const uint32_t* idx0; const uint32_t* pos0; const uint32_t* idx1; const uint32_t* pos1; };
+
+template <typename Get>
+static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_params* p, const char* fasta_path, const char* out_path,
+                    uint64_t* n_variants, uint64_t* n_events) {
     if (n_variants) *n_variants = 0;
     if (n_events) *n_events = 0;
     // zero candidates: the reference indexes an empty vector (clust2snp.cpp:531) and dies before creating the file
     if (n_cand == 0) return E2S_ERR_REF_CRASH;
-    const size_t stride = sizeof(e2s_cand_header) + (size_t)4 * list_cap * sizeof(uint32_t);
-    const uint8_t* base = (const uint8_t*)cands;
-    auto at_rec = [&](uint64_t c) { return base + (size_t)(order ? order[c] : c) * stride; };     // SA order
-    auto hdr = [&](uint64_t c) { return (const e2s_cand_header*)at_rec(c); };
-    auto lists = [&](uint64_t c) { return (const uint32_t*)(at_rec(c) + sizeof(e2s_cand_header)); };
 
     // all read ranks any candidate touches, ascending and unique (clust2snp.cpp:512-523)
     std::vector<uint64_t> ranks;
     ranks.reserve(n_cand * 8);
     for (uint64_t c = 0; c < n_cand; ++c) {
-        const e2s_cand_header* h = hdr(c);
-        if (h->n0 > list_cap || h->n1 > list_cap) return E2S_ERR_ARG;
-        const uint32_t* l = lists(c);
-        for (uint32_t t = 0; t < h->n0; ++t) ranks.push_back(l[t]);
-        for (uint32_t t = 0; t < h->n1; ++t) ranks.push_back(l[2 * list_cap + t]);
-        ranks.push_back(h->right_idx);
+        const CandView v = get(c);
+        if (v.h->n0 > list_cap || v.h->n1 > list_cap) return E2S_ERR_ARG;
+        for (uint32_t t = 0; t < v.h->n0; ++t) ranks.push_back(v.idx0[t]);
+        for (uint32_t t = 0; t < v.h->n1; ++t) ranks.push_back(v.idx1[t]);
+        ranks.push_back(v.h->right_idx);
     }
     std::sort(ranks.begin(), ranks.end());
     ranks.erase(std::unique(ranks.begin(), ranks.end()), ranks.end());
@@ -172,14 +168,14 @@ extern "C" int e2s_snp_from_candidates(const void* cands, const uint32_t* order,
     std::vector<Variant> vars;
     std::vector<int> cnt((size_t)kl * 4);
     for (uint64_t c = 0; c < n_cand; ++c) {
-        const e2s_cand_header* h = hdr(c);
-        const uint32_t* l = lists(c);
+        const CandView cv = get(c);
+        const e2s_cand_header* h = cv.h;
         std::string cons[2];
         int supp[2] = {0, 0};
         for (int s = 0; s < 2; ++s) {
             const uint32_t n = s ? h->n1 : h->n0;
-            const uint32_t* idx = l + (s ? 2 : 0) * list_cap;
-            const uint32_t* pos = idx + list_cap;
+            const uint32_t* idx = s ? cv.idx1 : cv.idx0;
+            const uint32_t* pos = s ? cv.pos1 : cv.pos0;
             // cons, include.hpp:334-371: the letter changes only on a strictly larger count (H8)
             std::string& C = cons[s];
             C.assign((size_t)kl, 'A');
@@ -240,4 +236,31 @@ extern "C" int e2s_snp_from_candidates(const void* cands, const uint32_t* order,
     fclose(out);
     if (n_events) *n_events = id - 1;
     return E2S_OK;
+}
+
+extern "C" int e2s_snp_from_candidates(const void* cands, const uint32_t* order, uint64_t n_cand, uint32_t list_cap,
+                                       const e2s_tail_params* p, const char* fasta_path, const char* out_path,
+                                       uint64_t* n_variants, uint64_t* n_events) {
+    if (!p || !fasta_path || !out_path || (!cands && n_cand)) return E2S_ERR_ARG;
+    const size_t stride = sizeof(e2s_cand_header) + (size_t)4 * list_cap * sizeof(uint32_t);
+    const uint8_t* base = (const uint8_t*)cands;
+    auto get = [&](uint64_t c) {                                      // SA order through `order`
+        const uint8_t* r = base + (size_t)(order ? order[c] : c) * stride;
+        const uint32_t* l = (const uint32_t*)(r + sizeof(e2s_cand_header));
+        return CandView{(const e2s_cand_header*)r, l, l + list_cap, l + 2 * (size_t)list_cap, l + 3 * (size_t)list_cap};
+    };
+    return snp_core(n_cand, list_cap, get, p, fasta_path, out_path, n_variants, n_events);
+}
+
+extern "C" int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n_cand, const e2s_tail_params* p,
+                                   const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events) {
+    if (!p || !fasta_path || !out_path || ((!stream || !offsets8) && n_cand)) return E2S_ERR_ARG;
+    const uint8_t* base = (const uint8_t*)stream;
+    auto get = [&](uint64_t c) {
+        const uint8_t* r = base + (size_t)offsets8[c] * 8;
+        const e2s_cand_header* h = (const e2s_cand_header*)r;
+        const uint32_t* l = (const uint32_t*)(r + sizeof(e2s_cand_header));
+        return CandView{h, l, l + h->n0, l + 2 * (size_t)h->n0, l + 2 * (size_t)h->n0 + h->n1};
+    };
+    return snp_core(n_cand, 0xFFFFFFFFu, get, p, fasta_path, out_path, n_variants, n_events);
 }

@@ -194,11 +194,15 @@ typedef struct {
 int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand);
 int e2s_candidate_stride(e2s_handle h, const e2s_c2s_params* p, uint32_t* list_cap, size_t* stride_bytes);
 int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand);  /* copied out in SA order */
-/* Zero-copy: the candidates as e2s_find_candidates left them in the library's pinned host buffer (arbitrary
- * order) plus the permutation that puts them in SA order: the i-th candidate is recs[order[i]].  Valid until
- * the next e2s_find_candidates / e2s_destroy on this handle. */
+/* The same fixed-stride records without a copy of the caller's (host memory owned by the handle) and a
+ * permutation `order` (the i-th candidate is recs[order[i]]; the identity since the packed transfer below).
+ * Valid until the next e2s_find_candidates / e2s_destroy on this handle. */
 int e2s_candidates_view(e2s_handle h, const void** recs, const uint32_t** order, uint64_t* n_cand,
                         uint32_t* list_cap, size_t* stride_bytes);
+/* Zero-copy, what e2s_find_candidates itself delivers: the candidates in SA order as a packed stream in the
+ * handle's pinned host buffer, written there by the GPU.  Candidate i starts at stream + 8 * offsets8[i]:
+ * [e2s_cand_header][u32 idx0[n0]][u32 pos0[n0]][u32 idx1[n1]][u32 pos1[n1]]; offsets8 has n_cand + 1 entries. */
+int e2s_candidates_packed(e2s_handle h, const void** stream, const uint32_t** offsets8, uint64_t* n_cand, uint64_t* stream_bytes);
 
 /* ---- host tail: candidates -> KisSNP2 text (extract_variants + distance + to_file) -------- */
 typedef struct {
@@ -210,6 +214,9 @@ typedef struct {
 int e2s_snp_from_candidates(const void* cands, const uint32_t* order, uint64_t n_cand, uint32_t list_cap,
                             const e2s_tail_params* p, const char* fasta_path, const char* out_path,
                             uint64_t* n_variants, uint64_t* n_events);
+/* The same over the packed stream of e2s_candidates_packed. */
+int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n_cand, const e2s_tail_params* p,
+                        const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 typedef struct {
