@@ -51,6 +51,7 @@ struct e2s_ctx {
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
     uint32_t* pin_order = nullptr;                                // offsets (8-byte units) of the packed candidates, n_cand + 1 entries
     uint32_t* d_size8 = nullptr; uint64_t size8_cap = 0;          // pack scratch
+    uint32_t* d_slot_off8 = nullptr; uint64_t slot_off8_cap = 0;  // where k_flagged_lists packed each candidate slot
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
@@ -156,7 +157,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->pin_cand) hipHostFree(h->pin_cand);
     if (h->pin_mail) hipHostFree(h->pin_mail);
     hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
-    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_size8);
+    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_size8); hipFree(h->d_slot_off8);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     if (h->stream2) hipStreamDestroy(h->stream2);
     hipStreamDestroy(h->stream);
@@ -1011,6 +1012,26 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             LCHK("e2s_launch_cluster_filter");
             CK(hipEventRecord(h->ev[4], h->stream));
             a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
+            {   // packed mode: K2b writes the candidates into the pinned host buffer itself
+                const size_t rec_bytes = (size_t)h->cand_cap * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
+                const size_t need = ord_off + ((size_t)h->cand_cap + 1) * 4;
+                if (need > h->pin_cand_bytes) {
+                    if (h->pin_cand) hipHostFree(h->pin_cand);
+                    h->pin_cand = nullptr; h->pin_cand_bytes = 0;
+                    CK(hipHostMalloc((void**)&h->pin_cand, need + 4096, hipHostMallocDefault));
+                    h->pin_cand_bytes = need + 4096;
+                }
+                if (h->cand_cap > h->slot_off8_cap) {
+                    hipFree(h->d_slot_off8); h->d_slot_off8 = nullptr; h->slot_off8_cap = 0;
+                    CK(hipMalloc((void**)&h->d_slot_off8, (h->cand_cap + 8) * 4));
+                    h->slot_off8_cap = h->cand_cap;
+                }
+                void* dev_pin = nullptr;
+                CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
+                a.host_stream = (uint8_t*)dev_pin; a.stream8_cap = rec_bytes / 8; a.slot_off8 = h->d_slot_off8;
+                a.stream8_count = (unsigned long long*)(h->d_scalars + 6);
+                CK(hipMemsetAsync(h->d_scalars + 6, 0, 8, h->stream));
+            }
             e2s_launch_flagged_lists(a, (const unsigned long long*)(h->d_scalars + 2), d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
             LCHK("e2s_launch_flagged_lists");
             CK(hipEventRecord(h->ev[7], h->stream));
@@ -1054,34 +1075,44 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             CK(hipMalloc((void**)&h->d_order, c2 * 4));
             h->order_cap = c2;
         }
-        // pinned host buffer: the packed stream can not exceed the fixed-stride size; offsets follow it
-        const size_t rec_bytes = (size_t)count * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
-        const size_t need = ord_off + ((size_t)count + 1) * 4;
-        if (need > h->pin_cand_bytes) {
-            if (h->pin_cand) hipHostFree(h->pin_cand);
-            h->pin_cand = nullptr; h->pin_cand_bytes = 0;
-            CK(hipHostMalloc((void**)&h->pin_cand, need + need / 4 + 4096, hipHostMallocDefault));
-            h->pin_cand_bytes = need + need / 4 + 4096;
-        }
-        h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
-        const uint64_t n_pad = (count + 4095) & ~4095ull;
-        if (n_pad + 1 > h->size8_cap) {
-            hipFree(h->d_size8); h->d_size8 = nullptr; h->size8_cap = 0;
-            CK(hipMalloc((void**)&h->d_size8, (n_pad + 4096 + 1) * 4));
-            h->size8_cap = n_pad + 4096 + 1;
-        }
         // k_flagged_lists leaves the SA-order keys next to the records; the record-driven pass builds them from the headers
         if (!streaming_done) e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
         const uint64_t key_lo = (streaming_done ? h->prov_lo : record_index_base) << 2;
         const uint64_t key_span = ((streaming_done ? h->n_prov : h->n_rec) + 1) << 2;
         e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, key_lo, key_span, h->d_rank, h->d_order, h->stream);
         LCHK("e2s_launch_cand_order");
-        // SA order, packed, straight into the pinned buffer (the GPU writes host memory: no copy, no second wait)
-        void* dev_pin = nullptr;
-        CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
-        e2s_launch_cand_pack(h->d_cand, a.stride, a.list_cap, h->d_order, count, h->d_size8, n_pad, (uint8_t*)dev_pin,
-                             (uint32_t*)((uint8_t*)dev_pin + ord_off), h->stream);
-        LCHK("e2s_launch_cand_pack");
+        if (streaming_done) {
+            // the packed records are already in the pinned buffer (K2b wrote them); only the SA-order offsets follow
+            const size_t rec_bytes = (size_t)h->cand_cap * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
+            h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
+            void* dev_pin = nullptr;
+            CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
+            e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, count, (const unsigned long long*)(h->d_scalars + 6),
+                                    (uint32_t*)((uint8_t*)dev_pin + ord_off), h->stream);
+            LCHK("e2s_launch_cand_offsets");
+        } else {
+            // fixed-stride records in HBM: pack them in SA order straight into the pinned buffer (the GPU writes host memory)
+            const size_t rec_bytes = (size_t)count * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
+            const size_t need = ord_off + ((size_t)count + 1) * 4;
+            if (need > h->pin_cand_bytes) {
+                if (h->pin_cand) hipHostFree(h->pin_cand);
+                h->pin_cand = nullptr; h->pin_cand_bytes = 0;
+                CK(hipHostMalloc((void**)&h->pin_cand, need + need / 4 + 4096, hipHostMallocDefault));
+                h->pin_cand_bytes = need + need / 4 + 4096;
+            }
+            h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
+            const uint64_t n_pad = (count + 4095) & ~4095ull;
+            if (n_pad + 1 > h->size8_cap) {
+                hipFree(h->d_size8); h->d_size8 = nullptr; h->size8_cap = 0;
+                CK(hipMalloc((void**)&h->d_size8, (n_pad + 4096 + 1) * 4));
+                h->size8_cap = n_pad + 4096 + 1;
+            }
+            void* dev_pin = nullptr;
+            CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
+            e2s_launch_cand_pack(h->d_cand, a.stride, a.list_cap, h->d_order, count, h->d_size8, n_pad, (uint8_t*)dev_pin,
+                                 (uint32_t*)((uint8_t*)dev_pin + ord_off), h->stream);
+            LCHK("e2s_launch_cand_pack");
+        }
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
         h->cand_downloaded = true;

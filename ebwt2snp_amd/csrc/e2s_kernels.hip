@@ -1551,13 +1551,56 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
 template <bool DEF>
 __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigned long long* n_dev) {
     __shared__ u32 s_nstage;
-    __shared__ u64 s_gbase;
+    __shared__ u64 s_gbase, s_sbase;
+    __shared__ u32 s_off8[FW_STAGE];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_nstage = 0;
     __syncthreads();
     auto stage_flush = [&]() {
         const u32 n = min(s_nstage, (u32)FW_STAGE);
-        if (n) {
+        if (n && a.host_stream) {
+            // packed mode: [header][idx0[n0]][pos0[n0]][idx1[n1]][pos1[n1]] straight into pinned host memory -- the
+            // transfer runs under the rest of this kernel and the ordering pass instead of after them
+            if (tid == 0) {
+                u32 run = 0;
+                for (u32 i = 0; i < n; ++i) {
+                    const CandHeader* hd = (const CandHeader*)(s_stage + (size_t)i * a.stride);
+                    s_off8[i] = run;
+                    run += (u32)(sizeof(CandHeader) / 8) + hd->n0 + hd->n1;
+                }
+                s_gbase = atomicAdd(a.cand_count, (unsigned long long)n);
+                s_sbase = atomicAdd(a.stream8_count, (unsigned long long)run);
+            }
+            __syncthreads();
+            const u64 gbase = s_gbase, sbase = s_sbase;
+            constexpr u32 HW = sizeof(CandHeader) / 4;
+            for (u32 i = wave; i < n; i += 4) {
+                const u32* hs = (const u32*)(s_stage + (size_t)i * a.stride);
+                const CandHeader* hd = (const CandHeader*)hs;
+                const u32 n0 = hd->n0, n1 = hd->n1, total = HW + 2u * (n0 + n1);
+                const u64 o8 = sbase + s_off8[i], slot = gbase + i;
+                if (slot < a.cand_cap && o8 + total / 2u <= a.stream8_cap) {
+                    u32* dst = (u32*)(a.host_stream + o8 * 8);
+                    const u32* l = hs + HW;
+                    for (u32 w = lane; w < total; w += 64u) {
+                        u32 v;
+                        if (w < HW) v = hs[w];
+                        else {
+                            const u32 t = w - HW;
+                            if (t < n0) v = l[t];
+                            else if (t < 2u * n0) v = l[a.list_cap + (t - n0)];
+                            else if (t < 2u * n0 + n1) v = l[2u * a.list_cap + (t - 2u * n0)];
+                            else v = l[3u * a.list_cap + (t - 2u * n0 - n1)];
+                        }
+                        dst[w] = v;
+                    }
+                    if (lane == 0) {
+                        a.slot_off8[slot] = (u32)o8;
+                        a.cand_keys[slot] = (hd->record_index << 2) | (u64)(hd->pair_index & 3u);
+                    }
+                }
+            }
+        } else if (n) {
             if (tid == 0) s_gbase = atomicAdd(a.cand_count, (unsigned long long)n);
             __syncthreads();
             const u64 gbase = s_gbase;
@@ -1721,6 +1764,15 @@ __global__ __launch_bounds__(256) void k_cand_pack(const uint8_t* cand, u32 stri
         }
         if (lane == 0) { off_out[i] = o8; if (i == n - 1) off_out[n] = o8 + total / 2u; }   // total words / 2 = 8-byte units
     }
+}
+// SA-order offsets of candidates that k_flagged_lists packed itself: off_out[i] = where slot order[i] went, off_out[n] = end
+__global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* stream8_count, u32* off_out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) off_out[i] = slot_off8[order[i]];
+    else if (i == n) off_out[n] = (u32)*stream8_count;
+}
+void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* stream8_count, u32* off_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, stream8_count, off_out);
 }
 // exclusive scan of size8[0..n_pad) in place + total at size8[n_pad]; n_pad a multiple of 4096
 void e2s_launch_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, const u32* order, u64 n, u32* size8 /* n_pad + 1 */, u64 n_pad,
