@@ -39,6 +39,9 @@ WORKLOADS = {
     "c1": (1000, 100),            # 2x1k x100bp, 2.02e5 entries (the reference's own CPU-runnable case)
     "c2": (1000000, 100),         # 2x1M x100bp, 2.02e8 entries  <- the metric's 1-GPU configuration
     "c2s": (250000, 100),         # quarter-size c2 for quick checks
+    # 3.02e9 entries: ten copies of an exactly sorted 2x1M x150bp block laid end to end, read ids remapped per copy
+    # ("C2-style block tiled with read-id remap") -- BASELINE.json configs[2], 21 GB of EGSA in HBM
+    "c3": (1000000, 150, 10),
 }
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -50,6 +53,22 @@ def build_block(R, L, device):
     pos = e["suff"].to(torch.uint8).contiguous()
     da = e["text"].to(torch.int32).contiguous()
     return reads, n1, dict(bwt=bwt, lcp=lcp, pos=pos, da=da)
+
+
+def tile_block(blk, n1, copies):
+    """`copies` blocks end to end; copy b holds reads b*n1 .. (b+1)*n1-1 of individual 1 and the same range of
+    individual 2 (ids >= copies*n1), so that every read id is distinct and `text < nr_reads1` still tells the
+    individuals apart.  The block ends with LCP 0, so no cluster crosses a seam."""
+    if copies == 1:
+        return blk, n1
+    out = {k: blk[k].repeat(copies) for k in ("bwt", "lcp", "pos")}
+    da = blk["da"]
+    m = da.numel()
+    big = torch.empty(m * copies, dtype=torch.int32, device=da.device)
+    for b in range(copies):
+        big[b * m:(b + 1) * m] = torch.where(da < n1, da + b * n1, da - n1 + copies * n1 + b * n1)
+    out["da"] = big
+    return out, n1 * copies
 
 
 def pick_cut(lcp, approx):
@@ -238,9 +257,11 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    R, L = WORKLOADS[a.workload]
+    R, L = WORKLOADS[a.workload][:2]
+    copies = WORKLOADS[a.workload][2] if len(WORKLOADS[a.workload]) > 2 else 1
     t0 = time.time()
-    reads, n1, blk = build_block(R, L, dev)
+    reads, n1_block, blk0 = build_block(R, L, dev)
+    blk, n1 = tile_block(blk0, n1_block, copies)
     m = blk["lcp"].numel()
     arrs, g0, n_own, hl, hr = shard_arrays(blk, m, rank, world)
     torch.cuda.synchronize()
@@ -302,8 +323,8 @@ def main():
             "metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": value, "unit": "EGSA entries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: 2x%d reads x %dbp synthetic EGSA per GPU, %d entries/GPU, BCR widths 1/4/1"
-                                   % (a.workload, R, L, m), "entries_total": n_total, "k": 16, "min_len": 2,
+            "config": {"workload": "%s: %s2x%d reads x %dbp synthetic EGSA per GPU, %d entries/GPU, BCR widths 1/4/1"
+                                   % (a.workload, ("%d copies of " % copies) if copies > 1 else "", R, L, m), "entries_total": n_total, "k": 16, "min_len": 2,
                        "parallelism": "sa-range x%d" % world, "cluster_records": tot_ends, "candidates": tot_cand,
                        "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2),
                        "host_phase_ms": {k2: round(v / a.steps * 1e3, 4) for k2, v in PHASES.items()}},
@@ -317,7 +338,7 @@ def main():
         }
         if world == 1 and a.cpu_sample > 0:
             try:
-                out["cpu_baseline"] = cpu_baseline(blk, reads, n1, a.cpu_sample)
+                out["cpu_baseline"] = cpu_baseline(blk0, reads, n1_block, a.cpu_sample)
             except Exception as ex:           # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "EGSA entries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out))

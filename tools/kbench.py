@@ -7,7 +7,7 @@ import numpy as np, torch
 from ebwt2snp_amd import capi
 import bench
 
-R, L = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
+R, L = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c2"][:2]
 dev = torch.device("cuda", 0)
 reads, n1, blk = bench.build_block(R, L, dev)
 torch.cuda.synchronize()

@@ -1,18 +1,19 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
-#   tools/profile.sh <tag>            -> gpurun_out/<tag>/{stats,FETCH_SIZE,WRITE_SIZE}/...
+#   tools/profile.sh <tag> [workload] -> gpurun_out/<tag>/{stats,FETCH_SIZE,WRITE_SIZE}/...
 # kernel-trace/stats and each PMC counter are separate passes (never combined), the program is the
 # direct child of rocprofv3.  Summarise afterwards with tools/profile_summary.py into profiles/.
 set -e
 tag=${1:-prof}
+wl=${2:-c2}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --cpu-sample 0"
+ARGS="--steps 10 --warmup 2 --cpu-sample 0 --workload $wl"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" $ARGS > "$out/stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-include-regex "^(void )?k_" --output-format csv -d "$out/$c" -o run -- python3 "$root/bench.py" --steps 3 --warmup 1 --cpu-sample 0 > "$out/$c.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-include-regex "^(void )?k_" --output-format csv -d "$out/$c" -o run -- python3 "$root/bench.py" --steps 3 --warmup 1 --cpu-sample 0 --workload $wl > "$out/$c.log" 2>&1
 done
 find "$out" -name "*.db" -delete; find "$out" -name "*kernel_trace.csv" -size +20M -delete
 du -sh "$out" "$out"/* | tail -8

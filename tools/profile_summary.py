@@ -3,7 +3,7 @@
    <round>_kernel_stats.csv  -- this repo's kernels from rocprofv3 --kernel-trace --stats
    <round>_pmc_traffic.json  -- FETCH_SIZE / WRITE_SIZE per launch per kernel, with the gfx950 correction
                                 (FETCH_SIZE doubled, MI355X_MICROARCH.md "HBM"; the counters are in KiB)
-usage: tools/profile_summary.py gpurun_out/<tag> profiles/<round>"""
+usage: tools/profile_summary.py gpurun_out/<tag> profiles/<round> [workload]"""
 import csv, glob, json, os, sys
 
 OURS = ("k_scan", "k_seg", "k_hist", "k_cluster_filter", "k_flagged", "k_cand", "k_candidates", "k_shard", "k_apply",
@@ -18,11 +18,11 @@ def short(name):
     return name.replace("void ", "").split("(")[0]
 
 
-def main(src, dst):
+def main(src, dst, workload="c2"):
     st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(st)) if ours(r["Name"])]
     with open(dst + "_kernel_stats.csv", "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0   (MI355X, workload c2: 2.02e8 entries)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --workload <workload>   (MI355X, workload %s)\n" % workload)
         f.write("# only this repo's kernels are listed; the rest of the trace is torch building the synthetic EGSA\n")
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
         for r in rows:
@@ -48,11 +48,11 @@ def main(src, dst):
         v["hbm_bytes_per_launch"] = v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0",
                "corrections": "counter unit KiB; FETCH_SIZE doubled on gfx950 (128-B requests tallied at 64 B)",
-               "workload": "c2", "kernels": pmc}, open(dst + "_pmc_traffic.json", "w"), indent=1)
+               "workload": workload, "kernels": pmc}, open(dst + "_pmc_traffic.json", "w"), indent=1)
     bj = os.path.join(src, "bench_under_rocprof.json")
     if os.path.exists(bj) and os.path.getsize(bj):
         open(dst + "_bench_under_rocprof.json", "w").write(open(bj).read())
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
