@@ -417,3 +417,55 @@ def test_fused_streaming_adversarial(H, tmp_path):
     for a, b in zip(got, oc):
         for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
             assert a[key] == b[key]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_fused_streaming_fuzz_columns(H, tmp_path, seed):
+    """random EGSA columns (not from reads): runs of LCP >= k of every length with inner local minima, so that
+    clusters begin and end at every lane / tile / worker offset of the plane kernels; bases skewed so that the
+    per-sample counts sit around mcov_out; LCP values around k_right; '$' and lower-case symbols ('N' is left out:
+    the reference, and the oracle with it, draws rand() % 4 for it -- DESIGN.md, non-determinism of the reference)"""
+    rnd = np.random.RandomState(seed)
+    n = 262144 + int(rnd.randint(0, 5000))
+    lcp = np.zeros(n, dtype=np.uint8)
+    bwt = np.zeros(n, dtype=np.uint8)
+    text = np.zeros(n, dtype=np.uint32)
+    suff = rnd.randint(0, 100, n).astype(np.uint8)
+    alphabet = np.array([65, 67, 71, 84, 97, 99, 103, 116, 36, 35], dtype=np.uint8)
+    i = int(rnd.randint(0, 70))
+    while i < n - 400:
+        length = int(rnd.choice([2, 3, 9, 10, 11, 20, 40, 63, 64, 65, 100, 127, 128, 129, 149, 150, 151, 200])) if rnd.rand() < 0.5 \
+            else int(rnd.randint(2, 160))
+        lv = rnd.randint(16, 60, length).astype(np.uint8)
+        if rnd.rand() < 0.5:
+            lv[:] = int(rnd.randint(16, 60))                   # flat run: one cluster
+        lcp[i + 1:i + length] = lv[1:]                           # entry i itself keeps LCP 0: the run is [i, i+length)
+        major, minor = rnd.choice(alphabet[:4], 2, replace=False)
+        nminor = int(rnd.choice([0, 1, 4, 5, 6, 10, length // 2]))
+        b = np.full(length, major, dtype=np.uint8)
+        where = rnd.choice(length, min(nminor, length), replace=False)
+        b[where] = minor
+        if rnd.rand() < 0.3:
+            b[rnd.randint(0, length)] = rnd.choice(alphabet[4:])
+        bwt[i:i + length] = b
+        # sample: minor allele mostly in sample 1
+        t = rnd.randint(0, 1000, length)
+        t[where] = rnd.randint(1000, 2000, where.size)
+        flip = rnd.rand(length) < 0.15
+        t[flip] = rnd.randint(0, 2000, int(flip.sum()))
+        text[i:i + length] = t
+        suff[i:i + length] = rnd.randint(20, 100, length)
+        i += length + int(rnd.choice([0, 0, 1, 2, 5, 64]))
+    lcp[-1] = 0
+    en = dict(text=text, suff=suff, lcp=lcp, bwt=bwt)
+    reads = np.full((2000, 100), 65, dtype=np.uint8)
+    mcov = int(rnd.choice([3, 5]))
+    Rc = int(rnd.choice([25, 30, 45]))
+    oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000, mcov=mcov, R=Rc, tag="fz%d" % seed)
+    got, mcl = _fused_candidates(H, en, 1000, mcov=mcov, R=Rc)
+    assert mcl == omcl and len(oc) > 50
+    assert len(got) == len(oc)
+    for a, b in zip(got, oc):
+        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+            assert a[key] == b[key]
