@@ -200,9 +200,30 @@ def cpu_baseline(blk, reads, n1, sample_entries):
             rc, _ = O.clust2snp(p, O.c2s_opts(n1))
             t2 = time.time()
             assert rc == 0
-        return dict(value=n / (t2 - t0), unit="EGSA entries/s", cores=1, kind=kind,
-                    sample="first %d entries of the same EGSA (BCR triple + FASTA on local disk): ebwt2clust %.2f s + clust2snp %.2f s"
-                           % (n, t1 - t0, t2 - t1))
+        res = dict(value=n / (t2 - t0), unit="EGSA entries/s", cores=1, kind=kind,
+                   sample="first %d entries of the same EGSA (BCR triple + FASTA on local disk): ebwt2clust %.2f s + clust2snp %.2f s"
+                          % (n, t1 - t0, t2 - t1))
+        # the drop-in executables of this repo on the very same files, end to end (process start, file reads, upload,
+        # kernels, host tail, file writes), and whether their outputs are byte-identical to the baseline's
+        try:
+            e2c, c2s = os.path.join(ROOT, "bin", "ebwt2clust"), os.path.join(ROOT, "bin", "clust2snp")
+            if os.path.exists(e2c) and os.path.exists(c2s):
+                snp = IO.snp_out_path(p)
+                want_cl, want_snp = open(p + ".clusters", "rb").read(), open(snp, "rb").read()
+                os.remove(p + ".clusters"); os.remove(snp)
+                u0 = time.time()
+                r1 = subprocess.run([e2c, "-i", p], capture_output=True)
+                u1 = time.time()
+                r2 = subprocess.run([c2s, "-i", p, "-n", str(n1)], capture_output=True)
+                u2 = time.time()
+                same = (r1.returncode == 0 and r2.returncode == 0 and open(p + ".clusters", "rb").read() == want_cl
+                        and open(snp, "rb").read() == want_snp)
+                res["drop_in"] = {"ebwt2clust_s": round(u1 - u0, 3), "clust2snp_s": round(u2 - u1, 3), "value": n / (u2 - u0),
+                                  "unit": "EGSA entries/s end to end incl. file I/O", "outputs_identical": bool(same),
+                                  "clusters_bytes": len(want_cl), "snp_bytes": len(want_snp)}
+        except Exception as ex:
+            res["drop_in"] = {"error": repr(ex)}
+        return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
