@@ -1035,6 +1035,23 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             e2s_launch_flagged_lists(a, (const unsigned long long*)(h->d_scalars + 2), d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
             LCHK("e2s_launch_flagged_lists");
             CK(hipEventRecord(h->ev[7], h->stream));
+            {   // SA order and offsets follow without a host round trip: the kernels read the candidate count on the device
+                if (h->cand_cap > h->order_cap) {
+                    hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
+                    CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(h->cand_cap)));
+                    CK(hipMalloc((void**)&h->d_order, h->cand_cap * 4));
+                    h->order_cap = h->cand_cap;
+                }
+                const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
+                e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
+                                      h->d_order, h->stream);
+                LCHK("e2s_launch_cand_order");
+                const size_t ord_off = (((size_t)h->cand_cap * a.stride) + 63) & ~(size_t)63;
+                h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
+                e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
+                                        (uint32_t*)(a.host_stream + ord_off), h->stream);
+                LCHK("e2s_launch_cand_offsets");
+            }
         } else {
             { const uint64_t* ds; const uint16_t* dl; int rc = records_contiguous(h, &ds, &dl); if (rc) return rc; a.starts = ds; a.lens = dl; }
             a.n_rec = h->n_rec; a.key_is_start = 0;
@@ -1066,8 +1083,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     const bool streaming_done = streaming;
     h->n_cand = count;
     h->cand_downloaded = false; h->host_fixed_valid = false;
-    if (count) {
-        // SA order on the GPU, then ONE download of records + permutation into pinned memory
+    if (count && !streaming_done) {
+        // record-driven pass: fixed-stride records in HBM; SA order on the GPU, then packed into the pinned buffer
         if (count > h->order_cap) {
             hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
             const uint64_t c2 = count + count / 4 + 1024;
@@ -1075,22 +1092,11 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             CK(hipMalloc((void**)&h->d_order, c2 * 4));
             h->order_cap = c2;
         }
-        // k_flagged_lists leaves the SA-order keys next to the records; the record-driven pass builds them from the headers
-        if (!streaming_done) e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
-        const uint64_t key_lo = (streaming_done ? h->prov_lo : record_index_base) << 2;
-        const uint64_t key_span = ((streaming_done ? h->n_prov : h->n_rec) + 1) << 2;
-        e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, key_lo, key_span, h->d_rank, h->d_order, h->stream);
+        e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
+        e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, nullptr, record_index_base << 2, (h->n_rec + 1) << 2, h->d_rank, h->d_order,
+                              h->stream);
         LCHK("e2s_launch_cand_order");
-        if (streaming_done) {
-            // the packed records are already in the pinned buffer (K2b wrote them); only the SA-order offsets follow
-            const size_t rec_bytes = (size_t)h->cand_cap * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
-            h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
-            void* dev_pin = nullptr;
-            CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
-            e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, count, (const unsigned long long*)(h->d_scalars + 6),
-                                    (uint32_t*)((uint8_t*)dev_pin + ord_off), h->stream);
-            LCHK("e2s_launch_cand_offsets");
-        } else {
+        {
             // fixed-stride records in HBM: pack them in SA order straight into the pinned buffer (the GPU writes host memory)
             const size_t rec_bytes = (size_t)count * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
             const size_t need = ord_off + ((size_t)count + 1) * 4;
@@ -1115,8 +1121,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         }
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
-        h->cand_downloaded = true;
     }
+    if (count) h->cand_downloaded = true;                         // streaming pass: everything arrived with the mailbox wait above
     hipEventElapsedTime(&h->tm.cand_ms, h->ev[6], h->ev[7]);
     hipEventElapsedTime(&h->tm.cand_main_ms, h->ev[6], h->ev[4]);
     h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;

@@ -160,12 +160,12 @@ void e2s_launch_hist_tail(const uint16_t* lens, unsigned long long n, int min_le
 void e2s_launch_cand_keys(const uint8_t* cand, uint32_t stride, unsigned long long n, unsigned long long* keys, hipStream_t st);
 constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
 size_t e2s_cand_order_scratch_bytes(unsigned long long n);
-void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* stream8_count,
-                             uint32_t* off_out, hipStream_t st);
+void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* n_dev,
+                             const unsigned long long* stream8_count, uint32_t* off_out, hipStream_t st);
 void e2s_launch_cand_pack(const uint8_t* cand, uint32_t stride, uint32_t list_cap, const uint32_t* order, unsigned long long n, uint32_t* size8,
                           unsigned long long n_pad, uint8_t* stream, uint32_t* off_out, hipStream_t st);
-void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, unsigned long long key_lo, unsigned long long key_span,
-                           void* scratch, uint32_t* order, hipStream_t st);
+void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,
+                           unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
 void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);
 void e2s_launch_unpack_pairsa(const uint8_t* src, unsigned long long n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st);

@@ -1655,7 +1655,10 @@ __device__ __forceinline__ u32 ko_bucket(u64 key, u64 key_lo, u32 shift, u32 nb)
     const u64 b = d >> shift;
     return b < nb ? (u32)b : nb - 1u;
 }
-__global__ void k_ko_count(const u64* keys, u64 n, u64 key_lo, u32 shift, u32 nb, u32* cnt, u32* slot) {
+// n_dev (optional): the count lives on the device (the launch is sized for the capacity n)
+__device__ __forceinline__ u64 ko_n(u64 n, const unsigned long long* n_dev) { return n_dev ? min(n, (u64)*n_dev) : n; }
+__global__ void k_ko_count(const u64* keys, u64 n, const unsigned long long* n_dev, u64 key_lo, u32 shift, u32 nb, u32* cnt, u32* slot) {
+    n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slot[i] = atomicAdd(&cnt[ko_bucket(keys[i], key_lo, shift, nb)], 1u);
 }
@@ -1708,14 +1711,16 @@ __global__ __launch_bounds__(1024) void k_ko_scan(u32* cnt, u32 nb) {
         }
     } else for (u32 i = 0; i < per; ++i) { const u32 c = cnt[lo + i]; cnt[lo + i] = run; run += c; }
 }
-__global__ void k_ko_place(const u64* keys, u64 n, u64 key_lo, u32 shift, u32 nb, const u32* off, const u32* slot, u64* gkeys, u32* gidx) {
+__global__ void k_ko_place(const u64* keys, u64 n, const unsigned long long* n_dev, u64 key_lo, u32 shift, u32 nb, const u32* off, const u32* slot, u64* gkeys, u32* gidx) {
+    n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 k = keys[i];
     const u32 at = off[ko_bucket(k, key_lo, shift, nb)] + slot[i];
     gkeys[at] = k; gidx[at] = (u32)i;
 }
-__global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, u64 key_lo, u32 shift, u32 nb, const u32* off, u32* order) {
+__global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, const unsigned long long* n_dev, u64 key_lo, u32 shift, u32 nb, const u32* off, u32* order) {
+    n = ko_n(n, n_dev);
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const u64 k = gkeys[j];
@@ -1766,13 +1771,14 @@ __global__ __launch_bounds__(256) void k_cand_pack(const uint8_t* cand, u32 stri
     }
 }
 // SA-order offsets of candidates that k_flagged_lists packed itself: off_out[i] = where slot order[i] went, off_out[n] = end
-__global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* stream8_count, u32* off_out) {
+__global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out) {
+    n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) off_out[i] = slot_off8[order[i]];
     else if (i == n) off_out[n] = (u32)*stream8_count;
 }
-void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* stream8_count, u32* off_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, stream8_count, off_out);
+void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out);
 }
 // exclusive scan of size8[0..n_pad) in place + total at size8[n_pad]; n_pad a multiple of 4096
 void e2s_launch_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, const u32* order, u64 n, u32* size8 /* n_pad + 1 */, u64 n_pad,
@@ -1790,7 +1796,7 @@ void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hip
 }
 // scratch layout (u32 words): cnt[nb + 1] | slot[n] | gidx[n] | (8-byte aligned) gkeys[n]
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
-void e2s_launch_cand_order(const u64* keys, u64 n, u64 key_lo, u64 key_span, void* scratch, u32* order, hipStream_t st) {
+void e2s_launch_cand_order(const u64* keys, u64 n, const unsigned long long* n_dev, u64 key_lo, u64 key_span, void* scratch, u32* order, hipStream_t st) {
     if (!n) return;
     u32 nb = 256;
     while (nb < E2S_KO_MAX_BUCKETS && (u64)nb * 2 < n) nb <<= 1;
@@ -1802,10 +1808,10 @@ void e2s_launch_cand_order(const u64* keys, u64 n, u64 key_lo, u64 key_span, voi
     u64* gkeys = (u64*)(((uintptr_t)(gidx + n) + 7) & ~(uintptr_t)7);
     hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, st);
     const dim3 g((unsigned)((n + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_ko_count, g, blk, 0, st, keys, n, key_lo, shift, nb, cnt, slot);
+    hipLaunchKernelGGL(k_ko_count, g, blk, 0, st, keys, n, n_dev, key_lo, shift, nb, cnt, slot);
     hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, cnt, nb);
-    hipLaunchKernelGGL(k_ko_place, g, blk, 0, st, keys, n, key_lo, shift, nb, (const u32*)cnt, (const u32*)slot, gkeys, gidx);
-    hipLaunchKernelGGL(k_ko_rank, g, blk, 0, st, (const u64*)gkeys, (const u32*)gidx, n, key_lo, shift, nb, (const u32*)cnt, order);
+    hipLaunchKernelGGL(k_ko_place, g, blk, 0, st, keys, n, n_dev, key_lo, shift, nb, (const u32*)cnt, (const u32*)slot, gkeys, gidx);
+    hipLaunchKernelGGL(k_ko_rank, g, blk, 0, st, (const u64*)gkeys, (const u32*)gidx, n, n_dev, key_lo, shift, nb, (const u32*)cnt, order);
 }
 
 // ----------------------------------------------------------------------------------------------
