@@ -1574,30 +1574,42 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
             __syncthreads();
             const u64 gbase = s_gbase, sbase = s_sbase;
             constexpr u32 HW = sizeof(CandHeader) / 4;
+            // pack the staged records side by side in LDS (second half of the dynamic buffer), then move the block's
+            // whole chunk to the host with 8-byte stores, 512 contiguous bytes per wave instruction: PCIe writes of a few
+            // words per record ran at half the rate
+            u32* const s_pack = (u32*)(s_stage + (size_t)FW_STAGE * a.stride);
             for (u32 i = wave; i < n; i += 4) {
                 const u32* hs = (const u32*)(s_stage + (size_t)i * a.stride);
                 const CandHeader* hd = (const CandHeader*)hs;
                 const u32 n0 = hd->n0, n1 = hd->n1, total = HW + 2u * (n0 + n1);
-                const u64 o8 = sbase + s_off8[i], slot = gbase + i;
-                if (slot < a.cand_cap && o8 + total / 2u <= a.stream8_cap) {
-                    u32* dst = (u32*)(a.host_stream + o8 * 8);
-                    const u32* l = hs + HW;
-                    for (u32 w = lane; w < total; w += 64u) {
-                        u32 v;
-                        if (w < HW) v = hs[w];
-                        else {
-                            const u32 t = w - HW;
-                            if (t < n0) v = l[t];
-                            else if (t < 2u * n0) v = l[a.list_cap + (t - n0)];
-                            else if (t < 2u * n0 + n1) v = l[2u * a.list_cap + (t - 2u * n0)];
-                            else v = l[3u * a.list_cap + (t - 2u * n0 - n1)];
-                        }
-                        dst[w] = v;
+                u32* dst = s_pack + 2u * s_off8[i];
+                const u32* l = hs + HW;
+                for (u32 w = lane; w < total; w += 64u) {
+                    u32 v;
+                    if (w < HW) v = hs[w];
+                    else {
+                        const u32 t = w - HW;
+                        if (t < n0) v = l[t];
+                        else if (t < 2u * n0) v = l[a.list_cap + (t - n0)];
+                        else if (t < 2u * n0 + n1) v = l[2u * a.list_cap + (t - 2u * n0)];
+                        else v = l[3u * a.list_cap + (t - 2u * n0 - n1)];
                     }
-                    if (lane == 0) {
-                        a.slot_off8[slot] = (u32)o8;
-                        a.cand_keys[slot] = (hd->record_index << 2) | (u64)(hd->pair_index & 3u);
-                    }
+                    dst[w] = v;
+                }
+                const u64 slot = gbase + i;
+                if (lane == 0 && slot < a.cand_cap) {
+                    a.slot_off8[slot] = (u32)(sbase + s_off8[i]);
+                    a.cand_keys[slot] = (hd->record_index << 2) | (u64)(hd->pair_index & 3u);
+                }
+            }
+            __syncthreads();
+            {
+                const CandHeader* hl = (const CandHeader*)(s_stage + (size_t)(n - 1) * a.stride);
+                const u32 run8 = s_off8[n - 1] + (u32)(sizeof(CandHeader) / 8) + hl->n0 + hl->n1;     // chunk length in 8-byte units
+                if (gbase + n <= a.cand_cap && sbase + run8 <= a.stream8_cap) {
+                    uint2* dst = (uint2*)(a.host_stream + sbase * 8);
+                    const uint2* src = (const uint2*)s_pack;
+                    for (u32 w = tid; w < run8; w += 256) dst[w] = src[w];
                 }
             }
         } else if (n) {
@@ -1621,6 +1633,7 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
     const u64 n = min((u64)*n_dev, a.n_rec);
     const u64 per_round = (u64)gridDim.x * 4;
     for (u64 base = (u64)blockIdx.x * 4; base < n; base += per_round) {
+        // (flushing earlier to start the PCIe stream sooner was tried: chunks of ~8 records ran 25 % slower)
         if (s_nstage > FW_STAGE - 16) stage_flush();                // a round adds at most 4 x 4 candidates
         const u64 r = base + wave;
         if (r < n) {
@@ -1952,7 +1965,7 @@ void e2s_launch_cluster_filter2(FilterArgs a, hipStream_t st) {
     hipLaunchKernelGGL(k_cluster_filter2, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, a);
 }
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
-    const size_t dyn = (size_t)FW_STAGE * a.stride;
+    const size_t dyn = (size_t)2 * FW_STAGE * a.stride;          // staged records + their packed image
     const unsigned blocks = 1024;
     if (def_widths) hipLaunchKernelGGL((k_flagged_lists<true>), dim3(blocks), dim3(256), dyn, st, a, n_dev);
     else hipLaunchKernelGGL((k_flagged_lists<false>), dim3(blocks), dim3(256), dyn, st, a, n_dev);
