@@ -127,7 +127,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     for (auto& ev : h->ev) hipEventCreate(&ev);
     hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, sizeof(ScanMail)) != hipSuccess ||
+        hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, 4096) != hipSuccess ||   // ScanMail | statistics at +256
         hipHostMalloc((void**)&h->pin_mail, 4096, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         delete h;
@@ -440,27 +440,25 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             sa.seg_cap = (uint32_t)seg_cap; sa.starts = h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
             sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
             CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
-            e2s_launch_shard_flags(a, h->xb, h->stream);
-            LCHK("e2s_launch_shard_flags");
             CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
             e2s_launch_scan_seg(sa, h->xb, h->stream);
             LCHK("e2s_launch_scan_seg");
             CK(hipEventRecord(h->ev[3], h->stream));
+            // k_seg_fix also evaluates the shard's boundary flags and clears the statistics buffer (fewer launches)
+            static_assert(sizeof(ScanMail) <= 256, "mail layout");
+            uint64_t* dh = (uint64_t*)((uint8_t*)h->d_mail + 256);
             e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb,
-                               h->d_mail, h->stream);
+                               h->d_mail, (unsigned long long*)dh, h->stream);
             LCHK("e2s_launch_seg_fix");
             CK(hipEventRecord(h->ev[1], h->stream));
             // statistics of the records in the same phase (no second round trip): e2s_scan_stats_desc / e2s_cluster_hist
-            uint64_t* dh = h->d_scalars + 8;
-            CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 5) * 8, h->stream));
             CK(hipEventRecord(h->ev[4], h->stream));
-            e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)dh, h->stream);
+            e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)dh,
+                                (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
             CK(hipEventRecord(h->ev[5], h->stream));
-            e2s_launch_hist_tail_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
             LCHK("e2s_launch_hist_seg");
-            CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
-            CK(hipMemcpyAsync(h->pin_mail + 256, dh, (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));
+            CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
             CK(hipStreamSynchronize(h->stream));
             CK(hipGetLastError());
             mail = *(const ScanMail*)h->pin_mail;
@@ -764,10 +762,9 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 5) * 8, h->stream));
     CK(hipEventRecord(h->ev[4], h->stream));
     if (h->segmented) {
-        if (h->n_ends) e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, (unsigned long long*)dh, h->stream);
+        if (h->n_ends) e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, (unsigned long long*)dh,
+                                           (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
         CK(hipEventRecord(h->ev[5], h->stream));
-        if (h->n_ends) e2s_launch_hist_tail_seg(h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len,
-                                                (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
     } else {
         if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
         CK(hipEventRecord(h->ev[5], h->stream));

@@ -145,10 +145,12 @@ void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* t
 void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st);
 int  e2s_scan_seg_resident_blocks(int xb);
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st);
-void e2s_launch_seg_fix(const SegArgs& a, const uint32_t* flags, const uint32_t* tailv, unsigned long long* seg_off, uint32_t* err,
-                        const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, hipStream_t st);
+void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsigned long long* seg_off, uint32_t* err,
+                        const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* hist_zero,
+                        hipStream_t st);
 void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, unsigned long long* out_starts, uint16_t* out_lens, hipStream_t st);
-void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out, hipStream_t st);
+void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out,
+                         unsigned long long* out_last, hipStream_t st);
 void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len,
                               unsigned long long* out_last_len, hipStream_t st);
 void e2s_launch_scan_mail(const ScanArgs& a, const uint32_t* words, const uint8_t* bwt, const void* pos, const void* da,

@@ -638,18 +638,69 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     }
 }
 
+// shard descriptors: begins_inside / open_after / end_before_last and the two last LCP values, evaluated scalar-ly on the
+// boundary entries (one thread)
+__device__ void shard_flags_eval(const void* lcp, u64 n_prov, u64 prov_lo, u64 own_lo, u64 start_hi, u64 end_hi, u32 k, u32 hge, u32 xb,
+                                 u32* flags3, u32* tailv2) {
+    auto L = [&](int64_t i) -> u32 {            // local index -> LCP, 0 outside the provided range
+        if (i < 0 || i >= (int64_t)n_prov) return 0u;
+        const uint8_t* p = (const uint8_t*)lcp + i * xb;
+        return xb == 1 ? (u32)p[0] : xb == 2 ? (u32)*(const uint16_t*)p : *(const u32*)p;
+    };
+    const bool never = hge == 0;
+    auto ge = [&](int64_t i) { return !never && L(i) >= k; };
+    auto gidx = [&](int64_t i) { return (int64_t)prov_lo + i; };
+    auto open = [&](int64_t i) -> bool {       // ebwt2clust.cpp:83-84,116
+        const int64_t g = gidx(i);
+        if (g < 0) return false;
+        if (g == 1) return ge(i - 1) || ge(i);
+        return ge(i);
+    };
+    auto endf = [&](int64_t i) -> bool {       // ebwt2clust.cpp:98-102 (never evaluated for j = 0)
+        const int64_t g = gidx(i);
+        if (g <= 0) return false;
+        return open(i) && ((L(i - 1) > L(i) && L(i) <= L(i + 1)) || !ge(i + 1));
+    };
+    auto startf = [&](int64_t i) -> bool {
+        const int64_t g = gidx(i);
+        if (!open(i)) return false;
+        if (g == 0) return true;
+        return !open(i - 1) || endf(i - 1);
+    };
+    const int64_t lo = (int64_t)own_lo, last = (int64_t)start_hi - 1;   // last owned entry
+    u32 begins_inside = 0, open_after = 0, end_before_last = 0;
+    if (start_hi > own_lo) {
+        begins_inside = (open(lo) && !startf(lo)) ? 1u : 0u;
+        // the end test of the very last entry of the EGSA needs the EOF phantom: left to e2s_stitch
+        const bool last_is_eof = (last >= (int64_t)end_hi);
+        open_after = (open(last) && (last_is_eof || !endf(last))) ? 1u : 0u;
+        // did a cluster close at n_total-2, i.e. did append_entry run in the reference's last real iteration?
+        if (last_is_eof) end_before_last = endf(last - 1) ? 1u : 0u;
+    }
+    flags3[E2S_FLAG_BEGINS_INSIDE] = begins_inside;
+    flags3[E2S_FLAG_OPEN_AFTER] = open_after;
+    flags3[E2S_FLAG_END_BEFORE_LAST] = end_before_last;
+    tailv2[0] = L(last);
+    tailv2[1] = L(last - 1);
+}
+
 // One block ties the segments together: record offsets (exclusive scan of the per-block counts), the records
 // whose start lies in an earlier block, and the ScanMail the host downloads.
 constexpr int SEGFIX_MAX = 8192;             // scan workers (= resident waves: 256 CUs x <= 32)
-__global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, const u32* tailv, u64* seg_off, u32* err,
-                                                  const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out) {
+__global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* tailv, u64* seg_off, u32* err,
+                                                  const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out,
+                                                  u64* hist_zero) {
     __shared__ u32 s_cnt[SEGFIX_MAX];
     __shared__ u64 s_open[SEGFIX_MAX];       // open_start | PASS (inside one cluster throughout) | NONE (closed after the block)
     __shared__ u32 s_part[1024];
     __shared__ u32 s_first, s_last, s_err;
     const u64 NONE = ~0ull, PASS = ~0ull - 1;
     const u32 tid = threadIdx.x, nb = a.n_blocks;
+    __shared__ u32 s_flags[4], s_tailv[2];
     if (tid == 0) { s_first = 0xFFFFFFFFu; s_last = 0; s_err = 0; }
+    // the shard's boundary flags (an otherwise idle thread, while the others fetch descriptors) and a clean statistics buffer
+    if (tid == 1023) shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, (u32)xb, s_flags, s_tailv);
+    if (hist_zero) for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 6); i += 1024) hist_zero[i] = 0ull;
     __syncthreads();
     // every descriptor this thread looks at is loaded up front (<= 8, all in flight together: the loop used to pay
     // one global-memory latency per trip, twice)
@@ -740,8 +791,10 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, const u32* flags, c
         const u32 v_lcp = xb == 1 ? (u32)((const uint8_t*)a.lcp)[li] : xb == 2 ? (u32)((const uint16_t*)a.lcp)[li] : ((const u32*)a.lcp)[li];
         const u32 v_bwt = bwt ? (u32)bwt[li] : 0u;
         const u32 v_wrap = *a.wrap_count, v_err = *err;
-        const u32 f0 = flags[E2S_FLAG_BEGINS_INSIDE], f1 = flags[E2S_FLAG_OPEN_AFTER], f2 = flags[E2S_FLAG_END_BEFORE_LAST];
-        const u32 tv0 = tailv[0], tv1 = tailv[1];
+        const u32 f0 = s_flags[E2S_FLAG_BEGINS_INSIDE], f1 = s_flags[E2S_FLAG_OPEN_AFTER], f2 = s_flags[E2S_FLAG_END_BEFORE_LAST];
+        const u32 tv0 = s_tailv[0], tv1 = s_tailv[1];
+        flags[E2S_FLAG_BEGINS_INSIDE] = f0; flags[E2S_FLAG_OPEN_AFTER] = f1; flags[E2S_FLAG_END_BEFORE_LAST] = f2;
+        tailv[0] = tv0; tailv[1] = tv1;
         m.total_ends = total;
         m.first_end_pos = any ? v_first_end : NONE;
         m.first_rec_addr = first_addr; m.last_rec_addr = last_addr;
@@ -799,50 +852,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const u32* cnt, u64* prefix,
     for (u64 i = lo; i < hi; ++i) { prefix[i] = run; run += cnt[i]; }
 }
 
-// shard descriptors: begins_inside / open_after, evaluated scalar-ly on the two boundary entries
 __global__ void k_shard_flags(ScanArgs a, u32 xb) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    auto L = [&](int64_t i) -> u32 {            // local index -> LCP, 0 outside the provided range
-        if (i < 0 || i >= (int64_t)a.n_prov) return 0u;
-        const uint8_t* p = (const uint8_t*)a.lcp + i * xb;
-        return xb == 1 ? (u32)p[0] : xb == 2 ? (u32)*(const uint16_t*)p : *(const u32*)p;
-    };
-    const u32 k = a.k_u32;
-    const bool never = a.hge == 0;
-    auto ge = [&](int64_t i) { return !never && L(i) >= k; };
-    auto gidx = [&](int64_t i) { return (int64_t)a.prov_lo + i; };
-    auto open = [&](int64_t i) -> bool {       // ebwt2clust.cpp:83-84,116
-        const int64_t g = gidx(i);
-        if (g < 0) return false;
-        if (g == 1) return ge(i - 1) || ge(i);
-        return ge(i);
-    };
-    auto endf = [&](int64_t i) -> bool {       // ebwt2clust.cpp:98-102 (never evaluated for j = 0)
-        const int64_t g = gidx(i);
-        if (g <= 0) return false;
-        return open(i) && ((L(i - 1) > L(i) && L(i) <= L(i + 1)) || !ge(i + 1));
-    };
-    auto startf = [&](int64_t i) -> bool {
-        const int64_t g = gidx(i);
-        if (!open(i)) return false;
-        if (g == 0) return true;
-        return !open(i - 1) || endf(i - 1);
-    };
-    const int64_t lo = (int64_t)a.own_lo, last = (int64_t)a.start_hi - 1;   // last owned entry
-    u32 begins_inside = 0, open_after = 0, end_before_last = 0;
-    if (a.start_hi > a.own_lo) {
-        begins_inside = (open(lo) && !startf(lo)) ? 1u : 0u;
-        // the end test of the very last entry of the EGSA needs the EOF phantom: left to e2s_stitch
-        const bool last_is_eof = (last >= (int64_t)a.end_hi);
-        open_after = (open(last) && (last_is_eof || !endf(last))) ? 1u : 0u;
-        // did a cluster close at n_total-2, i.e. did append_entry run in the reference's last real iteration?
-        if (last_is_eof) end_before_last = endf(last - 1) ? 1u : 0u;
-    }
-    a.flags[E2S_FLAG_BEGINS_INSIDE] = begins_inside;
-    a.flags[E2S_FLAG_OPEN_AFTER] = open_after;
-    a.flags[E2S_FLAG_END_BEFORE_LAST] = end_before_last;
-    a.tailv[0] = L(last);
-    a.tailv[1] = L(last - 1);
+    shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, xb, a.flags, a.tailv);
 }
 
 // one thread: collect what the host needs after a scan into one struct (one download instead of many)
@@ -921,7 +933,7 @@ __global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int m
 // flight: the first version walked the segments block by block, one global-memory latency each (31 us for 13 MB).
 // Per wave 4 histogram replicas in LDS (lengths concentrate on a few values).  Segments are 16-byte aligned
 // (seg_cap is a multiple of 8).
-__global__ __launch_bounds__(1024) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u64* out) {
+__global__ __launch_bounds__(1024) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u64* out, u64* out_last) {
     constexpr int REP = 4, NB = E2S_MAX_CLUST_LEN_K + 1, NWV = 16;
     __shared__ u32 s_freq[NWV * REP][NB + 1];
     __shared__ u64 s_acc[2];
@@ -929,6 +941,14 @@ __global__ __launch_bounds__(1024) void k_hist_seg(const uint16_t* lens, const S
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 1023 && out_last) {   // the last record that survives the min_len filter (H4), and where it lives
+        u64 v = 0, at = ~0ull; bool found = false;
+        for (u32 b = n_seg; b-- > 0 && !found;) {
+            const uint16_t* p = lens + (u64)b * seg_cap;
+            for (u32 i = desc[b].count; i-- > 0;) if ((int)p[i] >= min_len) { v = p[i]; at = (u64)b * seg_cap + i; found = true; break; }
+        }
+        out_last[0] = v; out_last[1] = at;
+    }
     u32* const my = s_freq[wave * REP + (lane & (REP - 1))];
     u64 nrec = 0, nb = 0;
     auto take = [&](u32 l) { if ((int)l >= min_len) { nrec++; nb += (u64)l; if (l <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&my[l], 1u); } };
@@ -1888,16 +1908,16 @@ void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
     else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((k_scan_seg<4>), grid, blk, 0, st, a);
 }
-void e2s_launch_seg_fix(const SegArgs& a, const u32* flags, const u32* tailv, u64* seg_off, u32* err, const uint8_t* bwt, const void* pos,
-                        const void* da, int xb, int yb, int zb, ScanMail* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, err, bwt, pos, da, xb, yb, zb, out);
+void e2s_launch_seg_fix(const SegArgs& a, u32* flags, u32* tailv, u64* seg_off, u32* err, const uint8_t* bwt, const void* pos,
+                        const void* da, int xb, int yb, int zb, ScanMail* out, u64* hist_zero, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, err, bwt, pos, da, xb, yb, zb, out, hist_zero);
 }
 void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_starts, uint16_t* out_lens, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, out_starts, out_lens);
 }
-void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, hipStream_t st) {
+void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, u64* out_last, hipStream_t st) {
     const unsigned want = (n_blocks + 15u) / 16u;                 // 16 waves per block, a segment per wave and trip
-    hipLaunchKernelGGL(k_hist_seg, dim3(want < 256u ? (want ? want : 1u) : 256u), dim3(1024), 0, st, lens, desc, seg_cap, n_blocks, min_len, out);
+    hipLaunchKernelGGL(k_hist_seg, dim3(want < 256u ? (want ? want : 1u) : 256u), dim3(1024), 0, st, lens, desc, seg_cap, n_blocks, min_len, out, out_last);
 }
 void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len, hipStream_t st) {
     hipLaunchKernelGGL(k_hist_tail_seg, dim3(1), dim3(64), 0, st, lens, desc, seg_cap, n_blocks, min_len, out_last_len);
