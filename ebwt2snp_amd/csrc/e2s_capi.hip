@@ -55,6 +55,7 @@ struct e2s_ctx {
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
+    hipEvent_t ev_wait = nullptr;
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
     uint64_t* d_keys = nullptr; uint64_t keys_cap = 0;
     bool cand_downloaded = false;
@@ -137,6 +138,21 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     return E2S_OK;
 }
 
+// Wait for the handle's stream with a short spin on an event before falling back to the blocking wait: the two
+// waits of a job (after the scan, after the per-cluster pass) sit on its critical path, and the blocking wait's
+// wake-up costs tens of microseconds.
+static hipError_t wait_stream(e2s_ctx* h) {
+    if (!h->ev_wait) { if (hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming) != hipSuccess) h->ev_wait = nullptr; }
+    if (h->ev_wait && hipEventRecord(h->ev_wait, h->stream) == hipSuccess) {
+        for (int spin = 0; spin < 200000; ++spin) {
+            const hipError_t q = hipEventQuery(h->ev_wait);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) break;
+        }
+    }
+    return hipStreamSynchronize(h->stream);
+}
+
 static void release_shard(e2s_ctx* h) {
     for (void* p : h->owned) hipFree(p);
     h->owned.clear();
@@ -159,6 +175,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
     hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_size8); hipFree(h->d_slot_off8);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
+    if (h->ev_wait) hipEventDestroy(h->ev_wait);
     if (h->stream2) hipStreamDestroy(h->stream2);
     hipStreamDestroy(h->stream);
     delete h;
@@ -459,7 +476,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             CK(hipEventRecord(h->ev[5], h->stream));
             LCHK("e2s_launch_hist_seg");
             CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
-            CK(hipStreamSynchronize(h->stream));
+            CK(wait_stream(h));
             CK(hipGetLastError());
             mail = *(const ScanMail*)h->pin_mail;
             if (!(mail.err & E2S_DEVERR_SEGFULL)) break;
@@ -1060,7 +1077,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         uint64_t* mb = (uint64_t*)(h->pin_mail + 1024);
         CK(hipMemcpyAsync(mb, h->d_scalars + 1, 16, hipMemcpyDeviceToHost, h->stream));        // cand_count, flagged
         CK(hipMemcpyAsync(mb + 2, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
-        CK(hipStreamSynchronize(h->stream));
+        CK(wait_stream(h));
         CK(hipGetLastError());
         count = mb[0];
         const uint64_t flagged = mb[1];
