@@ -131,12 +131,14 @@ struct FilterArgs {
     unsigned long long* fl_count;
     // k_cluster_filter2: wave workers over 4096-entry tiles (worker b owns w_per tiles, +1 for b < w_rem)
     uint64_t w_tiles; uint32_t w_per, w_rem, w_blocks;
+    uint64_t w_tile0;                                               // first tile of this launch (the pass may run in chunks)
 };
 
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
 void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
-void e2s_launch_cluster_filter2(FilterArgs a, hipStream_t st);
-void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
+void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, hipStream_t st);
+void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st);
+void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);
 #define E2S_WRAP_CAP 1024
 void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* tile_fix_end,

@@ -1367,8 +1367,8 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     const u32 lane = threadIdx.x & 63u;
     const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     if (b >= a.w_blocks) return;
-    const u64 t0 = (u64)b * a.w_per + min(b, a.w_rem);
-    const u64 t1 = min(t0 + (u64)a.w_per + (b < a.w_rem ? 1u : 0u), a.w_tiles);
+    const u64 t0 = a.w_tile0 + (u64)b * a.w_per + min(b, a.w_rem);
+    const u64 t1 = min(t0 + (u64)a.w_per + (b < a.w_rem ? 1u : 0u), a.w_tile0 + a.w_tiles);
     const u64 torg = t0 > 0 ? t0 - 1 : t0;                      // first tile processed (warm-up tile before the range)
     const uint8_t* base = a.lcp;
     const uint8_t* bwtb = a.bwt;
@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
 // K2b: lists and candidate records (clust2snp.cpp:431-496) for the few clusters K2a let through.  Persistent
 // blocks, one wave per cluster, candidates staged in LDS so that a block reserves output slots ~once per 32.
 template <bool DEF>
-__global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigned long long* n_dev) {
+__global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigned long long* lo_dev, const unsigned long long* n_dev) {
     __shared__ u32 s_nstage;
     __shared__ u64 s_gbase, s_sbase;
     __shared__ u32 s_off8[FW_STAGE];
@@ -1650,9 +1650,10 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
         if (tid == 0) s_nstage = 0;
         __syncthreads();
     };
-    const u64 n = min((u64)*n_dev, a.n_rec);
+    const u64 n = min((u64)*n_dev, a.n_rec);                     // this launch handles list entries [*lo_dev, *n_dev)
+    const u64 first = lo_dev ? (u64)*lo_dev : 0ull;
     const u64 per_round = (u64)gridDim.x * 4;
-    for (u64 base = (u64)blockIdx.x * 4; base < n; base += per_round) {
+    for (u64 base = first + (u64)blockIdx.x * 4; base < n; base += per_round) {
         // (flushing earlier to start the PCIe stream sooner was tried: chunks of ~8 records ran 25 % slower)
         if (s_nstage > FW_STAGE - 16) stage_flush();                // a round adds at most 4 x 4 candidates
         const u64 r = base + wave;
@@ -1972,23 +1973,31 @@ void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st) {
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_cluster_filter, dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
-void e2s_launch_cluster_filter2(FilterArgs a, hipStream_t st) {
+void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, hipStream_t st) {
     static int resident = 0;
     if (!resident) {
-        resident = 4 * resident_blocks((const void*)k_cluster_filter2, 256, 0);
-        if (const char* ev = getenv("E2S_FILTER_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < resident) resident = cap; }
+        // three workers per SIMD: the kernel is VALU bound (the same speed with 2..4), and this leaves registers for the
+        // waves of k_flagged_lists, which runs beside the next chunk of this pass
+        resident = 3 * 1024;
+        const int fit = 4 * resident_blocks((const void*)k_cluster_filter2, 256, 0);
+        if (fit < resident) resident = fit;
+        if (const char* ev = getenv("E2S_FILTER_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < fit) resident = cap; }
     }
-    a.w_tiles = (a.n_prov + 4095) / 4096;
+    if (tile_hi <= tile_lo) return;
+    a.w_tile0 = tile_lo; a.w_tiles = tile_hi - tile_lo;
     uint64_t nb = a.w_tiles < (uint64_t)resident ? a.w_tiles : (uint64_t)resident;
-    if (nb == 0) return;
     a.w_per = (uint32_t)(a.w_tiles / nb); a.w_rem = (uint32_t)(a.w_tiles % nb); a.w_blocks = (uint32_t)nb;
     hipLaunchKernelGGL(k_cluster_filter2, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, a);
 }
-void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
+__global__ void k_snapshot(const unsigned long long* src, unsigned long long* dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
+void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(64), 0, st, src, dst);
+}
+void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
     const size_t dyn = (size_t)2 * FW_STAGE * a.stride;          // staged records + their packed image
     const unsigned blocks = 1024;
-    if (def_widths) hipLaunchKernelGGL((k_flagged_lists<true>), dim3(blocks), dim3(256), dyn, st, a, n_dev);
-    else hipLaunchKernelGGL((k_flagged_lists<false>), dim3(blocks), dim3(256), dyn, st, a, n_dev);
+    if (def_widths) hipLaunchKernelGGL((k_flagged_lists<true>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev);
+    else hipLaunchKernelGGL((k_flagged_lists<false>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev);
 }
 void e2s_launch_unpack_pairsa(const uint8_t* src, u64 n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st) {
     if (!n) return;

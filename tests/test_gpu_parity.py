@@ -469,3 +469,23 @@ def test_fused_streaming_fuzz_columns(H, tmp_path, seed):
     for a, b in zip(got, oc):
         for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
             assert a[key] == b[key]
+
+
+@pytest.mark.gpu
+def test_chunked_prefilter_pipeline(tmp_path):
+    """the pre-filter in chunks with K2b on the second stream beside the next chunk (what large shards use), forced
+    onto a small input in a child process (the switches are read once per process); the fuzz columns again"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, pathlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, test_gpu_parity as T\n"
+        "from ebwt2snp_amd import capi\n"
+        "H = capi.Handle(0)\n"
+        "for seed in (101, 103):\n"
+        "    T.test_fused_streaming_fuzz_columns(H, pathlib.Path(%r), seed)\n"
+        "print('CHUNKED_OK')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                     str(tmp_path))
+    env = dict(os.environ, E2S_FILTER_CHUNKS="3", E2S_FILTER_CHUNK_MIN_TILES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CHUNKED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
