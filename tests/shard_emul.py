@@ -77,3 +77,29 @@ def apply_plan(starts, lens, plan):
     ts = [plan.tail_start[i] for i in range(plan.n_tail)]
     tl = [plan.tail_len[i] for i in range(plan.n_tail)]
     return np.concatenate([starts, np.asarray(ts, dtype=np.uint64)]), np.concatenate([lens, np.asarray(tl, dtype=np.uint16)])
+
+
+def hist_of(lens, m):
+    """e2s_hist of a record list (lengths as stored), min_len filter m"""
+    ln = np.asarray(lens).astype(np.int64)
+    keep = ln[ln >= m]
+    hs = capi.Hist()
+    for v in keep[keep <= capi.MAX_CLUST_LEN]:
+        hs.freq[int(v)] += 1
+    hs.n_records = int(keep.size)
+    hs.n_bases = int(keep.sum())
+    hs.last_len = int(keep[-1]) if keep.size else 0
+    return hs
+
+
+def raw_stats(lens, m):
+    """what the scan phase leaves (e2s_scan_stats): statistics of the shard's own records as stored before the
+    stitch, record 0 possibly provisional"""
+    ln = np.asarray(lens).astype(np.int64)
+    st = capi.ScanStats()
+    st.hist = hist_of(ln, m)
+    q = np.nonzero(ln >= m)[0]
+    st.last_none = int(q.size == 0)
+    st.last_is_first = int(q.size > 0 and q[-1] == 0)
+    st.min_len = m
+    return st

@@ -1,7 +1,7 @@
 """N > 1 path on CPU: two gloo ranks, each holding one SA range.  Every rank produces its shard's records and
 boundary descriptor (numpy emulation of the scan kernel, tests/shard_emul.py), the descriptors travel with
 ONE all-gather, each rank runs the product's e2s_stitch_plan, and the concatenated result must equal the
-sequential oracle on the whole array.  The statistics step (one more all-gather of histogram partials) is
+sequential oracle on the whole array.  The statistics travel with the descriptors (one all-gather) and are
 checked against the oracle's auto-detected max cluster length."""
 import ctypes
 import os
@@ -34,29 +34,26 @@ def _worker(rank, world, port, L, bwt, cuts, k, m, q):
         n = len(L)
         bounds = [0] + list(cuts) + [n]
         st, ln, b = SE.shard_scan(L, bwt, bounds[rank], bounds[rank + 1], k)
-        sz = ctypes.sizeof(capi.Boundary)
-        mine = torch.frombuffer(bytearray(bytes(b)), dtype=torch.uint8)
-        allt = torch.empty(world * sz, dtype=torch.uint8)
-        dist.all_gather_into_tensor(allt, mine)                       # the boundary stitch: one all-gather
-        raw = allt.numpy().tobytes()
-        allb = [capi.Boundary.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(world)]
+        # ONE all-gather: boundary descriptor + the statistics the scan phase left (record 0 still provisional)
+        raw = SE.raw_stats(ln, m)
+        sz, zz = ctypes.sizeof(capi.Boundary), ctypes.sizeof(capi.ScanStats)
+        mine = torch.frombuffer(bytearray(bytes(b) + bytes(raw)), dtype=torch.uint8)
+        allt = torch.empty(world * (sz + zz), dtype=torch.uint8)
+        dist.all_gather_into_tensor(allt, mine)
+        blob = allt.numpy().tobytes()
+        allb = [capi.Boundary.from_buffer_copy(blob[i * (sz + zz):i * (sz + zz) + sz]) for i in range(world)]
+        alls = [capi.ScanStats.from_buffer_copy(blob[i * (sz + zz) + sz:(i + 1) * (sz + zz)]) for i in range(world)]
         plan = capi.stitch_plan(allb, rank, n, k, 1)
         st, ln = SE.apply_plan(st, ln, plan)
         closed = st.size
+        # every rank evaluates every rank's plan and stitched statistics (pure host functions): no second exchange
+        hists = [capi.hist_after_stitch(alls[r], allb[r], capi.stitch_plan(allb, r, n, k, 1)) for r in range(world)]
+        mine_direct = SE.hist_of(ln, m)                               # ... equal to the statistics of the final records
+        assert list(hists[rank].freq) == list(mine_direct.freq)
+        assert (hists[rank].n_records, hists[rank].n_bases, hists[rank].last_len) == \
+               (mine_direct.n_records, mine_direct.n_bases, mine_direct.last_len)
         keep = ln.astype(np.int64) >= m
         st, ln = st[keep], ln[keep]
-        hs = capi.Hist()
-        for v in ln:
-            if v <= 150:
-                hs.freq[int(v)] += 1
-        hs.n_records = len(ln)
-        hs.n_bases = int(ln.astype(np.int64).sum())
-        hs.last_len = int(ln[-1]) if len(ln) else 0
-        hz = ctypes.sizeof(capi.Hist)
-        allh = torch.empty(world * hz, dtype=torch.uint8)
-        dist.all_gather_into_tensor(allh, torch.frombuffer(bytearray(bytes(hs)), dtype=torch.uint8))
-        rawh = allh.numpy().tobytes()
-        hists = [capi.Hist.from_buffer_copy(rawh[i * hz:(i + 1) * hz]) for i in range(world)]
         mcl, n_clust, _ = capi.auto_max_clust_length(hists, 5, 0.99)
         q.put((rank, st.tolist(), ln.tolist(), closed, mcl, n_clust))
     finally:

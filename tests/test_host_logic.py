@@ -55,6 +55,12 @@ def _stitch_all(L, bwt, cuts, k, m, x):
     for r, (st, ln, _) in enumerate(shards):
         plan = capi.stitch_plan(allb, r, n, k, x)
         st2, ln2 = SE.apply_plan(st, ln, plan)
+        # the statistics the scan phase leaves + the plan (e2s_hist_after_stitch, a pure host function) must equal the
+        # statistics of the records the shard holds after the stitch -- for every min_len that matters
+        for mm in (m, 1, 3, 40):
+            got, want = capi.hist_after_stitch(SE.raw_stats(ln, mm), allb[r], plan), SE.hist_of(ln2, mm)
+            assert list(got.freq) == list(want.freq)
+            assert (got.n_records, got.n_bases, got.last_len) == (want.n_records, want.n_bases, want.last_len)
         S.append(st2)
         Ln.append(ln2)
         closed += st2.size
@@ -150,6 +156,21 @@ def _pack_candidates(cands, cap):
     return buf
 
 
+def _pack_stream(cands):
+    """the packed layout of e2s_candidates_packed: [header][idx0[n0]][pos0[n0]][idx1[n1]][pos1[n1]], offsets in 8-byte units"""
+    parts, off8, at = [], [], 0
+    for i, c in enumerate(cands):
+        h = capi.CandHeader(i, 0, len(c["idx0"]), len(c["idx1"]), c["right_idx"], c["right_pos"], 0)
+        body = np.concatenate([np.asarray(c[k], dtype=np.uint32) for k in ("idx0", "pos0", "idx1", "pos1")]) if (c["idx0"] or c["idx1"]) \
+            else np.zeros(0, np.uint32)
+        rec = np.concatenate([np.frombuffer(bytes(h), dtype=np.uint8), body.view(np.uint8)])
+        off8.append(at // 8)
+        parts.append(rec)
+        at += rec.size
+    off8.append(at // 8)
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint8), np.asarray(off8, dtype=np.uint32)
+
+
 @pytest.mark.parametrize("meta", [m for m in goldens.e2e_cases() if m["name"] in ("tiny_bcr", "c1_bcr", "opts_bcr", "w282_bcr", "indel_bcr")],
                          ids=lambda m: m["name"])
 def test_host_tail_on_oracle_candidates(meta, tmp_path):
@@ -169,6 +190,12 @@ def test_host_tail_on_oracle_candidates(meta, tmp_path):
     nv, ne = capi.snp_from_candidates(_pack_candidates(cands, cap), len(cands), cap, p, out,
                                       a.get("L", 0) or 31, a.get("R", 0) or 30, a.get("g", 0) or 10, a.get("e", 0) or 2)
     assert open(out, "rb").read() == goldens.golden_snp(meta)
+    # the same tail over the packed stream (the layout the GPU writes into the pinned buffer)
+    stream, off8 = _pack_stream(cands)
+    out2 = str(tmp_path / "product_packed.snp")
+    nv2, ne2 = capi.snp_from_packed(stream, off8, len(cands), p, out2, a.get("L", 0) or 31, a.get("R", 0) or 30, a.get("g", 0) or 10,
+                                    a.get("e", 0) or 2)
+    assert (nv2, ne2) == (nv, ne) and open(out2, "rb").read() == goldens.golden_snp(meta)
     assert ne == meta["n_events"]
 
 
