@@ -11,7 +11,7 @@
 #define E2S_MAX_CLUST_LEN_K 150
 
 // device-side error bits
-#define E2S_DEVERR_SPIN   1u   // look-back wait expired
+#define E2S_DEVERR_SPIN   1u   // (reserved: wait expired in an earlier single-pass variant)
 #define E2S_DEVERR_REMOTE 2u   // a cluster's entries are not resident in this shard
 #define E2S_DEVERR_SEGFULL 8u  // an output segment of the segmented scan overflowed (rerun with larger segments)
 #define E2S_DEVERR_DENSE  4u   // a 4096-entry window holds more clusters than the LDS slots (fall back)
@@ -41,7 +41,7 @@ struct ScanArgs {
     uint64_t* tile_fix;       // [n_tiles], preset to ~0: rank of the tile's record whose start lies in an earlier tile
     uint64_t* tile_fix_end;   // [n_tiles]: that record's end position
     uint64_t* first_end_pos;  // SA position of the shard's first end (preset ~0)
-    // look-back workspace (MODE 0)
+    // workspace of an earlier single-pass variant (unused)
     uint64_t* tile_state;     // [n_tiles], preset to 0
     uint32_t* tile_counter;   // preset to 0
     uint32_t spin_limit;
@@ -153,8 +153,6 @@ void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsi
 void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, unsigned long long* out_starts, uint16_t* out_lens, hipStream_t st);
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out,
                          unsigned long long* out_last, hipStream_t st);
-void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len,
-                              unsigned long long* out_last_len, hipStream_t st);
 void e2s_launch_scan_mail(const ScanArgs& a, const uint32_t* words, const uint8_t* bwt, const void* pos, const void* da,
                           int xb, int yb, int zb, ScanMail* out, hipStream_t st);
 void e2s_launch_apply_plan(unsigned long long* starts, uint16_t* lens, uint32_t patch_first, unsigned long long first_start,

@@ -78,11 +78,9 @@ constexpr u32 CARRY_CLOSED = 0xFFFFFFFFu;   // last event of the thread-row was 
 constexpr u32 CARRY_NOEVENT = 0xFFFFFFFEu;  // no event: pass the predecessor's carry through
 constexpr u32 CARRY_UNKNOWN = 0xFFFFFFFDu;  // the open start lies before this tile
 
-constexpr u64 ST_FLAG_A = 1ull << 62;       // tile aggregate published
-constexpr u64 ST_FLAG_P = 2ull << 62;       // inclusive prefix published
-constexpr u64 ST_VALUE = (1ull << 62) - 1;
 
-// MODE 0: single pass, decoupled look-back.  MODE 1: count only.  MODE 2: emit with given prefixes.
+// scan_mode 1: MODE 1 counts the ends per tile, MODE 2 emits with the scanned prefixes.  (A single-pass variant with a
+// decoupled look-back chain was the first K1: the chain, not HBM, set its time; removed.)
 template <int X, int MODE>
 __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
     constexpr int EPT = 16 / X;                     // entries per thread-row
@@ -93,22 +91,13 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
     constexpr int EPW = Swar<X>::EPW;
     constexpr int NWAVES = SCAN_BLK / 64;
 
-    __shared__ u32 s_tile;
     __shared__ u32 s_wtot[SCAN_ROWS][NWAVES];
     __shared__ u32 s_wcarry[SCAN_ROWS][NWAVES];
-    __shared__ u64 s_prefix;
 
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, wave = tid >> 6;
 
-    u64 tile;
-    if (MODE == 0) {
-        if (tid == 0) s_tile = atomicAdd(a.tile_counter, 1u);    // dispatch-order ticket: predecessors have started
-        __syncthreads();
-        tile = s_tile;
-    } else {
-        tile = blockIdx.x;
-    }
+    const u64 tile = blockIdx.x;
     const int64_t tile_lo = (int64_t)tile * TILE;                // local entry index (0 = first provided entry)
     const uint8_t* base = (const uint8_t*)a.lcp;
     const int64_t n_prov = (int64_t)a.n_prov;
@@ -189,53 +178,8 @@ __global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
         return;
     }
 
-    // ---- tile prefix ----
-    u64 prefix;
-    if (MODE == 0) {
-        if (wave == 0) {
-            if (lane == 0) {
-                const u64 v = (tile == 0 ? ST_FLAG_P : ST_FLAG_A) | (u64)tile_total;
-                __hip_atomic_store(&a.tile_state[tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            u64 run = 0;
-            if (tile > 0) {
-                int64_t look = (int64_t)tile - 1 - (int64_t)lane;
-                bool done = false;
-                u32 spins = 0;
-                while (!done) {
-                    u64 v = ST_FLAG_P;                                   // before tile 0: prefix 0
-                    if (look >= 0) v = __hip_atomic_load(&a.tile_state[look], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const u64 ready = __ballot((v >> 62) != 0);
-                    const u64 isp = __ballot((v >> 62) == 2);
-                    // usable window: lanes 0..p where p = nearest predecessor holding an inclusive prefix,
-                    // provided every lane below it is ready
-                    u64 need = isp ? ((isp & (0 - isp)) << 1) - 1 : ~0ull;   // lanes up to and including first P
-                    if ((ready & need) == need) {
-                        u32 lo = (u32)(v & 0xFFFFFFFFull), hi = (u32)((v & ST_VALUE) >> 32);
-                        const bool use = ((need >> lane) & 1ull) != 0;
-                        lo = use ? lo : 0; hi = use ? hi : 0;
-                        // 64-bit wave sum of the used lanes (values < 2^62, counts fit comfortably)
-                        u64 s = ((u64)hi << 32) | lo;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                        run += s;
-                        if (isp) done = true; else look -= 64;
-                        spins = 0;
-                    } else {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > a.spin_limit) { if (lane == 0) atomicOr(a.err, E2S_DEVERR_SPIN); done = true; }
-                    }
-                }
-                if (lane == 0)
-                    __hip_atomic_store(&a.tile_state[tile], ST_FLAG_P | ((run + tile_total) & ST_VALUE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane == 0) s_prefix = run;
-        }
-        __syncthreads();
-        prefix = s_prefix;
-    } else {
-        prefix = a.tile_prefix[tile];
-    }
+    // ---- tile prefix (from the scan of the counts) ----
+    const u64 prefix = a.tile_prefix[tile];
     if (tile == a.n_tiles - 1 && tid == 0) *a.total_ends = prefix + tile_total;
 
     // ---- carries: the open start each thread-row inherits from the rows before it in the tile ----
@@ -976,17 +920,6 @@ __global__ __launch_bounds__(1024) void k_hist_seg(const uint16_t* lens, const S
     }
     if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
 }
-__global__ void k_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 v = 0, at = ~0ull; bool found = false;
-    for (u32 b = n_blocks; b-- > 0 && !found;) {
-        const uint16_t* p = lens + (u64)b * seg_cap;
-        for (u32 i = desc[b].count; i-- > 0;) if ((int)p[i] >= min_len) { v = p[i]; at = (u64)b * seg_cap + i; found = true; break; }
-    }
-    out_last_len[0] = v;
-    out_last_len[1] = at;                                        // where that record lives (~0: none qualifies)
-}
-
 // ----------------------------------------------------------------------------------------------
 // K2: per-cluster pass.  One wave per cluster record, lane i <-> entry start+i (clusters are
 // at most 150 entries: three 64-entry chunks).  find_variants, clust2snp.cpp:367-500.
@@ -1892,8 +1825,7 @@ __global__ void k_unpack_gesa(const uint8_t* src, u64 n, int yb_file, int zb_fil
 static int resident_blocks(const void* fn, int threads, size_t dyn_lds);
 template <int X> static void launch_scan_x(const ScanArgs& a, int mode, hipStream_t st) {
     const dim3 grid((unsigned)a.n_tiles), blk(SCAN_BLK);
-    if (mode == 0) hipLaunchKernelGGL((k_scan<X, 0>), grid, blk, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_scan<X, 1>), grid, blk, 0, st, a);
+    if (mode == 1) hipLaunchKernelGGL((k_scan<X, 1>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((k_scan<X, 2>), grid, blk, 0, st, a);
 }
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st) {
@@ -1919,9 +1851,6 @@ void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_start
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, u64* out_last, hipStream_t st) {
     const unsigned want = (n_blocks + 15u) / 16u;                 // 16 waves per block, a segment per wave and trip
     hipLaunchKernelGGL(k_hist_seg, dim3(want < 256u ? (want ? want : 1u) : 256u), dim3(1024), 0, st, lens, desc, seg_cap, n_blocks, min_len, out, out_last);
-}
-void e2s_launch_hist_tail_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out_last_len, hipStream_t st) {
-    hipLaunchKernelGGL(k_hist_tail_seg, dim3(1), dim3(64), 0, st, lens, desc, seg_cap, n_blocks, min_len, out_last_len);
 }
 void e2s_launch_tile_scan(const u32* cnt, u64* prefix, u64 n, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, n);
