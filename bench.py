@@ -145,21 +145,20 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None)
         st = h.scan_stats()
         sb, ss = ctypes.sizeof(capi.Boundary), ctypes.sizeof(capi.ScanStats)
         parts = _exchange(bytes(b) + bytes(st), world, dist, dev)
-        allb = [capi.Boundary.from_buffer_copy(p[:sb]) for p in parts]
-        alls = [capi.ScanStats.from_buffer_copy(p[sb:sb + ss]) for p in parts]
+        blob = np.frombuffer(b"".join(parts), dtype=np.uint8).reshape(world, sb + ss)
+        allb = (capi.Boundary * world).from_buffer_copy(np.ascontiguousarray(blob[:, :sb]).tobytes())
+        alls = (capi.ScanStats * world).from_buffer_copy(np.ascontiguousarray(blob[:, sb:]).tobytes())
+        h.stitch_array(allb, world, rank)
     else:
-        allb = [b]
-    h.stitch(allb, rank)
+        h.stitch([b], rank)
     t = _tick("stitch", t)
     if world > 1:
-        # every rank applies every rank's stitch plan to that rank's statistics (pure host functions)
-        hists = [capi.hist_after_stitch(alls[r], allb[r], capi.stitch_plan(allb, r, n_total, k, 1)) for r in range(world)]
+        # every rank derives the same statistics from the gathered blobs (pure host function, one call)
+        mcl, n_clust, _ = capi.auto_max_clust_length_ranks(allb, alls, n_total, k, 1, prm_base["m"], 0.99)
     else:
-        hists = [h.hist()]
+        mcl, n_clust, _ = capi.auto_max_clust_length([h.hist()], prm_base["m"], 0.99)
     t = _tick("hist", t)
-    mcl, n_clust, _ = capi.auto_max_clust_length(hists, prm_base["m"], 0.99)
     prm = capi.C2SParams(prm_base["n1"], 31, 30, prm_base["m"], 20, mcl, min_len)
-    t = _tick("stats", t)
     ncand = h.find_candidates(prm, rank << 40)
     t = _tick("candidates", t)
     stream, off8, ncand = h.candidates_packed()                  # pinned host memory, packed, SA order (what the host tail consumes)

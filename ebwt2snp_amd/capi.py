@@ -76,7 +76,7 @@ class Timing(C.Structure):
 SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
            "e2s_attach_soa", "e2s_upload_lcp", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
-           "e2s_hist_after_stitch",
+           "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
 
@@ -110,6 +110,8 @@ def lib():
     L.e2s_cluster_hist.argtypes = [H, C.POINTER(Hist)]
     L.e2s_scan_stats_desc.argtypes = [H, C.POINTER(ScanStats)]
     L.e2s_hist_after_stitch.argtypes = [C.POINTER(ScanStats), C.POINTER(Boundary), C.POINTER(StitchPlan), C.POINTER(Hist)]
+    L.e2s_auto_max_clust_length_ranks.argtypes = [C.POINTER(Boundary), C.POINTER(ScanStats), C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                                  C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_auto_max_clust_length.argtypes = [C.POINTER(Hist), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_find_candidates.argtypes = [H, C.POINTER(C2SParams), C.c_uint64, C.POINTER(C.c_uint64)]
@@ -194,6 +196,10 @@ class Handle:
     def stitch(self, all_b, rank):
         arr = (Boundary * len(all_b))(*all_b)
         self._ck(self.L.e2s_stitch(self.h, arr, len(all_b), rank))
+
+    def stitch_array(self, arr, n, rank):
+        """stitch with the gathered descriptors already in a ctypes array"""
+        self._ck(self.L.e2s_stitch(self.h, arr, n, rank))
 
     def scan_single(self, k=16, min_len=2, scan_mode=0):
         """scan + the (trivial) one-rank stitch"""
@@ -296,6 +302,19 @@ def hist_after_stitch(raw, boundary, plan):
     if rc:
         raise E2SError(rc, "e2s_hist_after_stitch")
     return hs
+
+
+def auto_max_clust_length_ranks(all_b, all_stats, n_total, k=16, lcp_bytes=1, mcov_out=5, pval=0.99):
+    """Host-only: plans + stitched statistics of every rank + the auto-detection, in one call.  all_b / all_stats may be
+    ctypes arrays (as gathered) or lists."""
+    nr = len(all_b)
+    ab = all_b if isinstance(all_b, C.Array) else (Boundary * nr)(*all_b)
+    st = all_stats if isinstance(all_stats, C.Array) else (ScanStats * nr)(*all_stats)
+    mcl, nc, nb = C.c_int(0), C.c_uint64(0), C.c_uint64(0)
+    rc = lib().e2s_auto_max_clust_length_ranks(ab, st, nr, n_total, k, lcp_bytes, mcov_out, pval, C.byref(mcl), C.byref(nc), C.byref(nb))
+    if rc:
+        raise E2SError(rc, "e2s_auto_max_clust_length_ranks")
+    return mcl.value, nc.value, nb.value
 
 
 def auto_max_clust_length(hists, mcov_out=5, pval=0.99):

@@ -1198,6 +1198,20 @@ static void expand_fixed(e2s_ctx* h) {
     h->host_fixed_valid = true;
 }
 
+extern "C" int e2s_auto_max_clust_length_ranks(const e2s_boundary* all, const e2s_scan_stats* stats, int nranks, uint64_t n_total, int k,
+                                               int lcp_bytes, int mcov_out, double pval, int* max_clust_length, uint64_t* n_clust,
+                                               uint64_t* n_bases) {
+    if (!all || !stats || nranks < 1 || !max_clust_length) return E2S_ERR_ARG;
+    std::vector<e2s_hist> hs((size_t)nranks);
+    for (int r = 0; r < nranks; ++r) {
+        e2s_stitch_plan_t pl;
+        int rc = e2s_stitch_plan(all, nranks, r, n_total, k, lcp_bytes, &pl);
+        if (rc) return rc;
+        if ((rc = e2s_hist_after_stitch(&stats[r], &all[r], &pl, &hs[(size_t)r]))) return rc;
+    }
+    return e2s_auto_max_clust_length(hs.data(), nranks, mcov_out, pval, max_clust_length, n_clust, n_bases);
+}
+
 extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand) {
     dbg_entry("e2s_fetch_candidates");
     if (!h || !n_cand) return E2S_ERR_ARG;

@@ -165,6 +165,11 @@ int e2s_scan_stats_desc(e2s_handle h, e2s_scan_stats* out);
 /* Host-only, pure: rank's statistics once its stitch plan (e2s_stitch_plan) is applied -- what e2s_cluster_hist
  * returns after e2s_stitch.  b = the rank's own descriptor. */
 int e2s_hist_after_stitch(const e2s_scan_stats* raw, const e2s_boundary* b, const e2s_stitch_plan_t* plan, e2s_hist* out);
+/* Host-only, pure: the whole statistics step of N ranks in one call -- every rank's stitch plan, its statistics after
+ * the stitch, and e2s_auto_max_clust_length over them (all[r] / stats[r] as gathered, rank order = SA order). */
+int e2s_auto_max_clust_length_ranks(const e2s_boundary* all, const e2s_scan_stats* stats, int nranks, uint64_t n_total, int k,
+                                    int lcp_bytes, int mcov_out, double pval, int* max_clust_length, uint64_t* n_clust,
+                                    uint64_t* n_bases);
 
 /* Host-only: merge per-rank partials in rank order, apply the reference's double count of the
  * last record (H4) and its auto-detection loop incl. the -Ofast arithmetic (H19).

@@ -55,6 +55,7 @@ def _worker(rank, world, port, L, bwt, cuts, k, m, q):
         keep = ln.astype(np.int64) >= m
         st, ln = st[keep], ln[keep]
         mcl, n_clust, _ = capi.auto_max_clust_length(hists, 5, 0.99)
+        assert capi.auto_max_clust_length_ranks(allb, alls, n, k, 1, 5, 0.99)[:2] == (mcl, n_clust)    # the same in one call
         q.put((rank, st.tolist(), ln.tolist(), closed, mcl, n_clust))
     finally:
         dist.destroy_process_group()
