@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
 // ----------------------------------------------------------------------------------------------
 // K2a, second formulation: the same pre-filter built like the scan kernel.  Every wave is a worker over a
 // contiguous range of 4096-entry tiles (a lane owns 64 entries); everything is a 64-bit plane per lane: cluster
-// starts / ends (the scan's stencil), LCP >= k_right, BWT = C / G / T.  A cluster is evaluated by the lane that
+// starts / ends (the scan's stencil), BWT = C / G / T.  A cluster is evaluated by the lane that
 // holds its END: its own piece [start or span begin, end] by population counts of the class planes, plus -- if
 // the cluster began in an earlier lane -- a carry (packed counts + flags) handed from lane to lane with DPP
 // wave_shr:1 (three rounds cover every cluster of <= 150 entries) and from tile to tile in an SGPR.  No LDS
@@ -1396,7 +1396,8 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
         }
         u64 C, G, T;
         span_bwt_classes<NR>(B, C, G, T);
-        const u64 KR = span_ge_plane<NR>(W + 1, a.krb, a.kr_hge);
+        // (LCP >= k_right somewhere in the cluster, clust2snp.cpp:396, is left to K2b's exact test: dropping the plane here lets
+        // through only the rare cluster whose LCPs all lie in [k, k_right) and saves 7 % of this kernel's instructions)
         // class changes inside clusters: F(e) = class(e) != class(e-1), e in a cluster and not its first entry
         const u64 c0 = C | T, c1 = G | T;
         const u32 ctop = (u32)(c0 >> 63) | ((u32)(c1 >> 63) << 1);
@@ -1408,7 +1409,7 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
         const int msbS = 63 - __clzll(S | 1ull);
         const u64 tm = hasS ? ~((1ull << msbS) - 1ull) : ~0ull;
         auto packed = [&](u64 m) -> u32 {
-            return (u32)__popcll(C & m) | ((u32)__popcll(G & m) << 8) | ((u32)__popcll(T & m) << 16) | ((KR & m) ? (1u << 24) : 0u) | ((F & m) ? (1u << 25) : 0u);
+            return (u32)__popcll(C & m) | ((u32)__popcll(G & m) << 8) | ((u32)__popcll(T & m) << 16) | ((F & m) ? (1u << 25) : 0u);
         };
         const u32 local = packed(tm);
         auto merge = [](u32 x, u32 y) -> u32 { return (((x & 0xFFFFFFu) + (y & 0xFFFFFFu)) & 0xFFFFFFu) | ((x | y) & 0xFF000000u); };
@@ -1458,14 +1459,13 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
             const int ms = 63 - __clzll(sc | 1ull);
             const u64 rm = have ? (upto & ~((1ull << ms) - 1ull)) : upto;
             u32 pk = (u32)__popcll(C & rm) | ((u32)__popcll(G & rm) << 8) | ((u32)__popcll(T & rm) << 16);
-            bool kr = (KR & rm) != 0ull;
-            if (!have) { pk = merge(pk, cin) & 0xFFFFFFu; kr = kr || ((cin >> 24) & 1u); }
+            if (!have) pk = merge(pk, cin) & 0xFFFFFFu;
             const u32 st1 = have ? base_off + (u32)ms + 1u : cur1;
             const u32 len = base_off + (u32)e + 2u - st1;
             const u32 cC = pk & 0xFFu, cG = (pk >> 8) & 0xFFu, cT = (pk >> 16) & 0xFFu, cA = len - cC - cG - cT;
             const u32 nfreq = (cA >= a.mcov_u ? 1u : 0u) + (cC >= a.mcov_u ? 1u : 0u) + (cG >= a.mcov_u ? 1u : 0u) + (cT >= a.mcov_u ? 1u : 0u);
             // st1 == 0: the cluster began before the warm-up tile, i.e. it is longer than a tile and fails the length test
-            const bool pass = act && st1 != 0u && (int)len >= a.len_lo && (int)len <= a.len_hi && kr && nfreq >= 2u;
+            const bool pass = act && st1 != 0u && (int)len >= a.len_lo && (int)len <= a.len_hi && nfreq >= 2u;
             const u64 pm = __ballot(pass);
             if (pass) {
                 const u32 idx = qn + (u32)__popcll(pm & ((1ull << lane) - 1ull));
