@@ -42,6 +42,7 @@ WORKLOADS = {
     # 3.02e9 entries: ten copies of an exactly sorted 2x1M x150bp block laid end to end, read ids remapped per copy
     # ("C2-style block tiled with read-id remap") -- BASELINE.json configs[2], 21 GB of EGSA in HBM
     "c3": (1000000, 150, 10),
+    "c3x": (1000000, 150, 15),    # 4.53e9 entries: SA positions beyond 2^32 on one GPU (stress check, 32 GB of EGSA)
 }
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
