@@ -489,3 +489,49 @@ def test_chunked_prefilter_pipeline(tmp_path):
     env = dict(os.environ, E2S_FILTER_CHUNKS="3", E2S_FILTER_CHUNK_MIN_TILES="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CHUNKED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_tiled_copies_property():
+    """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
+    remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
+    with remapped read ids -- the copies start at offsets that are no multiple of any tile or lane size"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda", 0)
+    reads, n1, blk = bench.build_block(20011, 100, dev)
+    m = blk["lcp"].numel()
+    assert m % 4096 != 0 and m % 64 != 0
+    res = []
+    for copies in (1, 3):
+        b, nn1 = bench.tile_block(blk, n1, copies)
+        h = capi.Handle(0)
+        h.attach_soa(capi.Handle.desc(m * copies), b["bwt"].data_ptr(), b["lcp"].data_ptr(), b["pos"].data_ptr(), b["da"].data_ptr(),
+                     keep=tuple(b.values()))
+        h.scan_single(16, 2, 0)
+        nclosed, _ = h.counts()
+        n_ends = h.boundary().n_ends                              # without the records the EOF rule adds at the very end
+        rec = h.fetch_clusters().view(IO.CLUSTER_DTYPE).copy()
+        mcl, _, _ = capi.auto_max_clust_length([h.hist()], 5, 0.99)
+        prm = capi.C2SParams(nn1, 31, 30, 5, 20, mcl, 2)
+        h.find_candidates(prm)
+        buf, nc, cap, stride = h.fetch_candidates(prm)
+        res.append((nclosed, n_ends, rec, mcl, capi.parse_candidates(buf, nc, cap, stride)))
+        h.close()
+    (c1, e1, r1, m1, k1), (c3, e3, r3, m3, k3) = res
+    # only the end of the whole array sees the EOF rule: the ends inside the copies triple, its extra records do not
+    assert e3 == 3 * e1 and c3 - e3 == c1 - e1 and m3 == m1 and len(k3) == 3 * len(k1) and len(k1) > 100
+    for b in range(3):
+        # copy b's records (by start position) equal the one-copy records shifted by b * m, up to the last few, where the one-copy
+        # run ends with the EOF rule and an inner copy with an ordinary end
+        st = r3["start"].astype(np.int64)
+        part = r3[(st >= b * m) & (st < (b + 1) * m)]
+        assert abs(len(part) - len(r1)) <= 2
+        q = min(len(part), len(r1)) - 3
+        assert np.array_equal(part["start"][:q], r1["start"][:q] + np.uint64(b * m)) and np.array_equal(part["length"][:q], r1["length"][:q])
+        remap = lambda ids: [i + b * n1 if i < n1 else i - n1 + 3 * n1 + b * n1 for i in ids]
+        for a, c in zip(k1, k3[b * len(k1):(b + 1) * len(k1)]):
+            assert c["right_pos"] == a["right_pos"] and c["pos0"] == a["pos0"] and c["pos1"] == a["pos1"]
+            assert c["right_idx"] == remap([a["right_idx"]])[0] and c["idx0"] == remap(a["idx0"]) and c["idx1"] == remap(a["idx1"])
