@@ -745,18 +745,21 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
     CK(hipSetDevice(h->device));
     int rc = ensure_records(h, n_records + 8);
     if (rc) return rc;
-    std::vector<uint64_t> s(n_records);
-    std::vector<uint16_t> l(n_records);
-    const uint8_t* p = (const uint8_t*)recs;
-    uint64_t prev_end = 0;
-    for (uint64_t i = 0; i < n_records; ++i) {
-        memcpy(&s[i], p + i * 10, 8); memcpy(&l[i], p + i * 10 + 8, 2);
-        if (i && s[i] < prev_end) return fail(h, E2S_ERR_INPUT, ".clusters records must be ascending and non-overlapping (H16)");
-        prev_end = s[i] + l[i];
-    }
     if (n_records) {
-        CK(hipMemcpy(h->d_starts, s.data(), n_records * 8, hipMemcpyHostToDevice));
-        CK(hipMemcpy(h->d_lens, l.data(), n_records * 2, hipMemcpyHostToDevice));
+        // the file image goes up as it is; unpacking and the ordering check (H16) run on the GPU
+        void* stage = nullptr;
+        CK(hipMalloc(&stage, n_records * 10 + 16));
+        hipError_t e1 = hipMemcpyAsync(stage, recs, n_records * 10, hipMemcpyHostToDevice, h->stream);
+        if (e1 == hipSuccess) e1 = hipMemsetAsync(h->d_words + 1, 0, 4, h->stream);
+        if (e1 == hipSuccess) {
+            e2s_launch_unpack_clusters((const uint8_t*)stage, n_records, (unsigned long long*)h->d_starts, h->d_lens, h->d_words + 1, h->stream);
+            uint32_t* mb = (uint32_t*)(h->pin_mail + 3072);
+            e1 = hipMemcpyAsync(mb, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream);
+            if (e1 == hipSuccess) e1 = hipStreamSynchronize(h->stream);
+            if (e1 == hipSuccess && (*mb & 1u)) { hipFree(stage); return fail(h, E2S_ERR_INPUT, ".clusters records must be ascending and non-overlapping (H16)"); }
+        }
+        hipFree(stage);
+        CK(e1);
     }
     h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;
     h->min_len = 0; h->segmented = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};

@@ -151,6 +151,7 @@ void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsi
                         const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* hist_zero,
                         hipStream_t st);
 void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, unsigned long long* out_starts, uint16_t* out_lens, hipStream_t st);
+void e2s_launch_unpack_clusters(const uint8_t* packed, unsigned long long n, unsigned long long* starts, uint16_t* lens, uint32_t* err, hipStream_t st);
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out,
                          unsigned long long* out_last, hipStream_t st);
 void e2s_launch_scan_mail(const ScanArgs& a, const uint32_t* words, const uint8_t* bwt, const void* pos, const void* da,

@@ -851,25 +851,58 @@ __global__ void k_hist_tail(const uint16_t* lens, u64 n, int min_len, u64* out_l
 // KH: histogram of cluster lengths (statistics(), clust2snp.cpp:889-909; H4 applied on the host)
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hist(const uint16_t* lens, u64 n, int min_len, u64* out /*151 freq, n_rec, n_bases*/) {
-    __shared__ u32 s_freq[E2S_MAX_CLUST_LEN_K + 1];
+    // 4 histogram replicas per wave (lengths concentrate on a few values: one copy serialises on the hot bins -- 21 ms for
+    // 3x10^6 records), 8 lengths per lane and load
+    constexpr int REP = 4, NB = E2S_MAX_CLUST_LEN_K + 1, NWV = 4;
+    __shared__ u32 s_freq[NWV * REP][NB + 1];
     __shared__ u64 s_acc[2];
-    for (int i = threadIdx.x; i <= E2S_MAX_CLUST_LEN_K; i += blockDim.x) s_freq[i] = 0;
+    for (int i = threadIdx.x; i < NWV * REP * (NB + 1); i += 256) (&s_freq[0][0])[i] = 0;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
     __syncthreads();
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32* const my = s_freq[wave * REP + (lane & (REP - 1))];
     u64 nrec = 0, nb = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const int l = lens[i];
-        if (l >= min_len) {                                   // append_entry's filter, ebwt2clust.cpp:56
-            nrec++; nb += (u64)l;
-            if (l <= E2S_MAX_CLUST_LEN_K) atomicAdd(&s_freq[l], 1u);
-        }
+    auto take = [&](u32 l) { if ((int)l >= min_len) { nrec++; nb += (u64)l; if (l <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&my[l], 1u); } };
+    const u64 nv = n >> 3;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nv; i += (u64)gridDim.x * 256) {
+        const uint4 v = *(const uint4*)(lens + 8 * i);
+        take(v.x & 0xFFFFu); take(v.x >> 16); take(v.y & 0xFFFFu); take(v.y >> 16);
+        take(v.z & 0xFFFFu); take(v.z >> 16); take(v.w & 0xFFFFu); take(v.w >> 16);
     }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7ull)) take((u32)lens[(nv << 3) + threadIdx.x]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { nrec += __shfl_xor(nrec, o); nb += __shfl_xor(nb, o); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd((u64*)&s_acc[0], nrec); atomicAdd((u64*)&s_acc[1], nb); }
+    if (lane == 0) { atomicAdd((u64*)&s_acc[0], nrec); atomicAdd((u64*)&s_acc[1], nb); }
     __syncthreads();
-    for (int i = threadIdx.x; i <= E2S_MAX_CLUST_LEN_K; i += blockDim.x) if (s_freq[i]) atomicAdd(&out[i], (u64)s_freq[i]);
-    if (threadIdx.x == 0) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
+    for (int i = threadIdx.x; i < NB; i += 256) {
+        u32 v = 0;
+#pragma unroll
+        for (int r = 0; r < NWV * REP; ++r) v += s_freq[r][i];
+        if (v) atomicAdd(&out[i], (u64)v);
+    }
+    if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
+}
+
+// .clusters file -> record arrays: packed {u64 start; u16 length} records as they are on disk; also checks that they are ascending
+// and non-overlapping (H16) -- err gets bit 0 otherwise
+__global__ void k_unpack_clusters(const uint8_t* packed, u64 n, u64* starts, uint16_t* lens, u32* err) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto rd = [&](u64 r, u64& st, u32& ln) {
+        const uint8_t* p = packed + r * 10;
+        u64 v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v |= (u64)p[b] << (8 * b);
+        st = v; ln = (u32)p[8] | ((u32)p[9] << 8);
+    };
+    u64 st; u32 ln;
+    rd(i, st, ln);
+    starts[i] = st; lens[i] = (uint16_t)ln;
+    if (i) { u64 ps; u32 pl; rd(i - 1, ps, pl); if (st < ps + pl) atomicOr(err, 1u); }
+}
+void e2s_launch_unpack_clusters(const uint8_t* packed, u64 n, u64* starts, uint16_t* lens, u32* err, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_unpack_clusters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed, n, starts, lens, err);
 }
 
 // the same over the segmented record storage of scan_mode 0.  A segment holds only ~10^3 lengths, so a wave takes

@@ -81,6 +81,7 @@ int main(int argc, char** argv) {
     (void)max_snvs;
     if (input.compare("") == 0 || nr_reads1 == 0) help();
 
+    PhaseClock pc;
     EgsaFiles F;
     F.open_or_die(input, lcp, da, pos);
     std::cout << "This is clust2snp." << std::endl
@@ -99,14 +100,18 @@ int main(int argc, char** argv) {
     filename_out.append(".snp");
     std::cout << "Output events will be stored in " << filename_out << std::endl;
 
+    pc.mark("open files");
     e2s_handle h = nullptr;
     int rc = e2s_create(0, &h);
+    pc.mark("e2s_create (HIP start-up)");
     if (rc) { std::cerr << "GPU unavailable: " << e2s_last_error(nullptr) << std::endl; return 2; }
     e2s_shard_desc d{};
     d.n_entries = F.n; d.n_total = F.n; d.lcp_bytes = lcp; d.da_bytes = da; d.pos_bytes = pos;
     if (F.gesa) die_on(e2s_upload_gesa(h, &d, F.aos.p), h, "upload (.gesa)");
     else die_on(e2s_upload_bcr(h, &d, F.bwt.p, F.lcp.p, F.pairsa.p), h, "upload (BCR)");
+    pc.mark("upload EGSA");
     die_on(e2s_load_clusters(h, CL.p, CL.n / 10), h, "load .clusters");
+    pc.mark("load .clusters");
 
     // statistics(), clust2snp.cpp:877-966
     e2s_hist hs;
@@ -143,8 +148,10 @@ int main(int argc, char** argv) {
     e2s_c2s_params prm{};
     prm.nr_reads1 = nr_reads1; prm.k_left = k_left; prm.k_right = k_right; prm.mcov_out = mcov_out;
     prm.consensus_reads = consensus_reads; prm.max_clust_length = max_clust_length; prm.min_len = 0;
+    pc.mark("statistics");
     uint64_t n_cand = 0;
     die_on(e2s_find_candidates(h, &prm, 0, &n_cand), h, "find candidates");
+    pc.mark("find candidates");
     std::cout << " 100% done." << std::endl;
     std::cout << "Done. " << n_cand << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
     // the candidates arrive packed and in SA order in the handle's pinned buffer; the tail reads them in place
@@ -157,7 +164,9 @@ int main(int argc, char** argv) {
     e2s_tail_params tp{k_left, k_right, max_gap, max_err};
     uint64_t nv = 0, ne = 0;
     rc = e2s_snp_from_packed(cstream, coff, n_cand, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
+    pc.mark("host tail + .snp");
     e2s_destroy(h);
+    pc.mark("e2s_destroy");
     if (rc == E2S_ERR_REF_CRASH) {
         std::cerr << "no candidate variant: the reference crashes here (SIGSEGV, clust2snp.cpp:531); no .snp written" << std::endl;
         return 139;

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <iostream>
 #include <string>
 
@@ -51,6 +52,19 @@ struct EgsaFiles {
         }
         std::cout << "Error: missing index files." << std::endl;
         exit(1);
+    }
+};
+
+// E2S_CLI_TIMING=1: wall time of the executable's phases on stderr
+struct PhaseClock {
+    bool on = getenv("E2S_CLI_TIMING") != nullptr;
+    double t0 = now();
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    void mark(const char* what) {
+        if (!on) return;
+        const double t = now();
+        std::cerr << "[timing] " << what << " " << (t - t0) << " ms" << std::endl;
+        t0 = t;
     }
 };
 

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <ctime>
+#include <cstdlib>
 
 #include "../../include/e2s_hip.h"
 
@@ -130,6 +132,14 @@ void distance(const std::string& a, const std::string& b, int max_gap, int& D, i
 
 struct Variant { std::string left0, left1, right; int s0, s1; };
 
+// E2S_CLI_TIMING=1: phase times of the tail on stderr
+struct TailClock {
+    bool on = getenv("E2S_CLI_TIMING") != nullptr;
+    double t0 = now();
+    static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    void mark(const char* what) { if (!on) return; const double t = now(); fprintf(stderr, "[timing]   tail: %s %.2f ms\n", what, t - t0); t0 = t; }
+};
+
 }  // namespace
 
 // one candidate, wherever it is stored
@@ -153,20 +163,25 @@ static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_
         for (uint32_t t = 0; t < v.h->n1; ++t) ranks.push_back(v.idx1[t]);
         ranks.push_back(v.h->right_idx);
     }
+    TailClock tc;
     std::sort(ranks.begin(), ranks.end());
     ranks.erase(std::unique(ranks.begin(), ranks.end()), ranks.end());
     if (ranks.size() == 1) return E2S_ERR_REF_CRASH;       // (i*100)/(size-1), clust2snp.cpp:200
     std::vector<std::string> reads;
+    tc.mark("read ranks sorted");
     if (!fetch_reads(fasta_path, ranks, reads)) return E2S_ERR_IO;
+    tc.mark("reads fetched from the FASTA");
     auto read_of = [&](uint32_t rank) -> const std::string& {
         return reads[(size_t)(std::lower_bound(ranks.begin(), ranks.end(), (uint64_t)rank) - ranks.begin())];
     };
-    auto at = [](const std::string& s, uint64_t i) -> unsigned char { return i < s.size() ? (unsigned char)s[i] : 0; };
 
     const int kl = p->k_left;
     if (kl < 0) return E2S_ERR_REF_CRASH;                  // cons(size_t(-n)) throws in the reference
     std::vector<Variant> vars;
     std::vector<int> cnt((size_t)kl * 4);
+    std::vector<unsigned char> ctx;
+    unsigned char b2i[256];
+    for (int ch = 0; ch < 256; ++ch) b2i[ch] = (unsigned char)base_to_int((unsigned char)ch);
     for (uint64_t c = 0; c < n_cand; ++c) {
         const CandView cv = get(c);
         const e2s_cand_header* h = cv.h;
@@ -180,18 +195,28 @@ static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_
             std::string& C = cons[s];
             C.assign((size_t)kl, 'A');
             std::fill(cnt.begin(), cnt.end(), 0);
+            // the left contexts of the allele, fetched once: ctx[j][i] = at(read_j, pos_j + i) (0 past the read's end)
+            ctx.resize((size_t)n * (size_t)kl);
             for (uint32_t j = 0; j < n; ++j) {
                 const std::string& r = read_of(idx[j]);
+                unsigned char* row = ctx.data() + (size_t)j * (size_t)kl;
+                const uint64_t p0 = pos[j], len = r.size();
+                const uint64_t have = p0 < len ? std::min<uint64_t>(len - p0, (uint64_t)kl) : 0;
+                memcpy(row, r.data() + (have ? p0 : 0), (size_t)have);
+                memset(row + have, 0, (size_t)kl - (size_t)have);
+            }
+            for (uint32_t j = 0; j < n; ++j) {
+                const unsigned char* row = ctx.data() + (size_t)j * (size_t)kl;
                 for (int i = 0; i < kl; ++i) {
-                    const unsigned char ch = at(r, (uint64_t)pos[j] + (uint64_t)i);
-                    const int b = base_to_int(ch);
-                    if (++cnt[(size_t)i * 4 + b] > cnt[(size_t)i * 4 + base_to_int((unsigned char)C[i])]) C[i] = (char)ch;
+                    const unsigned char ch = row[i];
+                    const int b = b2i[ch];
+                    if (++cnt[(size_t)i * 4 + b] > cnt[(size_t)i * 4 + b2i[(unsigned char)C[i]]]) C[i] = (char)ch;
                 }
             }
             for (uint32_t j = 0; j < n; ++j) {             // support = contexts within max_err of the consensus
-                const std::string& r = read_of(idx[j]);
+                const unsigned char* row = ctx.data() + (size_t)j * (size_t)kl;
                 int d = 0;
-                for (int i = 0; i < kl; ++i) d += (unsigned char)C[i] != at(r, (uint64_t)pos[j] + (uint64_t)i);
+                for (int i = 0; i < kl; ++i) d += (unsigned char)C[i] != row[i];
                 if (d <= p->max_err) supp[s]++;
             }
         }
@@ -207,6 +232,7 @@ static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_
     }
     if (n_variants) *n_variants = vars.size();
 
+    tc.mark("consensus");
     // to_file, clust2snp.cpp:633-780
     FILE* out = fopen(out_path, "w");
     if (!out) return E2S_ERR_IO;
@@ -234,6 +260,7 @@ static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_
         ++id;
     }
     fclose(out);
+    tc.mark("distance + text");
     if (n_events) *n_events = id - 1;
     return E2S_OK;
 }
