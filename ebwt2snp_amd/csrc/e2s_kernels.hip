@@ -373,15 +373,16 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     u32 state = 0;                                              // last event of the range so far: 0 none, 1 an end, 2 a start
     u32 in0 = 0, unknown = 0;
     u64 first_end = ~0ull;
-    // GE / end of the entry just before the range (bit 0 / bit 1): what lane 0 of the first tile inherits
-    u32 cb;
-    {
+    // GE / end of the entry just before the range (bit 0 / bit 1): what lane 0 of the first tile inherits.  Evaluated
+    // after the first tile's loads have been issued, so that a worker pays one memory latency at its start, not two.
+    u32 cb = 0;
+    auto range_carry = [&]() -> u32 {
         const int64_t r0 = (int64_t)t0 * TILE;
         const u32 lm2 = entry_at(r0 - 2), lm1 = entry_at(r0 - 1), l0 = entry_at(r0);
         const bool gm1 = a.hge != 0 && lm1 >= a.k_u32, g0 = a.hge != 0 && l0 >= a.k_u32;
         const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
-        cb = (u32)__builtin_amdgcn_readfirstlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)));
-    }
+        return (u32)__builtin_amdgcn_readfirstlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)));
+    };
     // Two register sets that swap roles from tile to tile (the loop body is instantiated twice): W = the tile
     // being processed, Wn = the next one, in flight meanwhile.
     u32 WA[NW], WB[NW];
@@ -556,13 +557,17 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         const u64 tfe = n_prov >= (int64_t)(TILE + EPW) ? (u64)((n_prov - EPW) / TILE) : 0ull;
         const u64 tf = min(t1, tfe);
         auto slow_run = [&](u64 upto) { for (; tile < upto; ++tile) { load_slow(tile, WA); body(tile, WA, WB, P0); } };
+        bool have_cb = false;
+        if (tile < min(t1, (u64)1)) { cb = range_carry(); have_cb = true; }
         slow_run(min(t1, (u64)1));
         if (tile < tf) {
             load_fast(tile, WA);
+            if (!have_cb) { cb = range_carry(); have_cb = true; }
             while (tile + 3 <= tf) { body(tile, WA, WB, P1); body(tile + 1, WB, WA, P1); tile += 2; }
             if (tile + 2 == tf) { body(tile, WA, WB, P1); body(tile + 1, WB, WA, P0); tile += 2; }
             else { body(tile, WA, WB, P0); tile += 1; }
         }
+        if (!have_cb) cb = range_carry();
         slow_run(t1);
     }
     // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
@@ -1377,15 +1382,15 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     u32 cin0 = 0;                                               // carry into lane 0 of the next tile: counts | flags << 24
     u32 ccarry = 0;                                             // class code of the entry before the tile (2 bits)
     u32 qn = 0;                                                 // queued flagged clusters (wave-uniform)
-    u32 cb;                                                     // GE / end of the entry before the first tile
-    {
+    u32 cb = 0;                                                 // GE / end of the entry before the first tile
+    auto range_carry = [&]() -> u32 {                           // (evaluated after the first tile's loads have been issued)
         const int64_t r0 = (int64_t)torg * TILE;
         const u32 lm2 = entry_at(r0 - 2), lm1 = entry_at(r0 - 1), l0 = entry_at(r0);
         const bool gm1 = a.hge != 0 && lm1 >= a.k_u32, g0 = a.hge != 0 && l0 >= a.k_u32;
         const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
-        cb = (u32)__builtin_amdgcn_readfirstlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)));
+        return (u32)__builtin_amdgcn_readfirstlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)));
         // (the class of the entry before the first tile only matters for a cluster that is rejected for its length)
-    }
+    };
     auto queue_flush = [&]() {
         if (qn) {
             u64 gbase = 0;
@@ -1514,19 +1519,24 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
         const u64 tfe = n_prov >= (int64_t)(TILE + 4) ? (u64)((n_prov - 4) / TILE) : 0ull;   // interior tiles are [1, tfe)
         const u64 tf = min(t1, tfe);
         // the warm-up tile (evaluates nothing), then tile 0 of the shard if it is ours: byte-wise loads
+        bool have_cb = false;
         if (tile < t0) {
             if (tile >= 1 && tile < tfe) load_fast(tile, WA, BA); else load_slow(tile, WA, BA);
+            cb = range_carry(); have_cb = true;
             body(tile, WA, BA, WB, BB, N, Y);
             ++tile;
         }
         auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, N, N); } };
+        if (!have_cb && tile < min(t1, (u64)1)) { cb = range_carry(); have_cb = true; }
         slow_run(min(t1, (u64)1));
         if (tile < tf) {
             load_fast(tile, WA, BA);
+            if (!have_cb) { cb = range_carry(); have_cb = true; }
             while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, Y, N); body(tile + 1, WB, BB, WA, BA, Y, N); tile += 2; }
             if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, Y, N); body(tile + 1, WB, BB, WA, BA, N, N); tile += 2; }
             else { body(tile, WA, BA, WB, BB, N, N); tile += 1; }
         }
+        if (!have_cb) cb = range_carry();
         slow_run(t1);
     }
     queue_flush();
