@@ -139,6 +139,7 @@ def _exchange(blob, world, dist, dev):
 def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None):
     t = time.perf_counter()
     h.cluster_scan(k, min_len, 0)                                  # scan + statistics of the shard's own records
+    h.prefilter_begin(prm_base["m"], min_len)                      # runs beside the exchange and the statistics below
     t = _tick("scan", t)
     b = h.boundary()
     if world > 1:

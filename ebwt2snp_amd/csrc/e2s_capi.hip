@@ -55,6 +55,7 @@ struct e2s_ctx {
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
+    bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
     hipEvent_t ev_wait = nullptr;
     hipEvent_t ev_chunk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
@@ -921,6 +922,63 @@ static int ensure_flagged(e2s_ctx* h, uint64_t cap) {
     return E2S_OK;
 }
 
+constexpr uint64_t E2S_SEED_SLOTS = 64;       // head of the flagged list reserved for the records the stencil cannot see
+
+static void filter_args(e2s_ctx* h, int mcov_out, int len_lo, int len_hi, FilterArgs& f) {
+    const e2s_shard_desc& d = h->d;
+    f = FilterArgs{};
+    f.bwt = h->bwt; f.lcp = (const uint8_t*)h->lcp; f.da = (const uint32_t*)h->da;
+    f.n_prov = h->n_prov; f.prov_lo = h->prov_lo; f.prov_is_global0 = h->prov_lo == 0;
+    f.own_lo = d.halo_left;
+    const uint64_t own_hi = (uint64_t)d.halo_left + d.n_entries;
+    const uint64_t last_end_global = d.n_total - 1;
+    f.end_hi = std::min<uint64_t>(own_hi, last_end_global > h->prov_lo ? last_end_global - h->prov_lo : 0);
+    if (f.end_hi < f.own_lo) f.end_hi = f.own_lo;
+    f.k_u32 = (uint32_t)h->k;
+    f.hge = ((uint64_t)f.k_u32 > 0xFFull) ? 0u : 0x80808080u;
+    f.kb = (f.k_u32 & 0xFF) * 0x01010101u;
+    f.mcov_u = (uint32_t)mcov_out; f.len_lo = len_lo; f.len_hi = len_hi;
+    f.n_tiles = (h->n_prov + 3935) / 3936;
+    f.err = h->d_words + 1;
+    f.fl_starts = h->d_fl_starts; f.fl_lens = h->d_fl_lens; f.fl_cap = h->fl_cap;
+    f.fl_count = (unsigned long long*)(h->d_scalars + 2);
+}
+
+static int c2s_len_lo(int mcov_out, int min_len) {   // `length >= mcov_out*2` (int compares), plus append_entry's filter
+    return (int)std::max<long long>(std::max<long long>(2LL * mcov_out, (long long)min_len), -1LL);
+}
+
+/* The pre-filter of the per-cluster pass depends on -m (mcov_out) and the scan only: it can run while the ranks
+ * exchange their descriptors and the host works out max_clust_length (it keeps clusters up to the absolute
+ * maximum length; e2s_find_candidates applies the exact bound).  Optional: without it e2s_find_candidates runs the
+ * pre-filter itself. */
+extern "C" int e2s_prefilter_begin(e2s_handle h, int mcov_out, int min_len) {
+    dbg_entry("e2s_prefilter_begin");
+    if (!h) return E2S_ERR_ARG;
+    h->pf_inflight = false;
+    if (!h->scanned) return fail(h, E2S_ERR_STATE, "e2s_cluster_scan has not run");
+    const e2s_shard_desc& d = h->d;
+    const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt) & 15u) == 0;
+    static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;
+    if (h->records_from_file || !h->segmented || d.lcp_bytes != 1 || !aligned || !h->bwt || filter_v1) return E2S_OK;   // nothing to start early
+    CK(hipSetDevice(h->device));
+    int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_ends / 8 + 4096 + E2S_SEED_SLOTS));
+    if (rc) return rc;
+    uint64_t* mc = (uint64_t*)(h->pin_mail + 2048 + 64 * 8 + 64 * 2);
+    *mc = E2S_SEED_SLOTS;                                       // the list starts behind the reserved slots
+    CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemsetAsync(h->d_fl_lens, 0, E2S_SEED_SLOTS * 2, h->stream));      // length 0 = empty slot
+    CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
+    FilterArgs f;
+    filter_args(h, mcov_out, c2s_len_lo(mcov_out, min_len), (int)E2S_MAX_CLUST_LEN, f);
+    CK(hipEventRecord(h->ev[6], h->stream));
+    e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, h->stream);
+    LCHK("e2s_launch_cluster_filter");
+    CK(hipEventRecord(h->ev[4], h->stream));
+    h->pf_inflight = true; h->pf_mcov = mcov_out; h->pf_len_lo = f.len_lo;
+    return E2S_OK;
+}
+
 extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand) {
     dbg_entry("e2s_find_candidates");
     if (!h || !p) return E2S_ERR_ARG;
@@ -947,8 +1005,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     a.k_left_u = (uint64_t)(int64_t)p->k_left; a.k_right_u = (uint64_t)(int64_t)p->k_right;   // uint64_t vs int compares
     a.k_left_lo = (uint32_t)p->k_left; a.mcov_u = (uint32_t)p->mcov_out;
     // `length >= mcov_out*2 and length <= max_clust_length` (int compares), plus append_entry's filter
-    const long long lo2 = 2LL * p->mcov_out;
-    a.len_lo = (int)std::max<long long>(std::max<long long>(lo2, (long long)p->min_len), -1LL);
+    a.len_lo = c2s_len_lo(p->mcov_out, p->min_len);
     a.len_hi = std::min(p->max_clust_length, (int)E2S_MAX_CLUST_LEN);
     a.list_cap = list_cap_of(p);
     a.stride = (uint32_t)(sizeof(e2s_cand_header) + (size_t)4 * a.list_cap * sizeof(uint32_t));
@@ -978,8 +1035,11 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             h->keys_cap = h->cand_cap;
         }
         a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap; a.cand_keys = (unsigned long long*)h->d_keys;
+        // a pre-filter launched ahead (e2s_prefilter_begin) with the same -m stands in for the first attempt's own
+        const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
+        h->pf_inflight = false;
         CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
-        CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
+        if (!use_pf) CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));      // (the early pre-filter may have set error bits)
         if (streaming) {
             // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
             std::vector<uint64_t> ss; std::vector<uint16_t> sl;
@@ -993,39 +1053,28 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 seed(st, ln);
             }
             const uint64_t nseed = ss.size();
-            int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096 + nseed));
-            if (rc) return rc;
-            if (nseed > 64) return fail(h, E2S_ERR_INPUT, "too many clusters with wrapped length");
-            {   // seeds travel through the pinned mailbox (asynchronous copies)
+            if (nseed > E2S_SEED_SLOTS) return fail(h, E2S_ERR_INPUT, "too many clusters with wrapped length");
+            if (!use_pf) {
+                int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096 + E2S_SEED_SLOTS));
+                if (rc) return rc;
+            }
+            {   // seeds travel through the pinned mailbox (asynchronous copies) into the reserved head of the list
                 uint64_t* ms = (uint64_t*)(h->pin_mail + 2048); uint16_t* ml = (uint16_t*)(h->pin_mail + 2048 + 64 * 8);
                 uint64_t* mc = (uint64_t*)(h->pin_mail + 2048 + 64 * 8 + 64 * 2);
-                for (uint64_t t = 0; t < nseed; ++t) { ms[t] = ss[t]; ml[t] = sl[t]; }
-                *mc = nseed;
-                if (nseed) {
-                    CK(hipMemcpyAsync(h->d_fl_starts, ms, nseed * 8, hipMemcpyHostToDevice, h->stream));
-                    CK(hipMemcpyAsync(h->d_fl_lens, ml, nseed * 2, hipMemcpyHostToDevice, h->stream));
+                for (uint64_t t = 0; t < E2S_SEED_SLOTS; ++t) { ms[t] = t < nseed ? ss[t] : 0; ml[t] = t < nseed ? sl[t] : 0; }   // length 0 = empty
+                CK(hipMemcpyAsync(h->d_fl_starts, ms, E2S_SEED_SLOTS * 8, hipMemcpyHostToDevice, h->stream));
+                CK(hipMemcpyAsync(h->d_fl_lens, ml, E2S_SEED_SLOTS * 2, hipMemcpyHostToDevice, h->stream));
+                if (!use_pf) {
+                    *mc = E2S_SEED_SLOTS;
+                    CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, h->stream));
                 }
-                CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, h->stream));
             }
-            FilterArgs f{};
-            f.bwt = h->bwt; f.lcp = (const uint8_t*)h->lcp; f.da = (const uint32_t*)h->da;
-            f.n_prov = h->n_prov; f.prov_lo = h->prov_lo; f.prov_is_global0 = h->prov_lo == 0;
-            f.own_lo = d.halo_left;
-            const uint64_t own_hi = (uint64_t)d.halo_left + d.n_entries;
-            const uint64_t last_end_global = d.n_total - 1;
-            f.end_hi = std::min<uint64_t>(own_hi, last_end_global > h->prov_lo ? last_end_global - h->prov_lo : 0);
-            if (f.end_hi < f.own_lo) f.end_hi = f.own_lo;
-            f.k_u32 = (uint32_t)h->k;
-            f.hge = ((uint64_t)f.k_u32 > 0xFFull) ? 0u : 0x80808080u;
-            f.kb = (f.k_u32 & 0xFF) * 0x01010101u;
-            f.kr_hge = (a.k_right_u > 0xFFull) ? 0u : 0x80808080u;
+            FilterArgs f;
+            filter_args(h, p->mcov_out, a.len_lo, a.len_hi, f);
+            f.kr_hge = (a.k_right_u > 0xFFull) ? 0u : 0x80808080u;                 // (first formulation only)
             f.krb = (uint32_t)(a.k_right_u & 0xFF) * 0x01010101u;
-            f.nr_reads1 = a.nr_reads1; f.mcov_u = a.mcov_u; f.len_lo = a.len_lo; f.len_hi = a.len_hi;
-            f.n_tiles = (h->n_prov + 3935) / 3936;
-            f.err = h->d_words + 1;
-            f.fl_starts = h->d_fl_starts; f.fl_lens = h->d_fl_lens; f.fl_cap = h->fl_cap;
-            f.fl_count = (unsigned long long*)(h->d_scalars + 2);
-            CK(hipEventRecord(h->ev[6], h->stream));
+            f.nr_reads1 = a.nr_reads1;
+            if (!use_pf) CK(hipEventRecord(h->ev[6], h->stream));
             a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
             {   // packed mode: K2b writes the candidates into the pinned host buffer itself
                 const size_t rec_bytes = (size_t)h->cand_cap * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
@@ -1058,7 +1107,10 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             static const long min_tiles = getenv("E2S_FILTER_CHUNK_MIN_TILES") ? atol(getenv("E2S_FILTER_CHUNK_MIN_TILES")) : 4096;
             if ((long)w_tiles < min_tiles || w_tiles < (uint64_t)chunks) chunks = 1;   // too little work per chunk to hide a launch
             const unsigned long long* fl_count = (const unsigned long long*)(h->d_scalars + 2);
-            if (chunks == 1) {
+            if (use_pf) {                                            // the pre-filter is already on the stream
+                e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
+                LCHK("e2s_launch_flagged_lists");
+            } else if (chunks == 1) {
                 if (filter_v1) e2s_launch_cluster_filter(f, h->stream); else e2s_launch_cluster_filter2(f, 0, w_tiles, h->stream);
                 LCHK("e2s_launch_cluster_filter");
                 CK(hipEventRecord(h->ev[4], h->stream));

@@ -1636,6 +1636,10 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
         if (r < n) {
             const u64 s = a.starts[r];
             const int len = (int)a.lens[r];
+            // length 0 = an unused reserved slot; the exact length bounds (the pre-filter may have run with the absolute maximum,
+            // before max_clust_length was known)
+            if (len == 0 || len < a.len_lo || len > a.len_hi) {
+            } else
             // entries must be resident (index n_total being the EOF phantom): a record from a broken list must not fault
             if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull) || len < 1 || len > 3 * 64) {
                 if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);

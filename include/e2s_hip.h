@@ -195,6 +195,11 @@ typedef struct {
     uint32_t right_idx, right_pos;
     uint32_t reserved;
 } e2s_cand_header;
+/* Optional: start the pre-filter of the per-cluster pass right after e2s_cluster_scan.  It needs only -m (mcov_out) and
+ * ebwt2clust's -m (min_len), so it runs while the ranks exchange descriptors and the host derives max_clust_length;
+ * e2s_find_candidates with the same values picks its result up (and applies the exact length bound), otherwise it
+ * runs the pre-filter itself.  No-op (E2S_OK) where the streaming pass does not apply. */
+int e2s_prefilter_begin(e2s_handle h, int mcov_out, int min_len);
 /* out layout: n_cand blocks of [e2s_cand_header][u32 idx0[cap]][u32 pos0[cap]][u32 idx1[cap]][u32 pos1[cap]] */
 int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand);
 int e2s_candidate_stride(e2s_handle h, const e2s_c2s_params* p, uint32_t* list_cap, size_t* stride_bytes);

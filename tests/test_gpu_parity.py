@@ -299,8 +299,9 @@ def test_drop_in_executables(tmp_path):
     assert r.returncode == 1 and "Error: missing index files." in r.stdout
 
 
-def _fused_candidates(h, en, n1, k=16, m=2, mcov=5, L=31, R=30, c=20, p=0.99, xyz=(1, 4, 1)):
-    """scan -> stitch -> hist -> candidates on one handle (records stay on the device: streaming pass)"""
+def _fused_candidates(h, en, n1, k=16, m=2, mcov=5, L=31, R=30, c=20, p=0.99, xyz=(1, 4, 1), early=False):
+    """scan -> stitch -> hist -> candidates on one handle (records stay on the device: streaming pass);
+    early: the pre-filter is started right after the scan (e2s_prefilter_begin), before stitch and statistics"""
     x, y, z = xyz
     n = en["lcp"].size
     d = capi.Handle.desc(n, x=x, y=y, z=z)
@@ -308,7 +309,10 @@ def _fused_candidates(h, en, n1, k=16, m=2, mcov=5, L=31, R=30, c=20, p=0.99, xy
     psa["s"] = en["suff"]
     psa["t"] = en["text"]
     h.upload_bcr(d, en["bwt"], en["lcp"].astype(IO._DT[x]).view(np.uint8), psa.view(np.uint8))
-    h.scan_single(k, m, 0)
+    h.cluster_scan(k, m, 0)
+    if early:
+        h.prefilter_begin(mcov, m)
+    h.stitch([h.boundary()], 0)
     mcl, _, _ = capi.auto_max_clust_length([h.hist()], mcov, p)
     prm = capi.C2SParams(n1 & ((1 << 64) - 1), L, R, mcov, c, mcl, m)
     h.find_candidates(prm)
@@ -403,7 +407,7 @@ def test_fused_streaming_adversarial(H, tmp_path):
     en = dict(text=text, suff=suff, lcp=lcp, bwt=bwt)
     reads = np.full((2000, 100), 65, dtype=np.uint8)
     oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000)
-    got, mcl = _fused_candidates(H, en, 1000)
+    got, mcl = _fused_candidates(H, en, 1000, early=True)
     assert mcl == omcl and len(oc) > 150
     assert len(got) == len(oc)
     for a, b in zip(got, oc):
@@ -463,12 +467,13 @@ def test_fused_streaming_fuzz_columns(H, tmp_path, seed):
     mcov = int(rnd.choice([3, 5]))
     Rc = int(rnd.choice([25, 30, 45]))
     oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000, mcov=mcov, R=Rc, tag="fz%d" % seed)
-    got, mcl = _fused_candidates(H, en, 1000, mcov=mcov, R=Rc)
-    assert mcl == omcl and len(oc) > 50
-    assert len(got) == len(oc)
-    for a, b in zip(got, oc):
-        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
-            assert a[key] == b[key]
+    for early in (False, True):                                  # pre-filter inside find_candidates / started ahead of the statistics
+        got, mcl = _fused_candidates(H, en, 1000, mcov=mcov, R=Rc, early=early)
+        assert mcl == omcl and len(oc) > 50
+        assert len(got) == len(oc)
+        for a, b in zip(got, oc):
+            for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+                assert a[key] == b[key]
 
 
 @pytest.mark.gpu
