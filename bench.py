@@ -163,7 +163,7 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None)
     prm = capi.C2SParams(prm_base["n1"], 31, 30, prm_base["m"], 20, mcl, min_len)
     ncand = h.find_candidates(prm, rank << 40)
     t = _tick("candidates", t)
-    stream, off8, ncand = h.candidates_packed()                  # pinned host memory, packed, SA order (what the host tail consumes)
+    stream, off8, ncand, _pw = h.candidates_packed()                  # pinned host memory, packed, SA order (what the host tail consumes)
     t = _tick("view", t)
     return dict(n_ends=b.n_ends, n_cand=ncand, mcl=mcl, n_clust=n_clust)
 

@@ -122,8 +122,9 @@ def lib():
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
     L.e2s_snp_from_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p,
                                           C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.e2s_candidates_packed.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.e2s_snp_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(TailParams), C.c_char_p, C.c_char_p,
+    L.e2s_candidates_packed.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint32)]
+    L.e2s_snp_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p, C.c_char_p,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_last_timing.argtypes = [H, C.POINTER(Timing)]
     L.e2s_stream.argtypes = [H, C.POINTER(C.c_void_p)]
@@ -266,15 +267,16 @@ class Handle:
         return r, o, n.value, cap.value, stride.value
 
     def candidates_packed(self):
-        """zero-copy: (packed stream uint8 view into the handle's pinned buffer, offsets8 uint32 view with n + 1 entries, n)"""
+        """zero-copy: (packed stream uint8 view into the handle's pinned buffer, offsets8 uint32 view with n + 1 entries, n,
+        bytes per position in the stream)"""
         st, off = C.c_void_p(), C.c_void_p()
-        n, nbytes = C.c_uint64(0), C.c_uint64(0)
-        self._ck(self.L.e2s_candidates_packed(self.h, C.byref(st), C.byref(off), C.byref(n), C.byref(nbytes)))
+        n, nbytes, pw = C.c_uint64(0), C.c_uint64(0), C.c_uint32(4)
+        self._ck(self.L.e2s_candidates_packed(self.h, C.byref(st), C.byref(off), C.byref(n), C.byref(nbytes), C.byref(pw)))
         if not n.value:
-            return np.zeros(0, np.uint8), np.zeros(1, np.uint32), 0
+            return np.zeros(0, np.uint8), np.zeros(1, np.uint32), 0, pw.value
         r = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint8)), shape=(nbytes.value,))
         o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint32)), shape=(n.value + 1,))
-        return r, o, n.value
+        return r, o, n.value, pw.value
 
     def timing(self):
         t = Timing()
@@ -346,10 +348,10 @@ def snp_from_candidates(cands, n_cand, list_cap, fasta_path, out_path, k_left=31
     return nv.value, ne.value
 
 
-def snp_from_packed(stream, offsets8, n_cand, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2):
+def snp_from_packed(stream, offsets8, n_cand, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2, pos_bytes=4):
     p = TailParams(k_left, k_right, max_gap, max_err)
     nv, ne = C.c_uint64(0), C.c_uint64(0)
-    rc = lib().e2s_snp_from_packed(_ptr(stream), _ptr(offsets8), n_cand, C.byref(p), fasta_path.encode(), out_path.encode(),
+    rc = lib().e2s_snp_from_packed(_ptr(stream), _ptr(offsets8), n_cand, pos_bytes, C.byref(p), fasta_path.encode(), out_path.encode(),
                                    C.byref(nv), C.byref(ne))
     if rc:
         raise E2SError(rc, "e2s_snp_from_packed")

@@ -51,6 +51,7 @@ struct e2s_ctx {
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
     uint32_t* pin_order = nullptr;                                // offsets (8-byte units) of the packed candidates, n_cand + 1 entries
     uint32_t* d_size8 = nullptr; uint64_t size8_cap = 0;          // pack scratch
+    uint32_t pos_pack = 4;                                        // bytes per position in the packed stream
     uint32_t* d_slot_off8 = nullptr; uint64_t slot_off8_cap = 0;  // where k_flagged_lists packed each candidate slot
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
@@ -1013,6 +1014,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     a.record_index_base = record_index_base;
     a.err = h->d_words + 1;
     h->list_cap = a.list_cap; h->cand_stride = a.stride;
+    a.pos_pack = d.pos_bytes <= 1 ? 1u : (d.pos_bytes == 2 ? 2u : 4u);        // positions (suff - k_left) fit the suffix field's width
+    h->pos_pack = a.pos_pack;
 
     // Streaming path: boundaries recomputed from the LCP inside the kernel.  Needs the records to be the
     // scan's own (same k), default field widths for what it reads, 16-byte aligned columns.
@@ -1216,7 +1219,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             }
             void* dev_pin = nullptr;
             CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
-            e2s_launch_cand_pack(h->d_cand, a.stride, a.list_cap, h->d_order, count, h->d_size8, n_pad, (uint8_t*)dev_pin,
+            e2s_launch_cand_pack(h->d_cand, a.stride, a.list_cap, a.pos_pack, h->d_order, count, h->d_size8, n_pad, (uint8_t*)dev_pin,
                                  (uint32_t*)((uint8_t*)dev_pin + ord_off), h->stream);
             LCHK("e2s_launch_cand_pack");
         }
@@ -1235,19 +1238,26 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
 // the fixed-stride layout of include/e2s_hip.h, in SA order, rebuilt on the host from the packed stream
 static void expand_fixed(e2s_ctx* h) {
     if (h->host_fixed_valid) return;
-    const size_t st = h->cand_stride; const uint32_t cap = h->list_cap;
+    const size_t st = h->cand_stride; const uint32_t cap = h->list_cap, pw = h->pos_pack;
     h->host_fixed.assign((size_t)h->n_cand * st, 0);
     h->host_ident.resize(h->n_cand);
+    auto rdpos = [&](const uint8_t* p, uint32_t j) -> uint32_t {
+        return pw == 1 ? (uint32_t)p[j] : pw == 2 ? (uint32_t)p[2 * j] | ((uint32_t)p[2 * j + 1] << 8) : ((const uint32_t*)p)[j];
+    };
     for (uint64_t i = 0; i < h->n_cand; ++i) {
         const uint8_t* r = h->pin_cand + (size_t)h->pin_order[i] * 8;
-        const e2s_cand_header* hd = (const e2s_cand_header*)r;
-        const uint32_t* l = (const uint32_t*)(r + sizeof(e2s_cand_header));
+        const uint32_t* w = (const uint32_t*)r;
+        const uint32_t n0 = w[0], n1 = w[1];
+        e2s_cand_header hd{};
+        hd.record_index = i; hd.pair_index = 0;                  // (the device-side ordering keys do not travel: rank in SA order instead)
+        hd.n0 = n0; hd.n1 = n1; hd.right_idx = w[2]; hd.right_pos = w[3];
         uint8_t* o = h->host_fixed.data() + i * st;
-        memcpy(o, hd, sizeof(e2s_cand_header));
+        memcpy(o, &hd, sizeof(hd));
         uint32_t* ol = (uint32_t*)(o + sizeof(e2s_cand_header));
-        memcpy(ol, l, (size_t)hd->n0 * 4); memcpy(ol + cap, l + hd->n0, (size_t)hd->n0 * 4);
-        memcpy(ol + 2 * (size_t)cap, l + 2 * (size_t)hd->n0, (size_t)hd->n1 * 4);
-        memcpy(ol + 3 * (size_t)cap, l + 2 * (size_t)hd->n0 + hd->n1, (size_t)hd->n1 * 4);
+        const uint32_t* idx0 = w + 4; const uint32_t* idx1 = idx0 + n0;
+        const uint8_t* p0 = r + 16 + 4 * (size_t)(n0 + n1); const uint8_t* p1 = p0 + (size_t)pw * n0;
+        for (uint32_t j = 0; j < n0; ++j) { ol[j] = idx0[j]; ol[cap + j] = rdpos(p0, j); }
+        for (uint32_t j = 0; j < n1; ++j) { ol[2 * (size_t)cap + j] = idx1[j]; ol[3 * (size_t)cap + j] = rdpos(p1, j); }
         h->host_ident[i] = (uint32_t)i;
     }
     h->host_fixed_valid = true;
@@ -1294,7 +1304,8 @@ extern "C" int e2s_candidates_view(e2s_handle h, const void** recs, const uint32
     return E2S_OK;
 }
 
-extern "C" int e2s_candidates_packed(e2s_handle h, const void** stream, const uint32_t** offsets8, uint64_t* n_cand, uint64_t* stream_bytes) {
+extern "C" int e2s_candidates_packed(e2s_handle h, const void** stream, const uint32_t** offsets8, uint64_t* n_cand, uint64_t* stream_bytes,
+                                     uint32_t* pos_bytes) {
     dbg_entry("e2s_candidates_packed");
     if (!h) return E2S_ERR_ARG;
     if (h->n_cand && !h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
@@ -1302,6 +1313,7 @@ extern "C" int e2s_candidates_packed(e2s_handle h, const void** stream, const ui
     if (offsets8) *offsets8 = h->n_cand ? h->pin_order : nullptr;
     if (n_cand) *n_cand = h->n_cand;
     if (stream_bytes) *stream_bytes = h->n_cand ? (uint64_t)h->pin_order[h->n_cand] * 8 : 0;
+    if (pos_bytes) *pos_bytes = h->pos_pack;
     return E2S_OK;
 }
 

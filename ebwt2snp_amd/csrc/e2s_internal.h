@@ -110,6 +110,7 @@ struct CandArgs {
     // k_flagged_lists, packed mode (host_stream != nullptr): candidates go straight to pinned host memory, packed, at
     // reserved offsets (8-byte units); slot_off8[slot] remembers where, for the SA-order offsets written afterwards
     uint8_t* host_stream; unsigned long long* stream8_count; uint64_t stream8_cap; uint32_t* slot_off8;
+    uint32_t pos_pack;                              // bytes per position in the packed record (1, 2 or 4)
     uint64_t record_index_base;
     uint32_t* err;
 };
@@ -165,7 +166,7 @@ constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
 size_t e2s_cand_order_scratch_bytes(unsigned long long n);
 void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* n_dev,
                              const unsigned long long* stream8_count, uint32_t* off_out, hipStream_t st);
-void e2s_launch_cand_pack(const uint8_t* cand, uint32_t stride, uint32_t list_cap, const uint32_t* order, unsigned long long n, uint32_t* size8,
+void e2s_launch_cand_pack(const uint8_t* cand, uint32_t stride, uint32_t list_cap, uint32_t pw, const uint32_t* order, unsigned long long n, uint32_t* size8,
                           unsigned long long n_pad, uint8_t* stream, uint32_t* off_out, hipStream_t st);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,
                            unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st);

@@ -1542,6 +1542,34 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     queue_flush();
 }
 
+// ---- packed candidate record (what crosses PCIe; include/e2s_hip.h, e2s_candidates_packed):
+//   u32 n0, n1, right_idx, right_pos | u32 idx0[n0] | u32 idx1[n1] | pos0[n0] | pos1[n1] (pw bytes each) | pad to 8 bytes
+// built from a fixed-stride record [CandHeader][idx0[cap]][pos0[cap]][idx1[cap]][pos1[cap]] by the 64 lanes of a wave.
+__device__ __forceinline__ u32 packed_size8(u32 n0, u32 n1, u32 pw) { return (16u + (4u + pw) * (n0 + n1) + 7u) >> 3; }
+__device__ __forceinline__ void pack_record(const u32* hs, u32 list_cap, u32 pw, u32* dst, u32 lane) {
+    constexpr u32 HW = sizeof(CandHeader) / 4;
+    const u32 n0 = hs[3], n1 = hs[4], n = n0 + n1;
+    const u32* l = hs + HW;
+    const u32 words = 2u * packed_size8(n0, n1, pw);
+    const u32 per = 4u / pw;                                   // positions per output word
+    for (u32 w = lane; w < words; w += 64u) {
+        u32 v = 0;
+        if (w < 4u) v = hs[3u + w];                             // n0, n1, right_idx, right_pos
+        else if (w < 4u + n) { const u32 t = w - 4u; v = t < n0 ? l[t] : l[2u * list_cap + (t - n0)]; }
+        else {
+            const u32 q = (w - 4u - n) * per;
+            for (u32 j = 0; j < per; ++j) {
+                const u32 e = q + j;
+                if (e < n) {
+                    const u32 pv = e < n0 ? l[list_cap + e] : l[3u * list_cap + (e - n0)];
+                    v |= (pw == 4u ? pv : (pv & ((1u << (8u * pw)) - 1u))) << (8u * pw * j);
+                }
+            }
+        }
+        dst[w] = v;
+    }
+}
+
 // K2b: lists and candidate records (clust2snp.cpp:431-496) for the few clusters K2a let through.  Persistent
 // blocks, one wave per cluster, candidates staged in LDS so that a block reserves output slots ~once per 32.
 template <bool DEF>
@@ -1562,36 +1590,20 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
                 for (u32 i = 0; i < n; ++i) {
                     const CandHeader* hd = (const CandHeader*)(s_stage + (size_t)i * a.stride);
                     s_off8[i] = run;
-                    run += (u32)(sizeof(CandHeader) / 8) + hd->n0 + hd->n1;
+                    run += packed_size8(hd->n0, hd->n1, a.pos_pack);
                 }
                 s_gbase = atomicAdd(a.cand_count, (unsigned long long)n);
                 s_sbase = atomicAdd(a.stream8_count, (unsigned long long)run);
             }
             __syncthreads();
             const u64 gbase = s_gbase, sbase = s_sbase;
-            constexpr u32 HW = sizeof(CandHeader) / 4;
             // pack the staged records side by side in LDS (second half of the dynamic buffer), then move the block's
-            // whole chunk to the host with 8-byte stores, 512 contiguous bytes per wave instruction: PCIe writes of a few
-            // words per record ran at half the rate
+            // whole chunk to the host with 8-byte stores, 512 contiguous bytes per wave instruction
             u32* const s_pack = (u32*)(s_stage + (size_t)FW_STAGE * a.stride);
             for (u32 i = wave; i < n; i += 4) {
                 const u32* hs = (const u32*)(s_stage + (size_t)i * a.stride);
                 const CandHeader* hd = (const CandHeader*)hs;
-                const u32 n0 = hd->n0, n1 = hd->n1, total = HW + 2u * (n0 + n1);
-                u32* dst = s_pack + 2u * s_off8[i];
-                const u32* l = hs + HW;
-                for (u32 w = lane; w < total; w += 64u) {
-                    u32 v;
-                    if (w < HW) v = hs[w];
-                    else {
-                        const u32 t = w - HW;
-                        if (t < n0) v = l[t];
-                        else if (t < 2u * n0) v = l[a.list_cap + (t - n0)];
-                        else if (t < 2u * n0 + n1) v = l[2u * a.list_cap + (t - 2u * n0)];
-                        else v = l[3u * a.list_cap + (t - 2u * n0 - n1)];
-                    }
-                    dst[w] = v;
-                }
+                pack_record(hs, a.list_cap, a.pos_pack, s_pack + 2u * s_off8[i], lane);
                 const u64 slot = gbase + i;
                 if (lane == 0 && slot < a.cand_cap) {
                     a.slot_off8[slot] = (u32)(sbase + s_off8[i]);
@@ -1601,7 +1613,7 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
             __syncthreads();
             {
                 const CandHeader* hl = (const CandHeader*)(s_stage + (size_t)(n - 1) * a.stride);
-                const u32 run8 = s_off8[n - 1] + (u32)(sizeof(CandHeader) / 8) + hl->n0 + hl->n1;     // chunk length in 8-byte units
+                const u32 run8 = s_off8[n - 1] + packed_size8(hl->n0, hl->n1, a.pos_pack);         // chunk length in 8-byte units
                 if (gbase + n <= a.cand_cap && sbase + run8 <= a.stream8_cap) {
                     uint2* dst = (uint2*)(a.host_stream + sbase * 8);
                     const uint2* src = (const uint2*)s_pack;
@@ -1746,42 +1758,25 @@ __global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, const unsign
 // ---- candidates for the host: packed, in SA order.  Records are fixed-stride in HBM (lists of <= list_cap, on
 // average a third full); what crosses PCIe is [header][idx0[n0]][pos0[n0]][idx1[n1]][pos1[n1]] per candidate, written
 // by the GPU straight into pinned host memory in SA order, plus the offsets (units of 8 bytes).
-__global__ void k_cand_sizes(const uint8_t* cand, u32 stride, const u32* order, u64 n, u64 n_pad, u32* size8) {
+__global__ void k_cand_sizes(const uint8_t* cand, u32 stride, const u32* order, u64 n, u64 n_pad, u32 pw, u32* size8) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     u32 v = 0;
     if (i < n) {
         const CandHeader* h = (const CandHeader*)(cand + (u64)order[i] * stride);
-        v = (u32)(sizeof(CandHeader) / 8) + h->n0 + h->n1;       // 8 bytes per (idx, pos) pair
+        v = packed_size8(h->n0, h->n1, pw);
     }
     size8[i] = v;
 }
-__global__ __launch_bounds__(256) void k_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, const u32* order, const u32* off8, u64 n,
+__global__ __launch_bounds__(256) void k_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, u32 pw, const u32* order, const u32* off8, u64 n,
                                                    uint8_t* stream, u32* off_out) {
     const u32 lane = threadIdx.x & 63u;
     const u64 gw = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
     for (u64 i = gw; i < n; i += nw) {
-        const uint8_t* src = cand + (u64)order[i] * stride;
-        const CandHeader* h = (const CandHeader*)src;
-        const u32 n0 = h->n0, n1 = h->n1, o8 = off8[i];
-        u32* dst = (u32*)(stream + (u64)o8 * 8);
-        const u32* hs = (const u32*)src;
-        const u32* l = hs + sizeof(CandHeader) / 4;
-        constexpr u32 HW = sizeof(CandHeader) / 4;
-        const u32 total = HW + 2u * (n0 + n1);
-        for (u32 w = lane; w < total; w += 64u) {
-            u32 v;
-            if (w < HW) v = hs[w];
-            else {
-                const u32 t = w - HW;
-                if (t < n0) v = l[t];
-                else if (t < 2u * n0) v = l[list_cap + (t - n0)];
-                else if (t < 2u * n0 + n1) v = l[2u * list_cap + (t - 2u * n0)];
-                else v = l[3u * list_cap + (t - 2u * n0 - n1)];
-            }
-            dst[w] = v;
-        }
-        if (lane == 0) { off_out[i] = o8; if (i == n - 1) off_out[n] = o8 + total / 2u; }   // total words / 2 = 8-byte units
+        const u32* hs = (const u32*)(cand + (u64)order[i] * stride);
+        const u32 o8 = off8[i];
+        pack_record(hs, list_cap, pw, (u32*)(stream + (u64)o8 * 8), lane);
+        if (lane == 0) { off_out[i] = o8; if (i == n - 1) off_out[n] = o8 + packed_size8(hs[3], hs[4], pw); }
     }
 }
 // SA-order offsets of candidates that k_flagged_lists packed itself: off_out[i] = where slot order[i] went, off_out[n] = end
@@ -1795,13 +1790,13 @@ void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, cons
     hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out);
 }
 // exclusive scan of size8[0..n_pad) in place + total at size8[n_pad]; n_pad a multiple of 4096
-void e2s_launch_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, const u32* order, u64 n, u32* size8 /* n_pad + 1 */, u64 n_pad,
+void e2s_launch_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, u32 pw, const u32* order, u64 n, u32* size8 /* n_pad + 1 */, u64 n_pad,
                           uint8_t* stream, u32* off_out, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_cand_sizes, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, cand, stride, order, n, n_pad, size8);
+    hipLaunchKernelGGL(k_cand_sizes, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, cand, stride, order, n, n_pad, pw, size8);
     hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, size8, (u32)n_pad);
     const u64 blocks = (n + 3) / 4;
-    hipLaunchKernelGGL(k_cand_pack, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, cand, stride, list_cap, order, (const u32*)size8, n,
+    hipLaunchKernelGGL(k_cand_pack, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, cand, stride, list_cap, pw, order, (const u32*)size8, n,
                        stream, off_out);
 }
 void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hipStream_t st) {

@@ -155,15 +155,15 @@ int main(int argc, char** argv) {
     std::cout << " 100% done." << std::endl;
     std::cout << "Done. " << n_cand << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
     // the candidates arrive packed and in SA order in the handle's pinned buffer; the tail reads them in place
-    const void* cstream = nullptr; const uint32_t* coff = nullptr; uint64_t cbytes = 0;
-    die_on(e2s_candidates_packed(h, &cstream, &coff, &n_cand, &cbytes), h, "candidates");
+    const void* cstream = nullptr; const uint32_t* coff = nullptr; uint64_t cbytes = 0; uint32_t cpw = 4;
+    die_on(e2s_candidates_packed(h, &cstream, &coff, &n_cand, &cbytes, &cpw), h, "candidates");
 
     std::cout << "(2/4) Extracting reads from fasta file ..." << std::endl;
     std::cout << "(3/4) Filtering " << n_cand << " candidates and computing consensus of left-contexts ... " << std::endl;
     std::cout << "(4/4) Computing edit distances and saving SNPs/indels to file ... " << std::endl;
     e2s_tail_params tp{k_left, k_right, max_gap, max_err};
     uint64_t nv = 0, ne = 0;
-    rc = e2s_snp_from_packed(cstream, coff, n_cand, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
+    rc = e2s_snp_from_packed(cstream, coff, n_cand, cpw, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
     pc.mark("host tail + .snp");
     e2s_destroy(h);
     pc.mark("e2s_destroy");

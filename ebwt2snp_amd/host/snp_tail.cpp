@@ -143,7 +143,16 @@ struct TailClock {
 }  // namespace
 
 // one candidate, wherever it is stored
-struct CandView { const e2s_cand_header* h; const uint32_t* idx0; const uint32_t* pos0; const uint32_t* idx1; const uint32_t* pos1; };
+struct CandView {
+    uint32_t n0, n1, right_idx, right_pos;
+    const uint32_t* idx0; const uint32_t* idx1;
+    const uint8_t* pos0; const uint8_t* pos1; uint32_t pw;       // positions: pw bytes each, little endian
+    uint32_t pos(int s, uint32_t j) const {
+        const uint8_t* p = s ? pos1 : pos0;
+        return pw == 1 ? (uint32_t)p[j] : pw == 2 ? (uint32_t)p[2 * j] | ((uint32_t)p[2 * j + 1] << 8)
+                                                   : (uint32_t)p[4 * j] | ((uint32_t)p[4 * j + 1] << 8) | ((uint32_t)p[4 * j + 2] << 16) | ((uint32_t)p[4 * j + 3] << 24);
+    }
+};
 
 template <typename Get>
 static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_params* p, const char* fasta_path, const char* out_path,
@@ -158,10 +167,10 @@ static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_
     ranks.reserve(n_cand * 8);
     for (uint64_t c = 0; c < n_cand; ++c) {
         const CandView v = get(c);
-        if (v.h->n0 > list_cap || v.h->n1 > list_cap) return E2S_ERR_ARG;
-        for (uint32_t t = 0; t < v.h->n0; ++t) ranks.push_back(v.idx0[t]);
-        for (uint32_t t = 0; t < v.h->n1; ++t) ranks.push_back(v.idx1[t]);
-        ranks.push_back(v.h->right_idx);
+        if (v.n0 > list_cap || v.n1 > list_cap) return E2S_ERR_ARG;
+        for (uint32_t t = 0; t < v.n0; ++t) ranks.push_back(v.idx0[t]);
+        for (uint32_t t = 0; t < v.n1; ++t) ranks.push_back(v.idx1[t]);
+        ranks.push_back(v.right_idx);
     }
     TailClock tc;
     std::sort(ranks.begin(), ranks.end());
@@ -184,13 +193,12 @@ static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_
     for (int ch = 0; ch < 256; ++ch) b2i[ch] = (unsigned char)base_to_int((unsigned char)ch);
     for (uint64_t c = 0; c < n_cand; ++c) {
         const CandView cv = get(c);
-        const e2s_cand_header* h = cv.h;
+        const CandView* h = &cv;
         std::string cons[2];
         int supp[2] = {0, 0};
         for (int s = 0; s < 2; ++s) {
             const uint32_t n = s ? h->n1 : h->n0;
             const uint32_t* idx = s ? cv.idx1 : cv.idx0;
-            const uint32_t* pos = s ? cv.pos1 : cv.pos0;
             // cons, include.hpp:334-371: the letter changes only on a strictly larger count (H8)
             std::string& C = cons[s];
             C.assign((size_t)kl, 'A');
@@ -200,7 +208,7 @@ static int snp_core(uint64_t n_cand, uint32_t list_cap, Get get, const e2s_tail_
             for (uint32_t j = 0; j < n; ++j) {
                 const std::string& r = read_of(idx[j]);
                 unsigned char* row = ctx.data() + (size_t)j * (size_t)kl;
-                const uint64_t p0 = pos[j], len = r.size();
+                const uint64_t p0 = cv.pos(s, j), len = r.size();
                 const uint64_t have = p0 < len ? std::min<uint64_t>(len - p0, (uint64_t)kl) : 0;
                 memcpy(row, r.data() + (have ? p0 : 0), (size_t)have);
                 memset(row + have, 0, (size_t)kl - (size_t)have);
@@ -273,21 +281,25 @@ extern "C" int e2s_snp_from_candidates(const void* cands, const uint32_t* order,
     const uint8_t* base = (const uint8_t*)cands;
     auto get = [&](uint64_t c) {                                      // SA order through `order`
         const uint8_t* r = base + (size_t)(order ? order[c] : c) * stride;
+        const e2s_cand_header* h = (const e2s_cand_header*)r;
         const uint32_t* l = (const uint32_t*)(r + sizeof(e2s_cand_header));
-        return CandView{(const e2s_cand_header*)r, l, l + list_cap, l + 2 * (size_t)list_cap, l + 3 * (size_t)list_cap};
+        return CandView{h->n0, h->n1, h->right_idx, h->right_pos, l, l + 2 * (size_t)list_cap,
+                        (const uint8_t*)(l + list_cap), (const uint8_t*)(l + 3 * (size_t)list_cap), 4u};
     };
     return snp_core(n_cand, list_cap, get, p, fasta_path, out_path, n_variants, n_events);
 }
 
-extern "C" int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n_cand, const e2s_tail_params* p,
+extern "C" int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n_cand, uint32_t pos_bytes, const e2s_tail_params* p,
                                    const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events) {
     if (!p || !fasta_path || !out_path || ((!stream || !offsets8) && n_cand)) return E2S_ERR_ARG;
+    if (pos_bytes != 1 && pos_bytes != 2 && pos_bytes != 4) return E2S_ERR_ARG;
     const uint8_t* base = (const uint8_t*)stream;
     auto get = [&](uint64_t c) {
         const uint8_t* r = base + (size_t)offsets8[c] * 8;
-        const e2s_cand_header* h = (const e2s_cand_header*)r;
-        const uint32_t* l = (const uint32_t*)(r + sizeof(e2s_cand_header));
-        return CandView{h, l, l + h->n0, l + 2 * (size_t)h->n0, l + 2 * (size_t)h->n0 + h->n1};
+        const uint32_t* w = (const uint32_t*)r;
+        const uint32_t n0 = w[0], n1 = w[1];
+        const uint8_t* p0 = r + 16 + 4 * (size_t)(n0 + n1);
+        return CandView{n0, n1, w[2], w[3], w + 4, w + 4 + n0, p0, p0 + (size_t)pos_bytes * n0, pos_bytes};
     };
     return snp_core(n_cand, 0xFFFFFFFFu, get, p, fasta_path, out_path, n_variants, n_events);
 }

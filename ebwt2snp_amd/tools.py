@@ -85,9 +85,9 @@ def clust2snp(input_path, n, L=0, R=0, g=0, v=0, c=0, e=0, m=0, p=0.0, x=0, y=0,
         mcl, n_clust, n_bases = capi.auto_max_clust_length([h.hist()], m, p)
         prm = capi.C2SParams(nr_reads1, L, R, m, c, mcl, 0)
         ncand = h.find_candidates(prm)
-        stream, off8, ncand = h.candidates_packed()
+        stream, off8, ncand, pw = h.candidates_packed()
         out = snp_out_path(input_path)
-        nv, ne = capi.snp_from_packed(stream, off8, ncand, input_path, out, L, R, g, e)
+        nv, ne = capi.snp_from_packed(stream, off8, ncand, input_path, out, L, R, g, e, pos_bytes=pw)
         res = dict(max_clust_length=mcl, n_clust=n_clust, n_bases=n_bases, n_candidates=ncand, n_variants=nv, n_events=ne,
                    out_path=out)
         if return_candidates:

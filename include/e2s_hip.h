@@ -205,14 +205,18 @@ int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_i
 int e2s_candidate_stride(e2s_handle h, const e2s_c2s_params* p, uint32_t* list_cap, size_t* stride_bytes);
 int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, uint64_t* n_cand);  /* copied out in SA order */
 /* The same fixed-stride records without a copy of the caller's (host memory owned by the handle) and a
- * permutation `order` (the i-th candidate is recs[order[i]]; the identity since the packed transfer below).
+ * permutation `order` (the i-th candidate is recs[order[i]]; the identity since the packed transfer below;
+ * record_index / pair_index of the headers are device-side ordering keys and come back as the SA rank / 0).
  * Valid until the next e2s_find_candidates / e2s_destroy on this handle. */
 int e2s_candidates_view(e2s_handle h, const void** recs, const uint32_t** order, uint64_t* n_cand,
                         uint32_t* list_cap, size_t* stride_bytes);
 /* Zero-copy, what e2s_find_candidates itself delivers: the candidates in SA order as a packed stream in the
- * handle's pinned host buffer, written there by the GPU.  Candidate i starts at stream + 8 * offsets8[i]:
- * [e2s_cand_header][u32 idx0[n0]][u32 pos0[n0]][u32 idx1[n1]][u32 pos1[n1]]; offsets8 has n_cand + 1 entries. */
-int e2s_candidates_packed(e2s_handle h, const void** stream, const uint32_t** offsets8, uint64_t* n_cand, uint64_t* stream_bytes);
+ * handle's pinned host buffer, written there by the GPU.  Candidate i starts at stream + 8 * offsets8[i]
+ * (offsets8 has n_cand + 1 entries, the last one = end of the stream):
+ *   u32 n0, n1, right_idx, right_pos | u32 idx0[n0] | u32 idx1[n1] | pos0[n0] | pos1[n1] | padding to 8 bytes
+ * with positions of *pos_bytes bytes each (1, 2 or 4: the width of the suffix field, little endian). */
+int e2s_candidates_packed(e2s_handle h, const void** stream, const uint32_t** offsets8, uint64_t* n_cand, uint64_t* stream_bytes,
+                          uint32_t* pos_bytes);
 
 /* ---- host tail: candidates -> KisSNP2 text (extract_variants + distance + to_file) -------- */
 typedef struct {
@@ -225,7 +229,7 @@ int e2s_snp_from_candidates(const void* cands, const uint32_t* order, uint64_t n
                             const e2s_tail_params* p, const char* fasta_path, const char* out_path,
                             uint64_t* n_variants, uint64_t* n_events);
 /* The same over the packed stream of e2s_candidates_packed. */
-int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n_cand, const e2s_tail_params* p,
+int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n_cand, uint32_t pos_bytes, const e2s_tail_params* p,
                         const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events);
 
 /* ---- measurement --------------------------------------------------------------------------- */

@@ -156,14 +156,17 @@ def _pack_candidates(cands, cap):
     return buf
 
 
-def _pack_stream(cands):
-    """the packed layout of e2s_candidates_packed: [header][idx0[n0]][pos0[n0]][idx1[n1]][pos1[n1]], offsets in 8-byte units"""
+def _pack_stream(cands, pw):
+    """the packed layout of e2s_candidates_packed: u32 n0, n1, right_idx, right_pos | idx0 | idx1 | pos0 | pos1 (pw bytes each),
+    padded to 8 bytes; offsets in 8-byte units"""
+    pdt = {1: np.uint8, 2: "<u2", 4: "<u4"}[pw]
     parts, off8, at = [], [], 0
-    for i, c in enumerate(cands):
-        h = capi.CandHeader(i, 0, len(c["idx0"]), len(c["idx1"]), c["right_idx"], c["right_pos"], 0)
-        body = np.concatenate([np.asarray(c[k], dtype=np.uint32) for k in ("idx0", "pos0", "idx1", "pos1")]) if (c["idx0"] or c["idx1"]) \
-            else np.zeros(0, np.uint32)
-        rec = np.concatenate([np.frombuffer(bytes(h), dtype=np.uint8), body.view(np.uint8)])
+    for c in cands:
+        hdr = np.asarray([len(c["idx0"]), len(c["idx1"]), c["right_idx"], c["right_pos"]], dtype="<u4").view(np.uint8)
+        idx = np.asarray(list(c["idx0"]) + list(c["idx1"]), dtype="<u4").view(np.uint8)
+        pos = np.asarray(list(c["pos0"]) + list(c["pos1"]), dtype=np.uint64).astype(pdt).view(np.uint8)
+        rec = np.concatenate([hdr, idx, pos])
+        rec = np.concatenate([rec, np.zeros((-rec.size) % 8, dtype=np.uint8)])
         off8.append(at // 8)
         parts.append(rec)
         at += rec.size
@@ -191,11 +194,15 @@ def test_host_tail_on_oracle_candidates(meta, tmp_path):
                                       a.get("L", 0) or 31, a.get("R", 0) or 30, a.get("g", 0) or 10, a.get("e", 0) or 2)
     assert open(out, "rb").read() == goldens.golden_snp(meta)
     # the same tail over the packed stream (the layout the GPU writes into the pinned buffer)
-    stream, off8 = _pack_stream(cands)
-    out2 = str(tmp_path / "product_packed.snp")
-    nv2, ne2 = capi.snp_from_packed(stream, off8, len(cands), p, out2, a.get("L", 0) or 31, a.get("R", 0) or 30, a.get("g", 0) or 10,
-                                    a.get("e", 0) or 2)
-    assert (nv2, ne2) == (nv, ne) and open(out2, "rb").read() == goldens.golden_snp(meta)
+    maxpos = max([0] + [v for c in cands for v in list(c["pos0"]) + list(c["pos1"])])
+    for pw in (1, 2, 4):
+        if maxpos >= 1 << (8 * pw):
+            continue
+        stream, off8 = _pack_stream(cands, pw)
+        out2 = str(tmp_path / ("product_packed%d.snp" % pw))
+        nv2, ne2 = capi.snp_from_packed(stream, off8, len(cands), p, out2, a.get("L", 0) or 31, a.get("R", 0) or 30, a.get("g", 0) or 10,
+                                        a.get("e", 0) or 2, pos_bytes=pw)
+        assert (nv2, ne2) == (nv, ne) and open(out2, "rb").read() == goldens.golden_snp(meta)
     assert ne == meta["n_events"]
 
 
