@@ -113,6 +113,9 @@ _XCHG = {}
 # E2S_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the N-rank logic (shards, single
 # exchange, stitch plans, merged statistics) on a one-GPU box; not a measurement
 REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
+# E2S_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path -- RCCL process group,
+# exchange, merged statistics -- with a single rank, to exercise it on a one-GPU box
+FORCE_DIST = os.environ.get("E2S_BENCH_FORCE_DIST", "0") == "1"
 
 
 def _exchange(blob, world, dist, dev):
@@ -142,7 +145,7 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None)
     h.prefilter_begin(prm_base["m"], min_len)                      # runs beside the exchange and the statistics below
     t = _tick("scan", t)
     b = h.boundary()
-    if world > 1:
+    if dist is not None:
         # the boundary stitch: ONE all-gather carries descriptor + statistics of every rank
         st = h.scan_stats()
         sb, ss = ctypes.sizeof(capi.Boundary), ctypes.sizeof(capi.ScanStats)
@@ -154,7 +157,7 @@ def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None)
     else:
         h.stitch([b], rank)
     t = _tick("stitch", t)
-    if world > 1:
+    if dist is not None:
         # every rank derives the same statistics from the gathered blobs (pure host function, one call)
         mcl, n_clust, _ = capi.auto_max_clust_length_ranks(allb, alls, n_total, k, 1, prm_base["m"], 0.99)
     else:
@@ -264,7 +267,7 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
     dist = None
-    if world > 1:
+    if world > 1 or (FORCE_DIST and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if REHEARSAL:
