@@ -131,10 +131,14 @@ def _exchange(blob, world, dist, dev):
         dist.all_gather_into_tensor(x["dst"], x["src"])
         raw = x["dst"].numpy().tobytes()
         return [raw[i * n:(i + 1) * n] for i in range(world)]
-    x["d_src"].copy_(x["src"], non_blocking=True)
-    dist.all_gather_into_tensor(x["d_dst"], x["d_src"])
-    x["dst"].copy_(x["d_dst"], non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    xs = x.get("stream")
+    if xs is None:
+        xs = x["stream"] = torch.cuda.Stream(device=dev, priority=-1)      # beside the pre-filter kernel, not behind it
+    with torch.cuda.stream(xs):
+        x["d_src"].copy_(x["src"], non_blocking=True)
+        dist.all_gather_into_tensor(x["d_dst"], x["d_src"])
+        x["dst"].copy_(x["d_dst"], non_blocking=True)
+    xs.synchronize()
     raw = x["dst"].numpy().tobytes()
     return [raw[i * n:(i + 1) * n] for i in range(world)]
 
@@ -270,6 +274,7 @@ def main():
     if world > 1 or (FORCE_DIST and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")    # the small all-gather runs beside the pre-filter kernel
         if REHEARSAL:
             local = 0
             import faulthandler
