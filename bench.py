@@ -116,6 +116,8 @@ REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
 # E2S_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path -- RCCL process group,
 # exchange, merged statistics -- with a single rank, to exercise it on a one-GPU box
 FORCE_DIST = os.environ.get("E2S_BENCH_FORCE_DIST", "0") == "1"
+# E2S_BENCH_OVERLAP=1: scan and pre-filter side by side on two streams (higher throughput; per-kernel times then include the sharing)
+OVERLAP = os.environ.get("E2S_BENCH_OVERLAP", "0") == "1"
 
 
 def _exchange(blob, world, dist, dev):
@@ -145,8 +147,10 @@ def _exchange(blob, world, dist, dev):
 
 def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None):
     t = time.perf_counter()
+    if OVERLAP:
+        h.prefilter_arm(prm_base["m"])                             # the scan starts the pre-filter beside itself (second stream)
     h.cluster_scan(k, min_len, 0)                                  # scan + statistics of the shard's own records
-    h.prefilter_begin(prm_base["m"], min_len)                      # runs beside the exchange and the statistics below
+    h.prefilter_begin(prm_base["m"], min_len)                      # (no-op if armed) runs beside the exchange and the statistics below
     t = _tick("scan", t)
     b = h.boundary()
     if dist is not None:

@@ -77,7 +77,7 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_attach_soa", "e2s_upload_lcp", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
-           "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
+           "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
 
 _lib = None
@@ -115,6 +115,7 @@ def lib():
     L.e2s_auto_max_clust_length.argtypes = [C.POINTER(Hist), C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_prefilter_begin.argtypes = [H, C.c_int, C.c_int]
+    L.e2s_prefilter_arm.argtypes = [H, C.c_int]
     L.e2s_find_candidates.argtypes = [H, C.POINTER(C2SParams), C.c_uint64, C.POINTER(C.c_uint64)]
     L.e2s_candidate_stride.argtypes = [H, C.POINTER(C2SParams), C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
     L.e2s_fetch_candidates.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -238,6 +239,10 @@ class Handle:
     def prefilter_begin(self, mcov_out=5, min_len=2):
         """start the pre-filter of the per-cluster pass ahead of find_candidates (runs beside the exchange / statistics)"""
         self._ck(self.L.e2s_prefilter_begin(self.h, mcov_out, min_len))
+
+    def prefilter_arm(self, mcov_out=5):
+        """the next cluster_scan starts the pre-filter on the second stream beside its own kernels"""
+        self._ck(self.L.e2s_prefilter_arm(self.h, mcov_out))
 
     def find_candidates(self, params, record_index_base=0):
         n = C.c_uint64(0)

@@ -57,6 +57,8 @@ struct e2s_ctx {
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
     bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
+    bool pf_armed = false; int pf_arm_mcov = 0;                   // e2s_prefilter_arm: the next scan starts it beside itself (second stream)
+    bool pf_on_stream2 = false; hipEvent_t ev_pf = nullptr;
     hipEvent_t ev_wait = nullptr;
     hipEvent_t ev_chunk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
@@ -141,6 +143,8 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     return E2S_OK;
 }
 
+static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st);
+
 // Wait for the handle's stream with a short spin on an event before falling back to the blocking wait: the two
 // waits of a job (after the scan, after the per-cluster pass) sit on its critical path, and the blocking wait's
 // wake-up costs tens of microseconds.
@@ -179,6 +183,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_size8); hipFree(h->d_slot_off8);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     if (h->ev_wait) hipEventDestroy(h->ev_wait);
+    if (h->ev_pf) hipEventDestroy(h->ev_pf);
     for (auto& e : h->ev_chunk) if (e) hipEventDestroy(e);
     if (h->stream2) hipStreamDestroy(h->stream2);
     hipStreamDestroy(h->stream);
@@ -442,6 +447,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         // as many workers as waves fit on the chip (a whole number per SIMD), tiles dealt out evenly: the kernel is
         // VALU bound, so a SIMD holding one worker more, or workers one tile longer, finishes that much later
         uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
+        if (h->pf_armed) nb = std::min<uint64_t>(nb, 4096);        // leave registers for the pre-filter's waves beside it
         if (nb == 0) nb = 1;
         sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
         sa.tiles_rem = (uint32_t)(sa.n_tiles % nb);
@@ -460,6 +466,10 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             if ((rc = ensure_records(h, nb * seg_cap))) return rc;
             sa.seg_cap = (uint32_t)seg_cap; sa.starts = h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
             sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
+            if (attempt == 0 && h->pf_armed) {                      // the pre-filter beside the scan (e2s_prefilter_arm)
+                h->pf_armed = false;
+                if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
+            }
             CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
             CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
@@ -940,7 +950,7 @@ static void filter_args(e2s_ctx* h, int mcov_out, int len_lo, int len_hi, Filter
     f.kb = (f.k_u32 & 0xFF) * 0x01010101u;
     f.mcov_u = (uint32_t)mcov_out; f.len_lo = len_lo; f.len_hi = len_hi;
     f.n_tiles = (h->n_prov + 3935) / 3936;
-    f.err = h->d_words + 1;
+    f.err = h->d_words + 20;                                     // the pre-filter's own error word (it may run beside the scan)
     f.fl_starts = h->d_fl_starts; f.fl_lens = h->d_fl_lens; f.fl_cap = h->fl_cap;
     f.fl_count = (unsigned long long*)(h->d_scalars + 2);
 }
@@ -953,30 +963,56 @@ static int c2s_len_lo(int mcov_out, int min_len) {   // `length >= mcov_out*2` (
  * exchange their descriptors and the host works out max_clust_length (it keeps clusters up to the absolute
  * maximum length; e2s_find_candidates applies the exact bound).  Optional: without it e2s_find_candidates runs the
  * pre-filter itself. */
-extern "C" int e2s_prefilter_begin(e2s_handle h, int mcov_out, int min_len) {
-    dbg_entry("e2s_prefilter_begin");
-    if (!h) return E2S_ERR_ARG;
+// launch the pre-filter on `st` (the handle's stream, or its second stream beside the scan); est_records sizes the list
+static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st) {
     h->pf_inflight = false;
-    if (!h->scanned) return fail(h, E2S_ERR_STATE, "e2s_cluster_scan has not run");
     const e2s_shard_desc& d = h->d;
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt) & 15u) == 0;
     static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;
-    if (h->records_from_file || !h->segmented || d.lcp_bytes != 1 || !aligned || !h->bwt || filter_v1) return E2S_OK;   // nothing to start early
-    CK(hipSetDevice(h->device));
-    int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_ends / 8 + 4096 + E2S_SEED_SLOTS));
+    if (h->records_from_file || d.lcp_bytes != 1 || !aligned || !h->bwt || filter_v1) return E2S_OK;   // nothing to start early
+    int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
     if (rc) return rc;
     uint64_t* mc = (uint64_t*)(h->pin_mail + 2048 + 64 * 8 + 64 * 2);
     *mc = E2S_SEED_SLOTS;                                       // the list starts behind the reserved slots
-    CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, h->stream));
-    CK(hipMemsetAsync(h->d_fl_lens, 0, E2S_SEED_SLOTS * 2, h->stream));      // length 0 = empty slot
-    CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
+    CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, st));
+    CK(hipMemsetAsync(h->d_fl_lens, 0, E2S_SEED_SLOTS * 2, st));             // length 0 = empty slot
+    CK(hipMemsetAsync(h->d_words + 20, 0, 4, st));
     FilterArgs f;
     filter_args(h, mcov_out, c2s_len_lo(mcov_out, min_len), (int)E2S_MAX_CLUST_LEN, f);
-    CK(hipEventRecord(h->ev[6], h->stream));
-    e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, h->stream);
+    CK(hipEventRecord(h->ev[6], st));
+    e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, max_workers, st);
     LCHK("e2s_launch_cluster_filter");
-    CK(hipEventRecord(h->ev[4], h->stream));
+    CK(hipEventRecord(h->ev[4], st));
     h->pf_inflight = true; h->pf_mcov = mcov_out; h->pf_len_lo = f.len_lo;
+    h->pf_on_stream2 = st != h->stream;
+    if (h->pf_on_stream2) {
+        if (!h->ev_pf) CK(hipEventCreateWithFlags(&h->ev_pf, hipEventDisableTiming));
+        CK(hipEventRecord(h->ev_pf, st));
+    }
+    return E2S_OK;
+}
+
+/* The pre-filter of the per-cluster pass depends on -m (mcov_out) and the scan only: it can run while the ranks
+ * exchange their descriptors and the host works out max_clust_length (it keeps clusters up to the absolute
+ * maximum length; e2s_find_candidates applies the exact bound).  Optional: without it e2s_find_candidates runs the
+ * pre-filter itself. */
+extern "C" int e2s_prefilter_begin(e2s_handle h, int mcov_out, int min_len) {
+    dbg_entry("e2s_prefilter_begin");
+    if (!h) return E2S_ERR_ARG;
+    if (h->pf_inflight) return E2S_OK;                          // already running (e2s_prefilter_arm)
+    if (!h->scanned) return fail(h, E2S_ERR_STATE, "e2s_cluster_scan has not run");
+    if (!h->segmented) return E2S_OK;
+    CK(hipSetDevice(h->device));
+    return start_prefilter(h, mcov_out, min_len, h->n_ends, 0, h->stream);
+}
+
+/* Even earlier: the pre-filter reads the LCP and the BWT, not the scan's records.  Armed with -m before
+ * e2s_cluster_scan, the scan launches it on the handle's second stream beside its own kernels (both are bound by
+ * instruction issue with bubbles at this size; together they fill the GPU better than one after the other). */
+extern "C" int e2s_prefilter_arm(e2s_handle h, int mcov_out) {
+    dbg_entry("e2s_prefilter_arm");
+    if (!h) return E2S_ERR_ARG;
+    h->pf_armed = true; h->pf_arm_mcov = mcov_out;
     return E2S_OK;
 }
 
@@ -1042,7 +1078,9 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
         h->pf_inflight = false;
         CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
-        if (!use_pf) CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));      // (the early pre-filter may have set error bits)
+        CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
+        if (!use_pf) CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));     // (an early pre-filter may have set its error bits)
+        if (use_pf && h->pf_on_stream2) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // it ran on the second stream
         if (streaming) {
             // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
             std::vector<uint64_t> ss; std::vector<uint16_t> sl;
@@ -1114,7 +1152,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
                 LCHK("e2s_launch_flagged_lists");
             } else if (chunks == 1) {
-                if (filter_v1) e2s_launch_cluster_filter(f, h->stream); else e2s_launch_cluster_filter2(f, 0, w_tiles, h->stream);
+                if (filter_v1) e2s_launch_cluster_filter(f, h->stream); else e2s_launch_cluster_filter2(f, 0, w_tiles, 0, h->stream);
                 LCHK("e2s_launch_cluster_filter");
                 CK(hipEventRecord(h->ev[4], h->stream));
                 e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
@@ -1127,7 +1165,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 CK(hipMemsetAsync(snap, 0, 8, h->stream));
                 if (!h->ev_chunk[0]) for (auto& e : h->ev_chunk) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 for (int c = 0; c < chunks; ++c) {
-                    e2s_launch_cluster_filter2(f, w_tiles * c / chunks, w_tiles * (c + 1) / chunks, h->stream);
+                    e2s_launch_cluster_filter2(f, w_tiles * c / chunks, w_tiles * (c + 1) / chunks, 0, h->stream);
                     e2s_launch_snapshot(fl_count, snap + c + 1, h->stream);
                     CK(hipEventRecord(h->ev_chunk[c], h->stream));
                     CK(hipStreamWaitEvent(h->stream2, h->ev_chunk[c], 0));
@@ -1167,11 +1205,12 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         uint64_t* mb = (uint64_t*)(h->pin_mail + 1024);
         CK(hipMemcpyAsync(mb, h->d_scalars + 1, 16, hipMemcpyDeviceToHost, h->stream));        // cand_count, flagged
         CK(hipMemcpyAsync(mb + 2, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
+        CK(hipMemcpyAsync((uint32_t*)(mb + 2) + 1, h->d_words + 20, 4, hipMemcpyDeviceToHost, h->stream));
         CK(wait_stream(h));
         CK(hipGetLastError());
         count = mb[0];
         const uint64_t flagged = mb[1];
-        const uint32_t err = *(const uint32_t*)(mb + 2);
+        const uint32_t err = ((const uint32_t*)(mb + 2))[0] | ((const uint32_t*)(mb + 2))[1];     // K2b's word | the pre-filter's
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
         if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
         if (streaming && flagged > h->fl_cap) {

@@ -137,7 +137,7 @@ struct FilterArgs {
 
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
 void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
-void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, hipStream_t st);
+void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st);
 void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st);
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);

@@ -1944,7 +1944,7 @@ void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st) {
     if (blocks == 0) return;
     hipLaunchKernelGGL(k_cluster_filter, dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
-void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, hipStream_t st) {
+void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st) {
     static int resident = 0;
     if (!resident) {
         // three workers per SIMD: the kernel is VALU bound (the same speed with 2..4), and this leaves registers for the
@@ -1956,7 +1956,8 @@ void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsign
     }
     if (tile_hi <= tile_lo) return;
     a.w_tile0 = tile_lo; a.w_tiles = tile_hi - tile_lo;
-    uint64_t nb = a.w_tiles < (uint64_t)resident ? a.w_tiles : (uint64_t)resident;
+    const uint64_t cap = (max_workers > 0 && max_workers < resident) ? (uint64_t)max_workers : (uint64_t)resident;
+    uint64_t nb = a.w_tiles < cap ? a.w_tiles : cap;
     a.w_per = (uint32_t)(a.w_tiles / nb); a.w_rem = (uint32_t)(a.w_tiles % nb); a.w_blocks = (uint32_t)nb;
     hipLaunchKernelGGL(k_cluster_filter2, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, a);
 }

@@ -301,7 +301,8 @@ def test_drop_in_executables(tmp_path):
 
 def _fused_candidates(h, en, n1, k=16, m=2, mcov=5, L=31, R=30, c=20, p=0.99, xyz=(1, 4, 1), early=False):
     """scan -> stitch -> hist -> candidates on one handle (records stay on the device: streaming pass);
-    early: the pre-filter is started right after the scan (e2s_prefilter_begin), before stitch and statistics"""
+    early: True = the pre-filter is started right after the scan (e2s_prefilter_begin), before stitch and statistics;
+    "arm" = armed before the scan, which then starts it on the second stream beside its own kernels"""
     x, y, z = xyz
     n = en["lcp"].size
     d = capi.Handle.desc(n, x=x, y=y, z=z)
@@ -309,8 +310,10 @@ def _fused_candidates(h, en, n1, k=16, m=2, mcov=5, L=31, R=30, c=20, p=0.99, xy
     psa["s"] = en["suff"]
     psa["t"] = en["text"]
     h.upload_bcr(d, en["bwt"], en["lcp"].astype(IO._DT[x]).view(np.uint8), psa.view(np.uint8))
+    if early == "arm":
+        h.prefilter_arm(mcov)                                    # the scan starts the pre-filter beside itself (second stream)
     h.cluster_scan(k, m, 0)
-    if early:
+    if early is True:
         h.prefilter_begin(mcov, m)
     h.stitch([h.boundary()], 0)
     mcl, _, _ = capi.auto_max_clust_length([h.hist()], mcov, p)
@@ -467,7 +470,7 @@ def test_fused_streaming_fuzz_columns(H, tmp_path, seed):
     mcov = int(rnd.choice([3, 5]))
     Rc = int(rnd.choice([25, 30, 45]))
     oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000, mcov=mcov, R=Rc, tag="fz%d" % seed)
-    for early in (False, True):                                  # pre-filter inside find_candidates / started ahead of the statistics
+    for early in (False, True, "arm"):                           # pre-filter inside find_candidates / after the scan / beside the scan
         got, mcl = _fused_candidates(H, en, 1000, mcov=mcov, R=Rc, early=early)
         assert mcl == omcl and len(oc) > 50
         assert len(got) == len(oc)
