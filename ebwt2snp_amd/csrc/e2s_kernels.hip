@@ -1807,8 +1807,10 @@ void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hip
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
 void e2s_launch_cand_order(const u64* keys, u64 n, const unsigned long long* n_dev, u64 key_lo, u64 key_span, void* scratch, u32* order, hipStream_t st) {
     if (!n) return;
+    // ~2 keys per bucket up to 2^16 buckets (the single-block scan of the counts costs ~0.4 us per 1024 buckets; beyond
+    // that longer buckets are cheaper than a longer scan)
     u32 nb = 256;
-    while (nb < E2S_KO_MAX_BUCKETS && (u64)nb * 2 < n) nb <<= 1;
+    while (nb < 65536u && nb < E2S_KO_MAX_BUCKETS && (u64)nb * 2 < n) nb <<= 1;
     u32 shift = 0;
     while (shift < 63 && (key_span >> shift) >= (u64)nb) ++shift;           // (key - key_lo) >> shift < nb for key - key_lo < key_span
     u32* cnt = (u32*)scratch;
