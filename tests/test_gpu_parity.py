@@ -543,3 +543,17 @@ def test_tiled_copies_property():
         for a, c in zip(k1, k3[b * len(k1):(b + 1) * len(k1)]):
             assert c["right_pos"] == a["right_pos"] and c["pos0"] == a["pos0"] and c["pos1"] == a["pos1"]
             assert c["right_idx"] == remap([a["right_idx"]])[0] and c["idx0"] == remap(a["idx0"]) and c["idx1"] == remap(a["idx1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [300, 301, 302])
+def test_sharded_fuzz_columns(seed):
+    """the random EGSA columns cut into 2-6 shards at random positions (halo 152 / 1), descriptors and scan statistics
+    merged by the pure host functions, the pre-filter inside find_candidates / after the scan / beside the scan by seed:
+    `.clusters` bytes, max_clust_length and every candidate against the oracle on the whole array"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("stress_columns", os.path.join(root, "tools", "stress_columns.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(seed)
