@@ -144,6 +144,8 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
 }
 
 static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st);
+static bool prefilter_eligible(const e2s_ctx* h);
+static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f);
 
 // Wait for the handle's stream with a short spin on an event before falling back to the blocking wait: the two
 // waits of a job (after the scan, after the per-cluster pass) sit on its critical path, and the blocking wait's
@@ -447,7 +449,13 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         // as many workers as waves fit on the chip (a whole number per SIMD), tiles dealt out evenly: the kernel is
         // VALU bound, so a SIMD holding one worker more, or workers one tile longer, finishes that much later
         uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
-        if (h->pf_armed) nb = std::min<uint64_t>(nb, 4096);        // leave registers for the pre-filter's waves beside it
+        // e2s_prefilter_arm: the pre-filter runs inside the scan kernel (E2S_FUSED=0: beside it, on the second stream)
+        static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
+        const bool fused = h->pf_armed && fused_env && prefilter_eligible(h);
+        if (fused) {
+            static const int fused_resident = e2s_scan_seg_fused_resident_blocks();
+            nb = std::min<uint64_t>(nb, (uint64_t)std::max(fused_resident, 4));
+        } else if (h->pf_armed) nb = std::min<uint64_t>(nb, 4096);   // leave registers for the pre-filter's waves beside it
         if (nb == 0) nb = 1;
         sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
         sa.tiles_rem = (uint32_t)(sa.n_tiles % nb);
@@ -466,14 +474,25 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             if ((rc = ensure_records(h, nb * seg_cap))) return rc;
             sa.seg_cap = (uint32_t)seg_cap; sa.starts = h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
             sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
-            if (attempt == 0 && h->pf_armed) {                      // the pre-filter beside the scan (e2s_prefilter_arm)
+            FilterArgs fa{};
+            bool fuse_now = false;
+            if (attempt == 0 && h->pf_armed) {                      // e2s_prefilter_arm
                 h->pf_armed = false;
-                if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
+                if (fused) {
+                    h->pf_inflight = false;
+                    if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa))) return rc;
+                    fuse_now = true;
+                } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
             }
             CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
             CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
-            e2s_launch_scan_seg(sa, h->xb, h->stream);
+            if (fuse_now) {
+                // (a rerun after a segment overflow scans alone: the pre-filter's list does not depend on the segments)
+                CK(hipEventRecord(h->ev[6], h->stream));            // (the pass's timing then starts at the fused kernel)
+                e2s_launch_scan_seg_fused(sa, fa, h->stream);
+                h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false;
+            } else e2s_launch_scan_seg(sa, h->xb, h->stream);
             LCHK("e2s_launch_scan_seg");
             CK(hipEventRecord(h->ev[3], h->stream));
             // k_seg_fix also evaluates the shard's boundary flags and clears the statistics buffer (fewer launches)
@@ -964,12 +983,13 @@ static int c2s_len_lo(int mcov_out, int min_len) {   // `length >= mcov_out*2` (
  * maximum length; e2s_find_candidates applies the exact bound).  Optional: without it e2s_find_candidates runs the
  * pre-filter itself. */
 // launch the pre-filter on `st` (the handle's stream, or its second stream beside the scan); est_records sizes the list
-static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st) {
-    h->pf_inflight = false;
-    const e2s_shard_desc& d = h->d;
+static bool prefilter_eligible(const e2s_ctx* h) {
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt) & 15u) == 0;
     static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;
-    if (h->records_from_file || d.lcp_bytes != 1 || !aligned || !h->bwt || filter_v1) return E2S_OK;   // nothing to start early
+    return !(h->records_from_file || h->d.lcp_bytes != 1 || !aligned || !h->bwt || filter_v1);
+}
+// the flagged-cluster list (empty, behind the reserved seed slots), the pre-filter's error word and its arguments
+static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f) {
     int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
     if (rc) return rc;
     uint64_t* mc = (uint64_t*)(h->pin_mail + 2048 + 64 * 8 + 64 * 2);
@@ -977,8 +997,16 @@ static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_r
     CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, st));
     CK(hipMemsetAsync(h->d_fl_lens, 0, E2S_SEED_SLOTS * 2, st));             // length 0 = empty slot
     CK(hipMemsetAsync(h->d_words + 20, 0, 4, st));
-    FilterArgs f;
     filter_args(h, mcov_out, c2s_len_lo(mcov_out, min_len), (int)E2S_MAX_CLUST_LEN, f);
+    return E2S_OK;
+}
+
+static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st) {
+    h->pf_inflight = false;
+    if (!prefilter_eligible(h)) return E2S_OK;                  // nothing to start early
+    FilterArgs f;
+    int rc = prefilter_setup(h, mcov_out, min_len, est_records, st, f);
+    if (rc) return rc;
     CK(hipEventRecord(h->ev[6], st));
     e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, max_workers, st);
     LCHK("e2s_launch_cluster_filter");

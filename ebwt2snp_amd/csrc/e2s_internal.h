@@ -148,6 +148,8 @@ void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* t
 void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st);
 int  e2s_scan_seg_resident_blocks(int xb);
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st);
+int  e2s_scan_seg_fused_resident_blocks();
+void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_t st);
 void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsigned long long* seg_off, uint32_t* err,
                         const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* hist_zero,
                         hipStream_t st);

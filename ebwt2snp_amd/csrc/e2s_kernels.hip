@@ -294,8 +294,17 @@ __device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
     return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xf, 0xf, false);    // wave_shr:1
 }
 
-template <int X>
-__global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
+constexpr int F2_Q = 64;                     // flagged clusters a wave queues in LDS between global reservations (pre-filter)
+// packed base counts C | G << 8 | T << 16 (added) and flags << 24 (or-ed)
+__device__ __forceinline__ u32 pf_merge(u32 x, u32 y) { return (((x & 0xFFFFFFu) + (y & 0xFFFFFFu)) & 0xFFFFFFu) | ((x | y) & 0xFF000000u); }
+
+// FUSED (X == 1 only, e2s_prefilter_arm): the pre-filter of the per-cluster pass (k_cluster_filter2 below, which
+// documents the method) runs inside the scan on the same GE / NLE / start / end planes -- the LCP is read once, the
+// stencil evaluated once; the worker additionally reads the BWT and first runs the tile before its range (WARM: no
+// record is emitted, only the pre-filter's carries are built up).  f is unused otherwise.
+template <int X, bool FUSED>
+__global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f) {
+    static_assert(!FUSED || (X == 1 && SPAN_WORDS == 16), "the fused pre-filter works on 1-byte LCPs, 64 entries per lane");
     constexpr int NR = SPAN_WORDS;
     constexpr int ES = 4 * NR / X;                           // entries per thread span
     constexpr int TILE = 64 * ES;                            // entries per wave-tile
@@ -310,7 +319,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     const uint8_t* base = (const uint8_t*)a.lcp;
     const int64_t n_prov = (int64_t)a.n_prov;
     const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
-    const u64 g_range = a.prov_lo + t0 * TILE;                  // SA position of the range's first entry
+    const u64 torg = (FUSED && t0 > 0) ? t0 - 1 : t0;           // first tile processed: offsets count from it
+    const u64 g_range = a.prov_lo + torg * TILE;                // SA position of offset 0
     const u64 seg = (u64)b * a.seg_cap;
     uint64_t* const seg_starts = a.starts + seg;                // worker-uniform bases: stores use a 32-bit record offset
     uint16_t* const seg_lens = a.lens + seg;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     // a lane reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of the wave
     // cover one 4 KiB stretch between them) plus the words just before and after its span
     // interior tile: all of its words, the word before and the word after lie inside the provided range
-    auto load_fast = [&](u64 tile, u32* W) {
+    auto load_fast = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
         const int64_t tl = (int64_t)tile * TILE;
 #ifdef E2S_ABL_NOLOAD                                            // diagnostic build: no memory reads, synthetic words (results are wrong)
         {
@@ -334,22 +344,30 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         for (int q = 0; q < NR / 4; ++q) {
             const uint4 v = *(const uint4*)(p + o + 16 * q);
             W[1 + 4 * q + 0] = v.x; W[1 + 4 * q + 1] = v.y; W[1 + 4 * q + 2] = v.z; W[1 + 4 * q + 3] = v.w;
+            if constexpr (FUSED) {
+                const uint4 w = *(const uint4*)(f.bwt + tl + o + 16 * q);
+                B[4 * q + 0] = w.x; B[4 * q + 1] = w.y; B[4 * q + 2] = w.z; B[4 * q + 3] = w.w;
+            }
         }
         W[0] = *(const u32*)(p + o - 4);
         W[NR + 1] = *(const u32*)(p + o + 4 * NR);
     };
     // the first tile of the shard and the tiles around its end: byte by byte, zero outside the provided range
-    auto load_slow = [&](u64 tile, u32* W) {
+    auto load_slow = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {                                  // (static indices: the array stays in registers)
-            u32 v = 0;
+            u32 v = 0, vb = 0;
 #pragma unroll
             for (int bt = 0; bt < 4; ++bt) {
                 const int64_t byte = i0 * X + (int64_t)(w - 1) * 4 + bt;
-                if (byte >= 0 && byte < n_prov * X) v |= (u32)base[byte] << (8 * bt);
+                if (byte >= 0 && byte < n_prov * X) {
+                    v |= (u32)base[byte] << (8 * bt);
+                    if constexpr (FUSED) vb |= (u32)f.bwt[byte] << (8 * bt);
+                }
             }
             W[w] = v;
+            if constexpr (FUSED) { if (w >= 1 && w <= NR) B[w - 1] = vb; }
         }
     };
     // one entry (0 outside the provided range), the same value in every lane
@@ -367,6 +385,23 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     // per-record stores were 16 of the kernel's 68 us)
     __shared__ uint64_t s_stage[4][SEG_STAGE];
     uint64_t* const st_rec = s_stage[threadIdx.x >> 6];
+    // pre-filter state (FUSED): see k_cluster_filter2
+    __shared__ u64 s_q[FUSED ? 4 : 1][FUSED ? F2_Q : 1];
+    u64* const q = s_q[FUSED ? (threadIdx.x >> 6) : 0];
+    u32 pf_open1 = 0, cin0 = 0, ccarry = 0, qn = 0;
+    auto queue_flush = [&]() {
+        if (qn) {
+            u64 gbase = 0;
+            if (lane == 0) gbase = atomicAdd(f.fl_count, (unsigned long long)qn);
+            gbase = __shfl(gbase, 0);
+            if (lane < qn) {
+                const u64 v = q[lane];
+                if (gbase + lane < f.fl_cap) { f.fl_starts[gbase + lane] = v & 0xFFFFFFFFFFFFull; f.fl_lens[gbase + lane] = (uint16_t)(v >> 48); }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        qn = 0;
+    };
 
     u32 run = 0;                                                // records written so far (wave-uniform)
     u32 open1 = 0;                                              // 1 + offset of the last start seen in the range (0: none yet)
@@ -377,7 +412,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     // after the first tile's loads have been issued, so that a worker pays one memory latency at its start, not two.
     u32 cb = 0;
     auto range_carry = [&]() -> u32 {
-        const int64_t r0 = (int64_t)t0 * TILE;
+        const int64_t r0 = (int64_t)torg * TILE;
         const u32 lm2 = entry_at(r0 - 2), lm1 = entry_at(r0 - 1), l0 = entry_at(r0);
         const bool gm1 = a.hge != 0 && lm1 >= a.k_u32, g0 = a.hge != 0 && l0 >= a.k_u32;
         const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
@@ -385,15 +420,15 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
     };
     // Two register sets that swap roles from tile to tile (the loop body is instantiated twice): W = the tile
     // being processed, Wn = the next one, in flight meanwhile.
-    u32 WA[NW], WB[NW];
-    auto body = [&](const u64 tile, u32* W, u32* Wn, auto prefetch) __attribute__((always_inline)) {
-        constexpr bool PF = decltype(prefetch)::value;
-        if (PF) load_fast(tile + 1, Wn);                        // in flight while this tile is processed
+    u32 WA[NW], WB[NW], BA[FUSED ? NR : 1], BB[FUSED ? NR : 1];
+    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch, auto warmup) __attribute__((always_inline)) {
+        constexpr bool PF = decltype(prefetch)::value, WARM = decltype(warmup)::value;
+        if (PF) load_fast(tile + 1, Wn, Bn);                    // in flight while this tile is processed
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
         // ---- start / end planes of the span ----
-        u64 S, E;                                               // bit e: a cluster starts / ends at entry e of the span
+        u64 S, E, GE;                                           // bit e: a cluster starts / ends at entry e of the span
         {
-            u64 GE, NLE; u32 after;
+            u64 NLE; u32 after;
             span_pred<X, NR>(W, a.kb, a.hge, GE, NLE, after);
             E = plane_end<ES>(GE, NLE, after);
             const u32 top = (u32)((GE >> (ES - 1)) & 1ull) | ((u32)((E >> (ES - 1)) & 1ull) << 1);
@@ -413,12 +448,43 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
                 S &= ~2ull;
                 E = end1 ? (E | 2ull) : (E & ~2ull);
                 if (e2v >= a.k_u32) S = end1 ? (S | 4ull) : (S & ~4ull);
+                GE |= 2ull;                                     // entry 1 belongs to the cluster opened at 0 whatever L[1] is (FUSED: "in a cluster")
             }
+        }
+        // ---- pre-filter, part 1: class planes and the lane-to-lane carry of packed base counts (k_cluster_filter2) ----
+        const u64 Sa = S, Ea = E;                               // before the window mask: the carries follow every cluster
+        u64 C = 0, G = 0, T = 0, F = 0; u32 cin = 0;
+        if constexpr (FUSED) {
+            span_bwt_classes<NR>(B, C, G, T);
+            const u64 c0 = C | T, c1 = G | T;
+            const u32 ctop = (u32)(c0 >> 63) | ((u32)(c1 >> 63) << 1);
+            const u32 cprev = wave_shr1(ctop, ccarry);
+            ccarry = (u32)__builtin_amdgcn_readlane((int)ctop, 63);
+            F = ((c0 ^ ((c0 << 1) | (u64)(cprev & 1u))) | (c1 ^ ((c1 << 1) | (u64)((cprev >> 1) & 1u)))) & GE & ~Sa;
+            const bool hasS = Sa != 0ull;
+            const int msbS = 63 - __clzll(Sa | 1ull);
+            const u64 tm = hasS ? ~((1ull << msbS) - 1ull) : ~0ull;
+            const u32 local = (u32)__popcll(C & tm) | ((u32)__popcll(G & tm) << 8) | ((u32)__popcll(T & tm) << 16) | ((F & tm) ? (1u << 25) : 0u);
+            u32 out = local;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const u32 in = wave_shr1(out, cin0);
+                out = hasS ? local : pf_merge(local, in);
+            }
+            cin = wave_shr1(out, cin0);                         // carry into this lane
+            cin0 = (u32)__builtin_amdgcn_readlane((int)out, 63);
         }
         // restrict to the owned window: only the tiles that straddle its edges (tile-uniform test, a scalar branch --
         // left per-thread the compiler if-converts the 64-bit compares into ~300 always-executed instructions)
         const int64_t tl = (int64_t)tile * TILE;
-        if (!(tl >= own_lo && tl + TILE <= end_hi && tl + TILE <= start_hi)) {
+        const bool masked = !(tl >= own_lo && tl + TILE <= end_hi && tl + TILE <= start_hi);
+        if constexpr (WARM) {
+            // the tile before the range: nothing is emitted or evaluated, the pre-filter remembers the last start
+            const u32 lsw = Sa ? (u32)(lane * ES) + (u32)(64 - __clzll(Sa)) : 0u;
+            pf_open1 = max(pf_open1, (u32)__builtin_amdgcn_readlane((int)wave_incl_max(lsw), 63));
+            return;
+        }
+        if (masked) {
             u64 ks = 0, ke = 0;
 #pragma unroll 1
             for (int f = 0; f < ES; ++f) {
@@ -436,7 +502,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         const u32 cnt = (u32)__popcll(E);
         const u32 inc = wave_incl_scan(cnt);
         const u32 tile_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
-        const u32 base_off = (u32)((tile - t0) * TILE) + lane * ES;   // offset from the range's first entry
+        const u32 base_off = (u32)((tile - torg) * TILE) + lane * ES; // offset from the first tile processed
         // the start an END without a start of its own in the lane belongs to: the last start below the lane
         const u32 ls1 = S ? base_off + (u32)(64 - __clzll(S)) : 0u;   // 1 + offset of the lane's last start
         const u32 mx = wave_incl_max(ls1);
@@ -452,6 +518,16 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
             state = ms > me ? 2u : 1u;
         }
         const u32 tile_last1 = (u32)__builtin_amdgcn_readlane((int)mx, 63);
+        // pre-filter: the last start before each lane, over ALL starts (in an edge tile the scan's are window-masked)
+        u32 pf_cur1 = 0;
+        if constexpr (FUSED) {
+            if (!masked) { pf_cur1 = max(wave_shr1(mx, 0u), pf_open1); pf_open1 = max(pf_open1, tile_last1); }
+            else {
+                const u32 m2 = wave_incl_max(Sa ? base_off + (u32)(64 - __clzll(Sa)) : 0u);
+                pf_cur1 = max(wave_shr1(m2, 0u), pf_open1);
+                pf_open1 = max(pf_open1, (u32)__builtin_amdgcn_readlane((int)m2, 63));
+            }
+        }
         // Wait for the prefetched words NOW, before the record stores: vmcnt counts loads and stores together and in
         // order, so waiting for the next tile's loads after a data-dependent number of stores would mean waiting for
         // every store to land (vmcnt(0)) once per tile.  The empty asm "uses and redefines" the registers: the compiler
@@ -460,6 +536,9 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         if (PF)
         asm volatile("" : "+v"(Wn[0]), "+v"(Wn[1]), "+v"(Wn[2]), "+v"(Wn[3]), "+v"(Wn[4]), "+v"(Wn[5]), "+v"(Wn[6]), "+v"(Wn[7]), "+v"(Wn[8]),
                           "+v"(Wn[9]), "+v"(Wn[10]), "+v"(Wn[11]), "+v"(Wn[12]), "+v"(Wn[13]), "+v"(Wn[14]), "+v"(Wn[15]), "+v"(Wn[16]), "+v"(Wn[17]));
+        if constexpr (FUSED && PF)
+        asm volatile("" : "+v"(Bn[0]), "+v"(Bn[1]), "+v"(Bn[2]), "+v"(Bn[3]), "+v"(Bn[4]), "+v"(Bn[5]), "+v"(Bn[6]), "+v"(Bn[7]),
+                          "+v"(Bn[8]), "+v"(Bn[9]), "+v"(Bn[10]), "+v"(Bn[11]), "+v"(Bn[12]), "+v"(Bn[13]), "+v"(Bn[14]), "+v"(Bn[15]));
         if (run == 0 && tile_total != 0) {                      // the range's first end (once per worker)
             if (cnt != 0 && inc == cnt) first_end = g_range + base_off + (u32)(__ffsll((long long)E) - 1);
         }
@@ -471,7 +550,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         // ones.  Staged word: (1 + SA position of the start) | length << 48.
         {
             const u32 rk0 = run + inc - cnt;
-            const u32 tile_end1 = (u32)((tile - t0 + 1) * TILE);
+            const u32 tile_end1 = (u32)((tile - torg + 1) * TILE);
             const bool plain = run + tile_total <= a.seg_cap && tile_end1 + 2u - open1 < 65536u && tile_total <= (u32)SEG_STAGE;
             auto emit_half = [&](u32 Eh, const u32 Sh, const u32 hbase, u32& rk, auto mode) {
                 constexpr int MODE = decltype(mode)::value;     // 0 plain, 1 every per-record check
@@ -546,6 +625,37 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         }
         run += tile_total;
         open1 = max(open1, tile_last1);
+        // ---- pre-filter, part 2: walk the owned ENDs of clusters that hold two different bases at all ----
+        if constexpr (FUSED) {
+            const u64 Fin = F | ((((cin >> 25) & 1u) && (GE & ~Sa & 1ull)) ? 1ull : 0ull);
+            const u64 R = GE & ~Ea;
+            u64 Ei = E & (((R + (Fin & R)) & Ea) | (Fin & Ea));     // E: the window-masked ends (own_lo <= end < end_hi)
+            if (qn > (u32)(F2_Q / 2)) queue_flush();
+            while (__ballot(Ei != 0ull)) {                          // wave-uniform: the queue position is wave state
+                const bool act = Ei != 0ull;
+                const int e = act ? __ffsll((long long)Ei) - 1 : 0;
+                Ei &= Ei - 1;
+                const u64 upto = (2ull << e) - 1ull;
+                const u64 sc = Sa & upto;
+                const bool have = sc != 0ull;
+                const int ms = 63 - __clzll(sc | 1ull);
+                const u64 rm = have ? (upto & ~((1ull << ms) - 1ull)) : upto;
+                u32 pk = (u32)__popcll(C & rm) | ((u32)__popcll(G & rm) << 8) | ((u32)__popcll(T & rm) << 16);
+                if (!have) pk = pf_merge(pk, cin) & 0xFFFFFFu;
+                const u32 st1 = have ? base_off + (u32)ms + 1u : pf_cur1;
+                const u32 len = base_off + (u32)e + 2u - st1;
+                const u32 cC = pk & 0xFFu, cG = (pk >> 8) & 0xFFu, cT = (pk >> 16) & 0xFFu, cA = len - cC - cG - cT;
+                const u32 nfreq = (cA >= f.mcov_u ? 1u : 0u) + (cC >= f.mcov_u ? 1u : 0u) + (cG >= f.mcov_u ? 1u : 0u) + (cT >= f.mcov_u ? 1u : 0u);
+                const bool pass = act && st1 != 0u && (int)len >= f.len_lo && (int)len <= f.len_hi && nfreq >= 2u;
+                const u64 pm = __ballot(pass);
+                if (pass) {
+                    const u32 idx = qn + (u32)__popcll(pm & ((1ull << lane) - 1ull));
+                    if (idx < (u32)F2_Q) q[idx] = (g_range + (u64)(st1 - 1u)) | ((u64)len << 48);
+                    else atomicOr(f.err, E2S_DEVERR_DENSE);
+                }
+                qn = min(qn + (u32)__popcll(pm), (u32)F2_Q);
+            }
+        }
     };
     // The hot loop runs over interior tiles only, two per trip (static register roles), and contains nothing but the
     // fast loader: with the byte-wise loader of the edge tiles inlined next to it the compiler's wait-count
@@ -556,19 +666,29 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a) {
         // interior tiles are [1, tfe): tile 0 has no word before it, the last ones no word after
         const u64 tfe = n_prov >= (int64_t)(TILE + EPW) ? (u64)((n_prov - EPW) / TILE) : 0ull;
         const u64 tf = min(t1, tfe);
-        auto slow_run = [&](u64 upto) { for (; tile < upto; ++tile) { load_slow(tile, WA); body(tile, WA, WB, P0); } };
+        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, P0, P0); } };
         bool have_cb = false;
-        if (tile < min(t1, (u64)1)) { cb = range_carry(); have_cb = true; }
+        if constexpr (FUSED) {
+            tile = torg;
+            if (tile < t0 && t0 < t1) {                         // the pre-filter's warm-up tile
+                if (tile >= 1 && tile < tfe) load_fast(tile, WA, BA); else load_slow(tile, WA, BA);
+                cb = range_carry(); have_cb = true;
+                body(tile, WA, BA, WB, BB, P0, P1);
+            }
+            tile = t0;
+        }
+        if (!have_cb && tile < min(t1, (u64)1)) { cb = range_carry(); have_cb = true; }
         slow_run(min(t1, (u64)1));
         if (tile < tf) {
-            load_fast(tile, WA);
+            load_fast(tile, WA, BA);
             if (!have_cb) { cb = range_carry(); have_cb = true; }
-            while (tile + 3 <= tf) { body(tile, WA, WB, P1); body(tile + 1, WB, WA, P1); tile += 2; }
-            if (tile + 2 == tf) { body(tile, WA, WB, P1); body(tile + 1, WB, WA, P0); tile += 2; }
-            else { body(tile, WA, WB, P0); tile += 1; }
+            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, P1, P0); body(tile + 1, WB, BB, WA, BA, P1, P0); tile += 2; }
+            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, P1, P0); body(tile + 1, WB, BB, WA, BA, P0, P0); tile += 2; }
+            else { body(tile, WA, BA, WB, BB, P0, P0); tile += 1; }
         }
         if (!have_cb) cb = range_carry();
         slow_run(t1);
+        if constexpr (FUSED) queue_flush();
     }
     // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
     const u64 unk_m = __ballot(unknown != 0);
@@ -1329,7 +1449,6 @@ __global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs 
 // (bit-parallel: a carry-propagating add over the interior of the runs); a worker first runs the tile before
 // its range without evaluating anything, to pick up the cluster that reaches into its range.
 // ----------------------------------------------------------------------------------------------
-constexpr int F2_Q = 64;                     // flagged clusters a wave queues in LDS between global reservations
 
 __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     constexpr int NR = 16, ES = 64, TILE = 4096, NW = NR + 2;
@@ -1876,14 +1995,20 @@ void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st) {
     if (xb == 1) launch_scan_x<1>(a, mode, st); else if (xb == 2) launch_scan_x<2>(a, mode, st); else launch_scan_x<4>(a, mode, st);
 }
 int e2s_scan_seg_resident_blocks(int xb) {                   // resident WORKERS (waves)
-    const void* fn = xb == 1 ? (const void*)k_scan_seg<1> : xb == 2 ? (const void*)k_scan_seg<2> : (const void*)k_scan_seg<4>;
+    const void* fn = xb == 1 ? (const void*)k_scan_seg<1, false> : xb == 2 ? (const void*)k_scan_seg<2, false> : (const void*)k_scan_seg<4, false>;
     return 4 * resident_blocks(fn, 256, 0);
 }
+int e2s_scan_seg_fused_resident_blocks() { return 4 * resident_blocks((const void*)k_scan_seg<1, true>, 256, 0); }
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
     const dim3 grid((a.n_blocks + 3) / 4), blk(256);           // four independent workers (waves) per block
-    if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1>), grid, blk, 0, st, a);
-    else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_scan_seg<4>), grid, blk, 0, st, a);
+    const FilterArgs f{};
+    if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1, false>), grid, blk, 0, st, a, f);
+    else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2, false>), grid, blk, 0, st, a, f);
+    else hipLaunchKernelGGL((k_scan_seg<4, false>), grid, blk, 0, st, a, f);
+}
+// the scan with the per-cluster pass's pre-filter inside (1-byte LCPs, 16-byte aligned LCP and BWT)
+void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_t st) {
+    hipLaunchKernelGGL((k_scan_seg<1, true>), dim3((a.n_blocks + 3) / 4), dim3(256), 0, st, a, f);
 }
 void e2s_launch_seg_fix(const SegArgs& a, u32* flags, u32* tailv, u64* seg_off, u32* err, const uint8_t* bwt, const void* pos,
                         const void* da, int xb, int yb, int zb, ScanMail* out, u64* hist_zero, hipStream_t st) {

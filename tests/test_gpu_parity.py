@@ -500,6 +500,29 @@ def test_chunked_prefilter_pipeline(tmp_path):
 
 
 @pytest.mark.gpu
+def test_prefilter_beside_scan_on_second_stream(tmp_path):
+    """e2s_prefilter_arm normally runs the pre-filter INSIDE the scan kernel (k_scan_seg<1, true>: what every "arm" case above
+    exercises); E2S_FUSED=0 keeps the two kernels apart, the pre-filter on the handle's second stream beside the scan.
+    The switch is read once per process: a child process runs the fuzz columns, unsharded and sharded, that way"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, pathlib, importlib.util; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, test_gpu_parity as T\n"
+        "from ebwt2snp_amd import capi\n"
+        "H = capi.Handle(0)\n"
+        "T.test_fused_streaming_fuzz_columns(H, pathlib.Path(%r), 102)\n"
+        "spec = importlib.util.spec_from_file_location('stress_columns', os.path.join(%r, 'tools', 'stress_columns.py'))\n"
+        "mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)\n"
+        "mod.run(304); mod.run(307)\n"
+        "print('TWO_STREAMS_OK')\n") % (os.path.dirname(os.path.abspath(__file__)), root, str(tmp_path), root)
+    env = dict(os.environ, E2S_FUSED="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TWO_STREAMS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
