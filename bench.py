@@ -116,11 +116,13 @@ REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
 # E2S_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path -- RCCL process group,
 # exchange, merged statistics -- with a single rank, to exercise it on a one-GPU box
 FORCE_DIST = os.environ.get("E2S_BENCH_FORCE_DIST", "0") == "1"
-# E2S_BENCH_OVERLAP=1: the timed steps arm the pre-filter before the scan (e2s_prefilter_arm): it then runs INSIDE the scan kernel
-# (k_scan_seg<1, true>; with E2S_FUSED=0 beside it on a second stream).  ~10 % more throughput; the default keeps the two kernels
-# apart so that each is measured against its own roofline, and reports the fused pipeline beside it ("fused_pipeline").
-OVERLAP = os.environ.get("E2S_BENCH_OVERLAP", "0") == "1"
+# E2S_BENCH_OVERLAP=1 (default): the timed steps arm the pre-filter before the scan (e2s_prefilter_arm): it then runs INSIDE the scan
+# kernel (k_scan_seg<1, true>; with E2S_FUSED=0 beside it on a second stream) -- one pass over the LCP, 13-18 % more throughput.
+# E2S_BENCH_OVERLAP=0 keeps the two kernels apart.  Either way the other mode is measured after the timed run and reported as
+# "other_mode", so that the separate kernels are also seen against their own rooflines.
+OVERLAP = os.environ.get("E2S_BENCH_OVERLAP", "1") == "1"
 FUSED = os.environ.get("E2S_FUSED", "1") != "0"
+SECOND_LEG = os.environ.get("E2S_BENCH_SECOND_LEG", "1") == "1"      # also measure the other mode (reported as other_mode)
 
 
 def _exchange(blob, world, dist, dev):
@@ -243,7 +245,8 @@ def cpu_baseline(blk, reads, n1, sample_entries):
         shutil.rmtree(d, ignore_errors=True)
 
 
-PMC_FILE = "profiles/round1_final_pmc_traffic.json"
+PMC_FILES = {"c2": "profiles/round1_fused_pmc_traffic.json", "c3": "profiles/round1_fused_c3_pmc_traffic.json"}
+PMC_FILE = PMC_FILES["c2"]
 
 
 def pmc_traffic(workload, kernel):
@@ -251,7 +254,7 @@ def pmc_traffic(workload, kernel):
     tools/profile.sh in separate --pmc runs of this same command, summarised by tools/profile_summary.py).  None when the
     committed profile is of another workload -- counters cannot be read from inside the timed run."""
     try:
-        j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)))
+        j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILES.get(workload, PMC_FILE))))
         if j.get("workload") != workload:
             return None
         names = (kernel,) if isinstance(kernel, str) else kernel
@@ -320,40 +323,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    info = None
-    for _ in range(a.warmup):
-        info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total)
-    scan_ms, cand_ms, scan_all_ms, hist_ms = [], [], [], []
-    barrier()
-    PHASES.clear()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total)
-        tm = h.timing()
-        scan_ms.append(tm.scan_main_ms); cand_ms.append(tm.cand_main_ms); scan_all_ms.append(tm.scan_ms); hist_ms.append(tm.hist_ms)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # the same job with the pre-filter armed before the scan (fused into the scan kernel), timed the same way after the run
-    # that `value` comes from; reported beside it, never as `value`
-    fused_elapsed, fused_scan_ms, host_phases = None, [], dict(PHASES)
-    if not OVERLAP and FUSED:
-        for _ in range(min(a.warmup, 2) + 1):
-            run_step(h, prm_base, world, rank, dist, dev, n_total=n_total, overlap=True)
+    def measure(overlap, warmup):
+        """W untimed + K timed steps of the whole job, bracketed by barrier + synchronize; max over ranks"""
+        info = None
+        for _ in range(warmup):
+            info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total, overlap=overlap)
+        r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[])
         barrier()
+        PHASES.clear()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            finfo = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total, overlap=True)
-            fused_scan_ms.append(h.timing().scan_main_ms)
+            info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total, overlap=overlap)
+            tm = h.timing()
+            r["scan_ms"].append(tm.scan_main_ms); r["cand_ms"].append(tm.cand_main_ms); r["scan_all_ms"].append(tm.scan_ms); r["hist_ms"].append(tm.hist_ms)
         barrier()
-        fused_elapsed = time.perf_counter() - t0
-        assert (finfo["n_ends"], finfo["n_cand"], finfo["mcl"]) == (info["n_ends"], info["n_cand"], info["mcl"]), "fused pipeline differs"
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            rdev = torch.device("cpu") if REHEARSAL else dev
+            t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        r.update(elapsed=elapsed, info=info, phases=dict(PHASES))
+        return r
+
+    # the timed run `value` comes from, then -- reported beside it, never as `value` -- the same job in the other mode
+    # (pre-filter inside the scan kernel / the two kernels apart, each against its own roofline)
+    prim = measure(OVERLAP, a.warmup)
+    other = measure(not OVERLAP, min(a.warmup, 2) + 1) if (FUSED and SECOND_LEG) else None
+    info = prim["info"]
+    if other is not None:
+        oi = other["info"]
+        assert (oi["n_ends"], oi["n_cand"], oi["mcl"]) == (info["n_ends"], info["n_cand"], info["mcl"]), "the two modes differ"
     if dist is not None:
         rdev = torch.device("cpu") if REHEARSAL else dev
-        t = torch.tensor([elapsed, fused_elapsed or 0.0], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0].item())
-        if fused_elapsed is not None:
-            fused_elapsed = float(t[1].item())
         cnt = torch.tensor([info["n_ends"], info["n_cand"]], dtype=torch.int64, device=rdev)
         dist.all_reduce(cnt)
         tot_ends, tot_cand = int(cnt[0].item()), int(cnt[1].item())
@@ -361,59 +363,59 @@ def main():
         tot_ends, tot_cand = info["n_ends"], info["n_cand"]
 
     if rank == 0:
-        tm = h.timing()
-        ms_step = elapsed / a.steps * 1e3
-        value = n_total * a.steps / elapsed
-        # dominant kernel: the streaming per-cluster pre-filter (k_cluster_filter2).  Algorithmic bytes per launch
-        # (DESIGN.md section 4): lcp 1 + bwt 1 per provided entry -- the kernel decides without the document array and
-        # without the cluster records.  SURVEY 8d's figure for the whole clust2snp pass (7 B/entry + 10 B/record,
-        # the reference's access pattern) is reported beside it as reference_pattern_bytes.
-        cand_avg_ms = float(np.mean(cand_ms))
-        cand_bytes = n_own * 2
         ref_pattern_bytes = n_own * 7 + info["n_ends"] * 10
-        cand_gbs = cand_bytes / (cand_avg_ms * 1e-3) / 1e9
-        scan_avg_ms = float(np.mean(scan_ms))
-        scan_bytes = n_own * 1 + info["n_ends"] * 10          # LCP read + 10 B/record written
-        scan_gbs = scan_bytes / (scan_avg_ms * 1e-3) / 1e9
-        k2_traffic, k1_traffic = pmc_traffic(a.workload, "k_cluster_filter2"), pmc_traffic(a.workload, ("k_scan_seg<1>", "k_scan_seg<1,false>"))
+
+        def rooflines(r, overlap):
+            """roofline objects of one mode.  Algorithmic bytes per launch:
+            pre-filter fused into the scan (k_scan_seg<1,true>): LCP 1 + BWT 1 per provided entry read once, 10 B per record written;
+            apart: the scan (k_scan_seg<1,false>) LCP 1 B/entry + 10 B/record, the pre-filter (k_cluster_filter2) LCP 1 + BWT 1 B/entry.
+            SURVEY 8d's figure for the reference's access pattern (7 B/entry + 10 B/record) is reported as reference_pattern_bytes."""
+            scan_avg = float(np.mean(r["scan_ms"]))
+            if overlap and FUSED:
+                fb = n_own * 2 + info["n_ends"] * 10
+                fg = fb / (scan_avg * 1e-3) / 1e9
+                tr = pmc_traffic(a.workload, "k_scan_seg<1,true>")
+                return {"roofline": {"bound": "hbm", "kernel": "k_scan_seg<1,true> (cluster scan + per-cluster pre-filter in one pass)", "achieved": fg,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fg / HBM_PEAK_GBS, "traffic": tr, "launch_ms": scan_avg,
+                                     "algorithmic_bytes": fb, "reference_pattern_bytes": ref_pattern_bytes + n_own,
+                                     "traffic_source": PMC_FILES.get(a.workload) if tr else None, "hist_ms": float(np.mean(r["hist_ms"]))}}
+            cand_avg = float(np.mean(r["cand_ms"]))
+            cand_bytes = n_own * 2
+            cand_gbs = cand_bytes / (cand_avg * 1e-3) / 1e9
+            scan_bytes = n_own * 1 + info["n_ends"] * 10
+            scan_gbs = scan_bytes / (scan_avg * 1e-3) / 1e9
+            k2_traffic, k1_traffic = pmc_traffic(a.workload, "k_cluster_filter2"), pmc_traffic(a.workload, ("k_scan_seg<1>", "k_scan_seg<1,false>"))
+            return {"roofline": {"bound": "hbm", "kernel": "k_cluster_filter2", "achieved": cand_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": cand_gbs / HBM_PEAK_GBS, "traffic": k2_traffic, "launch_ms": cand_avg, "algorithmic_bytes": cand_bytes,
+                                 "reference_pattern_bytes": ref_pattern_bytes, "traffic_source": PMC_FILES.get(a.workload) if k2_traffic else None},
+                    "roofline_scan": {"bound": "hbm", "kernel": "k_scan_seg<1,false>", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": scan_gbs / HBM_PEAK_GBS, "traffic": k1_traffic, "launch_ms": scan_avg,
+                                      "algorithmic_bytes": scan_bytes, "scan_all_kernels_ms": float(np.mean(r["scan_all_ms"])),
+                                      "hist_ms": float(np.mean(r["hist_ms"]))}}
+
+        def mode_name(overlap):
+            if not overlap:
+                return "separate kernels (E2S_BENCH_OVERLAP=0): scan, then pre-filter"
+            return ("pre-filter inside the scan kernel (e2s_prefilter_arm)" if FUSED
+                    else "pre-filter beside the scan on a second stream (E2S_FUSED=0; per-kernel times include the sharing)")
+
+        elapsed = prim["elapsed"]
         out = {
-            "metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": value, "unit": "EGSA entries/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": n_total * a.steps / elapsed, "unit": "EGSA entries/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %s2x%d reads x %dbp synthetic EGSA per GPU, %d entries/GPU, BCR widths 1/4/1"
                                    % (a.workload, ("%d copies of " % copies) if copies > 1 else "", R, L, m), "entries_total": n_total, "k": 16, "min_len": 2,
                        "parallelism": "sa-range x%d" % world, "cluster_records": tot_ends, "candidates": tot_cand,
-                       "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2),
-                       "host_phase_ms": {k2: round(v / a.steps * 1e3, 4) for k2, v in host_phases.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_cluster_filter2", "achieved": cand_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": cand_gbs / HBM_PEAK_GBS, "traffic": k2_traffic, "launch_ms": cand_avg_ms, "algorithmic_bytes": cand_bytes,
-                         "reference_pattern_bytes": ref_pattern_bytes, "traffic_source": PMC_FILE if k2_traffic else None},
-            "roofline_scan": {"bound": "hbm", "kernel": "k_scan_seg", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": scan_gbs / HBM_PEAK_GBS, "traffic": k1_traffic, "launch_ms": scan_avg_ms,
-                              "algorithmic_bytes": scan_bytes, "scan_all_kernels_ms": float(np.mean(scan_all_ms)),
-                              "hist_ms": float(np.mean(hist_ms))},
+                       "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2), "mode": mode_name(OVERLAP),
+                       "host_phase_ms": {k2: round(v / a.steps * 1e3, 4) for k2, v in prim["phases"].items()}},
         }
-        if fused_elapsed is not None:
-            fb = n_own * 2 + info["n_ends"] * 10
-            fms = float(np.mean(fused_scan_ms))
-            fg = fb / (fms * 1e-3) / 1e9
-            out["fused_pipeline"] = {
-                "what": "the same job with e2s_prefilter_arm: the pre-filter runs inside the scan kernel (E2S_BENCH_OVERLAP=1 makes this the timed mode)",
-                "value": n_total * a.steps / fused_elapsed, "unit": "EGSA entries/s", "ms_per_step": fused_elapsed / a.steps * 1e3,
-                "roofline": {"bound": "hbm", "kernel": "k_scan_seg<1,true>", "achieved": fg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": fg / HBM_PEAK_GBS, "traffic": pmc_traffic(a.workload, "k_scan_seg<1,true>"), "launch_ms": fms, "algorithmic_bytes": fb}}
-        if OVERLAP and FUSED:
-            # e2s_prefilter_arm: the pre-filter ran INSIDE the scan kernel (k_scan_seg<1, true>), which is then the dominant
-            # kernel: it reads LCP + BWT once (2 B/entry) and writes the records (10 B each)
-            fb = n_own * 2 + info["n_ends"] * 10
-            fg = fb / (scan_avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_scan_seg<1,true> (scan + pre-filter fused)", "achieved": fg, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": fg / HBM_PEAK_GBS, "traffic": None, "launch_ms": scan_avg_ms, "algorithmic_bytes": fb,
-                               "reference_pattern_bytes": ref_pattern_bytes + n_own * 1}
-            del out["roofline_scan"]
-            out["config"]["mode"] = "E2S_BENCH_OVERLAP=1: pre-filter fused into the scan kernel"
-        elif OVERLAP:
-            out["config"]["mode"] = "E2S_BENCH_OVERLAP=1 E2S_FUSED=0: pre-filter beside the scan on a second stream (per-kernel times include the sharing)"
+        out.update(rooflines(prim, OVERLAP))
+        if other is not None:
+            om = {"mode": mode_name(not OVERLAP), "value": n_total * a.steps / other["elapsed"], "unit": "EGSA entries/s",
+                  "ms_per_step": other["elapsed"] / a.steps * 1e3}
+            om.update(rooflines(other, not OVERLAP))
+            out["other_mode"] = om
         if world == 1 and a.cpu_sample > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(blk0, reads, n1_block, a.cpu_sample)

@@ -200,9 +200,10 @@ typedef struct {
  * e2s_find_candidates with the same values picks its result up (and applies the exact length bound), otherwise it
  * runs the pre-filter itself.  No-op (E2S_OK) where the streaming pass does not apply. */
 int e2s_prefilter_begin(e2s_handle h, int mcov_out, int min_len);
-/* Earlier still: armed before e2s_cluster_scan, the scan starts the pre-filter on the handle's second stream beside its
- * own kernels (the pre-filter reads LCP and BWT, not the scan's records).  Higher throughput, but the two kernels
- * then share the GPU and neither can be timed alone. */
+/* Earlier still: armed before e2s_cluster_scan, the pre-filter runs INSIDE the scan kernel (it needs the same start / end
+ * planes plus the BWT: one pass over the LCP instead of two; 1-byte LCPs, 16-byte aligned arrays -- otherwise, or with
+ * E2S_FUSED=0 in the environment, the scan starts it on the handle's second stream beside its own kernels).  What a job
+ * that runs ebwt2clust and clust2snp back to back should call; e2s_find_candidates picks the result up as above. */
 int e2s_prefilter_arm(e2s_handle h, int mcov_out);
 /* out layout: n_cand blocks of [e2s_cand_header][u32 idx0[cap]][u32 pos0[cap]][u32 idx1[cap]][u32 pos1[cap]] */
 int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand);
