@@ -56,6 +56,8 @@ struct e2s_ctx {
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
+    uint8_t* d_img = nullptr; uint8_t* d_img_scratch = nullptr; uint64_t img_cap = 0;     // `.clusters` image (e2s_stream_clusters)
+    uint8_t* pin_io[2] = {nullptr, nullptr}; uint64_t pin_io_cap = 0; hipEvent_t ev_io[2] = {nullptr, nullptr};
     bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
     bool pf_armed = false; int pf_arm_mcov = 0;                   // e2s_prefilter_arm: the next scan starts it beside itself (second stream)
     bool pf_on_stream2 = false; hipEvent_t ev_pf = nullptr;
@@ -184,6 +186,9 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
     hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_size8); hipFree(h->d_slot_off8);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
+    hipFree(h->d_img); hipFree(h->d_img_scratch);
+    for (auto& p : h->pin_io) if (p) hipHostFree(p);
+    for (auto& e : h->ev_io) if (e) hipEventDestroy(e);
     if (h->ev_wait) hipEventDestroy(h->ev_wait);
     if (h->ev_pf) hipEventDestroy(h->ev_pf);
     for (auto& e : h->ev_chunk) if (e) hipEventDestroy(e);
@@ -740,30 +745,92 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
     return E2S_OK;
 }
 
+// The `.clusters` image (append_entry's filter applied, 10 bytes per record) is packed on the GPU and leaves through two
+// pinned staging buffers: the copy of one chunk runs while the sink consumes the previous one.
+static int pack_image(e2s_ctx* h, uint64_t* n_records) {
+    *n_records = 0;
+    if (!h->n_rec) return E2S_OK;
+    const uint64_t* ds; const uint16_t* dl;
+    int rc = records_contiguous(h, &ds, &dl);
+    if (rc) return rc;
+    const uint64_t nb = e2s_pack_clusters_blocks(h->n_rec);
+    if (h->n_rec > h->img_cap) {
+        hipFree(h->d_img); hipFree(h->d_img_scratch); h->d_img = nullptr; h->d_img_scratch = nullptr; h->img_cap = 0;
+        CK(hipMalloc((void**)&h->d_img, h->n_rec * 10 + 16));
+        CK(hipMalloc((void**)&h->d_img_scratch, nb * 12 + 64));
+        h->img_cap = h->n_rec;
+    }
+    uint64_t* prefix = (uint64_t*)h->d_img_scratch;
+    uint32_t* cnt = (uint32_t*)(prefix + nb + 1);
+    e2s_launch_pack_clusters((const unsigned long long*)ds, dl, h->n_rec, h->min_len, cnt, (unsigned long long*)prefix, h->d_img,
+                             (unsigned long long*)(h->d_scalars + 220), h->stream);
+    LCHK("e2s_launch_pack_clusters");
+    uint64_t* mb = (uint64_t*)(h->pin_mail + 3080);
+    CK(hipMemcpyAsync(mb, h->d_scalars + 220, 8, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    *n_records = *mb;
+    return E2S_OK;
+}
+
+static int stream_image(e2s_ctx* h, uint64_t bytes, e2s_byte_sink sink, void* user) {
+    constexpr uint64_t CHUNK = 4000000;                         // a whole number of records; pinning the staging buffers costs ~1 ms per MB
+    const uint64_t want = std::min<uint64_t>(bytes, CHUNK);
+    if (want > h->pin_io_cap) {
+        for (auto& p : h->pin_io) { if (p) hipHostFree(p); p = nullptr; }
+        h->pin_io_cap = 0;
+        for (auto& p : h->pin_io) CK(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
+        h->pin_io_cap = want;
+    }
+    for (auto& e : h->ev_io) if (!e) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint64_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
+    auto issue = [&](uint64_t c) -> hipError_t {
+        const uint64_t off = c * CHUNK, len = std::min<uint64_t>(CHUNK, bytes - off);
+        hipError_t e = hipMemcpyAsync(h->pin_io[c & 1], h->d_img + off, len, hipMemcpyDeviceToHost, h->stream);
+        return e == hipSuccess ? hipEventRecord(h->ev_io[c & 1], h->stream) : e;
+    };
+    if (n_chunks) CK(issue(0));
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        CK(hipEventSynchronize(h->ev_io[c & 1]));
+        if (c + 1 < n_chunks) CK(issue(c + 1));                 // into the other buffer, while the sink works on this one
+        const uint64_t off = c * CHUNK, len = std::min<uint64_t>(CHUNK, bytes - off);
+        if (sink && sink(user, h->pin_io[c & 1], (size_t)len) != 0) { hipStreamSynchronize(h->stream); return fail(h, E2S_ERR_IO, "the byte sink reported an error"); }
+    }
+    return E2S_OK;
+}
+
+extern "C" int e2s_stream_clusters(e2s_handle h, e2s_byte_sink sink, void* user, uint64_t* n_records) {
+    dbg_entry("e2s_stream_clusters");
+    if (!h || !sink) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
+    CK(hipSetDevice(h->device));
+    const bool timing = getenv("E2S_CLI_TIMING") != nullptr;
+    auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t0 = now();
+    uint64_t w = 0;
+    int rc = pack_image(h, &w);
+    if (rc) return rc;
+    if (n_records) *n_records = w;
+    const double t1 = now();
+    rc = stream_image(h, w * 10, sink, user);
+    if (timing) fprintf(stderr, "[timing]   records: packed on the GPU %.2f ms, streamed to the sink %.2f ms\n", t1 - t0, now() - t1);
+    return rc;
+}
+
 extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records, uint64_t* n_records) {
     dbg_entry("e2s_fetch_clusters");
     if (!h || !n_records) return E2S_ERR_ARG;
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
     CK(hipSetDevice(h->device));
-    std::vector<uint64_t> s(h->n_rec);
-    std::vector<uint16_t> l(h->n_rec);
-    if (h->n_rec) {
-        const uint64_t* ds; const uint16_t* dl;
-        int rc = records_contiguous(h, &ds, &dl);
-        if (rc) return rc;
-        CK(hipMemcpy(s.data(), ds, h->n_rec * 8, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(l.data(), dl, h->n_rec * 2, hipMemcpyDeviceToHost));
-    }
     uint64_t w = 0;
-    uint8_t* o = (uint8_t*)out;
-    for (uint64_t i = 0; i < h->n_rec; ++i) {
-        if ((int)l[i] >= h->min_len) {                              // append_entry, ebwt2clust.cpp:56
-            if (o && w < cap_records) { memcpy(o + w * 10, &s[i], 8); memcpy(o + w * 10 + 8, &l[i], 2); }
-            ++w;
-        }
-    }
+    int rc = pack_image(h, &w);
+    if (rc) return rc;
     *n_records = w;
-    return (o && w > cap_records) ? E2S_ERR_CAPACITY : E2S_OK;
+    if (!out) return E2S_OK;
+    struct Dst { uint8_t* p; } dst{(uint8_t*)out};
+    auto copy = [](void* user, const void* data, size_t bytes) -> int { Dst* d = (Dst*)user; memcpy(d->p, data, bytes); d->p += bytes; return 0; };
+    rc = stream_image(h, std::min<uint64_t>(w, cap_records) * 10, copy, &dst);
+    if (rc) return rc;
+    return w > cap_records ? E2S_ERR_CAPACITY : E2S_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -141,6 +141,9 @@ void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsign
 void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st);
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);
+unsigned long long e2s_pack_clusters_blocks(unsigned long long n);
+void e2s_launch_pack_clusters(const unsigned long long* starts, const uint16_t* lens, unsigned long long n, int min_len, uint32_t* cnt,
+                              unsigned long long* prefix, uint8_t* out, unsigned long long* total, hipStream_t st);
 #define E2S_WRAP_CAP 1024
 void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* tile_fix_end,
                          const unsigned long long* starts, uint16_t* lens, unsigned long long cap, const uint32_t* flags,

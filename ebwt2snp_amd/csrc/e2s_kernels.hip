@@ -921,6 +921,53 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const u32* cnt, u64* prefix,
     for (u64 i = lo; i < hi; ++i) { prefix[i] = run; run += cnt[i]; }
 }
 
+// ---- `.clusters` file image on the device (append_entry, ebwt2clust.cpp:54-63): the records with length >= min_len, packed
+// [start:u64][length:u16] 10 bytes each, in order.  Count per 4096 records, k_tile_scan, then write through LDS.
+constexpr int PK_PER = 16, PK_BLOCK = 256 * PK_PER;
+__global__ __launch_bounds__(256) void k_pack_count(const uint16_t* lens, u64 n, int min_len, u32* cnt) {
+    __shared__ u32 s_c;
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    const u64 i0 = (u64)blockIdx.x * PK_BLOCK + (u64)threadIdx.x * PK_PER;
+    u32 c = 0;
+    for (int j = 0; j < PK_PER; ++j) if (i0 + j < n && (int)lens[i0 + j] >= min_len) ++c;
+    for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_c, c);
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_c;
+}
+__global__ __launch_bounds__(256) void k_pack_write(const u64* starts, const uint16_t* lens, u64 n, int min_len, const u64* prefix, const u32* cnt,
+                                                    u32 n_blocks, uint16_t* out, u64* total) {
+    __shared__ uint16_t s_img[PK_BLOCK * 5];
+    __shared__ u32 s_w[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u64 i0 = (u64)blockIdx.x * PK_BLOCK + (u64)tid * PK_PER;
+    u32 c = 0;
+    for (int j = 0; j < PK_PER; ++j) if (i0 + j < n && (int)lens[i0 + j] >= min_len) ++c;
+    u32 inc = c;                                                // inclusive scan over the block
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if (lane >= (u32)o) inc += v; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    u32 r = inc - c;
+    for (u32 w = 0; w < wave; ++w) r += s_w[w];
+    for (int j = 0; j < PK_PER; ++j) {
+        if (i0 + j < n) {
+            const uint16_t l = lens[i0 + j];
+            if ((int)l >= min_len) {
+                const u64 st = starts[i0 + j];
+                uint16_t* o = s_img + (size_t)r * 5;
+                o[0] = (uint16_t)st; o[1] = (uint16_t)(st >> 16); o[2] = (uint16_t)(st >> 32); o[3] = (uint16_t)(st >> 48); o[4] = l;
+                ++r;
+            }
+        }
+    }
+    __syncthreads();
+    const u32 m = cnt[blockIdx.x] * 5u;
+    uint16_t* dst = out + prefix[blockIdx.x] * 5ull;
+    for (u32 i = tid; i < m; i += 256u) dst[i] = s_img[i];
+    if (blockIdx.x == n_blocks - 1 && tid == 0) *total = prefix[blockIdx.x] + cnt[blockIdx.x];
+}
+
 __global__ void k_shard_flags(ScanArgs a, u32 xb) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, xb, a.flags, a.tailv);
@@ -2020,6 +2067,16 @@ void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_start
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, u64* out_last, hipStream_t st) {
     const unsigned want = (n_blocks + 15u) / 16u;                 // 16 waves per block, a segment per wave and trip
     hipLaunchKernelGGL(k_hist_seg, dim3(want < 256u ? (want ? want : 1u) : 256u), dim3(1024), 0, st, lens, desc, seg_cap, n_blocks, min_len, out, out_last);
+}
+u64 e2s_pack_clusters_blocks(u64 n) { return (n + PK_BLOCK - 1) / PK_BLOCK; }
+// scratch: cnt[blocks] (u32) and prefix[blocks] (u64); out: 10 bytes per record; total: records written
+void e2s_launch_pack_clusters(const u64* starts, const uint16_t* lens, u64 n, int min_len, u32* cnt, u64* prefix, uint8_t* out, u64* total,
+                              hipStream_t st) {
+    const u64 nb = e2s_pack_clusters_blocks(n);
+    if (nb == 0) { hipMemsetAsync(total, 0, 8, st); return; }
+    hipLaunchKernelGGL(k_pack_count, dim3((unsigned)nb), dim3(256), 0, st, lens, n, min_len, cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, nb);
+    hipLaunchKernelGGL(k_pack_write, dim3((unsigned)nb), dim3(256), 0, st, starts, lens, n, min_len, prefix, cnt, (u32)nb, (uint16_t*)out, total);
 }
 void e2s_launch_tile_scan(const u32* cnt, u64* prefix, u64 n, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, n);

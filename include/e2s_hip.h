@@ -135,6 +135,11 @@ int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int rank);
 int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_records);
 /* Packed 10-byte {u64 start; u16 length} records of this shard (ebwt2clust.cpp:58-59), ascending. */
 int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records, uint64_t* n_records);
+/* The same bytes handed to a sink chunk by chunk (whole records per call, in file order) straight out of pinned staging
+ * buffers, the next chunk's copy running meanwhile: what the ebwt2clust executable writes its output file with.  The sink
+ * returns 0 to continue; anything else stops the stream (E2S_ERR_IO). */
+typedef int (*e2s_byte_sink)(void* user, const void* data, size_t bytes);
+int e2s_stream_clusters(e2s_handle h, e2s_byte_sink sink, void* user, uint64_t* n_records);
 
 /* ---- clust2snp: per-cluster pass ---------------------------------------------------------- */
 /* Use a .clusters file instead of the device-resident scan result (stand-alone clust2snp).

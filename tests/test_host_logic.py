@@ -252,3 +252,42 @@ def test_host_tail_fasta_layouts(tmp_path):
         out = str(tmp_path / (variant + ".product.snp"))
         capi.snp_from_candidates(_pack_candidates(cands, 20), len(cands), 20, q, out)
         assert open(out, "rb").read() == open(IO.snp_out_path(q), "rb").read() == goldens.golden_snp(meta)
+
+
+@pytest.mark.parametrize("case", ["tiny_bcr", "c1_bcr"])
+def test_host_tail_threads_and_parallel_fasta(case, tmp_path, monkeypatch):
+    """the tail with worker threads (consensus per candidate; the FASTA cut into pieces at line starts) gives the bytes of the
+    single-threaded reference whatever the thread count and the FASTA layout: one line per read, wrapped at 37 and at 1
+    base per line, no final newline, CRLF line ends -- and layouts the piece-wise parser must hand back to the sequential
+    restatement of get_reads: a header directly after a header, a header as the last line"""
+    meta = [m for m in goldens.e2e_cases() if m["name"] == case][0]
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    assert O.ebwt2clust(p)[0] == 0
+    rc, cands, _ = O.candidates(p, O.c2s_opts(n1))
+    assert rc == 0 and cands
+    rl = [bytes(r).decode() for r in reads]
+    layouts = {}
+    for name, width in (("plain", None), ("w37", 37), ("w1", 1)):
+        q = str(tmp_path / (name + ".fasta"))
+        IO.write_fasta(q, rl) if width is None else IO.write_fasta(q, rl, width=width)
+        layouts[name] = open(q, "rb").read()
+    layouts["nonl"] = layouts["w37"][:-1]
+    layouts["crlf"] = layouts["plain"].replace(b"\n", b"\r\n")
+    layouts["tail_header"] = layouts["plain"] + b">one more header\n"
+    layouts["double_header"] = layouts["w37"] + b">empty\n>last\nACGT\n"
+    for name, data in layouts.items():
+        q = str(tmp_path / (name + ".fasta"))
+        open(q, "wb").write(data)
+        for ext in (".out", ".out.lcp", ".out.pairSA", ".clusters"):
+            if not os.path.exists(q + ext):
+                os.link(p + ext, q + ext)
+        assert O.clust2snp(q, O.c2s_opts(n1))[0] == 0, name
+        want = open(IO.snp_out_path(q), "rb").read()
+        assert len(want) > 0
+        for threads in ("1", "3", "8"):
+            monkeypatch.setenv("E2S_TAIL_THREADS", threads)
+            monkeypatch.setenv("E2S_TAIL_PAR_MIN_BYTES", "1")
+            out = str(tmp_path / ("%s.t%s.snp" % (name, threads)))
+            capi.snp_from_candidates(_pack_candidates(cands, 20), len(cands), 20, q, out)
+            assert open(out, "rb").read() == want, (name, threads)

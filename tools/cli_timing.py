@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""development aid: phase times of bin/clust2snp on a 10^8-entry sample (the files bench.py's cpu_baseline uses)"""
+"""development aid: phase times of bin/ebwt2clust and bin/clust2snp (E2S_CLI_TIMING=1) on files written here:
+   tools/cli_timing.py [entries=10^8] [reads=10^6] [len=100] [copies=1]   (copies > 1: the block laid end to end, bench.py's c3)"""
 import os, subprocess, sys, tempfile, shutil, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,7 +8,14 @@ import bench
 from ebwt2snp_amd import egsa_io as IO
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000000
 dev = torch.device("cuda", 0)
-reads, n1, blk = bench.build_block(1000000, 100, dev)
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+copies = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+reads, n1, blk = bench.build_block(R, L, dev)
+if copies > 1:
+    reads = torch.cat([reads[:n1].repeat(copies, 1), reads[n1:].repeat(copies, 1)])      # read ids as tile_block numbers them
+    blk, n1 = bench.tile_block(blk, n1, copies)
+n = min(n, blk["lcp"].numel())
 d = tempfile.mkdtemp(prefix="e2s_cli_")
 try:
     p = os.path.join(d, "reads.fasta")
