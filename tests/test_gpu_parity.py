@@ -351,12 +351,14 @@ def test_fused_streaming_candidates_equal_oracle(H, tmp_path, case):
     kw = dict(k=case.get("k", 0), m=case.get("m", 0), mcov=case.get("mcov", 0), L=case.get("Lc", 0), R=case.get("Rc", 0),
               c=case.get("c", 0), p=case.get("p", 0.0))
     oc, omcl = _oracle_candidates(tmp_path, reads.numpy(), en, n1, xyz=xyz, **kw)
-    got, mcl = _fused_candidates(H, en, n1, k=kw["k"] or 16, m=kw["m"] or 2, mcov=kw["mcov"] or 5, L=kw["L"] or 31,
-                                 R=kw["R"] or 30, c=kw["c"] or 20, p=kw["p"] or 0.99, xyz=xyz)
-    assert mcl == omcl and len(got) == len(oc) and len(oc) > 0
-    for a, b in zip(got, oc):
-        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
-            assert a[key] == b[key]
+    # pre-filter inside find_candidates / started after the scan / armed before it (inside the scan kernel where the widths allow)
+    for early in (False, True, "arm"):
+        got, mcl = _fused_candidates(H, en, n1, k=kw["k"] or 16, m=kw["m"] or 2, mcov=kw["mcov"] or 5, L=kw["L"] or 31,
+                                     R=kw["R"] or 30, c=kw["c"] or 20, p=kw["p"] or 0.99, xyz=xyz, early=early)
+        assert mcl == omcl and len(got) == len(oc) and len(oc) > 0, early
+        for a, b in zip(got, oc):
+            for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+                assert a[key] == b[key], early
 
 
 def test_fused_streaming_adversarial(H, tmp_path):
@@ -410,20 +412,22 @@ def test_fused_streaming_adversarial(H, tmp_path):
     en = dict(text=text, suff=suff, lcp=lcp, bwt=bwt)
     reads = np.full((2000, 100), 65, dtype=np.uint8)
     oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000)
-    got, mcl = _fused_candidates(H, en, 1000, early=True)
-    assert mcl == omcl and len(oc) > 150
-    assert len(got) == len(oc)
-    for a, b in zip(got, oc):
-        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
-            assert a[key] == b[key]
+    assert len(oc) > 150
+    for early in (True, "arm", False):
+        got, mcl = _fused_candidates(H, en, 1000, early=early)
+        assert mcl == omcl and len(got) == len(oc), early
+        for a, b in zip(got, oc):
+            for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+                assert a[key] == b[key], early
     # the same without the dense stretch: stays on the streaming pass
     lcp[200000:230000] = 0
     oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000, tag="o2")
-    got, mcl = _fused_candidates(H, en, 1000)
-    assert mcl == omcl and len(got) == len(oc) > 150
-    for a, b in zip(got, oc):
-        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
-            assert a[key] == b[key]
+    for early in (False, "arm"):
+        got, mcl = _fused_candidates(H, en, 1000, early=early)
+        assert mcl == omcl and len(got) == len(oc) > 150, early
+        for a, b in zip(got, oc):
+            for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+                assert a[key] == b[key], early
 
 
 @pytest.mark.gpu
