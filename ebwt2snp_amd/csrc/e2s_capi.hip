@@ -30,14 +30,14 @@ struct e2s_ctx {
     std::vector<void*> owned;
     // scan state
     uint64_t* d_starts = nullptr; uint16_t* d_lens = nullptr; uint64_t cap = 0;
-    uint64_t* d_tile_state = nullptr; uint64_t* d_tile_fix = nullptr; uint64_t* d_tile_fix_end = nullptr; uint32_t* d_tile_count = nullptr; uint64_t* d_tile_prefix = nullptr;
+    uint64_t* d_tile_fix = nullptr; uint64_t* d_tile_fix_end = nullptr; uint32_t* d_tile_count = nullptr; uint64_t* d_tile_prefix = nullptr;
     uint64_t* d_wrap = nullptr;                  // [E2S_WRAP_CAP] ranks of records whose true length wrapped the u16
     std::vector<uint64_t> wrap_ranks; bool wrap_overflow = false;
     uint64_t first_end_pos = E2S_NONE; bool first_wrapped = false;
     uint64_t* d_fl_starts = nullptr; uint16_t* d_fl_lens = nullptr; uint64_t fl_cap = 0; uint64_t n_flagged = 0;
     uint64_t tiles_cap = 0;
     uint64_t* d_scalars = nullptr;               // [0] total_ends  [1] cand_count  [2..] hist (153)
-    uint32_t* d_words = nullptr;                 // [0] tile_counter [1] err [2,3] flags [4,5] tailv
+    uint32_t* d_words = nullptr;                 // [1] err [2..4] flags [8,9] tailv [12] wrap count [20] pre-filter err
     bool scanned = false, stitched = false, records_from_file = false;
     int k = 16, min_len = 2;
     uint64_t n_ends = 0, n_rec = 0, n_closed = 0;
@@ -147,7 +147,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
 
 static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st);
 static bool prefilter_eligible(const e2s_ctx* h);
-static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f);
+static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words);
 
 // Wait for the handle's stream with a short spin on an event before falling back to the blocking wait: the two
 // waits of a job (after the scan, after the per-cluster pass) sit on its critical path, and the blocking wait's
@@ -178,7 +178,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     release_shard(h);
-    hipFree(h->d_starts); hipFree(h->d_lens); hipFree(h->d_tile_state); hipFree(h->d_tile_fix);
+    hipFree(h->d_starts); hipFree(h->d_lens); hipFree(h->d_tile_fix);
     hipFree(h->d_tile_count); hipFree(h->d_tile_prefix); hipFree(h->d_scalars); hipFree(h->d_words); hipFree(h->d_cand);
     hipFree(h->d_tile_fix_end); hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
     if (h->pin_cand) hipHostFree(h->pin_cand);
@@ -369,9 +369,8 @@ static int ensure_records(e2s_ctx* h, uint64_t cap) {
 
 static int ensure_tiles(e2s_ctx* h, uint64_t n_tiles) {
     if (n_tiles <= h->tiles_cap) return E2S_OK;
-    hipFree(h->d_tile_state); hipFree(h->d_tile_fix); hipFree(h->d_tile_fix_end); hipFree(h->d_tile_count); hipFree(h->d_tile_prefix);
+    hipFree(h->d_tile_fix); hipFree(h->d_tile_fix_end); hipFree(h->d_tile_count); hipFree(h->d_tile_prefix);
     h->tiles_cap = 0;
-    CK(hipMalloc((void**)&h->d_tile_state, n_tiles * 8));
     CK(hipMalloc((void**)&h->d_tile_fix, n_tiles * 8));
     CK(hipMalloc((void**)&h->d_tile_fix_end, n_tiles * 8));
     CK(hipMalloc((void**)&h->d_tile_count, n_tiles * 4));
@@ -431,7 +430,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     a.kb = h->xb == 1 ? (a.k_u32 & 0xFF) * 0x01010101u : h->xb == 2 ? (a.k_u32 & 0xFFFF) * 0x00010001u : a.k_u32;
     a.total_ends = h->d_scalars + 0;
     a.first_end_pos = h->d_scalars + 3;
-    a.tile_counter = h->d_words + 0; a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
+    a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
     int rc;
     ScanMail mail{};
 
@@ -485,11 +484,11 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
                 h->pf_armed = false;
                 if (fused) {
                     h->pf_inflight = false;
-                    if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa))) return rc;
+                    if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa, true))) return rc;
                     fuse_now = true;
                 } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
             }
-            CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
+            if (!fuse_now) CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
             CK(hipEventRecord(h->ev[0], h->stream));
             CK(hipEventRecord(h->ev[2], h->stream));
             if (fuse_now) {
@@ -547,8 +546,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         if (a.n_tiles > 0x7FFFFFFFull) return fail(h, E2S_ERR_ARG, "shard too large for one launch");
         if ((rc = ensure_tiles(h, a.n_tiles))) return rc;
         uint64_t want = std::max<uint64_t>(h->cap, d.n_entries / 8 + 4096);
-        a.spin_limit = 1u << 22;
-        a.tile_fix = h->d_tile_fix; a.tile_fix_end = h->d_tile_fix_end; a.tile_state = h->d_tile_state; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
+        a.tile_fix = h->d_tile_fix; a.tile_fix_end = h->d_tile_fix_end; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((rc = ensure_records(h, want))) return rc;
             a.starts = h->d_starts; a.lens = h->d_lens; a.cap = h->cap;
@@ -1056,14 +1054,15 @@ static bool prefilter_eligible(const e2s_ctx* h) {
     return !(h->records_from_file || h->d.lcp_bytes != 1 || !aligned || !h->bwt || filter_v1);
 }
 // the flagged-cluster list (empty, behind the reserved seed slots), the pre-filter's error word and its arguments
-static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f) {
+static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words = false) {
     int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
     if (rc) return rc;
-    uint64_t* mc = (uint64_t*)(h->pin_mail + 2048 + 64 * 8 + 64 * 2);
-    *mc = E2S_SEED_SLOTS;                                       // the list starts behind the reserved slots
-    CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, st));
-    CK(hipMemsetAsync(h->d_fl_lens, 0, E2S_SEED_SLOTS * 2, st));             // length 0 = empty slot
-    CK(hipMemsetAsync(h->d_words + 20, 0, 4, st));
+    // one launch: the list starts behind the reserved seed slots (length 0 = empty slot), the pre-filter's error word is
+    // cleared -- and, for the scan that carries the pre-filter, the scan's words as well
+    static_assert(E2S_SEED_SLOTS <= 256, "k_phase_init");
+    e2s_launch_phase_init((unsigned long long*)(h->d_scalars + 2), E2S_SEED_SLOTS, h->d_fl_lens, (uint32_t)E2S_SEED_SLOTS, h->d_words + 20, 1,
+                          scan_words ? h->d_words : nullptr, 16, st);
+    LCHK("e2s_launch_phase_init");
     filter_args(h, mcov_out, c2s_len_lo(mcov_out, min_len), (int)E2S_MAX_CLUST_LEN, f);
     return E2S_OK;
 }
@@ -1072,7 +1071,7 @@ static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_r
     h->pf_inflight = false;
     if (!prefilter_eligible(h)) return E2S_OK;                  // nothing to start early
     FilterArgs f;
-    int rc = prefilter_setup(h, mcov_out, min_len, est_records, st, f);
+    int rc = prefilter_setup(h, mcov_out, min_len, est_records, st, f, false);
     if (rc) return rc;
     CK(hipEventRecord(h->ev[6], st));
     e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, max_workers, st);
@@ -1172,10 +1171,12 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         // a pre-filter launched ahead (e2s_prefilter_begin) with the same -m stands in for the first attempt's own
         const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
         h->pf_inflight = false;
-        CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
-        CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
         if (!use_pf) CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));     // (an early pre-filter may have set its error bits)
         if (use_pf && h->pf_on_stream2) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // it ran on the second stream
+        if (!streaming) {
+            CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
+            CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
+        }
         if (streaming) {
             // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
             std::vector<uint64_t> ss; std::vector<uint16_t> sl;
@@ -1194,17 +1195,9 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096 + E2S_SEED_SLOTS));
                 if (rc) return rc;
             }
-            {   // seeds travel through the pinned mailbox (asynchronous copies) into the reserved head of the list
-                uint64_t* ms = (uint64_t*)(h->pin_mail + 2048); uint16_t* ml = (uint16_t*)(h->pin_mail + 2048 + 64 * 8);
-                uint64_t* mc = (uint64_t*)(h->pin_mail + 2048 + 64 * 8 + 64 * 2);
-                for (uint64_t t = 0; t < E2S_SEED_SLOTS; ++t) { ms[t] = t < nseed ? ss[t] : 0; ml[t] = t < nseed ? sl[t] : 0; }   // length 0 = empty
-                CK(hipMemcpyAsync(h->d_fl_starts, ms, E2S_SEED_SLOTS * 8, hipMemcpyHostToDevice, h->stream));
-                CK(hipMemcpyAsync(h->d_fl_lens, ml, E2S_SEED_SLOTS * 2, hipMemcpyHostToDevice, h->stream));
-                if (!use_pf) {
-                    *mc = E2S_SEED_SLOTS;
-                    CK(hipMemcpyAsync(h->d_scalars + 2, mc, 8, hipMemcpyHostToDevice, h->stream));
-                }
-            }
+            // seeds sit in the pinned mailbox; k_cand_init (below, one launch with the pass's counters) reads them from there
+            uint64_t* ms = (uint64_t*)(h->pin_mail + 2048); uint16_t* ml = (uint16_t*)(h->pin_mail + 2048 + 64 * 8);
+            for (uint64_t t = 0; t < E2S_SEED_SLOTS; ++t) { ms[t] = t < nseed ? ss[t] : 0; ml[t] = t < nseed ? sl[t] : 0; }   // length 0 = empty
             FilterArgs f;
             filter_args(h, p->mcov_out, a.len_lo, a.len_hi, f);
             f.kr_hge = (a.k_right_u > 0xFFull) ? 0u : 0x80808080u;                 // (first formulation only)
@@ -1230,7 +1223,13 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
                 a.host_stream = (uint8_t*)dev_pin; a.stream8_cap = rec_bytes / 8; a.slot_off8 = h->d_slot_off8;
                 a.stream8_count = (unsigned long long*)(h->d_scalars + 6);
-                CK(hipMemsetAsync(h->d_scalars + 6, 0, 8, h->stream));
+                void* dev_mail = nullptr;
+                CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
+                e2s_launch_cand_init((unsigned long long*)(h->d_scalars + 1), a.stream8_count, h->d_words + 1,
+                                     (const unsigned long long*)((uint8_t*)dev_mail + 2048), (const uint16_t*)((uint8_t*)dev_mail + 2048 + 64 * 8),
+                                     (uint32_t)E2S_SEED_SLOTS, (unsigned long long*)h->d_fl_starts, h->d_fl_lens,
+                                     (unsigned long long*)(h->d_scalars + 2), !use_pf, h->stream);
+                LCHK("e2s_launch_cand_init");
             }
             const bool defw = d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1;
             static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;   // the first formulation, kept for cross-checks

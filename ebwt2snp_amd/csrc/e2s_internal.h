@@ -11,7 +11,6 @@
 #define E2S_MAX_CLUST_LEN_K 150
 
 // device-side error bits
-#define E2S_DEVERR_SPIN   1u   // (reserved: wait expired in an earlier single-pass variant)
 #define E2S_DEVERR_REMOTE 2u   // a cluster's entries are not resident in this shard
 #define E2S_DEVERR_SEGFULL 8u  // an output segment of the segmented scan overflowed (rerun with larger segments)
 #define E2S_DEVERR_DENSE  4u   // a 4096-entry window holds more clusters than the LDS slots (fall back)
@@ -41,10 +40,6 @@ struct ScanArgs {
     uint64_t* tile_fix;       // [n_tiles], preset to ~0: rank of the tile's record whose start lies in an earlier tile
     uint64_t* tile_fix_end;   // [n_tiles]: that record's end position
     uint64_t* first_end_pos;  // SA position of the shard's first end (preset ~0)
-    // workspace of an earlier single-pass variant (unused)
-    uint64_t* tile_state;     // [n_tiles], preset to 0
-    uint32_t* tile_counter;   // preset to 0
-    uint32_t spin_limit;
     // MODE 1 / 2
     uint32_t* tile_count;
     const uint64_t* tile_prefix;
@@ -138,6 +133,11 @@ struct FilterArgs {
 void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
 void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
 void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st);
+void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
+                           uint32_t* w1, uint32_t n1, hipStream_t st);   // n_lens, n0, n1 <= 256
+void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* stream8_count, uint32_t* err, const unsigned long long* seed_starts,
+                          const uint16_t* seed_lens, uint32_t n_seed_slots, unsigned long long* fl_starts, uint16_t* fl_lens,
+                          unsigned long long* fl_count, bool set_fl_count, hipStream_t st);   // n_seed_slots <= 256
 void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st);
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);

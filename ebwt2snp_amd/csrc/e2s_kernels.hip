@@ -2145,6 +2145,32 @@ void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsign
     a.w_per = (uint32_t)(a.w_tiles / nb); a.w_rem = (uint32_t)(a.w_tiles % nb); a.w_blocks = (uint32_t)nb;
     hipLaunchKernelGGL(k_cluster_filter2, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, a);
 }
+// one launch instead of a handful of tiny memsets / copies before a phase (each costs a few microseconds of stream time)
+__global__ void k_phase_init(u64* count, u64 count_value, uint16_t* lens, u32 n_lens, u32* w0, u32 n0, u32* w1, u32 n1) {
+    const u32 t = threadIdx.x;
+    if (t == 0 && count) *count = count_value;
+    if (lens && t < n_lens) lens[t] = 0;
+    if (w0 && t < n0) w0[t] = 0;
+    if (w1 && t < n1) w1[t] = 0;
+}
+// the per-cluster pass's counters cleared and the seed clusters (read from the pinned mailbox) placed into the reserved head
+// of the flagged list, in one launch
+__global__ void k_cand_init(u64* cand_count, u64* stream8_count, u32* err, const u64* seed_starts, const uint16_t* seed_lens, u32 n_seed_slots,
+                            u64* fl_starts, uint16_t* fl_lens, u64* fl_count, u32 set_fl_count) {
+    const u32 t = threadIdx.x;
+    if (t == 0) { *cand_count = 0; if (stream8_count) *stream8_count = 0; *err = 0; if (set_fl_count) *fl_count = n_seed_slots; }
+    if (fl_starts && t < n_seed_slots) { fl_starts[t] = seed_starts[t]; fl_lens[t] = seed_lens[t]; }
+}
+void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* stream8_count, uint32_t* err, const unsigned long long* seed_starts,
+                          const uint16_t* seed_lens, uint32_t n_seed_slots, unsigned long long* fl_starts, uint16_t* fl_lens,
+                          unsigned long long* fl_count, bool set_fl_count, hipStream_t st) {
+    hipLaunchKernelGGL(k_cand_init, dim3(1), dim3(256), 0, st, (u64*)cand_count, (u64*)stream8_count, err, (const u64*)seed_starts, seed_lens,
+                       n_seed_slots, (u64*)fl_starts, fl_lens, (u64*)fl_count, set_fl_count ? 1u : 0u);
+}
+void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
+                           uint32_t* w1, uint32_t n1, hipStream_t st) {
+    hipLaunchKernelGGL(k_phase_init, dim3(1), dim3(256), 0, st, (u64*)count, (u64)count_value, lens, n_lens, w0, n0, w1, n1);
+}
 __global__ void k_snapshot(const unsigned long long* src, unsigned long long* dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
 void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st) {
     hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(64), 0, st, src, dst);
