@@ -1169,6 +1169,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         }
         a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap; a.cand_keys = (unsigned long long*)h->d_keys;
         // a pre-filter launched ahead (e2s_prefilter_begin) with the same -m stands in for the first attempt's own
+        bool mailed = false;
         const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
         h->pf_inflight = false;
         if (!use_pf) CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));     // (an early pre-filter may have set its error bits)
@@ -1284,9 +1285,13 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 LCHK("e2s_launch_cand_order");
                 const size_t ord_off = (((size_t)h->cand_cap * a.stride) + 63) & ~(size_t)63;
                 h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
+                void* dev_mail = nullptr;
+                CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
                 e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
-                                        (uint32_t*)(a.host_stream + ord_off), h->stream);
+                                        (uint32_t*)(a.host_stream + ord_off), (const unsigned long long*)(h->d_scalars + 2), h->d_words + 1,
+                                        h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 1024), h->stream);
                 LCHK("e2s_launch_cand_offsets");
+                mailed = true;
             }
         } else {
             { const uint64_t* ds; const uint16_t* dl; int rc = records_contiguous(h, &ds, &dl); if (rc) return rc; a.starts = ds; a.lens = dl; }
@@ -1297,9 +1302,11 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             CK(hipEventRecord(h->ev[7], h->stream));
         }
         uint64_t* mb = (uint64_t*)(h->pin_mail + 1024);
-        CK(hipMemcpyAsync(mb, h->d_scalars + 1, 16, hipMemcpyDeviceToHost, h->stream));        // cand_count, flagged
-        CK(hipMemcpyAsync(mb + 2, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
-        CK(hipMemcpyAsync((uint32_t*)(mb + 2) + 1, h->d_words + 20, 4, hipMemcpyDeviceToHost, h->stream));
+        if (!mailed) {                                               // (the streaming pass's last kernel wrote them itself)
+            CK(hipMemcpyAsync(mb, h->d_scalars + 1, 16, hipMemcpyDeviceToHost, h->stream));        // cand_count, flagged
+            CK(hipMemcpyAsync(mb + 2, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
+            CK(hipMemcpyAsync((uint32_t*)(mb + 2) + 1, h->d_words + 20, 4, hipMemcpyDeviceToHost, h->stream));
+        }
         CK(wait_stream(h));
         CK(hipGetLastError());
         count = mb[0];

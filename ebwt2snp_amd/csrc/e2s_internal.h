@@ -170,7 +170,8 @@ void e2s_launch_cand_keys(const uint8_t* cand, uint32_t stride, unsigned long lo
 constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
 size_t e2s_cand_order_scratch_bytes(unsigned long long n);
 void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* n_dev,
-                             const unsigned long long* stream8_count, uint32_t* off_out, hipStream_t st);
+                             const unsigned long long* stream8_count, uint32_t* off_out, const unsigned long long* fl_count, const uint32_t* err_a,
+                             const uint32_t* err_b, unsigned long long* mail, hipStream_t st);
 void e2s_launch_cand_pack(const uint8_t* cand, uint32_t stride, uint32_t list_cap, uint32_t pw, const uint32_t* order, unsigned long long n, uint32_t* size8,
                           unsigned long long n_pad, uint8_t* stream, uint32_t* off_out, hipStream_t st);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,

@@ -1946,14 +1946,21 @@ __global__ __launch_bounds__(256) void k_cand_pack(const uint8_t* cand, u32 stri
     }
 }
 // SA-order offsets of candidates that k_flagged_lists packed itself: off_out[i] = where slot order[i] went, off_out[n] = end
-__global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out) {
+// (also the pass's mail: candidate count, flagged count and the two error words, written straight into the pinned mailbox)
+__global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
+                               const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail) {
     n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) off_out[i] = slot_off8[order[i]];
-    else if (i == n) off_out[n] = (u32)*stream8_count;
+    else if (i == n) {
+        off_out[n] = (u32)*stream8_count;
+        if (mail) { mail[0] = *n_dev; mail[1] = *fl_count; mail[2] = (unsigned long long)*err_a | ((unsigned long long)*err_b << 32); }
+    }
 }
-void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out);
+void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
+                             const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, hipStream_t st) {
+    hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out,
+                       fl_count, err_a, err_b, mail);
 }
 // exclusive scan of size8[0..n_pad) in place + total at size8[n_pad]; n_pad a multiple of 4096
 void e2s_launch_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, u32 pw, const u32* order, u64 n, u32* size8 /* n_pad + 1 */, u64 n_pad,
