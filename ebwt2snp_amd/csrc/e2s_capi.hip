@@ -236,6 +236,34 @@ static int dev_alloc(e2s_ctx* h, void** p, size_t bytes) {
     return E2S_OK;
 }
 
+// An LCP column of 2- or 4-byte values that all fit a byte is replaced by a byte column (the values are what every kernel
+// compares; the file width only matters to the EOF phantom, which is modelled on the host from e2s_shard_desc).  The fast
+// kernels -- plane stencil, fused pre-filter, streaming per-cluster pass -- are written for byte columns; egsa's default
+// output has 4-byte LCPs although short reads never exceed 255.  E2S_NARROW_LCP=0 keeps the column as it is.
+static int narrow_lcp(e2s_ctx* h) {
+    static const int enabled = getenv("E2S_NARROW_LCP") ? atoi(getenv("E2S_NARROW_LCP")) : 1;
+    if (!enabled || h->xb == 1 || !h->n_prov) return E2S_OK;
+    uint32_t* mb = (uint32_t*)(h->pin_mail + 3088);
+    CK(hipMemsetAsync(h->d_words + 24, 0, 4, h->stream));
+    e2s_launch_lcp_max(h->lcp, h->xb, h->n_prov, h->d_words + 24, h->stream);
+    LCHK("e2s_launch_lcp_max");
+    CK(hipMemcpyAsync(mb, h->d_words + 24, 4, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    if (*mb > 255u) return E2S_OK;
+    void* nl = nullptr;
+    int rc = dev_alloc(h, &nl, h->n_prov);
+    if (rc) return rc;
+    e2s_launch_lcp_narrow(h->lcp, h->xb, h->n_prov, (uint8_t*)nl, h->stream);
+    LCHK("e2s_launch_lcp_narrow");
+    CK(hipStreamSynchronize(h->stream));
+    if (!h->attached) {                                         // the wide column was ours
+        for (auto it = h->owned.begin(); it != h->owned.end(); ++it) if (*it == h->lcp) { h->owned.erase(it); break; }
+        hipFree(h->lcp);
+    }
+    h->lcp = nl; h->xb = 1;
+    return E2S_OK;
+}
+
 extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa) {
     dbg_entry("e2s_upload_bcr");
     int rc = check_desc(h, d);
@@ -273,7 +301,7 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     CK(hipFree(stage));
     CK(hipGetLastError());
     hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
-    return E2S_OK;
+    return narrow_lcp(h);
 }
 
 extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void* aos) {
@@ -303,7 +331,7 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     CK(hipFree(stage));
     CK(hipGetLastError());
     hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
-    return E2S_OK;
+    return narrow_lcp(h);
 }
 
 extern "C" int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, const void* d_lcp, const void* d_pos,
@@ -320,7 +348,7 @@ extern "C" int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void*
     h->layout = 0;
     h->attached = true;
     h->bwt = (uint8_t*)d_bwt; h->lcp = (void*)d_lcp; h->pos = (void*)d_pos; h->da = (void*)d_da;
-    return E2S_OK;
+    return narrow_lcp(h);                                       // (a byte-wide copy of a wider column, if its values allow)
 }
 
 extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void* lcp, uint8_t tail_bwt) {
@@ -351,7 +379,7 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
     CK(hipStreamSynchronize(h->stream));
     CK(hipGetLastError());
     hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
-    return E2S_OK;
+    return narrow_lcp(h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1051,7 +1079,7 @@ static int c2s_len_lo(int mcov_out, int min_len) {   // `length >= mcov_out*2` (
 static bool prefilter_eligible(const e2s_ctx* h) {
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt) & 15u) == 0;
     static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;
-    return !(h->records_from_file || h->d.lcp_bytes != 1 || !aligned || !h->bwt || filter_v1);
+    return !(h->records_from_file || h->xb != 1 || !aligned || !h->bwt || filter_v1);
 }
 // the flagged-cluster list (empty, behind the reserved seed slots), the pre-filter's error word and its arguments
 static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words = false) {
@@ -1150,7 +1178,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     // Streaming path: boundaries recomputed from the LCP inside the kernel.  Needs the records to be the
     // scan's own (same k), default field widths for what it reads, 16-byte aligned columns.
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt | (uintptr_t)h->da) & 15u) == 0;
-    bool streaming = !h->records_from_file && d.lcp_bytes == 1 && d.da_bytes == 4 && aligned && !h->wrap_overflow;
+    bool streaming = !h->records_from_file && h->xb == 1 && h->yb == 4 && aligned && !h->wrap_overflow;   // (widths of the device columns)
 
     uint64_t want = std::max<uint64_t>(4096, h->n_rec / 256);
     uint64_t count = 0;
@@ -1232,7 +1260,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                                      (unsigned long long*)(h->d_scalars + 2), !use_pf, h->stream);
                 LCHK("e2s_launch_cand_init");
             }
-            const bool defw = d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1;
+            const bool defw = h->xb == 1 && h->yb == 4 && h->zb == 1;
             static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;   // the first formulation, kept for cross-checks
             // chunked mode is opt-in: on 2x10^8 entries 2 / 4 chunks took 0.34 / 0.44 ms for this phase against 0.26 ms in
             // one piece (every chunk pays the workers' warm-up tile and its own launch ramp, and the two kernels slow each
@@ -1297,7 +1325,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             { const uint64_t* ds; const uint16_t* dl; int rc = records_contiguous(h, &ds, &dl); if (rc) return rc; a.starts = ds; a.lens = dl; }
             a.n_rec = h->n_rec; a.key_is_start = 0;
             CK(hipEventRecord(h->ev[6], h->stream));
-            if (h->n_rec) e2s_launch_candidates(a, d.lcp_bytes == 1 && d.da_bytes == 4 && d.pos_bytes == 1, h->stream);
+            if (h->n_rec) e2s_launch_candidates(a, h->xb == 1 && h->yb == 4 && h->zb == 1, h->stream);
             CK(hipEventRecord(h->ev[4], h->stream));
             CK(hipEventRecord(h->ev[7], h->stream));
         }

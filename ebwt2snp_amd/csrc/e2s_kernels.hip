@@ -2152,6 +2152,31 @@ void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsign
     a.w_per = (uint32_t)(a.w_tiles / nb); a.w_rem = (uint32_t)(a.w_tiles % nb); a.w_blocks = (uint32_t)nb;
     hipLaunchKernelGGL(k_cluster_filter2, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, a);
 }
+// LCP columns wider than a byte whose values all fit one (short reads: LCP < read length) are kept as bytes: the plane kernels
+// and the streaming per-cluster pass then apply.  Max reduction, then the narrowing copy.
+template <typename T>
+__global__ __launch_bounds__(256) void k_lcp_max(const T* lcp, u64 n, u32* out) {
+    u32 m = 0;
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) m = max(m, (u32)lcp[i]);
+    for (int o = 32; o; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_lcp_narrow(const T* lcp, u64 n, uint8_t* out) {
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) out[i] = (uint8_t)lcp[i];
+}
+void e2s_launch_lcp_max(const void* lcp, int xb, unsigned long long n, uint32_t* out, hipStream_t st) {
+    const unsigned g = (unsigned)std::min<u64>((n + 255) / 256, 8192);
+    if (!g) return;
+    if (xb == 2) hipLaunchKernelGGL((k_lcp_max<uint16_t>), dim3(g), dim3(256), 0, st, (const uint16_t*)lcp, (u64)n, out);
+    else hipLaunchKernelGGL((k_lcp_max<u32>), dim3(g), dim3(256), 0, st, (const u32*)lcp, (u64)n, out);
+}
+void e2s_launch_lcp_narrow(const void* lcp, int xb, unsigned long long n, uint8_t* out, hipStream_t st) {
+    const unsigned g = (unsigned)std::min<u64>((n + 255) / 256, 8192);
+    if (!g) return;
+    if (xb == 2) hipLaunchKernelGGL((k_lcp_narrow<uint16_t>), dim3(g), dim3(256), 0, st, (const uint16_t*)lcp, (u64)n, out);
+    else hipLaunchKernelGGL((k_lcp_narrow<u32>), dim3(g), dim3(256), 0, st, (const u32*)lcp, (u64)n, out);
+}
 // one launch instead of a handful of tiny memsets / copies before a phase (each costs a few microseconds of stream time)
 __global__ void k_phase_init(u64* count, u64 count_value, uint16_t* lens, u32 n_lens, u32* w0, u32 n0, u32* w1, u32 n1) {
     const u32 t = threadIdx.x;

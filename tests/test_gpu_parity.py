@@ -527,6 +527,21 @@ def test_prefilter_beside_scan_on_second_stream(tmp_path):
 
 
 @pytest.mark.gpu
+def test_wide_lcp_columns_kept_wide(tmp_path):
+    """LCP columns of 2 / 4 / 8-byte files whose values fit a byte are narrowed to bytes on upload (the tests above run them
+    that way: plane kernels, streaming per-cluster pass); with E2S_NARROW_LCP=0 (read once per process) they stay wide and
+    take the SWAR scan and the record-driven pass -- a child pytest runs the width cases like that"""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, E2S_NARROW_LCP="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "e2c_golden_table or w444 or w282 or scan_fuzz_vs_oracle or seed56 or crafted_c2s_golden"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
