@@ -1180,6 +1180,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt | (uintptr_t)h->da) & 15u) == 0;
     bool streaming = !h->records_from_file && h->xb == 1 && h->yb == 4 && aligned && !h->wrap_overflow;   // (widths of the device columns)
 
+    const bool rec_pf_ok = true;
+    bool list_done = false;
     uint64_t want = std::max<uint64_t>(4096, h->n_rec / 256);
     uint64_t count = 0;
     bool done = false;
@@ -1198,21 +1200,26 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap; a.cand_keys = (unsigned long long*)h->d_keys;
         // a pre-filter launched ahead (e2s_prefilter_begin) with the same -m stands in for the first attempt's own
         bool mailed = false;
+        // records that are not the streaming pass's to recompute (a `.clusters` file, wide or unaligned columns): a thread-per-record
+        // pre-filter on the records as they are, then the same list kernels.  E2S_RECORD_PREFILTER=0: one wave per record instead.
+        static const int rec_pf_env = getenv("E2S_RECORD_PREFILTER") ? atoi(getenv("E2S_RECORD_PREFILTER")) : 1;
+        const bool rec_pf = !streaming && rec_pf_ok && rec_pf_env && h->bwt && h->n_rec > 0;
+        const bool listmode = streaming || rec_pf;
         const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
         h->pf_inflight = false;
         if (!use_pf) CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));     // (an early pre-filter may have set its error bits)
         if (use_pf && h->pf_on_stream2) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // it ran on the second stream
-        if (!streaming) {
+        if (!listmode) {
             CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
             CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
         }
-        if (streaming) {
+        if (listmode) {
             // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
             std::vector<uint64_t> ss; std::vector<uint16_t> sl;
             auto seed = [&](uint64_t st, uint16_t ln) { if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); } };
-            for (uint32_t t = 0; t < h->plan.n_tail; ++t) seed(h->plan.tail_start[t], h->plan.tail_len[t]);
-            if (h->first_wrapped) seed(h->plan.first_start, h->plan.first_len);
-            for (uint64_t r : h->wrap_ranks) {                       // rare: a cluster of 65536+ entries
+            if (streaming) for (uint32_t t = 0; t < h->plan.n_tail; ++t) seed(h->plan.tail_start[t], h->plan.tail_len[t]);
+            if (streaming && h->first_wrapped) seed(h->plan.first_start, h->plan.first_len);
+            if (streaming) for (uint64_t r : h->wrap_ranks) {        // rare: a cluster of 65536+ entries
                 uint64_t st = 0; uint16_t ln = 0;
                 CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
                 CK(hipMemcpy(&ln, h->d_lens + r, 2, hipMemcpyDeviceToHost));
@@ -1271,7 +1278,18 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             static const long min_tiles = getenv("E2S_FILTER_CHUNK_MIN_TILES") ? atol(getenv("E2S_FILTER_CHUNK_MIN_TILES")) : 4096;
             if ((long)w_tiles < min_tiles || w_tiles < (uint64_t)chunks) chunks = 1;   // too little work per chunk to hide a launch
             const unsigned long long* fl_count = (const unsigned long long*)(h->d_scalars + 2);
-            if (use_pf) {                                            // the pre-filter is already on the stream
+            if (rec_pf) {                                            // the records as they are
+                const uint64_t* ds; const uint16_t* dl;
+                int rc = records_contiguous(h, &ds, &dl);
+                if (rc) return rc;
+                e2s_launch_record_prefilter((const unsigned long long*)ds, dl, h->n_rec, h->bwt, h->prov_lo, h->prov_lo + h->n_prov, (uint32_t)p->mcov_out,
+                                            a.len_lo, a.len_hi, (unsigned long long*)h->d_fl_starts, h->d_fl_lens, h->fl_cap,
+                                            (unsigned long long*)(h->d_scalars + 2), h->stream);
+                LCHK("e2s_launch_record_prefilter");
+                CK(hipEventRecord(h->ev[4], h->stream));
+                e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
+                LCHK("e2s_launch_flagged_lists");
+            } else if (use_pf) {                                     // the pre-filter is already on the stream
                 e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
                 LCHK("e2s_launch_flagged_lists");
             } else if (chunks == 1) {
@@ -1342,17 +1360,18 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         const uint32_t err = ((const uint32_t*)(mb + 2))[0] | ((const uint32_t*)(mb + 2))[1];     // K2b's word | the pre-filter's
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
         if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
-        if (streaming && flagged > h->fl_cap) {
+        if (listmode && flagged > h->fl_cap) {
             int rc = ensure_flagged(h, flagged + 4096);
             if (rc) return rc;
             continue;
         }
         h->n_flagged = flagged;
+        list_done = listmode;
         if (count <= h->cand_cap) { done = true; break; }
         want = count + 1024;
     }
     if (!done) return fail(h, E2S_ERR_CAPACITY, "candidate / flagged buffer overflow");
-    const bool streaming_done = streaming;
+    const bool streaming_done = list_done;
     h->n_cand = count;
     h->cand_downloaded = false; h->host_fixed_valid = false;
     if (count && !streaming_done) {

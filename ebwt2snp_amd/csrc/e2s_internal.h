@@ -140,6 +140,9 @@ void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* st
                           unsigned long long* fl_count, bool set_fl_count, hipStream_t st);   // n_seed_slots <= 256
 void e2s_launch_lcp_max(const void* lcp, int xb, unsigned long long n, uint32_t* out, hipStream_t st);        // xb = 2 or 4
 void e2s_launch_lcp_narrow(const void* lcp, int xb, unsigned long long n, uint8_t* out, hipStream_t st);
+void e2s_launch_record_prefilter(const unsigned long long* starts, const uint16_t* lens, unsigned long long n_rec, const uint8_t* bwt,
+                                 unsigned long long prov_lo, unsigned long long prov_hi, uint32_t mcov, int len_lo, int len_hi,
+                                 unsigned long long* fl_starts, uint16_t* fl_lens, unsigned long long fl_cap, unsigned long long* fl_count, hipStream_t st);
 void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st);
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st);
 void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsigned long long n, hipStream_t st);

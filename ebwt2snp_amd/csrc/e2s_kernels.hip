@@ -2177,6 +2177,42 @@ void e2s_launch_lcp_narrow(const void* lcp, int xb, unsigned long long n, uint8_
     if (xb == 2) hipLaunchKernelGGL((k_lcp_narrow<uint16_t>), dim3(g), dim3(256), 0, st, (const uint16_t*)lcp, (u64)n, out);
     else hipLaunchKernelGGL((k_lcp_narrow<u32>), dim3(g), dim3(256), 0, st, (const u32*)lcp, (u64)n, out);
 }
+// Pre-filter over cluster RECORDS as they are (a `.clusters` file of unknown k, wide columns, ...): one thread per record
+// counts the bases of its stretch of the BWT; the records that hold at least two different bases with >= mcov occurrences
+// (necessary for clust2snp.cpp:419-429, see k_cluster_filter2) go to the flagged list for k_flagged_lists.  A record that
+// reaches the EOF phantom or outside the resident shard is passed on as it is (k_flagged_lists models / reports it).
+__global__ __launch_bounds__(256) void k_record_prefilter(const u64* starts, const uint16_t* lens, u64 n_rec, const uint8_t* bwt, u64 prov_lo, u64 prov_hi,
+                                                          u32 mcov, int len_lo, int len_hi, u64* fl_starts, uint16_t* fl_lens, u64 fl_cap,
+                                                          unsigned long long* fl_count) {
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n_rec; i += (u64)gridDim.x * 256u) {
+        const u32 len = lens[i];
+        if ((int)len < len_lo || (int)len > len_hi) continue;   // clust2snp.cpp:816
+        const u64 s = starts[i];
+        bool pass = s < prov_lo || s + len > prov_hi;           // not (entirely) real resident entries
+        if (!pass) {
+            const uint8_t* p = bwt + (s - prov_lo);
+            u32 cC = 0, cG = 0, cT = 0;
+            for (u32 j = 0; j < len; ++j) {
+                const u32 c = (u32)p[j] & 0xDFu;                // fold case
+                cC += c == 'C' ? 1u : 0u; cG += c == 'G' ? 1u : 0u; cT += c == 'T' ? 1u : 0u;
+            }
+            const u32 cA = len - cC - cG - cT;                  // everything else counts as A (include.hpp:265-279)
+            pass = (cA >= mcov ? 1u : 0u) + (cC >= mcov ? 1u : 0u) + (cG >= mcov ? 1u : 0u) + (cT >= mcov ? 1u : 0u) >= 2u;
+        }
+        if (pass) {
+            const u64 at = atomicAdd(fl_count, 1ull);
+            if (at < fl_cap) { fl_starts[at] = s; fl_lens[at] = (uint16_t)len; }
+        }
+    }
+}
+void e2s_launch_record_prefilter(const unsigned long long* starts, const uint16_t* lens, unsigned long long n_rec, const uint8_t* bwt,
+                                 unsigned long long prov_lo, unsigned long long prov_hi, uint32_t mcov, int len_lo, int len_hi,
+                                 unsigned long long* fl_starts, uint16_t* fl_lens, unsigned long long fl_cap, unsigned long long* fl_count, hipStream_t st) {
+    const unsigned g = (unsigned)std::min<u64>((n_rec + 255) / 256, 65536);
+    if (!g) return;
+    hipLaunchKernelGGL(k_record_prefilter, dim3(g), dim3(256), 0, st, (const u64*)starts, lens, (u64)n_rec, bwt, (u64)prov_lo, (u64)prov_hi, mcov, len_lo,
+                       len_hi, (u64*)fl_starts, fl_lens, (u64)fl_cap, fl_count);
+}
 // one launch instead of a handful of tiny memsets / copies before a phase (each costs a few microseconds of stream time)
 __global__ void k_phase_init(u64* count, u64 count_value, uint16_t* lens, u32 n_lens, u32* w0, u32 n0, u32* w1, u32 n1) {
     const u32 t = threadIdx.x;

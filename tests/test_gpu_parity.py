@@ -542,6 +542,21 @@ def test_wide_lcp_columns_kept_wide(tmp_path):
 
 
 @pytest.mark.gpu
+def test_wave_per_record_pass_kept(tmp_path):
+    """records that are not the streaming pass's own (a `.clusters` file, columns kept wide) go through a thread-per-record
+    pre-filter and the list kernels (every file-driven case above); E2S_RECORD_PREFILTER=0 keeps the first implementation,
+    one wave per record (k_candidates), alive: a child pytest runs the file-driven cases that way"""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, E2S_RECORD_PREFILTER="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "e2e_golden or crafted_c2s_golden or candidates_equal_oracle or seed56"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
