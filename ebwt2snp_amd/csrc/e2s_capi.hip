@@ -48,6 +48,7 @@ struct e2s_ctx {
     // candidates
     uint8_t* d_cand = nullptr; uint64_t cand_cap = 0, cand_bytes = 0; uint32_t cand_stride = 0, list_cap = 0; uint64_t n_cand = 0;
     bool tail_bwt_given = false; uint8_t tail_bwt_arg = 0;
+    size_t stream_cap_bytes = 0; uint32_t stream_per_cand = 128;  // packed candidate stream: room per candidate slot (raised to the stride on overflow)
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
     uint32_t* pin_order = nullptr;                                // offsets (8-byte units) of the packed candidates, n_cand + 1 entries
     uint32_t* d_size8 = nullptr; uint64_t size8_cap = 0;          // pack scratch
@@ -127,6 +128,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     if (device_id < 0 || device_id >= ndev) { g_create_error = "device id out of range"; return E2S_ERR_ARG; }
     e2s_ctx* h = new e2s_ctx();
     h->device = device_id;
+    if (const char* ev = getenv("E2S_STREAM_PER_CAND")) h->stream_per_cand = (uint32_t)std::max(8, atoi(ev));   // (tests: force the overflow path)
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("hipSetDevice/hipStreamCreate: ") + hipGetErrorString(e);
         delete h;
@@ -1242,8 +1244,13 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             if (!use_pf) CK(hipEventRecord(h->ev[6], h->stream));
             a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
             {   // packed mode: K2b writes the candidates into the pinned host buffer itself
-                const size_t rec_bytes = (size_t)h->cand_cap * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
+                // lists are a third full on average (~100 B packed per candidate against the 352-B stride): the pinned buffer is sized
+                // for 128 B per slot -- pinning costs ~1 ms per MB -- and for the full stride if that ever overflows (checked below)
+                const size_t rec_bytes = std::min((size_t)h->cand_cap * a.stride,
+                                                  std::max((size_t)h->cand_cap * h->stream_per_cand, (size_t)1 << 16)) & ~(size_t)7;
+                const size_t ord_off = (rec_bytes + 63) & ~(size_t)63;
                 const size_t need = ord_off + ((size_t)h->cand_cap + 1) * 4;
+                h->stream_cap_bytes = rec_bytes;
                 if (need > h->pin_cand_bytes) {
                     if (h->pin_cand) hipHostFree(h->pin_cand);
                     h->pin_cand = nullptr; h->pin_cand_bytes = 0;
@@ -1329,7 +1336,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
                                       h->d_order, h->stream);
                 LCHK("e2s_launch_cand_order");
-                const size_t ord_off = (((size_t)h->cand_cap * a.stride) + 63) & ~(size_t)63;
+                const size_t ord_off = (h->stream_cap_bytes + 63) & ~(size_t)63;
                 h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
                 void* dev_mail = nullptr;
                 CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
@@ -1360,6 +1367,10 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         const uint32_t err = ((const uint32_t*)(mb + 2))[0] | ((const uint32_t*)(mb + 2))[1];     // K2b's word | the pre-filter's
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
         if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
+        if (listmode && mailed && mb[3] * 8 > h->stream_cap_bytes) {   // the packed stream outgrew its 128 B per slot: room for full lists
+            h->stream_per_cand = a.stride;
+            continue;
+        }
         if (listmode && flagged > h->fl_cap) {
             int rc = ensure_flagged(h, flagged + 4096);
             if (rc) return rc;

@@ -1954,7 +1954,7 @@ __global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, co
     if (i < n) off_out[i] = slot_off8[order[i]];
     else if (i == n) {
         off_out[n] = (u32)*stream8_count;
-        if (mail) { mail[0] = *n_dev; mail[1] = *fl_count; mail[2] = (unsigned long long)*err_a | ((unsigned long long)*err_b << 32); }
+        if (mail) { mail[0] = *n_dev; mail[1] = *fl_count; mail[2] = (unsigned long long)*err_a | ((unsigned long long)*err_b << 32); mail[3] = *stream8_count; }
     }
 }
 void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,

@@ -557,6 +557,21 @@ def test_wave_per_record_pass_kept(tmp_path):
 
 
 @pytest.mark.gpu
+def test_packed_stream_overflow_retry(tmp_path):
+    """the pinned buffer for the packed candidates is sized for 128 B per slot; when fuller lists outgrow it the pass is
+    rerun with room for full lists.  E2S_STREAM_PER_CAND=8 (read at e2s_create) makes every case overflow: a child
+    pytest runs candidate comparisons that way"""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, E2S_STREAM_PER_CAND="8")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "fused_streaming_candidates_equal_oracle or crafted_c2s_golden or fused_streaming_fuzz_columns"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
