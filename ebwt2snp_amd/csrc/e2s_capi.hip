@@ -570,6 +570,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         }
     } else {
         // ---- three-kernel count / scan / emit into contiguous arrays ----
+        h->pf_armed = false;                                        // (e2s_prefilter_arm belongs to the segmented scan)
         h->segmented = false; h->first_rec_addr = 0; h->raw_stats_valid = false;
         const uint64_t tile_entries = (uint64_t)E2S_SCAN_ROWS * E2S_SCAN_BLOCK * (16 / h->xb);
         a.n_tiles = (h->n_prov + tile_entries - 1) / tile_entries;

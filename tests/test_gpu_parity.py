@@ -143,6 +143,19 @@ def test_scan_fuzz_vs_oracle(H, x):
                 rec = H.fetch_clusters().view(IO.CLUSTER_DTYPE)
                 assert closed == ec and nrec == es.size, (n, mode, sm)
                 assert np.array_equal(rec["start"], es) and np.array_equal(rec["length"], el), (n, mode, sm)
+    if x != 1:
+        # the narrowing decision: a column whose largest value is 255 becomes a byte column, 256 keeps the file's width
+        dt = {2: np.uint16, 4: np.uint32}[x]
+        for top in (255, 256):
+            n = 70001
+            L = np.minimum(_adversarial_lcp(rnd, n, 1).astype(np.uint32), 200)
+            L[n // 2 - 1:n // 2 + 2] = [top - 1, top, top - 1]
+            bwt = rnd.choice([36, 65, 67, 71, 84], n).astype(np.uint8)
+            es, el, ec = O.cluster_lm_mem(L, O.phantom_lcp_for_scan(L, bwt, 16, x), 16, 2)
+            H.upload_lcp(capi.Handle.desc(n, x=x), L.astype(dt).view(np.uint8), int(bwt[-1]))
+            H.scan_single(16, 2, 0)
+            rec = H.fetch_clusters().view(IO.CLUSTER_DTYPE)
+            assert H.counts() == (ec, es.size) and np.array_equal(rec["start"], es) and np.array_equal(rec["length"], el), top
 
 
 def test_sharded_scan_and_candidates_on_one_gpu(tmp_path):
