@@ -116,11 +116,12 @@ REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
 # E2S_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path -- RCCL process group,
 # exchange, merged statistics -- with a single rank, to exercise it on a one-GPU box
 FORCE_DIST = os.environ.get("E2S_BENCH_FORCE_DIST", "0") == "1"
-# E2S_BENCH_OVERLAP=1 (default): the timed steps arm the pre-filter before the scan (e2s_prefilter_arm): it then runs INSIDE the scan
-# kernel (k_scan_seg<1, true>; with E2S_FUSED=0 beside it on a second stream) -- one pass over the LCP, 13-18 % more throughput.
-# E2S_BENCH_OVERLAP=0 keeps the two kernels apart.  Either way the other mode is measured after the timed run and reported as
-# "other_mode", so that the separate kernels are also seen against their own rooflines.
-OVERLAP = os.environ.get("E2S_BENCH_OVERLAP", "1") == "1"
+# E2S_BENCH_OVERLAP=1: the timed steps arm the pre-filter before the scan (e2s_prefilter_arm): it then runs INSIDE the scan kernel
+# (k_scan_seg<1, true>; with E2S_FUSED=0 beside it on a second stream) -- one pass over the LCP, 13-18 % more throughput on one GPU.
+# E2S_BENCH_OVERLAP=0 keeps the two kernels apart: with several ranks the pre-filter then runs while the descriptors are exchanged.
+# Default "auto": inside the scan kernel unless there is an exchange AND the shard is small (see main).  Either way the other mode
+# is measured after the timed run and reported as "other_mode", so that the separate kernels are also seen against their rooflines.
+OVERLAP = os.environ.get("E2S_BENCH_OVERLAP", "auto")             # "1" / "0" / "auto" (resolved in main once the shard size is known)
 FUSED = os.environ.get("E2S_FUSED", "1") != "0"
 SECOND_LEG = os.environ.get("E2S_BENCH_SECOND_LEG", "1") == "1"      # also measure the other mode (reported as other_mode)
 
@@ -348,6 +349,10 @@ def main():
 
     # the timed run `value` comes from, then -- reported beside it, never as `value` -- the same job in the other mode
     # (pre-filter inside the scan kernel / the two kernels apart, each against its own roofline)
+    # auto: the pre-filter goes inside the scan kernel unless there is an exchange to hide behind it AND the shard is small
+    # enough for that to matter (c2-size shards, N > 1: 0.37 against 0.38 ms per job; c3-size: the fusion's 0.4 ms win)
+    global OVERLAP
+    OVERLAP = (dist is None or n_own >= 10 ** 9) if OVERLAP == "auto" else (OVERLAP == "1")
     prim = measure(OVERLAP, a.warmup)
     other = measure(not OVERLAP, min(a.warmup, 2) + 1) if (FUSED and SECOND_LEG) else None
     info = prim["info"]
