@@ -585,6 +585,21 @@ def test_packed_stream_overflow_retry(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 11, 27, 64, 128, 256, 301, 377])
+def test_executables_random_cases_vs_reference(seed):
+    """tools/stress_cli.py's cases: a random synthetic input, random widths / format / options, through bin/ebwt2clust and
+    bin/clust2snp and through the reference's own executables (oracle/_ref): same `.clusters`, `.snp`, "Done." line, exit codes"""
+    import importlib.util
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("stress_cli", os.path.join(root, "tools", "stress_cli.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(seed)
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
