@@ -600,6 +600,22 @@ def test_executables_random_cases_vs_reference(seed):
 
 
 @pytest.mark.gpu
+def test_few_workers_many_tiles_each(tmp_path):
+    """on test-sized inputs every wave worker of the plane kernels owns a single tile; E2S_SCAN_WORKERS=7 / E2S_FILTER_WORKERS=5
+    (read once per process) give each worker a range of ~10 tiles, i.e. the two-tiles-per-trip hot loops with their register
+    roles and tile-to-tile carries that large shards run in: a child pytest repeats the column / candidate cases that way"""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, E2S_SCAN_WORKERS="7", E2S_FILTER_WORKERS="5")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "fused_streaming_fuzz_columns or sharded_fuzz_columns or fused_streaming_candidates_equal_oracle or "
+                              "fused_streaming_adversarial or scan_fuzz_vs_oracle"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
