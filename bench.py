@@ -241,6 +241,32 @@ def cpu_baseline(blk, reads, n1, sample_entries):
                                   "clusters_bytes": len(want_cl), "snp_bytes": len(want_snp)}
         except Exception as ex:
             res["drop_in"] = {"error": repr(ex)}
+        # ... and the library pipeline exactly as the timed steps run it (pre-filter inside the scan kernel, packed candidates in
+        # pinned memory) on the same sample, finished by the host tail: `.clusters` and `.snp` bytes against the baseline's
+        try:
+            want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
+            sub = {k2: blk[k2][:n].clone() for k2 in ("bwt", "lcp", "pos", "da")}
+            sub["lcp"][-1] = 0
+            h = capi.Handle(blk["lcp"].device.index or 0)
+            h.attach_soa(capi.Handle.desc(n), sub["bwt"].data_ptr(), sub["lcp"].data_ptr(), sub["pos"].data_ptr(), sub["da"].data_ptr(),
+                         keep=tuple(sub.values()))
+            u0 = time.time()
+            h.prefilter_arm(5)
+            h.cluster_scan(16, 2, 0)
+            h.stitch([h.boundary()], 0)
+            got_cl = h.fetch_clusters().tobytes()
+            mcl, _, _ = capi.auto_max_clust_length([h.hist()], 5, 0.99)
+            h.find_candidates(capi.C2SParams(n1, 31, 30, 5, 20, mcl, 2), 0)
+            stream, off8, nc, pw = h.candidates_packed()
+            out_snp = os.path.join(d, "library.snp")
+            capi.snp_from_packed(stream, off8, nc, p, out_snp, pos_bytes=pw)
+            u1 = time.time()
+            res["library_pipeline"] = {"what": "attach -> arm -> scan -> stitch -> statistics -> candidates -> host tail on the same sample (resident EGSA)",
+                                       "seconds": round(u1 - u0, 3), "candidates": int(nc),
+                                       "outputs_identical": bool(got_cl == want_cl and open(out_snp, "rb").read() == want_snp)}
+            h.close()
+        except Exception as ex:
+            res["library_pipeline"] = {"error": repr(ex)}
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
