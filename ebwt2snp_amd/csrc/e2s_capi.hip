@@ -1244,6 +1244,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
             f.nr_reads1 = a.nr_reads1;
             if (!use_pf) CK(hipEventRecord(h->ev[6], h->stream));
             a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
+            a.blocks_hint = h->n_rec > 50000000ull ? 4096u : 1024u;      // ~0.3 % of the records reach K2b
             {   // packed mode: K2b writes the candidates into the pinned host buffer itself
                 // lists are a third full on average (~100 B packed per candidate against the 352-B stride): the pinned buffer is sized
                 // for 128 B per slot -- pinning costs ~1 ms per MB -- and for the full stride if that ever overflows (checked below)

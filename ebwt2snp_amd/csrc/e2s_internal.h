@@ -106,6 +106,7 @@ struct CandArgs {
     // reserved offsets (8-byte units); slot_off8[slot] remembers where, for the SA-order offsets written afterwards
     uint8_t* host_stream; unsigned long long* stream8_count; uint64_t stream8_cap; uint32_t* slot_off8;
     uint32_t pos_pack;                              // bytes per position in the packed record (1, 2 or 4)
+    uint32_t blocks_hint;                           // k_flagged_lists: blocks to launch (0: 1024)
     uint64_t record_index_base;
     uint32_t* err;
 };

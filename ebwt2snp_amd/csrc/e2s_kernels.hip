@@ -2245,7 +2245,10 @@ void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst,
 }
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
     const size_t dyn = (size_t)2 * FW_STAGE * a.stride;          // staged records + their packed image
-    const unsigned blocks = 1024;
+    static const int env_blocks = getenv("E2S_K2B_BLOCKS") ? atoi(getenv("E2S_K2B_BLOCKS")) : 0;
+    // c2 (2x10^4 flagged clusters): 512 / 1024 / 2048 / 4096 blocks -> 0.124 / 0.117 / 0.131 / 0.177 ms for the phase; c3 (3x10^5): 1024 / 4096 ->
+    // 0.889 / 0.845 ms: the caller asks for more blocks when it expects many clusters
+    const unsigned blocks = env_blocks > 0 ? (unsigned)env_blocks : (a.blocks_hint ? a.blocks_hint : 1024u);
     if (def_widths) hipLaunchKernelGGL((k_flagged_lists<true>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev);
     else hipLaunchKernelGGL((k_flagged_lists<false>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev);
 }
