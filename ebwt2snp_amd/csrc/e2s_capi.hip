@@ -59,6 +59,7 @@ struct e2s_ctx {
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
     uint8_t* d_img = nullptr; uint8_t* d_img_scratch = nullptr; uint64_t img_cap = 0;     // `.clusters` image (e2s_stream_clusters)
     uint8_t* pin_io[2] = {nullptr, nullptr}; uint64_t pin_io_cap = 0; hipEvent_t ev_io[2] = {nullptr, nullptr};
+    int scan_start_ev = 0; bool pf_fused = false;                // which event began the last scan; the in-flight pre-filter ran inside it
     bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
     bool pf_armed = false; int pf_arm_mcov = 0;                   // e2s_prefilter_arm: the next scan starts it beside itself (second stream)
     bool pf_on_stream2 = false; hipEvent_t ev_pf = nullptr;
@@ -519,13 +520,14 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
                 } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
             }
             if (!fuse_now) CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
-            CK(hipEventRecord(h->ev[0], h->stream));
-            CK(hipEventRecord(h->ev[2], h->stream));
+            // four timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix, after the
+            // statistics.  With the pre-filter inside the scan kernel the start event is the per-cluster pass's (ev[6]).
+            h->scan_start_ev = fuse_now ? 6 : 0;
+            CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
             if (fuse_now) {
                 // (a rerun after a segment overflow scans alone: the pre-filter's list does not depend on the segments)
-                CK(hipEventRecord(h->ev[6], h->stream));            // (the pass's timing then starts at the fused kernel)
                 e2s_launch_scan_seg_fused(sa, fa, h->stream);
-                h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false;
+                h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true;
             } else e2s_launch_scan_seg(sa, h->xb, h->stream);
             LCHK("e2s_launch_scan_seg");
             CK(hipEventRecord(h->ev[3], h->stream));
@@ -537,7 +539,6 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             LCHK("e2s_launch_seg_fix");
             CK(hipEventRecord(h->ev[1], h->stream));
             // statistics of the records in the same phase (no second round trip): e2s_scan_stats_desc / e2s_cluster_hist
-            CK(hipEventRecord(h->ev[4], h->stream));
             e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)dh,
                                 (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
             CK(hipEventRecord(h->ev[5], h->stream));
@@ -566,7 +567,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             rs.hist.last_len = rs.last_none ? 0 : buf[E2S_MAX_CLUST_LEN + 3];
             rs.min_len = min_len;
             h->raw_stats_valid = true;
-            hipEventElapsedTime(&h->tm.hist_ms, h->ev[4], h->ev[5]);
+            hipEventElapsedTime(&h->tm.hist_ms, h->ev[1], h->ev[5]);
         }
     } else {
         // ---- three-kernel count / scan / emit into contiguous arrays ----
@@ -587,8 +588,8 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             CK(hipMemsetAsync(h->d_tile_fix, 0xFF, a.n_tiles * 8, h->stream));
             e2s_launch_shard_flags(a, h->xb, h->stream);
             LCHK("e2s_launch_shard_flags");
+            h->scan_start_ev = 0;
             CK(hipEventRecord(h->ev[0], h->stream));
-            CK(hipEventRecord(h->ev[2], h->stream));
             e2s_launch_scan(a, h->xb, 1, h->stream);
             LCHK("e2s_launch_scan");
             e2s_launch_tile_scan(h->d_tile_count, (unsigned long long*)h->d_tile_prefix, a.n_tiles, h->stream);
@@ -616,8 +617,8 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
     h->tail_lcp = mail.tail_lcp; h->tail_prev_lcp = mail.tail_prev_lcp;
     const uint32_t wrap_n = mail.wrap_count;
-    hipEventElapsedTime(&h->tm.scan_ms, h->ev[0], h->ev[1]);
-    hipEventElapsedTime(&h->tm.scan_main_ms, h->ev[2], h->ev[3]);
+    hipEventElapsedTime(&h->tm.scan_ms, h->ev[h->scan_start_ev], h->ev[1]);
+    hipEventElapsedTime(&h->tm.scan_main_ms, h->ev[h->scan_start_ev], h->ev[3]);
     h->tm.scan_bytes_read = d.n_entries * (uint64_t)d.lcp_bytes;
     h->tm.scan_bytes_written = h->n_ends * 10;
 
@@ -1108,7 +1109,7 @@ static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_r
     e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, max_workers, st);
     LCHK("e2s_launch_cluster_filter");
     CK(hipEventRecord(h->ev[4], st));
-    h->pf_inflight = true; h->pf_mcov = mcov_out; h->pf_len_lo = f.len_lo;
+    h->pf_inflight = true; h->pf_mcov = mcov_out; h->pf_len_lo = f.len_lo; h->pf_fused = false;
     h->pf_on_stream2 = st != h->stream;
     if (h->pf_on_stream2) {
         if (!h->ev_pf) CK(hipEventCreateWithFlags(&h->ev_pf, hipEventDisableTiming));
@@ -1185,6 +1186,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
 
     const bool rec_pf_ok = true;
     bool list_done = false;
+    int pf_end_ev = 4;
     uint64_t want = std::max<uint64_t>(4096, h->n_rec / 256);
     uint64_t count = 0;
     bool done = false;
@@ -1209,7 +1211,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         const bool rec_pf = !streaming && rec_pf_ok && rec_pf_env && h->bwt && h->n_rec > 0;
         const bool listmode = streaming || rec_pf;
         const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
-        h->pf_inflight = false;
+        pf_end_ev = (use_pf && h->pf_fused) ? 3 : 4;            // the pre-filter ended with the scan kernel / with its own event
+        h->pf_inflight = false; h->pf_fused = false;
         if (!use_pf) CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));     // (an early pre-filter may have set its error bits)
         if (use_pf && h->pf_on_stream2) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // it ran on the second stream
         if (!listmode) {
@@ -1428,7 +1431,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     }
     if (count) h->cand_downloaded = true;                         // streaming pass: everything arrived with the mailbox wait above
     hipEventElapsedTime(&h->tm.cand_ms, h->ev[6], h->ev[7]);
-    hipEventElapsedTime(&h->tm.cand_main_ms, h->ev[6], h->ev[4]);
+    hipEventElapsedTime(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev]);   // the pre-filter (inside the scan kernel: that kernel)
     h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
     h->tm.cand_bytes_written = count * a.stride;
     if (n_cand) *n_cand = count;
