@@ -1370,6 +1370,10 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         count = mb[0];
         const uint64_t flagged = mb[1];
         const uint32_t err = ((const uint32_t*)(mb + 2))[0] | ((const uint32_t*)(mb + 2))[1];     // K2b's word | the pre-filter's
+        if (getenv("E2S_DEBUG_CAND"))
+            fprintf(stderr, "[cand] attempt %d: listmode %d use_pf %d mailed %d cand_cap %llu stream_cap %zu | count %llu flagged %llu (fl_cap %llu) stream8 %llu err %x\n", attempt,
+                    (int)listmode, (int)use_pf, (int)mailed, (unsigned long long)h->cand_cap, h->stream_cap_bytes, (unsigned long long)count, (unsigned long long)flagged,
+                    (unsigned long long)h->fl_cap, (unsigned long long)(mailed ? mb[3] : 0), err);
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
         if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
         if (listmode && mailed && mb[3] * 8 > h->stream_cap_bytes) {   // the packed stream outgrew its 128 B per slot: room for full lists

@@ -10,6 +10,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 R, L = bench.WORKLOADS[wl][:2]
 reads, n1, blk = bench.build_block(R, L, dev)
 m = blk["lcp"].numel()
+torch.cuda.synchronize()   # the arrays are built on torch's stream; the library runs on its own
 h = capi.Handle(0)
 d = capi.Handle.desc(m)
 h.attach_soa(d, blk["bwt"].data_ptr(), blk["lcp"].data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr())

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""development aid: the pipeline on the same EGSA with 1-byte and 4-byte LCP columns (the latter narrowed on attach)"""
 import sys, time, torch, numpy as np
 sys.path.insert(0, '/root/repo')
 import bench
@@ -6,6 +8,7 @@ dev = torch.device("cuda", 0)
 R, L = bench.WORKLOADS["c2"][:2]
 reads, n1, blk = bench.build_block(R, L, dev)
 m = blk["lcp"].numel()
+torch.cuda.synchronize()   # the arrays are built on torch's stream; the library runs on its own
 for x in (1, 4):
     lcp = blk["lcp"] if x == 1 else blk["lcp"].to(torch.int32).contiguous()
     h = capi.Handle(0)
