@@ -247,6 +247,7 @@ def cpu_baseline(blk, reads, n1, sample_entries):
             want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
             sub = {k2: blk[k2][:n].clone() for k2 in ("bwt", "lcp", "pos", "da")}
             sub["lcp"][-1] = 0
+            torch.cuda.synchronize()                                # (the handle's stream is not ordered after torch's)
             h = capi.Handle(blk["lcp"].device.index or 0)
             h.attach_soa(capi.Handle.desc(n), sub["bwt"].data_ptr(), sub["lcp"].data_ptr(), sub["pos"].data_ptr(), sub["da"].data_ptr(),
                          keep=tuple(sub.values()))

@@ -79,7 +79,10 @@ int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const
 /* .gesa array-of-structs (include.hpp:126-155): [da:y][pos:z][lcp:x][bwt:1] per entry. */
 int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void* aos);
 /* Struct-of-arrays already in HBM (device pointers, widths as in d, 8-byte widths not allowed);
- * zero-copy: the caller keeps ownership and must keep them alive until detach/destroy. */
+ * zero-copy: the caller keeps ownership and must keep them alive until detach/destroy.  The arrays must be COMPLETE when
+ * this is called: the handle works on a stream of its own (e2s_stream) that is not ordered after the caller's streams --
+ * synchronise whatever produced them first (torch.cuda.synchronize(), hipStreamSynchronize, or an event the caller makes
+ * e2s_stream wait for). */
 int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, const void* d_lcp,
                    const void* d_pos, const void* d_da);
 /* LCP column only (host pointer, x bytes per entry) -- all ebwt2clust needs: cluster_lm reads and

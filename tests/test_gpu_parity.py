@@ -632,6 +632,7 @@ def test_tiled_copies_property():
     for copies in (1, 3):
         b, nn1 = bench.tile_block(blk, n1, copies)
         h = capi.Handle(0)
+        torch.cuda.synchronize()                                  # built on torch's stream; the handle has its own
         h.attach_soa(capi.Handle.desc(m * copies), b["bwt"].data_ptr(), b["lcp"].data_ptr(), b["pos"].data_ptr(), b["da"].data_ptr(),
                      keep=tuple(b.values()))
         h.scan_single(16, 2, 0)

@@ -13,6 +13,7 @@ reads, n1, blk = bench.build_block(R, L, dev)
 torch.cuda.synchronize()
 n = blk["lcp"].numel()
 h = capi.Handle(0)
+torch.cuda.synchronize()
 h.attach_soa(capi.Handle.desc(n), blk["bwt"].data_ptr(), blk["lcp"].data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr())
 flush = torch.zeros(1 << 30, dtype=torch.uint8, device=dev)       # > Infinity Cache: evicts the LCP between scans, as a full step does
 for mode in ("warm (LCP may sit in the 256 MiB Infinity Cache)", "cold (1 GiB written in between)"):
