@@ -1807,13 +1807,17 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
     const u64 n = min((u64)*n_dev, a.n_rec);                     // this launch handles list entries [*lo_dev, *n_dev)
     const u64 first = lo_dev ? (u64)*lo_dev : 0ull;
     const u64 per_round = (u64)gridDim.x * 4;
+    // a wave's list entry for the NEXT round is fetched while it works on the current one (a round is a chain of dependent
+    // memory latencies: entry -> EGSA columns -> ...; the block's four waves meet at the barrier below every round)
+    u64 s_nx = 0; int len_nx = 0;
+    { const u64 r0 = first + (u64)blockIdx.x * 4 + wave; if (r0 < n) { s_nx = a.starts[r0]; len_nx = (int)a.lens[r0]; } }
     for (u64 base = first + (u64)blockIdx.x * 4; base < n; base += per_round) {
         // (flushing earlier to start the PCIe stream sooner was tried: chunks of ~8 records ran 25 % slower)
         if (s_nstage > FW_STAGE - 16) stage_flush();                // a round adds at most 4 x 4 candidates
         const u64 r = base + wave;
+        const u64 s = s_nx; const int len = len_nx;
+        { const u64 rn = r + per_round; if (rn < n) { s_nx = a.starts[rn]; len_nx = (int)a.lens[rn]; } }
         if (r < n) {
-            const u64 s = a.starts[r];
-            const int len = (int)a.lens[r];
             // length 0 = an unused reserved slot; the exact length bounds (the pre-filter may have run with the absolute maximum,
             // before max_clust_length was known)
             if (len == 0 || len < a.len_lo || len > a.len_hi) {
