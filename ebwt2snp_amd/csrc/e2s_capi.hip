@@ -1271,12 +1271,19 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
                 a.host_stream = (uint8_t*)dev_pin; a.stream8_cap = rec_bytes / 8; a.slot_off8 = h->d_slot_off8;
                 a.stream8_count = (unsigned long long*)(h->d_scalars + 6);
+                if (h->cand_cap > h->order_cap) {                   // scratch of the ordering pass (its bucket counts are cleared by k_cand_init)
+                    hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
+                    CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(h->cand_cap)));
+                    CK(hipMalloc((void**)&h->d_order, h->cand_cap * 4));
+                    h->order_cap = h->cand_cap;
+                }
                 void* dev_mail = nullptr;
                 CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
                 e2s_launch_cand_init((unsigned long long*)(h->d_scalars + 1), a.stream8_count, h->d_words + 1,
                                      (const unsigned long long*)((uint8_t*)dev_mail + 2048), (const uint16_t*)((uint8_t*)dev_mail + 2048 + 64 * 8),
                                      (uint32_t)E2S_SEED_SLOTS, (unsigned long long*)h->d_fl_starts, h->d_fl_lens,
-                                     (unsigned long long*)(h->d_scalars + 2), !use_pf, h->stream);
+                                     (unsigned long long*)(h->d_scalars + 2), !use_pf, (uint32_t*)h->d_rank,
+                                     e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);
                 LCHK("e2s_launch_cand_init");
             }
             const bool defw = h->xb == 1 && h->yb == 4 && h->zb == 1;
@@ -1339,7 +1346,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 }
                 const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
                 e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
-                                      h->d_order, h->stream);
+                                      h->d_order, h->stream, true);
                 LCHK("e2s_launch_cand_order");
                 const size_t ord_off = (h->stream_cap_bytes + 63) & ~(size_t)63;
                 h->pin_order = (uint32_t*)(h->pin_cand + ord_off);

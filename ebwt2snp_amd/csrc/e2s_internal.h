@@ -138,7 +138,7 @@ void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_v
                            uint32_t* w1, uint32_t n1, hipStream_t st);   // n_lens, n0, n1 <= 256
 void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* stream8_count, uint32_t* err, const unsigned long long* seed_starts,
                           const uint16_t* seed_lens, uint32_t n_seed_slots, unsigned long long* fl_starts, uint16_t* fl_lens,
-                          unsigned long long* fl_count, bool set_fl_count, hipStream_t st);   // n_seed_slots <= 256
+                          unsigned long long* fl_count, bool set_fl_count, uint32_t* ko_cnt, uint32_t n_ko, hipStream_t st);   // n_seed_slots <= 256
 void e2s_launch_lcp_max(const void* lcp, int xb, unsigned long long n, uint32_t* out, hipStream_t st);        // xb = 2 or 4
 void e2s_launch_lcp_narrow(const void* lcp, int xb, unsigned long long n, uint8_t* out, hipStream_t st);
 void e2s_launch_record_prefilter(const unsigned long long* starts, const uint16_t* lens, unsigned long long n_rec, const uint8_t* bwt,
@@ -180,8 +180,9 @@ void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, u
                              const uint32_t* err_b, unsigned long long* mail, hipStream_t st);
 void e2s_launch_cand_pack(const uint8_t* cand, uint32_t stride, uint32_t list_cap, uint32_t pw, const uint32_t* order, unsigned long long n, uint32_t* size8,
                           unsigned long long n_pad, uint8_t* stream, uint32_t* off_out, hipStream_t st);
+uint32_t e2s_cand_order_buckets(unsigned long long n);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,
-                           unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st);
+                           unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st, bool counts_cleared = false);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
 void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);
 void e2s_launch_unpack_pairsa(const uint8_t* src, unsigned long long n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st);

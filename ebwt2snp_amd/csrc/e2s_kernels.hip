@@ -1982,19 +1982,25 @@ void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hip
 }
 // scratch layout (u32 words): cnt[nb + 1] | slot[n] | gidx[n] | (8-byte aligned) gkeys[n]
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
-void e2s_launch_cand_order(const u64* keys, u64 n, const unsigned long long* n_dev, u64 key_lo, u64 key_span, void* scratch, u32* order, hipStream_t st) {
-    if (!n) return;
-    // ~2 keys per bucket up to 2^16 buckets (the single-block scan of the counts costs ~0.4 us per 1024 buckets; beyond
-    // that longer buckets are cheaper than a longer scan)
+// ~2 keys per bucket up to 2^16 buckets (the single-block scan of the counts costs ~0.4 us per 1024 buckets; beyond
+// that longer buckets are cheaper than a longer scan)
+uint32_t e2s_cand_order_buckets(unsigned long long n) {
     u32 nb = 256;
     while (nb < 65536u && nb < E2S_KO_MAX_BUCKETS && (u64)nb * 2 < n) nb <<= 1;
+    return nb;
+}
+// counts_cleared: the caller has zeroed the first e2s_cand_order_buckets(n) + 1 words of `scratch` already (k_cand_init)
+void e2s_launch_cand_order(const u64* keys, u64 n, const unsigned long long* n_dev, u64 key_lo, u64 key_span, void* scratch, u32* order, hipStream_t st,
+                           bool counts_cleared) {
+    if (!n) return;
+    const u32 nb = e2s_cand_order_buckets(n);
     u32 shift = 0;
     while (shift < 63 && (key_span >> shift) >= (u64)nb) ++shift;           // (key - key_lo) >> shift < nb for key - key_lo < key_span
     u32* cnt = (u32*)scratch;
     u32* slot = cnt + E2S_KO_MAX_BUCKETS + 2;
     u32* gidx = slot + n;
     u64* gkeys = (u64*)(((uintptr_t)(gidx + n) + 7) & ~(uintptr_t)7);
-    hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, st);
+    if (!counts_cleared) hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, st);
     const dim3 g((unsigned)((n + 255) / 256)), blk(256);
     hipLaunchKernelGGL(k_ko_count, g, blk, 0, st, keys, n, n_dev, key_lo, shift, nb, cnt, slot);
     hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, cnt, nb);
@@ -2228,16 +2234,17 @@ __global__ void k_phase_init(u64* count, u64 count_value, uint16_t* lens, u32 n_
 // the per-cluster pass's counters cleared and the seed clusters (read from the pinned mailbox) placed into the reserved head
 // of the flagged list, in one launch
 __global__ void k_cand_init(u64* cand_count, u64* stream8_count, u32* err, const u64* seed_starts, const uint16_t* seed_lens, u32 n_seed_slots,
-                            u64* fl_starts, uint16_t* fl_lens, u64* fl_count, u32 set_fl_count) {
+                            u64* fl_starts, uint16_t* fl_lens, u64* fl_count, u32 set_fl_count, u32* ko_cnt, u32 n_ko) {
     const u32 t = threadIdx.x;
     if (t == 0) { *cand_count = 0; if (stream8_count) *stream8_count = 0; *err = 0; if (set_fl_count) *fl_count = n_seed_slots; }
     if (fl_starts && t < n_seed_slots) { fl_starts[t] = seed_starts[t]; fl_lens[t] = seed_lens[t]; }
+    if (ko_cnt) for (u32 i = t; i < n_ko; i += 256u) ko_cnt[i] = 0u;     // the ordering pass's bucket counts
 }
 void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* stream8_count, uint32_t* err, const unsigned long long* seed_starts,
                           const uint16_t* seed_lens, uint32_t n_seed_slots, unsigned long long* fl_starts, uint16_t* fl_lens,
-                          unsigned long long* fl_count, bool set_fl_count, hipStream_t st) {
+                          unsigned long long* fl_count, bool set_fl_count, uint32_t* ko_cnt, uint32_t n_ko, hipStream_t st) {
     hipLaunchKernelGGL(k_cand_init, dim3(1), dim3(256), 0, st, (u64*)cand_count, (u64*)stream8_count, err, (const u64*)seed_starts, seed_lens,
-                       n_seed_slots, (u64*)fl_starts, fl_lens, (u64*)fl_count, set_fl_count ? 1u : 0u);
+                       n_seed_slots, (u64*)fl_starts, fl_lens, (u64*)fl_count, set_fl_count ? 1u : 0u, ko_cnt, n_ko);
 }
 void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
                            uint32_t* w1, uint32_t n1, hipStream_t st) {
