@@ -294,14 +294,55 @@ __device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
     return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xf, 0xf, false);    // wave_shr:1
 }
 
+// What the pre-filter inherits at the start of a worker's range (local entry r0 >= 4096): the class code of the entry before it
+// and its view of a cluster that reaches into the range -- start, base counts, whether it holds a class change so far.  A
+// cluster that matters is at most 150 entries long, so the 192 entries before the range are enough: three entries per lane,
+// ballots and scalar population counts (a whole warm-up tile through the plane code cost 8 % of a 12-tile worker).
+// Offsets count from the tile before the range (open1 = 1 + offset of the last start among the 192 entries, 0: none).
+struct PfCarry { u32 open1, cin0, ccarry; };
+__device__ __forceinline__ PfCarry prefilter_carry_192(const uint8_t* lcp, const uint8_t* bwt, const int64_t r0, const u32 k_u32, const u32 hge, const u32 lane) {
+    auto cls = [](u32 x) -> u32 { x &= 0xDFu; return x == 'C' ? 1u : x == 'G' ? 2u : x == 'T' ? 3u : 0u; };
+    u64 Sm[3], Cm[3], Gm[3], Tm[3], Fm[3];
+    PfCarry r{0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int64_t e = r0 - 192 + 64 * p + (int64_t)lane;
+        const u32 lm2 = lcp[e - 2], lm1 = lcp[e - 1], l0 = lcp[e];
+        const bool gm1 = hge != 0 && lm1 >= k_u32, g0 = hge != 0 && l0 >= k_u32;
+        const bool endm1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
+        const u32 c = cls(bwt[e]), cp = cls(bwt[e - 1]);
+        Sm[p] = __ballot(g0 && !(gm1 && !endm1));
+        Cm[p] = __ballot(c == 1u); Gm[p] = __ballot(c == 2u); Tm[p] = __ballot(c == 3u);
+        Fm[p] = __ballot(c != cp);
+        if (p == 2) r.ccarry = (u32)__builtin_amdgcn_readlane((int)c, 63);      // C = 1, G = 2, T = 3: bit 0 = C|T, bit 1 = G|T
+    }
+    int sp = -1;                                                // the last start among the 192 entries
+#pragma unroll
+    for (int p = 2; p >= 0; --p) if (sp < 0 && Sm[p]) sp = 64 * p + 63 - __clzll(Sm[p]);
+    if (sp >= 0) {
+        u32 cC = 0, cG = 0, cT = 0; bool fl = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int lo = sp - 64 * p;                                 // entries of this pass at or after the start
+            const u64 m = lo >= 64 ? 0ull : (lo <= 0 ? ~0ull : (~0ull << lo));
+            const u64 mf = lo >= 63 ? 0ull : (lo < 0 ? ~0ull : (~0ull << (lo + 1)));   // strictly after the start
+            cC += (u32)__popcll(Cm[p] & m); cG += (u32)__popcll(Gm[p] & m); cT += (u32)__popcll(Tm[p] & m);
+            fl = fl || (Fm[p] & mf) != 0ull;
+        }
+        r.open1 = 1u + (u32)(4096 - 192 + sp);
+        r.cin0 = cC | (cG << 8) | (cT << 16) | (fl ? (1u << 25) : 0u);
+    }
+    return r;
+}
+
 constexpr int F2_Q = 64;                     // flagged clusters a wave queues in LDS between global reservations (pre-filter)
 // packed base counts C | G << 8 | T << 16 (added) and flags << 24 (or-ed)
 __device__ __forceinline__ u32 pf_merge(u32 x, u32 y) { return (((x & 0xFFFFFFu) + (y & 0xFFFFFFu)) & 0xFFFFFFu) | ((x | y) & 0xFF000000u); }
 
 // FUSED (X == 1 only, e2s_prefilter_arm): the pre-filter of the per-cluster pass (k_cluster_filter2 below, which
 // documents the method) runs inside the scan on the same GE / NLE / start / end planes -- the LCP is read once, the
-// stencil evaluated once; the worker additionally reads the BWT and first runs the tile before its range (WARM: no
-// record is emitted, only the pre-filter's carries are built up).  f is unused otherwise.
+// stencil evaluated once; the worker additionally reads the BWT, and before its range it looks at the 192 entries in front of
+// it (start_carry below) for the pre-filter's view of a cluster that reaches into the range.  f is unused otherwise.
 template <int X, bool FUSED>
 __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f) {
     static_assert(!FUSED || (X == 1 && SPAN_WORDS == 16), "the fused pre-filter works on 1-byte LCPs, 64 entries per lane");
@@ -412,7 +453,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // after the first tile's loads have been issued, so that a worker pays one memory latency at its start, not two.
     u32 cb = 0;
     auto range_carry = [&]() -> u32 {
-        const int64_t r0 = (int64_t)torg * TILE;
+        const int64_t r0 = (int64_t)t0 * TILE;
         const u32 lm2 = entry_at(r0 - 2), lm1 = entry_at(r0 - 1), l0 = entry_at(r0);
         const bool gm1 = a.hge != 0 && lm1 >= a.k_u32, g0 = a.hge != 0 && l0 >= a.k_u32;
         const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
@@ -421,8 +462,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // Two register sets that swap roles from tile to tile (the loop body is instantiated twice): W = the tile
     // being processed, Wn = the next one, in flight meanwhile.
     u32 WA[NW], WB[NW], BA[FUSED ? NR : 1], BB[FUSED ? NR : 1];
-    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch, auto warmup) __attribute__((always_inline)) {
-        constexpr bool PF = decltype(prefetch)::value, WARM = decltype(warmup)::value;
+    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
+        constexpr bool PF = decltype(prefetch)::value;
         if (PF) load_fast(tile + 1, Wn, Bn);                    // in flight while this tile is processed
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
         // ---- start / end planes of the span ----
@@ -478,12 +519,6 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         // left per-thread the compiler if-converts the 64-bit compares into ~300 always-executed instructions)
         const int64_t tl = (int64_t)tile * TILE;
         const bool masked = !(tl >= own_lo && tl + TILE <= end_hi && tl + TILE <= start_hi);
-        if constexpr (WARM) {
-            // the tile before the range: nothing is emitted or evaluated, the pre-filter remembers the last start
-            const u32 lsw = Sa ? (u32)(lane * ES) + (u32)(64 - __clzll(Sa)) : 0u;
-            pf_open1 = max(pf_open1, (u32)__builtin_amdgcn_readlane((int)wave_incl_max(lsw), 63));
-            return;
-        }
         if (masked) {
             u64 ks = 0, ke = 0;
 #pragma unroll 1
@@ -666,27 +701,29 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         // interior tiles are [1, tfe): tile 0 has no word before it, the last ones no word after
         const u64 tfe = n_prov >= (int64_t)(TILE + EPW) ? (u64)((n_prov - EPW) / TILE) : 0ull;
         const u64 tf = min(t1, tfe);
-        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, P0, P0); } };
+        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, P0); } };
         bool have_cb = false;
-        if constexpr (FUSED) {
-            tile = torg;
-            if (tile < t0 && t0 < t1) {                         // the pre-filter's warm-up tile
-                if (tile >= 1 && tile < tfe) load_fast(tile, WA, BA); else load_slow(tile, WA, BA);
-                cb = range_carry(); have_cb = true;
-                body(tile, WA, BA, WB, BB, P0, P1);
+        // what the range inherits: the scan's GE / end of the entry before it, and (FUSED) the pre-filter's carries
+        auto start_carry = [&]() __attribute__((always_inline)) {
+            cb = range_carry();
+            if constexpr (FUSED) {
+                if (t0 > 0 && t0 < t1) {                        // (t0 >= 1: the 192 entries before the range lie inside the provided range)
+                    const PfCarry pc = prefilter_carry_192(base, f.bwt, (int64_t)t0 * TILE, a.k_u32, a.hge, lane);
+                    pf_open1 = pc.open1; cin0 = pc.cin0; ccarry = pc.ccarry;
+                }
             }
-            tile = t0;
-        }
-        if (!have_cb && tile < min(t1, (u64)1)) { cb = range_carry(); have_cb = true; }
+        };
+        if constexpr (FUSED) tile = t0;
+        if (!have_cb && tile < min(t1, (u64)1)) { start_carry(); have_cb = true; }
         slow_run(min(t1, (u64)1));
         if (tile < tf) {
             load_fast(tile, WA, BA);
-            if (!have_cb) { cb = range_carry(); have_cb = true; }
-            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, P1, P0); body(tile + 1, WB, BB, WA, BA, P1, P0); tile += 2; }
-            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, P1, P0); body(tile + 1, WB, BB, WA, BA, P0, P0); tile += 2; }
-            else { body(tile, WA, BA, WB, BB, P0, P0); tile += 1; }
+            if (!have_cb) { start_carry(); have_cb = true; }
+            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, P1); body(tile + 1, WB, BB, WA, BA, P1); tile += 2; }
+            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, P1); body(tile + 1, WB, BB, WA, BA, P0); tile += 2; }
+            else { body(tile, WA, BA, WB, BB, P0); tile += 1; }
         }
-        if (!have_cb) cb = range_carry();
+        if (!have_cb) start_carry();
         slow_run(t1);
         if constexpr (FUSED) queue_flush();
     }
@@ -1506,7 +1543,7 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     if (b >= a.w_blocks) return;
     const u64 t0 = a.w_tile0 + (u64)b * a.w_per + min(b, a.w_rem);
     const u64 t1 = min(t0 + (u64)a.w_per + (b < a.w_rem ? 1u : 0u), a.w_tile0 + a.w_tiles);
-    const u64 torg = t0 > 0 ? t0 - 1 : t0;                      // first tile processed (warm-up tile before the range)
+    const u64 torg = t0 > 0 ? t0 - 1 : t0;                      // offsets count from the tile before the range (the carries' 192 entries lie in it)
     const uint8_t* base = a.lcp;
     const uint8_t* bwtb = a.bwt;
     const int64_t n_prov = (int64_t)a.n_prov;
@@ -1550,7 +1587,7 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     u32 qn = 0;                                                 // queued flagged clusters (wave-uniform)
     u32 cb = 0;                                                 // GE / end of the entry before the first tile
     auto range_carry = [&]() -> u32 {                           // (evaluated after the first tile's loads have been issued)
-        const int64_t r0 = (int64_t)torg * TILE;
+        const int64_t r0 = (int64_t)t0 * TILE;
         const u32 lm2 = entry_at(r0 - 2), lm1 = entry_at(r0 - 1), l0 = entry_at(r0);
         const bool gm1 = a.hge != 0 && lm1 >= a.k_u32, g0 = a.hge != 0 && l0 >= a.k_u32;
         const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
@@ -1572,8 +1609,8 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     };
 
     u32 WA[NW], WB[NW], BA[NR], BB[NR];
-    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch, auto warmup) __attribute__((always_inline)) {
-        constexpr bool PF = decltype(prefetch)::value, WARM = decltype(warmup)::value;
+    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
+        constexpr bool PF = decltype(prefetch)::value;
         if (PF) load_fast(tile + 1, Wn, Bn);
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
         u64 S, E, GE;
@@ -1638,7 +1675,6 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
             asm volatile("" : "+v"(Bn[0]), "+v"(Bn[1]), "+v"(Bn[2]), "+v"(Bn[3]), "+v"(Bn[4]), "+v"(Bn[5]), "+v"(Bn[6]), "+v"(Bn[7]),
                               "+v"(Bn[8]), "+v"(Bn[9]), "+v"(Bn[10]), "+v"(Bn[11]), "+v"(Bn[12]), "+v"(Bn[13]), "+v"(Bn[14]), "+v"(Bn[15]));
         }
-        if (WARM) return;
         // ENDs to evaluate: owned, and of clusters with a class change somewhere (incoming flag: bit 25 of the carry)
         u64 Ev = E;
         const int64_t tl = (int64_t)tile * TILE;
@@ -1668,7 +1704,7 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
             const u32 len = base_off + (u32)e + 2u - st1;
             const u32 cC = pk & 0xFFu, cG = (pk >> 8) & 0xFFu, cT = (pk >> 16) & 0xFFu, cA = len - cC - cG - cT;
             const u32 nfreq = (cA >= a.mcov_u ? 1u : 0u) + (cC >= a.mcov_u ? 1u : 0u) + (cG >= a.mcov_u ? 1u : 0u) + (cT >= a.mcov_u ? 1u : 0u);
-            // st1 == 0: the cluster began before the warm-up tile, i.e. it is longer than a tile and fails the length test
+            // st1 == 0: the cluster began more than 192 entries before the range, i.e. it fails the length test
             const bool pass = act && st1 != 0u && (int)len >= a.len_lo && (int)len <= a.len_hi && nfreq >= 2u;
             const u64 pm = __ballot(pass);
             if (pass) {
@@ -1684,25 +1720,28 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
         u64 tile = torg;
         const u64 tfe = n_prov >= (int64_t)(TILE + 4) ? (u64)((n_prov - 4) / TILE) : 0ull;   // interior tiles are [1, tfe)
         const u64 tf = min(t1, tfe);
-        // the warm-up tile (evaluates nothing), then tile 0 of the shard if it is ours: byte-wise loads
+        // what the range inherits: GE / end of the entry before it, and the carries of a cluster that reaches into it (from the 192
+        // entries before the range; offsets count from the tile before the range)
+        auto start_carry = [&]() __attribute__((always_inline)) {
+            cb = range_carry();
+            if (t0 > 0 && t0 < t1) {
+                const PfCarry pc = prefilter_carry_192(base, bwtb, (int64_t)t0 * TILE, a.k_u32, a.hge, lane);
+                open1 = pc.open1; cin0 = pc.cin0; ccarry = pc.ccarry;
+            }
+        };
+        tile = t0;
         bool have_cb = false;
-        if (tile < t0) {
-            if (tile >= 1 && tile < tfe) load_fast(tile, WA, BA); else load_slow(tile, WA, BA);
-            cb = range_carry(); have_cb = true;
-            body(tile, WA, BA, WB, BB, N, Y);
-            ++tile;
-        }
-        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, N, N); } };
-        if (!have_cb && tile < min(t1, (u64)1)) { cb = range_carry(); have_cb = true; }
+        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, N); } };
+        if (!have_cb && tile < min(t1, (u64)1)) { start_carry(); have_cb = true; }
         slow_run(min(t1, (u64)1));
         if (tile < tf) {
             load_fast(tile, WA, BA);
-            if (!have_cb) { cb = range_carry(); have_cb = true; }
-            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, Y, N); body(tile + 1, WB, BB, WA, BA, Y, N); tile += 2; }
-            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, Y, N); body(tile + 1, WB, BB, WA, BA, N, N); tile += 2; }
-            else { body(tile, WA, BA, WB, BB, N, N); tile += 1; }
+            if (!have_cb) { start_carry(); have_cb = true; }
+            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, Y); body(tile + 1, WB, BB, WA, BA, Y); tile += 2; }
+            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, Y); body(tile + 1, WB, BB, WA, BA, N); tile += 2; }
+            else { body(tile, WA, BA, WB, BB, N); tile += 1; }
         }
-        if (!have_cb) cb = range_carry();
+        if (!have_cb) start_carry();
         slow_run(t1);
     }
     queue_flush();
