@@ -157,6 +157,7 @@ class Handle:
         self._cbuf = None
 
     def close(self):
+        self._packed_views = None
         if self.h:
             self.L.e2s_destroy(self.h)
             self.h = C.c_void_p()
@@ -279,9 +280,15 @@ class Handle:
         self._ck(self.L.e2s_candidates_packed(self.h, C.byref(st), C.byref(off), C.byref(n), C.byref(nbytes), C.byref(pw)))
         if not n.value:
             return np.zeros(0, np.uint8), np.zeros(1, np.uint32), 0, pw.value
-        r = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint8)), shape=(nbytes.value,))
-        o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint32)), shape=(n.value + 1,))
-        return r, o, n.value, pw.value
+        # views of the handle's pinned buffer; building them costs ~25 us (np.ctypeslib.as_array creates a ctypes type per shape),
+        # and a job repeated on the same handle gets the same addresses and sizes back: keep the last pair
+        key = (st.value, nbytes.value, off.value, n.value)
+        cached = getattr(self, "_packed_views", None)
+        if cached is None or cached[0] != key:
+            r = np.frombuffer((C.c_uint8 * nbytes.value).from_address(st.value), dtype=np.uint8)
+            o = np.frombuffer((C.c_uint32 * (n.value + 1)).from_address(off.value), dtype=np.uint32)
+            cached = self._packed_views = (key, r, o)
+        return cached[1], cached[2], n.value, pw.value
 
     def timing(self):
         t = Timing()
