@@ -616,6 +616,20 @@ def test_few_workers_many_tiles_each(tmp_path):
 
 
 @pytest.mark.gpu
+def test_first_prefilter_formulation_kept(tmp_path):
+    """E2S_FILTER_V1=1 selects the first formulation of the pre-filter (thread rows of 16 entries, LDS slots per cluster), kept as an
+    independent implementation of the same superset test: a child pytest runs the candidate comparisons with it"""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    env = dict(os.environ, E2S_FILTER_V1="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "fused_streaming_candidates_equal_oracle or fused_streaming_fuzz_columns or fused_streaming_adversarial"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
