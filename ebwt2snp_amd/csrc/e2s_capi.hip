@@ -520,7 +520,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
                 } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
             }
             if (!fuse_now) CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
-            // four timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix, after the
+            // three timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix + the
             // statistics.  With the pre-filter inside the scan kernel the start event is the per-cluster pass's (ev[6]).
             h->scan_start_ev = fuse_now ? 6 : 0;
             CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
@@ -537,11 +537,10 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb,
                                h->d_mail, (unsigned long long*)dh, h->stream);
             LCHK("e2s_launch_seg_fix");
-            CK(hipEventRecord(h->ev[1], h->stream));
             // statistics of the records in the same phase (no second round trip): e2s_scan_stats_desc / e2s_cluster_hist
             e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)dh,
                                 (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
-            CK(hipEventRecord(h->ev[5], h->stream));
+            CK(hipEventRecord(h->ev[1], h->stream));                // (no event between the two follow-up kernels: each costs stream time)
             LCHK("e2s_launch_hist_seg");
             CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
             CK(wait_stream(h));
@@ -567,7 +566,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             rs.hist.last_len = rs.last_none ? 0 : buf[E2S_MAX_CLUST_LEN + 3];
             rs.min_len = min_len;
             h->raw_stats_valid = true;
-            hipEventElapsedTime(&h->tm.hist_ms, h->ev[1], h->ev[5]);
+            hipEventElapsedTime(&h->tm.hist_ms, h->ev[3], h->ev[1]);     // k_seg_fix + the statistics
         }
     } else {
         // ---- three-kernel count / scan / emit into contiguous arrays ----

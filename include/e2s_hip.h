@@ -247,9 +247,9 @@ int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n
 
 /* ---- measurement --------------------------------------------------------------------------- */
 typedef struct {
-    float scan_ms;        /* e2s_cluster_scan kernels (HIP events on the handle's stream) */
+    float scan_ms;        /* e2s_cluster_scan kernels incl. the statistics (HIP events on the handle's stream) */
     float scan_main_ms;   /* the dominant scan kernel alone */
-    float hist_ms;
+    float hist_ms;        /* the scan's follow-up kernels (segment fix-up + statistics); e2s_cluster_hist: its own kernel */
     float cand_ms;        /* e2s_find_candidates kernels */
     float cand_main_ms;   /* the dominant per-cluster kernel alone */
     float upload_ms;
