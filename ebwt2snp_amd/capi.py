@@ -73,6 +73,7 @@ class Timing(C.Structure):
 
 
 # every symbol include/e2s_hip.h declares (checked by tests/test_capi_symbols.py)
+BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)     # e2s_byte_sink
 SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
            "e2s_attach_soa", "e2s_upload_lcp", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_stream_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
@@ -106,6 +107,7 @@ def lib():
     L.e2s_stitch_plan.argtypes = [C.POINTER(Boundary), C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(StitchPlan)]
     L.e2s_cluster_counts.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_fetch_clusters.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.e2s_stream_clusters.argtypes = [H, BYTE_SINK, C.c_void_p, C.POINTER(C.c_uint64)]
     L.e2s_load_clusters.argtypes = [H, C.c_void_p, C.c_uint64]
     L.e2s_cluster_hist.argtypes = [H, C.POINTER(Hist)]
     L.e2s_scan_stats_desc.argtypes = [H, C.POINTER(ScanStats)]
@@ -221,6 +223,16 @@ class Handle:
         buf = np.zeros(max(n.value, 1) * 10, dtype=np.uint8)
         self._ck(self.L.e2s_fetch_clusters(self.h, _ptr(buf), n.value, C.byref(n)))
         return buf[:n.value * 10]
+
+    def stream_clusters(self, sink):
+        """the `.clusters` bytes handed to sink(bytes) chunk by chunk (whole records, file order); sink returns None / 0 to go on,
+        anything else stops the stream (E2S_ERR_IO).  Returns the number of records."""
+        def cb(_user, data, nbytes):
+            r = sink(C.string_at(data, nbytes))
+            return int(r) if r else 0
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_stream_clusters(self.h, BYTE_SINK(cb), None, C.byref(n)))
+        return n.value
 
     def load_clusters(self, packed):
         packed = np.ascontiguousarray(packed, dtype=np.uint8)

@@ -630,6 +630,27 @@ def test_first_prefilter_formulation_kept(tmp_path):
 
 
 @pytest.mark.gpu
+def test_stream_clusters_sink(H):
+    """e2s_stream_clusters: the `.clusters` image leaves in chunks of whole records that concatenate to e2s_fetch_clusters' bytes
+    (an output larger than one staging chunk, min_len filter active); a sink that refuses stops the stream with E2S_ERR_IO"""
+    rnd = np.random.RandomState(5)
+    n = 12000000
+    lcp = np.where(rnd.rand(n) < 0.55, rnd.randint(16, 40, n), rnd.randint(0, 16, n)).astype(np.uint8)
+    lcp[-1] = 0
+    H.upload_lcp(capi.Handle.desc(n), lcp, 65)
+    H.scan_single(16, 3, 0)
+    whole = H.fetch_clusters().tobytes()
+    chunks = []
+    nrec = H.stream_clusters(lambda b: chunks.append(b))
+    assert nrec * 10 == len(whole) > 4000000 and len(chunks) >= 2 and all(len(c) % 10 == 0 for c in chunks)
+    assert b"".join(chunks) == whole
+    seen = []
+    with pytest.raises(capi.E2SError):
+        H.stream_clusters(lambda b: (seen.append(len(b)), 1)[1])
+    assert len(seen) == 1
+
+
+@pytest.mark.gpu
 def test_tiled_copies_property():
     """size-independent property at a size the oracle is not needed for: k copies of a block laid end to end (read ids
     remapped per copy, as bench.py's c3 does) must give k times the records and, copy by copy, the same candidates
