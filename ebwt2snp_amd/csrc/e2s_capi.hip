@@ -1279,7 +1279,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
                 void* dev_mail = nullptr;
                 CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
                 e2s_launch_cand_init((unsigned long long*)(h->d_scalars + 1), a.stream8_count, h->d_words + 1,
-                                     (const unsigned long long*)((uint8_t*)dev_mail + 2048), (const uint16_t*)((uint8_t*)dev_mail + 2048 + 64 * 8),
+                                     nseed ? (const unsigned long long*)((uint8_t*)dev_mail + 2048) : nullptr, (const uint16_t*)((uint8_t*)dev_mail + 2048 + 64 * 8),
                                      (uint32_t)E2S_SEED_SLOTS, (unsigned long long*)h->d_fl_starts, h->d_fl_lens,
                                      (unsigned long long*)(h->d_scalars + 2), !use_pf, (uint32_t*)h->d_rank,
                                      e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);

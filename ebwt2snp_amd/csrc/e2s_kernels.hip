@@ -2276,7 +2276,8 @@ __global__ void k_cand_init(u64* cand_count, u64* stream8_count, u32* err, const
                             u64* fl_starts, uint16_t* fl_lens, u64* fl_count, u32 set_fl_count, u32* ko_cnt, u32 n_ko) {
     const u32 t = threadIdx.x;
     if (t == 0) { *cand_count = 0; if (stream8_count) *stream8_count = 0; *err = 0; if (set_fl_count) *fl_count = n_seed_slots; }
-    if (fl_starts && t < n_seed_slots) { fl_starts[t] = seed_starts[t]; fl_lens[t] = seed_lens[t]; }
+    // (seed_starts == nullptr: no seeds -- the usual case; reading the empty slots from host memory would cost a PCIe round trip)
+    if (fl_starts && t < n_seed_slots) { fl_starts[t] = seed_starts ? seed_starts[t] : 0ull; fl_lens[t] = seed_starts ? seed_lens[t] : (uint16_t)0; }
     if (ko_cnt) for (u32 i = t; i < n_ko; i += 256u) ko_cnt[i] = 0u;     // the ordering pass's bucket counts
 }
 void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* stream8_count, uint32_t* err, const unsigned long long* seed_starts,
