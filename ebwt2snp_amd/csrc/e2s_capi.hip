@@ -61,6 +61,7 @@ struct e2s_ctx {
     uint8_t* pin_io[2] = {nullptr, nullptr}; uint64_t pin_io_cap = 0; hipEvent_t ev_io[2] = {nullptr, nullptr};
     int scan_start_ev = 0; bool pf_fused = false;                // which event began the last scan; the in-flight pre-filter ran inside it
     bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
+    uint64_t scan_gen = 0, pf_gen = 0;                            // the scan a pre-filter result belongs to (a stale one is never consumed)
     bool pf_armed = false; int pf_arm_mcov = 0;                   // e2s_prefilter_arm: the next scan starts it beside itself (second stream)
     bool pf_on_stream2 = false; hipEvent_t ev_pf = nullptr;
     hipEvent_t ev_wait = nullptr;
@@ -135,13 +136,18 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
         delete h;
         return E2S_ERR_HIP;
     }
-    for (auto& ev : h->ev) hipEventCreate(&ev);
-    hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+    bool ok = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;   // (a null stream2 would be the default stream)
+    for (auto& ev : h->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    if (!ok) {
+        g_create_error = "hipStreamCreate / hipEventCreate failed";
+        e2s_destroy(h);
+        return E2S_ERR_HIP;
+    }
     if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, 4096) != hipSuccess ||   // ScanMail | statistics at +256
         hipHostMalloc((void**)&h->pin_mail, 4096, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "hipMalloc failed";
-        delete h;
+        e2s_destroy(h);
         return E2S_ERR_HIP;
     }
     *out = h;
@@ -167,7 +173,16 @@ static hipError_t wait_stream(e2s_ctx* h) {
     return hipStreamSynchronize(h->stream);
 }
 
+// Forget a pre-filter result that was started ahead of e2s_find_candidates (arm / begin): whatever replaces the shard, the
+// records or the scan it was computed for makes it stale.  One that runs on the second stream is ordered before anything
+// that follows on the handle's stream, since it writes the flagged list the next one will reuse.
+static void drop_prefilter(e2s_ctx* h) {
+    if (h->pf_inflight && h->pf_on_stream2 && h->ev_pf) hipStreamWaitEvent(h->stream, h->ev_pf, 0);
+    h->pf_inflight = false; h->pf_fused = false; h->pf_on_stream2 = false;
+}
+
 static void release_shard(e2s_ctx* h) {
+    drop_prefilter(h);
     for (void* p : h->owned) hipFree(p);
     h->owned.clear();
     h->bwt = nullptr; h->lcp = h->pos = h->da = nullptr;
@@ -179,7 +194,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     dbg_entry("e2s_destroy");
     if (!h) return E2S_OK;
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    if (h->stream) hipStreamSynchronize(h->stream);
     release_shard(h);
     hipFree(h->d_starts); hipFree(h->d_lens); hipFree(h->d_tile_fix);
     hipFree(h->d_tile_count); hipFree(h->d_tile_prefix); hipFree(h->d_scalars); hipFree(h->d_words); hipFree(h->d_cand);
@@ -196,7 +211,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->ev_pf) hipEventDestroy(h->ev_pf);
     for (auto& e : h->ev_chunk) if (e) hipEventDestroy(e);
     if (h->stream2) hipStreamDestroy(h->stream2);
-    hipStreamDestroy(h->stream);
+    if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return E2S_OK;
 }
@@ -424,10 +439,11 @@ static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_
         SegArgs sa{};
         sa.starts = h->d_starts; sa.lens = h->d_lens; sa.seg_cap = h->seg_cap; sa.desc = h->d_seg_desc; sa.n_blocks = h->seg_blocks;
         if (h->n_ends) e2s_launch_seg_compact(sa, (const unsigned long long*)h->d_seg_off, (unsigned long long*)h->d_cstarts, h->d_clens, h->stream);
-        if (h->stitched && h->plan.n_tail)
+        if (h->stitched && h->plan.n_tail) {
             e2s_launch_apply_plan((unsigned long long*)h->d_cstarts, h->d_clens, 0, 0, 0, h->n_ends, h->plan.n_tail, h->plan.tail_start[0],
                                   h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], h->stream);
             LCHK("e2s_launch_apply_plan");
+        }
         CK(hipStreamSynchronize(h->stream));
         CK(hipGetLastError());
         h->compact_valid = true;
@@ -445,6 +461,8 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     const e2s_shard_desc& d = h->d;
     h->k = k; h->min_len = min_len;
     h->scanned = h->stitched = false; h->records_from_file = false; h->compact_valid = false;
+    drop_prefilter(h);                                          // (a result of an earlier scan: other k, other data)
+    ++h->scan_gen;
 
     ScanArgs a{};
     a.lcp = h->lcp; a.n_prov = h->n_prov; a.prov_lo = h->prov_lo; a.prov_is_global0 = h->prov_lo == 0;
@@ -527,7 +545,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             if (fuse_now) {
                 // (a rerun after a segment overflow scans alone: the pre-filter's list does not depend on the segments)
                 e2s_launch_scan_seg_fused(sa, fa, h->stream);
-                h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true;
+                h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true; h->pf_gen = h->scan_gen;
             } else e2s_launch_scan_seg(sa, h->xb, h->stream);
             LCHK("e2s_launch_scan_seg");
             CK(hipEventRecord(h->ev[3], h->stream));
@@ -742,17 +760,19 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     if (h->segmented) {
         // record 0 lives at the head of the first non-empty segment; the tail records stay on the host
         // (hist and the per-cluster pass take them from the plan, records_contiguous() appends them)
-        if (pl.patch_first && h->first_rec_addr != E2S_NONE)
+        if (pl.patch_first && h->first_rec_addr != E2S_NONE) {
             e2s_launch_apply_plan((unsigned long long*)h->d_starts + h->first_rec_addr, h->d_lens + h->first_rec_addr, 1, pl.first_start,
                                   pl.first_len, 0, 0, 0, 0, 0, 0, h->stream);
             LCHK("e2s_launch_apply_plan");
+        }
         h->compact_valid = false;
     } else {
         if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
-        if (pl.patch_first || pl.n_tail)
+        if (pl.patch_first || pl.n_tail) {
             e2s_launch_apply_plan((unsigned long long*)h->d_starts, h->d_lens, pl.patch_first, pl.first_start, pl.first_len, h->n_ends,
                                   pl.n_tail, pl.tail_start[0], pl.tail_len[0], pl.tail_start[1], pl.tail_len[1], h->stream);
             LCHK("e2s_launch_apply_plan");
+        }
     }
     h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
     h->plan = pl;
@@ -870,6 +890,7 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
     if (!h || (!recs && n_records)) return E2S_ERR_ARG;
     if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
     CK(hipSetDevice(h->device));
+    drop_prefilter(h); h->pf_armed = false;                     // (it belonged to the scan's records)
     int rc = ensure_records(h, n_records + 8);
     if (rc) return rc;
     if (n_records) {
@@ -1108,7 +1129,7 @@ static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_r
     e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, max_workers, st);
     LCHK("e2s_launch_cluster_filter");
     CK(hipEventRecord(h->ev[4], st));
-    h->pf_inflight = true; h->pf_mcov = mcov_out; h->pf_len_lo = f.len_lo; h->pf_fused = false;
+    h->pf_inflight = true; h->pf_mcov = mcov_out; h->pf_len_lo = f.len_lo; h->pf_fused = false; h->pf_gen = h->scan_gen;
     h->pf_on_stream2 = st != h->stream;
     if (h->pf_on_stream2) {
         if (!h->ev_pf) CK(hipEventCreateWithFlags(&h->ev_pf, hipEventDisableTiming));
@@ -1209,8 +1230,9 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         static const int rec_pf_env = getenv("E2S_RECORD_PREFILTER") ? atoi(getenv("E2S_RECORD_PREFILTER")) : 1;
         const bool rec_pf = !streaming && rec_pf_ok && rec_pf_env && h->bwt && h->n_rec > 0;
         const bool listmode = streaming || rec_pf;
-        const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
+        const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_gen == h->scan_gen && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
         pf_end_ev = (use_pf && h->pf_fused) ? 3 : 4;            // the pre-filter ended with the scan kernel / with its own event
+        if (!use_pf && h->pf_inflight && h->pf_on_stream2 && h->ev_pf) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // (it still writes the list)
         h->pf_inflight = false; h->pf_fused = false;
         if (!use_pf) CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));     // (an early pre-filter may have set its error bits)
         if (use_pf && h->pf_on_stream2) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // it ran on the second stream

@@ -39,8 +39,15 @@ struct EgsaFiles {
     bool gesa = false;
     MappedFile aos, bwt, lcp, pairsa;
     uint64_t n = 0;
-    // exits like the reference when nothing is found
+    // exits like the reference when nothing is found.  The reference derives everything from the LCP stream's EOF
+    // (include.hpp:92-107) and keeps reading stale values when another file is shorter; here a width outside 1/2/4/8 or a
+    // file too short for the entry count is refused before anything is mapped onto the GPU.
     void open_or_die(const std::string& input, int x, int y, int z) {
+        auto width_ok = [](int w) { return w == 1 || w == 2 || w == 4 || w == 8; };
+        if (!width_ok(x) || !width_ok(y) || !width_ok(z)) {
+            std::cerr << "byte widths (-x -y -z) must be 1, 2, 4 or 8 (the reference leaves fields of other widths uninitialised)" << std::endl;
+            exit(2);
+        }
         if (aos.open(input + ".gesa")) {
             gesa = true;
             n = aos.n / (size_t)(x + y + z + 1);
@@ -48,6 +55,11 @@ struct EgsaFiles {
         }
         if (lcp.open(input + ".out.lcp") && bwt.open(input + ".out") && pairsa.open(input + ".out.pairSA")) {
             n = lcp.n / (size_t)x;
+            if (bwt.n < n || pairsa.n < n * (size_t)(y + z)) {
+                std::cerr << "index files are inconsistent: " << n << " LCP entries of " << x << " bytes, but " << bwt.n << " BWT bytes and "
+                          << pairsa.n << " pairSA bytes (" << (y + z) << " per entry): wrong -x/-y/-z or a truncated file" << std::endl;
+                exit(2);
+            }
             return;
         }
         std::cout << "Error: missing index files." << std::endl;

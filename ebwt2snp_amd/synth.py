@@ -20,11 +20,13 @@ _ASCII = torch.tensor([65, 67, 71, 84], dtype=torch.uint8)  # A C G T
 
 
 def make_reads(n_reads_per_indiv, read_len, coverage=20, snp_every=300, indel_every=5000,
-               seed=1, device="cpu"):
+               seed=1, device="cpu", truth=None):
     """Two individuals from one random genome; individual 2 carries SNPs and 3-bp deletions.
 
     Returns (reads uint8 [2R, L] of ASCII codes, nr_reads1 = R).  Reads 0..R-1 come from
     individual 1, R..2R-1 from individual 2; no reverse complements, no 'N'.
+    truth: an optional dict that receives the planted ground truth (genome of individual 1 as ASCII,
+    0-based SNP positions on it, REF / ALT letters) -- what snp_vs_vcf (snp_vs_vcf.cpp:108-573) is fed with.
     """
     R, L = int(n_reads_per_indiv), int(read_len)
     g = torch.Generator(device="cpu")
@@ -38,6 +40,9 @@ def make_reads(n_reads_per_indiv, read_len, coverage=20, snp_every=300, indel_ev
     keep = torch.ones(G, dtype=torch.bool)
     for p in range(indel_every // 2, G - 3, indel_every):
         keep[p:p + 3] = False
+    if truth is not None:
+        truth.update(genome=_ASCII[genome].numpy(), snp_pos=snp_pos.numpy(), ref=_ASCII[genome[snp_pos]].numpy(),
+                     alt=_ASCII[ind2[snp_pos]].numpy(), deleted=(~keep).numpy())
     ind2 = ind2[keep]
     g2 = torch.Generator(device="cpu")
     g2.manual_seed(seed + 1)

@@ -1,0 +1,50 @@
+// integration_snippet.cpp -- the C++ snippets of INTEGRATION.md, compiled (never run) against include/e2s_hip.h by
+// tests/test_host_logic.py::test_integration_snippets_compile, which also checks that every ```cpp block of the document
+// appears here verbatim: the document cannot drift from the header again.
+// The declarations in front of each block stand for what the reference's main() has in scope at that seam.
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+#include "e2s_hip.h"      // (the snippets' own #include line, at file scope where the reference would have it)
+using namespace std;
+
+int snippet_ebwt2clust(int lcp, int da, int pos, int k, int min_len, uint64_t n, const void* lcp_bytes, uint8_t bwt_last_byte, ofstream& out) {
+// [snippet 1: ebwt2clust.cpp]
+// after parsing options; lcp/da/pos/k/min_len already defaulted (:175-180)
+e2s_handle h; if (e2s_create(0, &h)) { cerr << e2s_last_error(NULL) << endl; return 2; }
+e2s_shard_desc d = {0, n, n, 0, 0, lcp, da, pos, 0};           // whole EGSA on one GPU
+// BCR triple mapped/read by the caller (X.out.lcp, last byte of X.out):
+e2s_upload_lcp(h, &d, lcp_bytes, bwt_last_byte);               // cluster_lm only ever looks at the LCP
+e2s_cluster_scan(h, k, min_len, 0);
+e2s_boundary b; e2s_boundary_desc(h, &b); e2s_stitch(h, &b, 1, 0);   // one rank: trivial stitch, resolves the EOF rule
+uint64_t n_closed, n_rec; e2s_cluster_counts(h, &n_closed, &n_rec);
+std::vector<char> recs(n_rec * 10); e2s_fetch_clusters(h, recs.data(), n_rec, &n_rec);
+out.write(recs.data(), n_rec * 10);                             // same bytes append_entry (:54-63) would have written
+// (large outputs: e2s_stream_clusters(h, sink, user, &n_rec) hands the same bytes to a sink chunk by chunk out of pinned
+//  staging buffers -- what this repo's ebwt2clust uses, with write(2) as the sink)
+cout << "Done. " << (unsigned)n_closed << " clusters saved to output file." << endl;   // :137
+// [end]
+    return 0;
+}
+
+int snippet_clust2snp(e2s_handle h, e2s_shard_desc d, const void* bwt, const void* lcp, const void* pairsa, const void* clusters_bytes, uint64_t n_records,
+                      int mcov_out, double pval, uint64_t nr_reads1, int k_left, int k_right, int consensus_reads, int max_gap, int max_err,
+                      string input, string filename_out) {
+    int max_clust_length; uint64_t n_clust, n_bases;
+// [snippet 2: clust2snp.cpp]
+e2s_upload_bcr(h, &d, bwt, lcp, pairsa);        // or e2s_upload_gesa(h, &d, gesa)
+e2s_load_clusters(h, clusters_bytes, n_records); // the .clusters file as is
+e2s_hist hs; e2s_cluster_hist(h, &hs);
+e2s_auto_max_clust_length(&hs, 1, mcov_out, pval, &max_clust_length, &n_clust, &n_bases);   // :936-946 incl. the H4 double count
+e2s_c2s_params p = {nr_reads1, k_left, k_right, mcov_out, consensus_reads, max_clust_length, 0};
+uint64_t n_cand; e2s_find_candidates(h, &p, 0, &n_cand);        // find_events + find_variants (:788-857, :367-500)
+const void* stream; const uint32_t* off8; uint64_t bytes; uint32_t pos_bytes;
+e2s_candidates_packed(h, &stream, &off8, &n_cand, &bytes, &pos_bytes);   // pinned host memory written by the GPU: packed, SA order
+e2s_tail_params t = {k_left, k_right, max_gap, max_err};
+uint64_t nv, ne;
+e2s_snp_from_packed(stream, off8, n_cand, pos_bytes, &t, input.c_str(), filename_out.c_str(), &nv, &ne);   // :505-780
+// [end]
+    return (int)(nv + ne);
+}

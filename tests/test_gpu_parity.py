@@ -709,3 +709,49 @@ def test_sharded_fuzz_columns(seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run(seed)
+
+
+@pytest.mark.gpu
+def test_stale_prefilter_result_is_not_consumed(H, tmp_path):
+    """a pre-filter started ahead of e2s_find_candidates (arm / begin) belongs to ONE scan: a rescan with another k, a new shard or
+    records loaded from a file must not pick its flagged list up (it would silently give the candidates of the earlier scan)"""
+    reads, n1, e = synth.synth_case(2500, 100, seed=61)
+    en = synth.egsa_to_numpy(e)
+    n = en["lcp"].size
+    psa = np.zeros(n, dtype=np.dtype([("s", IO._DT[1]), ("t", IO._DT[4])]))
+    psa["s"] = en["suff"]
+    psa["t"] = en["text"]
+    oc20, omcl20 = _oracle_candidates(tmp_path, reads.numpy(), en, n1, k=20, tag="k20")
+
+    def finish(k):
+        H.stitch([H.boundary()], 0)
+        mcl, _, _ = capi.auto_max_clust_length([H.hist()], 5, 0.99)
+        prm = capi.C2SParams(n1, 31, 30, 5, 20, mcl, 2)
+        H.find_candidates(prm)
+        buf, nc, cap, stride = H.fetch_candidates(prm)
+        return capi.parse_candidates(buf, nc, cap, stride), mcl
+
+    for early in ("arm", "begin"):
+        H.upload_bcr(capi.Handle.desc(n), en["bwt"], en["lcp"].view(np.uint8), psa.view(np.uint8))
+        if early == "arm":
+            H.prefilter_arm(5)
+        H.cluster_scan(16, 2, 0)
+        if early == "begin":
+            H.prefilter_begin(5, 2)
+        H.cluster_scan(20, 2, 0)                                  # unarmed rescan with another k: the k = 16 result is stale
+        got, mcl = finish(20)
+        assert mcl == omcl20 and len(got) == len(oc20) > 0, early
+        for a, b in zip(got, oc20):
+            for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+                assert a[key] == b[key], early
+    # ... and a new shard (other data) after an armed scan whose result was never used
+    reads2, n12, e2 = synth.synth_case(2000, 100, seed=62)
+    en2 = synth.egsa_to_numpy(e2)
+    oc2, omcl2 = _oracle_candidates(tmp_path, reads2.numpy(), en2, n12, tag="other")
+    H.prefilter_arm(5)
+    H.cluster_scan(16, 2, 0)
+    got, mcl = _fused_candidates(H, en2, n12, early=False)
+    assert mcl == omcl2 and len(got) == len(oc2) > 0
+    for a, b in zip(got, oc2):
+        for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
+            assert a[key] == b[key]

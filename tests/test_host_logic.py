@@ -291,3 +291,20 @@ def test_host_tail_threads_and_parallel_fasta(case, tmp_path, monkeypatch):
             out = str(tmp_path / ("%s.t%s.snp" % (name, threads)))
             capi.snp_from_candidates(_pack_candidates(cands, 20), len(cands), 20, q, out)
             assert open(out, "rb").read() == want, (name, threads)
+
+
+def test_integration_snippets_compile():
+    """INTEGRATION.md's C++ snippets are what a maintainer of the reference would paste: every ```cpp block of the document must
+    appear verbatim (its #include line apart) in tests/integration_snippet.cpp, and that file must compile against
+    include/e2s_hip.h -- so the document cannot drift from the header"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src_path = os.path.join(ROOT, "tests", "integration_snippet.cpp")
+    src = open(src_path).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", doc, flags=re.S)
+    assert len(blocks) >= 2
+    for b in blocks:
+        body = "\n".join(l for l in b.split("\n") if not l.startswith("#include"))
+        assert body.strip() and body in src, "INTEGRATION.md block not found verbatim in tests/integration_snippet.cpp:\n" + body[:300]
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src_path],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
