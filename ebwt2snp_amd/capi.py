@@ -8,11 +8,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libe2s_hip.so")
+if os.environ.get("E2S_LIB_PATH"):            # development aid: an ablation build of the library (tools/kbench.py)
+    LIB_PATH = os.environ["E2S_LIB_PATH"]
 
 E2S_NONE = (1 << 64) - 1
 MAX_CLUST_LEN = 150
 
-ERR = {0: "OK", 1: "ERR_ARG", 2: "ERR_HIP", 3: "ERR_STATE", 4: "ERR_CAPACITY", 5: "ERR_SPIN_TIMEOUT",
+ERR = {0: "OK", 1: "ERR_ARG", 2: "ERR_HIP", 3: "ERR_STATE", 4: "ERR_CAPACITY", 5: "ERR_5_UNUSED",
        6: "ERR_INPUT", 7: "ERR_REF_CRASH", 8: "ERR_IO"}
 
 
@@ -67,7 +69,7 @@ class TailParams(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("scan_main_ms", C.c_float), ("hist_ms", C.c_float), ("cand_ms", C.c_float),
-                ("cand_main_ms", C.c_float), ("upload_ms", C.c_float),
+                ("cand_main_ms", C.c_float), ("upload_ms", C.c_float), ("tail_ms", C.c_float),
                 ("scan_bytes_read", C.c_uint64), ("scan_bytes_written", C.c_uint64),
                 ("cand_bytes_read", C.c_uint64), ("cand_bytes_written", C.c_uint64)]
 
@@ -79,7 +81,8 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_stream_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
-           "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize"]
+           "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize",
+           "e2s_upload_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp"]
 
 _lib = None
 
@@ -129,6 +132,13 @@ def lib():
                                         C.POINTER(C.c_uint32)]
     L.e2s_snp_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p, C.c_char_p,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_upload_reads.argtypes = [H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    L.e2s_attach_reads.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    L.e2s_upload_reads_fasta.argtypes = [H, C.c_char_p, C.POINTER(C.c_uint64)]
+    L.e2s_call_variants.argtypes = [H, C.POINTER(TailParams), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_fetch_snp.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.e2s_stream_snp.argtypes = [H, BYTE_SINK, C.c_void_p]
+    L.e2s_write_snp.argtypes = [H, C.POINTER(TailParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_last_timing.argtypes = [H, C.POINTER(Timing)]
     L.e2s_stream.argtypes = [H, C.POINTER(C.c_void_p)]
     L.e2s_synchronize.argtypes = [H]
@@ -301,6 +311,41 @@ class Handle:
             o = np.frombuffer((C.c_uint32 * (n.value + 1)).from_address(off.value), dtype=np.uint32)
             cached = self._packed_views = (key, r, o)
         return cached[1], cached[2], n.value, pw.value
+
+    def upload_reads_fasta(self, path):
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_upload_reads_fasta(self.h, path.encode(), C.byref(n)))
+        return n.value
+
+    def upload_reads(self, text, start, length):
+        """reads as host arrays: text uint8, start uint64 [n], length uint32 [n]"""
+        text = np.ascontiguousarray(text, dtype=np.uint8); start = np.ascontiguousarray(start, dtype=np.uint64)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        self._ck(self.L.e2s_upload_reads(self.h, _ptr(text), text.size, _ptr(start), _ptr(length), start.size, int(length.max()) if length.size else 0))
+
+    def attach_reads(self, d_text, d_start, d_len, n_reads, max_len, keep=()):
+        self._keep_reads = list(keep)
+        self._ck(self.L.e2s_attach_reads(self.h, _ptr(d_text), _ptr(d_start), _ptr(d_len), n_reads, max_len))
+
+    def call_variants(self, k_left=31, k_right=30, max_gap=10, max_err=2, first_id=1):
+        """the tail on the GPU: (n_variants, n_events, snp_bytes); raises E2SError (ERR_STATE) where only the host tail applies"""
+        p = TailParams(k_left, k_right, max_gap, max_err)
+        nv, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.e2s_call_variants(self.h, C.byref(p), first_id, C.byref(nv), C.byref(ne), C.byref(nb)))
+        return nv.value, ne.value, nb.value
+
+    def fetch_snp(self):
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_fetch_snp(self.h, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        self._ck(self.L.e2s_fetch_snp(self.h, _ptr(buf), n.value, C.byref(n)))
+        return buf[:n.value]
+
+    def write_snp(self, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2):
+        p = TailParams(k_left, k_right, max_gap, max_err)
+        nv, ne = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.e2s_write_snp(self.h, C.byref(p), fasta_path.encode(), out_path.encode(), C.byref(nv), C.byref(ne)))
+        return nv.value, ne.value
 
     def timing(self):
         t = Timing()

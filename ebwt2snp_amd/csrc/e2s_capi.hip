@@ -30,12 +30,10 @@ struct e2s_ctx {
     std::vector<void*> owned;
     // scan state
     uint64_t* d_starts = nullptr; uint16_t* d_lens = nullptr; uint64_t cap = 0;
-    uint64_t* d_tile_fix = nullptr; uint64_t* d_tile_fix_end = nullptr; uint32_t* d_tile_count = nullptr; uint64_t* d_tile_prefix = nullptr;
     uint64_t* d_wrap = nullptr;                  // [E2S_WRAP_CAP] ranks of records whose true length wrapped the u16
     std::vector<uint64_t> wrap_ranks; bool wrap_overflow = false;
     uint64_t first_end_pos = E2S_NONE; bool first_wrapped = false;
     uint64_t* d_fl_starts = nullptr; uint16_t* d_fl_lens = nullptr; uint64_t fl_cap = 0; uint64_t n_flagged = 0;
-    uint64_t tiles_cap = 0;
     uint64_t* d_scalars = nullptr;               // [0] total_ends  [1] cand_count  [2..] hist (153)
     uint32_t* d_words = nullptr;                 // [1] err [2..4] flags [8,9] tailv [12] wrap count [20] pre-filter err
     bool scanned = false, stitched = false, records_from_file = false;
@@ -46,16 +44,24 @@ struct e2s_ctx {
     uint16_t first_len_prov = 0;
     uint64_t open_start = E2S_NONE, last_end_start = E2S_NONE;
     // candidates
-    uint8_t* d_cand = nullptr; uint64_t cand_cap = 0, cand_bytes = 0; uint32_t cand_stride = 0, list_cap = 0; uint64_t n_cand = 0;
+    uint64_t cand_cap = 0; uint32_t cand_stride = 0, list_cap = 0; uint64_t n_cand = 0;        // cand_cap: candidate slots (keys, offsets, order)
     bool tail_bwt_given = false; uint8_t tail_bwt_arg = 0;
     size_t stream_cap_bytes = 0; uint32_t stream_per_cand = 128;  // packed candidate stream: room per candidate slot (raised to the stride on overflow)
     uint8_t* pin_cand = nullptr; size_t pin_cand_bytes = 0;      // pinned host staging: candidate records, then the SA-order permutation
     uint32_t* pin_order = nullptr;                                // offsets (8-byte units) of the packed candidates, n_cand + 1 entries
-    uint32_t* d_size8 = nullptr; uint64_t size8_cap = 0;          // pack scratch
     uint32_t pos_pack = 4;                                        // bytes per position in the packed stream
-    uint32_t* d_slot_off8 = nullptr; uint64_t slot_off8_cap = 0;  // where k_flagged_lists packed each candidate slot
+    uint32_t* d_slot_off8 = nullptr;                              // where k_flagged_lists packed each candidate slot
+    size_t stream_ord_off = 0; uint64_t stream8_used = 0;         // the SA-order offsets follow the stream at this byte offset; 8-byte units written
+    uint8_t* d_stream = nullptr; size_t d_stream_bytes = 0;       // the same stream in HBM (reads resident: the tail runs on the GPU)
+    bool cand_dev = false, cand_host_valid = false;               // where the last pass's candidates are
+    // reads resident in HBM + the GPU tail (e2s_tail.hip)
+    bool have_reads = false, reads_owned = false; uint8_t* d_text = nullptr; uint64_t* d_rstart = nullptr; uint32_t* d_rlen = nullptr;
+    uint64_t n_reads = 0; uint32_t reads_max_len = 0;
+    uint8_t* d_cons = nullptr; TailRec* d_trec = nullptr; uint64_t tail_cap = 0; unsigned long long* d_part = nullptr; uint64_t part_cap = 0;
+    uint8_t* d_snp = nullptr; uint64_t snp_cap = 0, snp_bytes = 0, n_events = 0, n_variants = 0; bool variants_valid = false, snp_valid = false;
+    e2s_tail_params tail_p{}; uint64_t snp_first_id = 1;
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
-    void* d_rank = nullptr; uint32_t* d_order = nullptr; uint64_t order_cap = 0;     // d_rank: scratch of the candidate ordering
+    void* d_rank = nullptr; uint32_t* d_order = nullptr;           // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
     uint8_t* d_img = nullptr; uint8_t* d_img_scratch = nullptr; uint64_t img_cap = 0;     // `.clusters` image (e2s_stream_clusters)
     uint8_t* pin_io[2] = {nullptr, nullptr}; uint64_t pin_io_cap = 0; hipEvent_t ev_io[2] = {nullptr, nullptr};
@@ -67,7 +73,7 @@ struct e2s_ctx {
     hipEvent_t ev_wait = nullptr;
     hipEvent_t ev_chunk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
-    uint64_t* d_keys = nullptr; uint64_t keys_cap = 0;
+    uint64_t* d_keys = nullptr;
     bool cand_downloaded = false;
     // segmented record storage (scan_mode 0): segment b = d_starts/d_lens[b*seg_cap ...), SegDesc per block
     bool segmented = false; uint32_t seg_cap = 0, seg_blocks = 0; SegDesc* d_seg_desc = nullptr; uint64_t* d_seg_off = nullptr;
@@ -173,6 +179,11 @@ static hipError_t wait_stream(e2s_ctx* h) {
     return hipStreamSynchronize(h->stream);
 }
 
+static void release_reads(e2s_ctx* h) {
+    if (h->reads_owned) { hipFree(h->d_text); hipFree(h->d_rstart); hipFree(h->d_rlen); }
+    h->d_text = nullptr; h->d_rstart = nullptr; h->d_rlen = nullptr; h->have_reads = h->reads_owned = false; h->n_reads = 0;
+}
+
 // Forget a pre-filter result that was started ahead of e2s_find_candidates (arm / begin): whatever replaces the shard, the
 // records or the scan it was computed for makes it stale.  One that runs on the second stream is ordered before anything
 // that follows on the handle's stream, since it writes the flagged list the next one will reuse.
@@ -196,13 +207,15 @@ extern "C" int e2s_destroy(e2s_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     release_shard(h);
-    hipFree(h->d_starts); hipFree(h->d_lens); hipFree(h->d_tile_fix);
-    hipFree(h->d_tile_count); hipFree(h->d_tile_prefix); hipFree(h->d_scalars); hipFree(h->d_words); hipFree(h->d_cand);
-    hipFree(h->d_tile_fix_end); hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
+    hipFree(h->d_starts); hipFree(h->d_lens);
+    hipFree(h->d_scalars); hipFree(h->d_words);
+    hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
     if (h->pin_cand) hipHostFree(h->pin_cand);
     if (h->pin_mail) hipHostFree(h->pin_mail);
     hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
-    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_size8); hipFree(h->d_slot_off8);
+    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_slot_off8); hipFree(h->d_stream);
+    release_reads(h);
+    hipFree(h->d_cons); hipFree(h->d_trec); hipFree(h->d_part); hipFree(h->d_snp);
     for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
     hipFree(h->d_img); hipFree(h->d_img_scratch);
     for (auto& p : h->pin_io) if (p) hipHostFree(p);
@@ -413,18 +426,6 @@ static int ensure_records(e2s_ctx* h, uint64_t cap) {
     return E2S_OK;
 }
 
-static int ensure_tiles(e2s_ctx* h, uint64_t n_tiles) {
-    if (n_tiles <= h->tiles_cap) return E2S_OK;
-    hipFree(h->d_tile_fix); hipFree(h->d_tile_fix_end); hipFree(h->d_tile_count); hipFree(h->d_tile_prefix);
-    h->tiles_cap = 0;
-    CK(hipMalloc((void**)&h->d_tile_fix, n_tiles * 8));
-    CK(hipMalloc((void**)&h->d_tile_fix_end, n_tiles * 8));
-    CK(hipMalloc((void**)&h->d_tile_count, n_tiles * 4));
-    CK(hipMalloc((void**)&h->d_tile_prefix, n_tiles * 8));
-    h->tiles_cap = n_tiles;
-    return E2S_OK;
-}
-
 // contiguous record arrays for consumers that index records by rank (file output, record-driven pass).
 // scan_mode 0 keeps records in per-block segments; this gathers them once, on demand, tail records included.
 static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_t** lens) {
@@ -456,7 +457,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     dbg_entry("e2s_cluster_scan");
     if (!h) return E2S_ERR_ARG;
     if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
-    if (scan_mode != 0 && scan_mode != 1) return fail(h, E2S_ERR_ARG, "scan_mode must be 0 or 1");
+    if (scan_mode != 0) return fail(h, E2S_ERR_ARG, "scan_mode must be 0 (kept in the signature for ABI stability)");
     CK(hipSetDevice(h->device));
     const e2s_shard_desc& d = h->d;
     h->k = k; h->min_len = min_len;
@@ -483,8 +484,8 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     int rc;
     ScanMail mail{};
 
-    if (scan_mode == 0) {
-        // ---- segmented single-pass scan: persistent blocks over contiguous tile ranges ----
+    {
+        // ---- segmented single-pass scan: wave workers over contiguous tile ranges ----
         const uint64_t row_entries = (uint64_t)64 * (E2S_SPAN_BYTES / h->xb);   // entries per wave-tile (64 lanes x 64 B)
         SegArgs sa{};
         sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
@@ -585,50 +586,6 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             rs.min_len = min_len;
             h->raw_stats_valid = true;
             hipEventElapsedTime(&h->tm.hist_ms, h->ev[3], h->ev[1]);     // k_seg_fix + the statistics
-        }
-    } else {
-        // ---- three-kernel count / scan / emit into contiguous arrays ----
-        h->pf_armed = false;                                        // (e2s_prefilter_arm belongs to the segmented scan)
-        h->segmented = false; h->first_rec_addr = 0; h->raw_stats_valid = false;
-        const uint64_t tile_entries = (uint64_t)E2S_SCAN_ROWS * E2S_SCAN_BLOCK * (16 / h->xb);
-        a.n_tiles = (h->n_prov + tile_entries - 1) / tile_entries;
-        if (a.n_tiles > 0x7FFFFFFFull) return fail(h, E2S_ERR_ARG, "shard too large for one launch");
-        if ((rc = ensure_tiles(h, a.n_tiles))) return rc;
-        uint64_t want = std::max<uint64_t>(h->cap, d.n_entries / 8 + 4096);
-        a.tile_fix = h->d_tile_fix; a.tile_fix_end = h->d_tile_fix_end; a.tile_count = h->d_tile_count; a.tile_prefix = h->d_tile_prefix;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if ((rc = ensure_records(h, want))) return rc;
-            a.starts = h->d_starts; a.lens = h->d_lens; a.cap = h->cap;
-            CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
-            CK(hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-            CK(hipMemsetAsync(h->d_scalars + 3, 0xFF, 8, h->stream));
-            CK(hipMemsetAsync(h->d_tile_fix, 0xFF, a.n_tiles * 8, h->stream));
-            e2s_launch_shard_flags(a, h->xb, h->stream);
-            LCHK("e2s_launch_shard_flags");
-            h->scan_start_ev = 0;
-            CK(hipEventRecord(h->ev[0], h->stream));
-            e2s_launch_scan(a, h->xb, 1, h->stream);
-            LCHK("e2s_launch_scan");
-            e2s_launch_tile_scan(h->d_tile_count, (unsigned long long*)h->d_tile_prefix, a.n_tiles, h->stream);
-            LCHK("e2s_launch_tile_scan");
-            e2s_launch_scan(a, h->xb, 2, h->stream);
-            LCHK("e2s_launch_scan");
-            CK(hipEventRecord(h->ev[3], h->stream));
-            e2s_launch_scan_fix(a.n_tiles, (const unsigned long long*)h->d_tile_fix, (const unsigned long long*)h->d_tile_fix_end,
-                                (const unsigned long long*)h->d_starts, h->d_lens, h->cap, a.flags, (unsigned long long*)h->d_wrap,
-                                h->d_words + 12, h->stream);
-            LCHK("e2s_launch_scan_fix");
-            CK(hipEventRecord(h->ev[1], h->stream));
-            e2s_launch_scan_mail(a, h->d_words, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, h->stream);
-            LCHK("e2s_launch_scan_mail");
-            CK(hipMemcpyAsync(h->pin_mail, h->d_mail, sizeof(ScanMail), hipMemcpyDeviceToHost, h->stream));
-            CK(hipStreamSynchronize(h->stream));
-            CK(hipGetLastError());
-            mail = *(const ScanMail*)h->pin_mail;
-            h->n_ends = mail.total_ends;
-            if (mail.total_ends + 4 <= h->cap) break;
-            if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow");
-            want = mail.total_ends + 4096;                             // rare: rerun with the exact size
         }
     }
     h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
@@ -821,7 +778,7 @@ static int pack_image(e2s_ctx* h, uint64_t* n_records) {
     return E2S_OK;
 }
 
-static int stream_image(e2s_ctx* h, uint64_t bytes, e2s_byte_sink sink, void* user) {
+static int stream_image(e2s_ctx* h, const uint8_t* img, uint64_t bytes, e2s_byte_sink sink, void* user) {
     constexpr uint64_t CHUNK = 4000000;                         // a whole number of records; pinning the staging buffers costs ~1 ms per MB
     const uint64_t want = std::min<uint64_t>(bytes, CHUNK);
     if (want > h->pin_io_cap) {
@@ -834,7 +791,7 @@ static int stream_image(e2s_ctx* h, uint64_t bytes, e2s_byte_sink sink, void* us
     const uint64_t n_chunks = (bytes + CHUNK - 1) / CHUNK;
     auto issue = [&](uint64_t c) -> hipError_t {
         const uint64_t off = c * CHUNK, len = std::min<uint64_t>(CHUNK, bytes - off);
-        hipError_t e = hipMemcpyAsync(h->pin_io[c & 1], h->d_img + off, len, hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipMemcpyAsync(h->pin_io[c & 1], img + off, len, hipMemcpyDeviceToHost, h->stream);
         return e == hipSuccess ? hipEventRecord(h->ev_io[c & 1], h->stream) : e;
     };
     if (n_chunks) CK(issue(0));
@@ -860,7 +817,7 @@ extern "C" int e2s_stream_clusters(e2s_handle h, e2s_byte_sink sink, void* user,
     if (rc) return rc;
     if (n_records) *n_records = w;
     const double t1 = now();
-    rc = stream_image(h, w * 10, sink, user);
+    rc = stream_image(h, h->d_img, w * 10, sink, user);
     if (timing) fprintf(stderr, "[timing]   records: packed on the GPU %.2f ms, streamed to the sink %.2f ms\n", t1 - t0, now() - t1);
     return rc;
 }
@@ -877,7 +834,7 @@ extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records,
     if (!out) return E2S_OK;
     struct Dst { uint8_t* p; } dst{(uint8_t*)out};
     auto copy = [](void* user, const void* data, size_t bytes) -> int { Dst* d = (Dst*)user; memcpy(d->p, data, bytes); d->p += bytes; return 0; };
-    rc = stream_image(h, std::min<uint64_t>(w, cap_records) * 10, copy, &dst);
+    rc = stream_image(h, h->d_img, std::min<uint64_t>(w, cap_records) * 10, copy, &dst);
     if (rc) return rc;
     return w > cap_records ? E2S_ERR_CAPACITY : E2S_OK;
 }
@@ -1102,8 +1059,7 @@ static int c2s_len_lo(int mcov_out, int min_len) {   // `length >= mcov_out*2` (
 // launch the pre-filter on `st` (the handle's stream, or its second stream beside the scan); est_records sizes the list
 static bool prefilter_eligible(const e2s_ctx* h) {
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt) & 15u) == 0;
-    static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;
-    return !(h->records_from_file || h->xb != 1 || !aligned || !h->bwt || filter_v1);
+    return !(h->records_from_file || h->xb != 1 || !aligned || !h->bwt);
 }
 // the flagged-cluster list (empty, behind the reserved seed slots), the pre-filter's error word and its arguments
 static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words = false) {
@@ -1162,14 +1118,14 @@ extern "C" int e2s_prefilter_arm(e2s_handle h, int mcov_out) {
     return E2S_OK;
 }
 
-extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand) {
-    dbg_entry("e2s_find_candidates");
-    if (!h || !p) return E2S_ERR_ARG;
-    if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
-    if (!h->bwt || !h->pos || !h->da) return fail(h, E2S_ERR_STATE, "the per-cluster pass needs all four EGSA arrays");
-    CK(hipSetDevice(h->device));
+// ---- e2s_find_candidates, in pieces ------------------------------------------------------------------------------------------
+// The per-cluster pass is: a PRE-FILTER that lists the few clusters worth the exact test (one of three ways, below), K2b
+// (k_flagged_lists: exact test, lists, packed candidates), and the ordering pass (SA order + offsets + mailbox).
+
+// what K2b needs to know about the shard and the options (clust2snp.cpp:367-500)
+static int cand_args(e2s_ctx* h, const e2s_c2s_params* p, uint64_t record_index_base, CandArgs& a) {
     const e2s_shard_desc& d = h->d;
-    CandArgs a{};
+    a = CandArgs{};
     a.bwt = h->bwt; a.lcp = h->lcp; a.pos = h->pos; a.da = h->da; a.xb = h->xb; a.yb = h->yb; a.zb = h->zb;
     a.prov_lo = h->prov_lo; a.prov_hi = h->prov_lo + h->n_prov; a.n_total = d.n_total;
     if (a.prov_hi == d.n_total) {
@@ -1195,278 +1151,257 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     a.cand_count = (unsigned long long*)(h->d_scalars + 1);
     a.record_index_base = record_index_base;
     a.err = h->d_words + 1;
-    h->list_cap = a.list_cap; h->cand_stride = a.stride;
     a.pos_pack = d.pos_bytes <= 1 ? 1u : (d.pos_bytes == 2 ? 2u : 4u);        // positions (suff - k_left) fit the suffix field's width
-    h->pos_pack = a.pos_pack;
+    a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
+    a.blocks_hint = h->n_rec > 50000000ull ? 4096u : 1024u;                   // ~0.3 % of the records reach K2b
+    h->list_cap = a.list_cap; h->cand_stride = a.stride; h->pos_pack = a.pos_pack;
+    return E2S_OK;
+}
 
-    // Streaming path: boundaries recomputed from the LCP inside the kernel.  Needs the records to be the
-    // scan's own (same k), default field widths for what it reads, 16-byte aligned columns.
+// room for `want` candidate slots: ordering keys and scratch, the slots' offsets, and the packed stream itself -- in pinned
+// host memory (the GPU writes it over PCIe while it runs; what the host tail reads), or in HBM when the reads are resident
+// and the tail runs on the GPU (e2s_call_variants).  Lists are a third full on average (~100 B packed per candidate against
+// the 352-B stride): the stream is sized for 128 B per slot -- pinning costs ~1 ms per MB -- and for the full stride if that
+// ever overflows.
+static int cand_buffers(e2s_ctx* h, CandArgs& a, uint64_t want) {
+    if (want > h->cand_cap) {
+        hipFree(h->d_keys); hipFree(h->d_slot_off8); hipFree(h->d_rank); hipFree(h->d_order);
+        h->d_keys = nullptr; h->d_slot_off8 = nullptr; h->d_rank = nullptr; h->d_order = nullptr; h->cand_cap = 0;
+        CK(hipMalloc((void**)&h->d_keys, (want + 8) * 8));
+        CK(hipMalloc((void**)&h->d_slot_off8, (want + 8) * 4));
+        CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(want)));
+        CK(hipMalloc((void**)&h->d_order, want * 4));
+        h->cand_cap = want;
+    }
+    const size_t rec_bytes = std::min((size_t)h->cand_cap * a.stride, std::max((size_t)h->cand_cap * h->stream_per_cand, (size_t)1 << 16)) & ~(size_t)7;
+    const size_t ord_off = (rec_bytes + 63) & ~(size_t)63;
+    const size_t need = ord_off + ((size_t)h->cand_cap + 1) * 4;
+    h->stream_cap_bytes = rec_bytes; h->stream_ord_off = ord_off;
+    h->cand_dev = h->have_reads;
+    if (h->cand_dev) {
+        if (need > h->d_stream_bytes) {
+            hipFree(h->d_stream); h->d_stream = nullptr; h->d_stream_bytes = 0;
+            CK(hipMalloc((void**)&h->d_stream, need + 4096));
+            h->d_stream_bytes = need + 4096;
+        }
+        a.host_stream = h->d_stream;
+    } else {
+        if (need > h->pin_cand_bytes) {
+            if (h->pin_cand) hipHostFree(h->pin_cand);
+            h->pin_cand = nullptr; h->pin_cand_bytes = 0;
+            CK(hipHostMalloc((void**)&h->pin_cand, need + 4096, hipHostMallocDefault));
+            h->pin_cand_bytes = need + 4096;
+        }
+        void* dev_pin = nullptr;
+        CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
+        a.host_stream = (uint8_t*)dev_pin;
+    }
+    a.cand_cap = h->cand_cap; a.cand_keys = (unsigned long long*)h->d_keys;
+    a.stream8_cap = rec_bytes / 8; a.slot_off8 = h->d_slot_off8;
+    a.stream8_count = (unsigned long long*)(h->d_scalars + 6);
+    return E2S_OK;
+}
+
+// records the stencil cannot see -- the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths -- go into the reserved head of
+// the flagged list: written to the pinned mailbox here, copied into the list by k_cand_init
+static int cand_seeds(e2s_ctx* h, const CandArgs& a, bool streaming, uint64_t* n_seed) {
+    std::vector<uint64_t> ss; std::vector<uint16_t> sl;
+    auto seed = [&](uint64_t st, uint16_t ln) { if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); } };
+    if (streaming) {
+        for (uint32_t t = 0; t < h->plan.n_tail; ++t) seed(h->plan.tail_start[t], h->plan.tail_len[t]);
+        if (h->first_wrapped) seed(h->plan.first_start, h->plan.first_len);
+        for (uint64_t r : h->wrap_ranks) {                          // rare: a cluster of 65536+ entries
+            uint64_t st = 0; uint16_t ln = 0;
+            CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(&ln, h->d_lens + r, 2, hipMemcpyDeviceToHost));
+            seed(st, ln);
+        }
+    }
+    if (ss.size() > E2S_SEED_SLOTS) return fail(h, E2S_ERR_INPUT, "too many clusters with wrapped length");
+    uint64_t* ms = (uint64_t*)(h->pin_mail + 2048); uint16_t* ml = (uint16_t*)(h->pin_mail + 2048 + 64 * 8);
+    for (uint64_t t = 0; t < E2S_SEED_SLOTS; ++t) { ms[t] = t < ss.size() ? ss[t] : 0; ml[t] = t < ss.size() ? sl[t] : 0; }   // length 0 = empty
+    *n_seed = ss.size();
+    return E2S_OK;
+}
+
+// pre-filter, way 1: the streaming pass -- boundaries recomputed from the LCP (k_cluster_filter2), in one piece or in chunks with
+// K2b for the clusters a chunk let through on the second stream beside the next chunk (opt-in: E2S_FILTER_CHUNKS; on 2x10^8
+// entries 2 / 4 chunks took 0.34 / 0.44 ms for this phase against 0.26 ms in one piece)
+static int cand_streaming_pass(e2s_ctx* h, const CandArgs& a, const FilterArgs& f, bool defw) {
+    static const int env_chunks = getenv("E2S_FILTER_CHUNKS") ? atoi(getenv("E2S_FILTER_CHUNKS")) : 1;
+    static const long min_tiles = getenv("E2S_FILTER_CHUNK_MIN_TILES") ? atol(getenv("E2S_FILTER_CHUNK_MIN_TILES")) : 4096;
+    const uint64_t w_tiles = (h->n_prov + 4095) / 4096;
+    int chunks = std::max(1, std::min(env_chunks, 8));
+    if ((long)w_tiles < min_tiles || w_tiles < (uint64_t)chunks) chunks = 1;   // too little work per chunk to hide a launch
+    const unsigned long long* fl_count = (const unsigned long long*)(h->d_scalars + 2);
+    if (chunks == 1) {
+        e2s_launch_cluster_filter2(f, 0, w_tiles, 0, h->stream);
+        LCHK("e2s_launch_cluster_filter2");
+        CK(hipEventRecord(h->ev[4], h->stream));
+        e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
+        LCHK("e2s_launch_flagged_lists");
+        return E2S_OK;
+    }
+    unsigned long long* snap = (unsigned long long*)(h->d_scalars + 200);   // snap[c] = length of the list after chunk c - 1
+    CK(hipMemsetAsync(snap, 0, 8, h->stream));
+    if (!h->ev_chunk[0]) for (auto& e : h->ev_chunk) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int c = 0; c < chunks; ++c) {
+        e2s_launch_cluster_filter2(f, w_tiles * c / chunks, w_tiles * (c + 1) / chunks, 0, h->stream);
+        e2s_launch_snapshot(fl_count, snap + c + 1, h->stream);
+        CK(hipEventRecord(h->ev_chunk[c], h->stream));
+        CK(hipStreamWaitEvent(h->stream2, h->ev_chunk[c], 0));
+        e2s_launch_flagged_lists(a, snap + c, snap + c + 1, defw, h->stream2);
+    }
+    LCHK("e2s_launch_cluster_filter2 (chunks)");
+    CK(hipEventRecord(h->ev[4], h->stream));
+    CK(hipEventRecord(h->ev_chunk[8], h->stream2));
+    CK(hipStreamWaitEvent(h->stream, h->ev_chunk[8], 0));          // the ordering pass needs every candidate
+    return E2S_OK;
+}
+
+// pre-filter, way 2: records that are not the streaming pass's to recompute (a `.clusters` file, wide or unaligned columns, a
+// window too dense for the plane kernels' queue): one thread per record on the records as they are
+static int cand_record_pass(e2s_ctx* h, const CandArgs& a, const e2s_c2s_params* p, bool defw) {
+    const uint64_t* ds; const uint16_t* dl;
+    int rc = records_contiguous(h, &ds, &dl);
+    if (rc) return rc;
+    e2s_launch_record_prefilter((const unsigned long long*)ds, dl, h->n_rec, h->bwt, h->prov_lo, h->prov_lo + h->n_prov, (uint32_t)p->mcov_out,
+                                a.len_lo, a.len_hi, (unsigned long long*)h->d_fl_starts, h->d_fl_lens, h->fl_cap,
+                                (unsigned long long*)(h->d_scalars + 2), h->stream);
+    LCHK("e2s_launch_record_prefilter");
+    CK(hipEventRecord(h->ev[4], h->stream));
+    e2s_launch_flagged_lists(a, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
+    LCHK("e2s_launch_flagged_lists");
+    return E2S_OK;
+}
+
+// SA order and offsets follow without a host round trip (the kernels read the candidate count on the device); the last kernel
+// writes counts and error words into the pinned mailbox
+static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a) {
+    const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
+    e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
+                          h->d_order, h->stream, true);
+    LCHK("e2s_launch_cand_order");
+    void* dev_mail = nullptr;
+    CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
+    e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
+                            (uint32_t*)(a.host_stream + h->stream_ord_off), (const unsigned long long*)(h->d_scalars + 2), h->d_words + 1,
+                            h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 1024), h->stream);
+    LCHK("e2s_launch_cand_offsets");
+    return E2S_OK;
+}
+
+extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand) {
+    dbg_entry("e2s_find_candidates");
+    if (!h || !p) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
+    if (!h->bwt || !h->pos || !h->da) return fail(h, E2S_ERR_STATE, "the per-cluster pass needs all four EGSA arrays");
+    CK(hipSetDevice(h->device));
+    const e2s_shard_desc& d = h->d;
+    CandArgs a;
+    int rc = cand_args(h, p, record_index_base, a);
+    if (rc) return rc;
+    h->variants_valid = false; h->cand_host_valid = false;
+    const bool defw = h->xb == 1 && h->yb == 4 && h->zb == 1;
+    // Streaming pass: boundaries recomputed from the LCP inside the kernel.  Needs the records to be the scan's own (same k),
+    // byte LCPs and 4-byte document ids on the device, 16-byte aligned columns.
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt | (uintptr_t)h->da) & 15u) == 0;
-    bool streaming = !h->records_from_file && h->xb == 1 && h->yb == 4 && aligned && !h->wrap_overflow;   // (widths of the device columns)
-
-    const bool rec_pf_ok = true;
-    bool list_done = false;
+    bool streaming = !h->records_from_file && h->xb == 1 && h->yb == 4 && aligned && !h->wrap_overflow;
     int pf_end_ev = 4;
-    uint64_t want = std::max<uint64_t>(4096, h->n_rec / 256);
+    uint64_t want = std::max<uint64_t>(std::max<uint64_t>(4096, h->n_rec / 256), h->cand_cap);
     uint64_t count = 0;
     bool done = false;
+    if (h->n_rec == 0) { done = true; CK(hipEventRecord(h->ev[6], h->stream)); CK(hipEventRecord(h->ev[4], h->stream)); CK(hipEventRecord(h->ev[7], h->stream)); }
     for (int attempt = 0; attempt < 5 && !done; ++attempt) {
-        if (!h->d_cand || want * a.stride > h->cand_bytes) {
-            hipFree(h->d_cand); h->d_cand = nullptr; h->cand_bytes = 0;
-            CK(hipMalloc((void**)&h->d_cand, (size_t)want * a.stride + 256));
-            h->cand_bytes = want * a.stride;
-        }
-        h->cand_cap = h->cand_bytes / a.stride;
-        if (h->cand_cap > h->keys_cap) {
-            hipFree(h->d_keys); h->d_keys = nullptr; h->keys_cap = 0;
-            CK(hipMalloc((void**)&h->d_keys, (h->cand_cap + 8) * 8));
-            h->keys_cap = h->cand_cap;
-        }
-        a.cand_buf = h->d_cand; a.cand_cap = h->cand_cap; a.cand_keys = (unsigned long long*)h->d_keys;
-        // a pre-filter launched ahead (e2s_prefilter_begin) with the same -m stands in for the first attempt's own
-        bool mailed = false;
-        // records that are not the streaming pass's to recompute (a `.clusters` file, wide or unaligned columns): a thread-per-record
-        // pre-filter on the records as they are, then the same list kernels.  E2S_RECORD_PREFILTER=0: one wave per record instead.
-        static const int rec_pf_env = getenv("E2S_RECORD_PREFILTER") ? atoi(getenv("E2S_RECORD_PREFILTER")) : 1;
-        const bool rec_pf = !streaming && rec_pf_ok && rec_pf_env && h->bwt && h->n_rec > 0;
-        const bool listmode = streaming || rec_pf;
+        if ((rc = cand_buffers(h, a, want))) return rc;
+        // a pre-filter launched ahead (e2s_prefilter_arm / e2s_prefilter_begin) for this very scan and the same -m stands in for
+        // the first attempt's own
         const bool use_pf = attempt == 0 && streaming && h->pf_inflight && h->pf_gen == h->scan_gen && h->pf_mcov == p->mcov_out && h->pf_len_lo == a.len_lo;
         pf_end_ev = (use_pf && h->pf_fused) ? 3 : 4;            // the pre-filter ended with the scan kernel / with its own event
         if (!use_pf && h->pf_inflight && h->pf_on_stream2 && h->ev_pf) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // (it still writes the list)
+        const bool pf_stream2 = h->pf_on_stream2;
         h->pf_inflight = false; h->pf_fused = false;
         if (!use_pf) CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));     // (an early pre-filter may have set its error bits)
-        if (use_pf && h->pf_on_stream2) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // it ran on the second stream
-        if (!listmode) {
-            CK(hipMemsetAsync(h->d_scalars + 1, 0, 8, h->stream));
-            CK(hipMemsetAsync(h->d_words + 1, 0, 4, h->stream));
+        if (use_pf && pf_stream2) CK(hipStreamWaitEvent(h->stream, h->ev_pf, 0));   // it ran on the second stream
+        uint64_t nseed = 0;
+        if ((rc = cand_seeds(h, a, streaming, &nseed))) return rc;
+        if (!use_pf && (rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096 + E2S_SEED_SLOTS)))) return rc;
+        a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap;
+        FilterArgs f;
+        filter_args(h, p->mcov_out, a.len_lo, a.len_hi, f);
+        if (!use_pf) CK(hipEventRecord(h->ev[6], h->stream));
+        {   // one launch: the pass's counters, the seeds into the reserved head of the list, the ordering pass's bucket counts
+            void* dev_mail = nullptr;
+            CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
+            e2s_launch_cand_init((unsigned long long*)(h->d_scalars + 1), a.stream8_count, h->d_words + 1,
+                                 nseed ? (const unsigned long long*)((uint8_t*)dev_mail + 2048) : nullptr, (const uint16_t*)((uint8_t*)dev_mail + 2048 + 64 * 8),
+                                 (uint32_t)E2S_SEED_SLOTS, (unsigned long long*)h->d_fl_starts, h->d_fl_lens,
+                                 (unsigned long long*)(h->d_scalars + 2), !use_pf, (uint32_t*)h->d_rank,
+                                 e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);
+            LCHK("e2s_launch_cand_init");
         }
-        if (listmode) {
-            // records the stencil cannot see: the EOF tail (resolved in e2s_stitch) and u16-wrapped lengths
-            std::vector<uint64_t> ss; std::vector<uint16_t> sl;
-            auto seed = [&](uint64_t st, uint16_t ln) { if ((int)ln >= a.len_lo && (int)ln <= a.len_hi) { ss.push_back(st); sl.push_back(ln); } };
-            if (streaming) for (uint32_t t = 0; t < h->plan.n_tail; ++t) seed(h->plan.tail_start[t], h->plan.tail_len[t]);
-            if (streaming && h->first_wrapped) seed(h->plan.first_start, h->plan.first_len);
-            if (streaming) for (uint64_t r : h->wrap_ranks) {        // rare: a cluster of 65536+ entries
-                uint64_t st = 0; uint16_t ln = 0;
-                CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
-                CK(hipMemcpy(&ln, h->d_lens + r, 2, hipMemcpyDeviceToHost));
-                seed(st, ln);
-            }
-            const uint64_t nseed = ss.size();
-            if (nseed > E2S_SEED_SLOTS) return fail(h, E2S_ERR_INPUT, "too many clusters with wrapped length");
-            if (!use_pf) {
-                int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096 + E2S_SEED_SLOTS));
-                if (rc) return rc;
-            }
-            // seeds sit in the pinned mailbox; k_cand_init (below, one launch with the pass's counters) reads them from there
-            uint64_t* ms = (uint64_t*)(h->pin_mail + 2048); uint16_t* ml = (uint16_t*)(h->pin_mail + 2048 + 64 * 8);
-            for (uint64_t t = 0; t < E2S_SEED_SLOTS; ++t) { ms[t] = t < nseed ? ss[t] : 0; ml[t] = t < nseed ? sl[t] : 0; }   // length 0 = empty
-            FilterArgs f;
-            filter_args(h, p->mcov_out, a.len_lo, a.len_hi, f);
-            f.kr_hge = (a.k_right_u > 0xFFull) ? 0u : 0x80808080u;                 // (first formulation only)
-            f.krb = (uint32_t)(a.k_right_u & 0xFF) * 0x01010101u;
-            f.nr_reads1 = a.nr_reads1;
-            if (!use_pf) CK(hipEventRecord(h->ev[6], h->stream));
-            a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap; a.key_is_start = 1;
-            a.blocks_hint = h->n_rec > 50000000ull ? 4096u : 1024u;      // ~0.3 % of the records reach K2b
-            {   // packed mode: K2b writes the candidates into the pinned host buffer itself
-                // lists are a third full on average (~100 B packed per candidate against the 352-B stride): the pinned buffer is sized
-                // for 128 B per slot -- pinning costs ~1 ms per MB -- and for the full stride if that ever overflows (checked below)
-                const size_t rec_bytes = std::min((size_t)h->cand_cap * a.stride,
-                                                  std::max((size_t)h->cand_cap * h->stream_per_cand, (size_t)1 << 16)) & ~(size_t)7;
-                const size_t ord_off = (rec_bytes + 63) & ~(size_t)63;
-                const size_t need = ord_off + ((size_t)h->cand_cap + 1) * 4;
-                h->stream_cap_bytes = rec_bytes;
-                if (need > h->pin_cand_bytes) {
-                    if (h->pin_cand) hipHostFree(h->pin_cand);
-                    h->pin_cand = nullptr; h->pin_cand_bytes = 0;
-                    CK(hipHostMalloc((void**)&h->pin_cand, need + 4096, hipHostMallocDefault));
-                    h->pin_cand_bytes = need + 4096;
-                }
-                if (h->cand_cap > h->slot_off8_cap) {
-                    hipFree(h->d_slot_off8); h->d_slot_off8 = nullptr; h->slot_off8_cap = 0;
-                    CK(hipMalloc((void**)&h->d_slot_off8, (h->cand_cap + 8) * 4));
-                    h->slot_off8_cap = h->cand_cap;
-                }
-                void* dev_pin = nullptr;
-                CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
-                a.host_stream = (uint8_t*)dev_pin; a.stream8_cap = rec_bytes / 8; a.slot_off8 = h->d_slot_off8;
-                a.stream8_count = (unsigned long long*)(h->d_scalars + 6);
-                if (h->cand_cap > h->order_cap) {                   // scratch of the ordering pass (its bucket counts are cleared by k_cand_init)
-                    hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
-                    CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(h->cand_cap)));
-                    CK(hipMalloc((void**)&h->d_order, h->cand_cap * 4));
-                    h->order_cap = h->cand_cap;
-                }
-                void* dev_mail = nullptr;
-                CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
-                e2s_launch_cand_init((unsigned long long*)(h->d_scalars + 1), a.stream8_count, h->d_words + 1,
-                                     nseed ? (const unsigned long long*)((uint8_t*)dev_mail + 2048) : nullptr, (const uint16_t*)((uint8_t*)dev_mail + 2048 + 64 * 8),
-                                     (uint32_t)E2S_SEED_SLOTS, (unsigned long long*)h->d_fl_starts, h->d_fl_lens,
-                                     (unsigned long long*)(h->d_scalars + 2), !use_pf, (uint32_t*)h->d_rank,
-                                     e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);
-                LCHK("e2s_launch_cand_init");
-            }
-            const bool defw = h->xb == 1 && h->yb == 4 && h->zb == 1;
-            static const int filter_v1 = getenv("E2S_FILTER_V1") ? atoi(getenv("E2S_FILTER_V1")) : 0;   // the first formulation, kept for cross-checks
-            // chunked mode is opt-in: on 2x10^8 entries 2 / 4 chunks took 0.34 / 0.44 ms for this phase against 0.26 ms in
-            // one piece (every chunk pays the workers' warm-up tile and its own launch ramp, and the two kernels slow each
-            // other down more than PCIe waiting gives back)
-            static const int env_chunks = getenv("E2S_FILTER_CHUNKS") ? atoi(getenv("E2S_FILTER_CHUNKS")) : 1;
-            const uint64_t w_tiles = (h->n_prov + 4095) / 4096;
-            int chunks = filter_v1 ? 1 : std::max(1, std::min(env_chunks, 8));
-            static const long min_tiles = getenv("E2S_FILTER_CHUNK_MIN_TILES") ? atol(getenv("E2S_FILTER_CHUNK_MIN_TILES")) : 4096;
-            if ((long)w_tiles < min_tiles || w_tiles < (uint64_t)chunks) chunks = 1;   // too little work per chunk to hide a launch
-            const unsigned long long* fl_count = (const unsigned long long*)(h->d_scalars + 2);
-            if (rec_pf) {                                            // the records as they are
-                const uint64_t* ds; const uint16_t* dl;
-                int rc = records_contiguous(h, &ds, &dl);
-                if (rc) return rc;
-                e2s_launch_record_prefilter((const unsigned long long*)ds, dl, h->n_rec, h->bwt, h->prov_lo, h->prov_lo + h->n_prov, (uint32_t)p->mcov_out,
-                                            a.len_lo, a.len_hi, (unsigned long long*)h->d_fl_starts, h->d_fl_lens, h->fl_cap,
-                                            (unsigned long long*)(h->d_scalars + 2), h->stream);
-                LCHK("e2s_launch_record_prefilter");
-                CK(hipEventRecord(h->ev[4], h->stream));
-                e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
-                LCHK("e2s_launch_flagged_lists");
-            } else if (use_pf) {                                     // the pre-filter is already on the stream
-                e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
-                LCHK("e2s_launch_flagged_lists");
-            } else if (chunks == 1) {
-                if (filter_v1) e2s_launch_cluster_filter(f, h->stream); else e2s_launch_cluster_filter2(f, 0, w_tiles, 0, h->stream);
-                LCHK("e2s_launch_cluster_filter");
-                CK(hipEventRecord(h->ev[4], h->stream));
-                e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
-                LCHK("e2s_launch_flagged_lists");
-            } else {
-                // The pass runs in chunks of the tile range; K2b for the clusters a chunk let through runs on the second
-                // stream beside the next chunk: K2b spends most of its time waiting for PCIe (it writes the candidates into
-                // host memory), the pre-filter is VALU bound.  snap[c] = length of the list after chunk c - 1.
-                unsigned long long* snap = (unsigned long long*)(h->d_scalars + 200);
-                CK(hipMemsetAsync(snap, 0, 8, h->stream));
-                if (!h->ev_chunk[0]) for (auto& e : h->ev_chunk) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                for (int c = 0; c < chunks; ++c) {
-                    e2s_launch_cluster_filter2(f, w_tiles * c / chunks, w_tiles * (c + 1) / chunks, 0, h->stream);
-                    e2s_launch_snapshot(fl_count, snap + c + 1, h->stream);
-                    CK(hipEventRecord(h->ev_chunk[c], h->stream));
-                    CK(hipStreamWaitEvent(h->stream2, h->ev_chunk[c], 0));
-                    e2s_launch_flagged_lists(a, snap + c, snap + c + 1, defw, h->stream2);
-                }
-                LCHK("e2s_launch_cluster_filter");
-                CK(hipEventRecord(h->ev[4], h->stream));
-                CK(hipEventRecord(h->ev_chunk[8], h->stream2));
-                CK(hipStreamWaitEvent(h->stream, h->ev_chunk[8], 0));     // the ordering pass needs every candidate
-            }
-            CK(hipEventRecord(h->ev[7], h->stream));
-            {   // SA order and offsets follow without a host round trip: the kernels read the candidate count on the device
-                if (h->cand_cap > h->order_cap) {
-                    hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
-                    CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(h->cand_cap)));
-                    CK(hipMalloc((void**)&h->d_order, h->cand_cap * 4));
-                    h->order_cap = h->cand_cap;
-                }
-                const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
-                e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
-                                      h->d_order, h->stream, true);
-                LCHK("e2s_launch_cand_order");
-                const size_t ord_off = (h->stream_cap_bytes + 63) & ~(size_t)63;
-                h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
-                void* dev_mail = nullptr;
-                CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
-                e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
-                                        (uint32_t*)(a.host_stream + ord_off), (const unsigned long long*)(h->d_scalars + 2), h->d_words + 1,
-                                        h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 1024), h->stream);
-                LCHK("e2s_launch_cand_offsets");
-                mailed = true;
-            }
-        } else {
-            { const uint64_t* ds; const uint16_t* dl; int rc = records_contiguous(h, &ds, &dl); if (rc) return rc; a.starts = ds; a.lens = dl; }
-            a.n_rec = h->n_rec; a.key_is_start = 0;
-            CK(hipEventRecord(h->ev[6], h->stream));
-            if (h->n_rec) e2s_launch_candidates(a, h->xb == 1 && h->yb == 4 && h->zb == 1, h->stream);
-            CK(hipEventRecord(h->ev[4], h->stream));
-            CK(hipEventRecord(h->ev[7], h->stream));
-        }
-        uint64_t* mb = (uint64_t*)(h->pin_mail + 1024);
-        if (!mailed) {                                               // (the streaming pass's last kernel wrote them itself)
-            CK(hipMemcpyAsync(mb, h->d_scalars + 1, 16, hipMemcpyDeviceToHost, h->stream));        // cand_count, flagged
-            CK(hipMemcpyAsync(mb + 2, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream));
-            CK(hipMemcpyAsync((uint32_t*)(mb + 2) + 1, h->d_words + 20, 4, hipMemcpyDeviceToHost, h->stream));
-        }
+        if (use_pf) {                                            // the pre-filter is already on the stream
+            e2s_launch_flagged_lists(a, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
+            LCHK("e2s_launch_flagged_lists");
+        } else if (streaming) rc = cand_streaming_pass(h, a, f, defw);
+        else rc = cand_record_pass(h, a, p, defw);
+        if (rc) return rc;
+        CK(hipEventRecord(h->ev[7], h->stream));
+        if ((rc = cand_order_and_mail(h, a))) return rc;
         CK(wait_stream(h));
         CK(hipGetLastError());
+        const uint64_t* mb = (const uint64_t*)(h->pin_mail + 1024);
         count = mb[0];
         const uint64_t flagged = mb[1];
         const uint32_t err = ((const uint32_t*)(mb + 2))[0] | ((const uint32_t*)(mb + 2))[1];     // K2b's word | the pre-filter's
         if (getenv("E2S_DEBUG_CAND"))
-            fprintf(stderr, "[cand] attempt %d: listmode %d use_pf %d mailed %d cand_cap %llu stream_cap %zu | count %llu flagged %llu (fl_cap %llu) stream8 %llu err %x\n", attempt,
-                    (int)listmode, (int)use_pf, (int)mailed, (unsigned long long)h->cand_cap, h->stream_cap_bytes, (unsigned long long)count, (unsigned long long)flagged,
-                    (unsigned long long)h->fl_cap, (unsigned long long)(mailed ? mb[3] : 0), err);
+            fprintf(stderr, "[cand] attempt %d: streaming %d use_pf %d cand_cap %llu stream_cap %zu | count %llu flagged %llu (fl_cap %llu) stream8 %llu err %x\n", attempt,
+                    (int)streaming, (int)use_pf, (unsigned long long)h->cand_cap, h->stream_cap_bytes, (unsigned long long)count, (unsigned long long)flagged,
+                    (unsigned long long)h->fl_cap, (unsigned long long)mb[3], err);
         if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
-        if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: record-driven pass
-        if (listmode && mailed && mb[3] * 8 > h->stream_cap_bytes) {   // the packed stream outgrew its 128 B per slot: room for full lists
+        if (streaming && (err & E2S_DEVERR_DENSE)) { streaming = false; continue; }      // pathological density: the record pass
+        if (mb[3] * 8 > h->stream_cap_bytes) {                   // the packed stream outgrew its 128 B per slot: room for full lists
             h->stream_per_cand = a.stride;
             continue;
         }
-        if (listmode && flagged > h->fl_cap) {
-            int rc = ensure_flagged(h, flagged + 4096);
-            if (rc) return rc;
+        if (flagged > h->fl_cap) {
+            if ((rc = ensure_flagged(h, flagged + 4096))) return rc;
             continue;
         }
         h->n_flagged = flagged;
-        list_done = listmode;
+        h->stream8_used = mb[3];
         if (count <= h->cand_cap) { done = true; break; }
         want = count + 1024;
     }
     if (!done) return fail(h, E2S_ERR_CAPACITY, "candidate / flagged buffer overflow");
-    const bool streaming_done = list_done;
     h->n_cand = count;
-    h->cand_downloaded = false; h->host_fixed_valid = false;
-    if (count && !streaming_done) {
-        // record-driven pass: fixed-stride records in HBM; SA order on the GPU, then packed into the pinned buffer
-        if (count > h->order_cap) {
-            hipFree(h->d_rank); hipFree(h->d_order); h->d_rank = h->d_order = nullptr; h->order_cap = 0;
-            const uint64_t c2 = count + count / 4 + 1024;
-            CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(c2)));
-            CK(hipMalloc((void**)&h->d_order, c2 * 4));
-            h->order_cap = c2;
-        }
-        e2s_launch_cand_keys(h->d_cand, a.stride, count, (unsigned long long*)h->d_keys, h->stream);
-        e2s_launch_cand_order((const unsigned long long*)h->d_keys, count, nullptr, record_index_base << 2, (h->n_rec + 1) << 2, h->d_rank, h->d_order,
-                              h->stream);
-        LCHK("e2s_launch_cand_order");
-        {
-            // fixed-stride records in HBM: pack them in SA order straight into the pinned buffer (the GPU writes host memory)
-            const size_t rec_bytes = (size_t)count * a.stride, ord_off = (rec_bytes + 63) & ~(size_t)63;
-            const size_t need = ord_off + ((size_t)count + 1) * 4;
-            if (need > h->pin_cand_bytes) {
-                if (h->pin_cand) hipHostFree(h->pin_cand);
-                h->pin_cand = nullptr; h->pin_cand_bytes = 0;
-                CK(hipHostMalloc((void**)&h->pin_cand, need + need / 4 + 4096, hipHostMallocDefault));
-                h->pin_cand_bytes = need + need / 4 + 4096;
-            }
-            h->pin_order = (uint32_t*)(h->pin_cand + ord_off);
-            const uint64_t n_pad = (count + 4095) & ~4095ull;
-            if (n_pad + 1 > h->size8_cap) {
-                hipFree(h->d_size8); h->d_size8 = nullptr; h->size8_cap = 0;
-                CK(hipMalloc((void**)&h->d_size8, (n_pad + 4096 + 1) * 4));
-                h->size8_cap = n_pad + 4096 + 1;
-            }
-            void* dev_pin = nullptr;
-            CK(hipHostGetDevicePointer(&dev_pin, h->pin_cand, 0));
-            e2s_launch_cand_pack(h->d_cand, a.stride, a.list_cap, a.pos_pack, h->d_order, count, h->d_size8, n_pad, (uint8_t*)dev_pin,
-                                 (uint32_t*)((uint8_t*)dev_pin + ord_off), h->stream);
-            LCHK("e2s_launch_cand_pack");
-        }
-        CK(hipStreamSynchronize(h->stream));
-        CK(hipGetLastError());
-    }
-    if (count) h->cand_downloaded = true;                         // streaming pass: everything arrived with the mailbox wait above
+    h->host_fixed_valid = false;
+    h->cand_downloaded = count != 0;                             // everything arrived with the mailbox wait above
+    h->pin_order = h->pin_cand ? (uint32_t*)(h->pin_cand + h->stream_ord_off) : nullptr;
+    h->cand_host_valid = !h->cand_dev;
     hipEventElapsedTime(&h->tm.cand_ms, h->ev[6], h->ev[7]);
     hipEventElapsedTime(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev]);   // the pre-filter (inside the scan kernel: that kernel)
     h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
     h->tm.cand_bytes_written = count * a.stride;
     if (n_cand) *n_cand = count;
+    return E2S_OK;
+}
+
+// candidates that K2b left in HBM (reads resident: the GPU tail consumes them there) are copied to the pinned buffer on demand
+static int cand_to_host(e2s_ctx* h) {
+    if (h->cand_host_valid || !h->n_cand) return E2S_OK;
+    const size_t need = h->stream_ord_off + ((size_t)h->cand_cap + 1) * 4;
+    if (need > h->pin_cand_bytes) {
+        if (h->pin_cand) hipHostFree(h->pin_cand);
+        h->pin_cand = nullptr; h->pin_cand_bytes = 0;
+        CK(hipHostMalloc((void**)&h->pin_cand, need + 4096, hipHostMallocDefault));
+        h->pin_cand_bytes = need + 4096;
+    }
+    CK(hipMemcpyAsync(h->pin_cand, h->d_stream, (size_t)h->stream8_used * 8, hipMemcpyDeviceToHost, h->stream));
+    CK(hipMemcpyAsync(h->pin_cand + h->stream_ord_off, h->d_stream + h->stream_ord_off, ((size_t)h->n_cand + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->pin_order = (uint32_t*)(h->pin_cand + h->stream_ord_off);
+    h->cand_host_valid = true;
     return E2S_OK;
 }
 
@@ -1520,6 +1455,7 @@ extern "C" int e2s_fetch_candidates(e2s_handle h, void* out, uint64_t cap_cand, 
     if (cap_cand < h->n_cand) return fail(h, E2S_ERR_CAPACITY, "candidate output too small");
     if (!h->n_cand) return E2S_OK;
     if (!h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
+    { int rc = cand_to_host(h); if (rc) return rc; }
     expand_fixed(h);
     memcpy(out, h->host_fixed.data(), h->host_fixed.size());
     return E2S_OK;
@@ -1530,6 +1466,7 @@ extern "C" int e2s_candidates_view(e2s_handle h, const void** recs, const uint32
     dbg_entry("e2s_candidates_view");
     if (!h) return E2S_ERR_ARG;
     if (h->n_cand && !h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
+    { int rc = cand_to_host(h); if (rc) return rc; }
     if (h->n_cand) expand_fixed(h);
     if (recs) *recs = h->n_cand ? h->host_fixed.data() : nullptr;
     if (order) *order = h->n_cand ? h->host_ident.data() : nullptr;
@@ -1544,12 +1481,136 @@ extern "C" int e2s_candidates_packed(e2s_handle h, const void** stream, const ui
     dbg_entry("e2s_candidates_packed");
     if (!h) return E2S_ERR_ARG;
     if (h->n_cand && !h->cand_downloaded) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
+    { int rc = cand_to_host(h); if (rc) return rc; }
     if (stream) *stream = h->n_cand ? h->pin_cand : nullptr;
     if (offsets8) *offsets8 = h->n_cand ? h->pin_order : nullptr;
     if (n_cand) *n_cand = h->n_cand;
     if (stream_bytes) *stream_bytes = h->n_cand ? (uint64_t)h->pin_order[h->n_cand] * 8 : 0;
     if (pos_bytes) *pos_bytes = h->pos_pack;
     return E2S_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// clust2snp's tail on the GPU: reads resident in HBM, consensus / distance / KisSNP2 text by e2s_tail.hip
+// ---------------------------------------------------------------------------------------------
+extern "C" int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len) {
+    dbg_entry("e2s_attach_reads");
+    if (!h || (n_reads && (!d_text || !d_start || !d_len))) return E2S_ERR_ARG;
+    CK(hipSetDevice(h->device));
+    release_reads(h);
+    h->d_text = (uint8_t*)d_text; h->d_rstart = (uint64_t*)d_start; h->d_rlen = (uint32_t*)d_len;
+    h->n_reads = n_reads; h->reads_max_len = max_len; h->have_reads = n_reads != 0; h->reads_owned = false;
+    h->variants_valid = false;
+    return E2S_OK;
+}
+
+extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
+                                uint32_t max_len) {
+    dbg_entry("e2s_upload_reads");
+    if (!h || !n_reads || !text || !start || !len) return E2S_ERR_ARG;
+    CK(hipSetDevice(h->device));
+    release_reads(h);
+    h->reads_owned = true;
+    CK(hipMalloc((void**)&h->d_text, text_bytes + 256));
+    CK(hipMalloc((void**)&h->d_rstart, n_reads * 8 + 64));
+    CK(hipMalloc((void**)&h->d_rlen, n_reads * 4 + 64));
+    CK(hipMemcpyAsync(h->d_text, text, text_bytes, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_rstart, start, n_reads * 8, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_rlen, len, n_reads * 4, hipMemcpyHostToDevice, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->n_reads = n_reads; h->reads_max_len = max_len; h->have_reads = true; h->variants_valid = false;
+    return E2S_OK;
+}
+
+extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_t first_id, uint64_t* n_variants, uint64_t* n_events, uint64_t* snp_bytes) {
+    dbg_entry("e2s_call_variants");
+    if (!h || !p) return E2S_ERR_ARG;
+    if (n_variants) *n_variants = 0;
+    if (n_events) *n_events = 0;
+    if (snp_bytes) *snp_bytes = 0;
+    if (!h->have_reads) return fail(h, E2S_ERR_STATE, "no reads resident (e2s_upload_reads / e2s_attach_reads)");
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
+    if (h->n_cand && !h->cand_dev) return fail(h, E2S_ERR_STATE, "the candidates were delivered to the host: make the reads resident BEFORE e2s_find_candidates");
+    // zero candidates: the reference indexes an empty vector (clust2snp.cpp:531) and dies before creating the file
+    if (h->n_cand == 0) return E2S_ERR_REF_CRASH;
+    if (p->k_left < 0) return E2S_ERR_REF_CRASH;                 // cons(size_t(-n)) throws in the reference
+    if (p->k_left < 1 || p->k_left > 64) return fail(h, E2S_ERR_STATE, "GPU tail: -L outside 1..64 (use the host tail, e2s_snp_from_packed)");
+    CK(hipSetDevice(h->device));
+    const uint64_t n = h->n_cand, ng = (n + 255) / 256;
+    if (n > h->tail_cap) {
+        hipFree(h->d_cons); hipFree(h->d_trec); h->d_cons = nullptr; h->d_trec = nullptr; h->tail_cap = 0;
+        const uint64_t c2 = n + n / 4 + 1024;
+        CK(hipMalloc((void**)&h->d_cons, c2 * 128));
+        CK(hipMalloc((void**)&h->d_trec, c2 * sizeof(TailRec)));
+        h->tail_cap = c2;
+    }
+    if (ng + 1 > h->part_cap) {
+        hipFree(h->d_part); h->d_part = nullptr; h->part_cap = 0;
+        CK(hipMalloc((void**)&h->d_part, (ng + 64) * 2 * 8 * 2 + 64));   // raw sums | exclusive prefixes
+        h->part_cap = ng + 63;
+    }
+    // the image is sized from a bound per event: two header lines (prefix, id, right length, type, support) and two DNA lines
+    const uint64_t rmax = p->k_right < 0 ? h->reads_max_len : std::min<uint64_t>((uint64_t)p->k_right, h->reads_max_len);
+    const uint64_t bound = n * (2 * (uint64_t)(1 + 5 + 13 + 20 + 5 + 10 + 1 + 66 + 1 + 10 + 10) + 2 * ((uint64_t)p->k_left + rmax + 1)) + 256;
+    if (bound > h->snp_cap) {
+        hipFree(h->d_snp); h->d_snp = nullptr; h->snp_cap = 0;
+        CK(hipMalloc((void**)&h->d_snp, bound + bound / 8));
+        h->snp_cap = bound + bound / 8;
+    }
+    unsigned long long* part_raw = h->d_part; unsigned long long* part_excl = h->d_part + 2 * (h->part_cap + 1);
+    unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);       // events, bytes, kept, error bits | n_keep at +4
+    CK(hipMemsetAsync(part_raw, 0, ng * 16, h->stream));
+    CK(hipMemsetAsync(totals, 0, 48, h->stream));
+    CK(hipMemsetAsync(h->d_words + 28, 0, 4, h->stream));
+    TailArgs a{};
+    a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
+    a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads;
+    a.kl = p->k_left; a.kr = p->k_right; a.max_gap = p->max_gap; a.max_err = p->max_err;
+    a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = h->d_words + 28;
+    CK(hipEventRecord(h->ev[2], h->stream));
+    e2s_launch_consensus(a, h->stream);
+    LCHK("e2s_launch_consensus");
+    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, h->d_words + 28, h->stream);
+    LCHK("e2s_launch_tail_partials");
+    e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
+    LCHK("e2s_launch_tail_write");
+    CK(hipEventRecord(h->ev[5], h->stream));
+    uint64_t* mb = (uint64_t*)(h->pin_mail + 3200);
+    CK(hipMemcpyAsync(mb, totals, 32, hipMemcpyDeviceToHost, h->stream));
+    CK(wait_stream(h));
+    CK(hipGetLastError());
+    hipEventElapsedTime(&h->tm.tail_ms, h->ev[2], h->ev[5]);
+    const uint32_t err = (uint32_t)mb[3];
+    if (err & E2S_TAILERR_RANK) return fail(h, E2S_ERR_STATE, "GPU tail: a candidate names a read past the last one (the reference repeats stale text: use the host tail)");
+    if (err & E2S_TAILERR_CRASH) return E2S_ERR_REF_CRASH;      // substr throws in the reference
+    if (mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
+    h->n_events = mb[0]; h->snp_bytes = mb[1]; h->n_variants = mb[2];
+    h->variants_valid = true; h->tail_p = *p; h->snp_first_id = first_id;
+    if (n_variants) *n_variants = h->n_variants;
+    if (n_events) *n_events = h->n_events;
+    if (snp_bytes) *snp_bytes = h->snp_bytes;
+    return E2S_OK;
+}
+
+extern "C" int e2s_stream_snp(e2s_handle h, e2s_byte_sink sink, void* user) {
+    dbg_entry("e2s_stream_snp");
+    if (!h || !sink) return E2S_ERR_ARG;
+    if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
+    CK(hipSetDevice(h->device));
+    return stream_image(h, h->d_snp, h->snp_bytes, sink, user);
+}
+
+extern "C" int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64_t* bytes) {
+    dbg_entry("e2s_fetch_snp");
+    if (!h || !bytes) return E2S_ERR_ARG;
+    if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
+    *bytes = h->snp_bytes;
+    if (!out) return E2S_OK;
+    if (cap_bytes < h->snp_bytes) return fail(h, E2S_ERR_CAPACITY, "`.snp` output too small");
+    CK(hipSetDevice(h->device));
+    struct Dst { uint8_t* p; } dst{(uint8_t*)out};
+    auto copy = [](void* user, const void* data, size_t n) -> int { Dst* d = (Dst*)user; memcpy(d->p, data, n); d->p += n; return 0; };
+    return stream_image(h, h->d_snp, h->snp_bytes, copy, &dst);
 }
 
 extern "C" int e2s_last_timing(e2s_handle h, e2s_timing* out) {

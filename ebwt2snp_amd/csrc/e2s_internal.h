@@ -131,8 +131,33 @@ struct FilterArgs {
     uint64_t w_tile0;                                               // first tile of this launch (the pass may run in chunks)
 };
 
-void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st);
-void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st);
+// ---- clust2snp's tail on the GPU (e2s_tail.hip) ----
+#define E2S_TAILERR_RANK  1u   // a candidate names a read past the last one (the reference repeats stale text: host tail instead)
+#define E2S_TAILERR_CRASH 2u   // right_pos beyond the read's end: substr throws in the reference
+struct TailRec {               // one per candidate, written by k_consensus
+    uint32_t emit;             // both supports > 0 and distance <= 3: an event of the `.snp`
+    int32_t  L;                // indel length of distance() (0: SNP)
+    uint32_t s0, s1;           // supports
+    uint32_t right_len;        // length of the right context
+    uint32_t base_len;         // bytes of the event's four lines without the digits of its id
+    uint64_t right_at;         // where the right context starts in the reads' text
+};
+struct TailArgs {
+    const uint8_t* stream; const uint32_t* off8; uint64_t n_cand; uint32_t pos_pack;      // packed candidates in SA order (device memory)
+    const uint8_t* text; const uint64_t* rstart; const uint32_t* rlen; uint64_t n_reads;  // the reads: read r = text[rstart[r] .. +rlen[r])
+    int kl, kr, max_gap, max_err;
+    uint8_t* cons;             // [n_cand][2][64] consensus strings
+    TailRec* rec;              // [n_cand]
+    unsigned long long* part;  // [groups of 256 candidates][2]: events, text bytes without id digits
+    unsigned long long* n_keep;
+    uint32_t* err;
+};
+void e2s_launch_consensus(const TailArgs& a, hipStream_t st);
+void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
+                              unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, hipStream_t st);
+void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, uint8_t* out, unsigned long long out_cap,
+                           hipStream_t st);
+
 void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st);
 void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
                            uint32_t* w1, uint32_t n1, hipStream_t st);   // n_lens, n0, n1 <= 256
@@ -151,10 +176,6 @@ unsigned long long e2s_pack_clusters_blocks(unsigned long long n);
 void e2s_launch_pack_clusters(const unsigned long long* starts, const uint16_t* lens, unsigned long long n, int min_len, uint32_t* cnt,
                               unsigned long long* prefix, uint8_t* out, unsigned long long* total, hipStream_t st);
 #define E2S_WRAP_CAP 1024
-void e2s_launch_scan_fix(unsigned long long n_tiles, const unsigned long long* tile_fix, const unsigned long long* tile_fix_end,
-                         const unsigned long long* starts, uint16_t* lens, unsigned long long cap, const uint32_t* flags,
-                         unsigned long long* wrap_list, uint32_t* wrap_count, hipStream_t st);
-void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st);
 int  e2s_scan_seg_resident_blocks(int xb);
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st);
 int  e2s_scan_seg_fused_resident_blocks();
@@ -166,25 +187,19 @@ void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off,
 void e2s_launch_unpack_clusters(const uint8_t* packed, unsigned long long n, unsigned long long* starts, uint16_t* lens, uint32_t* err, hipStream_t st);
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out,
                          unsigned long long* out_last, hipStream_t st);
-void e2s_launch_scan_mail(const ScanArgs& a, const uint32_t* words, const uint8_t* bwt, const void* pos, const void* da,
-                          int xb, int yb, int zb, ScanMail* out, hipStream_t st);
 void e2s_launch_apply_plan(unsigned long long* starts, uint16_t* lens, uint32_t patch_first, unsigned long long first_start,
                            uint16_t first_len, unsigned long long n_ends, uint32_t n_tail, unsigned long long t0, uint16_t l0,
                            unsigned long long t1, uint16_t l1, hipStream_t st);
 void e2s_launch_hist_tail(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out_last_len, hipStream_t st);
-void e2s_launch_cand_keys(const uint8_t* cand, uint32_t stride, unsigned long long n, unsigned long long* keys, hipStream_t st);
 constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
 size_t e2s_cand_order_scratch_bytes(unsigned long long n);
 void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* n_dev,
                              const unsigned long long* stream8_count, uint32_t* off_out, const unsigned long long* fl_count, const uint32_t* err_a,
                              const uint32_t* err_b, unsigned long long* mail, hipStream_t st);
-void e2s_launch_cand_pack(const uint8_t* cand, uint32_t stride, uint32_t list_cap, uint32_t pw, const uint32_t* order, unsigned long long n, uint32_t* size8,
-                          unsigned long long n_pad, uint8_t* stream, uint32_t* off_out, hipStream_t st);
 uint32_t e2s_cand_order_buckets(unsigned long long n);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,
                            unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st, bool counts_cleared = false);
 void e2s_launch_hist(const uint16_t* lens, unsigned long long n, int min_len, unsigned long long* out, hipStream_t st);
-void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st);
 void e2s_launch_unpack_pairsa(const uint8_t* src, unsigned long long n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st);
 void e2s_launch_narrow8(const uint8_t* src, unsigned long long n, uint32_t* dst, hipStream_t st);
 void e2s_launch_unpack_gesa(const uint8_t* src, unsigned long long n, int yf, int zf, int xf, uint8_t* bwt, void* lcp, int xb,

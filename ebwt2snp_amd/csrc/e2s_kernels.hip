@@ -15,242 +15,25 @@
 #include <type_traits>
 #include "e2s_swar.h"
 
+
 // ----------------------------------------------------------------------------------------------
 // wave64 helpers
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // inclusive add-scan across the 64 lanes of a wave (DPP row shifts + row broadcasts)
+// (bound_ctrl on the row shifts: lanes without a source add 0, and the compiler folds each step into ONE v_add_u32_dpp --
+// with bound_ctrl off it emits v_mov / v_mov_dpp / v_add per step, three times the instructions)
 __device__ __forceinline__ u32 wave_incl_scan(u32 x) {
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
-    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);    // row_shr:8
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
     return x;
 }
 __device__ __forceinline__ u32 wave_bcast_last(u32 x) { return (u32)__builtin_amdgcn_readlane((int)x, 63); }
-
-// alignbyte, bfi, Swar<X>, row_flags<X>: e2s_swar.h
-
-// mask (lane-MSB form) of entries b of the row with lo <= b < hi
-template <int X> __device__ __forceinline__ void range_mask(int lo, int hi, u32* m) {
-    constexpr int EPW = Swar<X>::EPW;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        u32 v = 0;
-#pragma unroll
-        for (int e = 0; e < EPW; ++e) {
-            const int b = w * EPW + e;
-            if (b >= lo && b < hi) v |= 1u << (e * 8 * X + 8 * X - 1);
-        }
-        m[w] = v;
-    }
-}
-
-// The j = 0,1 rules of ebwt2clust.cpp:83-84, applied to the thread-row that holds global index 0:
-// with L[0] >= k the cluster opened at 0 swallows entry 1 whatever L[1] is, and j = 0 is never tested.
-template <int X>
-__device__ __forceinline__ void patch_global0(const u32* W, u32 k, u32 hge, RowFlags& f) {
-    constexpr int PRE = (X == 4) ? 2 : 1;
-    constexpr u32 B0 = 1u << (8 * X - 1);
-    constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
-    constexpr int w1 = (X == 4) ? 1 : 0;
-    constexpr u32 B1 = (X == 4) ? B0 : (B0 << (8 * (X & 3)));
-    constexpr int w2 = (X == 4) ? 2 : (X == 2 ? 1 : 0);
-    constexpr u32 B2 = (X == 1) ? (B0 << 16) : B0;
-    const u32 e0v = W[PRE] & LM;
-    const u32 e1v = (X == 4) ? W[PRE + 1] : ((W[PRE] >> (8 * (X & 3))) & LM);
-    const u32 e2v = (X == 4) ? W[PRE + 2] : (X == 2 ? (W[PRE + 1] & LM) : ((W[PRE] >> 16) & LM));
-    f.end[0] &= ~B0;
-    if (hge != 0 && e0v >= k) {
-        const bool end1 = ((e0v > e1v) && (e1v <= e2v)) || (e2v < k);
-        f.start[w1] &= ~B1;
-        if (end1) f.end[w1] |= B1; else f.end[w1] &= ~B1;
-        if (e2v >= k) { if (end1) f.start[w2] |= B2; else f.start[w2] &= ~B2; }
-    }
-}
-
-constexpr int SCAN_BLK = E2S_SCAN_BLOCK;
-constexpr int SCAN_ROWS = E2S_SCAN_ROWS;
-constexpr u32 CARRY_CLOSED = 0xFFFFFFFFu;   // last event of the thread-row was an end
-constexpr u32 CARRY_NOEVENT = 0xFFFFFFFEu;  // no event: pass the predecessor's carry through
-constexpr u32 CARRY_UNKNOWN = 0xFFFFFFFDu;  // the open start lies before this tile
-
-
-// scan_mode 1: MODE 1 counts the ends per tile, MODE 2 emits with the scanned prefixes.  (A single-pass variant with a
-// decoupled look-back chain was the first K1: the chain, not HBM, set its time; removed.)
-template <int X, int MODE>
-__global__ __launch_bounds__(SCAN_BLK) void k_scan(ScanArgs a) {
-    constexpr int EPT = 16 / X;                     // entries per thread-row
-    constexpr int ROW_ENTRIES = SCAN_BLK * EPT;
-    constexpr int TILE = SCAN_ROWS * ROW_ENTRIES;
-    constexpr int PRE = (X == 4) ? 2 : 1;
-    constexpr int LB = Swar<X>::LB;                 // log2(bits per entry lane)
-    constexpr int EPW = Swar<X>::EPW;
-    constexpr int NWAVES = SCAN_BLK / 64;
-
-    __shared__ u32 s_wtot[SCAN_ROWS][NWAVES];
-    __shared__ u32 s_wcarry[SCAN_ROWS][NWAVES];
-
-    const u32 tid = threadIdx.x;
-    const u32 lane = tid & 63u, wave = tid >> 6;
-
-    const u64 tile = blockIdx.x;
-    const int64_t tile_lo = (int64_t)tile * TILE;                // local entry index (0 = first provided entry)
-    const uint8_t* base = (const uint8_t*)a.lcp;
-    const int64_t n_prov = (int64_t)a.n_prov;
-
-    // owned window in local indices: ends for [own_lo, end_hi), starts for [own_lo, start_hi)
-    const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
-
-    RowFlags F[SCAN_ROWS];
-    u32 cnt[SCAN_ROWS];
-#pragma unroll
-    for (int r = 0; r < SCAN_ROWS; ++r) {
-        const int64_t i0 = tile_lo + (int64_t)r * ROW_ENTRIES + (int64_t)tid * EPT;
-        u32 W[PRE + 5];
-        if (i0 >= PRE * EPW && i0 + EPT + EPW <= n_prov) {
-            // interior: one 16-B load plus the two edge words (L1/L2 hits: neighbours load the same lines)
-            const uint4 v = *(const uint4*)(base + i0 * X);
-            W[PRE + 0] = v.x; W[PRE + 1] = v.y; W[PRE + 2] = v.z; W[PRE + 3] = v.w;
-#pragma unroll
-            for (int p = 0; p < PRE; ++p) W[p] = *(const u32*)(base + i0 * X - 4 * (PRE - p));
-            W[PRE + 4] = *(const u32*)(base + i0 * X + 16);
-        } else {
-            // array edges: byte-guarded loads, zeros outside the provided range (LCP 0 < k: "not open")
-#pragma unroll
-            for (int w = 0; w < PRE + 5; ++w) {
-                u32 v = 0;
-#pragma unroll
-                for (int bt = 0; bt < 4; ++bt) {
-                    const int64_t byte = i0 * X + (int64_t)(w - PRE) * 4 + bt;
-                    if (byte >= 0 && byte < n_prov * X) v |= (u32)base[byte] << (8 * bt);
-                }
-                W[w] = v;
-            }
-        }
-        row_flags<X>(W, a.kb, a.hge, F[r]);
-        if (a.prov_is_global0 && i0 == 0) patch_global0<X>(W, a.k_u32, a.hge, F[r]);
-        // restrict to the owned window
-        if (!(i0 >= own_lo && i0 + EPT <= end_hi)) {
-            u32 m[4];
-            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, end_hi - i0)), m);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) F[r].end[w] &= m[w];
-        }
-        if (!(i0 >= own_lo && i0 + EPT <= start_hi)) {
-            u32 m[4];
-            range_mask<X>((int)max((int64_t)0, min((int64_t)EPT, own_lo - i0)), (int)max((int64_t)0, min((int64_t)EPT, start_hi - i0)), m);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) F[r].start[w] &= m[w];
-        }
-        cnt[r] = __popc(F[r].end[0]) + __popc(F[r].end[1]) + __popc(F[r].end[2]) + __popc(F[r].end[3]);
-    }
-
-    // ---- block-level exclusive scan of end counts in row-major order ----
-    u32 excl[SCAN_ROWS];
-#pragma unroll
-    for (int r = 0; r < SCAN_ROWS; ++r) {
-        const u32 inc = wave_incl_scan(cnt[r]);
-        excl[r] = inc - cnt[r];
-        if (lane == 63) s_wtot[r][wave] = inc;
-    }
-    __syncthreads();
-    u32 tile_total = 0;
-    {
-        u32 run = 0;
-#pragma unroll
-        for (int r = 0; r < SCAN_ROWS; ++r) {
-#pragma unroll
-            for (int w = 0; w < NWAVES; ++w) {
-                const u32 v = s_wtot[r][w];
-                if (w == (int)wave) excl[r] += run;
-                run += v;
-            }
-        }
-        tile_total = run;
-    }
-
-    if (MODE == 1) {
-        if (tid == 0) a.tile_count[tile] = tile_total;
-        return;
-    }
-
-    // ---- tile prefix (from the scan of the counts) ----
-    const u64 prefix = a.tile_prefix[tile];
-    if (tile == a.n_tiles - 1 && tid == 0) *a.total_ends = prefix + tile_total;
-
-    // ---- carries: the open start each thread-row inherits from the rows before it in the tile ----
-    u32 carry_out[SCAN_ROWS], carry_in[SCAN_ROWS];
-#pragma unroll
-    for (int r = 0; r < SCAN_ROWS; ++r) {
-        const int64_t row_lo = (int64_t)r * ROW_ENTRIES + (int64_t)tid * EPT;    // tile-local entry offset
-        u32 co = CARRY_NOEVENT;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const u32 ev = F[r].end[w] | F[r].start[w];
-            if (ev) {
-                const int top = 31 - __clz(ev);
-                // at one position the start precedes the end, so a set end bit means the last event is an end
-                if ((F[r].end[w] >> top) & 1u) co = CARRY_CLOSED;
-                else co = (u32)(row_lo + w * EPW + (top >> LB));
-            }
-        }
-        carry_out[r] = co;
-        const u64 evm = __ballot(co != CARRY_NOEVENT);
-        const u64 below = evm & ((1ull << lane) - 1ull);
-        // every lane takes part in the permute (an inactive source lane would read as 0)
-        const u32 got = (u32)__shfl((int)co, below ? 63 - __clzll(below) : (int)lane);
-        carry_in[r] = below ? got : CARRY_NOEVENT;
-        const u32 wlast = evm ? (u32)__builtin_amdgcn_readlane((int)co, 63 - __clzll(evm)) : CARRY_NOEVENT;
-        if (lane == 0) s_wcarry[r][wave] = wlast;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SCAN_ROWS; ++r) {
-        if (carry_in[r] == CARRY_NOEVENT) {
-            u32 ci = CARRY_UNKNOWN;
-            for (int q = r * NWAVES + (int)wave - 1; q >= 0; --q) {
-                const u32 c = s_wcarry[q / NWAVES][q % NWAVES];
-                if (c != CARRY_NOEVENT) { ci = c; break; }
-            }
-            carry_in[r] = ci;
-        }
-    }
-
-    // ---- emit: walk the events of each thread-row in order (start before end at one position) ----
-    const u64 g_tile = a.prov_lo + (u64)tile_lo;                 // global SA index of the tile's first entry
-#pragma unroll
-    for (int r = 0; r < SCAN_ROWS; ++r) {
-        u64 rk = prefix + excl[r];
-        u32 pend = carry_in[r];
-        const u32 row_lo = (u32)(r * ROW_ENTRIES) + tid * EPT;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            u32 ev = F[r].end[w] | F[r].start[w];
-            while (ev) {
-                const int bit = __ffs(ev) - 1;
-                ev &= ev - 1;
-                const u32 off = row_lo + w * EPW + (bit >> LB);
-                if ((F[r].start[w] >> bit) & 1u) {
-                    if (rk < a.cap) a.starts[rk] = g_tile + off;
-                    pend = off;
-                }
-                if ((F[r].end[w] >> bit) & 1u) {
-                    if (rk < a.cap) {
-                        if (pend < CARRY_UNKNOWN) a.lens[rk] = (uint16_t)(off - pend + 1);
-                        else { a.lens[rk] = (uint16_t)((g_tile + off + 1) & 0xFFFFull); a.tile_fix[tile] = rk; a.tile_fix_end[tile] = g_tile + off; }
-                    }
-                    if (rk == 0) *a.first_end_pos = g_tile + off;
-                    ++rk;
-                    pend = CARRY_CLOSED;
-                }
-            }
-        }
-    }
-}
 
 // ----------------------------------------------------------------------------------------------
 // K1 (scan_mode 0): segmented single-pass scan.  A persistent block owns a CONTIGUOUS range of tiles
@@ -301,7 +84,7 @@ __device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
 // Offsets count from the tile before the range (open1 = 1 + offset of the last start among the 192 entries, 0: none).
 struct PfCarry { u32 open1, cin0, ccarry; };
 __device__ __forceinline__ PfCarry prefilter_carry_192(const uint8_t* lcp, const uint8_t* bwt, const int64_t r0, const u32 k_u32, const u32 hge, const u32 lane) {
-    auto cls = [](u32 x) -> u32 { x &= 0xDFu; return x == 'C' ? 1u : x == 'G' ? 2u : x == 'T' ? 3u : 0u; };
+    auto cls = [](u32 x) -> u32 { x &= 0xDFu; return x == 'C' ? 1u : x == 'G' ? 3u : x == 'T' ? 2u : 0u; };   // bit 0 = C|G, bit 1 = G|T (span_bwt_code_planes)
     u64 Sm[3], Cm[3], Gm[3], Tm[3], Fm[3];
     PfCarry r{0u, 0u, 0u};
 #pragma unroll
@@ -312,9 +95,9 @@ __device__ __forceinline__ PfCarry prefilter_carry_192(const uint8_t* lcp, const
         const bool endm1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
         const u32 c = cls(bwt[e]), cp = cls(bwt[e - 1]);
         Sm[p] = __ballot(g0 && !(gm1 && !endm1));
-        Cm[p] = __ballot(c == 1u); Gm[p] = __ballot(c == 2u); Tm[p] = __ballot(c == 3u);
+        Cm[p] = __ballot(c == 1u); Gm[p] = __ballot(c == 3u); Tm[p] = __ballot(c == 2u);
         Fm[p] = __ballot(c != cp);
-        if (p == 2) r.ccarry = (u32)__builtin_amdgcn_readlane((int)c, 63);      // C = 1, G = 2, T = 3: bit 0 = C|T, bit 1 = G|T
+        if (p == 2) r.ccarry = (u32)__builtin_amdgcn_readlane((int)c, 63);      // C = 1, G = 3, T = 2: bit 0 = C|G, bit 1 = G|T
     }
     int sp = -1;                                                // the last start among the 192 entries
 #pragma unroll
@@ -424,7 +207,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // records of a tile are staged in LDS by the lanes that own their ENDs and written out in rank order, 64 per
     // store: a sparse store per record costs ~55 SIMD cycles on this chip whatever the number of active lanes (the
     // per-record stores were 16 of the kernel's 68 us)
-    __shared__ uint64_t s_stage[4][SEG_STAGE];
+    __shared__ uint64_t s_stage[4][SEG_STAGE + 1];               // (+1: the start of a cluster still open at the tile's end)
     uint64_t* const st_rec = s_stage[threadIdx.x >> 6];
     // pre-filter state (FUSED): see k_cluster_filter2
     __shared__ u64 s_q[FUSED ? 4 : 1][FUSED ? F2_Q : 1];
@@ -462,6 +245,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // Two register sets that swap roles from tile to tile (the loop body is instantiated twice): W = the tile
     // being processed, Wn = the next one, in flight meanwhile.
     u32 WA[NW], WB[NW], BA[FUSED ? NR : 1], BB[FUSED ? NR : 1];
+    ClassConsts kc = class_consts();                            // (FUSED) held in VGPRs: see e2s_swar.h
+    if constexpr (FUSED) asm volatile("" : "+v"(kc.m07), "+v"(kc.ehi), "+v"(kc.elo), "+v"(kc.c20), "+v"(kc.one), "+v"(kc.h));
     auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
         constexpr bool PF = decltype(prefetch)::value;
         if (PF) load_fast(tile + 1, Wn, Bn);                    // in flight while this tile is processed
@@ -496,8 +281,9 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         const u64 Sa = S, Ea = E;                               // before the window mask: the carries follow every cluster
         u64 C = 0, G = 0, T = 0, F = 0; u32 cin = 0;
         if constexpr (FUSED) {
-            span_bwt_classes<NR>(B, C, G, T);
-            const u64 c0 = C | T, c1 = G | T;
+            u64 c0, c1;                                             // code planes: c0 = C | G, c1 = G | T
+            span_bwt_code_planes<NR>(B, kc, c0, c1);
+            C = c0 & ~c1; G = c0 & c1; T = ~c0 & c1;
             const u32 ctop = (u32)(c0 >> 63) | ((u32)(c1 >> 63) << 1);
             const u32 cprev = wave_shr1(ctop, ccarry);
             ccarry = (u32)__builtin_amdgcn_readlane((int)ctop, 63);
@@ -538,12 +324,14 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         const u32 inc = wave_incl_scan(cnt);
         const u32 tile_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
         const u32 base_off = (u32)((tile - torg) * TILE) + lane * ES; // offset from the first tile processed
-        // the start an END without a start of its own in the lane belongs to: the last start below the lane
-        const u32 ls1 = S ? base_off + (u32)(64 - __clzll(S)) : 0u;   // 1 + offset of the lane's last start
-        const u32 mx = wave_incl_max(ls1);
-        u32 cur1 = max(wave_shr1(mx, 0u), open1);
+        // 1 + offset of the lane's last start (meaningless where the lane has none); the last one of the tile is what later tiles
+        // inherit: the lane is found with a ballot, no scan across the lanes
+        const u32 ls1 = base_off + (u32)(64 - __clzll(S | 1ull));
+        const u64 sm = __ballot(S != 0ull);
+        u32 tile_last1 = 0;
+        if (sm) tile_last1 = (u32)__builtin_amdgcn_readlane((int)ls1, 63 - __clzll(sm));
         // the last event of the tile decides what the range hands on
-        const u64 evm = __ballot((S | E) != 0ull);
+        const u64 evm = sm | __ballot(E != 0ull);
         if (evm) {
             const int ll = 63 - __clzll(evm);
             const u32 slo = (u32)__builtin_amdgcn_readlane((int)(u32)S, ll), shi = (u32)__builtin_amdgcn_readlane((int)(u32)(S >> 32), ll);
@@ -552,15 +340,18 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
             const int ms = sS ? 63 - __clzll(sS) : -1, me = sE ? 63 - __clzll(sE) : -1;   // a start precedes an end at one position
             state = ms > me ? 2u : 1u;
         }
-        const u32 tile_last1 = (u32)__builtin_amdgcn_readlane((int)mx, 63);
-        // pre-filter: the last start before each lane, over ALL starts (in an edge tile the scan's are window-masked)
-        u32 pf_cur1 = 0;
+        // the last start strictly below each lane (0: none in this tile) -- only the per-record path and the pre-filter's walk need it
+        auto last_start_below = [&](const u64 Sx) -> u32 {
+            const u32 m = wave_incl_max(Sx ? base_off + (u32)(64 - __clzll(Sx)) : 0u);
+            return wave_shr1(m, 0u);
+        };
+        // pre-filter: what it inherits from tile to tile is taken over ALL starts (in an edge tile the scan's are window-masked)
+        u32 pf_prev = pf_open1;
         if constexpr (FUSED) {
-            if (!masked) { pf_cur1 = max(wave_shr1(mx, 0u), pf_open1); pf_open1 = max(pf_open1, tile_last1); }
+            if (!masked) pf_open1 = max(pf_open1, tile_last1);
             else {
-                const u32 m2 = wave_incl_max(Sa ? base_off + (u32)(64 - __clzll(Sa)) : 0u);
-                pf_cur1 = max(wave_shr1(m2, 0u), pf_open1);
-                pf_open1 = max(pf_open1, (u32)__builtin_amdgcn_readlane((int)m2, 63));
+                const u64 sm2 = __ballot(Sa != 0ull);
+                if (sm2) pf_open1 = max(pf_open1, (u32)__builtin_amdgcn_readlane((int)(base_off + (u32)(64 - __clzll(Sa | 1ull))), 63 - __clzll(sm2)));
             }
         }
         // Wait for the prefetched words NOW, before the record stores: vmcnt counts loads and stores together and in
@@ -577,86 +368,101 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         if (run == 0 && tile_total != 0) {                      // the range's first end (once per worker)
             if (cnt != 0 && inc == cnt) first_end = g_range + base_off + (u32)(__ffsll((long long)E) - 1);
         }
-        // emit: one record per iteration, staged by the lane that owns its END, half plane by half plane.  Its start
-        // is the start bit between the previous end and this end, or -- if there is none -- the last start before
-        // (cur1; 0 = not seen in this range: the record is finished by k_seg_fix / e2s_stitch).  Almost every tile
-        // takes the plain loop: no cluster can be 65536 long (every start used is at or after the last one seen
-        // before the tile), the segment and the staging buffer have room -- tile-uniform tests instead of per-record
-        // ones.  Staged word: (1 + SA position of the start) | length << 48.
+        // emit.  Starts and ends alternate along the array (S0 <= E0 < S1 <= E1 ...), so the cluster that starts at p is the
+        // tile's record number "ends strictly before p", and the one that ends at q is record number "ends strictly before q":
+        // every lane walks the END bits and the START bits of its plane SEPARATELY, each a bare ctz / clear-lowest loop that
+        // drops a 32-bit offset into the record's slot in LDS -- slot r = {1 + offset of the start, offset of the end} -- at
+        // consecutive ranks from the lane's exclusive END count.  Slot 0 is preset with the cluster that is open when the tile
+        // begins (0 = began before the range: the record is finished by k_seg_fix / e2s_stitch).  The records then leave in
+        // rank order, 64 per store.  Almost every tile takes this path: no cluster can be 65536 long (every start used is at or
+        // after the last one seen before the tile), the segment and the staging buffer have room, the tile lies inside the owned
+        // window -- tile-uniform tests instead of per-record ones.
         {
             const u32 rk0 = run + inc - cnt;
             const u32 tile_end1 = (u32)((tile - torg + 1) * TILE);
-            const bool plain = run + tile_total <= a.seg_cap && tile_end1 + 2u - open1 < 65536u && tile_total <= (u32)SEG_STAGE;
-            auto emit_half = [&](u32 Eh, const u32 Sh, const u32 hbase, u32& rk, auto mode) {
-                constexpr int MODE = decltype(mode)::value;     // 0 plain, 1 every per-record check
-                u32 done = 0;                                   // entries of the half up to and including the previous end
-                while (Eh) {
-                    const u32 e = (u32)__builtin_ctz(Eh);
-                    const u32 upto = (2u << e) - 1u;
-                    const u32 sc = Sh & upto & ~done;
-                    done = upto;
-                    Eh &= ~upto;
-                    const u32 off = hbase + e;
-                    const u32 st1 = sc ? hbase + (32u - (u32)__builtin_clz(sc)) : cur1;      // 1 + offset of the start
-                    if (MODE == 0) {
-#ifdef E2S_ABL_NOSTORE                                          // diagnostic build: the plain loop without its stores
-                        asm volatile("" :: "v"(st1), "v"(off), "v"(rk));
-#else
-                        st_rec[rk - run] = (g_range + st1) | ((u64)((off + 2u - st1) << 16) << 32);      // tile-local rank
-#endif
-                    } else if (rk < a.seg_cap) {
-                        if (st1 != 0u) {
-                            const u32 len = off + 2u - st1;
-                            seg_starts[rk] = g_range + (st1 - 1u);
-                            seg_lens[rk] = (uint16_t)len;
-                            if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
-                        } else {
-                            seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);       // finished by k_seg_fix / e2s_stitch
-                            unknown = 1;
-                        }
-                    }
-                    ++rk;
-                }
-                // a start after the half's last end is what a later half's first end belongs to
-                const u32 pend = Sh & ~done;
-                if (pend) cur1 = hbase + (32u - (u32)__builtin_clz(pend));
-            };
-            auto emit_all = [&](auto mode) {
-                u32 rk = rk0;
-                emit_half((u32)E, (u32)S, base_off, rk, mode);
-                if (ES > 32) emit_half((u32)(E >> 32), (u32)(S >> 32), base_off + 32u, rk, mode);
-            };
-#ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loop
-            asm volatile("" :: "v"(rk0), "v"(cur1));
+            const bool plain = run + tile_total <= a.seg_cap && tile_end1 + 2u - open1 < 65536u && tile_total <= (u32)SEG_STAGE && !masked;
+#ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loops
+            asm volatile("" :: "v"(rk0));
             if (rk0 == 0xFFFFFFFFu)
 #endif
             if (plain) {
-                emit_all(std::integral_constant<int, 0>{});
+                u32* const st32 = (u32*)st_rec;
+                if (lane == 0) st32[0] = open1;
+                {
+                    u32* pe = st32 + 2u * (inc - cnt) + 1u;
+                    u32 h = (u32)E;
+                    while (h) { *pe = base_off + (u32)__builtin_ctz(h); h &= h - 1u; pe += 2; }
+                    h = (u32)(E >> 32);
+                    while (h) { *pe = base_off + 32u + (u32)__builtin_ctz(h); h &= h - 1u; pe += 2; }
+                }
+                {
+                    const u64 below = (S & (0ull - S)) - 1ull;          // the entries before the lane's first start
+                    u32* ps = st32 + 2u * (inc - cnt + ((E & below) != 0ull ? 1u : 0u));
+                    u32 h = (u32)S;
+                    while (h) { *ps = base_off + 1u + (u32)__builtin_ctz(h); h &= h - 1u; ps += 2; }
+                    h = (u32)(S >> 32);
+                    while (h) { *ps = base_off + 33u + (u32)__builtin_ctz(h); h &= h - 1u; ps += 2; }
+                }
 #ifndef E2S_ABL_NOSTORE
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                constexpr u64 M48 = (1ull << 48) - 1ull;
                 if (open1 != 0u) {
                     for (u32 r = lane; r < tile_total; r += 64u) {          // dense, rank-ordered stores
                         const u64 v = st_rec[r];
-                        seg_starts[run + r] = (v & M48) - 1ull;
-                        seg_lens[run + r] = (uint16_t)(v >> 48);
+                        const u32 s1 = (u32)v, e = (u32)(v >> 32);
+                        seg_starts[run + r] = g_range + (s1 - 1u);
+                        seg_lens[run + r] = (uint16_t)(e + 2u - s1);
                     }
                 } else {                                                    // no start seen in the range before this tile
                     for (u32 r = lane; r < tile_total; r += 64u) {
                         const u64 v = st_rec[r];
-                        if ((v & M48) != g_range) {
-                            seg_starts[run + r] = (v & M48) - 1ull;
-                            seg_lens[run + r] = (uint16_t)(v >> 48);
-                        } else {                                            // staged length = offset of the end + 2
-                            seg_lens[run + r] = (uint16_t)((u32)(v >> 48) - 1u + (u32)g_range);
+                        const u32 s1 = (u32)v, e = (u32)(v >> 32);
+                        if (s1 != 0u) {
+                            seg_starts[run + r] = g_range + (s1 - 1u);
+                            seg_lens[run + r] = (uint16_t)(e + 2u - s1);
+                        } else {
+                            seg_lens[run + r] = (uint16_t)((g_range + e + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
                             unknown = 1;
                         }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
 #endif
-            } else emit_all(std::integral_constant<int, 1>{});
+            } else {
+                // the rare tiles: one record per iteration with every check (segment full, start unknown, length >= 65536), written
+                // where it belongs by the lane that owns its END
+                u32 cur1 = max(last_start_below(S), open1);
+                u32 rk = rk0;
+                auto emit_half = [&](u32 Eh, const u32 Sh, const u32 hbase) {
+                    u32 done = 0;                               // entries of the half up to and including the previous end
+                    while (Eh) {
+                        const u32 e = (u32)__builtin_ctz(Eh);
+                        const u32 upto = (2u << e) - 1u;
+                        const u32 sc = Sh & upto & ~done;
+                        done = upto;
+                        Eh &= ~upto;
+                        const u32 off = hbase + e;
+                        const u32 st1 = sc ? hbase + (32u - (u32)__builtin_clz(sc)) : cur1;      // 1 + offset of the start
+                        if (rk < a.seg_cap) {
+                            if (st1 != 0u) {
+                                const u32 len = off + 2u - st1;
+                                seg_starts[rk] = g_range + (st1 - 1u);
+                                seg_lens[rk] = (uint16_t)len;
+                                if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
+                            } else {
+                                seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);       // finished by k_seg_fix / e2s_stitch
+                                unknown = 1;
+                            }
+                        }
+                        ++rk;
+                    }
+                    // a start after the half's last end is what a later half's first end belongs to
+                    const u32 pend = Sh & ~done;
+                    if (pend) cur1 = hbase + (32u - (u32)__builtin_clz(pend));
+                };
+                emit_half((u32)E, (u32)S, base_off);
+                if (ES > 32) emit_half((u32)(E >> 32), (u32)(S >> 32), base_off + 32u);
+            }
         }
         run += tile_total;
         open1 = max(open1, tile_last1);
@@ -666,6 +472,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
             const u64 R = GE & ~Ea;
             u64 Ei = E & (((R + (Fin & R)) & Ea) | (Fin & Ea));     // E: the window-masked ends (own_lo <= end < end_hi)
             if (qn > (u32)(F2_Q / 2)) queue_flush();
+            u32 pf_cur1 = 0;                                        // the last start before each lane, over ALL starts
+            if (__ballot(Ei != 0ull)) pf_cur1 = max(last_start_below(Sa), pf_prev);
             while (__ballot(Ei != 0ull)) {                          // wave-uniform: the queue position is wave state
                 const bool act = Ei != 0ull;
                 const int e = act ? __ffsll((long long)Ei) - 1 : 0;
@@ -927,22 +735,6 @@ __global__ __launch_bounds__(256) void k_seg_compact(SegArgs a, const u64* seg_o
 
 // one thread per tile: finish the record whose start lies in an earlier tile.  Records whose true length
 // reaches 65536 (the reference's uint16_t length wraps, ebwt2clust.cpp:104) are listed for the per-cluster pass.
-__global__ void k_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* tile_fix_end, const u64* starts, uint16_t* lens, u64 cap,
-                           const u32* flags, u64* wrap_list, u32* wrap_count) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const u64 r = tile_fix[t];
-    if (r == ~0ull || r >= cap) return;
-    if (r == 0 && flags[E2S_FLAG_BEGINS_INSIDE]) return;        // start lives in an earlier shard: e2s_stitch
-    const u64 true_len = tile_fix_end[t] - starts[r] + 1;
-    lens[r] = (uint16_t)(true_len & 0xFFFFull);
-    if (true_len >= 65536ull) {
-        const u32 i = atomicAdd(wrap_count, 1u);
-        if (i < E2S_WRAP_CAP) wrap_list[i] = r;
-    }
-}
-
-// exclusive scan of per-tile counts (MODE 1 -> MODE 2), single block
 __global__ __launch_bounds__(1024) void k_tile_scan(const u32* cnt, u64* prefix, u64 n) {
     __shared__ u64 s_part[1024];
     const u32 tid = threadIdx.x;
@@ -1005,41 +797,6 @@ __global__ __launch_bounds__(256) void k_pack_write(const u64* starts, const uin
     if (blockIdx.x == n_blocks - 1 && tid == 0) *total = prefix[blockIdx.x] + cnt[blockIdx.x];
 }
 
-__global__ void k_shard_flags(ScanArgs a, u32 xb) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, xb, a.flags, a.tailv);
-}
-
-// one thread: collect what the host needs after a scan into one struct (one download instead of many)
-__global__ void k_scan_mail(ScanArgs a, const u32* words, const uint8_t* bwt, const void* pos, const void* da,
-                            int xb, int yb, int zb, ScanMail* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    ScanMail m;
-    m.total_ends = *a.total_ends;
-    m.first_end_pos = *a.first_end_pos;
-    m.begins_inside = a.flags[E2S_FLAG_BEGINS_INSIDE];
-    m.open_after = a.flags[E2S_FLAG_OPEN_AFTER];
-    m.end_before_last = a.flags[E2S_FLAG_END_BEFORE_LAST];
-    m.err = *a.err;
-    m.wrap_count = words[12];
-    m.tail_lcp = a.tailv[0];
-    m.tail_prev_lcp = a.tailv[1];
-    const u64 ne = m.total_ends;
-    const bool fits = ne + 1 < a.cap;
-    const bool own_open = m.open_after && !(ne == 0 && m.begins_inside);
-    m.open_start = (own_open && fits) ? a.starts[ne] : ~0ull;
-    m.last_end_start = (ne > 0 && fits && !(ne == 1 && m.begins_inside)) ? a.starts[ne - 1] : ~0ull;
-    m.first_len_prov = (ne > 0 && fits) ? a.lens[0] : 0u;
-    const u64 li = a.n_prov - 1;
-    auto ld = [&](const void* p, int w) -> u32 {
-        if (!p) return 0u;
-        return w == 1 ? (u32)((const uint8_t*)p)[li] : w == 2 ? (u32)((const uint16_t*)p)[li] : ((const u32*)p)[li];
-    };
-    m.last_text = ld(da, yb); m.last_suff = ld(pos, zb); m.last_lcp = ld(a.lcp, xb); m.last_bwt = bwt ? (u32)bwt[li] : 0u;
-    *out = m;
-}
-
-// apply e2s_stitch_plan to the device-resident records (values travel as kernel arguments)
 __global__ void k_apply_plan(u64* starts, uint16_t* lens, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_ends, u32 n_tail,
                              u64 t0, uint16_t l0, u64 t1, uint16_t l1) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1281,68 +1038,6 @@ __device__ __forceinline__ void cluster_record(const CandArgs& a, const u64 s, c
     }
 }
 
-struct GlobalAlloc {
-    const CandArgs& a;
-    __device__ __forceinline__ uint8_t* operator()(u32 lane) const {
-        u64 slot = 0;
-        if (lane == 0) slot = atomicAdd(a.cand_count, 1ull);
-        slot = __shfl(slot, 0);
-        return slot < a.cand_cap ? a.cand_buf + slot * a.stride : nullptr;
-    }
-};
-
-template <bool DEF>
-__global__ __launch_bounds__(CAND_WAVES * 64) void k_candidates(CandArgs a) {
-    const u32 lane = threadIdx.x & 63u;
-    const u64 gw = ((u64)blockIdx.x * CAND_WAVES) + (threadIdx.x >> 6);
-    const u64 n_waves = (u64)gridDim.x * CAND_WAVES;
-    for (u64 r = gw; r < a.n_rec; r += n_waves) {
-        const int len = (int)a.lens[r];
-        if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 (+ append_entry's filter)
-        const u64 s = a.starts[r];
-        // entries must be resident: [s, s+len) within the provided range, index n_total being the EOF phantom
-        if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull)) {
-            if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
-            continue;
-        }
-        cluster_record<DEF>(a, s, len, a.key_is_start ? s : a.record_index_base + r, lane, GlobalAlloc{a});
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
-// K2a: streaming per-cluster PRE-filter (phase A of find_events/find_variants, clust2snp.cpp:816,377-429).
-// Entry-parallel: a thread-row is 16 consecutive entries; a block walks windows of 4096 entries that overlap
-// the previous window by 160, so every cluster of <= 150 entries that ENDS in the window's new part lies inside
-// the window.  Cluster boundaries are recomputed from the LCP with the same SWAR stencil as the scan; per-cluster
-// base counts are reduced in LDS (packed 4 x 8-bit counters, one slot per cluster of the window).
-// What it keeps is a SUPERSET of the clusters the reference accepts, decided without the document array:
-// a cluster passes clust2snp.cpp:419-429 only if the two samples' sets of frequent bases are non-empty and
-// different, so at least two different bases occur >= mcov_out times in the cluster as a whole.  That test
-// needs the BWT only; `da` (4 of the 7 bytes of an entry) is read by K2b for the ~0.3 % of the clusters that
-// survive, where the exact per-sample test of the reference is applied.  Bytes read per entry: lcp 1 + bwt 1.
-// Default LCP width only (1 B).
-// ----------------------------------------------------------------------------------------------
-constexpr int FW_WIN = 4096;                 // window = 256 thread-rows of 16 entries
-constexpr int FW_HALO = 160;                 // >= E2S_MAX_CLUST_LEN + margin, multiple of 16
-constexpr int FW_NEW = FW_WIN - FW_HALO;     // 3936
-constexpr int FW_SLOTS = 2048;               // clusters per window held in LDS; denser windows raise E2S_DEVERR_DENSE
-constexpr u32 SE_ENDED = 1u << 24, SE_KR = 1u << 25;
-
-// clean lane-MSB masks of a 16-byte row (bytes are 0x80 or 0) -> 16-bit compact mask, bit e = entry e.
-// v_dot4_u32_u8 with weights 1,2,4,8 | 16,32,64,128 sums 128 * (the 8 mask bits of two words): four dot4 + two ops.
-__device__ __forceinline__ u32 compact16(const u32* m) {
-    const u32 lo = __builtin_amdgcn_udot4(m[1], 0x80402010u, __builtin_amdgcn_udot4(m[0], 0x08040201u, 0u, false), false);
-    const u32 hi = __builtin_amdgcn_udot4(m[3], 0x80402010u, __builtin_amdgcn_udot4(m[2], 0x08040201u, 0u, false), false);
-    return ((hi << 8) | lo) >> 7;
-}
-// lane-wise x == K (K broadcast): top bit of each byte
-__device__ __forceinline__ u32 swar_eq(u32 x, u32 kb) {
-    const u32 y = x ^ kb;
-    const u32 z = ((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y;       // top bit set iff byte != 0
-    return ~z & 0x80808080u;
-}
-
-constexpr int FW_FLQ = 128;                  // flagged clusters queued in LDS before one global reservation
 constexpr int FW_STAGE = 32;                 // candidates staged in LDS before one global slot reservation
 
 struct StageAlloc {
@@ -1356,171 +1051,6 @@ struct StageAlloc {
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // FW_STAGE candidate records (k_flagged_lists)
-
-#ifndef FW_LB_WAVES
-#define FW_LB_WAVES 3
-#endif
-__global__ __launch_bounds__(256, FW_LB_WAVES) void k_cluster_filter(FilterArgs a) {
-    __shared__ u32 s_all[FW_SLOTS];          // C | G<<8 | T<<16 | n<<24 over both samples
-    __shared__ u32 s_se[FW_SLOTS];           // start offset | end offset << 12 | SE_ENDED | SE_KR
-    __shared__ u64 s_flq[FW_FLQ];            // flagged clusters waiting for a global reservation: start | len << 48
-    __shared__ u32 s_wtot[4];
-    __shared__ u32 s_nfl;
-    __shared__ u64 s_gbase;
-    if (threadIdx.x == 0) s_nfl = 0;
-    // one global reservation for the whole queue (the single-word atomic rate is ~88/us: never per cluster)
-    auto queue_flush = [&]() {
-        const u32 n = min(s_nfl, (u32)FW_FLQ);
-        if (n) {
-            if (threadIdx.x == 0) s_gbase = atomicAdd(a.fl_count, (unsigned long long)n);
-            __syncthreads();
-            const u64 gbase = s_gbase;
-            for (u32 i = threadIdx.x; i < n; i += 256) {
-                const u64 v = s_flq[i];
-                if (gbase + i < a.fl_cap) { a.fl_starts[gbase + i] = v & 0xFFFFFFFFFFFFull; a.fl_lens[gbase + i] = (uint16_t)(v >> 48); }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_nfl = 0;
-        __syncthreads();
-    };
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const int64_t n_prov = (int64_t)a.n_prov;
-    const uint8_t* lcpb = a.lcp;
-    const uint8_t* bwtb = a.bwt;
-
-    // one window's worth of loads: lcp row + edge words, bwt row, da in coalesced order
-    // (lane i of load q holds entries wave*1024 + q*256 + 4i .. +3)
-    struct FwRegs { u32 W[6]; u32 B[4]; };
-    auto fw_load = [&](u64 tile, FwRegs& r) {
-        const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;
-        if (win_lo >= 4 && win_lo + FW_WIN + 4 <= n_prov) {
-            // interior window (uniform test): scalar base + 32-bit lane offset for every load
-            const uint8_t* lp = lcpb + win_lo;
-            const uint8_t* bp = bwtb + win_lo;
-            const u32 o = tid * 16u;
-            const uint4 v = *(const uint4*)(lp + o);
-            r.W[1] = v.x; r.W[2] = v.y; r.W[3] = v.z; r.W[4] = v.w;
-            r.W[0] = *(const u32*)(lp + o - 4);
-            r.W[5] = *(const u32*)(lp + o + 16);
-            const uint4 b = *(const uint4*)(bp + o);
-            r.B[0] = b.x; r.B[1] = b.y; r.B[2] = b.z; r.B[3] = b.w;
-            return;
-        }
-        const int64_t i0 = win_lo + (int64_t)tid * 16;
-#pragma unroll
-        for (int w = 0; w < 6; ++w) {                                   // (static indices: the arrays stay in registers)
-            u32 v = 0, vb = 0;
-#pragma unroll
-            for (int bt = 0; bt < 4; ++bt) {
-                const int64_t e = i0 + (int64_t)(w - 1) * 4 + bt;
-                if (e >= 0 && e < n_prov) { v |= (u32)lcpb[e] << (8 * bt); vb |= (u32)bwtb[e] << (8 * bt); }
-            }
-            r.W[w] = v;
-            if (w >= 1 && w <= 4) r.B[w - 1] = vb;
-        }
-    };
-
-    FwRegs cur, nxt;
-    if (blockIdx.x < a.n_tiles) fw_load(blockIdx.x, cur);
-    for (u64 tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        // software pipeline: the next window's loads are in flight while this one is processed
-        if (tile + gridDim.x < a.n_tiles) fw_load(tile + gridDim.x, nxt);
-        const int64_t win_lo = (int64_t)tile * FW_NEW - FW_HALO;       // local index of the window's first entry
-        const int64_t i0 = win_lo + (int64_t)tid * 16;
-        u32 W[6], B[4];
-#pragma unroll
-        for (int w = 0; w < 6; ++w) W[w] = cur.W[w];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) B[w] = cur.B[w];
-        // ---- cluster boundaries (same stencil as the scan) ----
-        RowFlags F;
-        row_flags<1>(W, a.kb, a.hge, F);
-        if (a.prov_is_global0 && i0 == 0) patch_global0<1>(W, a.k_u32, a.hge, F);
-        const u32 END = compact16(F.end), ST = compact16(F.start);
-        const bool in0 = (a.hge != 0) && ((W[1] & 0xFFu) >= a.k_u32) && !(ST & 1u);
-        // ---- per-entry classes, compact 16-bit masks ----
-        u32 mC[4], mG[4], mT[4], mK[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const u32 x = B[w] & 0xDFDFDFDFu;                       // fold case (include.hpp:269-272)
-            mC[w] = swar_eq(x, 0x43434343u);
-            mG[w] = swar_eq(x, 0x47474747u);
-            mT[w] = swar_eq(x, 0x54545454u);
-            const u32 xh = W[w + 1] | 0x80808080u;
-            mK[w] = bfi(W[w + 1] ^ a.krb, W[w + 1], xh - (a.krb & 0x7f7f7f7fu)) & a.kr_hge;    // lcp >= k_right
-        }
-        const u32 isC = compact16(mC), isG = compact16(mG), isT = compact16(mT), KR = compact16(mK);
-
-        // ---- slot numbering: exclusive count of cluster starts before this thread-row ----
-        const u32 nst = (u32)__popc(ST);
-        const u32 inc = wave_incl_scan(nst);
-        if (lane == 63) s_wtot[wave] = inc;
-        __syncthreads();                                             // also: previous window fully evaluated
-        u32 sbase = inc - nst, nslots = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { const u32 v = s_wtot[w]; if (w < (int)wave) sbase += v; nslots += v; }
-        const bool dense = nslots > FW_SLOTS;
-        if (dense) { if (tid == 0) atomicOr(a.err, E2S_DEVERR_DENSE); nslots = FW_SLOTS; }
-        for (u32 s2 = tid; s2 < nslots; s2 += 256) { s_all[s2] = 0; s_se[s2] = 0; }
-        __syncthreads();
-
-        // ---- walk the events of the thread-row, flush each piece of a cluster into its slot ----
-        {
-            int slot = (int)sbase - 1;                                // cluster open at the row's first entry (-1: began before the window)
-            bool in = in0;
-            int lo = 0;
-            const u32 row_off = tid * 16;
-            auto flush = [&](int hi, bool ended) {
-                if (slot < 0 || slot >= FW_SLOTS) return;
-                const u32 rm = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
-                const u32 all = (u32)__popc(isC & rm) | ((u32)__popc(isG & rm) << 8) | ((u32)__popc(isT & rm) << 16) | ((u32)__popc(rm) << 24);
-                atomicAdd(&s_all[slot], all);
-                u32 se = (KR & rm) ? SE_KR : 0u;
-                if (ended) se |= SE_ENDED | ((row_off + (u32)hi) << 12);
-                if (se) atomicOr(&s_se[slot], se);
-            };
-            u32 ev = END | ST;
-            while (ev) {
-                const int b = __ffs(ev) - 1;
-                ev &= ev - 1;
-                if ((ST >> b) & 1u) {                                 // a start precedes an end at the same position
-                    ++slot; lo = b; in = true;
-                    if (slot < FW_SLOTS) atomicOr(&s_se[slot], row_off + (u32)b);
-                }
-                if ((END >> b) & 1u) { flush(b, true); in = false; }
-            }
-            if (in) flush(15, false);                                 // the cluster continues in the next thread-row
-        }
-        __syncthreads();
-
-        // ---- evaluate the clusters that END in the new part of the window ----
-        const int64_t new_lo = (int64_t)tile * FW_NEW;
-        const int64_t e_lo = max(new_lo, (int64_t)a.own_lo), e_hi = min(new_lo + FW_NEW, (int64_t)a.end_hi);
-        for (u32 s2 = tid; s2 < nslots; s2 += 256) {
-            const u32 se = s_se[s2];
-            if (!(se & SE_ENDED) || !(se & SE_KR)) continue;          // no end here, or max LCP < k_right (:396)
-            const int so = (int)(se & 0xFFFu), eo = (int)((se >> 12) & 0xFFFu);
-            const int64_t epos = win_lo + eo;
-            if (epos < e_lo || epos >= e_hi) continue;
-            const int len = eo - so + 1;
-            if (len < a.len_lo || len > a.len_hi) continue;           // clust2snp.cpp:816 + append_entry's filter
-            // at least two different bases with >= mcov_out occurrences over both samples (necessary for :419-429)
-            const u32 all = s_all[s2];
-            const u32 cC = all & 0xFFu, cG = (all >> 8) & 0xFFu, cT = (all >> 16) & 0xFFu, cA = (all >> 24) - cC - cG - cT;
-            const u32 nfreq = (cA >= a.mcov_u ? 1u : 0u) + (cC >= a.mcov_u ? 1u : 0u) + (cG >= a.mcov_u ? 1u : 0u) + (cT >= a.mcov_u ? 1u : 0u);
-            if (nfreq < 2u) continue;
-            const u32 idx = atomicAdd(&s_nfl, 1u);
-            if (idx < FW_FLQ) s_flq[idx] = (a.prov_lo + (u64)(win_lo + so)) | ((u64)len << 48);
-            else atomicOr(a.err, E2S_DEVERR_DENSE);
-        }
-        __syncthreads();
-        if (s_nfl > FW_FLQ / 2) queue_flush();                      // uniform: s_nfl is stable after the barrier
-        cur = nxt;
-    }
-    __syncthreads();
-    queue_flush();
-}
 
 // ----------------------------------------------------------------------------------------------
 // K2a, second formulation: the same pre-filter built like the scan kernel.  Every wave is a worker over a
@@ -1609,6 +1139,8 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     };
 
     u32 WA[NW], WB[NW], BA[NR], BB[NR];
+    ClassConsts kc = class_consts();                            // held in VGPRs: see e2s_swar.h
+    asm volatile("" : "+v"(kc.m07), "+v"(kc.ehi), "+v"(kc.elo), "+v"(kc.c20), "+v"(kc.one), "+v"(kc.h));
     auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
         constexpr bool PF = decltype(prefetch)::value;
         if (PF) load_fast(tile + 1, Wn, Bn);
@@ -1635,12 +1167,12 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
                 IN |= 2ull;                                     // entry 1 belongs to the cluster opened at 0 whatever L[1] is
             }
         }
-        u64 C, G, T;
-        span_bwt_classes<NR>(B, C, G, T);
+        u64 c0, c1;                                             // code planes: c0 = C | G, c1 = G | T (e2s_swar.h)
+        span_bwt_code_planes<NR>(B, kc, c0, c1);
+        const u64 C = c0 & ~c1, G = c0 & c1, T = ~c0 & c1;
         // (LCP >= k_right somewhere in the cluster, clust2snp.cpp:396, is left to K2b's exact test: dropping the plane here lets
         // through only the rare cluster whose LCPs all lie in [k, k_right) and saves 7 % of this kernel's instructions)
         // class changes inside clusters: F(e) = class(e) != class(e-1), e in a cluster and not its first entry
-        const u64 c0 = C | T, c1 = G | T;
         const u32 ctop = (u32)(c0 >> 63) | ((u32)(c1 >> 63) << 1);
         const u32 cprev = wave_shr1(ctop, ccarry);
         ccarry = (u32)__builtin_amdgcn_readlane((int)ctop, 63);
@@ -1879,12 +1411,6 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
 // bucket.  O(n) work for evenly spread keys (the first version ranked by counting all pairs: 54 us for
 // 1.7x10^4 keys and quadratic beyond).
 // ----------------------------------------------------------------------------------------------
-__global__ void k_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const CandHeader* h = (const CandHeader*)(cand + i * stride);
-    keys[i] = (h->record_index << 2) | (u64)(h->pair_index & 3u);
-}
 __device__ __forceinline__ u32 ko_bucket(u64 key, u64 key_lo, u32 shift, u32 nb) {
     const u64 d = key >= key_lo ? key - key_lo : 0ull;
     const u64 b = d >> shift;
@@ -1964,32 +1490,6 @@ __global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, const unsign
     for (u32 t = lo; t < hi; ++t) r += gkeys[t] < k ? 1u : 0u;
     order[r] = gidx[j];
 }
-// ---- candidates for the host: packed, in SA order.  Records are fixed-stride in HBM (lists of <= list_cap, on
-// average a third full); what crosses PCIe is [header][idx0[n0]][pos0[n0]][idx1[n1]][pos1[n1]] per candidate, written
-// by the GPU straight into pinned host memory in SA order, plus the offsets (units of 8 bytes).
-__global__ void k_cand_sizes(const uint8_t* cand, u32 stride, const u32* order, u64 n, u64 n_pad, u32 pw, u32* size8) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    u32 v = 0;
-    if (i < n) {
-        const CandHeader* h = (const CandHeader*)(cand + (u64)order[i] * stride);
-        v = packed_size8(h->n0, h->n1, pw);
-    }
-    size8[i] = v;
-}
-__global__ __launch_bounds__(256) void k_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, u32 pw, const u32* order, const u32* off8, u64 n,
-                                                   uint8_t* stream, u32* off_out) {
-    const u32 lane = threadIdx.x & 63u;
-    const u64 gw = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
-    for (u64 i = gw; i < n; i += nw) {
-        const u32* hs = (const u32*)(cand + (u64)order[i] * stride);
-        const u32 o8 = off8[i];
-        pack_record(hs, list_cap, pw, (u32*)(stream + (u64)o8 * 8), lane);
-        if (lane == 0) { off_out[i] = o8; if (i == n - 1) off_out[n] = o8 + packed_size8(hs[3], hs[4], pw); }
-    }
-}
-// SA-order offsets of candidates that k_flagged_lists packed itself: off_out[i] = where slot order[i] went, off_out[n] = end
-// (also the pass's mail: candidate count, flagged count and the two error words, written straight into the pinned mailbox)
 __global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
                                const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail) {
     n = ko_n(n, n_dev);
@@ -2005,21 +1505,6 @@ void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, cons
     hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out,
                        fl_count, err_a, err_b, mail);
 }
-// exclusive scan of size8[0..n_pad) in place + total at size8[n_pad]; n_pad a multiple of 4096
-void e2s_launch_cand_pack(const uint8_t* cand, u32 stride, u32 list_cap, u32 pw, const u32* order, u64 n, u32* size8 /* n_pad + 1 */, u64 n_pad,
-                          uint8_t* stream, u32* off_out, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_cand_sizes, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, cand, stride, order, n, n_pad, pw, size8);
-    hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, size8, (u32)n_pad);
-    const u64 blocks = (n + 3) / 4;
-    hipLaunchKernelGGL(k_cand_pack, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, cand, stride, list_cap, pw, order, (const u32*)size8, n,
-                       stream, off_out);
-}
-void e2s_launch_cand_keys(const uint8_t* cand, u32 stride, u64 n, u64* keys, hipStream_t st) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_cand_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cand, stride, n, keys);
-}
-// scratch layout (u32 words): cnt[nb + 1] | slot[n] | gidx[n] | (8-byte aligned) gkeys[n]
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
 // ~2 keys per bucket up to 2^16 buckets (the single-block scan of the counts costs ~0.4 us per 1024 buckets; beyond
 // that longer buckets are cheaper than a longer scan)
@@ -2089,14 +1574,6 @@ __global__ void k_unpack_gesa(const uint8_t* src, u64 n, int yb_file, int zb_fil
 // launchers (called from e2s_capi.cpp through e2s_internal.h)
 // ----------------------------------------------------------------------------------------------
 static int resident_blocks(const void* fn, int threads, size_t dyn_lds);
-template <int X> static void launch_scan_x(const ScanArgs& a, int mode, hipStream_t st) {
-    const dim3 grid((unsigned)a.n_tiles), blk(SCAN_BLK);
-    if (mode == 1) hipLaunchKernelGGL((k_scan<X, 1>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_scan<X, 2>), grid, blk, 0, st, a);
-}
-void e2s_launch_scan(const ScanArgs& a, int xb, int mode, hipStream_t st) {
-    if (xb == 1) launch_scan_x<1>(a, mode, st); else if (xb == 2) launch_scan_x<2>(a, mode, st); else launch_scan_x<4>(a, mode, st);
-}
 int e2s_scan_seg_resident_blocks(int xb) {                   // resident WORKERS (waves)
     const void* fn = xb == 1 ? (const void*)k_scan_seg<1, false> : xb == 2 ? (const void*)k_scan_seg<2, false> : (const void*)k_scan_seg<4, false>;
     return 4 * resident_blocks(fn, 256, 0);
@@ -2137,18 +1614,6 @@ void e2s_launch_pack_clusters(const u64* starts, const uint16_t* lens, u64 n, in
 void e2s_launch_tile_scan(const u32* cnt, u64* prefix, u64 n, hipStream_t st) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, n);
 }
-void e2s_launch_scan_fix(u64 n_tiles, const u64* tile_fix, const u64* tile_fix_end, const u64* starts, uint16_t* lens, u64 cap,
-                         const u32* flags, u64* wrap_list, u32* wrap_count, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_fix, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, n_tiles, tile_fix, tile_fix_end, starts, lens, cap,
-                       flags, wrap_list, wrap_count);
-}
-void e2s_launch_shard_flags(const ScanArgs& a, int xb, hipStream_t st) {
-    hipLaunchKernelGGL(k_shard_flags, dim3(1), dim3(64), 0, st, a, (u32)xb);
-}
-void e2s_launch_scan_mail(const ScanArgs& a, const u32* words, const uint8_t* bwt, const void* pos, const void* da,
-                          int xb, int yb, int zb, ScanMail* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_mail, dim3(1), dim3(64), 0, st, a, words, bwt, pos, da, xb, yb, zb, out);
-}
 void e2s_launch_apply_plan(u64* starts, uint16_t* lens, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_ends, u32 n_tail,
                            u64 t0, uint16_t l0, u64 t1, uint16_t l1, hipStream_t st) {
     hipLaunchKernelGGL(k_apply_plan, dim3(1), dim3(64), 0, st, starts, lens, patch_first, first_start, first_len, n_ends, n_tail, t0, l0, t1, l1);
@@ -2162,13 +1627,6 @@ void e2s_launch_hist(const uint16_t* lens, u64 n, int min_len, u64* out, hipStre
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_hist, dim3((unsigned)blocks), dim3(256), 0, st, lens, n, min_len, out);
 }
-void e2s_launch_candidates(const CandArgs& a, bool def_widths, hipStream_t st) {
-    u64 blocks = (a.n_rec + CAND_WAVES - 1) / CAND_WAVES;
-    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;              // grid-stride beyond that
-    if (blocks == 0) return;
-    if (def_widths) hipLaunchKernelGGL((k_candidates<true>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
-    else hipLaunchKernelGGL((k_candidates<false>), dim3((unsigned)blocks), dim3(CAND_WAVES * 64), 0, st, a);
-}
 // persistent grids: exactly the blocks that can be resident (a larger static-stride grid would run in two rounds)
 static int resident_blocks(const void* fn, int threads, size_t dyn_lds) {
     int per_cu = 0, dev = 0, cus = 256;
@@ -2176,13 +1634,6 @@ static int resident_blocks(const void* fn, int threads, size_t dyn_lds) {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     return per_cu * cus;
-}
-void e2s_launch_cluster_filter(const FilterArgs& a, hipStream_t st) {
-    static int resident = 0;
-    if (!resident) resident = resident_blocks((const void*)k_cluster_filter, 256, 0);
-    u64 blocks = a.n_tiles < (u64)resident ? a.n_tiles : (u64)resident;
-    if (blocks == 0) return;
-    hipLaunchKernelGGL(k_cluster_filter, dim3((unsigned)blocks), dim3(256), 0, st, a);
 }
 void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st) {
     static int resident = 0;

@@ -314,6 +314,46 @@ E2S_HD void span_bwt_classes(const u32* B, u64& C, u64& G, u64& T) {
     }
     span_assemble<NR>(sc, C); span_assemble<NR>(sg, G); span_assemble<NR>(st, T);
 }
+// ---- K2a class planes, second formulation: TWO planes that encode the class of every entry -- P1 = C | G, P2 = G | T
+// (C = P1 & ~P2, G = P1 & P2, T = ~P1 & P2, everything else counts as A: include.hpp:250-279) -- from the two bits in which
+// the letters differ, (byte >> 1) & 3 = A 0, C 1, G 3, T 2, gated by an EXACT test "the case-folded byte is C, G or T":
+// the low three bits of the byte select the one letter it could be from an 8-entry table (v_perm_b32), one XOR-compare
+// and one v_lerp_u8 zero test decide.  Per word 4 + 4 + 2 instructions instead of 16, two plane assemblies instead of three.
+// The constants travel in a struct so that the kernel can hold them in VGPRs (v_bitop3_b32 issues twice as fast with
+// register operands as with an SGPR or a literal: tools/valu_rate.hip).
+struct ClassConsts { u32 m07, ehi, elo, c20, one, h; };
+E2S_HD ClassConsts class_consts() { return ClassConsts{0x07070707u, 0x47FFFF54u, 0x43FFFFFFu, 0x20202020u, 0x01010101u, 0x80808080u}; }
+// byte i of the result = byte sel.byte[i] (0..7) of the eight bytes {hi, lo} -- v_perm_b32 on the GPU
+E2S_HD u32 e2s_perm8(u32 hi, u32 lo, u32 sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const u64 t = ((u64)hi << 32) | lo;
+    u32 r = 0;
+    for (int i = 0; i < 4; ++i) r |= (u32)((t >> (8 * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+    return r;
+#endif
+}
+template <int NR>
+E2S_HD void span_bwt_code_planes(const u32* B, const ClassConsts& k, u64& P1, u64& P2) {
+    static_assert(NR == 16, "one 64-bit plane per code bit");
+    u32 s1[NR / 2], s2[NR / 2];
+#pragma unroll
+    for (int j = 0; j < NR / 2; ++j) {
+        u32 m1[2], m2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32 x = B[2 * j + i];
+            const u32 e = e2s_perm8(k.ehi, k.elo, x & k.m07);      // the letter with these low three bits (0xFF: none)
+            const u32 nd = ~(x ^ e) | k.c20;                       // 0xFF  <=>  the byte is that letter, in either case
+            const u32 v = e2s_lerp_u8(nd, 0u, k.one);              // top bit: nd == 0xFF
+            m1[i] = (x << 6) & v & k.h;                            // bit 1 of the byte: C, G
+            m2[i] = (x << 5) & v & k.h;                            // bit 2: G, T
+        }
+        s1[j] = e2s_pack8(m1[0], m1[1]); s2[j] = e2s_pack8(m2[0], m2[1]);
+    }
+    span_assemble<NR>(s1, P1); span_assemble<NR>(s2, P2);
+}
 template <int NR>
 E2S_HD u64 span_ge_plane(const u32* W /* the NR span words */, u32 kb, u32 hge) {
     static_assert(NR == 16, "one 64-bit plane");

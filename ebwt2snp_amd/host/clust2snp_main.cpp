@@ -1,7 +1,7 @@
 // clust2snp -- drop-in for the reference executable (clust2snp.cpp:969-1085): same getopt string (so
 // -M and -b stay unparseable, H5), same defaults (0 = default), same files in and out, same phases.
-// The per-cluster pass (find_events + find_variants) runs on the GPU through the C ABI; the
-// histogram rule, consensus, distance and the KisSNP2 writer are host code in libe2s_hip.so.
+// The per-cluster pass (find_events + find_variants) and the tail (consensus, distance, KisSNP2 text) run on the
+// GPU through the C ABI; the histogram rule is host code in libe2s_hip.so, as is the tail for irregular inputs.
 #include <unistd.h>
 
 #include <cmath>
@@ -110,6 +110,14 @@ int main(int argc, char** argv) {
     if (F.gesa) die_on(e2s_upload_gesa(h, &d, F.aos.p), h, "upload (.gesa)");
     else die_on(e2s_upload_bcr(h, &d, F.bwt.p, F.lcp.p, F.pairsa.p), h, "upload (BCR)");
     pc.mark("upload EGSA");
+    // the reads go to HBM too (get_reads done once, clust2snp.cpp:147-212): consensus, distance and the KisSNP2 text then run on
+    // the GPU and the candidates never cross PCIe.  An irregular FASTA stays on the host (the sequential restatement decides).
+    {
+        uint64_t n_reads = 0;
+        rc = e2s_upload_reads_fasta(h, input.c_str(), &n_reads);
+        if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) die_on(rc, h, "upload reads");
+    }
+    pc.mark("index + upload reads");
     die_on(e2s_load_clusters(h, CL.p, CL.n / 10), h, "load .clusters");
     pc.mark("load .clusters");
 
@@ -154,17 +162,14 @@ int main(int argc, char** argv) {
     pc.mark("find candidates");
     std::cout << " 100% done." << std::endl;
     std::cout << "Done. " << n_cand << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
-    // the candidates arrive packed and in SA order in the handle's pinned buffer; the tail reads them in place
-    const void* cstream = nullptr; const uint32_t* coff = nullptr; uint64_t cbytes = 0; uint32_t cpw = 4;
-    die_on(e2s_candidates_packed(h, &cstream, &coff, &n_cand, &cbytes, &cpw), h, "candidates");
 
     std::cout << "(2/4) Extracting reads from fasta file ..." << std::endl;
     std::cout << "(3/4) Filtering " << n_cand << " candidates and computing consensus of left-contexts ... " << std::endl;
     std::cout << "(4/4) Computing edit distances and saving SNPs/indels to file ... " << std::endl;
     e2s_tail_params tp{k_left, k_right, max_gap, max_err};
     uint64_t nv = 0, ne = 0;
-    rc = e2s_snp_from_packed(cstream, coff, n_cand, cpw, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);
-    pc.mark("host tail + .snp");
+    rc = e2s_write_snp(h, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);      // extract_variants + to_file (clust2snp.cpp:864-868)
+    pc.mark("tail + .snp");
     e2s_destroy(h);
     pc.mark("e2s_destroy");
     if (rc == E2S_ERR_REF_CRASH) {

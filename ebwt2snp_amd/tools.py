@@ -63,8 +63,10 @@ def ebwt2clust(input_path, k=0, m=0, x=0, y=0, z=0, device=0, scan_mode=0, handl
 
 
 def clust2snp(input_path, n, L=0, R=0, g=0, v=0, c=0, e=0, m=0, p=0.0, x=0, y=0, z=0, device=0, handle=None,
-              return_candidates=False):
-    """clust2snp -i input -n N [...].  Reads input.clusters + the EGSA + the FASTA; writes the .snp file."""
+              return_candidates=False, tail="auto"):
+    """clust2snp -i input -n N [...].  Reads input.clusters + the EGSA + the FASTA; writes the .snp file.
+    tail: "auto" = what the executable does (reads made resident, consensus / distance / text on the GPU, the host tail where
+    only it reproduces the reference), "host" = the host tail (snp_tail.cpp) over the packed candidates."""
     x, y, z = _widths(x, y, z)
     L = L or 31
     R = R or 30
@@ -80,14 +82,24 @@ def clust2snp(input_path, n, L=0, R=0, g=0, v=0, c=0, e=0, m=0, p=0.0, x=0, y=0,
     h = handle or capi.Handle(device)
     try:
         _open_shard(h, input_path, x, y, z)
+        h.attach_reads(None, None, None, 0, 0)                      # (a handle reused across jobs: forget the previous job's reads)
+        if tail != "host":
+            try:
+                h.upload_reads_fasta(input_path)
+            except capi.E2SError as ex:
+                if ex.code not in (6, 8):                           # ERR_INPUT: irregular FASTA, ERR_IO: unreadable -> the host tail decides
+                    raise
         recs = np.fromfile(cl_path, dtype=np.uint8)
         h.load_clusters(recs[:(recs.size // 10) * 10])
         mcl, n_clust, n_bases = capi.auto_max_clust_length([h.hist()], m, p)
         prm = capi.C2SParams(nr_reads1, L, R, m, c, mcl, 0)
         ncand = h.find_candidates(prm)
-        stream, off8, ncand, pw = h.candidates_packed()
         out = snp_out_path(input_path)
-        nv, ne = capi.snp_from_packed(stream, off8, ncand, input_path, out, L, R, g, e, pos_bytes=pw)
+        if tail == "host":
+            stream, off8, ncand, pw = h.candidates_packed()
+            nv, ne = capi.snp_from_packed(stream, off8, ncand, input_path, out, L, R, g, e, pos_bytes=pw)
+        else:
+            nv, ne = h.write_snp(input_path, out, L, R, g, e)
         res = dict(max_clust_length=mcl, n_clust=n_clust, n_bases=n_bases, n_candidates=ncand, n_variants=nv, n_events=ne,
                    out_path=out)
         if return_candidates:

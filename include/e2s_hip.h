@@ -13,7 +13,9 @@
  *   e2s_cluster_hist                statistics (histogram pass)    clust2snp.cpp:877-909
  *   e2s_auto_max_clust_length       statistics (auto max length)   clust2snp.cpp:936-946
  *   e2s_find_candidates             find_events + find_variants    clust2snp.cpp:788-857,367-500
- *   e2s_snp_from_candidates         extract_variants + to_file     clust2snp.cpp:505-780
+ *   e2s_upload_reads[_fasta]        get_reads                      clust2snp.cpp:147-212
+ *   e2s_call_variants               extract_variants + distance + to_file (on the GPU)   clust2snp.cpp:505-780, 254-302
+ *   e2s_snp_from_candidates         the same on the host           clust2snp.cpp:505-780
  *
  * Conventions: one handle per GPU; the caller is single-threaded per handle; no
  * exceptions cross the boundary; every call returns E2S_OK (0) or an error code
@@ -36,7 +38,6 @@ extern "C" {
 #define E2S_ERR_HIP          2   /* a HIP runtime call failed (no GPU, OOM, ...) */
 #define E2S_ERR_STATE        3   /* call out of order (e.g. scan before upload) */
 #define E2S_ERR_CAPACITY     4   /* output buffer too small; required count returned */
-#define E2S_ERR_SPIN_TIMEOUT 5   /* bounded in-kernel wait expired (look-back chain) */
 #define E2S_ERR_INPUT        6   /* malformed input (.clusters not ascending / past EOF) */
 #define E2S_ERR_REF_CRASH    7   /* the reference crashes on this input (H6); nothing written */
 #define E2S_ERR_IO           8
@@ -91,7 +92,8 @@ int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, con
 int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void* lcp, uint8_t tail_bwt);
 
 /* ---- ebwt2clust: cluster boundaries ------------------------------------------------------- */
-/* scan_mode: 0 = single-pass decoupled look-back (default), 1 = three-kernel count/scan/emit. */
+/* scan_mode: must be 0 (the segmented single-pass scan: every wave a worker over a contiguous range of 4-KiB tiles; the
+ * argument stays in the signature for ABI stability -- the count/scan/emit implementation it used to select is gone). */
 int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode);
 
 /* What one shard tells the others (fixed size; exchanged with ONE all-gather). */
@@ -245,6 +247,32 @@ int e2s_snp_from_candidates(const void* cands, const uint32_t* order, uint64_t n
 int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n_cand, uint32_t pos_bytes, const e2s_tail_params* p,
                         const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events);
 
+/* ---- the tail on the GPU: reads resident in HBM -------------------------------- */
+/* get_reads (clust2snp.cpp:147-212) done once for ALL reads: read r = text[start[r] .. start[r] + len[r]), max_len = the longest.
+ * e2s_upload_reads copies host arrays to HBM; e2s_attach_reads takes device pointers (the caller keeps ownership);
+ * e2s_upload_reads_fasta indexes a FASTA file on the host (worker threads) and uploads it -- E2S_ERR_INPUT for a file whose
+ * line structure is irregular (a header after a header, no header first, ...), where the reference's line juggling yields
+ * text this index cannot express: keep to e2s_snp_from_packed then.
+ * Make the reads resident BEFORE e2s_find_candidates: the candidates then stay in HBM instead of crossing PCIe. */
+int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
+                     uint32_t max_len);
+int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len);
+int e2s_upload_reads_fasta(e2s_handle h, const char* fasta_path, uint64_t* n_reads);
+/* extract_variants + distance + to_file (clust2snp.cpp:505-780) over the candidates of the last e2s_find_candidates, on the
+ * GPU: one wave per candidate gathers the left contexts, builds the two consensus strings (cons' tie-break, include.hpp:334-371),
+ * counts the supports, runs distance() and the KisSNP2 text of every event is written into an image in HBM, ids counting
+ * from first_id (1 for a whole job; a later rank / chunk continues where the previous one stopped).  n_variants = candidates
+ * with both supports > 0, n_events = records of the `.snp`, snp_bytes = size of the image.
+ * E2S_ERR_REF_CRASH where the reference crashes (no candidate; a right context beyond its read); E2S_ERR_STATE where only the
+ * host tail reproduces the reference (-L outside 1..64, a read rank past the last read): use e2s_snp_from_packed then. */
+int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_t first_id, uint64_t* n_variants, uint64_t* n_events, uint64_t* snp_bytes);
+/* the image, copied out whole or handed to a sink chunk by chunk (as e2s_stream_clusters) */
+int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64_t* bytes);
+int e2s_stream_snp(e2s_handle h, e2s_byte_sink sink, void* user);
+/* What the clust2snp executable calls after e2s_find_candidates: the GPU tail when the reads are resident and it applies,
+ * otherwise the host tail over the packed candidates; writes out_path either way (nothing where the reference crashes). */
+int e2s_write_snp(e2s_handle h, const e2s_tail_params* p, const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 typedef struct {
     float scan_ms;        /* e2s_cluster_scan kernels incl. the statistics (HIP events on the handle's stream) */
@@ -253,6 +281,7 @@ typedef struct {
     float cand_ms;        /* e2s_find_candidates kernels */
     float cand_main_ms;   /* the dominant per-cluster kernel alone */
     float upload_ms;
+    float tail_ms;        /* e2s_call_variants kernels */
     uint64_t scan_bytes_read, scan_bytes_written;   /* algorithmic bytes of the last call */
     uint64_t cand_bytes_read, cand_bytes_written;
 } e2s_timing;

@@ -110,11 +110,13 @@ static int run_classes(unsigned seed, int iters) {
     const unsigned char pool[] = {'A', 'C', 'G', 'T', 'a', 'c', 'g', 't', 'N', '$', 'n', 0x42, 0x44, 0x46, 0x48, 0x53, 0x55, 0x63 ^ 0x80, 0xC3, 0xFF, 0x00, 0x23, 0x67 | 0x80};
     for (int it = 0; it < iters; ++it) {
         unsigned char b[64], l[64];
-        for (int i = 0; i < 64; ++i) { b[i] = (rand() % 3) ? pool[rand() % sizeof(pool)] : (unsigned char)rand(); l[i] = (unsigned char)rand(); }
+        for (int i = 0; i < 64; ++i) { b[i] = it < 4 ? (unsigned char)(64 * it + i) : (rand() % 3) ? pool[rand() % sizeof(pool)] : (unsigned char)rand(); l[i] = (unsigned char)rand(); }   // (the first four rounds: every byte value)
         u32 B[16], W[16];
         memcpy(B, b, 64); memcpy(W, l, 64);
-        u64 C, G, T;
+        u64 C, G, T, P1, P2;
         span_bwt_classes<16>(B, C, G, T);
+        span_bwt_code_planes<16>(B, class_consts(), P1, P2);
+        if ((P1 & ~P2) != C || (P1 & P2) != G || (~P1 & P2) != T) { if (bad < 5) fprintf(stderr, "code planes differ from the class planes\n"); ++bad; }
         const u64 kr = (u64)(rand() % 300);
         const u32 hge = kr > 0xFF ? 0u : 0x80808080u, kb = (u32)(kr & 0xFF) * 0x01010101u;
         const u64 K = span_ge_plane<16>(W, kb, hge);

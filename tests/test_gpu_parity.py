@@ -33,21 +33,22 @@ def _write_e2c(c, p):
     return x, y, z
 
 
-@pytest.mark.parametrize("scan_mode", [0, 1])
-def test_e2c_golden_table(H, tmp_path, scan_mode):
+def test_e2c_golden_table(H, tmp_path):
     """every known answer of the reference's ebwt2clust, incl. u16 wrap, all widths, both formats, EOF phantom"""
     p = str(tmp_path / "t.fa")
     for c in goldens.e2c_table():
         x, y, z = _write_e2c(c, p)
-        cnt = tools.ebwt2clust(p, c.get("k", 0), c.get("m", 0), x, y, z, scan_mode=scan_mode, handle=H)
+        cnt = tools.ebwt2clust(p, c.get("k", 0), c.get("m", 0), x, y, z, handle=H)
         s, l = IO.read_clusters(p + ".clusters")
         assert cnt == c["expect"]["n_printed"], {k: v for k, v in c.items() if k not in ("lcp", "lcp_rle", "expect")}
         assert s.tolist() == c["expect"]["starts"] and l.tolist() == c["expect"]["lens"]
 
 
+@pytest.mark.parametrize("tail", ["auto", "host"])
 @pytest.mark.parametrize("meta", goldens.e2e_cases(), ids=lambda m: m["name"])
-def test_e2e_golden(H, meta, tmp_path):
-    """ebwt2clust -> .clusters -> clust2snp -> .snp, byte-identical to the reference's files"""
+def test_e2e_golden(H, meta, tmp_path, tail):
+    """ebwt2clust -> .clusters -> clust2snp -> .snp, byte-identical to the reference's files; the tail (consensus, distance,
+    KisSNP2 text) on the GPU with the reads resident in HBM ("auto": what the executable does) and on the host"""
     reads, n1, en = goldens.e2e_inputs(meta)
     p = goldens.write_case_files(meta, reads, en, str(tmp_path))
     x, y, z = meta["xyz"]
@@ -58,7 +59,7 @@ def test_e2e_golden(H, meta, tmp_path):
     assert hashlib.sha256(cl).hexdigest() == meta["clusters_sha256"]
     a = meta["c2s"]
     r = tools.clust2snp(p, n1, L=a.get("L", 0), R=a.get("R", 0), g=a.get("g", 0), c=a.get("c", 0), e=a.get("e", 0),
-                        m=a.get("m", 0), p=a.get("p", 0.0), x=x, y=y, z=z, handle=H)
+                        m=a.get("m", 0), p=a.get("p", 0.0), x=x, y=y, z=z, handle=H, tail=tail)
     assert r["max_clust_length"] == meta["max_clust_length"]
     assert r["n_candidates"] == meta["n_candidates"]
     assert open(r["out_path"], "rb").read() == goldens.golden_snp(meta)
@@ -77,10 +78,11 @@ def test_crafted_c2s_golden(H, tmp_path):
         (IO.write_gesa if c["gesa"] else IO.write_bcr)(p, ent[:, 0], ent[:, 1], ent[:, 2], ent[:, 3], x, y, z)
         IO.write_clusters(p + ".clusters", [s for s, _ in c["clusters"]], [l for _, l in c["clusters"]])
         a = c["args"]
-        r = tools.clust2snp(p, c["n1"], L=a.get("L", 0), R=a.get("R", 0), g=a.get("g", 0), c=a.get("c", 0),
-                            e=a.get("e", 0), m=a.get("m", 0), p=a.get("p", 0.0), x=x, y=y, z=z, handle=H)
-        assert open(r["out_path"]).read() == c["expected_snp"], c["name"]
-        assert r["n_candidates"] == c["n_candidates"] and r["max_clust_length"] == c["max_clust_length"]
+        for tail in ("auto", "host"):
+            r = tools.clust2snp(p, c["n1"], L=a.get("L", 0), R=a.get("R", 0), g=a.get("g", 0), c=a.get("c", 0),
+                                e=a.get("e", 0), m=a.get("m", 0), p=a.get("p", 0.0), x=x, y=y, z=z, handle=H, tail=tail)
+            assert open(r["out_path"]).read() == c["expected_snp"], (c["name"], tail)
+            assert r["n_candidates"] == c["n_candidates"] and r["max_clust_length"] == c["max_clust_length"]
 
 
 def test_candidates_equal_oracle(H, tmp_path):
@@ -121,7 +123,7 @@ def _adversarial_lcp(rnd, n, mode):
 @pytest.mark.parametrize("x", [1, 2, 4])
 def test_scan_fuzz_vs_oracle(H, x):
     """seeded adversarial LCP arrays (several tiles, cross-tile and multi-tile clusters, dense events)
-    against the sequential oracle, both scan modes"""
+    against the sequential oracle"""
     rnd = np.random.RandomState(100 + x)
     sizes = [1, 3, 17, 4095, 4096, 4097, 16383, 16384, 16385, 70001, 250000, 1200003]
     for n in sizes:
@@ -136,7 +138,7 @@ def test_scan_fuzz_vs_oracle(H, x):
             es, el, ec = O.cluster_lm_mem(L, ph, k, 2)
             dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[x]
             d = capi.Handle.desc(n, x=x)
-            for sm in (0, 1):
+            for sm in (0,):
                 H.upload_lcp(d, L.astype(dt).view(np.uint8), int(bwt[-1]))
                 H.scan_single(k, 2, sm)
                 closed, nrec = H.counts()
@@ -236,7 +238,7 @@ def test_sharded_scan_and_candidates_on_one_gpu(tmp_path):
 
 def test_attach_device_arrays_and_full_pipeline_properties():
     """zero-copy path used by bench.py: torch tensors resident in HBM, attached by pointer.  At a size
-    the oracle cannot follow quickly, check properties: both scan modes agree, records are ascending
+    the oracle cannot follow quickly, check properties: two scans of the same shard agree, records are ascending
     and disjoint, the printed count equals a vectorised torch restatement of the stencil."""
     import torch
     dev = torch.device("cuda:0")
@@ -250,7 +252,7 @@ def test_attach_device_arrays_and_full_pipeline_properties():
     h = capi.Handle(0)
     d = capi.Handle.desc(n)
     out = []
-    for sm in (0, 1):
+    for sm in (0, 0):
         h.attach_soa(d, bwt.data_ptr(), lcp.data_ptr(), pos.data_ptr(), da.data_ptr(), keep=(bwt, lcp, pos, da))
         h.scan_single(16, 2, sm)
         out.append((h.counts(), h.fetch_clusters().copy()))
@@ -555,21 +557,6 @@ def test_wide_lcp_columns_kept_wide(tmp_path):
 
 
 @pytest.mark.gpu
-def test_wave_per_record_pass_kept(tmp_path):
-    """records that are not the streaming pass's own (a `.clusters` file, columns kept wide) go through a thread-per-record
-    pre-filter and the list kernels (every file-driven case above); E2S_RECORD_PREFILTER=0 keeps the first implementation,
-    one wave per record (k_candidates), alive: a child pytest runs the file-driven cases that way"""
-    import subprocess
-    import sys
-    here = os.path.abspath(__file__)
-    env = dict(os.environ, E2S_RECORD_PREFILTER="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "e2e_golden or crafted_c2s_golden or candidates_equal_oracle or seed56"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-@pytest.mark.gpu
 def test_packed_stream_overflow_retry(tmp_path):
     """the pinned buffer for the packed candidates is sized for 128 B per slot; when fuller lists outgrow it the pass is
     rerun with room for full lists.  E2S_STREAM_PER_CAND=8 (read at e2s_create) makes every case overflow: a child
@@ -611,20 +598,6 @@ def test_few_workers_many_tiles_each(tmp_path):
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "fused_streaming_fuzz_columns or sharded_fuzz_columns or fused_streaming_candidates_equal_oracle or "
                               "fused_streaming_adversarial or scan_fuzz_vs_oracle"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-@pytest.mark.gpu
-def test_first_prefilter_formulation_kept(tmp_path):
-    """E2S_FILTER_V1=1 selects the first formulation of the pre-filter (thread rows of 16 entries, LDS slots per cluster), kept as an
-    independent implementation of the same superset test: a child pytest runs the candidate comparisons with it"""
-    import subprocess
-    import sys
-    here = os.path.abspath(__file__)
-    env = dict(os.environ, E2S_FILTER_V1="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "fused_streaming_candidates_equal_oracle or fused_streaming_fuzz_columns or fused_streaming_adversarial"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 

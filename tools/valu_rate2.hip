@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void NAME(u32* out, u32 s0, u32 s1) {         
     lds[threadIdx.x] = s0;                                                                             \
     _Pragma("unroll") for (int i = 0; i < UN; ++i) a[i] = threadIdx.x * 2654435761u + i * s0;          \
     for (int it = 0; it < ITER; ++it) {                                                                \
-        _Pragma("unroll") for (int i = 0; i < UN; ++i) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c), "s"(s1), "v"(la) : "vcc", "s20", "s21", "s22", "s23", "s24", "memory"); \
+        _Pragma("unroll") for (int i = 0; i < UN; ++i) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c), "s"(s1), "v"(la) : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "memory"); \
     }                                                                                                  \
     u32 r = 0; _Pragma("unroll") for (int i = 0; i < UN; ++i) r ^= a[i];                               \
     if (r == 0x12345u) out[threadIdx.x] = r + lds[1];                                                  \
@@ -73,7 +73,7 @@ int main() {
             const double cyc = ms * 1e-3 * clk_khz * 1e3 / ((double)ITER * UN * wps);
             printf("  wps%d: %6.2f", wps, cyc);
         }
-        printf("\n");
+        printf("\n"); fflush(stdout);
     }
     return 0;
 }
