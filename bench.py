@@ -1,22 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- EGSA entries/sec through ebwt2clust+clust2snp on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path over a synthetic EGSA that is already resident in HBM:
-  cluster-boundary scan (ebwt2clust) -> boundary stitch -> cluster-length statistics ->
-  per-cluster allele-count/candidate pass (clust2snp) -> candidates copied to the host.
-The host tail (consensus / distance / KisSNP2 text for the ~1-per-12k-entries candidates) is outside the
-step; DESIGN.md quotes it separately.
+A step = one pass of the hot path over a synthetic EGSA (and its reads) already resident in HBM, ending with BOTH outputs as
+file images in HBM (ebwt2snp_amd/pipeline.py):
+  cluster-boundary scan with clust2snp's pre-filter in the same kernel (ebwt2clust) -> boundary stitch -> cluster-length
+  statistics -> `.clusters` image packed on a second stream || per-cluster pass (clust2snp) -> consensus, distance and
+  KisSNP2 text on the GPU -> `.snp` image.
+`value` is that step's rate.  Beside it: `value_outputs_on_host` (the same step plus both images copied to pinned host memory:
+PCIe included on the way out) and `value_end_to_end` (this repo's executables through files on the CPU-baseline sample).
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 1 --steps 20 --warmup 3                      (default workload: c3, BASELINE.json configs[2])
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+      bench.py --gpus N --steps K --warmup W [--scaling strong]
 
-N > 1: weak scaling.  The global EGSA is N copies of the block; rank r owns a contiguous SA range whose
-cuts fall INSIDE clusters, so the stitch is real: ONE all-gather of the 88-byte boundary descriptors
-(plus one of the 1.2 KB histogram partials for the statistics step), RCCL over xGMI.
+N > 1, --scaling weak (default): the global EGSA is N copies of the workload; rank r owns a contiguous SA range whose cuts fall
+INSIDE clusters, so the stitch is real.  --scaling strong (BASELINE.json configs[3]): the SAME workload cut into N SA ranges.
+Either way: ONE all-gather of the 88-byte boundary descriptors + 1.2-KB statistics (RCCL over xGMI), and an 8-byte one for the
+`.snp` ids, which are sequential over the ranks.
 """
 import argparse
-import ctypes
 import json
 import os
 import shutil
@@ -31,16 +33,16 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from ebwt2snp_amd import capi, synth
+from ebwt2snp_amd import capi, pipeline, synth
 from ebwt2snp_amd import egsa_io as IO
 
 WORKLOADS = {
-    # name: (reads per individual, read length)  -- BASELINE.json configs
+    # name: (reads per individual, read length[, copies])  -- BASELINE.json configs
     "c1": (1000, 100),            # 2x1k x100bp, 2.02e5 entries (the reference's own CPU-runnable case)
-    "c2": (1000000, 100),         # 2x1M x100bp, 2.02e8 entries  <- the metric's 1-GPU configuration
+    "c2": (1000000, 100),         # 2x1M x100bp, 2.02e8 entries
     "c2s": (250000, 100),         # quarter-size c2 for quick checks
     # 3.02e9 entries: ten copies of an exactly sorted 2x1M x150bp block laid end to end, read ids remapped per copy
-    # ("C2-style block tiled with read-id remap") -- BASELINE.json configs[2], 21 GB of EGSA in HBM
+    # ("C2-style block tiled with read-id remap") -- BASELINE.json configs[2], 21 GB of EGSA + 3 GB of reads in HBM
     "c3": (1000000, 150, 10),
     "c3x": (1000000, 150, 15),    # 4.53e9 entries: SA positions beyond 2^32 on one GPU (stress check, 32 GB of EGSA)
 }
@@ -72,6 +74,13 @@ def tile_block(blk, n1, copies):
     return out, n1 * copies
 
 
+def tile_reads(reads, n1, copies):
+    """the reads of the tiled EGSA in id order: individual 1 of every copy, then individual 2 of every copy"""
+    if copies == 1:
+        return reads
+    return torch.cat([reads[:n1]] * copies + [reads[n1:]] * copies).contiguous()
+
+
 def pick_cut(lcp, approx):
     """an SA position near `approx` that lies strictly inside a cluster (both neighbours share >= 16)"""
     w = lcp[approx:approx + 100000].to(torch.int32)
@@ -81,8 +90,8 @@ def pick_cut(lcp, approx):
     return approx + idx + 2
 
 
-def shard_arrays(blk, m, rank, world):
-    """rank's slice of the N-block global EGSA: [rank*m + d_r, (rank+1)*m + d_{r+1}) plus halos"""
+def shard_weak(blk, m, rank, world):
+    """rank's slice of the N-copy global EGSA: [rank*m + d_r, (rank+1)*m + d_{r+1}) plus halos"""
     cuts = [0] * (world + 1)
     for r in range(1, world):
         cuts[r] = pick_cut(blk["lcp"], m // 3 + 1000 * r)
@@ -100,30 +109,34 @@ def shard_arrays(blk, m, rank, world):
     return out, g0, n_own, hl, hr
 
 
+def shard_strong(blk, m, rank, world):
+    """rank's SA range of the ONE workload (BASELINE.json configs[3]): cuts near r*m/N, inside clusters"""
+    cuts = [0] + [pick_cut(blk["lcp"], (m * r) // world) for r in range(1, world)] + [m]
+    lo, hi = cuts[rank], cuts[rank + 1]
+    hl = min(152, lo)
+    hr = 1 if rank < world - 1 else 0
+    out = {k: v[lo - hl:hi + hr].contiguous() for k, v in blk.items()}
+    return out, lo, hi - lo, hl, hr
+
+
 PHASES = {}
+_T = [0.0]
 
 
-def _tick(name, t0):
+def _tick(name):
     t1 = time.perf_counter()
-    PHASES[name] = PHASES.get(name, 0.0) + (t1 - t0)
-    return t1
+    PHASES[name] = PHASES.get(name, 0.0) + (t1 - _T[0])
+    _T[0] = t1
 
 
 _XCHG = {}
-# E2S_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the N-rank logic (shards, single
-# exchange, stitch plans, merged statistics) on a one-GPU box; not a measurement
+# E2S_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- exercises the N-rank logic (shards, exchanges, stitch plans,
+# merged statistics, sequential ids) on a one-GPU box; not a measurement
 REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
-# E2S_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path -- RCCL process group,
-# exchange, merged statistics -- with a single rank, to exercise it on a one-GPU box
+# E2S_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the N-rank code path -- RCCL process group, exchanges --
+# with a single rank, to exercise it on a one-GPU box
 FORCE_DIST = os.environ.get("E2S_BENCH_FORCE_DIST", "0") == "1"
-# E2S_BENCH_OVERLAP=1: the timed steps arm the pre-filter before the scan (e2s_prefilter_arm): it then runs INSIDE the scan kernel
-# (k_scan_seg<1, true>; with E2S_FUSED=0 beside it on a second stream) -- one pass over the LCP, 13-18 % more throughput on one GPU.
-# E2S_BENCH_OVERLAP=0 keeps the two kernels apart: with several ranks the pre-filter then runs while the descriptors are exchanged.
-# Default "auto": inside the scan kernel unless there is an exchange AND the shard is small (see main).  Either way the other mode
-# is measured after the timed run and reported as "other_mode", so that the separate kernels are also seen against their rooflines.
-OVERLAP = os.environ.get("E2S_BENCH_OVERLAP", "auto")             # "1" / "0" / "auto" (resolved in main once the shard size is known)
-FUSED = os.environ.get("E2S_FUSED", "1") != "0"
-SECOND_LEG = os.environ.get("E2S_BENCH_SECOND_LEG", "1") == "1"      # also measure the other mode (reported as other_mode)
+SECOND_LEG = os.environ.get("E2S_BENCH_SECOND_LEG", "1") == "1"      # also time the two kernels apart (reported as other_mode)
 
 
 def _exchange(blob, world, dist, dev):
@@ -141,7 +154,7 @@ def _exchange(blob, world, dist, dev):
         return [raw[i * n:(i + 1) * n] for i in range(world)]
     xs = x.get("stream")
     if xs is None:
-        xs = x["stream"] = torch.cuda.Stream(device=dev, priority=-1)      # beside the pre-filter kernel, not behind it
+        xs = x["stream"] = torch.cuda.Stream(device=dev, priority=-1)
     with torch.cuda.stream(xs):
         x["d_src"].copy_(x["src"], non_blocking=True)
         dist.all_gather_into_tensor(x["d_dst"], x["d_src"])
@@ -151,44 +164,26 @@ def _exchange(blob, world, dist, dev):
     return [raw[i * n:(i + 1) * n] for i in range(world)]
 
 
-def run_step(h, prm_base, world, rank, dist, dev, k=16, min_len=2, n_total=None, overlap=None):
-    t = time.perf_counter()
-    if OVERLAP if overlap is None else overlap:
-        h.prefilter_arm(prm_base["m"])                             # the scan starts the pre-filter beside itself (second stream)
-    h.cluster_scan(k, min_len, 0)                                  # scan + statistics of the shard's own records
-    h.prefilter_begin(prm_base["m"], min_len)                      # (no-op if armed) runs beside the exchange and the statistics below
-    t = _tick("scan", t)
-    b = h.boundary()
+def run_step(h, n1, n_total, world, rank, dist, dev, fused=True, on_host=False):
+    _T[0] = time.perf_counter()
+    ex = pipeline.exchange_none if dist is None else (lambda blob: _exchange(blob, world, dist, dev))
+    ids = None
     if dist is not None:
-        # the boundary stitch: ONE all-gather carries descriptor + statistics of every rank
-        st = h.scan_stats()
-        sb, ss = ctypes.sizeof(capi.Boundary), ctypes.sizeof(capi.ScanStats)
-        parts = _exchange(bytes(b) + bytes(st), world, dist, dev)
-        blob = np.frombuffer(b"".join(parts), dtype=np.uint8).reshape(world, sb + ss)
-        allb = (capi.Boundary * world).from_buffer_copy(np.ascontiguousarray(blob[:, :sb]).tobytes())
-        alls = (capi.ScanStats * world).from_buffer_copy(np.ascontiguousarray(blob[:, sb:]).tobytes())
-        h.stitch_array(allb, world, rank)
-    else:
-        h.stitch([b], rank)
-    t = _tick("stitch", t)
-    if dist is not None:
-        # every rank derives the same statistics from the gathered blobs (pure host function, one call)
-        mcl, n_clust, _ = capi.auto_max_clust_length_ranks(allb, alls, n_total, k, 1, prm_base["m"], 0.99)
-    else:
-        mcl, n_clust, _ = capi.auto_max_clust_length([h.hist()], prm_base["m"], 0.99)
-    t = _tick("hist", t)
-    prm = capi.C2SParams(prm_base["n1"], 31, 30, prm_base["m"], 20, mcl, min_len)
-    ncand = h.find_candidates(prm, rank << 40)
-    t = _tick("candidates", t)
-    stream, off8, ncand, _pw = h.candidates_packed()                  # pinned host memory, packed, SA order (what the host tail consumes)
-    t = _tick("view", t)
-    return dict(n_ends=b.n_ends, n_cand=ncand, mcl=mcl, n_clust=n_clust)
+        def ids(ne):
+            parts = _exchange(np.uint64(ne).tobytes(), world, dist, dev)
+            return int(sum(np.frombuffer(p, dtype=np.uint64)[0] for p in parts[:rank]))
+    r = pipeline.resident_job(h, n1, n_total, rank, world, ex, fused=fused, ids_exchange=ids, tick=_tick)
+    if on_host:                                                    # both images over PCIe into host memory
+        r["clusters_host"] = h.fetch_clusters()
+        r["snp_host"] = h.fetch_snp() if r.get("n_events") else np.zeros(0, np.uint8)
+        _tick("outputs to host")
+    return r
 
 
-def cpu_baseline(blk, reads, n1, sample_entries):
-    """the reference's own executables (oracle/_ref) -- or, without them, the C restatement -- timed on
-    one host core over the first `sample_entries` entries of the same EGSA, through files like the
-    reference works (BCR triple + FASTA)."""
+def cpu_baseline(blk, reads, n1, sample_entries, dev):
+    """the reference's own executables (oracle/_ref) -- or, without them, the C restatement -- timed on one host core over the
+    first `sample_entries` entries of the same EGSA, through files like the reference works (BCR triple + FASTA); then this repo's
+    executables on the very same files, and the resident job on the sample: all outputs compared byte for byte."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     n = int(min(sample_entries, blk["lcp"].numel()))
@@ -221,13 +216,13 @@ def cpu_baseline(blk, reads, n1, sample_entries):
         res = dict(value=n / (t2 - t0), unit="EGSA entries/s", cores=1, kind=kind,
                    sample="first %d entries of the same EGSA (BCR triple + FASTA on local disk): ebwt2clust %.2f s + clust2snp %.2f s"
                           % (n, t1 - t0, t2 - t1))
-        # the drop-in executables of this repo on the very same files, end to end (process start, file reads, upload,
-        # kernels, host tail, file writes), and whether their outputs are byte-identical to the baseline's
+        snp = IO.snp_out_path(p)
+        want_cl, want_snp = open(p + ".clusters", "rb").read(), open(snp, "rb").read()
+        # the drop-in executables of this repo on the very same files, end to end (process start, file reads, upload, kernels,
+        # tail, file writes), and whether their outputs are byte-identical to the baseline's
         try:
             e2c, c2s = os.path.join(ROOT, "bin", "ebwt2clust"), os.path.join(ROOT, "bin", "clust2snp")
             if os.path.exists(e2c) and os.path.exists(c2s):
-                snp = IO.snp_out_path(p)
-                want_cl, want_snp = open(p + ".clusters", "rb").read(), open(snp, "rb").read()
                 os.remove(p + ".clusters"); os.remove(snp)
                 u0 = time.time()
                 r1 = subprocess.run([e2c, "-i", p], capture_output=True)
@@ -241,63 +236,188 @@ def cpu_baseline(blk, reads, n1, sample_entries):
                                   "clusters_bytes": len(want_cl), "snp_bytes": len(want_snp)}
         except Exception as ex:
             res["drop_in"] = {"error": repr(ex)}
-        # ... and the library pipeline exactly as the timed steps run it (pre-filter inside the scan kernel, packed candidates in
-        # pinned memory) on the same sample, finished by the host tail: `.clusters` and `.snp` bytes against the baseline's
+        # ... and the resident job exactly as the timed steps run it, on the same sample: both images against the baseline's bytes
         try:
-            want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
             sub = {k2: blk[k2][:n].clone() for k2 in ("bwt", "lcp", "pos", "da")}
             sub["lcp"][-1] = 0
+            rd = reads.to(dev).contiguous()
+            L = rd.shape[1]
             torch.cuda.synchronize()                                # (the handle's stream is not ordered after torch's)
-            h = capi.Handle(blk["lcp"].device.index or 0)
+            h = capi.Handle(dev.index or 0)
+            h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
             h.attach_soa(capi.Handle.desc(n), sub["bwt"].data_ptr(), sub["lcp"].data_ptr(), sub["pos"].data_ptr(), sub["da"].data_ptr(),
                          keep=tuple(sub.values()))
-            same, secs, nc = True, {}, 0
-            for mode in ("arm", "begin", "inside"):                 # pre-filter inside the scan kernel / after the scan / inside find_candidates
+            same, secs, r = True, {}, {}
+            for mode in ("pre-filter inside the scan kernel", "pre-filter after the scan"):
                 u0 = time.time()
-                if mode == "arm":
-                    h.prefilter_arm(5)
-                h.cluster_scan(16, 2, 0)
-                if mode == "begin":
-                    h.prefilter_begin(5, 2)
-                h.stitch([h.boundary()], 0)
-                got_cl = h.fetch_clusters().tobytes()
-                mcl, _, _ = capi.auto_max_clust_length([h.hist()], 5, 0.99)
-                h.find_candidates(capi.C2SParams(n1, 31, 30, 5, 20, mcl, 2), 0)
-                stream, off8, nc, pw = h.candidates_packed()
-                out_snp = os.path.join(d, "library_%s.snp" % mode)
-                capi.snp_from_packed(stream, off8, nc, p, out_snp, pos_bytes=pw)
-                secs[mode] = round(time.time() - u0, 3)
-                same = same and got_cl == want_cl and open(out_snp, "rb").read() == want_snp
-            res["library_pipeline"] = {"what": "attach -> [arm] -> scan -> [begin] -> stitch -> statistics -> candidates -> host tail on the same sample "
-                                               "(resident EGSA), the three ways of running the pre-filter",
-                                       "seconds": secs, "candidates": int(nc), "outputs_identical": bool(same)}
+                r = pipeline.resident_job(h, n1, n, fused=mode.startswith("pre-filter inside"))
+                got_cl, got_snp = h.fetch_clusters().tobytes(), h.fetch_snp().tobytes()
+                secs[mode] = round(time.time() - u0, 4)
+                same = same and got_cl == want_cl and got_snp == want_snp
+            res["resident_job"] = {"what": "the timed step on the same sample (EGSA and reads resident), both images copied out and compared",
+                                   "seconds_incl_copy_out": secs, "candidates": int(r.get("n_cand", 0)), "events": int(r.get("n_events", 0)),
+                                   "outputs_identical": bool(same)}
             h.close()
         except Exception as ex:
-            res["library_pipeline"] = {"error": repr(ex)}
+            res["resident_job"] = {"error": repr(ex)}
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-PMC_FILES = {"c2": "profiles/round1_fused_pmc_traffic.json", "c3": "profiles/round1_fused_c3_pmc_traffic.json"}
-PMC_FILE = PMC_FILES["c2"]
-
-
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE; collected by
-    tools/profile.sh in separate --pmc runs of this same command, summarised by tools/profile_summary.py).  None when the
-    committed profile is of another workload -- counters cannot be read from inside the timed run."""
-    try:
-        j = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILES.get(workload, PMC_FILE))))
-        if j.get("workload") != workload:
-            return None
-        names = (kernel,) if isinstance(kernel, str) else kernel
-        for k2, v in j["kernels"].items():
-            if k2.replace(" ", "") in [x.replace(" ", "") for x in names]:
-                return float(v["hbm_bytes_per_launch"])
-        return None
-    except Exception:
-        return None
+    tools/profile.sh in separate --pmc runs of this same command, summarised by tools/profile_summary.py).  None when no
+    committed profile covers the workload -- counters cannot be read from inside the timed run."""
+    for rnd in ("round2", "round1"):
+        for name in ("%s_%s_pmc_traffic.json" % (rnd, workload), "%s_fused_%s_pmc_traffic.json" % (rnd, workload),
+                     "%s_fused_pmc_traffic.json" % rnd):
+            try:
+                j = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if j.get("workload") != workload:
+                    continue
+                names = [x.replace(" ", "") for x in ((kernel,) if isinstance(kernel, str) else kernel)]
+                for k2, v in j["kernels"].items():
+                    if k2.replace(" ", "") in names:
+                        return float(v["hbm_bytes_per_launch"]), "profiles/" + name
+            except Exception:
+                pass
+    return None, None
+
+
+def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scaling, with_cpu):
+    """build the workload, attach it, time W + K steps (+ the other mode, + outputs to host); returns the result dict on rank 0"""
+    R, L = WORKLOADS[name][:2]
+    copies = WORKLOADS[name][2] if len(WORKLOADS[name]) > 2 else 1
+    t0 = time.time()
+    if REHEARSAL and dist is not None:
+        # every rank lives on ONE GPU here: build in turns (four concurrent 2x10^8-entry sorts on one device stalled for minutes)
+        for turn in range(world):
+            if turn == rank:
+                reads, n1_block, blk0 = build_block(R, L, dev)
+                torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        reads, n1_block, blk0 = build_block(R, L, dev)
+    blk, n1 = tile_block(blk0, n1_block, copies)
+    m = blk["lcp"].numel()
+    if world == 1:
+        arrs, g0, n_own, hl, hr, n_total = blk, 0, m, 0, 0, m      # (no copy)
+    elif scaling == "strong":
+        arrs, g0, n_own, hl, hr = shard_strong(blk, m, rank, world)
+        n_total = m
+    else:
+        arrs, g0, n_own, hl, hr = shard_weak(blk, m, rank, world)
+        n_total = m * world
+    rd = tile_reads(reads.to(dev), n1_block, copies)               # dense [reads][L] matrix: read r at r * L
+    if world > 1:
+        del blk
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+
+    h = capi.Handle(local)
+    h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
+    d = capi.Handle.desc(n_total, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr)
+    h.attach_soa(d, arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(), arrs["pos"].data_ptr(), arrs["da"].data_ptr(), keep=tuple(arrs.values()))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(fused, n_warm, n_steps, on_host=False):
+        """W untimed + K timed steps of the whole job, bracketed by barrier + synchronize; max over ranks"""
+        info = None
+        for _ in range(n_warm):
+            info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host)
+        r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[], tail_ms=[])
+        barrier()
+        PHASES.clear()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host)
+            tm = h.timing()
+            r["scan_ms"].append(tm.scan_main_ms); r["cand_ms"].append(tm.cand_main_ms); r["scan_all_ms"].append(tm.scan_ms)
+            r["hist_ms"].append(tm.hist_ms); r["tail_ms"].append(tm.tail_ms)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            rdev = torch.device("cpu") if REHEARSAL else dev
+            t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        r.update(elapsed=elapsed, info=info, phases=dict(PHASES), steps=n_steps)
+        return r
+
+    prim = measure(True, warmup, steps)
+    other = measure(False, min(warmup, 2) + 1, max(3, steps // 2)) if SECOND_LEG else None
+    host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True)
+    info = prim["info"]
+    keys = ("n_ends", "n_cand", "mcl", "n_events", "snp_bytes", "n_records")
+    if other is not None:
+        assert tuple(other["info"][k2] for k2 in keys) == tuple(info[k2] for k2 in keys), "the two modes differ"
+    tot = {}
+    for k2 in ("n_ends", "n_cand", "n_events", "snp_bytes", "n_records"):
+        v = int(info.get(k2, 0))
+        if dist is not None:
+            rdev = torch.device("cpu") if REHEARSAL else dev
+            t = torch.tensor([v], dtype=torch.int64, device=rdev)
+            dist.all_reduce(t)
+            v = int(t.item())
+        tot[k2] = v
+    out = None
+    if rank == 0:
+        ref_pattern_bytes = n_own * 7 + info["n_ends"] * 10         # SURVEY 8d: the reference touches all four fields of every entry
+
+        def roof(kernel, nbytes, ms, note=None):
+            g = nbytes / (ms * 1e-3) / 1e9
+            tr, src = pmc_traffic(name, kernel)
+            o = {"bound": "hbm", "kernel": kernel if isinstance(kernel, str) else kernel[-1], "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": g / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "launch_ms": ms, "algorithmic_bytes": nbytes}
+            if note:
+                o["note"] = note
+            return o
+
+        fused_ms = float(np.mean(prim["scan_ms"]))
+        fused_bytes = n_own * 2 + info["n_ends"] * 10
+        res = {
+            "value": n_total * steps / prim["elapsed"], "ms_per_step": prim["elapsed"] / steps * 1e3,
+            "config": {"workload": "%s: %s2x%d reads x %dbp synthetic EGSA%s, %d entries/GPU, BCR widths 1/4/1"
+                                   % (name, ("%d copies of " % copies) if copies > 1 else "", R, L, "" if scaling == "strong" or world == 1 else " per GPU",
+                                      n_own), "entries_total": n_total, "k": 16, "min_len": 2, "parallelism": "sa-range x%d (%s)" % (world, scaling),
+                       "cluster_records": tot["n_ends"], "clusters_file_records": tot["n_records"], "candidates": tot["n_cand"],
+                       "snp_events": tot["n_events"], "snp_bytes": tot["snp_bytes"], "max_clust_length": info["mcl"],
+                       "input_build_s": round(t_build, 2),
+                       "step": "arm -> scan+pre-filter -> stitch -> statistics -> .clusters image (2nd stream) || candidates -> GPU tail -> .snp image; inputs and outputs in HBM",
+                       "host_phase_ms": {k2: round(v / steps * 1e3, 4) for k2, v in prim["phases"].items()}},
+            # the dominant kernel of the timed step.  Algorithmic bytes (DESIGN.md section 4): LCP 1 + BWT 1 per entry read once, 10 B per record
+            # written.  SURVEY 8d prices the reference's access pattern (7 B/entry + 10 B/record); this design never reads DA / pos for
+            # the 99.7 % of clusters its pre-filter rejects, so against THAT figure the kernel would read 'frac_vs_survey_bytes' > 1
+            "roofline": roof("k_scan_seg<1,true>", fused_bytes, fused_ms),
+            "value_outputs_on_host": n_total * host["steps"] / host["elapsed"],
+            "tail_ms": float(np.mean(prim["tail_ms"])),
+        }
+        res["roofline"].update({"survey_8d_bytes": ref_pattern_bytes + n_own, "frac_vs_survey_bytes": (ref_pattern_bytes + n_own) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "frac_uses": "algorithmic_bytes (2 B/entry + 10 B/record)", "hist_ms": float(np.mean(prim["hist_ms"]))})
+        res["config"]["outputs_on_host_phase_ms"] = {k2: round(v / host["steps"] * 1e3, 4) for k2, v in host["phases"].items()}
+        if other is not None:
+            scan_ms, pf_ms = float(np.mean(other["scan_ms"])), float(np.mean(other["cand_ms"]))
+            # the north-star kernel -- ebwt2clust's scan alone -- and the pre-filter as a kernel of its own
+            res["roofline_scan"] = roof(("k_scan_seg<1>", "k_scan_seg<1,false>"), n_own * 1 + info["n_ends"] * 10, scan_ms,
+                                        "ebwt2clust's scan alone (1 B/entry + 10 B/record; SURVEY 8d K1 figure), measured in the separate-kernels leg")
+            res["roofline_prefilter"] = roof("k_cluster_filter2", n_own * 2, pf_ms)
+            res["other_mode"] = {"mode": "separate kernels: scan, then pre-filter (e2s_prefilter_begin)", "value": n_total * other["steps"] / other["elapsed"],
+                                 "ms_per_step": other["elapsed"] / other["steps"] * 1e3}
+        if with_cpu and world == 1 and a.cpu_sample > 0:
+            try:
+                res["cpu_baseline"] = cpu_baseline(blk0, reads, n1_block, a.cpu_sample, dev)
+            except Exception as ex:           # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "EGSA entries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+        out = res
+    h.close()
+    del arrs, rd, blk0
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -305,8 +425,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample", type=int, default=100000000, help="entries of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--second-workload", default="c2", help="a second, shorter leg on this workload ('' = none; N = 1 only)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -322,11 +444,11 @@ def main():
     if world > 1 or (FORCE_DIST and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")    # the small all-gather runs beside the pre-filter kernel
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if REHEARSAL:
             local = 0
             import faulthandler
-            faulthandler.dump_traceback_later(600, exit=True)     # a rehearsal that stalls says where
+            faulthandler.dump_traceback_later(900, exit=True)     # a rehearsal that stalls says where
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the box's hostname may not resolve
             dist.init_process_group("gloo")
         else:
@@ -335,132 +457,35 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    R, L = WORKLOADS[a.workload][:2]
-    copies = WORKLOADS[a.workload][2] if len(WORKLOADS[a.workload]) > 2 else 1
-    t0 = time.time()
-    reads, n1_block, blk0 = build_block(R, L, dev)
-    blk, n1 = tile_block(blk0, n1_block, copies)
-    m = blk["lcp"].numel()
-    arrs, g0, n_own, hl, hr = shard_arrays(blk, m, rank, world)
-    torch.cuda.synchronize()
-    t_build = time.time() - t0
-    n_total = m * world
-
-    h = capi.Handle(local)
-    d = capi.Handle.desc(n_total, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr)
-    h.attach_soa(d, arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(), arrs["pos"].data_ptr(), arrs["da"].data_ptr(),
-                 keep=tuple(arrs.values()))
-    prm_base = dict(n1=n1, m=5)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def measure(overlap, warmup):
-        """W untimed + K timed steps of the whole job, bracketed by barrier + synchronize; max over ranks"""
-        info = None
-        for _ in range(warmup):
-            info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total, overlap=overlap)
-        r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[])
-        barrier()
-        PHASES.clear()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            info = run_step(h, prm_base, world, rank, dist, dev, n_total=n_total, overlap=overlap)
-            tm = h.timing()
-            r["scan_ms"].append(tm.scan_main_ms); r["cand_ms"].append(tm.cand_main_ms); r["scan_all_ms"].append(tm.scan_ms); r["hist_ms"].append(tm.hist_ms)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            rdev = torch.device("cpu") if REHEARSAL else dev
-            t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        r.update(elapsed=elapsed, info=info, phases=dict(PHASES))
-        return r
-
-    # the timed run `value` comes from, then -- reported beside it, never as `value` -- the same job in the other mode
-    # (pre-filter inside the scan kernel / the two kernels apart, each against its own roofline)
-    # auto: the pre-filter goes inside the scan kernel unless there is an exchange to hide behind it AND the shard is small
-    # enough for that to matter (c2-size shards, N > 1: 0.37 against 0.38 ms per job; c3-size: the fusion's 0.4 ms win)
-    global OVERLAP
-    OVERLAP = (dist is None or n_own >= 10 ** 9) if OVERLAP == "auto" else (OVERLAP == "1")
-    prim = measure(OVERLAP, a.warmup)
-    other = measure(not OVERLAP, min(a.warmup, 2) + 1) if (FUSED and SECOND_LEG) else None
-    info = prim["info"]
-    if other is not None:
-        oi = other["info"]
-        assert (oi["n_ends"], oi["n_cand"], oi["mcl"]) == (info["n_ends"], info["n_cand"], info["mcl"]), "the two modes differ"
-    if dist is not None:
-        rdev = torch.device("cpu") if REHEARSAL else dev
-        cnt = torch.tensor([info["n_ends"], info["n_cand"]], dtype=torch.int64, device=rdev)
-        dist.all_reduce(cnt)
-        tot_ends, tot_cand = int(cnt[0].item()), int(cnt[1].item())
-    else:
-        tot_ends, tot_cand = info["n_ends"], info["n_cand"]
-
+    res = measure_workload(a, a.workload, world, rank, local, dist, dev, a.steps, a.warmup, a.scaling, with_cpu=False)
+    second = None
+    if world == 1 and a.second_workload and a.second_workload != a.workload and a.second_workload in WORKLOADS:
+        second = measure_workload(a, a.second_workload, world, rank, local, dist, dev, a.steps, a.warmup, "weak", with_cpu=True)
+    elif world == 1 and a.cpu_sample > 0:
+        second = None
+        R, L = WORKLOADS[a.workload][:2]
+        reads, n1_block, blk0 = build_block(R, L, dev)
+        try:
+            res["cpu_baseline"] = cpu_baseline(blk0, reads, n1_block, a.cpu_sample, dev)
+        except Exception as ex:
+            res["cpu_baseline"] = {"value": None, "unit": "EGSA entries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
     if rank == 0:
-        ref_pattern_bytes = n_own * 7 + info["n_ends"] * 10
-
-        def rooflines(r, overlap):
-            """roofline objects of one mode.  Algorithmic bytes per launch:
-            pre-filter fused into the scan (k_scan_seg<1,true>): LCP 1 + BWT 1 per provided entry read once, 10 B per record written;
-            apart: the scan (k_scan_seg<1,false>) LCP 1 B/entry + 10 B/record, the pre-filter (k_cluster_filter2) LCP 1 + BWT 1 B/entry.
-            SURVEY 8d's figure for the reference's access pattern (7 B/entry + 10 B/record) is reported as reference_pattern_bytes."""
-            scan_avg = float(np.mean(r["scan_ms"]))
-            if overlap and FUSED:
-                fb = n_own * 2 + info["n_ends"] * 10
-                fg = fb / (scan_avg * 1e-3) / 1e9
-                tr = pmc_traffic(a.workload, "k_scan_seg<1,true>")
-                return {"roofline": {"bound": "hbm", "kernel": "k_scan_seg<1,true> (cluster scan + per-cluster pre-filter in one pass)", "achieved": fg,
-                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fg / HBM_PEAK_GBS, "traffic": tr, "launch_ms": scan_avg,
-                                     "algorithmic_bytes": fb, "reference_pattern_bytes": ref_pattern_bytes + n_own,
-                                     "traffic_source": PMC_FILES.get(a.workload) if tr else None, "hist_ms": float(np.mean(r["hist_ms"]))}}
-            cand_avg = float(np.mean(r["cand_ms"]))
-            cand_bytes = n_own * 2
-            cand_gbs = cand_bytes / (cand_avg * 1e-3) / 1e9
-            scan_bytes = n_own * 1 + info["n_ends"] * 10
-            scan_gbs = scan_bytes / (scan_avg * 1e-3) / 1e9
-            k2_traffic, k1_traffic = pmc_traffic(a.workload, "k_cluster_filter2"), pmc_traffic(a.workload, ("k_scan_seg<1>", "k_scan_seg<1,false>"))
-            return {"roofline": {"bound": "hbm", "kernel": "k_cluster_filter2", "achieved": cand_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": cand_gbs / HBM_PEAK_GBS, "traffic": k2_traffic, "launch_ms": cand_avg, "algorithmic_bytes": cand_bytes,
-                                 "reference_pattern_bytes": ref_pattern_bytes, "traffic_source": PMC_FILES.get(a.workload) if k2_traffic else None},
-                    "roofline_scan": {"bound": "hbm", "kernel": "k_scan_seg<1,false>", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": scan_gbs / HBM_PEAK_GBS, "traffic": k1_traffic, "launch_ms": scan_avg,
-                                      "algorithmic_bytes": scan_bytes, "scan_all_kernels_ms": float(np.mean(r["scan_all_ms"])),
-                                      "hist_ms": float(np.mean(r["hist_ms"]))}}
-
-        def mode_name(overlap):
-            if not overlap:
-                return "separate kernels (E2S_BENCH_OVERLAP=0): scan, then pre-filter"
-            return ("pre-filter inside the scan kernel (e2s_prefilter_arm)" if FUSED
-                    else "pre-filter beside the scan on a second stream (E2S_FUSED=0; per-kernel times include the sharing)")
-
-        elapsed = prim["elapsed"]
-        out = {
-            "metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": n_total * a.steps / elapsed, "unit": "EGSA entries/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %s2x%d reads x %dbp synthetic EGSA per GPU, %d entries/GPU, BCR widths 1/4/1"
-                                   % (a.workload, ("%d copies of " % copies) if copies > 1 else "", R, L, m), "entries_total": n_total, "k": 16, "min_len": 2,
-                       "parallelism": "sa-range x%d" % world, "cluster_records": tot_ends, "candidates": tot_cand,
-                       "max_clust_length": info["mcl"], "input_build_s": round(t_build, 2), "mode": mode_name(OVERLAP),
-                       "host_phase_ms": {k2: round(v / a.steps * 1e3, 4) for k2, v in prim["phases"].items()}},
-        }
-        out.update(rooflines(prim, OVERLAP))
-        if other is not None:
-            om = {"mode": mode_name(not OVERLAP), "value": n_total * a.steps / other["elapsed"], "unit": "EGSA entries/s",
-                  "ms_per_step": other["elapsed"] / a.steps * 1e3}
-            om.update(rooflines(other, not OVERLAP))
-            out["other_mode"] = om
-        if world == 1 and a.cpu_sample > 0:
-            try:
-                out["cpu_baseline"] = cpu_baseline(blk0, reads, n1_block, a.cpu_sample)
-            except Exception as ex:           # the baseline must never take the GPU number down with it
-                out["cpu_baseline"] = {"value": None, "unit": "EGSA entries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (ex,)}
+        out = {"metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": res["value"], "unit": "EGSA entries/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+               "scaling": a.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+        out.update({k2: v for k2, v in res.items() if k2 not in ("value", "ms_per_step")})
+        if second is not None:
+            cb = second.pop("cpu_baseline", None)
+            if cb is not None:
+                # the CPU baseline and the end-to-end executables run on a 10^8-entry sample of the second workload's EGSA (100-bp reads)
+                out["cpu_baseline"] = cb
+            out["second_workload"] = second
+        cb = out.get("cpu_baseline") or {}
+        out["value_end_to_end"] = (cb.get("drop_in") or {}).get("value")
+        out["value_definitions"] = {"value": "the step with inputs and BOTH output images resident in HBM",
+                                    "value_outputs_on_host": "the same step plus both images copied to host memory (PCIe on the way out)",
+                                    "value_end_to_end": "bin/ebwt2clust + bin/clust2snp through files on the cpu_baseline sample (process start, file I/O, PCIe both ways)"}
         print(json.dumps(out))
-    h.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -82,7 +82,7 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize",
-           "e2s_upload_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp"]
+           "e2s_pack_clusters", "e2s_clusters_image", "e2s_upload_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_renumber_snp", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp"]
 
 _lib = None
 
@@ -132,10 +132,13 @@ def lib():
                                         C.POINTER(C.c_uint32)]
     L.e2s_snp_from_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(TailParams), C.c_char_p, C.c_char_p,
                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_pack_clusters.argtypes = [H, C.c_int]
+    L.e2s_clusters_image.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.e2s_upload_reads.argtypes = [H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
     L.e2s_attach_reads.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
     L.e2s_upload_reads_fasta.argtypes = [H, C.c_char_p, C.POINTER(C.c_uint64)]
     L.e2s_call_variants.argtypes = [H, C.POINTER(TailParams), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.e2s_renumber_snp.argtypes = [H, C.c_uint64, C.POINTER(C.c_uint64)]
     L.e2s_fetch_snp.argtypes = [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.e2s_stream_snp.argtypes = [H, BYTE_SINK, C.c_void_p]
     L.e2s_write_snp.argtypes = [H, C.POINTER(TailParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -233,6 +236,16 @@ class Handle:
         buf = np.zeros(max(n.value, 1) * 10, dtype=np.uint8)
         self._ck(self.L.e2s_fetch_clusters(self.h, _ptr(buf), n.value, C.byref(n)))
         return buf[:n.value * 10]
+
+    def pack_clusters(self, async_=False):
+        """build the `.clusters` image in HBM (async_: on the second stream, beside the per-cluster pass)"""
+        self._ck(self.L.e2s_pack_clusters(self.h, 1 if async_ else 0))
+
+    def clusters_image(self):
+        """(device pointer of the image, records): waits for a pack in flight"""
+        p, n = C.c_void_p(), C.c_uint64(0)
+        self._ck(self.L.e2s_clusters_image(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def stream_clusters(self, sink):
         """the `.clusters` bytes handed to sink(bytes) chunk by chunk (whole records, file order); sink returns None / 0 to go on,
@@ -333,6 +346,11 @@ class Handle:
         nv, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         self._ck(self.L.e2s_call_variants(self.h, C.byref(p), first_id, C.byref(nv), C.byref(ne), C.byref(nb)))
         return nv.value, ne.value, nb.value
+
+    def renumber_snp(self, first_id):
+        nb = C.c_uint64(0)
+        self._ck(self.L.e2s_renumber_snp(self.h, first_id, C.byref(nb)))
+        return nb.value
 
     def fetch_snp(self):
         n = C.c_uint64(0)

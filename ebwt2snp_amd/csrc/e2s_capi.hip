@@ -63,7 +63,8 @@ struct e2s_ctx {
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr;           // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
-    uint8_t* d_img = nullptr; uint8_t* d_img_scratch = nullptr; uint64_t img_cap = 0;     // `.clusters` image (e2s_stream_clusters)
+    uint8_t* d_img = nullptr; uint8_t* d_img_scratch = nullptr; uint64_t img_cap = 0;     // `.clusters` image (e2s_pack_clusters, e2s_stream_clusters)
+    bool img_valid = false, img_pending = false; uint64_t img_records = 0; hipEvent_t ev_img = nullptr;
     uint8_t* pin_io[2] = {nullptr, nullptr}; uint64_t pin_io_cap = 0; hipEvent_t ev_io[2] = {nullptr, nullptr};
     int scan_start_ev = 0; bool pf_fused = false;                // which event began the last scan; the in-flight pre-filter ran inside it
     bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
@@ -197,6 +198,8 @@ static void release_shard(e2s_ctx* h) {
     for (void* p : h->owned) hipFree(p);
     h->owned.clear();
     h->bwt = nullptr; h->lcp = h->pos = h->da = nullptr;
+    if (h->img_pending && h->ev_img) hipEventSynchronize(h->ev_img);
+    h->img_valid = h->img_pending = false;
     h->have_shard = false; h->attached = false; h->scanned = h->stitched = false; h->records_from_file = false; h->raw_stats_valid = false;
     h->tail_bwt_given = false; h->last_known = false;
 }
@@ -222,6 +225,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     for (auto& e : h->ev_io) if (e) hipEventDestroy(e);
     if (h->ev_wait) hipEventDestroy(h->ev_wait);
     if (h->ev_pf) hipEventDestroy(h->ev_pf);
+    if (h->ev_img) hipEventDestroy(h->ev_img);
     for (auto& e : h->ev_chunk) if (e) hipEventDestroy(e);
     if (h->stream2) hipStreamDestroy(h->stream2);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -462,6 +466,8 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     const e2s_shard_desc& d = h->d;
     h->k = k; h->min_len = min_len;
     h->scanned = h->stitched = false; h->records_from_file = false; h->compact_valid = false;
+    if (h->img_pending) hipEventSynchronize(h->ev_img);
+    h->img_valid = h->img_pending = false;
     drop_prefilter(h);                                          // (a result of an earlier scan: other k, other data)
     ++h->scan_gen;
 
@@ -734,6 +740,8 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
     h->plan = pl;
     h->stitched = true;
+    if (h->img_pending) hipEventSynchronize(h->ev_img);
+    h->img_valid = h->img_pending = false;
     return E2S_OK;
 }
 
@@ -751,30 +759,78 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
     return E2S_OK;
 }
 
-// The `.clusters` image (append_entry's filter applied, 10 bytes per record) is packed on the GPU and leaves through two
-// pinned staging buffers: the copy of one chunk runs while the sink consumes the previous one.
-static int pack_image(e2s_ctx* h, uint64_t* n_records) {
-    *n_records = 0;
-    if (!h->n_rec) return E2S_OK;
-    const uint64_t* ds; const uint16_t* dl;
-    int rc = records_contiguous(h, &ds, &dl);
-    if (rc) return rc;
-    const uint64_t nb = e2s_pack_clusters_blocks(h->n_rec);
+// The `.clusters` image (append_entry's filter applied, 10 bytes per record) is packed on the GPU -- straight from the scan's
+// segments (k_pack_seg_*), or from contiguous records loaded from a file -- and leaves through two pinned staging buffers: the
+// copy of one chunk runs while the sink consumes the previous one.  The pack can run on the handle's second stream beside the
+// per-cluster pass (e2s_pack_clusters with async != 0): it is bandwidth bound, that pass latency bound.
+static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
+    h->img_valid = false; h->img_pending = false; h->img_records = 0;
+    if (!h->n_rec) { h->img_valid = true; return E2S_OK; }
     if (h->n_rec > h->img_cap) {
         hipFree(h->d_img); hipFree(h->d_img_scratch); h->d_img = nullptr; h->d_img_scratch = nullptr; h->img_cap = 0;
-        CK(hipMalloc((void**)&h->d_img, h->n_rec * 10 + 16));
-        CK(hipMalloc((void**)&h->d_img_scratch, nb * 12 + 64));
-        h->img_cap = h->n_rec;
+        const uint64_t cap = h->n_rec + h->n_rec / 8 + 4096;
+        CK(hipMalloc((void**)&h->d_img, cap * 10 + 16));
+        CK(hipMalloc((void**)&h->d_img_scratch, std::max<uint64_t>(e2s_pack_clusters_blocks(cap) * 12 + 64, (uint64_t)(8192 + 2) * 12 + 64)));
+        h->img_cap = cap;
     }
-    uint64_t* prefix = (uint64_t*)h->d_img_scratch;
-    uint32_t* cnt = (uint32_t*)(prefix + nb + 1);
-    e2s_launch_pack_clusters((const unsigned long long*)ds, dl, h->n_rec, h->min_len, cnt, (unsigned long long*)prefix, h->d_img,
-                             (unsigned long long*)(h->d_scalars + 220), h->stream);
-    LCHK("e2s_launch_pack_clusters");
-    uint64_t* mb = (uint64_t*)(h->pin_mail + 3080);
-    CK(hipMemcpyAsync(mb, h->d_scalars + 220, 8, hipMemcpyDeviceToHost, h->stream));
-    CK(hipStreamSynchronize(h->stream));
-    *n_records = *mb;
+    if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
+    if (st != h->stream) {                                       // after everything that shaped the records (stitch patch) ...
+        CK(hipEventRecord(h->ev_img, h->stream));
+        CK(hipStreamWaitEvent(st, h->ev_img, 0));
+    }
+    if (h->segmented) {
+        uint64_t* off = (uint64_t*)h->d_img_scratch;             // [n_seg + 1] record offsets, then the kept counts
+        uint32_t* kept = (uint32_t*)(off + h->seg_blocks + 1);
+        e2s_launch_pack_segments((const unsigned long long*)h->d_starts, h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, kept,
+                                 (unsigned long long*)off, h->d_img, (unsigned long long*)(h->d_scalars + 220), h->stitched ? h->plan.n_tail : 0,
+                                 h->plan.tail_start[0], h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], st);
+        LCHK("e2s_launch_pack_segments");
+    } else {
+        const uint64_t nb = e2s_pack_clusters_blocks(h->n_rec);
+        uint64_t* prefix = (uint64_t*)h->d_img_scratch;
+        uint32_t* cnt = (uint32_t*)(prefix + nb + 1);
+        e2s_launch_pack_clusters((const unsigned long long*)h->d_starts, h->d_lens, h->n_rec, h->min_len, cnt, (unsigned long long*)prefix, h->d_img,
+                                 (unsigned long long*)(h->d_scalars + 220), st);
+        LCHK("e2s_launch_pack_clusters");
+    }
+    CK(hipMemcpyAsync(h->pin_mail + 3080, h->d_scalars + 220, 8, hipMemcpyDeviceToHost, st));
+    CK(hipEventRecord(h->ev_img, st));
+    h->img_pending = true;
+    return E2S_OK;
+}
+static int pack_image_finish(e2s_ctx* h, uint64_t* n_records) {
+    if (h->img_pending) {
+        CK(hipEventSynchronize(h->ev_img));
+        CK(hipGetLastError());
+        h->img_records = *(const uint64_t*)(h->pin_mail + 3080);
+        h->img_pending = false; h->img_valid = true;
+    }
+    if (n_records) *n_records = h->img_records;
+    return E2S_OK;
+}
+static int pack_image(e2s_ctx* h, uint64_t* n_records) {
+    if (!h->img_valid && !h->img_pending) { int rc = pack_image_launch(h, h->stream); if (rc) return rc; }
+    return pack_image_finish(h, n_records);
+}
+
+extern "C" int e2s_pack_clusters(e2s_handle h, int async) {
+    dbg_entry("e2s_pack_clusters");
+    if (!h) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
+    CK(hipSetDevice(h->device));
+    int rc = pack_image_launch(h, async ? h->stream2 : h->stream);
+    if (rc || async) return rc;
+    return pack_image_finish(h, nullptr);
+}
+
+extern "C" int e2s_clusters_image(e2s_handle h, const void** d_image, uint64_t* n_records) {
+    dbg_entry("e2s_clusters_image");
+    if (!h) return E2S_ERR_ARG;
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
+    CK(hipSetDevice(h->device));
+    int rc = pack_image(h, n_records);
+    if (rc) return rc;
+    if (d_image) *d_image = h->d_img;
     return E2S_OK;
 }
 
@@ -868,6 +924,8 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
     }
     h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;
     h->min_len = 0; h->segmented = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};
+    if (h->img_pending) hipEventSynchronize(h->ev_img);
+    h->img_valid = h->img_pending = false;
     h->wrap_ranks.clear(); h->wrap_overflow = false; h->first_wrapped = false;
     h->scanned = true; h->stitched = true; h->records_from_file = true;
     return E2S_OK;
@@ -1495,7 +1553,7 @@ extern "C" int e2s_candidates_packed(e2s_handle h, const void** stream, const ui
 // ---------------------------------------------------------------------------------------------
 extern "C" int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len) {
     dbg_entry("e2s_attach_reads");
-    if (!h || (n_reads && (!d_text || !d_start || !d_len))) return E2S_ERR_ARG;
+    if (!h || (n_reads && (!d_text || ((d_start == nullptr) != (d_len == nullptr)) || (!d_start && !max_len)))) return E2S_ERR_ARG;
     CK(hipSetDevice(h->device));
     release_reads(h);
     h->d_text = (uint8_t*)d_text; h->d_rstart = (uint64_t*)d_start; h->d_rlen = (uint32_t*)d_len;
@@ -1519,6 +1577,19 @@ extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_by
     CK(hipMemcpyAsync(h->d_rlen, len, n_reads * 4, hipMemcpyHostToDevice, h->stream));
     CK(hipStreamSynchronize(h->stream));
     h->n_reads = n_reads; h->reads_max_len = max_len; h->have_reads = true; h->variants_valid = false;
+    // reads of ONE length (what sequencers and the synthetic sets give) become a dense matrix: read r at r * len, no index arrays --
+    // every left context then costs one random access instead of three
+    bool uniform = max_len > 0;
+    for (uint64_t r = 0; r < n_reads && uniform; ++r) uniform = len[r] == max_len;
+    if (uniform) {
+        uint8_t* dense = nullptr;
+        CK(hipMalloc((void**)&dense, n_reads * (uint64_t)max_len + 256));
+        e2s_launch_reads_compact(h->d_text, h->d_rstart, max_len, n_reads, dense, h->stream);
+        LCHK("e2s_launch_reads_compact");
+        CK(hipStreamSynchronize(h->stream));
+        hipFree(h->d_text); hipFree(h->d_rstart); hipFree(h->d_rlen);
+        h->d_text = dense; h->d_rstart = nullptr; h->d_rlen = nullptr;
+    }
     return E2S_OK;
 }
 
@@ -1546,7 +1617,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     }
     if (ng + 1 > h->part_cap) {
         hipFree(h->d_part); h->d_part = nullptr; h->part_cap = 0;
-        CK(hipMalloc((void**)&h->d_part, (ng + 64) * 2 * 8 * 2 + 64));   // raw sums | exclusive prefixes
+        CK(hipMalloc((void**)&h->d_part, (ng + 64) * 5 * 8 + 64));       // raw sums (3 per group) | exclusive prefixes (2 per group)
         h->part_cap = ng + 63;
     }
     // the image is sized from a bound per event: two header lines (prefix, id, right length, type, support) and two DNA lines
@@ -1557,18 +1628,18 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
         CK(hipMalloc((void**)&h->d_snp, bound + bound / 8));
         h->snp_cap = bound + bound / 8;
     }
-    unsigned long long* part_raw = h->d_part; unsigned long long* part_excl = h->d_part + 2 * (h->part_cap + 1);
-    unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);       // events, bytes, kept, error bits | n_keep at +4
-    CK(hipMemsetAsync(part_raw, 0, ng * 16, h->stream));
+    unsigned long long* part_raw = h->d_part; unsigned long long* part_excl = h->d_part + 3 * (h->part_cap + 1);
+    unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);       // events, bytes, kept, error bits
+    CK(hipMemsetAsync(part_raw, 0, ng * 24, h->stream));
     CK(hipMemsetAsync(totals, 0, 48, h->stream));
     CK(hipMemsetAsync(h->d_words + 28, 0, 4, h->stream));
     TailArgs a{};
     a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
-    a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads;
+    a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len;
     a.kl = p->k_left; a.kr = p->k_right; a.max_gap = p->max_gap; a.max_err = p->max_err;
     a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = h->d_words + 28;
     CK(hipEventRecord(h->ev[2], h->stream));
-    e2s_launch_consensus(a, h->stream);
+    e2s_launch_consensus(a, h->list_cap, h->stream);
     LCHK("e2s_launch_consensus");
     e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, h->d_words + 28, h->stream);
     LCHK("e2s_launch_tail_partials");
@@ -1588,6 +1659,34 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     h->variants_valid = true; h->tail_p = *p; h->snp_first_id = first_id;
     if (n_variants) *n_variants = h->n_variants;
     if (n_events) *n_events = h->n_events;
+    if (snp_bytes) *snp_bytes = h->snp_bytes;
+    return E2S_OK;
+}
+
+extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_bytes) {
+    dbg_entry("e2s_renumber_snp");
+    if (!h) return E2S_ERR_ARG;
+    if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
+    CK(hipSetDevice(h->device));
+    if (first_id != h->snp_first_id) {                           // the text again with other ids: consensus and distance results stay
+        const uint64_t n = h->n_cand, ng = (n + 255) / 256;
+        unsigned long long* part_raw = h->d_part; unsigned long long* part_excl = h->d_part + 3 * (h->part_cap + 1);
+        unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);
+        TailArgs a{};
+        a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
+        a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len;
+        a.kl = h->tail_p.k_left; a.kr = h->tail_p.k_right; a.max_gap = h->tail_p.max_gap; a.max_err = h->tail_p.max_err;
+        a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = h->d_words + 28;
+        e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, h->d_words + 28, h->stream);
+        e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
+        LCHK("e2s_launch_tail_write");
+        uint64_t* mb = (uint64_t*)(h->pin_mail + 3200);
+        CK(hipMemcpyAsync(mb, totals, 32, hipMemcpyDeviceToHost, h->stream));
+        CK(wait_stream(h));
+        CK(hipGetLastError());
+        if (mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
+        h->snp_bytes = mb[1]; h->snp_first_id = first_id;
+    }
     if (snp_bytes) *snp_bytes = h->snp_bytes;
     return E2S_OK;
 }

@@ -145,6 +145,7 @@ struct TailRec {               // one per candidate, written by k_consensus
 struct TailArgs {
     const uint8_t* stream; const uint32_t* off8; uint64_t n_cand; uint32_t pos_pack;      // packed candidates in SA order (device memory)
     const uint8_t* text; const uint64_t* rstart; const uint32_t* rlen; uint64_t n_reads;  // the reads: read r = text[rstart[r] .. +rlen[r])
+    uint32_t stride;           // rstart == nullptr: every read is `stride` long and read r starts at r * stride (no index to look up)
     int kl, kr, max_gap, max_err;
     uint8_t* cons;             // [n_cand][2][64] consensus strings
     TailRec* rec;              // [n_cand]
@@ -152,9 +153,10 @@ struct TailArgs {
     unsigned long long* n_keep;
     uint32_t* err;
 };
-void e2s_launch_consensus(const TailArgs& a, hipStream_t st);
+void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st);
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, hipStream_t st);
+void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st);
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, uint8_t* out, unsigned long long out_cap,
                            hipStream_t st);
 
@@ -175,6 +177,9 @@ void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsig
 unsigned long long e2s_pack_clusters_blocks(unsigned long long n);
 void e2s_launch_pack_clusters(const unsigned long long* starts, const uint16_t* lens, unsigned long long n, int min_len, uint32_t* cnt,
                               unsigned long long* prefix, uint8_t* out, unsigned long long* total, hipStream_t st);
+void e2s_launch_pack_segments(const unsigned long long* starts, const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_seg, int min_len,
+                              uint32_t* kept, unsigned long long* off, uint8_t* out, unsigned long long* total, uint32_t n_tail, unsigned long long t0,
+                              uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st);
 #define E2S_WRAP_CAP 1024
 int  e2s_scan_seg_resident_blocks(int xb);
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st);

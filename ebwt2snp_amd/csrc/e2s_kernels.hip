@@ -797,6 +797,120 @@ __global__ __launch_bounds__(256) void k_pack_write(const u64* starts, const uin
     if (blockIdx.x == n_blocks - 1 && tid == 0) *total = prefix[blockIdx.x] + cnt[blockIdx.x];
 }
 
+// ---- the same image straight from the scan's segmented storage (no contiguous copy first): kept records per segment, a scan of
+// the <= 8192 counts, then every segment packs itself at its offset; the EOF tail records of the stitch plan follow the last one.
+__global__ __launch_bounds__(256) void k_pack_seg_count(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, int min_len, u32* kept) {
+    __shared__ u32 s_c;
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    const u32 b = blockIdx.x, n = desc[b].count;
+    const uint16_t* p = lens + (u64)b * seg_cap;
+    u32 c = 0;
+    const u32 nv = n >> 3;
+    for (u32 i = threadIdx.x; i < nv; i += 256u) {
+        const uint4 v = *(const uint4*)(p + 8u * i);
+        c += ((int)(v.x & 0xFFFFu) >= min_len) + ((int)(v.x >> 16) >= min_len) + ((int)(v.y & 0xFFFFu) >= min_len) + ((int)(v.y >> 16) >= min_len) +
+             ((int)(v.z & 0xFFFFu) >= min_len) + ((int)(v.z >> 16) >= min_len) + ((int)(v.w & 0xFFFFu) >= min_len) + ((int)(v.w >> 16) >= min_len);
+    }
+    const u32 r = (nv << 3) + threadIdx.x;
+    if (r < n && (int)p[r] >= min_len) ++c;
+    for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_c, c);
+    __syncthreads();
+    if (threadIdx.x == 0) kept[b] = s_c;
+}
+__global__ __launch_bounds__(1024) void k_pack_seg_scan(const u32* kept, u32 n_seg, u64* off, u32 n_tail_kept, u64* total) {
+    __shared__ u64 s_v[1024];
+    __shared__ u64 s_run;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (u32 g0 = 0; g0 < n_seg; g0 += 1024) {
+        const u32 g = g0 + tid;
+        const u64 v = g < n_seg ? (u64)kept[g] : 0ull;
+        s_v[tid] = v;
+        __syncthreads();
+        for (u32 d = 1; d < 1024; d <<= 1) { const u64 x = tid >= d ? s_v[tid - d] : 0ull; __syncthreads(); s_v[tid] += x; __syncthreads(); }
+        if (g < n_seg) off[g] = s_run + s_v[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_run += s_v[1023];
+        __syncthreads();
+    }
+    if (tid == 0) { off[n_seg] = s_run; *total = s_run + n_tail_kept; }
+}
+// One block per segment, 1024 records per trip.  Ranks come from ballots (a lane looks at ONE record, so the loads are
+// coalesced); the records are laid out in LDS at the image's own alignment (LDS offset = byte offset in the image mod 16), so the
+// image leaves in whole 16-byte units -- the first version wrote it 2 bytes per lane and took 4 ms for 1.07 GB.
+constexpr int PKS_REC = 1024;                                // records per trip (4 waves x 4 x 64)
+__global__ __launch_bounds__(256) void k_pack_seg_write(const u64* starts, const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len,
+                                                        const u64* off, uint8_t* out, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[PKS_REC * 10 + 32];
+    __shared__ u32 s_w[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 b = blockIdx.x, n = desc[b].count;
+    const u64* ps = starts + (u64)b * seg_cap;
+    const uint16_t* pl = lens + (u64)b * seg_cap;
+    u64 done = off[b];                                          // records of the image before the trip at hand
+    for (u32 c0 = 0; c0 < n; c0 += PKS_REC) {
+        // wave w looks at records c0 + 256 w + 64 q + lane, q = 0..3
+        u64 st[4]; u32 ln[4]; u32 keep[4]; u32 cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 i = c0 + 256u * wave + 64u * q + lane;
+            ln[q] = i < n ? (u32)pl[i] : 0u;
+            st[q] = i < n ? ps[i] : 0ull;
+            keep[q] = (i < n && (int)ln[q] >= min_len) ? 1u : 0u;
+            cnt += (u32)__popcll(__ballot(keep[q] != 0u));
+        }
+        if (lane == 0) s_w[wave] = cnt;
+        __syncthreads();
+        u32 r = 0;
+        for (u32 w = 0; w < wave; ++w) r += s_w[w];
+        const u32 m = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const u64 D = done * 10ull;                              // byte offset of the trip's first record in the image
+        const u32 sh = (u32)(D & 15ull);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u64 bm = __ballot(keep[q] != 0u);
+            if (keep[q]) {
+                const u32 rr = r + (u32)__popcll(bm & ((1ull << lane) - 1ull));
+                uint16_t* o = (uint16_t*)(s_img + sh + (size_t)rr * 10);
+                o[0] = (uint16_t)st[q]; o[1] = (uint16_t)(st[q] >> 16); o[2] = (uint16_t)(st[q] >> 32); o[3] = (uint16_t)(st[q] >> 48); o[4] = (uint16_t)ln[q];
+            }
+            r += (u32)__popcll(bm);
+        }
+        __syncthreads();
+        // the 16-byte units [D & ~15, ...) that the trip's bytes [D, D + 10 m) touch: whole units as one store, the two partial ones by 2 bytes
+        const u32 nbytes = m * 10u, units = (sh + nbytes + 15u) >> 4;
+        uint8_t* const g0 = out + (D & ~15ull);
+        for (u32 u = tid; u < units; u += 256u) {
+            const u32 lo = u << 4, hi = lo + 16u;
+            if (lo >= sh && hi <= sh + nbytes) *(uint4*)(g0 + lo) = *(const uint4*)(s_img + lo);
+            else for (u32 x = max(lo, sh); x < min(hi, sh + nbytes); x += 2u) *(uint16_t*)(g0 + x) = *(const uint16_t*)(s_img + x);
+        }
+        done += m;
+        __syncthreads();
+    }
+    if (b == n_seg - 1 && tid == 0) {                            // the records the EOF rule adds (e2s_stitch_plan)
+        u64 at = off[n_seg];
+        const u64 ts[2] = {t0, t1}; const uint16_t tl[2] = {l0, l1};
+        for (u32 t = 0; t < n_tail; ++t) if ((int)tl[t] >= min_len) {
+            uint16_t* o = (uint16_t*)(out + at * 10ull);
+            o[0] = (uint16_t)ts[t]; o[1] = (uint16_t)(ts[t] >> 16); o[2] = (uint16_t)(ts[t] >> 32); o[3] = (uint16_t)(ts[t] >> 48); o[4] = tl[t];
+            ++at;
+        }
+    }
+}
+void e2s_launch_pack_segments(const u64* starts, const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u32* kept, u64* off,
+                              uint8_t* out, u64* total, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1, hipStream_t st) {
+    u32 n_tail_kept = 0;
+    if (n_tail > 0 && (int)l0 >= min_len) ++n_tail_kept;
+    if (n_tail > 1 && (int)l1 >= min_len) ++n_tail_kept;
+    hipLaunchKernelGGL(k_pack_seg_count, dim3(n_seg), dim3(256), 0, st, lens, desc, seg_cap, min_len, kept);
+    hipLaunchKernelGGL(k_pack_seg_scan, dim3(1), dim3(1024), 0, st, kept, n_seg, off, n_tail_kept, total);
+    hipLaunchKernelGGL(k_pack_seg_write, dim3(n_seg), dim3(256), 0, st, starts, lens, desc, seg_cap, n_seg, min_len, off, out, n_tail, t0, l0, t1, l1);
+}
+
 __global__ void k_apply_plan(u64* starts, uint16_t* lens, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_ends, u32 n_tail,
                              u64 t0, uint16_t l0, u64 t1, uint16_t l1) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -37,11 +37,21 @@ __device__ __forceinline__ u32 tl_pos(const uint8_t* p, u32 pw, u32 j) {
 }  // namespace
 
 // ---- K3a ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_consensus(TailArgs a) {
+// One wave per candidate.  The work is a chain of dependent gathers (candidate record -> read index -> text), so nothing is
+// fetched one item at a time: lane j fetches list entry j and its read's start / length (one round trip for the whole list),
+// then the n x k_left characters of an allele's left contexts are gathered by all 64 lanes at once into LDS (rows of 64
+// bytes, 64 / kw rows per wave instruction, kw = k_left rounded up to a power of two), and consensus and supports run on LDS.
+// Dynamic LDS per wave: list_cap rows of 64 B + list_cap x (8 + 4) B of row bases / lengths.
+extern __shared__ __attribute__((aligned(16))) uint8_t s_tail[];
+__global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32 kw_shift) {
     __shared__ uint8_t s_ab[4][2][128];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
     const u64 c = (u64)blockIdx.x * 4 + wave;
     if (c >= a.n_cand) return;
+    const size_t per_wave = (size_t)list_cap * (64 + 8 + 4);
+    uint8_t* const ctx = s_tail + wave * per_wave;                  // [list_cap][64]
+    u64* const rbase = (u64*)(ctx + (size_t)list_cap * 64);         // text offset of row j's first character
+    u32* const rhave = (u32*)(rbase + list_cap);                    // characters of row j that exist (the rest read as 0)
     const uint8_t* r = a.stream + (size_t)a.off8[c] * 8;
     const u32* w = (const u32*)r;
     const u32 n0 = w[0], n1 = w[1], right_idx = w[2], right_pos = w[3];
@@ -50,19 +60,37 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a) {
     uint8_t* const sb = s_ab[wave][1];
     u32 supp[2] = {0u, 0u};
     u32 bad = 0;
+    const u32 kw = 1u << kw_shift, rows_per = 64u >> kw_shift, row_of = lane >> kw_shift, col = lane & (kw - 1u);
     for (int s = 0; s < 2; ++s) {
-        const u32 n = s ? n1 : n0;
+        const u32 n = min(s ? n1 : n0, list_cap);
         const u32* idx = s ? (w + 4 + n0) : (w + 4);
         const uint8_t* pp = r + 16 + 4 * (size_t)(n0 + n1) + (s ? (size_t)a.pos_pack * n0 : 0);
+        for (u32 j = lane; j < n; j += 64u) {                       // row bases: one round trip for the list, one for the reads' index
+            const u32 rd = idx[j];
+            u64 base = 0; u32 have = 0;
+            if ((u64)rd >= a.n_reads) bad |= E2S_TAILERR_RANK;
+            else {
+                const u32 len = a.rstart ? a.rlen[rd] : a.stride, p0 = tl_pos(pp, a.pos_pack, j);
+                have = p0 < len ? min(len - p0, kl) : 0u;
+                base = (a.rstart ? a.rstart[rd] : (u64)rd * a.stride) + p0;
+            }
+            rbase[j] = base; rhave[j] = have;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 j0 = 0; j0 < n; j0 += rows_per) {                  // the characters: every load of the allele in flight together
+            const u32 j = j0 + row_of;
+            if (j < n && col < 64u) {
+                const u32 have = rhave[j];
+                ctx[(size_t)j * 64 + col] = col < have ? a.text[rbase[j] + col] : (uint8_t)0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // cons (include.hpp:334-371), one lane per column: the letter changes only on a strictly larger count (H8)
         u32 C = 'A', k0 = 0, k1 = 0, k2 = 0, k3 = 0;
         for (u32 j = 0; j < n; ++j) {
-            const u32 rd = idx[j];
-            if ((u64)rd >= a.n_reads) { bad |= E2S_TAILERR_RANK; continue; }
-            const u64 base = a.rstart[rd]; const u32 len = a.rlen[rd];
-            const u32 p0 = tl_pos(pp, a.pos_pack, j);
-            const u32 have = p0 < len ? min(len - p0, kl) : 0u;
-            const u32 ch = lane < have ? (u32)a.text[base + p0 + lane] : 0u;
+            const u32 ch = lane < kl ? (u32)ctx[(size_t)j * 64 + lane] : 0u;
             const u32 b = tl_b2i(ch), bc = tl_b2i(C);
             k0 += b == 0u; k1 += b == 1u; k2 += b == 2u; k3 += b == 3u;
             const u32 nb = b == 0u ? k0 : b == 1u ? k1 : b == 2u ? k2 : k3;
@@ -71,19 +99,16 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a) {
         }
         // support = contexts within max_err of the consensus (clust2snp.cpp:544-593)
         for (u32 j = 0; j < n; ++j) {
-            const u32 rd = idx[j];
-            if ((u64)rd >= a.n_reads) continue;
-            const u64 base = a.rstart[rd]; const u32 len = a.rlen[rd];
-            const u32 p0 = tl_pos(pp, a.pos_pack, j);
-            const u32 have = p0 < len ? min(len - p0, kl) : 0u;
-            const u32 ch = lane < have ? (u32)a.text[base + p0 + lane] : 0u;
+            const u32 ch = lane < kl ? (u32)ctx[(size_t)j * 64 + lane] : 0u;
             const int d = __popcll(__ballot(lane < kl && C != ch));
             if (d <= a.max_err) ++supp[s];
         }
         (s ? sb : sa)[lane] = (uint8_t)C;
         (s ? sb : sa)[64 + lane] = 0;
         if (lane < kl) a.cons[c * 128 + (u64)s * 64 + lane] = (uint8_t)C;
+        __builtin_amdgcn_wave_barrier();
     }
+    bad = (u32)(__ballot(bad & E2S_TAILERR_RANK) ? E2S_TAILERR_RANK : 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool keep = supp[0] > 0u && supp[1] > 0u;                // clust2snp.cpp:595-611
@@ -114,12 +139,12 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a) {
     if (keep) {
         if ((u64)right_idx >= a.n_reads) bad |= E2S_TAILERR_RANK;
         else {
-            const u32 len = a.rlen[right_idx];
+            const u32 len = a.rstart ? a.rlen[right_idx] : a.stride;
             if (right_pos > len) bad |= E2S_TAILERR_CRASH;          // substr throws in the reference
             else {
                 const u32 avail = len - right_pos;
                 right_len = a.kr < 0 ? avail : min(avail, (u32)a.kr);
-                right_at = a.rstart[right_idx] + right_pos;
+                right_at = (a.rstart ? a.rstart[right_idx] : (u64)right_idx * a.stride) + right_pos;
             }
         }
     }
@@ -132,8 +157,9 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a) {
         TailRec t;
         t.emit = emit ? 1u : 0u; t.L = L; t.s0 = supp[0]; t.s1 = supp[1]; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
         a.rec[c] = t;
-        if (keep) atomicAdd(a.n_keep, 1ull);
-        if (emit) { atomicAdd(&a.part[2 * (c >> 8)], 1ull); atomicAdd(&a.part[2 * (c >> 8) + 1], (u64)t.base_len); }
+        // (per group of 256 candidates: one counter for the whole job saturates at ~90 atomics per microsecond -- 3 ms for 2.6x10^5 waves)
+        if (keep) atomicAdd(&a.part[3 * (c >> 8) + 2], 1ull);
+        if (emit) { atomicAdd(&a.part[3 * (c >> 8)], 1ull); atomicAdd(&a.part[3 * (c >> 8) + 1], (u64)t.base_len); }
         if (bad) atomicOr(a.err, bad);
     }
 }
@@ -143,13 +169,14 @@ __global__ __launch_bounds__(1024) void k_tail_partials(const unsigned long long
                                                         unsigned long long* totals /* events, bytes, kept, error bits */, const unsigned long long* n_keep,
                                                         const u32* err) {
     __shared__ u64 s_e[1024], s_b[1024];
-    __shared__ u64 run_e, run_b;
+    __shared__ u64 run_e, run_b, run_k;
     const u32 tid = threadIdx.x;
-    if (tid == 0) { run_e = 0; run_b = 0; }
+    if (tid == 0) { run_e = 0; run_b = 0; run_k = 0; }
     __syncthreads();
     for (u32 g0 = 0; g0 < ng; g0 += 1024) {
         const u32 g = g0 + tid;
-        const u64 e = g < ng ? part[2 * g] : 0ull, b = g < ng ? part[2 * g + 1] : 0ull;
+        const u64 e = g < ng ? part[3 * g] : 0ull, b = g < ng ? part[3 * g + 1] : 0ull;
+        if (g < ng && part[3 * g + 2]) atomicAdd((unsigned long long*)&run_k, part[3 * g + 2]);
         s_e[tid] = e; s_b[tid] = b;
         __syncthreads();
         for (u32 d = 1; d < 1024; d <<= 1) {
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(1024) void k_tail_partials(const unsigned long long
     if (tid == 0) {
         totals[0] = run_e;
         totals[1] = run_b + 2ull * (tl_digit_sum_below(first_id + run_e) - tl_digit_sum_below(first_id));
-        totals[2] = *n_keep;
+        totals[2] = run_k;
         totals[3] = (u64)*err;
     }
 }
@@ -179,36 +206,59 @@ __device__ __forceinline__ u32 tl_put_num(uint8_t* b, u32 at, u64 v) {
     return at + d;
 }
 
-__global__ __launch_bounds__(256) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, uint8_t* out, u64 out_cap) {
+// A block takes a group of 256 candidates (the unit of the scan): 256 threads rank its events, then its 16 waves write 16
+// candidates each -- an event is a chain of dependent steps (consensus letters -> header text -> stores), and short chains on
+// many waves are what hides their latency (four waves of 64 candidates each took 0.63 ms for 2.6x10^5 events).
+__global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, uint8_t* out, u64 out_cap) {
     __shared__ u32 s_we[4], s_wb[4];
-    __shared__ uint8_t s_hdr[4][2][128];
+    __shared__ u64 s_rank[256], s_off[256];
+    __shared__ TailRec s_rec[256];
+    __shared__ uint8_t s_hdr[16][2][128];
+    __shared__ uint8_t s_cab[16][2][64];
     const u32 tid = threadIdx.x, lane = tl_lane(), wave = tid >> 6;
-    const u64 g = blockIdx.x, c = g * 256 + tid;
-    TailRec t; t.emit = 0; t.base_len = 0; t.L = 0; t.s0 = t.s1 = t.right_len = 0; t.right_at = 0;
-    if (c < a.n_cand) t = a.rec[c];
-    // exclusive scan of (emit, base_len) inside the group: inside the wave by ballots / DPP-free shuffles, then across the four waves
-    const u64 em = __ballot(t.emit != 0u);
-    const u32 e_before = (u32)__popcll(em & ((1ull << lane) - 1ull));
-    u32 bl = t.emit ? t.base_len : 0u, incl = bl;
-    for (u32 d = 1; d < 64; d <<= 1) { const u32 v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-    if (lane == 63) { s_we[wave] = (u32)__popcll(em); s_wb[wave] = incl; }
+    const u64 g = blockIdx.x;
+    if (tid < 256) {
+        const u64 c = g * 256 + tid;
+        TailRec t; t.emit = 0; t.base_len = 0; t.L = 0; t.s0 = t.s1 = t.right_len = 0; t.right_at = 0;
+        if (c < a.n_cand) t = a.rec[c];
+        // exclusive scan of (emit, base_len) inside the group: inside the wave by ballot / shuffles, then across the four waves
+        const u64 em = __ballot(t.emit != 0u);
+        const u32 e_before = (u32)__popcll(em & ((1ull << lane) - 1ull));
+        const u32 bl = t.emit ? t.base_len : 0u;
+        u32 incl = bl;
+        for (u32 d = 1; d < 64; d <<= 1) { const u32 v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        if (lane == 63) { s_we[wave] = (u32)__popcll(em); s_wb[wave] = incl; }
+        s_rec[tid] = t;
+        s_rank[tid] = e_before; s_off[tid] = incl - bl;
+    }
     __syncthreads();
-    u32 we = 0, wb = 0;
-    for (u32 q = 0; q < wave; ++q) { we += s_we[q]; wb += s_wb[q]; }
-    const u64 rank = part_excl[2 * g] + we + e_before;              // events before this one
-    const u64 off = part_excl[2 * g + 1] + wb + (incl - bl) + 2ull * (tl_digit_sum_below(first_id + rank) - tl_digit_sum_below(first_id));
+    if (tid < 256) {
+        u32 we = 0, wb = 0;
+        for (u32 q = 0; q < wave; ++q) { we += s_we[q]; wb += s_wb[q]; }
+        const u64 rank = part_excl[2 * g] + we + s_rank[tid];       // events before this one
+        s_rank[tid] = rank;
+        s_off[tid] = part_excl[2 * g + 1] + wb + s_off[tid] + 2ull * (tl_digit_sum_below(first_id + rank) - tl_digit_sum_below(first_id));
+    }
+    __syncthreads();
     const u32 kl = (u32)a.kl;
     uint8_t* const h1 = s_hdr[wave][0];
     uint8_t* const h3 = s_hdr[wave][1];
-    // one event at a time per wave: its owner's fields broadcast, lane 0 builds the two header lines in LDS, every lane copies
-    for (u64 m = em; m; m &= m - 1) {
-        const int src = __ffsll((long long)m) - 1;
-        const u64 c2 = g * 256 + wave * 64 + (u64)src;
-        const int L = __shfl(t.L, src);
-        const u32 s0 = __shfl(t.s0, src), s1 = __shfl(t.s1, src), rl = __shfl(t.right_len, src);
-        const u64 rat = __shfl(t.right_at, src), o = __shfl(off, src), id = first_id + __shfl(rank, src);
+    uint8_t* const la = s_cab[wave][0];
+    uint8_t* const lb = s_cab[wave][1];
+    for (u32 k = 0; k < 16; ++k) {
+        const u32 ci = wave * 16 + k;
+        const TailRec t = s_rec[ci];
+        if (!t.emit) continue;                                      // (wave-uniform)
+        const u64 c2 = g * 256 + ci;
+        const int L = t.L;
+        const u32 s0 = t.s0, s1 = t.s1, rl = t.right_len;
+        const u64 rat = t.right_at, o = s_off[ci], id = first_id + s_rank[ci];
         const uint8_t* ca = a.cons + c2 * 128;
         const uint8_t* cbp = ca + 64;
+        const u32 ach = lane < kl ? (u32)ca[lane] : 0u, bch = lane < kl ? (u32)cbp[lane] : 0u;   // the two consensus strings, one letter per lane
+        la[lane] = (uint8_t)ach; lb[lane] = (uint8_t)bch;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         u32 n1 = 0, n3 = 0;
         if (lane == 0) {
             for (int line = 0; line < 2; ++line) {
@@ -221,9 +271,9 @@ __global__ __launch_bounds__(256) void k_tail_write(TailArgs a, const unsigned l
                 at = tl_put(b, at, "|P_1:");
                 at = tl_put_num(b, at, rl);
                 b[at++] = '_';
-                if (L == 0) { b[at++] = ca[kl - 1]; b[at++] = '/'; b[at++] = cbp[kl - 1]; }         // last consensus letters (H20)
-                else if (L > 0) { for (u32 i = kl - (u32)L; i < kl; ++i) b[at++] = ca[i]; b[at++] = '/'; }
-                else { b[at++] = '/'; for (u32 i = kl - (u32)(-L); i < kl; ++i) b[at++] = cbp[i]; }
+                if (L == 0) { b[at++] = la[kl - 1]; b[at++] = '/'; b[at++] = lb[kl - 1]; }         // last consensus letters (H20)
+                else if (L > 0) { for (u32 i = kl - (u32)L; i < kl; ++i) b[at++] = la[i]; b[at++] = '/'; }
+                else { b[at++] = '/'; for (u32 i = kl - (u32)(-L); i < kl; ++i) b[at++] = lb[i]; }
                 b[at++] = '|';
                 at = tl_put_num(b, at, line ? s1 : s0);
                 at = tl_put(b, at, "|nb_pol_1\n");
@@ -239,13 +289,13 @@ __global__ __launch_bounds__(256) void k_tail_write(TailArgs a, const unsigned l
             uint8_t* p = out + o;
             for (u32 i = lane; i < n1; i += 64) p[i] = h1[i];
             p += n1;
-            if (lane >= skip0 && lane < kl) p[lane - skip0] = ca[lane];
+            if (lane >= skip0 && lane < kl) p[lane - skip0] = (uint8_t)ach;
             for (u32 i = lane; i < rl; i += 64) p[kl - skip0 + i] = a.text[rat + i];
             if (lane == 0) p[kl - skip0 + rl] = '\n';
             p += l2;
             for (u32 i = lane; i < n3; i += 64) p[i] = h3[i];
             p += n3;
-            if (lane >= skip1 && lane < kl) p[lane - skip1] = cbp[lane];
+            if (lane >= skip1 && lane < kl) p[lane - skip1] = (uint8_t)bch;
             for (u32 i = lane; i < rl; i += 64) p[kl - skip1 + i] = a.text[rat + i];
             if (lane == 0) p[kl - skip1 + rl] = '\n';
         }
@@ -253,9 +303,28 @@ __global__ __launch_bounds__(256) void k_tail_write(TailArgs a, const unsigned l
     }
 }
 
-void e2s_launch_consensus(const TailArgs& a, hipStream_t st) {
+// reads of one length, gathered into a dense [n_reads][len] matrix (one wave per read): the tail then needs no index lookups
+__global__ __launch_bounds__(256) void k_reads_compact(const uint8_t* text, const u64* rstart, u32 len, u64 n_reads, uint8_t* out) {
+    const u32 lane = tl_lane();
+    const u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const uint8_t* src = text + rstart[r];
+    uint8_t* dst = out + r * len;
+    for (u32 i = lane; i < len; i += 64u) dst[i] = src[i];
+}
+void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st) {
+    if (!n_reads) return;
+    hipLaunchKernelGGL(k_reads_compact, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, text, (const u64*)rstart, len, n_reads, out);
+}
+void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) {
     if (!a.n_cand) return;
-    hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + 3) / 4)), dim3(256), 0, st, a);
+    uint32_t kw_shift = 0;
+    while ((1u << kw_shift) < (uint32_t)a.kl) ++kw_shift;          // k_left <= 64
+    if (list_cap < 1) list_cap = 1;
+    const size_t lds = (size_t)4 * list_cap * (64 + 8 + 4);
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+    hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + 3) / 4)), dim3(256), lds, st, a, list_cap, kw_shift);
 }
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, hipStream_t st) {
@@ -264,5 +333,5 @@ void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, uint8_t* out, unsigned long long out_cap,
                            hipStream_t st) {
     if (!a.n_cand) return;
-    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)((a.n_cand + 255) / 256)), dim3(256), 0, st, a, part_excl, first_id, out, out_cap);
+    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)((a.n_cand + 255) / 256)), dim3(1024), 0, st, a, part_excl, first_id, out, out_cap);
 }

@@ -138,7 +138,13 @@ int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int rank);
 /* After e2s_stitch: n_closed = this shard's share of the count ebwt2clust prints
  * (ebwt2clust.cpp:137, before the min_len filter); n_records = records it writes. */
 int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_records);
-/* Packed 10-byte {u64 start; u16 length} records of this shard (ebwt2clust.cpp:58-59), ascending. */
+/* The `.clusters` image of this shard -- packed 10-byte {u64 start; u16 length} records (ebwt2clust.cpp:58-59), ascending,
+ * append_entry's length filter applied -- built in HBM.  async != 0: on the handle's second stream, returning at once, so that it runs
+ * beside the per-cluster pass (the pack is bandwidth bound, that pass latency bound); e2s_clusters_image, e2s_fetch_clusters and
+ * e2s_stream_clusters wait for it (and build the image themselves if nobody has). */
+int e2s_pack_clusters(e2s_handle h, int async);
+int e2s_clusters_image(e2s_handle h, const void** d_image, uint64_t* n_records);
+/* The same bytes copied to the host. */
 int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records, uint64_t* n_records);
 /* The same bytes handed to a sink chunk by chunk (whole records per call, in file order) straight out of pinned staging
  * buffers, the next chunk's copy running meanwhile: what the ebwt2clust executable writes its output file with.  The sink
@@ -249,7 +255,8 @@ int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n
 
 /* ---- the tail on the GPU: reads resident in HBM -------------------------------- */
 /* get_reads (clust2snp.cpp:147-212) done once for ALL reads: read r = text[start[r] .. start[r] + len[r]), max_len = the longest.
- * e2s_upload_reads copies host arrays to HBM; e2s_attach_reads takes device pointers (the caller keeps ownership);
+ * e2s_upload_reads copies host arrays to HBM (reads of one length are gathered into a dense matrix there); e2s_attach_reads takes
+ * device pointers (the caller keeps ownership; d_start = d_len = NULL: a dense matrix, read r = d_text[r * max_len .. +max_len));
  * e2s_upload_reads_fasta indexes a FASTA file on the host (worker threads) and uploads it -- E2S_ERR_INPUT for a file whose
  * line structure is irregular (a header after a header, no header first, ...), where the reference's line juggling yields
  * text this index cannot express: keep to e2s_snp_from_packed then.
@@ -266,6 +273,9 @@ int e2s_upload_reads_fasta(e2s_handle h, const char* fasta_path, uint64_t* n_rea
  * E2S_ERR_REF_CRASH where the reference crashes (no candidate; a right context beyond its read); E2S_ERR_STATE where only the
  * host tail reproduces the reference (-L outside 1..64, a read rank past the last read): use e2s_snp_from_packed then. */
 int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_t first_id, uint64_t* n_variants, uint64_t* n_events, uint64_t* snp_bytes);
+/* The same events with ids counting from another first_id (several ranks: every rank learns how many events the ranks before it
+ * hold only after its own e2s_call_variants); consensus and distance results are kept, only the text is written again. */
+int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_bytes);
 /* the image, copied out whole or handed to a sink chunk by chunk (as e2s_stream_clusters) */
 int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64_t* bytes);
 int e2s_stream_snp(e2s_handle h, e2s_byte_sink sink, void* user);

@@ -728,3 +728,113 @@ def test_stale_prefilter_result_is_not_consumed(H, tmp_path):
     for a, b in zip(got, oc2):
         for key in ("right_idx", "right_pos", "idx0", "pos0", "idx1", "pos1"):
             assert a[key] == b[key]
+
+
+def _attach_job_inputs(h, reads, en, n_total, lo, hi, hl, hr, dev):
+    """EGSA columns [lo - hl, hi + hr) and all reads as torch tensors in HBM, attached by pointer (what bench.py does)"""
+    import torch
+    sl = slice(lo - hl, hi + hr)
+    t = dict(bwt=torch.from_numpy(en["bwt"][sl].copy()).to(dev), lcp=torch.from_numpy(en["lcp"][sl].astype(np.uint8)).to(dev),
+             pos=torch.from_numpy(en["suff"][sl].astype(np.uint8)).to(dev), da=torch.from_numpy(en["text"][sl].astype(np.int32)).to(dev))
+    rd = torch.from_numpy(np.ascontiguousarray(reads)).to(dev)
+    L = rd.shape[1]
+    rstart = (torch.arange(rd.shape[0], device=dev, dtype=torch.int64) * L).contiguous()
+    rlen = torch.full((rd.shape[0],), L, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()
+    h.attach_reads(rd.data_ptr(), rstart.data_ptr(), rlen.data_ptr(), rd.shape[0], L, keep=(rd, rstart, rlen))
+    h.attach_soa(capi.Handle.desc(n_total, offset=lo, n_entries=hi - lo, halo_left=hl, halo_right=hr), t["bwt"].data_ptr(), t["lcp"].data_ptr(),
+                 t["pos"].data_ptr(), t["da"].data_ptr(), keep=tuple(t.values()))
+
+
+@pytest.mark.gpu
+def test_resident_job_images_equal_oracle(tmp_path):
+    """the step bench.py times (ebwt2snp_amd/pipeline.py): EGSA and reads resident, both outputs as images in HBM -- `.clusters`
+    and `.snp` bytes against the oracle's files, the pre-filter started in its three ways; then the same EGSA cut into two and
+    three SA ranges (one handle each, descriptors and event counts exchanged by hand): the images concatenate to the same files"""
+    import torch
+    from ebwt2snp_amd import pipeline
+    dev = torch.device("cuda", 0)
+    reads, n1, e = synth.synth_case(5000, 100, seed=71)
+    en = synth.egsa_to_numpy(e)
+    n = en["lcp"].size
+    p = str(tmp_path / "j.fasta")
+    IO.write_fasta(p, reads.numpy())
+    IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+    assert O.ebwt2clust(p)[0] == 0 and O.clust2snp(p, O.c2s_opts(n1))[0] == 0
+    want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
+    h = capi.Handle(0)
+    _attach_job_inputs(h, reads.numpy(), en, n, 0, n, 0, 0, dev)
+    for pf in ("arm", "begin", "inside"):
+        r = pipeline.resident_job(h, n1, n, prefilter=pf)
+        assert h.fetch_clusters().tobytes() == want_cl and h.fetch_snp().tobytes() == want_snp, pf
+        assert r["n_records"] * 10 == len(want_cl) and r["snp_bytes"] == len(want_snp) and r["n_events"] > 20
+    h.close()
+    rnd = np.random.RandomState(3)
+    for world in (2, 3):
+        cuts = [0] + sorted(int(c) for c in rnd.randint(n // 10, n - n // 10, world - 1)) + [n]
+        hs = [capi.Handle(0) for _ in range(world)]
+        for r in range(world):
+            _attach_job_inputs(hs[r], reads.numpy(), en, n, cuts[r], cuts[r + 1], min(152, cuts[r]), 1 if r < world - 1 else 0, dev)
+        # phase 1 on every rank, then the "all-gather", then the rest rank by rank (ids sequential over the ranks)
+        for r in range(world):
+            hs[r].prefilter_arm(5)
+            hs[r].cluster_scan(16, 2, 0)
+        blobs = [bytes(hs[r].boundary()) + bytes(hs[r].scan_stats()) for r in range(world)]
+        cl, snp, events = b"", b"", 0
+        for r in range(world):
+            state = {"first": True}
+
+            def ex(blob, r=r):
+                return blobs
+
+            # (resident_job runs the scan again: same result, the exchange hands back every rank's blob)
+            out = pipeline.resident_job(hs[r], n1, n, rank=r, world=world, exchange=ex, ids_exchange=lambda ne, ev=events: ev)
+            cl += hs[r].fetch_clusters().tobytes()
+            snp += hs[r].fetch_snp().tobytes() if out["n_cand"] else b""
+            events += out["n_events"]
+        assert cl == want_cl and snp == want_snp, (world, cuts)
+        for x in hs:
+            x.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c2_first_1e8", "c3_block"])
+def test_full_size_outputs_equal_reference(case, tmp_path):
+    """BASELINE.json's single-GPU configurations at full scale against the reference's own executables (oracle/_ref): the first 10^8
+    entries of the c2 EGSA (2x10^6 reads x 100 bp) and one whole block of c3 (2x10^6 x 150 bp, 3.02x10^8 entries; c3 is ten such
+    blocks end to end) -- `.clusters` and `.snp` images of the resident job byte for byte, with the pre-filter inside the scan
+    kernel, after the scan, and inside e2s_find_candidates"""
+    import sys
+    import torch
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from ebwt2snp_amd import pipeline
+    dev = torch.device("cuda", 0)
+    R, L, n = (1000000, 100, 100000000) if case == "c2_first_1e8" else (1000000, 150, None)
+    reads, n1, blk = bench.build_block(R, L, dev)
+    n = n or blk["lcp"].numel()
+    p = str(tmp_path / "reads.fasta")
+    IO.write_fasta_fast(p, reads.cpu().numpy())
+    lcp = blk["lcp"][:n].cpu().numpy().copy()
+    lcp[-1] = 0
+    IO.write_bcr(p, blk["da"][:n].cpu().numpy(), blk["pos"][:n].cpu().numpy(), lcp, blk["bwt"][:n].cpu().numpy())
+    rc, out = O.ref_ebwt2clust(p)
+    assert rc == 0, out[-300:]
+    rc, out = O.ref_clust2snp(p, n1)
+    assert rc == 0, out[-300:]
+    want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
+    sub = {k: blk[k][:n].clone() for k in ("bwt", "lcp", "pos", "da")}
+    sub["lcp"][-1] = 0
+    rd = reads.to(dev).contiguous()                                 # dense matrix: read r at r * L (what bench.py attaches)
+    torch.cuda.synchronize()
+    h = capi.Handle(0)
+    h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
+    h.attach_soa(capi.Handle.desc(n), sub["bwt"].data_ptr(), sub["lcp"].data_ptr(), sub["pos"].data_ptr(), sub["da"].data_ptr(), keep=tuple(sub.values()))
+    for pf in ("arm", "begin", "inside"):
+        r = pipeline.resident_job(h, n1, n, prefilter=pf)
+        assert r["n_records"] * 10 == len(want_cl) and r["snp_bytes"] == len(want_snp), pf
+        assert h.fetch_clusters().tobytes() == want_cl, pf
+        assert h.fetch_snp().tobytes() == want_snp, pf
+    h.close()
