@@ -12,7 +12,7 @@ all: lib bins oracle
 
 lib: $(LIB)
 
-LIBSRC   = $(CSRC)/e2s_kernels.hip $(CSRC)/e2s_tail.hip $(CSRC)/e2s_capi.hip $(HOST)/snp_tail.cpp $(HOST)/fasta_index.cpp $(HOST)/reads_upload.cpp
+LIBSRC   = $(CSRC)/e2s_kernels.hip $(CSRC)/e2s_tail.hip $(CSRC)/e2s_capi.hip $(HOST)/snp_tail.cpp $(HOST)/fasta_index.cpp $(HOST)/reads_upload.cpp $(HOST)/chunked.cpp
 $(LIB): $(LIBSRC) $(CSRC)/e2s_internal.h $(CSRC)/e2s_swar.h $(HOST)/fasta_index.hpp include/e2s_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIBSRC) -lpthread
 

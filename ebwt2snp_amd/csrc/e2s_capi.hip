@@ -1562,6 +1562,15 @@ extern "C" int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t
     return E2S_OK;
 }
 
+// (private, ebwt2snp_amd/host/chunked.cpp) a second handle on the same device reads the first one's resident reads
+extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src) {
+    if (!dst || !src || dst->device != src->device) return E2S_ERR_ARG;
+    release_reads(dst);
+    dst->d_text = src->d_text; dst->d_rstart = src->d_rstart; dst->d_rlen = src->d_rlen; dst->n_reads = src->n_reads;
+    dst->reads_max_len = src->reads_max_len; dst->have_reads = src->have_reads; dst->reads_owned = false; dst->variants_valid = false;
+    return E2S_OK;
+}
+
 extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
                                 uint32_t max_len) {
     dbg_entry("e2s_upload_reads");

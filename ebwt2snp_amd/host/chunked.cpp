@@ -1,0 +1,363 @@
+// chunked.cpp -- whole jobs over an EGSA that comes from the host in chunks (include/e2s_hip.h, "whole jobs ...").
+//
+// The reference streams its index files with O(cluster) memory (egsa_stream::read_el, include.hpp:120-199; the loops of
+// ebwt2clust.cpp:90-122 and clust2snp.cpp:806-857).  Here the array passes through ONE GPU in chunks of SA positions: two handles on
+// the device, an uploader thread filling one while the other is processed, every chunk a rank of the boundary stitch the multi-GPU
+// path uses (e2s_stitch_plan, halo 152 / 1) -- no new semantics, the outputs are those of one pass over the whole array.
+// Host code over the public C ABI (plus e2s_share_reads: the second handle uses the first one's resident reads).
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/e2s_hip.h"
+
+extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src);    // e2s_capi.hip (not part of the public ABI)
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Chunk { uint64_t lo, hi; uint32_t hl, hr; };
+
+// chunks of `ce` owned entries; right halo 1 for the scan (the stencil looks one entry ahead), max cluster length + 1 where the
+// records come from a file (a cluster is handled by the chunk that holds its START there)
+std::vector<Chunk> plan_chunks(uint64_t n, uint64_t ce, uint32_t right_halo) {
+    std::vector<Chunk> v;
+    if (ce == 0) ce = 1500000000ull;                            // 10.5 GB of EGSA per chunk at default widths, two in flight
+    ce = std::max<uint64_t>(ce, 4096);
+    for (uint64_t lo = 0; lo < n; lo += ce) {
+        Chunk c;
+        c.lo = lo; c.hi = std::min(n, lo + ce);
+        if (n - c.hi < 2 && c.hi < n) c.hi = n;                 // (the last rank must own at least two entries)
+        c.hl = (uint32_t)std::min<uint64_t>(lo, E2S_MAX_CLUST_LEN + 2);
+        c.hr = (uint32_t)std::min<uint64_t>(n - c.hi, right_halo);
+        v.push_back(c);
+        if (c.hi == n) break;
+    }
+    return v;
+}
+
+// two handles on one device and an uploader thread: chunk r goes into handle r & 1 while chunk r - 1 is processed on the other
+class ChunkPipe {
+  public:
+    ChunkPipe(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::vector<Chunk>& chunks, bool want_all)
+        : p_(p), src_(src), chunks_(chunks), want_all_(want_all) {}
+    ~ChunkPipe() { stop(); for (auto& h : h_) if (h) e2s_destroy(h); }
+    int start() {
+        for (auto& h : h_) { int rc = e2s_create(p_.device, &h); if (rc) { err_ = e2s_last_error(nullptr); return rc; } }
+        th_ = std::thread([this]() { run(); });
+        return E2S_OK;
+    }
+    e2s_handle handle(int slot) { return h_[slot]; }
+    // waits until chunk r is resident; returns its handle (nullptr + rc on failure)
+    int acquire(size_t r, e2s_handle* h) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&]() { return rc_ != 0 || ready_[r & 1] == (long)r; });
+        if (rc_) return rc_;
+        *h = h_[r & 1];
+        return E2S_OK;
+    }
+    void done(size_t r) {
+        { std::lock_guard<std::mutex> lk(m_); ready_[r & 1] = -1; }
+        cv_.notify_all();
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(m_); quit_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    const std::string& error() const { return err_; }
+    double upload_seconds() const { return up_s_; }
+
+  private:
+    void fail(int rc, const char* what, e2s_handle h) {
+        { std::lock_guard<std::mutex> lk(m_); rc_ = rc ? rc : E2S_ERR_IO; err_ = std::string(what) + ": " + (h ? e2s_last_error(h) : "source"); }
+        cv_.notify_all();
+    }
+    void run() {
+        for (size_t r = 0; r < chunks_.size(); ++r) {
+            const int slot = (int)(r & 1);
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return quit_ || ready_[slot] == -1; });
+                if (quit_) return;
+            }
+            const Chunk& c = chunks_[r];
+            const uint64_t lo = c.lo - c.hl, n = (c.hi - c.lo) + c.hl + c.hr;
+            const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
+            const double t0 = now_s();
+            if (src_.get(src_.user, slot, lo, n, want_all_ ? 1 : 0, &bwt, &lcp, &psa, &aos) != 0) { fail(E2S_ERR_IO, "EGSA source", nullptr); return; }
+            e2s_shard_desc d{};
+            d.global_offset = c.lo; d.n_entries = c.hi - c.lo; d.n_total = p_.n_total; d.halo_left = c.hl; d.halo_right = c.hr;
+            d.lcp_bytes = p_.lcp_bytes; d.da_bytes = p_.da_bytes; d.pos_bytes = p_.pos_bytes;
+            int rc;
+            if (src_.gesa) rc = e2s_upload_gesa(h_[slot], &d, aos);
+            else if (want_all_) rc = e2s_upload_bcr(h_[slot], &d, bwt, lcp, psa);
+            else rc = e2s_upload_lcp(h_[slot], &d, lcp, ((const uint8_t*)bwt)[c.hl + (c.hi - c.lo) - 1]);   // the BWT byte of the last owned entry (EOF rule)
+            if (src_.release) src_.release(src_.user, slot);
+            up_s_ += now_s() - t0;
+            if (rc) { fail(rc, "upload", h_[slot]); return; }
+            { std::lock_guard<std::mutex> lk(m_); ready_[slot] = (long)r; }
+            cv_.notify_all();
+        }
+    }
+    e2s_chunk_params p_; e2s_egsa_source src_; const std::vector<Chunk>& chunks_; bool want_all_;
+    e2s_handle h_[2] = {nullptr, nullptr};
+    std::thread th_; std::mutex m_; std::condition_variable cv_;
+    long ready_[2] = {-1, -1}; bool quit_ = false; int rc_ = 0; std::string err_; double up_s_ = 0;
+};
+
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+// pass A: the scan of every chunk, stitched in order; descriptors and statistics of all chunks are kept for a second pass
+struct ScanPass {
+    std::vector<e2s_boundary> all; std::vector<e2s_scan_stats> stats; std::vector<e2s_hist> hists;
+    uint64_t n_closed = 0, n_records = 0; double up_s = 0;
+};
+int scan_pass(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::vector<Chunk>& chunks, e2s_byte_sink sink, void* user, ScanPass& out) {
+    const int nr = (int)chunks.size();
+    out.all.assign(nr, e2s_boundary{}); out.stats.assign(nr, e2s_scan_stats{}); out.hists.assign(nr, e2s_hist{});
+    ChunkPipe pipe(p, src, chunks, false);
+    RC(pipe.start());
+    for (int r = 0; r < nr; ++r) {
+        e2s_handle h = nullptr;
+        RC(pipe.acquire((size_t)r, &h));
+        RC(e2s_cluster_scan(h, p.k, p.min_len, 0));
+        RC(e2s_boundary_desc(h, &out.all[r]));
+        RC(e2s_scan_stats_desc(h, &out.stats[r]));
+        RC(e2s_stitch(h, out.all.data(), nr, r));                // (reads the descriptors of ranks <= r only)
+        uint64_t nc = 0, nrec = 0;
+        RC(e2s_cluster_counts(h, &nc, &nrec));
+        RC(e2s_cluster_hist(h, &out.hists[r]));
+        out.n_closed += nc;
+        if (sink) { uint64_t w = 0; RC(e2s_stream_clusters(h, sink, user, &w)); out.n_records += w; } else out.n_records += nrec;
+        pipe.done((size_t)r);
+    }
+    pipe.stop();
+    out.up_s = pipe.upload_seconds();
+    return E2S_OK;
+}
+
+// the tail of one chunk: GPU tail streamed to the sink, or -- where only the host tail reproduces the reference -- the packed
+// candidates appended to host buffers for one e2s_snp_from_packed at the end
+struct TailState {
+    e2s_tail_params tp; uint64_t events = 0, variants = 0, cands = 0;
+    bool host_mode = false; std::vector<uint8_t> stream; std::vector<uint32_t> off8; uint32_t pw = 4;
+};
+int chunk_tail(e2s_handle h, uint64_t n_cand, e2s_byte_sink snp_sink, void* snp_user, TailState& ts) {
+    ts.cands += n_cand;
+    if (!n_cand) return E2S_OK;
+    if (!ts.host_mode) {
+        uint64_t nv = 0, ne = 0, nb = 0;
+        int rc = e2s_call_variants(h, &ts.tp, 1 + ts.events, &nv, &ne, &nb);
+        if (rc == E2S_OK) {
+            ts.events += ne; ts.variants += nv;
+            return nb ? e2s_stream_snp(h, snp_sink, snp_user) : E2S_OK;
+        }
+        if (rc != E2S_ERR_STATE) return rc;
+        if (ts.events) return E2S_ERR_STATE;                     // (earlier chunks already wrote their events: cannot switch tails mid-way)
+        ts.host_mode = true;
+    }
+    const void* st = nullptr; const uint32_t* of = nullptr; uint64_t n = 0, bytes = 0; uint32_t pw = 4;
+    RC(e2s_candidates_packed(h, &st, &of, &n, &bytes, &pw));
+    const uint64_t base8 = ts.stream.size() / 8;
+    if (base8 + bytes / 8 >= (1ull << 32)) return E2S_ERR_CAPACITY;
+    ts.stream.insert(ts.stream.end(), (const uint8_t*)st, (const uint8_t*)st + bytes);
+    for (uint64_t i = 0; i < n; ++i) ts.off8.push_back((uint32_t)(base8 + of[i]));
+    ts.pw = pw;
+    return E2S_OK;
+}
+int finish_tail(TailState& ts, const char* fasta_path, e2s_byte_sink snp_sink, void* snp_user, const char* out_path) {
+    if (ts.cands == 0) return E2S_ERR_REF_CRASH;                 // zero candidates: the reference crashes before creating the file
+    if (!ts.host_mode) return E2S_OK;
+    if (!fasta_path) return E2S_ERR_STATE;
+    ts.off8.push_back((uint32_t)(ts.stream.size() / 8));
+    std::string tmp = out_path ? std::string(out_path) : std::string("/tmp/e2s_tail_XXXXXX");
+    if (!out_path) { const int fd = mkstemp(&tmp[0]); if (fd < 0) return E2S_ERR_IO; close(fd); }
+    uint64_t nv = 0, ne = 0;
+    int rc = e2s_snp_from_packed(ts.stream.data(), ts.off8.data(), ts.off8.size() - 1, ts.pw, &ts.tp, fasta_path, tmp.c_str(), &nv, &ne);
+    ts.variants = nv; ts.events = ne;
+    if (rc == E2S_OK && !out_path) {                             // the text goes to the sink
+        FILE* f = fopen(tmp.c_str(), "rb");
+        if (!f) rc = E2S_ERR_IO;
+        else {
+            std::vector<char> buf(1 << 20);
+            size_t got;
+            while (rc == E2S_OK && (got = fread(buf.data(), 1, buf.size(), f)) > 0) if (snp_sink(snp_user, buf.data(), got)) rc = E2S_ERR_IO;
+            fclose(f);
+        }
+    }
+    if (!out_path) unlink(tmp.c_str());
+    return rc;
+}
+
+int file_sink(void* user, const void* data, size_t bytes) { return fwrite(data, 1, bytes, (FILE*)user) == bytes ? 0 : 1; }
+// a file that comes into being with its first byte (where the reference crashes before creating it, nothing must be left behind)
+struct LazyFile { FILE* f; const char* path; };
+int lazy_file_sink(void* user, const void* data, size_t bytes) {
+    LazyFile* c = (LazyFile*)user;
+    if (!c->f) { c->f = fopen(c->path, "w"); if (!c->f) return 1; }
+    return file_sink(c->f, data, bytes);
+}
+
+void fill_report(e2s_job_report* rep, const ScanPass* sp, const TailState* ts, int mcl, uint64_t n_clust, uint64_t n_bases, size_t n_chunks, double up_s, double t0) {
+    if (!rep) return;
+    if (sp) {
+        rep->n_closed = sp->n_closed; rep->n_records = sp->n_records;
+        memset(&rep->hist, 0, sizeof(rep->hist));
+        for (const e2s_hist& hs : sp->hists) {
+            for (int i = 0; i <= E2S_MAX_CLUST_LEN; ++i) rep->hist.freq[i] += hs.freq[i];
+            rep->hist.n_records += hs.n_records; rep->hist.n_bases += hs.n_bases;
+            if (hs.n_records) rep->hist.last_len = hs.last_len;
+        }
+    }
+    if (ts) { rep->n_candidates = ts->cands; rep->n_variants = ts->variants; rep->n_events = ts->events; }
+    rep->max_clust_length = mcl; rep->n_clust = n_clust; rep->n_bases = n_bases; rep->n_chunks = (int32_t)n_chunks;
+    rep->seconds_upload = up_s; rep->seconds_total = now_s() - t0;
+}
+
+}  // namespace
+
+extern "C" int e2s_ebwt2clust_chunked(const e2s_chunk_params* p, const e2s_egsa_source* src, e2s_byte_sink clusters_sink, void* sink_user, e2s_job_report* rep) {
+    if (!p || !src || !src->get || !p->n_total) return E2S_ERR_ARG;
+    const double t0 = now_s();
+    if (rep) memset(rep, 0, sizeof(*rep));
+    const std::vector<Chunk> chunks = plan_chunks(p->n_total, p->chunk_entries, 1);
+    ScanPass sp;
+    RC(scan_pass(*p, *src, chunks, clusters_sink, sink_user, sp));
+    fill_report(rep, &sp, nullptr, 0, 0, 0, chunks.size(), sp.up_s, t0);
+    return E2S_OK;
+}
+
+extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src, const char* fasta_path,
+                                    const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len,
+                                    e2s_byte_sink clusters_sink, void* clusters_user, e2s_byte_sink snp_sink, void* snp_user, e2s_job_report* rep) {
+    if (!p || !o || !src || !src->get || !p->n_total || !snp_sink || (!fasta_path && !d_text)) return E2S_ERR_ARG;
+    const double t0 = now_s();
+    if (rep) memset(rep, 0, sizeof(*rep));
+    const std::vector<Chunk> chunks = plan_chunks(p->n_total, p->chunk_entries, 1);
+    const int nr = (int)chunks.size();
+    // pass A: ebwt2clust (LCP column only): records out, descriptors and statistics of every chunk kept
+    ScanPass sp;
+    RC(scan_pass(*p, *src, chunks, clusters_sink, clusters_user, sp));
+    int mcl = 0; uint64_t n_clust = 0, n_bases = 0;
+    int rc = e2s_auto_max_clust_length(sp.hists.data(), nr, o->mcov_out, o->pval, &mcl, &n_clust, &n_bases);
+    if (rc) { fill_report(rep, &sp, nullptr, 0, 0, 0, chunks.size(), sp.up_s, t0); return rc; }
+    // pass B: clust2snp: all four columns, the scan again with the pre-filter inside, the per-cluster pass and the tail
+    ChunkPipe pipe(*p, *src, chunks, true);
+    RC(pipe.start());
+    if (fasta_path) {
+        rc = e2s_upload_reads_fasta(pipe.handle(0), fasta_path, nullptr);
+        if (rc != E2S_OK && rc != E2S_ERR_INPUT) return rc;      // (an irregular FASTA: the host tail decides)
+        if (rc == E2S_OK) RC(e2s_share_reads(pipe.handle(1), pipe.handle(0)));
+    } else {
+        RC(e2s_attach_reads(pipe.handle(0), d_text, d_start, d_len, n_reads, max_len));
+        RC(e2s_attach_reads(pipe.handle(1), d_text, d_start, d_len, n_reads, max_len));
+    }
+    TailState ts;
+    ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
+    for (int r = 0; r < nr; ++r) {
+        e2s_handle h = nullptr;
+        RC(pipe.acquire((size_t)r, &h));
+        RC(e2s_prefilter_arm(h, o->mcov_out));
+        RC(e2s_cluster_scan(h, p->k, p->min_len, 0));
+        RC(e2s_stitch(h, sp.all.data(), nr, r));                 // the descriptors of pass A: the same array, the same cuts
+        e2s_c2s_params prm{};
+        prm.nr_reads1 = o->nr_reads1; prm.k_left = o->k_left; prm.k_right = o->k_right; prm.mcov_out = o->mcov_out;
+        prm.consensus_reads = o->consensus_reads; prm.max_clust_length = mcl; prm.min_len = p->min_len;
+        uint64_t n_cand = 0;
+        RC(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand));
+        RC(chunk_tail(h, n_cand, snp_sink, snp_user, ts));
+        pipe.done((size_t)r);
+    }
+    pipe.stop();
+    rc = finish_tail(ts, fasta_path, snp_sink, snp_user, nullptr);
+    fill_report(rep, &sp, &ts, mcl, n_clust, n_bases, chunks.size(), sp.up_s + pipe.upload_seconds(), t0);
+    return rc;
+}
+
+extern "C" int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, int max_clust_length, const e2s_egsa_source* src,
+                                     const void* recs, uint64_t n_records, const char* fasta_path, const char* out_path, e2s_job_report* rep) {
+    if (!p || !o || !src || !src->get || !p->n_total || !fasta_path || !out_path || (!recs && n_records)) return E2S_ERR_ARG;
+    const double t0 = now_s();
+    if (rep) memset(rep, 0, sizeof(*rep));
+    // records are handled where they START; the cluster must be resident: right halo = the largest length that matters + the EOF phantom
+    const std::vector<Chunk> chunks = plan_chunks(p->n_total, p->chunk_entries, E2S_MAX_CLUST_LEN + 1);
+    const int nr = (int)chunks.size();
+    auto start_of = [&](uint64_t i) { uint64_t s; memcpy(&s, (const uint8_t*)recs + i * 10, 8); return s; };
+    auto first_at_or_after = [&](uint64_t pos) {                  // records are ascending (H16: checked on the GPU per chunk)
+        uint64_t a = 0, b = n_records;
+        while (a < b) { const uint64_t m = (a + b) / 2; if (start_of(m) < pos) a = m + 1; else b = m; }
+        return a;
+    };
+    ChunkPipe pipe(*p, *src, chunks, true);
+    RC(pipe.start());
+    int rc = e2s_upload_reads_fasta(pipe.handle(0), fasta_path, nullptr);
+    if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) return rc;
+    if (rc == E2S_OK) RC(e2s_share_reads(pipe.handle(1), pipe.handle(0)));
+    TailState ts;
+    ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
+    LazyFile out{nullptr, out_path};
+    for (int r = 0; r < nr; ++r) {
+        e2s_handle h = nullptr;
+        RC(pipe.acquire((size_t)r, &h));
+        const uint64_t i0 = first_at_or_after(chunks[r].lo), i1 = r == nr - 1 ? n_records : first_at_or_after(chunks[r].hi);
+        RC(e2s_load_clusters(h, (const uint8_t*)recs + i0 * 10, i1 - i0));
+        e2s_c2s_params prm{};
+        prm.nr_reads1 = o->nr_reads1; prm.k_left = o->k_left; prm.k_right = o->k_right; prm.mcov_out = o->mcov_out;
+        prm.consensus_reads = o->consensus_reads; prm.max_clust_length = max_clust_length; prm.min_len = 0;
+        uint64_t n_cand = 0;
+        RC(e2s_find_candidates(h, &prm, i0, &n_cand));
+        RC(chunk_tail(h, n_cand, lazy_file_sink, &out, ts));
+        pipe.done((size_t)r);
+    }
+    pipe.stop();
+    if (out.f) fclose(out.f);
+    rc = finish_tail(ts, fasta_path, nullptr, nullptr, out_path);
+    fill_report(rep, nullptr, &ts, max_clust_length, 0, 0, chunks.size(), pipe.upload_seconds(), t0);
+    return rc;
+}
+
+extern "C" int e2s_hist_of_records(const void* recs, uint64_t n_records, e2s_hist* out) {
+    if (!out || (!recs && n_records)) return E2S_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), n_records / 1000000));
+    std::vector<e2s_hist> part(T);
+    std::vector<int> bad(T, 0);
+    std::vector<std::thread> th;
+    auto work = [&](unsigned t) {
+        e2s_hist& hs = part[t];
+        memset(&hs, 0, sizeof(hs));
+        const uint64_t a = n_records * t / T, b = n_records * (t + 1) / T;
+        const uint8_t* p = (const uint8_t*)recs;
+        uint64_t prev_end = 0;
+        if (a) { uint64_t s; uint16_t l; memcpy(&s, p + (a - 1) * 10, 8); memcpy(&l, p + (a - 1) * 10 + 8, 2); prev_end = s + l; }
+        for (uint64_t i = a; i < b; ++i) {
+            uint64_t s; uint16_t l;
+            memcpy(&s, p + i * 10, 8); memcpy(&l, p + i * 10 + 8, 2);
+            if (i && s < prev_end) bad[t] = 1;                     // records must be ascending and disjoint (H16: the lock-step cursor of clust2snp.cpp:818-833)
+            prev_end = s + l;
+            hs.n_records++; hs.n_bases += l;
+            if (l <= E2S_MAX_CLUST_LEN) hs.freq[l]++;
+        }
+    };
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (unsigned t = 0; t < T; ++t) {
+        for (int i = 0; i <= E2S_MAX_CLUST_LEN; ++i) out->freq[i] += part[t].freq[i];
+        out->n_records += part[t].n_records; out->n_bases += part[t].n_bases;
+    }
+    if (n_records) { uint16_t l; memcpy(&l, (const uint8_t*)recs + (n_records - 1) * 10 + 8, 2); out->last_len = l; }
+    for (unsigned t = 0; t < T; ++t) if (bad[t]) return E2S_ERR_INPUT;
+    return E2S_OK;
+}

@@ -101,29 +101,20 @@ int main(int argc, char** argv) {
     std::cout << "Output events will be stored in " << filename_out << std::endl;
 
     pc.mark("open files");
-    e2s_handle h = nullptr;
-    int rc = e2s_create(0, &h);
-    pc.mark("e2s_create (HIP start-up)");
-    if (rc) { std::cerr << "GPU unavailable: " << e2s_last_error(nullptr) << std::endl; return 2; }
-    e2s_shard_desc d{};
-    d.n_entries = F.n; d.n_total = F.n; d.lcp_bytes = lcp; d.da_bytes = da; d.pos_bytes = pos;
-    if (F.gesa) die_on(e2s_upload_gesa(h, &d, F.aos.p), h, "upload (.gesa)");
-    else die_on(e2s_upload_bcr(h, &d, F.bwt.p, F.lcp.p, F.pairsa.p), h, "upload (BCR)");
-    pc.mark("upload EGSA");
-    // the reads go to HBM too (get_reads done once, clust2snp.cpp:147-212): consensus, distance and the KisSNP2 text then run on
-    // the GPU and the candidates never cross PCIe.  An irregular FASTA stays on the host (the sequential restatement decides).
     {
-        uint64_t n_reads = 0;
-        rc = e2s_upload_reads_fasta(h, input.c_str(), &n_reads);
-        if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) die_on(rc, h, "upload reads");
+        e2s_handle probe = nullptr;
+        const int rc0 = e2s_create(0, &probe);
+        if (rc0) { std::cerr << "GPU unavailable: " << e2s_last_error(nullptr) << std::endl; return 2; }
+        e2s_destroy(probe);
     }
-    pc.mark("index + upload reads");
-    die_on(e2s_load_clusters(h, CL.p, CL.n / 10), h, "load .clusters");
-    pc.mark("load .clusters");
+    pc.mark("e2s_create (HIP start-up)");
+    int rc;
 
-    // statistics(), clust2snp.cpp:877-966
+    // statistics(), clust2snp.cpp:877-966: one pass over the records of the file (host threads)
     e2s_hist hs;
-    die_on(e2s_cluster_hist(h, &hs), h, "histogram");
+    rc = e2s_hist_of_records(CL.p, CL.n / 10, &hs);
+    if (rc == E2S_ERR_INPUT) { std::cerr << "load .clusters failed (" << rc << "): .clusters records must be ascending and non-overlapping (H16)" << std::endl; return 2; }
+    if (rc) { std::cerr << "histogram failed (" << rc << ")" << std::endl; return 2; }
     int max_clust_length = 0;
     uint64_t n_clust = 0, n_bases = 0;
     rc = e2s_auto_max_clust_length(&hs, 1, mcov_out, pval, &max_clust_length, &n_clust, &n_bases);
@@ -131,7 +122,7 @@ int main(int argc, char** argv) {
         std::cerr << "no usable cluster record: the reference divides by zero here (SIGFPE); nothing written" << std::endl;
         return 136;
     }
-    die_on(rc, h, "statistics");
+    if (rc) { std::cerr << "statistics failed (" << rc << ")" << std::endl; return 2; }
     {
         // the histogram print-out of clust2snp.cpp:916-934 (with the double-counted last record, H4)
         uint64_t freq[E2S_MAX_CLUST_LEN + 1];
@@ -153,25 +144,27 @@ int main(int argc, char** argv) {
     }
 
     std::cout << "(1/4) Filtering relevant clusters ... " << std::endl;
-    e2s_c2s_params prm{};
-    prm.nr_reads1 = nr_reads1; prm.k_left = k_left; prm.k_right = k_right; prm.mcov_out = mcov_out;
-    prm.consensus_reads = consensus_reads; prm.max_clust_length = max_clust_length; prm.min_len = 0;
     pc.mark("statistics");
-    uint64_t n_cand = 0;
-    die_on(e2s_find_candidates(h, &prm, 0, &n_cand), h, "find candidates");
-    pc.mark("find candidates");
+    // find_events + extract_variants + to_file (clust2snp.cpp:788-868): the EGSA goes through the GPU in chunks of SA positions (one
+    // chunk if it fits), the next one uploading while the current one is processed; the reads are resident in HBM throughout and
+    // consensus, distance and the KisSNP2 text run there too (the host tail takes over for an irregular FASTA or -L outside 1..64)
+    FileSource fs{&F, lcp, da, pos};
+    const e2s_egsa_source src = fs.source();
+    e2s_chunk_params cp{};
+    cp.device = 0; cp.k = 0; cp.min_len = 0; cp.lcp_bytes = lcp; cp.da_bytes = da; cp.pos_bytes = pos;
+    cp.n_total = F.n; cp.chunk_entries = chunk_entries_env();
+    e2s_c2s_options co{};
+    co.nr_reads1 = nr_reads1; co.k_left = k_left; co.k_right = k_right; co.mcov_out = mcov_out; co.consensus_reads = consensus_reads;
+    co.max_gap = max_gap; co.max_err = max_err; co.pval = pval;
+    e2s_job_report rep{};
+    rc = e2s_clust2snp_chunked(&cp, &co, max_clust_length, &src, CL.p, CL.n / 10, input.c_str(), filename_out.c_str(), &rep);
+    if (pc.on) std::cerr << "[timing]   " << rep.n_chunks << " chunk(s), upload " << rep.seconds_upload * 1e3 << " ms of " << rep.seconds_total * 1e3 << " ms" << std::endl;
+    pc.mark("upload + candidates + tail + .snp");
     std::cout << " 100% done." << std::endl;
-    std::cout << "Done. " << n_cand << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
-
+    std::cout << "Done. " << rep.n_candidates << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
     std::cout << "(2/4) Extracting reads from fasta file ..." << std::endl;
-    std::cout << "(3/4) Filtering " << n_cand << " candidates and computing consensus of left-contexts ... " << std::endl;
+    std::cout << "(3/4) Filtering " << rep.n_candidates << " candidates and computing consensus of left-contexts ... " << std::endl;
     std::cout << "(4/4) Computing edit distances and saving SNPs/indels to file ... " << std::endl;
-    e2s_tail_params tp{k_left, k_right, max_gap, max_err};
-    uint64_t nv = 0, ne = 0;
-    rc = e2s_write_snp(h, &tp, input.c_str(), filename_out.c_str(), &nv, &ne);      // extract_variants + to_file (clust2snp.cpp:864-868)
-    pc.mark("tail + .snp");
-    e2s_destroy(h);
-    pc.mark("e2s_destroy");
     if (rc == E2S_ERR_REF_CRASH) {
         std::cerr << "no candidate variant: the reference crashes here (SIGSEGV, clust2snp.cpp:531); no .snp written" << std::endl;
         return 139;

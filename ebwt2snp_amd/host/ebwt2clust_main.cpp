@@ -58,24 +58,16 @@ int main(int argc, char** argv) {
     pc.mark("open files");
     std::cout << "This is ebwt2clust. Input file: " << input << std::endl;
 
-    e2s_handle h = nullptr;
-    int rc = e2s_create(gpu, &h);
-    if (rc) { std::cerr << "GPU unavailable: " << e2s_last_error(nullptr) << std::endl; return 2; }
+    // The EGSA goes through the GPU in chunks of SA positions (one chunk if it fits): the next chunk uploads while the current one is
+    // scanned, the chunks are stitched like the ranks of a multi-GPU job, and the records stream out of pinned staging buffers
+    // into <input>.clusters -- any size of input, O(chunk) memory on the device (e2s_ebwt2clust_chunked).
+    {
+        e2s_handle probe = nullptr;
+        int rc0 = e2s_create(gpu, &probe);
+        if (rc0) { std::cerr << "GPU unavailable: " << e2s_last_error(nullptr) << std::endl; return 2; }
+        e2s_destroy(probe);
+    }
     pc.mark("e2s_create (HIP start-up)");
-    e2s_shard_desc d{};
-    d.global_offset = 0; d.n_entries = F.n; d.n_total = F.n; d.halo_left = d.halo_right = 0;
-    d.lcp_bytes = lcp; d.da_bytes = da; d.pos_bytes = pos;
-    if (F.gesa) die_on(e2s_upload_gesa(h, &d, F.aos.p), h, "upload (.gesa)");
-    else die_on(e2s_upload_lcp(h, &d, F.lcp.p, F.n ? F.bwt.p[F.n - 1] : 0), h, "upload (LCP)");   // cluster_lm only reads the LCP
-    pc.mark("upload");
-    die_on(e2s_cluster_scan(h, k, min_len, 0), h, "cluster scan");
-    e2s_boundary b;
-    die_on(e2s_boundary_desc(h, &b), h, "boundary");
-    die_on(e2s_stitch(h, &b, 1, 0), h, "stitch");
-    uint64_t n_closed = 0, n_rec = 0;
-    die_on(e2s_cluster_counts(h, &n_closed, &n_rec), h, "counts");
-    pc.mark("scan");
-    // <input>.clusters: the packed records stream out of the library's pinned staging buffers into the file
     std::string filename_out = input;
     filename_out.append(".clusters");
     const int ofd = ::open(filename_out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
@@ -91,11 +83,19 @@ int main(int argc, char** argv) {
         }
         return 0;
     };
-    die_on(e2s_stream_clusters(h, sink, &sinkst, &n_rec), h, "fetch clusters");
+    FileSource fs{&F, lcp, da, pos};
+    const e2s_egsa_source src = fs.source();
+    e2s_chunk_params cp{};
+    cp.device = gpu; cp.k = k; cp.min_len = min_len; cp.lcp_bytes = lcp; cp.da_bytes = da; cp.pos_bytes = pos;
+    cp.n_total = F.n; cp.chunk_entries = chunk_entries_env();
+    e2s_job_report rep{};
+    int rc = e2s_ebwt2clust_chunked(&cp, &src, sink, &sinkst, &rep);
+    if (rc) { std::cerr << "cluster scan failed (" << rc << ")" << std::endl; return 2; }
     if (ofd >= 0) ::close(ofd);
-    pc.mark("records -> .clusters");
+    if (pc.on) std::cerr << "[timing]   " << rep.n_chunks << " chunk(s), upload " << rep.seconds_upload * 1e3 << " ms of " << rep.seconds_total * 1e3 << " ms" << std::endl;
+    pc.mark("upload + scan + records -> .clusters");
+    const uint64_t n_closed = rep.n_closed;
     // the reference prints the count as unsigned int (ebwt2clust.cpp:88,137)
     std::cout << "Done. " << (unsigned int)n_closed << " clusters saved to output file." << std::endl;
-    e2s_destroy(h);
     return 0;
 }

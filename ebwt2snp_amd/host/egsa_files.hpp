@@ -67,6 +67,20 @@ struct EgsaFiles {
     }
 };
 
+// the mapped files as a chunk source of the library's chunked jobs (e2s_egsa_source): pointers into the mappings, nothing copied
+struct FileSource {
+    const EgsaFiles* F; int x, y, z;
+    static int get(void* user, int, uint64_t lo, uint64_t, int, const void** bwt, const void** lcp, const void** pairsa, const void** aos) {
+        const FileSource* s = (const FileSource*)user;
+        if (s->F->gesa) { *aos = s->F->aos.p + lo * (uint64_t)(s->x + s->y + s->z + 1); return 0; }
+        *bwt = s->F->bwt.p + lo; *lcp = s->F->lcp.p + lo * (uint64_t)s->x; *pairsa = s->F->pairsa.p + lo * (uint64_t)(s->y + s->z);
+        return 0;
+    }
+    e2s_egsa_source source() const { e2s_egsa_source r{}; r.get = &FileSource::get; r.release = nullptr; r.user = (void*)this; r.gesa = F->gesa ? 1 : 0; return r; }
+};
+// E2S_CHUNK_ENTRIES: SA positions per chunk (default: the library's, 1.5x10^9); inputs that fit one chunk go through in one piece
+inline uint64_t chunk_entries_env() { const char* e = getenv("E2S_CHUNK_ENTRIES"); return e ? strtoull(e, nullptr, 10) : 0ull; }
+
 // E2S_CLI_TIMING=1: wall time of the executable's phases on stderr
 struct PhaseClock {
     bool on = getenv("E2S_CLI_TIMING") != nullptr;

@@ -283,6 +283,58 @@ int e2s_stream_snp(e2s_handle h, e2s_byte_sink sink, void* user);
  * otherwise the host tail over the packed candidates; writes out_path either way (nothing where the reference crashes). */
 int e2s_write_snp(e2s_handle h, const e2s_tail_params* p, const char* fasta_path, const char* out_path, uint64_t* n_variants, uint64_t* n_events);
 
+/* ---- whole jobs over an EGSA that comes from the host in chunks (EGSAs larger than HBM) --------------------------
+ * The array goes through ONE GPU in chunks of chunk_entries SA positions (left halo 152, right halo 1 -- or max cluster length + 1
+ * where records come from a file), chunk i + 1 uploading on a second handle while chunk i is processed.  Every chunk is a rank of
+ * the boundary stitch (e2s_stitch_plan / e2s_hist_after_stitch), so the outputs are byte for byte those of one pass over the whole
+ * array: no new semantics.  The reference streams the same files with O(cluster) memory (include.hpp:120-199, ebwt2clust.cpp:90-122). */
+typedef struct {
+    /* Hands out host memory holding the entries [lo, lo + n) of the EGSA (global SA positions).  BCR layout (gesa == 0): *bwt (1 byte per
+     * entry), *lcp (x bytes), *pairsa (z + y bytes: [pos][da]); .gesa layout: *aos (y + z + x + 1 bytes per entry: [da][pos][lcp][bwt]).
+     * want_all == 0: only the LCP column and *bwt are needed (ebwt2clust reads and discards the rest).  The pointers stay valid until
+     * release(user, slot); slots 0 and 1 are in use alternately, never the same one twice at a time.  Returns 0, or non-zero to abort. */
+    int (*get)(void* user, int slot, uint64_t lo, uint64_t n, int want_all, const void** bwt, const void** lcp, const void** pairsa, const void** aos);
+    void (*release)(void* user, int slot);                     /* may be NULL */
+    void* user;
+    int32_t gesa;
+    int32_t reserved;
+} e2s_egsa_source;
+typedef struct {
+    int32_t device;
+    int32_t k, min_len;                  /* ebwt2clust -k -m */
+    int32_t lcp_bytes, da_bytes, pos_bytes;
+    uint64_t n_total;
+    uint64_t chunk_entries;              /* 0: a default that fits one MI355X comfortably */
+} e2s_chunk_params;
+typedef struct {
+    uint64_t nr_reads1;                  /* -n */
+    int32_t k_left, k_right, mcov_out, consensus_reads, max_gap, max_err;   /* -L -R -m -c -g -e */
+    double pval;                         /* -p */
+} e2s_c2s_options;
+typedef struct {
+    uint64_t n_closed, n_records;        /* ebwt2clust's printed count / records of the `.clusters` file */
+    int32_t max_clust_length; int32_t n_chunks;
+    uint64_t n_clust, n_bases;           /* statistics() incl. the H4 double count */
+    uint64_t n_candidates, n_variants, n_events;
+    e2s_hist hist;                       /* the merged histogram (before the H4 double count) */
+    double seconds_upload, seconds_total;
+} e2s_job_report;
+/* ebwt2clust, chunked: the `.clusters` bytes go to clusters_sink chunk by chunk (file order). */
+int e2s_ebwt2clust_chunked(const e2s_chunk_params* p, const e2s_egsa_source* src, e2s_byte_sink clusters_sink, void* sink_user, e2s_job_report* rep);
+/* clust2snp, chunked, for records taken from a `.clusters` file (recs: all of them, packed 10-byte records): the EGSA passes through
+ * HBM once; the reads (fasta_path) are resident throughout; max_clust_length from e2s_auto_max_clust_length over e2s_hist_of_records.
+ * Writes out_path (nothing where the reference crashes: E2S_ERR_REF_CRASH). */
+int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, int max_clust_length, const e2s_egsa_source* src, const void* recs,
+                          uint64_t n_records, const char* fasta_path, const char* out_path, e2s_job_report* rep);
+/* both tools in one process: pass A streams the LCP column (scan, `.clusters` bytes to clusters_sink -- may be NULL --, statistics);
+ * pass B streams all four columns (scan + pre-filter in one kernel, stitch with the descriptors of pass A, per-cluster pass, tail).
+ * The reads: fasta_path, or (d_text, d_start, d_len, n_reads, max_len) already in HBM when fasta_path is NULL (e2s_attach_reads). */
+int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src, const char* fasta_path,
+                         const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len,
+                         e2s_byte_sink clusters_sink, void* clusters_user, e2s_byte_sink snp_sink, void* snp_user, e2s_job_report* rep);
+/* host-only: the partial statistics of packed 10-byte records (clust2snp.cpp:889-909 without the H4 double count), worker threads */
+int e2s_hist_of_records(const void* recs, uint64_t n_records, e2s_hist* out);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 typedef struct {
     float scan_ms;        /* e2s_cluster_scan kernels incl. the statistics (HIP events on the handle's stream) */

@@ -838,3 +838,46 @@ def test_full_size_outputs_equal_reference(case, tmp_path):
         assert h.fetch_clusters().tobytes() == want_cl, pf
         assert h.fetch_snp().tobytes() == want_snp, pf
     h.close()
+    del sub, rd, blk
+    torch.cuda.empty_cache()
+    # ... and the executables on the same files with the EGSA going through the GPU in 6-7 chunks (what an input larger
+    # than HBM takes), the next chunk uploading while the current one is processed
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, E2S_CHUNK_ENTRIES=str(n // 6 - 12345))
+    os.remove(p + ".clusters"); os.remove(IO.snp_out_path(p))
+    r1 = subprocess.run([os.path.join(root, "bin", "ebwt2clust"), "-i", p], capture_output=True, text=True, env=env)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    assert open(p + ".clusters", "rb").read() == want_cl
+    r2 = subprocess.run([os.path.join(root, "bin", "clust2snp"), "-i", p, "-n", str(n1)], capture_output=True, text=True, env=env)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert open(IO.snp_out_path(p), "rb").read() == want_snp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [9973, 20000, 61000])
+def test_chunked_executables_on_goldens(chunk, tmp_path):
+    """every end-to-end golden through bin/ebwt2clust + bin/clust2snp with E2S_CHUNK_ENTRIES small enough for 3 to 60 chunks (cuts at
+    positions that are no multiple of any tile size, inside clusters, a last chunk of a few entries): the chunks are ranks of the
+    boundary stitch, so `.clusters` and `.snp` must be the reference's bytes whatever the chunk size"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, E2S_CHUNK_ENTRIES=str(chunk))
+    for meta in goldens.e2e_cases():
+        d = tmp_path / meta["name"]
+        d.mkdir()
+        reads, n1, en = goldens.e2e_inputs(meta)
+        p = goldens.write_case_files(meta, reads, en, str(d))
+        x, y, z = meta["xyz"]
+        a = []
+        for kk, vv in meta["e2c"].items():
+            a += ["-" + kk, str(vv)]
+        r = subprocess.run([os.path.join(root, "bin", "ebwt2clust"), "-i", p, "-x", str(x), "-y", str(y), "-z", str(z)] + a, capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "Done. %d clusters saved to output file." % meta["n_printed"] in r.stdout, (meta["name"], r.stdout, r.stderr)
+        assert hashlib.sha256(open(p + ".clusters", "rb").read()).hexdigest() == meta["clusters_sha256"], meta["name"]
+        a = []
+        for kk, vv in meta["c2s"].items():
+            a += ["-" + kk, str(vv)]
+        r = subprocess.run([os.path.join(root, "bin", "clust2snp"), "-i", p, "-n", str(n1), "-x", str(x), "-y", str(y), "-z", str(z)] + a, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, (meta["name"], r.stdout[-500:], r.stderr)
+        assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta), meta["name"]
