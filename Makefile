@@ -2,6 +2,7 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
+ROCM    ?= /opt/rocm
 EXTRA   ?=
 HIPFLAGS = $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude
 LIB      = ebwt2snp_amd/libe2s_hip.so
@@ -16,7 +17,13 @@ LIBSRC   = $(CSRC)/e2s_kernels.hip $(CSRC)/e2s_tail.hip $(CSRC)/e2s_capi.hip $(H
 $(LIB): $(LIBSRC) $(CSRC)/e2s_internal.h $(CSRC)/e2s_swar.h $(HOST)/fasta_index.hpp include/e2s_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIBSRC) -lpthread
 
-bins: bin/ebwt2clust bin/clust2snp
+bins: bin/ebwt2clust bin/clust2snp bin/ebwt2snp_mgpu
+
+# the multi-GPU driver links RCCL directly (ncclCommInitAll / ncclAllGather) and the HIP runtime for its exchange buffers
+bin/ebwt2snp_mgpu: $(HOST)/ebwt2snp_mgpu_main.cpp $(HOST)/egsa_files.hpp $(LIB)
+	@mkdir -p bin
+	$(CXX) -O2 -std=c++17 -Wall -D__HIP_PLATFORM_AMD__ -Iinclude -I$(HOST) -I$(ROCM)/include -o $@ $< -Lebwt2snp_amd -le2s_hip -L$(ROCM)/lib -lrccl -lamdhip64 -lpthread \
+	    -Wl,-rpath,'$$ORIGIN/../ebwt2snp_amd' -Wl,-rpath,$(ROCM)/lib
 
 bin/%: $(HOST)/%_main.cpp $(HOST)/egsa_files.hpp $(LIB)
 	@mkdir -p bin

@@ -45,6 +45,9 @@ WORKLOADS = {
     # ("C2-style block tiled with read-id remap") -- BASELINE.json configs[2], 21 GB of EGSA + 3 GB of reads in HBM
     "c3": (1000000, 150, 10),
     "c3x": (1000000, 150, 15),    # 4.53e9 entries: SA positions beyond 2^32 on one GPU (stress check, 32 GB of EGSA)
+    # BASELINE.json configs[4] on ONE GPU: 3.02e10 entries (211 GB of EGSA, more than HBM) streamed from host memory through the GPU in
+    # 100 chunks by the library's chunked job (ebwt2snp_amd/host/chunked.cpp); PCIe-inclusive by construction, run with --workload c5s
+    "c5s": (1000000, 150, 100),
 }
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -265,6 +268,60 @@ def cpu_baseline(blk, reads, n1, sample_entries, dev):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def run_c5s(a, dev):
+    """an EGSA larger than HBM through one GPU: `copies` copies of the exactly sorted block, handed to e2s_ebwt2snp_chunked chunk by chunk
+    from host memory (one chunk = one copy + halos: the host block carries 152 wrap-around entries in front and 1 behind, so every chunk is
+    a contiguous piece of it and nothing is composed on the host).  Both passes, both outputs (sinks count the bytes), PCIe included."""
+    R, L, copies = WORKLOADS["c5s"]
+    copies = int(os.environ.get("E2S_BENCH_C5S_COPIES", copies))
+    t0 = time.time()
+    reads, n1, blk = build_block(R, L, dev)
+    m = blk["lcp"].numel()
+    HL = 152
+
+    def padded(t, width=1):
+        x = t.cpu().numpy()
+        if width != 1:
+            x = x.reshape(-1)
+        return np.ascontiguousarray(np.concatenate([x[-HL * width:], x, x[:1 * width]]))
+    bwt, lcp = padded(blk["bwt"]), padded(blk["lcp"])
+    psa = np.zeros(m, dtype=np.dtype([("s", np.uint8), ("t", "<u4")]))      # [pos:1][da:4] per entry (BCR pairSA, include.hpp:159-188)
+    psa["s"] = blk["pos"].cpu().numpy(); psa["t"] = blk["da"].cpu().numpy().astype(np.uint32)
+    psa = padded(torch.from_numpy(psa.view(np.uint8)), width=5)
+    rd = reads.to(dev).contiguous()
+    del blk
+    torch.cuda.empty_cache(); torch.cuda.synchronize()
+    t_build = time.time() - t0
+    n_total = m * copies
+    base = dict(bwt=bwt.ctypes.data, lcp=lcp.ctypes.data, psa=psa.ctypes.data)
+
+    def get(slot, lo, n, want_all):
+        # global [lo, lo + n): chunk r owns copy r; lo = r*m - 152 for r > 0: offset 0 of the padded block; r = 0: offset 152
+        off = (lo + HL) % m if lo else HL
+        assert off + n <= m + HL + 1, (lo, n)
+        return base["bwt"] + off, base["lcp"] + off, base["psa"] + 5 * off
+    cnt = {"cl": 0, "snp": 0}
+
+    def cl_sink(_addr, nbytes):
+        cnt["cl"] += nbytes
+
+    def snp_sink(_addr, nbytes):
+        cnt["snp"] += nbytes
+    t1 = time.time()
+    rep = capi.ebwt2snp_chunked(get, n_total, m, n1, rd.data_ptr(), rd.shape[0], L, cl_sink, snp_sink, device=dev.index or 0)
+    secs = time.time() - t1
+    out = {"metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": n_total / secs, "unit": "EGSA entries/s", "n_gpus": 1, "steps": 1, "warmup": 0,
+           "ms_per_step": secs * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "c5s: %d copies of 2x%d reads x %dbp = %d entries (%.0f GB of EGSA at 7 B/entry, more than HBM) streamed from host memory through ONE GPU in %d chunks, "
+                                  "PCIe INCLUDED (pass A: the LCP column, pass B: all four); both outputs streamed back to host sinks" % (copies, R, L, n_total, n_total * 7 / 1e9, rep.n_chunks),
+                      "entries_total": n_total, "chunks": rep.n_chunks, "seconds_total": rep.seconds_total, "seconds_in_uploads": rep.seconds_upload,
+                      "bytes_uploaded": n_total * 1 + n_total * 7, "upload_GBps_while_uploading": (n_total * 8) / max(rep.seconds_upload, 1e-9) / 1e9,
+                      "clusters_file_records": rep.n_records, "clusters_bytes": cnt["cl"], "clusters_printed": rep.n_closed, "candidates": rep.n_candidates,
+                      "snp_events": rep.n_events, "snp_bytes": cnt["snp"], "max_clust_length": rep.max_clust_length, "input_build_s": round(t_build, 2)},
+           "note": "not the resident-HBM metric: an input of this size cannot be resident; compare with value_outputs_on_host / value_end_to_end of the default run"}
+    print(json.dumps(out))
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE; collected by
     tools/profile.sh in separate --pmc runs of this same command, summarised by tools/profile_summary.py).  None when no
@@ -456,6 +513,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if a.workload == "c5s":
+        if world == 1:
+            run_c5s(a, dev)
+        return
 
     res = measure_workload(a, a.workload, world, rank, local, dist, dev, a.steps, a.warmup, a.scaling, with_cpu=False)
     second = None

@@ -380,6 +380,69 @@ class Handle:
         self._ck(self.L.e2s_synchronize(self.h))
 
 
+class EgsaSource(C.Structure):
+    pass
+
+
+EGSA_GET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
+EGSA_RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+EgsaSource._fields_ = [("get", EGSA_GET), ("release", EGSA_RELEASE), ("user", C.c_void_p), ("gesa", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ChunkParams(C.Structure):
+    _fields_ = [("device", C.c_int32), ("k", C.c_int32), ("min_len", C.c_int32), ("lcp_bytes", C.c_int32), ("da_bytes", C.c_int32),
+                ("pos_bytes", C.c_int32), ("n_total", C.c_uint64), ("chunk_entries", C.c_uint64)]
+
+
+class C2SOptions(C.Structure):
+    _fields_ = [("nr_reads1", C.c_uint64), ("k_left", C.c_int32), ("k_right", C.c_int32), ("mcov_out", C.c_int32),
+                ("consensus_reads", C.c_int32), ("max_gap", C.c_int32), ("max_err", C.c_int32), ("pval", C.c_double)]
+
+
+class JobReport(C.Structure):
+    _fields_ = [("n_closed", C.c_uint64), ("n_records", C.c_uint64), ("max_clust_length", C.c_int32), ("n_chunks", C.c_int32),
+                ("n_clust", C.c_uint64), ("n_bases", C.c_uint64), ("n_candidates", C.c_uint64), ("n_variants", C.c_uint64),
+                ("n_events", C.c_uint64), ("hist", Hist), ("seconds_upload", C.c_double), ("seconds_total", C.c_double)]
+
+
+def ebwt2snp_chunked(get, n_total, chunk_entries, n1, d_text, n_reads, read_len, clusters_sink=None, snp_sink=None, device=0, k=16, min_len=2,
+                     mcov=5, k_left=31, k_right=30, max_gap=10, max_err=2, cons_reads=20, pval=0.99, widths=(1, 4, 1)):
+    """both tools over an EGSA handed out chunk by chunk by get(slot, lo, n, want_all) -> (bwt_ptr, lcp_ptr, pairsa_ptr) (host
+    addresses, BCR layout); the reads as a dense matrix in HBM (d_text).  Sinks: callables (address, nbytes) -> None.  Returns JobReport."""
+    L = lib()
+    L.e2s_ebwt2snp_chunked.argtypes = [C.POINTER(ChunkParams), C.POINTER(C2SOptions), C.POINTER(EgsaSource), C.c_char_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_uint64, C.c_uint32, BYTE_SINK, C.c_void_p, BYTE_SINK, C.c_void_p, C.POINTER(JobReport)]
+
+    def _get(_user, slot, lo, n, want_all, pb, pl, pp, pa):
+        try:
+            b, l, p = get(slot, lo, n, want_all)
+            pb[0], pl[0], pp[0] = b, l, p
+            return 0
+        except Exception:                                          # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _sink(fn):
+        def cb(_user, data, nbytes):
+            if fn is not None:
+                fn(data, nbytes)
+            return 0
+        return BYTE_SINK(cb)
+
+    src = EgsaSource(EGSA_GET(_get), EGSA_RELEASE(0), None, 0, 0)
+    p = ChunkParams(device, k, min_len, widths[0], widths[1], widths[2], n_total, chunk_entries)
+    o = C2SOptions(n1, k_left, k_right, mcov, cons_reads, max_gap, max_err, pval)
+    rep = JobReport()
+    cs, ss = _sink(clusters_sink), _sink(snp_sink)
+    rc = L.e2s_ebwt2snp_chunked(C.byref(p), C.byref(o), C.byref(src), None, C.c_void_p(int(d_text)), None, None, n_reads, read_len, cs, None, ss, None,
+                                C.byref(rep))
+    if rc:
+        raise E2SError(rc, "e2s_ebwt2snp_chunked")
+    return rep
+
+
 def stitch_plan(all_b, rank, n_total, k=16, lcp_bytes=1):
     """Host-only: what `rank` must patch/append once it holds every shard's boundary descriptor."""
     arr = (Boundary * len(all_b))(*all_b)

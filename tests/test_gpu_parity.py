@@ -881,3 +881,36 @@ def test_chunked_executables_on_goldens(chunk, tmp_path):
         r = subprocess.run([os.path.join(root, "bin", "clust2snp"), "-i", p, "-n", str(n1), "-x", str(x), "-y", str(y), "-z", str(z)] + a, capture_output=True, text=True, env=env)
         assert r.returncode == 0, (meta["name"], r.stdout[-500:], r.stderr)
         assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta), meta["name"]
+
+
+@pytest.mark.gpu
+def test_multi_gpu_driver_on_goldens(tmp_path):
+    """bin/ebwt2snp_mgpu (C++ over the C ABI, RCCL linked directly): -G 1 takes the RCCL path with a one-rank communicator
+    (ncclCommInitAll / ncclAllGather on the one-GPU box); E2S_MGPU_SHARED_DEVICE=1 rehearses 2, 3 and 5 ranks on GPU 0 with the
+    exchange through host memory (RCCL refuses two ranks on one device) -- same shard / stitch / statistics / id code.  Every
+    end-to-end golden: `.clusters` and `.snp` are the reference's bytes"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "ebwt2snp_mgpu")
+    for meta in goldens.e2e_cases():
+        d = tmp_path / meta["name"]
+        d.mkdir()
+        reads, n1, en = goldens.e2e_inputs(meta)
+        p = goldens.write_case_files(meta, reads, en, str(d))
+        x, y, z = meta["xyz"]
+        a = ["-x", str(x), "-y", str(y), "-z", str(z)]
+        for kk, vv in meta["e2c"].items():
+            a += ["-" + kk, str(vv)]
+        for kk, vv in meta["c2s"].items():
+            a += ["-" + ("M" if kk == "m" else kk), str(vv)]
+        for ranks, shared in ((1, False), (2, True), (3, True), (5, True)):
+            for f in (p + ".clusters", IO.snp_out_path(p)):
+                if os.path.exists(f):
+                    os.remove(f)
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0")
+            r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)] + a, capture_output=True, text=True, env=env, timeout=300)
+            assert r.returncode == 0, (meta["name"], ranks, r.stdout[-800:], r.stderr[-800:])
+            assert ("RCCL all-gather" in r.stdout) == (not shared)
+            assert "Done. %d clusters saved to output file." % meta["n_printed"] in r.stdout, (meta["name"], ranks, r.stdout)
+            assert hashlib.sha256(open(p + ".clusters", "rb").read()).hexdigest() == meta["clusters_sha256"], (meta["name"], ranks)
+            assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta), (meta["name"], ranks)
