@@ -118,7 +118,7 @@ def shard_strong(blk, m, rank, world):
     lo, hi = cuts[rank], cuts[rank + 1]
     hl = min(152, lo)
     hr = 1 if rank < world - 1 else 0
-    out = {k: v[lo - hl:hi + hr].contiguous() for k, v in blk.items()}
+    out = {k: v[lo - hl:hi + hr].clone() for k, v in blk.items()}       # (a copy: the library wants 16-byte aligned columns)
     return out, lo, hi - lo, hl, hr
 
 

@@ -914,3 +914,26 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
             assert "Done. %d clusters saved to output file." % meta["n_printed"] in r.stdout, (meta["name"], ranks, r.stdout)
             assert hashlib.sha256(open(p + ".clusters", "rb").read()).hexdigest() == meta["clusters_sha256"], (meta["name"], ranks)
             assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta), (meta["name"], ranks)
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_equals_one_rank():
+    """bench.py's N-rank path with the HIP kernels in separate processes (E2S_BENCH_REHEARSAL=1: both ranks on GPU 0, gloo instead of
+    RCCL): the SAME EGSA cut into two SA ranges (--scaling strong) gives exactly the one-rank totals -- records, records of the
+    `.clusters` file, candidates, events and the size of the `.snp` image (ids sequential over the ranks)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--workload", "c2s", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--second-workload", ""]
+    outs = []
+    for extra, env in ((["--gpus", "1"], {}), (["--gpus", "2", "--scaling", "strong"], {"E2S_BENCH_REHEARSAL": "1"})):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        outs.append(json.loads(line))
+    a, b = outs
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and a["config"]["entries_total"] == b["config"]["entries_total"]
+    for key in ("cluster_records", "clusters_file_records", "candidates", "snp_events", "snp_bytes", "max_clust_length"):
+        assert a["config"][key] == b["config"][key], key
+    assert a["config"]["snp_events"] > 1000 and a["roofline"]["frac"] > 0 and a["value"] > 0
