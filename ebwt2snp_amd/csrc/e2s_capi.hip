@@ -240,6 +240,14 @@ extern "C" int e2s_synchronize(e2s_handle h) {
 
 static bool width_ok(int w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 
+// a device staging buffer that is freed on every way out of the function that made it (the CK() early returns included)
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) hipFree(p); }
+    hipError_t alloc(size_t bytes) { if (p) { hipFree(p); p = nullptr; } return hipMalloc(&p, bytes); }
+    void release() { if (p) { hipFree(p); p = nullptr; } }
+};
+
 static int check_desc(e2s_handle h, const e2s_shard_desc* d) {
     if (!h || !d) return E2S_ERR_ARG;
     if (!width_ok(d->lcp_bytes) || !width_ok(d->da_bytes) || !width_ok(d->pos_bytes))
@@ -315,25 +323,23 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
     if ((rc = dev_alloc(h, &h->da, n * h->yb))) return rc;
     CK(hipMemcpyAsync(h->bwt, bwt, n, hipMemcpyHostToDevice, h->stream));
-    void* stage = nullptr;
+    DevScratch stage8, stage;
     if (d->lcp_bytes == 8) {
-        CK(hipMalloc(&stage, n * 8));
-        CK(hipMemcpyAsync(stage, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
-        e2s_launch_narrow8((const uint8_t*)stage, n, (uint32_t*)h->lcp, h->stream);
+        CK(stage8.alloc(n * 8));
+        CK(hipMemcpyAsync(stage8.p, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        e2s_launch_narrow8((const uint8_t*)stage8.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
-        CK(hipStreamSynchronize(h->stream));
-        CK(hipFree(stage));
     } else {
         CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
     }
     const size_t rec = (size_t)d->pos_bytes + d->da_bytes;
-    CK(hipMalloc(&stage, n * rec + 16));
-    CK(hipMemcpyAsync(stage, pairsa, n * rec, hipMemcpyHostToDevice, h->stream));
-    e2s_launch_unpack_pairsa((const uint8_t*)stage, n, d->pos_bytes, d->da_bytes, h->pos, h->zb, h->da, h->yb, h->stream);
+    CK(stage.alloc(n * rec + 16));
+    CK(hipMemcpyAsync(stage.p, pairsa, n * rec, hipMemcpyHostToDevice, h->stream));
+    e2s_launch_unpack_pairsa((const uint8_t*)stage.p, n, d->pos_bytes, d->da_bytes, h->pos, h->zb, h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_pairsa");
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
-    CK(hipFree(stage));
+    stage.release(); stage8.release();
     CK(hipGetLastError());
     hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
     return narrow_lcp(h);
@@ -355,15 +361,15 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
     if ((rc = dev_alloc(h, &h->da, n * h->yb))) return rc;
     const size_t rec = (size_t)d->da_bytes + d->pos_bytes + d->lcp_bytes + 1;
-    void* stage = nullptr;
-    CK(hipMalloc(&stage, n * rec + 16));
-    CK(hipMemcpyAsync(stage, aos, n * rec, hipMemcpyHostToDevice, h->stream));
-    e2s_launch_unpack_gesa((const uint8_t*)stage, n, d->da_bytes, d->pos_bytes, d->lcp_bytes, h->bwt, h->lcp, h->xb, h->pos, h->zb,
+    DevScratch stage;
+    CK(stage.alloc(n * rec + 16));
+    CK(hipMemcpyAsync(stage.p, aos, n * rec, hipMemcpyHostToDevice, h->stream));
+    e2s_launch_unpack_gesa((const uint8_t*)stage.p, n, d->da_bytes, d->pos_bytes, d->lcp_bytes, h->bwt, h->lcp, h->xb, h->pos, h->zb,
                            h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_gesa");
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
-    CK(hipFree(stage));
+    stage.release();
     CK(hipGetLastError());
     hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
     return narrow_lcp(h);
@@ -399,14 +405,14 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
     const uint64_t n = h->n_prov;
     CK(hipEventRecord(h->ev[0], h->stream));
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
+    DevScratch stage;
     if (d->lcp_bytes == 8) {
-        void* stage = nullptr;
-        CK(hipMalloc(&stage, n * 8));
-        CK(hipMemcpyAsync(stage, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
-        e2s_launch_narrow8((const uint8_t*)stage, n, (uint32_t*)h->lcp, h->stream);
+        CK(stage.alloc(n * 8));
+        CK(hipMemcpyAsync(stage.p, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        e2s_launch_narrow8((const uint8_t*)stage.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
         CK(hipStreamSynchronize(h->stream));
-        CK(hipFree(stage));
+        stage.release();
     } else {
         CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
     }
@@ -908,8 +914,9 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
     if (rc) return rc;
     if (n_records) {
         // the file image goes up as it is; unpacking and the ordering check (H16) run on the GPU
-        void* stage = nullptr;
-        CK(hipMalloc(&stage, n_records * 10 + 16));
+        DevScratch sg;
+        CK(sg.alloc(n_records * 10 + 16));
+        void* stage = sg.p;
         hipError_t e1 = hipMemcpyAsync(stage, recs, n_records * 10, hipMemcpyHostToDevice, h->stream);
         if (e1 == hipSuccess) e1 = hipMemsetAsync(h->d_words + 1, 0, 4, h->stream);
         if (e1 == hipSuccess) {
@@ -917,9 +924,8 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
             uint32_t* mb = (uint32_t*)(h->pin_mail + 3072);
             e1 = hipMemcpyAsync(mb, h->d_words + 1, 4, hipMemcpyDeviceToHost, h->stream);
             if (e1 == hipSuccess) e1 = hipStreamSynchronize(h->stream);
-            if (e1 == hipSuccess && (*mb & 1u)) { hipFree(stage); return fail(h, E2S_ERR_INPUT, ".clusters records must be ascending and non-overlapping (H16)"); }
+            if (e1 == hipSuccess && (*mb & 1u)) return fail(h, E2S_ERR_INPUT, ".clusters records must be ascending and non-overlapping (H16)");
         }
-        hipFree(stage);
         CK(e1);
     }
     h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;

@@ -1129,20 +1129,27 @@ __device__ __forceinline__ void cluster_record(const CandArgs& a, const u64 s, c
             }
             const u32 e0 = min(n0, a.list_cap), e1 = min(n1, a.list_cap);  // size() < consensus_reads (:458,469)
             if (e0 > 0 && e1 > 0) {                                        // :478
-                uint8_t* rec = alloc(lane);
-                if (rec) {
+                // the candidate in its packed form (include/e2s_hip.h, e2s_candidates_packed), written where `alloc` says:
+                //   u32 n0, n1, right_idx, right_pos | idx0[n0] | idx1[n1] | pos0[n0] | pos1[n1] (pos_pack bytes each) | zero padding to 8 bytes
+                const u32 size8 = (16u + (4u + a.pos_pack) * (e0 + e1) + 7u) >> 3;
+                u32* w = alloc(lane, size8, (key << 2) | (u64)(pair & 3u));
+                if (w) {
                     if (lane == 0) {
-                        CandHeader* h = (CandHeader*)rec;
-                        h->record_index = key;
-                        h->pair_index = pair; h->n0 = e0; h->n1 = e1;
-                        h->right_idx = best_text; h->right_pos = best_suff; h->reserved = 0;
+                        ((u64*)w)[size8 - 1u] = 0ull;                          // (the padding; list entries that share the unit follow in program order)
+                        w[0] = e0; w[1] = e1; w[2] = best_text; w[3] = best_suff;
                     }
-                    u32* l = (u32*)(rec + sizeof(CandHeader));
+                    __builtin_amdgcn_wave_barrier();
+                    uint8_t* const pb = (uint8_t*)(w + 4u + e0 + e1);
+                    auto put_pos = [&](u32 at, u32 v) {
+                        if (a.pos_pack == 1u) pb[at] = (uint8_t)v;
+                        else if (a.pos_pack == 2u) { pb[2u * at] = (uint8_t)v; pb[2u * at + 1u] = (uint8_t)(v >> 8); }
+                        else { pb[4u * at] = (uint8_t)v; pb[4u * at + 1u] = (uint8_t)(v >> 8); pb[4u * at + 2u] = (uint8_t)(v >> 16); pb[4u * at + 3u] = (uint8_t)(v >> 24); }
+                    };
 #pragma unroll
                     for (int c = 0; c < MAXCH; ++c) {
                         if (c < nch) {
-                            if (m0[c] && rk0[c] < a.list_cap) { l[rk0[c]] = text[c]; l[a.list_cap + rk0[c]] = suff[c] - a.k_left_lo; }
-                            if (m1[c] && rk1[c] < a.list_cap) { l[2 * a.list_cap + rk1[c]] = text[c]; l[3 * a.list_cap + rk1[c]] = suff[c] - a.k_left_lo; }
+                            if (m0[c] && rk0[c] < a.list_cap) { w[4u + rk0[c]] = text[c]; put_pos(rk0[c], suff[c] - a.k_left_lo); }
+                            if (m1[c] && rk1[c] < a.list_cap) { w[4u + e0 + rk1[c]] = text[c]; put_pos(e0 + rk1[c], suff[c] - a.k_left_lo); }
                         }
                     }
                 }
@@ -1152,19 +1159,23 @@ __device__ __forceinline__ void cluster_record(const CandArgs& a, const u64 s, c
     }
 }
 
-constexpr int FW_STAGE = 32;                 // candidates staged in LDS before one global slot reservation
-
+constexpr int FW_STAGE = 256;                // candidates a block stages in LDS (packed) before one global reservation
+// a block's staging area for packed candidates: [s_used, 8-byte units) of the dynamic buffer; one LDS atomic per candidate
 struct StageAlloc {
-    uint8_t* stage; u32* n; u32 stride;
-    __device__ __forceinline__ uint8_t* operator()(u32 lane) const {
-        u32 slot = 0;
-        if (lane == 0) slot = atomicAdd(n, 1u);
-        slot = (u32)__shfl((int)slot, 0);
-        return slot < FW_STAGE ? stage + (size_t)slot * stride : nullptr;
+    uint8_t* buf; u32 cap8; u32* used8; u32* n; u64* keys; u32* offs;
+    __device__ __forceinline__ u32* operator()(u32 lane, u32 size8, u64 key) const {
+        u32 off = 0xFFFFFFFFu;
+        if (lane == 0) {
+            const u32 slot = atomicAdd(n, 1u);
+            const u32 o = atomicAdd(used8, size8);
+            if (slot < (u32)FW_STAGE && o + size8 <= cap8) { keys[slot] = key; offs[slot] = o; off = o; }
+        }
+        off = (u32)__shfl((int)off, 0);
+        return off != 0xFFFFFFFFu ? (u32*)(buf + (size_t)off * 8) : nullptr;   // (never null: the kernel flushes while a round's worst case still fits)
     }
 };
 
-extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // FW_STAGE candidate records (k_flagged_lists)
+extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];   // packed candidates of a block (k_flagged_lists)
 
 // ----------------------------------------------------------------------------------------------
 // K2a, second formulation: the same pre-filter built like the scan kernel.  Every wave is a worker over a
@@ -1397,96 +1408,42 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
 //   u32 n0, n1, right_idx, right_pos | u32 idx0[n0] | u32 idx1[n1] | pos0[n0] | pos1[n1] (pw bytes each) | pad to 8 bytes
 // built from a fixed-stride record [CandHeader][idx0[cap]][pos0[cap]][idx1[cap]][pos1[cap]] by the 64 lanes of a wave.
 __device__ __forceinline__ u32 packed_size8(u32 n0, u32 n1, u32 pw) { return (16u + (4u + pw) * (n0 + n1) + 7u) >> 3; }
-__device__ __forceinline__ void pack_record(const u32* hs, u32 list_cap, u32 pw, u32* dst, u32 lane) {
-    constexpr u32 HW = sizeof(CandHeader) / 4;
-    const u32 n0 = hs[3], n1 = hs[4], n = n0 + n1;
-    const u32* l = hs + HW;
-    const u32 words = 2u * packed_size8(n0, n1, pw);
-    const u32 per = 4u / pw;                                   // positions per output word
-    for (u32 w = lane; w < words; w += 64u) {
-        u32 v = 0;
-        if (w < 4u) v = hs[3u + w];                             // n0, n1, right_idx, right_pos
-        else if (w < 4u + n) { const u32 t = w - 4u; v = t < n0 ? l[t] : l[2u * list_cap + (t - n0)]; }
-        else {
-            const u32 q = (w - 4u - n) * per;
-            for (u32 j = 0; j < per; ++j) {
-                const u32 e = q + j;
-                if (e < n) {
-                    const u32 pv = e < n0 ? l[list_cap + e] : l[3u * list_cap + (e - n0)];
-                    v |= (pw == 4u ? pv : (pv & ((1u << (8u * pw)) - 1u))) << (8u * pw * j);
-                }
-            }
-        }
-        dst[w] = v;
-    }
-}
-
 // K2b: lists and candidate records (clust2snp.cpp:431-496) for the few clusters K2a let through.  Persistent
 // blocks, one wave per cluster, candidates staged in LDS so that a block reserves output slots ~once per 32.
 template <bool DEF>
-__global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigned long long* lo_dev, const unsigned long long* n_dev) {
-    __shared__ u32 s_nstage;
+__global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigned long long* lo_dev, const unsigned long long* n_dev, u32 cap8) {
+    __shared__ u32 s_nstage, s_used8;
     __shared__ u64 s_gbase, s_sbase;
-    __shared__ u32 s_off8[FW_STAGE];
+    __shared__ u64 s_keys[FW_STAGE];
+    __shared__ u32 s_offs[FW_STAGE];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) s_nstage = 0;
+    if (tid == 0) { s_nstage = 0; s_used8 = 0; }
     __syncthreads();
+    // a round adds at most 4 waves x 4 pairs of the largest record: flush while that still fits
+    const u32 max8 = (16u + (4u + a.pos_pack) * 2u * a.list_cap + 7u) >> 3;
     auto stage_flush = [&]() {
-        const u32 n = min(s_nstage, (u32)FW_STAGE);
-        if (n && a.host_stream) {
-            // packed mode: [header][idx0[n0]][pos0[n0]][idx1[n1]][pos1[n1]] straight into pinned host memory -- the
-            // transfer runs under the rest of this kernel and the ordering pass instead of after them
+        const u32 n = min(s_nstage, (u32)FW_STAGE), used = min(s_used8, cap8);
+        if (n) {
+            // ONE reservation of slots and of stream space per flush (global atomics on one word saturate at ~90 per microsecond:
+            // with 32 fixed-stride records per flush they were half of this kernel's time), then the block's chunk leaves in 8-byte units
             if (tid == 0) {
-                u32 run = 0;
-                for (u32 i = 0; i < n; ++i) {
-                    const CandHeader* hd = (const CandHeader*)(s_stage + (size_t)i * a.stride);
-                    s_off8[i] = run;
-                    run += packed_size8(hd->n0, hd->n1, a.pos_pack);
-                }
                 s_gbase = atomicAdd(a.cand_count, (unsigned long long)n);
-                s_sbase = atomicAdd(a.stream8_count, (unsigned long long)run);
+                s_sbase = atomicAdd(a.stream8_count, (unsigned long long)used);
             }
             __syncthreads();
             const u64 gbase = s_gbase, sbase = s_sbase;
-            // pack the staged records side by side in LDS (second half of the dynamic buffer), then move the block's
-            // whole chunk to the host with 8-byte stores, 512 contiguous bytes per wave instruction
-            u32* const s_pack = (u32*)(s_stage + (size_t)FW_STAGE * a.stride);
-            for (u32 i = wave; i < n; i += 4) {
-                const u32* hs = (const u32*)(s_stage + (size_t)i * a.stride);
-                const CandHeader* hd = (const CandHeader*)hs;
-                pack_record(hs, a.list_cap, a.pos_pack, s_pack + 2u * s_off8[i], lane);
+            for (u32 i = tid; i < n; i += 256u) {
                 const u64 slot = gbase + i;
-                if (lane == 0 && slot < a.cand_cap) {
-                    a.slot_off8[slot] = (u32)(sbase + s_off8[i]);
-                    a.cand_keys[slot] = (hd->record_index << 2) | (u64)(hd->pair_index & 3u);
-                }
+                if (slot < a.cand_cap) { a.slot_off8[slot] = (u32)(sbase + s_offs[i]); a.cand_keys[slot] = s_keys[i]; }
             }
-            __syncthreads();
-            {
-                const CandHeader* hl = (const CandHeader*)(s_stage + (size_t)(n - 1) * a.stride);
-                const u32 run8 = s_off8[n - 1] + packed_size8(hl->n0, hl->n1, a.pos_pack);         // chunk length in 8-byte units
-                if (gbase + n <= a.cand_cap && sbase + run8 <= a.stream8_cap) {
-                    uint2* dst = (uint2*)(a.host_stream + sbase * 8);
-                    const uint2* src = (const uint2*)s_pack;
-                    for (u32 w = tid; w < run8; w += 256) dst[w] = src[w];
-                }
-            }
-        } else if (n) {
-            if (tid == 0) s_gbase = atomicAdd(a.cand_count, (unsigned long long)n);
-            __syncthreads();
-            const u64 gbase = s_gbase;
-            const u32 q = a.stride / 16;
-            for (u32 i = tid; i < n * q; i += 256) {
-                const u64 slot = gbase + i / q;
-                if (slot < a.cand_cap) ((uint4*)(a.cand_buf + slot * a.stride))[i % q] = ((const uint4*)s_stage)[i];
-            }
-            for (u32 i = tid; i < n; i += 256) {                    // SA-order key of each slot, contiguous for the ordering pass
-                const CandHeader* hd = (const CandHeader*)(s_stage + (size_t)i * a.stride);
-                if (gbase + i < a.cand_cap) a.cand_keys[gbase + i] = (hd->record_index << 2) | (u64)(hd->pair_index & 3u);
+            if (gbase + n <= a.cand_cap && sbase + used <= a.stream8_cap) {
+                uint2* dst = (uint2*)(a.host_stream + sbase * 8);
+                const uint2* src = (const uint2*)s_stage;
+                for (u32 w = tid; w < used; w += 256u) dst[w] = src[w];
             }
         }
         __syncthreads();
-        if (tid == 0) s_nstage = 0;
+        if (tid == 0) { s_nstage = 0; s_used8 = 0; }
         __syncthreads();
     };
     const u64 n = min((u64)*n_dev, a.n_rec);                     // this launch handles list entries [*lo_dev, *n_dev)
@@ -1498,7 +1455,7 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
     { const u64 r0 = first + (u64)blockIdx.x * 4 + wave; if (r0 < n) { s_nx = a.starts[r0]; len_nx = (int)a.lens[r0]; } }
     for (u64 base = first + (u64)blockIdx.x * 4; base < n; base += per_round) {
         // (flushing earlier to start the PCIe stream sooner was tried: chunks of ~8 records ran 25 % slower)
-        if (s_nstage > FW_STAGE - 16) stage_flush();                // a round adds at most 4 x 4 candidates
+        if (s_nstage > (u32)FW_STAGE - 16u || s_used8 + 16u * max8 > cap8) stage_flush();
         const u64 r = base + wave;
         const u64 s = s_nx; const int len = len_nx;
         { const u64 rn = r + per_round; if (rn < n) { s_nx = a.starts[rn]; len_nx = (int)a.lens[rn]; } }
@@ -1510,7 +1467,7 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
             // entries must be resident (index n_total being the EOF phantom): a record from a broken list must not fault
             if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull) || len < 1 || len > 3 * 64) {
                 if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
-            } else cluster_record<DEF>(a, s, len, s, lane, StageAlloc{s_stage, &s_nstage, a.stride});
+            } else cluster_record<DEF>(a, s, len, s, lane, StageAlloc{s_stage, cap8, &s_used8, &s_nstage, s_keys, s_offs});
         }
         __syncthreads();
     }
@@ -1860,13 +1817,20 @@ void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst,
     hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(64), 0, st, src, dst);
 }
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
-    const size_t dyn = (size_t)2 * FW_STAGE * a.stride;          // staged records + their packed image
+    // room for two rounds' worst case and, at usual list lengths, ~200 packed candidates between two global reservations
+    const uint32_t max8 = (16u + (4u + a.pos_pack) * 2u * a.list_cap + 7u) >> 3;
+    const uint32_t cap8 = std::max<uint32_t>(3072u, 2u * 16u * max8);
+    const size_t dyn = (size_t)cap8 * 8;
     static const int env_blocks = getenv("E2S_K2B_BLOCKS") ? atoi(getenv("E2S_K2B_BLOCKS")) : 0;
     // c2 (2x10^4 flagged clusters): 512 / 1024 / 2048 / 4096 blocks -> 0.124 / 0.117 / 0.131 / 0.177 ms for the phase; c3 (3x10^5): 1024 / 4096 ->
     // 0.889 / 0.845 ms: the caller asks for more blocks when it expects many clusters
     const unsigned blocks = env_blocks > 0 ? (unsigned)env_blocks : (a.blocks_hint ? a.blocks_hint : 1024u);
-    if (def_widths) hipLaunchKernelGGL((k_flagged_lists<true>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev);
-    else hipLaunchKernelGGL((k_flagged_lists<false>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev);
+    if (dyn > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_flagged_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipFuncSetAttribute((const void*)k_flagged_lists<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    }
+    if (def_widths) hipLaunchKernelGGL((k_flagged_lists<true>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev, cap8);
+    else hipLaunchKernelGGL((k_flagged_lists<false>), dim3(blocks), dim3(256), dyn, st, a, lo_dev, n_dev, cap8);
 }
 void e2s_launch_unpack_pairsa(const uint8_t* src, u64 n, int zf, int yf, void* pos, int zb, void* da, int yb, hipStream_t st) {
     if (!n) return;

@@ -41,17 +41,17 @@ __device__ __forceinline__ u32 tl_pos(const uint8_t* p, u32 pw, u32 j) {
 // fetched one item at a time: lane j fetches list entry j and its read's start / length (one round trip for the whole list),
 // then the n x k_left characters of an allele's left contexts are gathered by all 64 lanes at once into LDS (rows of 64
 // bytes, 64 / kw rows per wave instruction, kw = k_left rounded up to a power of two), and consensus and supports run on LDS.
-// Dynamic LDS per wave: list_cap rows of 64 B + list_cap x (8 + 4) B of row bases / lengths.
+// Dynamic LDS per wave: 2 x list_cap rows of 64 B + (8 + 4) B of row base / length each.
 extern __shared__ __attribute__((aligned(16))) uint8_t s_tail[];
 __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32 kw_shift) {
     __shared__ uint8_t s_ab[4][2][128];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
     const u64 c = (u64)blockIdx.x * 4 + wave;
     if (c >= a.n_cand) return;
-    const size_t per_wave = (size_t)list_cap * (64 + 8 + 4);
-    uint8_t* const ctx = s_tail + wave * per_wave;                  // [list_cap][64]
-    u64* const rbase = (u64*)(ctx + (size_t)list_cap * 64);         // text offset of row j's first character
-    u32* const rhave = (u32*)(rbase + list_cap);                    // characters of row j that exist (the rest read as 0)
+    const size_t per_wave = (size_t)2 * list_cap * (64 + 8 + 4);
+    uint8_t* const ctx = s_tail + wave * per_wave;                  // [2 * list_cap][64]: allele 0's rows, then allele 1's
+    u64* const rbase = (u64*)(ctx + (size_t)2 * list_cap * 64);     // text offset of row j's first character
+    u32* const rhave = (u32*)(rbase + 2 * list_cap);                // characters of row j that exist (the rest read as 0)
     const uint8_t* r = a.stream + (size_t)a.off8[c] * 8;
     const u32* w = (const u32*)r;
     const u32 n0 = w[0], n1 = w[1], right_idx = w[2], right_pos = w[3];
@@ -61,36 +61,40 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32
     u32 supp[2] = {0u, 0u};
     u32 bad = 0;
     const u32 kw = 1u << kw_shift, rows_per = 64u >> kw_shift, row_of = lane >> kw_shift, col = lane & (kw - 1u);
+    // rows 0 .. n0-1: allele 0, rows n0 .. n0+n1-1: allele 1 -- both gathered in ONE sweep (the lists lie side by side in the record)
+    const u32 m0 = min(n0, list_cap), m1 = min(n1, list_cap), nrows = m0 + m1;
+    const u32* idx = w + 4;
+    const uint8_t* pp = r + 16 + 4 * (size_t)(n0 + n1);
+    for (u32 j = lane; j < nrows; j += 64u) {                       // row bases: one round trip for the lists, none for the reads' index when dense
+        const u32 e = j < m0 ? j : n0 + (j - m0);                   // entry of the record (the lists are n0 / n1 long there)
+        const u32 rd = idx[e];
+        u64 base = 0; u32 have = 0;
+        if ((u64)rd >= a.n_reads) bad |= E2S_TAILERR_RANK;
+        else {
+            const u32 len = a.rstart ? a.rlen[rd] : a.stride, p0 = tl_pos(pp, a.pos_pack, e);
+            have = p0 < len ? min(len - p0, kl) : 0u;
+            base = (a.rstart ? a.rstart[rd] : (u64)rd * a.stride) + p0;
+        }
+        rbase[j] = base; rhave[j] = have;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (u32 j0 = 0; j0 < nrows; j0 += rows_per) {                  // the characters: every load of the candidate in flight together
+        const u32 j = j0 + row_of;
+        if (j < nrows) {
+            const u32 have = rhave[j];
+            ctx[(size_t)j * 64 + col] = col < have ? a.text[rbase[j] + col] : (uint8_t)0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int s = 0; s < 2; ++s) {
-        const u32 n = min(s ? n1 : n0, list_cap);
-        const u32* idx = s ? (w + 4 + n0) : (w + 4);
-        const uint8_t* pp = r + 16 + 4 * (size_t)(n0 + n1) + (s ? (size_t)a.pos_pack * n0 : 0);
-        for (u32 j = lane; j < n; j += 64u) {                       // row bases: one round trip for the list, one for the reads' index
-            const u32 rd = idx[j];
-            u64 base = 0; u32 have = 0;
-            if ((u64)rd >= a.n_reads) bad |= E2S_TAILERR_RANK;
-            else {
-                const u32 len = a.rstart ? a.rlen[rd] : a.stride, p0 = tl_pos(pp, a.pos_pack, j);
-                have = p0 < len ? min(len - p0, kl) : 0u;
-                base = (a.rstart ? a.rstart[rd] : (u64)rd * a.stride) + p0;
-            }
-            rbase[j] = base; rhave[j] = have;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (u32 j0 = 0; j0 < n; j0 += rows_per) {                  // the characters: every load of the allele in flight together
-            const u32 j = j0 + row_of;
-            if (j < n && col < 64u) {
-                const u32 have = rhave[j];
-                ctx[(size_t)j * 64 + col] = col < have ? a.text[rbase[j] + col] : (uint8_t)0;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const u32 n = s ? m1 : m0;
+        const uint8_t* rows = ctx + (size_t)(s ? m0 : 0u) * 64;
         // cons (include.hpp:334-371), one lane per column: the letter changes only on a strictly larger count (H8)
         u32 C = 'A', k0 = 0, k1 = 0, k2 = 0, k3 = 0;
         for (u32 j = 0; j < n; ++j) {
-            const u32 ch = lane < kl ? (u32)ctx[(size_t)j * 64 + lane] : 0u;
+            const u32 ch = lane < kl ? (u32)rows[(size_t)j * 64 + lane] : 0u;
             const u32 b = tl_b2i(ch), bc = tl_b2i(C);
             k0 += b == 0u; k1 += b == 1u; k2 += b == 2u; k3 += b == 3u;
             const u32 nb = b == 0u ? k0 : b == 1u ? k1 : b == 2u ? k2 : k3;
@@ -99,14 +103,13 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32
         }
         // support = contexts within max_err of the consensus (clust2snp.cpp:544-593)
         for (u32 j = 0; j < n; ++j) {
-            const u32 ch = lane < kl ? (u32)ctx[(size_t)j * 64 + lane] : 0u;
+            const u32 ch = lane < kl ? (u32)rows[(size_t)j * 64 + lane] : 0u;
             const int d = __popcll(__ballot(lane < kl && C != ch));
             if (d <= a.max_err) ++supp[s];
         }
         (s ? sb : sa)[lane] = (uint8_t)C;
         (s ? sb : sa)[64 + lane] = 0;
         if (lane < kl) a.cons[c * 128 + (u64)s * 64 + lane] = (uint8_t)C;
-        __builtin_amdgcn_wave_barrier();
     }
     bad = (u32)(__ballot(bad & E2S_TAILERR_RANK) ? E2S_TAILERR_RANK : 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -321,7 +324,7 @@ void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) 
     uint32_t kw_shift = 0;
     while ((1u << kw_shift) < (uint32_t)a.kl) ++kw_shift;          // k_left <= 64
     if (list_cap < 1) list_cap = 1;
-    const size_t lds = (size_t)4 * list_cap * (64 + 8 + 4);
+    const size_t lds = (size_t)4 * 2 * list_cap * (64 + 8 + 4);
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
     hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + 3) / 4)), dim3(256), lds, st, a, list_cap, kw_shift);

@@ -6,8 +6,8 @@
 usage: tools/profile_summary.py gpurun_out/<tag> profiles/<round> [workload]"""
 import csv, glob, json, os, sys
 
-OURS = ("k_scan", "k_seg", "k_hist", "k_cluster_filter", "k_flagged", "k_cand", "k_candidates", "k_shard", "k_apply",
-        "k_tile", "k_unpack", "k_ko")
+OURS = ("k_scan", "k_seg", "k_hist", "k_cluster_filter", "k_flagged", "k_cand", "k_apply", "k_tile", "k_unpack", "k_ko",
+        "k_pack", "k_consensus", "k_tail", "k_reads", "k_record", "k_phase", "k_lcp", "k_snapshot")
 
 
 def ours(name):
@@ -49,6 +49,15 @@ def main(src, dst, workload="c2"):
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0",
                "corrections": "counter unit KiB; FETCH_SIZE doubled on gfx950 (128-B requests tallied at 64 B)",
                "workload": workload, "kernels": pmc}, open(dst + "_pmc_traffic.json", "w"), indent=1)
+    ck = os.path.join(src, "clocks_under_load.txt")
+    if os.path.exists(ck):
+        # sclk / mclk samples taken by rocm-smi every half second while the profiled bench ran: the box's sustained clocks
+        import re
+        sc = [int(x) for x in re.findall(r"sclk clock level: \d+: \((\d+)Mhz\)", open(ck).read())]
+        mc = [int(x) for x in re.findall(r"mclk clock level: \d+: \((\d+)Mhz\)", open(ck).read())]
+        json.dump({"source": "rocm-smi --showclocks sampled every 0.5 s during the rocprofv3 --stats run", "sclk_mhz_samples": len(sc),
+                   "sclk_mhz_max": max(sc) if sc else None, "sclk_mhz_median": sorted(sc)[len(sc) // 2] if sc else None,
+                   "mclk_mhz_max": max(mc) if mc else None}, open(dst + "_clocks.json", "w"), indent=1)
     bj = os.path.join(src, "bench_under_rocprof.json")
     if os.path.exists(bj) and os.path.getsize(bj):
         open(dst + "_bench_under_rocprof.json", "w").write(open(bj).read())
