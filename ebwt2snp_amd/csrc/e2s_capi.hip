@@ -1622,7 +1622,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     if (p->k_left < 0) return E2S_ERR_REF_CRASH;                 // cons(size_t(-n)) throws in the reference
     if (p->k_left < 1 || p->k_left > 64) return fail(h, E2S_ERR_STATE, "GPU tail: -L outside 1..64 (use the host tail, e2s_snp_from_packed)");
     CK(hipSetDevice(h->device));
-    const uint64_t n = h->n_cand, ng = (n + 255) / 256;
+    const uint64_t n = h->n_cand, ng = (n + 63) / 64;
     if (n > h->tail_cap) {
         hipFree(h->d_cons); hipFree(h->d_trec); h->d_cons = nullptr; h->d_trec = nullptr; h->tail_cap = 0;
         const uint64_t c2 = n + n / 4 + 1024;
@@ -1684,7 +1684,7 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
     if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
     CK(hipSetDevice(h->device));
     if (first_id != h->snp_first_id) {                           // the text again with other ids: consensus and distance results stay
-        const uint64_t n = h->n_cand, ng = (n + 255) / 256;
+        const uint64_t n = h->n_cand, ng = (n + 63) / 64;
         unsigned long long* part_raw = h->d_part; unsigned long long* part_excl = h->d_part + 3 * (h->part_cap + 1);
         unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);
         TailArgs a{};

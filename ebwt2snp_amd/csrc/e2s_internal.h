@@ -149,7 +149,7 @@ struct TailArgs {
     int kl, kr, max_gap, max_err;
     uint8_t* cons;             // [n_cand][2][64] consensus strings
     TailRec* rec;              // [n_cand]
-    unsigned long long* part;  // [groups of 256 candidates][2]: events, text bytes without id digits
+    unsigned long long* part;  // [groups of 64 candidates][3]: events, text bytes without id digits, candidates kept
     unsigned long long* n_keep;
     uint32_t* err;
 };

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32
         TailRec t;
         t.emit = emit ? 1u : 0u; t.L = L; t.s0 = supp[0]; t.s1 = supp[1]; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
         a.rec[c] = t;
-        // (per group of 256 candidates: one counter for the whole job saturates at ~90 atomics per microsecond -- 3 ms for 2.6x10^5 waves)
-        if (keep) atomicAdd(&a.part[3 * (c >> 8) + 2], 1ull);
-        if (emit) { atomicAdd(&a.part[3 * (c >> 8)], 1ull); atomicAdd(&a.part[3 * (c >> 8) + 1], (u64)t.base_len); }
+        // (per group of 64 candidates: one counter for the whole job saturates at ~90 atomics per microsecond -- 3 ms for 2.6x10^5 waves)
+        if (keep) atomicAdd(&a.part[3 * (c >> 6) + 2], 1ull);
+        if (emit) { atomicAdd(&a.part[3 * (c >> 6)], 1ull); atomicAdd(&a.part[3 * (c >> 6) + 1], (u64)t.base_len); }
         if (bad) atomicOr(a.err, bad);
     }
 }
@@ -209,53 +209,40 @@ __device__ __forceinline__ u32 tl_put_num(uint8_t* b, u32 at, u64 v) {
     return at + d;
 }
 
-// A block takes a group of 256 candidates (the unit of the scan): 256 threads rank its events, then its 16 waves write 16
-// candidates each -- an event is a chain of dependent steps (consensus letters -> header text -> stores), and short chains on
-// many waves are what hides their latency (four waves of 64 candidates each took 0.63 ms for 2.6x10^5 events).
+// A block takes a group of 64 candidates (the unit of the scan of event counts and text lengths): each of its 16 waves ranks the
+// group's events for itself (ballot + shuffles, no LDS, no barrier) and writes four of the candidates -- an event is a chain of
+// dependent steps (consensus letters -> header text -> stores), and short chains on many waves are what hides their latency
+// (four waves of 64 candidates each took 0.63 ms for 2.6x10^5 events, sixteen of 16 each 0.42 ms).
 __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, uint8_t* out, u64 out_cap) {
-    __shared__ u32 s_we[4], s_wb[4];
-    __shared__ u64 s_rank[256], s_off[256];
-    __shared__ TailRec s_rec[256];
     __shared__ uint8_t s_hdr[16][2][128];
     __shared__ uint8_t s_cab[16][2][64];
-    const u32 tid = threadIdx.x, lane = tl_lane(), wave = tid >> 6;
+    const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
     const u64 g = blockIdx.x;
-    if (tid < 256) {
-        const u64 c = g * 256 + tid;
-        TailRec t; t.emit = 0; t.base_len = 0; t.L = 0; t.s0 = t.s1 = t.right_len = 0; t.right_at = 0;
+    TailRec t; t.emit = 0; t.base_len = 0; t.L = 0; t.s0 = t.s1 = t.right_len = 0; t.right_at = 0;
+    {
+        const u64 c = g * 64 + lane;
         if (c < a.n_cand) t = a.rec[c];
-        // exclusive scan of (emit, base_len) inside the group: inside the wave by ballot / shuffles, then across the four waves
-        const u64 em = __ballot(t.emit != 0u);
-        const u32 e_before = (u32)__popcll(em & ((1ull << lane) - 1ull));
-        const u32 bl = t.emit ? t.base_len : 0u;
-        u32 incl = bl;
-        for (u32 d = 1; d < 64; d <<= 1) { const u32 v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-        if (lane == 63) { s_we[wave] = (u32)__popcll(em); s_wb[wave] = incl; }
-        s_rec[tid] = t;
-        s_rank[tid] = e_before; s_off[tid] = incl - bl;
     }
-    __syncthreads();
-    if (tid < 256) {
-        u32 we = 0, wb = 0;
-        for (u32 q = 0; q < wave; ++q) { we += s_we[q]; wb += s_wb[q]; }
-        const u64 rank = part_excl[2 * g] + we + s_rank[tid];       // events before this one
-        s_rank[tid] = rank;
-        s_off[tid] = part_excl[2 * g + 1] + wb + s_off[tid] + 2ull * (tl_digit_sum_below(first_id + rank) - tl_digit_sum_below(first_id));
-    }
-    __syncthreads();
+    // exclusive scan of (emit, base_len) inside the group
+    const u64 em = __ballot(t.emit != 0u);
+    const u32 e_before = (u32)__popcll(em & ((1ull << lane) - 1ull));
+    const u32 bl = t.emit ? t.base_len : 0u;
+    u32 incl = bl;
+    for (u32 d = 1; d < 64; d <<= 1) { const u32 v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    const u64 my_rank = part_excl[2 * g] + e_before;                // events before this one
+    const u64 my_off = part_excl[2 * g + 1] + (incl - bl) + 2ull * (tl_digit_sum_below(first_id + my_rank) - tl_digit_sum_below(first_id));
     const u32 kl = (u32)a.kl;
     uint8_t* const h1 = s_hdr[wave][0];
     uint8_t* const h3 = s_hdr[wave][1];
     uint8_t* const la = s_cab[wave][0];
     uint8_t* const lb = s_cab[wave][1];
-    for (u32 k = 0; k < 16; ++k) {
-        const u32 ci = wave * 16 + k;
-        const TailRec t = s_rec[ci];
-        if (!t.emit) continue;                                      // (wave-uniform)
-        const u64 c2 = g * 256 + ci;
-        const int L = t.L;
-        const u32 s0 = t.s0, s1 = t.s1, rl = t.right_len;
-        const u64 rat = t.right_at, o = s_off[ci], id = first_id + s_rank[ci];
+    for (u32 k = 0; k < 4; ++k) {
+        const int src = (int)(wave * 4 + k);
+        if (!((em >> src) & 1ull)) continue;                        // (wave-uniform)
+        const u64 c2 = g * 64 + (u64)src;
+        const int L = __shfl(t.L, src);
+        const u32 s0 = __shfl(t.s0, src), s1 = __shfl(t.s1, src), rl = __shfl(t.right_len, src);
+        const u64 rat = __shfl(t.right_at, src), o = __shfl(my_off, src), id = first_id + __shfl(my_rank, src);
         const uint8_t* ca = a.cons + c2 * 128;
         const uint8_t* cbp = ca + 64;
         const u32 ach = lane < kl ? (u32)ca[lane] : 0u, bch = lane < kl ? (u32)cbp[lane] : 0u;   // the two consensus strings, one letter per lane
@@ -336,5 +323,5 @@ void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, uint8_t* out, unsigned long long out_cap,
                            hipStream_t st) {
     if (!a.n_cand) return;
-    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)((a.n_cand + 255) / 256)), dim3(1024), 0, st, a, part_excl, first_id, out, out_cap);
+    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)((a.n_cand + 63) / 64)), dim3(1024), 0, st, a, part_excl, first_id, out, out_cap);
 }
