@@ -35,16 +35,41 @@ int snippet_clust2snp(e2s_handle h, e2s_shard_desc d, const void* bwt, const voi
     int max_clust_length; uint64_t n_clust, n_bases;
 // [snippet 2: clust2snp.cpp]
 e2s_upload_bcr(h, &d, bwt, lcp, pairsa);        // or e2s_upload_gesa(h, &d, gesa)
+e2s_upload_reads_fasta(h, input.c_str(), NULL);  // get_reads once, for all reads: they stay in HBM (E2S_ERR_INPUT: irregular FASTA, the host tail decides)
 e2s_load_clusters(h, clusters_bytes, n_records); // the .clusters file as is
 e2s_hist hs; e2s_cluster_hist(h, &hs);
 e2s_auto_max_clust_length(&hs, 1, mcov_out, pval, &max_clust_length, &n_clust, &n_bases);   // :936-946 incl. the H4 double count
 e2s_c2s_params p = {nr_reads1, k_left, k_right, mcov_out, consensus_reads, max_clust_length, 0};
 uint64_t n_cand; e2s_find_candidates(h, &p, 0, &n_cand);        // find_events + find_variants (:788-857, :367-500)
-const void* stream; const uint32_t* off8; uint64_t bytes; uint32_t pos_bytes;
-e2s_candidates_packed(h, &stream, &off8, &n_cand, &bytes, &pos_bytes);   // pinned host memory written by the GPU: packed, SA order
 e2s_tail_params t = {k_left, k_right, max_gap, max_err};
 uint64_t nv, ne;
-e2s_snp_from_packed(stream, off8, n_cand, pos_bytes, &t, input.c_str(), filename_out.c_str(), &nv, &ne);   // :505-780
+e2s_write_snp(h, &t, input.c_str(), filename_out.c_str(), &nv, &ne);   // extract_variants + to_file (:505-780): on the GPU, or the host tail where only it applies
 // [end]
+    {
+// [snippet 3: the host tail]
+const void* stream; const uint32_t* off8; uint64_t bytes; uint32_t pos_bytes;
+e2s_candidates_packed(h, &stream, &off8, &n_cand, &bytes, &pos_bytes);   // host memory: packed, SA order
+e2s_snp_from_packed(stream, off8, n_cand, pos_bytes, &t, input.c_str(), filename_out.c_str(), &nv, &ne);   // :505-780 on the host
+// [end]
+    }
     return (int)(nv + ne);
+}
+
+int snippet_chunked(const uint8_t* bwt_bytes, const uint8_t* lcp_bytes, const uint8_t* pairsa_bytes, int lcp, int da, int pos, int k, int min_len, uint64_t n,
+                    e2s_byte_sink sink, void* sink_user) {
+// [snippet 4: inputs of any size]
+struct Mapped { const uint8_t *bwt, *lcp, *pairsa; int x, y, z; };          // the three BCR files, memory-mapped
+auto get = [](void* user, int, uint64_t lo, uint64_t, int, const void** bwt, const void** lcp, const void** pairsa, const void**) -> int {
+    const Mapped* m = (const Mapped*)user;
+    *bwt = m->bwt + lo; *lcp = m->lcp + lo * m->x; *pairsa = m->pairsa + lo * (m->y + m->z);
+    return 0;
+};
+Mapped files = {bwt_bytes, lcp_bytes, pairsa_bytes, lcp, da, pos};
+e2s_egsa_source src = {get, NULL, &files, 0, 0};
+e2s_chunk_params cp = {0, k, min_len, lcp, da, pos, n, 0};      // device 0, chunk size: the library's default
+e2s_job_report rep;
+e2s_ebwt2clust_chunked(&cp, &src, sink, sink_user, &rep);       // sink: int (*)(void*, const void*, size_t) -- write(2) in bin/ebwt2clust
+cout << "Done. " << (unsigned)rep.n_closed << " clusters saved to output file." << endl;
+// [end]
+    return 0;
 }
