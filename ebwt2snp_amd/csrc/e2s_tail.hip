@@ -41,16 +41,16 @@ __device__ __forceinline__ u32 tl_pos(const uint8_t* p, u32 pw, u32 j) {
 // fetched one item at a time: lane j fetches list entry j and its read's start / length (one round trip for the whole list),
 // then the n x k_left characters of an allele's left contexts are gathered by all 64 lanes at once into LDS (rows of 64
 // bytes, 64 / kw rows per wave instruction, kw = k_left rounded up to a power of two), and consensus and supports run on LDS.
-// Dynamic LDS per wave: 2 x list_cap rows of 64 B + (8 + 4) B of row base / length each.
+// Dynamic LDS per wave: 2 x list_cap rows of 64 x 2 B (character | its base_to_int) + (8 + 4) B of row base / length each.
 extern __shared__ __attribute__((aligned(16))) uint8_t s_tail[];
 __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32 kw_shift) {
     __shared__ uint8_t s_ab[4][2][128];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
-    const u64 c = (u64)blockIdx.x * 4 + wave;
+    const u64 c = (u64)blockIdx.x * (blockDim.x >> 6) + wave;      // (1, 2 or 4 waves per block: long lists need the LDS)
     if (c >= a.n_cand) return;
-    const size_t per_wave = (size_t)2 * list_cap * (64 + 8 + 4);
-    uint8_t* const ctx = s_tail + wave * per_wave;                  // [2 * list_cap][64]: allele 0's rows, then allele 1's
-    u64* const rbase = (u64*)(ctx + (size_t)2 * list_cap * 64);     // text offset of row j's first character
+    const size_t per_wave = (size_t)2 * list_cap * (128 + 8 + 4);
+    uint16_t* const ctx = (uint16_t*)(s_tail + wave * per_wave);    // [2 * list_cap][64] of (character | base_to_int << 8): allele 0's rows, then allele 1's
+    u64* const rbase = (u64*)(s_tail + wave * per_wave + (size_t)2 * list_cap * 128);   // text offset of row j's first character
     u32* const rhave = (u32*)(rbase + 2 * list_cap);                // characters of row j that exist (the rest read as 0)
     const uint8_t* r = a.stream + (size_t)a.off8[c] * 8;
     const u32* w = (const u32*)r;
@@ -83,27 +83,27 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32
         const u32 j = j0 + row_of;
         if (j < nrows) {
             const u32 have = rhave[j];
-            ctx[(size_t)j * 64 + col] = col < have ? a.text[rbase[j] + col] : (uint8_t)0;
+            const u32 ch = col < have ? (u32)a.text[rbase[j] + col] : 0u;
+            ctx[(size_t)j * 64 + col] = (uint16_t)(ch | (tl_b2i(ch) << 8));   // base_to_int once per character, by all lanes at once
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int s = 0; s < 2; ++s) {
         const u32 n = s ? m1 : m0;
-        const uint8_t* rows = ctx + (size_t)(s ? m0 : 0u) * 64;
-        // cons (include.hpp:334-371), one lane per column: the letter changes only on a strictly larger count (H8)
-        u32 C = 'A', k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        const uint16_t* rows = ctx + (size_t)(s ? m0 : 0u) * 64;
+        // cons (include.hpp:334-371), one lane per column: the letter changes only on a strictly larger count (H8).  The four counts
+        // of a column live in one register, 8 bits each (a list holds at most 150 contexts).
+        u32 C = 'A', bc8 = 0u, cnt = 0u;                            // bc8 = 8 * base_to_int(C)
         for (u32 j = 0; j < n; ++j) {
-            const u32 ch = lane < kl ? (u32)rows[(size_t)j * 64 + lane] : 0u;
-            const u32 b = tl_b2i(ch), bc = tl_b2i(C);
-            k0 += b == 0u; k1 += b == 1u; k2 += b == 2u; k3 += b == 3u;
-            const u32 nb = b == 0u ? k0 : b == 1u ? k1 : b == 2u ? k2 : k3;
-            const u32 nc = bc == 0u ? k0 : bc == 1u ? k1 : bc == 2u ? k2 : k3;
-            if (nb > nc) C = ch;
+            const u32 v = lane < kl ? (u32)rows[(size_t)j * 64 + lane] : 0u;
+            const u32 ch = v & 0xFFu, b8 = (v >> 8) << 3;
+            cnt += 1u << b8;
+            if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
         }
         // support = contexts within max_err of the consensus (clust2snp.cpp:544-593)
         for (u32 j = 0; j < n; ++j) {
-            const u32 ch = lane < kl ? (u32)rows[(size_t)j * 64 + lane] : 0u;
+            const u32 ch = lane < kl ? ((u32)rows[(size_t)j * 64 + lane] & 0xFFu) : 0u;
             const int d = __popcll(__ballot(lane < kl && C != ch));
             if (d <= a.max_err) ++supp[s];
         }
@@ -311,10 +311,12 @@ void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) 
     uint32_t kw_shift = 0;
     while ((1u << kw_shift) < (uint32_t)a.kl) ++kw_shift;          // k_left <= 64
     if (list_cap < 1) list_cap = 1;
-    const size_t lds = (size_t)4 * 2 * list_cap * (64 + 8 + 4);
+    const size_t per_wave = (size_t)2 * list_cap * (128 + 8 + 4);
+    const unsigned wpb = 4 * per_wave <= 60 * 1024 ? 4u : 2 * per_wave <= 120 * 1024 ? 2u : 1u;
+    const size_t lds = wpb * per_wave;
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
-    hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + 3) / 4)), dim3(256), lds, st, a, list_cap, kw_shift);
+    hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, a, list_cap, kw_shift);
 }
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, hipStream_t st) {

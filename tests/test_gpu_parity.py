@@ -937,3 +937,27 @@ def test_bench_two_rank_rehearsal_equals_one_rank():
     for key in ("cluster_records", "clusters_file_records", "candidates", "snp_events", "snp_bytes", "max_clust_length"):
         assert a["config"][key] == b["config"][key], key
     assert a["config"]["snp_events"] > 1000 and a["roofline"]["frac"] > 0 and a["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(c=150, L=64), dict(c=45, L=1, R=5), dict(c=3, L=40, g=64, e=5), dict(c=20, L=31, R=200)])
+def test_gpu_tail_option_corners(H, tmp_path, opts):
+    """the GPU tail at the edges of its domain: the longest lists (-c 150: one wave per block for the LDS rows), -L 1 and -L 64, a
+    gap bound longer than the contexts, right contexts cut short by the read's end -- `.snp` bytes against the oracle's"""
+    reads, n1, e = synth.synth_case(4000, 100, seed=81, coverage=30)
+    en = synth.egsa_to_numpy(e)
+    out = {}
+    for tag in ("hip", "orc"):
+        os.makedirs(str(tmp_path / tag))
+        p = str(tmp_path / tag / "reads.fasta")
+        IO.write_fasta(p, reads.numpy())
+        IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+        if tag == "hip":
+            tools.ebwt2clust(p, handle=H)
+            r = tools.clust2snp(p, n1, handle=H, **opts)
+            assert r["n_candidates"] > 5
+        else:
+            assert O.ebwt2clust(p)[0] == 0
+            assert O.clust2snp(p, O.c2s_opts(n1, **opts))[0] == 0
+        out[tag] = open(IO.snp_out_path(p), "rb").read()
+    assert out["hip"] == out["orc"] and len(out["orc"]) > 1000

@@ -28,11 +28,13 @@ def case(seed, d):
     if rnd.random() < 0.5: a1 += ["-k", rnd.choice([8, 12, 20, 31])]
     if rnd.random() < 0.4: a1 += ["-m", rnd.choice([1, 3, 8])]
     a2 = list(wopt)
-    for opt, vals, pr in (("-L", [20, 25, 40], .3), ("-R", [10, 20, 45], .3), ("-m", [2, 3, 7], .4), ("-c", [4, 6, 30], .3), ("-p", [0.9, 0.5, 0.999], .3),
-                          ("-g", [0, 3, 12], .3), ("-e", [0, 1, 4], .3), ("-v", [1, 5], .2)):
+    for opt, vals, pr in (("-L", [20, 25, 40, 1, 64, 65, 80], .35), ("-R", [10, 20, 45, 200], .3), ("-m", [2, 3, 7], .4), ("-c", [4, 6, 30, 150], .3),
+                          ("-p", [0.9, 0.5, 0.999], .3), ("-g", [0, 3, 12, 70], .3), ("-e", [0, 1, 4], .3), ("-v", [1, 5], .2)):
         if rnd.random() < pr: a2 += [opt, rnd.choice(vals)]
     nn = rnd.choice([n1, n1, n1 // 2, n1 + 10])
-    return p, a1, a2, nn
+    # the executables stream the EGSA in chunks: sometimes small ones (cuts anywhere, a last chunk of a few entries)
+    chunk = rnd.choice([None, None, 5000, 20011, 70000])
+    return p, a1, a2, nn, chunk
 
 
 def outputs(p):
@@ -53,21 +55,22 @@ def norm_rc(rc):        # the reference dies by signal (SIGFPE / SIGSEGV / abort
 def run(seed):
     d = tempfile.mkdtemp(prefix="e2s_cli_")
     try:
-        p, a1, a2, nn = case(seed, d)
+        p, a1, a2, nn, chunk = case(seed, d)
+        env = dict(os.environ, E2S_CHUNK_ENTRIES=str(chunk)) if chunk else dict(os.environ)
         r1, o1 = O.ref_ebwt2clust(p, a1)
         want_cl = outputs(p)[0]
         r2, o2 = O.ref_clust2snp(p, nn, a2) if r1 == 0 else (None, "")
         want = outputs(p)
         clean(p)
-        g1 = subprocess.run([E2C, "-i", p, *map(str, a1)], capture_output=True, text=True)
+        g1 = subprocess.run([E2C, "-i", p, *map(str, a1)], capture_output=True, text=True, env=env)
         assert norm_rc(g1.returncode) == norm_rc(r1), ("ebwt2clust exit", g1.returncode, r1, a1)
         assert outputs(p)[0] == want_cl, ("clusters differ", a1)
         assert [l for l in g1.stdout.splitlines() if l.startswith("Done.")] == [l for l in o1.splitlines() if l.startswith("Done.")], "ebwt2clust stdout"
         if r1 == 0:
-            g2 = subprocess.run([C2S, "-i", p, "-n", str(nn), *map(str, a2)], capture_output=True, text=True)
+            g2 = subprocess.run([C2S, "-i", p, "-n", str(nn), *map(str, a2)], capture_output=True, text=True, env=env)
             assert norm_rc(g2.returncode) == norm_rc(r2), ("clust2snp exit", g2.returncode, r2, a2, g2.stderr[-300:])
             got = outputs(p)
-            assert got[1] == want[1], ("snp differs", a1, a2, nn, None if got[1] is None else len(got[1]), None if want[1] is None else len(want[1]))
+            assert got[1] == want[1], ("snp differs", a1, a2, nn, chunk, None if got[1] is None else len(got[1]), None if want[1] is None else len(want[1]))
         return True
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -81,6 +84,8 @@ if __name__ == "__main__":
             run(seed)
         except AssertionError as ex:
             bad += 1
-            print("SEED", seed, "FAILED", str(ex)[:400])
+            print("SEED", seed, "FAILED", str(ex)[:400], flush=True)
+        if seed % 25 == 0:
+            print("... seed", seed, flush=True)
     print("cli stress done, failures:", bad)
     sys.exit(1 if bad else 0)

@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ src, 
     };
     auto flush = [&](u32 cnt) {
         if (WM == 1 || WM == 4 || WM == 9) for (u32 r = lane; r < cnt; r += 64) { ss[run + r] = (u64)acc + r; sl[run + r] = (uint16_t)(acc + r); }
+        if (WM == 10) { uint32_t* s4 = (uint32_t*)seg; for (u32 r = lane; r < cnt; r += 64) { s4[run + r] = acc + r; sl[run + r] = (uint16_t)(acc + r); } }
+        if (WM == 11) { uint32_t* s4 = (uint32_t*)seg; for (u32 r = lane; r < cnt; r += 64) s4[run + r] = acc + r; }
         if (WM == 6) for (u32 r = lane; r < cnt; r += 64) { __builtin_nontemporal_store((u64)acc + r, &ss[run + r]); __builtin_nontemporal_store((uint16_t)(acc + r), &sl[run + r]); }
         if (WM == 2) for (u32 r = lane; r < cnt; r += 64) ((uint4*)seg)[run + r] = make_uint4(acc, r, acc, r);
         if (WM == 3 || WM == 5 || WM == 8) { const u32 q16 = (cnt * 10 + 15) / 16; for (u32 r = lane; r < q16; r += 64) ((uint4*)seg)[run * 10 / 16 + r] = make_uint4(acc, r, acc, r); }
@@ -73,7 +75,7 @@ template <int WM, int EDGE = 1> static void run(const char* name, const uint8_t*
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (it && ms < best) best = ms;
     }
-    const double wr = WM == 0 ? 0.0 : (double)n_tiles * 131 * (WM == 2 ? 16 : 10);
+    const double wr = WM == 0 ? 0.0 : (double)n_tiles * 131 * (WM == 2 ? 16 : WM == 10 ? 6 : WM == 11 ? 4 : 10);
     printf("%-62s %.4f ms  read %.0f GB/s  read+write %.0f GB/s  (as 10-B records: %.0f GB/s)\n", name, best, n / (best * 1e-3) / 1e9, (n + wr) / (best * 1e-3) / 1e9,
            (n + (WM ? (double)n_tiles * 1310 : 0.0)) / (best * 1e-3) / 1e9);
     fflush(stdout);
@@ -92,6 +94,8 @@ int main(int argc, char** argv) {
     run<1, 0>("1 u64 + u16 arrays per tile, no edge words", src, n, workers, out, seg_bytes, sink);
     run<1, 2>("1 u64 + u16 arrays per tile, edge words by the outer lanes", src, n, workers, out, seg_bytes, sink);
     run<1>("1 u64 + u16 arrays, 131 records per tile (the scan today)", src, n, workers, out, seg_bytes, sink);
+    run<10>("10 u32 + u16 arrays (6 B per record), per tile", src, n, workers, out, seg_bytes, sink);
+    run<11>("11 one u32 per record (4 B), per tile", src, n, workers, out, seg_bytes, sink);
     run<2>("2 one 16-B record, per tile", src, n, workers, out, seg_bytes, sink);
     run<3>("3 packed 10-B stream as 16-B stores, per tile", src, n, workers, out, seg_bytes, sink);
     run<4>("4 u64 + u16 arrays, every 4 tiles", src, n, workers, out, seg_bytes, sink);
