@@ -4,7 +4,7 @@ CXX     ?= g++
 ARCH    ?= gfx950
 ROCM    ?= /opt/rocm
 EXTRA   ?=
-HIPFLAGS = $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude
+HIPFLAGS = $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
 LIB      = ebwt2snp_amd/libe2s_hip.so
 CSRC     = ebwt2snp_amd/csrc
 HOST     = ebwt2snp_amd/host

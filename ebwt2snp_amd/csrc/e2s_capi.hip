@@ -101,6 +101,13 @@ struct e2s_ctx {
 
 static int fail(e2s_handle h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
 
+// Teardown and timing calls whose result cannot change what the caller does next: the result is dropped on purpose, in one place.
+static inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+static inline void pin_free(void* p) { if (p) (void)hipHostFree(p); }
+static inline void ev_destroy(hipEvent_t e) { if (e) (void)hipEventDestroy(e); }
+static inline void stream_destroy(hipStream_t s) { if (s) (void)hipStreamDestroy(s); }
+static inline void ev_ms(float* ms, hipEvent_t a, hipEvent_t b) { if (hipEventElapsedTime(ms, a, b) != hipSuccess) *ms = 0.f; }
+
 // E2S_DEBUG_SYNC=1: synchronise and check after every launch, naming the one that failed (development aid)
 static bool debug_sync() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_DEBUG_SYNC"); v = (e && *e == '1') ? 1 : 0; } return v == 1; }
 static void dbg_entry(const char* name) {
@@ -181,7 +188,7 @@ static hipError_t wait_stream(e2s_ctx* h) {
 }
 
 static void release_reads(e2s_ctx* h) {
-    if (h->reads_owned) { hipFree(h->d_text); hipFree(h->d_rstart); hipFree(h->d_rlen); }
+    if (h->reads_owned) { dev_free(h->d_text); dev_free(h->d_rstart); dev_free(h->d_rlen); }
     h->d_text = nullptr; h->d_rstart = nullptr; h->d_rlen = nullptr; h->have_reads = h->reads_owned = false; h->n_reads = 0;
 }
 
@@ -189,17 +196,24 @@ static void release_reads(e2s_ctx* h) {
 // records or the scan it was computed for makes it stale.  One that runs on the second stream is ordered before anything
 // that follows on the handle's stream, since it writes the flagged list the next one will reuse.
 static void drop_prefilter(e2s_ctx* h) {
-    if (h->pf_inflight && h->pf_on_stream2 && h->ev_pf) hipStreamWaitEvent(h->stream, h->ev_pf, 0);
+    if (h->pf_inflight && h->pf_on_stream2 && h->ev_pf && hipStreamWaitEvent(h->stream, h->ev_pf, 0) != hipSuccess)
+        (void)hipDeviceSynchronize();                           // (no ordering edge to be had: wait for everything instead)
     h->pf_inflight = false; h->pf_fused = false; h->pf_on_stream2 = false;
+}
+
+// The image of the records that may still be packing on the second stream belongs to the records being replaced: let it
+// finish (its buffers are reused) and forget it.
+static void drop_image(e2s_ctx* h) {
+    if (h->img_pending && h->ev_img && hipEventSynchronize(h->ev_img) != hipSuccess) (void)hipDeviceSynchronize();
+    h->img_valid = h->img_pending = false;
 }
 
 static void release_shard(e2s_ctx* h) {
     drop_prefilter(h);
-    for (void* p : h->owned) hipFree(p);
+    for (void* p : h->owned) dev_free(p);
     h->owned.clear();
     h->bwt = nullptr; h->lcp = h->pos = h->da = nullptr;
-    if (h->img_pending && h->ev_img) hipEventSynchronize(h->ev_img);
-    h->img_valid = h->img_pending = false;
+    drop_image(h);
     h->have_shard = false; h->attached = false; h->scanned = h->stitched = false; h->records_from_file = false; h->raw_stats_valid = false;
     h->tail_bwt_given = false; h->last_known = false;
 }
@@ -207,28 +221,28 @@ static void release_shard(e2s_ctx* h) {
 extern "C" int e2s_destroy(e2s_handle h) {
     dbg_entry("e2s_destroy");
     if (!h) return E2S_OK;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, E2S_ERR_HIP, "e2s_destroy: the handle's device cannot be selected");
+    if (h->stream) (void)hipStreamSynchronize(h->stream);      // (a failed stream is torn down all the same)
     release_shard(h);
-    hipFree(h->d_starts); hipFree(h->d_lens);
-    hipFree(h->d_scalars); hipFree(h->d_words);
-    hipFree(h->d_wrap); hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
-    if (h->pin_cand) hipHostFree(h->pin_cand);
-    if (h->pin_mail) hipHostFree(h->pin_mail);
-    hipFree(h->d_mail); hipFree(h->d_seg_desc); hipFree(h->d_seg_off); hipFree(h->d_cstarts); hipFree(h->d_clens);
-    hipFree(h->d_rank); hipFree(h->d_order); hipFree(h->d_keys); hipFree(h->d_slot_off8); hipFree(h->d_stream);
+    dev_free(h->d_starts); dev_free(h->d_lens);
+    dev_free(h->d_scalars); dev_free(h->d_words);
+    dev_free(h->d_wrap); dev_free(h->d_fl_starts); dev_free(h->d_fl_lens);
+    if (h->pin_cand) pin_free(h->pin_cand);
+    if (h->pin_mail) pin_free(h->pin_mail);
+    dev_free(h->d_mail); dev_free(h->d_seg_desc); dev_free(h->d_seg_off); dev_free(h->d_cstarts); dev_free(h->d_clens);
+    dev_free(h->d_rank); dev_free(h->d_order); dev_free(h->d_keys); dev_free(h->d_slot_off8); dev_free(h->d_stream);
     release_reads(h);
-    hipFree(h->d_cons); hipFree(h->d_trec); hipFree(h->d_part); hipFree(h->d_snp);
-    for (auto& ev : h->ev) if (ev) hipEventDestroy(ev);
-    hipFree(h->d_img); hipFree(h->d_img_scratch);
-    for (auto& p : h->pin_io) if (p) hipHostFree(p);
-    for (auto& e : h->ev_io) if (e) hipEventDestroy(e);
-    if (h->ev_wait) hipEventDestroy(h->ev_wait);
-    if (h->ev_pf) hipEventDestroy(h->ev_pf);
-    if (h->ev_img) hipEventDestroy(h->ev_img);
-    for (auto& e : h->ev_chunk) if (e) hipEventDestroy(e);
-    if (h->stream2) hipStreamDestroy(h->stream2);
-    if (h->stream) hipStreamDestroy(h->stream);
+    dev_free(h->d_cons); dev_free(h->d_trec); dev_free(h->d_part); dev_free(h->d_snp);
+    for (auto& ev : h->ev) if (ev) ev_destroy(ev);
+    dev_free(h->d_img); dev_free(h->d_img_scratch);
+    for (auto& p : h->pin_io) if (p) pin_free(p);
+    for (auto& e : h->ev_io) if (e) ev_destroy(e);
+    if (h->ev_wait) ev_destroy(h->ev_wait);
+    if (h->ev_pf) ev_destroy(h->ev_pf);
+    if (h->ev_img) ev_destroy(h->ev_img);
+    for (auto& e : h->ev_chunk) if (e) ev_destroy(e);
+    if (h->stream2) stream_destroy(h->stream2);
+    if (h->stream) stream_destroy(h->stream);
     delete h;
     return E2S_OK;
 }
@@ -243,9 +257,9 @@ static bool width_ok(int w) { return w == 1 || w == 2 || w == 4 || w == 8; }
 // a device staging buffer that is freed on every way out of the function that made it (the CK() early returns included)
 struct DevScratch {
     void* p = nullptr;
-    ~DevScratch() { if (p) hipFree(p); }
-    hipError_t alloc(size_t bytes) { if (p) { hipFree(p); p = nullptr; } return hipMalloc(&p, bytes); }
-    void release() { if (p) { hipFree(p); p = nullptr; } }
+    ~DevScratch() { if (p) dev_free(p); }
+    hipError_t alloc(size_t bytes) { if (p) { dev_free(p); p = nullptr; } return hipMalloc(&p, bytes); }
+    void release() { if (p) { dev_free(p); p = nullptr; } }
 };
 
 static int check_desc(e2s_handle h, const e2s_shard_desc* d) {
@@ -301,7 +315,7 @@ static int narrow_lcp(e2s_ctx* h) {
     CK(hipStreamSynchronize(h->stream));
     if (!h->attached) {                                         // the wide column was ours
         for (auto it = h->owned.begin(); it != h->owned.end(); ++it) if (*it == h->lcp) { h->owned.erase(it); break; }
-        hipFree(h->lcp);
+        dev_free(h->lcp);
     }
     h->lcp = nl; h->xb = 1;
     return E2S_OK;
@@ -341,7 +355,7 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     CK(hipStreamSynchronize(h->stream));
     stage.release(); stage8.release();
     CK(hipGetLastError());
-    hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
     return narrow_lcp(h);
 }
 
@@ -371,7 +385,7 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     CK(hipStreamSynchronize(h->stream));
     stage.release();
     CK(hipGetLastError());
-    hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
     return narrow_lcp(h);
 }
 
@@ -419,7 +433,7 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
     CK(hipGetLastError());
-    hipEventElapsedTime(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
     return narrow_lcp(h);
 }
 
@@ -428,7 +442,7 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
 // ---------------------------------------------------------------------------------------------
 static int ensure_records(e2s_ctx* h, uint64_t cap) {
     if (cap <= h->cap && h->d_starts) return E2S_OK;
-    hipFree(h->d_starts); hipFree(h->d_lens);
+    dev_free(h->d_starts); dev_free(h->d_lens);
     h->d_starts = nullptr; h->d_lens = nullptr; h->cap = 0;
     CK(hipMalloc((void**)&h->d_starts, (cap + 8) * sizeof(uint64_t)));
     CK(hipMalloc((void**)&h->d_lens, (cap + 8) * sizeof(uint16_t) + 64));
@@ -442,7 +456,7 @@ static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_
     if (!h->segmented) { *starts = h->d_starts; *lens = h->d_lens; return E2S_OK; }
     if (!h->compact_valid) {
         if (h->n_rec + 8 > h->ccap) {
-            hipFree(h->d_cstarts); hipFree(h->d_clens); h->d_cstarts = nullptr; h->d_clens = nullptr; h->ccap = 0;
+            dev_free(h->d_cstarts); dev_free(h->d_clens); h->d_cstarts = nullptr; h->d_clens = nullptr; h->ccap = 0;
             CK(hipMalloc((void**)&h->d_cstarts, (h->n_rec + 8) * 8));
             CK(hipMalloc((void**)&h->d_clens, (h->n_rec + 8) * 2 + 64));
             h->ccap = h->n_rec + 8;
@@ -472,8 +486,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     const e2s_shard_desc& d = h->d;
     h->k = k; h->min_len = min_len;
     h->scanned = h->stitched = false; h->records_from_file = false; h->compact_valid = false;
-    if (h->img_pending) hipEventSynchronize(h->ev_img);
-    h->img_valid = h->img_pending = false;
+    drop_image(h);
     drop_prefilter(h);                                          // (a result of an earlier scan: other k, other data)
     ++h->scan_gen;
 
@@ -528,7 +541,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         if (nb > 8192) return fail(h, E2S_ERR_STATE, "more scan workers than k_seg_fix handles");
         sa.n_blocks = (uint32_t)nb;
         if (nb + 1 > h->seg_blocks_cap) {
-            hipFree(h->d_seg_desc); hipFree(h->d_seg_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->seg_blocks_cap = 0;
+            dev_free(h->d_seg_desc); dev_free(h->d_seg_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->seg_blocks_cap = 0;
             CK(hipMalloc((void**)&h->d_seg_desc, (nb + 1) * sizeof(SegDesc)));
             CK(hipMalloc((void**)&h->d_seg_off, (nb + 2) * 8));
             h->seg_blocks_cap = (uint32_t)(nb + 1);
@@ -597,14 +610,14 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             rs.hist.last_len = rs.last_none ? 0 : buf[E2S_MAX_CLUST_LEN + 3];
             rs.min_len = min_len;
             h->raw_stats_valid = true;
-            hipEventElapsedTime(&h->tm.hist_ms, h->ev[3], h->ev[1]);     // k_seg_fix + the statistics
+            ev_ms(&h->tm.hist_ms, h->ev[3], h->ev[1]);     // k_seg_fix + the statistics
         }
     }
     h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
     h->tail_lcp = mail.tail_lcp; h->tail_prev_lcp = mail.tail_prev_lcp;
     const uint32_t wrap_n = mail.wrap_count;
-    hipEventElapsedTime(&h->tm.scan_ms, h->ev[h->scan_start_ev], h->ev[1]);
-    hipEventElapsedTime(&h->tm.scan_main_ms, h->ev[h->scan_start_ev], h->ev[3]);
+    ev_ms(&h->tm.scan_ms, h->ev[h->scan_start_ev], h->ev[1]);
+    ev_ms(&h->tm.scan_main_ms, h->ev[h->scan_start_ev], h->ev[3]);
     h->tm.scan_bytes_read = d.n_entries * (uint64_t)d.lcp_bytes;
     h->tm.scan_bytes_written = h->n_ends * 10;
 
@@ -746,8 +759,7 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
     h->plan = pl;
     h->stitched = true;
-    if (h->img_pending) hipEventSynchronize(h->ev_img);
-    h->img_valid = h->img_pending = false;
+    drop_image(h);
     return E2S_OK;
 }
 
@@ -773,7 +785,7 @@ static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
     h->img_valid = false; h->img_pending = false; h->img_records = 0;
     if (!h->n_rec) { h->img_valid = true; return E2S_OK; }
     if (h->n_rec > h->img_cap) {
-        hipFree(h->d_img); hipFree(h->d_img_scratch); h->d_img = nullptr; h->d_img_scratch = nullptr; h->img_cap = 0;
+        dev_free(h->d_img); dev_free(h->d_img_scratch); h->d_img = nullptr; h->d_img_scratch = nullptr; h->img_cap = 0;
         const uint64_t cap = h->n_rec + h->n_rec / 8 + 4096;
         CK(hipMalloc((void**)&h->d_img, cap * 10 + 16));
         CK(hipMalloc((void**)&h->d_img_scratch, std::max<uint64_t>(e2s_pack_clusters_blocks(cap) * 12 + 64, (uint64_t)(8192 + 2) * 12 + 64)));
@@ -844,7 +856,7 @@ static int stream_image(e2s_ctx* h, const uint8_t* img, uint64_t bytes, e2s_byte
     constexpr uint64_t CHUNK = 4000000;                         // a whole number of records; pinning the staging buffers costs ~1 ms per MB
     const uint64_t want = std::min<uint64_t>(bytes, CHUNK);
     if (want > h->pin_io_cap) {
-        for (auto& p : h->pin_io) { if (p) hipHostFree(p); p = nullptr; }
+        for (auto& p : h->pin_io) { if (p) pin_free(p); p = nullptr; }
         h->pin_io_cap = 0;
         for (auto& p : h->pin_io) CK(hipHostMalloc((void**)&p, want, hipHostMallocDefault));
         h->pin_io_cap = want;
@@ -861,7 +873,7 @@ static int stream_image(e2s_ctx* h, const uint8_t* img, uint64_t bytes, e2s_byte
         CK(hipEventSynchronize(h->ev_io[c & 1]));
         if (c + 1 < n_chunks) CK(issue(c + 1));                 // into the other buffer, while the sink works on this one
         const uint64_t off = c * CHUNK, len = std::min<uint64_t>(CHUNK, bytes - off);
-        if (sink && sink(user, h->pin_io[c & 1], (size_t)len) != 0) { hipStreamSynchronize(h->stream); return fail(h, E2S_ERR_IO, "the byte sink reported an error"); }
+        if (sink && sink(user, h->pin_io[c & 1], (size_t)len) != 0) { (void)hipStreamSynchronize(h->stream); return fail(h, E2S_ERR_IO, "the byte sink reported an error"); }
     }
     return E2S_OK;
 }
@@ -930,8 +942,7 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
     }
     h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;
     h->min_len = 0; h->segmented = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};
-    if (h->img_pending) hipEventSynchronize(h->ev_img);
-    h->img_valid = h->img_pending = false;
+    drop_image(h);
     h->wrap_ranks.clear(); h->wrap_overflow = false; h->first_wrapped = false;
     h->scanned = true; h->stitched = true; h->records_from_file = true;
     return E2S_OK;
@@ -965,7 +976,7 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     CK(hipMemcpyAsync(buf, dh, (E2S_MAX_CLUST_LEN + 4) * 8, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
     CK(hipGetLastError());
-    hipEventElapsedTime(&h->tm.hist_ms, h->ev[4], h->ev[5]);
+    ev_ms(&h->tm.hist_ms, h->ev[4], h->ev[5]);
     memcpy(out->freq, buf, (E2S_MAX_CLUST_LEN + 1) * 8);
     out->n_records = buf[E2S_MAX_CLUST_LEN + 1];
     out->n_bases = buf[E2S_MAX_CLUST_LEN + 2];
@@ -1082,7 +1093,7 @@ static void phantom_entry(const e2s_ctx* h, uint32_t text, uint32_t suff, uint32
 
 static int ensure_flagged(e2s_ctx* h, uint64_t cap) {
     if (cap <= h->fl_cap && h->d_fl_starts) return E2S_OK;
-    hipFree(h->d_fl_starts); hipFree(h->d_fl_lens);
+    dev_free(h->d_fl_starts); dev_free(h->d_fl_lens);
     h->d_fl_starts = nullptr; h->d_fl_lens = nullptr; h->fl_cap = 0;
     CK(hipMalloc((void**)&h->d_fl_starts, (cap + 8) * 8));
     CK(hipMalloc((void**)&h->d_fl_lens, (cap + 8) * 2 + 64));
@@ -1229,7 +1240,7 @@ static int cand_args(e2s_ctx* h, const e2s_c2s_params* p, uint64_t record_index_
 // ever overflows.
 static int cand_buffers(e2s_ctx* h, CandArgs& a, uint64_t want) {
     if (want > h->cand_cap) {
-        hipFree(h->d_keys); hipFree(h->d_slot_off8); hipFree(h->d_rank); hipFree(h->d_order);
+        dev_free(h->d_keys); dev_free(h->d_slot_off8); dev_free(h->d_rank); dev_free(h->d_order);
         h->d_keys = nullptr; h->d_slot_off8 = nullptr; h->d_rank = nullptr; h->d_order = nullptr; h->cand_cap = 0;
         CK(hipMalloc((void**)&h->d_keys, (want + 8) * 8));
         CK(hipMalloc((void**)&h->d_slot_off8, (want + 8) * 4));
@@ -1244,14 +1255,14 @@ static int cand_buffers(e2s_ctx* h, CandArgs& a, uint64_t want) {
     h->cand_dev = h->have_reads;
     if (h->cand_dev) {
         if (need > h->d_stream_bytes) {
-            hipFree(h->d_stream); h->d_stream = nullptr; h->d_stream_bytes = 0;
+            dev_free(h->d_stream); h->d_stream = nullptr; h->d_stream_bytes = 0;
             CK(hipMalloc((void**)&h->d_stream, need + 4096));
             h->d_stream_bytes = need + 4096;
         }
         a.host_stream = h->d_stream;
     } else {
         if (need > h->pin_cand_bytes) {
-            if (h->pin_cand) hipHostFree(h->pin_cand);
+            if (h->pin_cand) pin_free(h->pin_cand);
             h->pin_cand = nullptr; h->pin_cand_bytes = 0;
             CK(hipHostMalloc((void**)&h->pin_cand, need + 4096, hipHostMallocDefault));
             h->pin_cand_bytes = need + 4096;
@@ -1443,8 +1454,8 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     h->cand_downloaded = count != 0;                             // everything arrived with the mailbox wait above
     h->pin_order = h->pin_cand ? (uint32_t*)(h->pin_cand + h->stream_ord_off) : nullptr;
     h->cand_host_valid = !h->cand_dev;
-    hipEventElapsedTime(&h->tm.cand_ms, h->ev[6], h->ev[7]);
-    hipEventElapsedTime(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev]);   // the pre-filter (inside the scan kernel: that kernel)
+    ev_ms(&h->tm.cand_ms, h->ev[6], h->ev[7]);
+    ev_ms(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev]);   // the pre-filter (inside the scan kernel: that kernel)
     h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
     h->tm.cand_bytes_written = count * a.stride;
     if (n_cand) *n_cand = count;
@@ -1456,7 +1467,7 @@ static int cand_to_host(e2s_ctx* h) {
     if (h->cand_host_valid || !h->n_cand) return E2S_OK;
     const size_t need = h->stream_ord_off + ((size_t)h->cand_cap + 1) * 4;
     if (need > h->pin_cand_bytes) {
-        if (h->pin_cand) hipHostFree(h->pin_cand);
+        if (h->pin_cand) pin_free(h->pin_cand);
         h->pin_cand = nullptr; h->pin_cand_bytes = 0;
         CK(hipHostMalloc((void**)&h->pin_cand, need + 4096, hipHostMallocDefault));
         h->pin_cand_bytes = need + 4096;
@@ -1602,7 +1613,7 @@ extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_by
         e2s_launch_reads_compact(h->d_text, h->d_rstart, max_len, n_reads, dense, h->stream);
         LCHK("e2s_launch_reads_compact");
         CK(hipStreamSynchronize(h->stream));
-        hipFree(h->d_text); hipFree(h->d_rstart); hipFree(h->d_rlen);
+        dev_free(h->d_text); dev_free(h->d_rstart); dev_free(h->d_rlen);
         h->d_text = dense; h->d_rstart = nullptr; h->d_rlen = nullptr;
     }
     return E2S_OK;
@@ -1624,14 +1635,14 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     CK(hipSetDevice(h->device));
     const uint64_t n = h->n_cand, ng = (n + 63) / 64;
     if (n > h->tail_cap) {
-        hipFree(h->d_cons); hipFree(h->d_trec); h->d_cons = nullptr; h->d_trec = nullptr; h->tail_cap = 0;
+        dev_free(h->d_cons); dev_free(h->d_trec); h->d_cons = nullptr; h->d_trec = nullptr; h->tail_cap = 0;
         const uint64_t c2 = n + n / 4 + 1024;
         CK(hipMalloc((void**)&h->d_cons, c2 * 128));
         CK(hipMalloc((void**)&h->d_trec, c2 * sizeof(TailRec)));
         h->tail_cap = c2;
     }
     if (ng + 1 > h->part_cap) {
-        hipFree(h->d_part); h->d_part = nullptr; h->part_cap = 0;
+        dev_free(h->d_part); h->d_part = nullptr; h->part_cap = 0;
         CK(hipMalloc((void**)&h->d_part, (ng + 64) * 5 * 8 + 64));       // raw sums (3 per group) | exclusive prefixes (2 per group)
         h->part_cap = ng + 63;
     }
@@ -1639,7 +1650,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     const uint64_t rmax = p->k_right < 0 ? h->reads_max_len : std::min<uint64_t>((uint64_t)p->k_right, h->reads_max_len);
     const uint64_t bound = n * (2 * (uint64_t)(1 + 5 + 13 + 20 + 5 + 10 + 1 + 66 + 1 + 10 + 10) + 2 * ((uint64_t)p->k_left + rmax + 1)) + 256;
     if (bound > h->snp_cap) {
-        hipFree(h->d_snp); h->d_snp = nullptr; h->snp_cap = 0;
+        dev_free(h->d_snp); h->d_snp = nullptr; h->snp_cap = 0;
         CK(hipMalloc((void**)&h->d_snp, bound + bound / 8));
         h->snp_cap = bound + bound / 8;
     }
@@ -1665,7 +1676,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     CK(hipMemcpyAsync(mb, totals, 32, hipMemcpyDeviceToHost, h->stream));
     CK(wait_stream(h));
     CK(hipGetLastError());
-    hipEventElapsedTime(&h->tm.tail_ms, h->ev[2], h->ev[5]);
+    ev_ms(&h->tm.tail_ms, h->ev[2], h->ev[5]);
     const uint32_t err = (uint32_t)mb[3];
     if (err & E2S_TAILERR_RANK) return fail(h, E2S_ERR_STATE, "GPU tail: a candidate names a read past the last one (the reference repeats stale text: use the host tail)");
     if (err & E2S_TAILERR_CRASH) return E2S_ERR_REF_CRASH;      // substr throws in the reference

@@ -1047,7 +1047,6 @@ __device__ __forceinline__ u32 base_to_int(u32 c) {
     return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
 }
 
-constexpr int CAND_WAVES = 4;
 constexpr int MAXCH = 3;                           // ceil(150/64)
 
 // One cluster record [s, s+len) handled by one wave: lane i <-> entry s+i (three 64-entry chunks cover
@@ -1595,7 +1594,7 @@ void e2s_launch_cand_order(const u64* keys, u64 n, const unsigned long long* n_d
     u32* slot = cnt + E2S_KO_MAX_BUCKETS + 2;
     u32* gidx = slot + n;
     u64* gkeys = (u64*)(((uintptr_t)(gidx + n) + 7) & ~(uintptr_t)7);
-    if (!counts_cleared) hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, st);
+    if (!counts_cleared) (void)hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, st);   // (a failure stays in hipGetLastError, which the caller reads after the launches)
     const dim3 g((unsigned)((n + 255) / 256)), blk(256);
     hipLaunchKernelGGL(k_ko_count, g, blk, 0, st, keys, n, n_dev, key_lo, shift, nb, cnt, slot);
     hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, cnt, nb);
@@ -1677,7 +1676,7 @@ u64 e2s_pack_clusters_blocks(u64 n) { return (n + PK_BLOCK - 1) / PK_BLOCK; }
 void e2s_launch_pack_clusters(const u64* starts, const uint16_t* lens, u64 n, int min_len, u32* cnt, u64* prefix, uint8_t* out, u64* total,
                               hipStream_t st) {
     const u64 nb = e2s_pack_clusters_blocks(n);
-    if (nb == 0) { hipMemsetAsync(total, 0, 8, st); return; }
+    if (nb == 0) { (void)hipMemsetAsync(total, 0, 8, st); return; }
     hipLaunchKernelGGL(k_pack_count, dim3((unsigned)nb), dim3(256), 0, st, lens, n, min_len, cnt);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, cnt, prefix, nb);
     hipLaunchKernelGGL(k_pack_write, dim3((unsigned)nb), dim3(256), 0, st, starts, lens, n, min_len, prefix, cnt, (u32)nb, (uint16_t*)out, total);
