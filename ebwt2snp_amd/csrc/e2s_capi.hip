@@ -14,7 +14,7 @@
 static_assert(sizeof(CandHeader) == sizeof(e2s_cand_header), "candidate header layout");
 static_assert(E2S_MAX_CLUST_LEN == E2S_MAX_CLUST_LEN_K, "max cluster length");
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;             // errors of the calls that have no handle (this thread's last one)
 
 struct e2s_ctx {
     int device = 0;
@@ -99,7 +99,7 @@ struct e2s_ctx {
         }                                                                                                \
     } while (0)
 
-static int fail(e2s_handle h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
+static int fail(e2s_handle h, int code, const std::string& msg) { if (h) h->err = msg; else g_create_error = msg; return code; }
 
 // Teardown and timing calls whose result cannot change what the caller does next: the result is dropped on purpose, in one place.
 static inline void dev_free(void* p) { if (p) (void)hipFree(p); }
@@ -1036,15 +1036,15 @@ extern "C" int e2s_auto_max_clust_length(const e2s_hist* parts, int nparts, int 
         nrec += parts[p].n_records; nb += parts[p].n_bases;
         if (parts[p].n_records) last_len = parts[p].last_len;
     }
-    if (nrec == 0) return E2S_ERR_REF_CRASH;                       // empty .clusters: SIGFPE in the reference (H6)
+    if (nrec == 0) return fail(nullptr, E2S_ERR_REF_CRASH, "no cluster record: the reference divides by zero here");   // empty .clusters: SIGFPE in the reference (H6)
     // H4: `while(not clusters.eof())` counts the last record twice
     if (last_len <= E2S_MAX_CLUST_LEN) freq[last_len]++;
     nrec += 1; nb += last_len;
     uint64_t mx = 0;
     for (uint64_t i = 1; i <= E2S_MAX_CLUST_LEN; ++i) mx = std::max(mx, freq[i] * i);
-    if (mx == 0) return E2S_ERR_REF_CRASH;                         // clust2snp.cpp:921 divides by max
+    if (mx == 0) return fail(nullptr, E2S_ERR_REF_CRASH, "no cluster of length <= 150: the reference divides by zero here");   // clust2snp.cpp:921 divides by max
     int mcl = 2 * mcov_out;
-    if (mcl < 0 || mcl > E2S_MAX_CLUST_LEN) return E2S_ERR_REF_CRASH;
+    if (mcl < 0 || mcl > E2S_MAX_CLUST_LEN) return fail(nullptr, E2S_ERR_REF_CRASH, "the automatic -c falls outside the histogram: the reference reads past it here");
     uint64_t cum = freq[mcl] * (uint64_t)mcl;
     const double dnb = (double)nb;
     if ((double)cum / dnb < pval) {
@@ -1629,8 +1629,8 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
     if (h->n_cand && !h->cand_dev) return fail(h, E2S_ERR_STATE, "the candidates were delivered to the host: make the reads resident BEFORE e2s_find_candidates");
     // zero candidates: the reference indexes an empty vector (clust2snp.cpp:531) and dies before creating the file
-    if (h->n_cand == 0) return E2S_ERR_REF_CRASH;
-    if (p->k_left < 0) return E2S_ERR_REF_CRASH;                 // cons(size_t(-n)) throws in the reference
+    if (h->n_cand == 0) return fail(h, E2S_ERR_REF_CRASH, "no candidate cluster: the reference crashes before it creates the output");
+    if (p->k_left < 0) return fail(h, E2S_ERR_REF_CRASH, "negative -L: the reference throws here");                // cons(size_t(-n)) throws in the reference
     if (p->k_left < 1 || p->k_left > 64) return fail(h, E2S_ERR_STATE, "GPU tail: -L outside 1..64 (use the host tail, e2s_snp_from_packed)");
     CK(hipSetDevice(h->device));
     const uint64_t n = h->n_cand, ng = (n + 63) / 64;
@@ -1679,7 +1679,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     ev_ms(&h->tm.tail_ms, h->ev[2], h->ev[5]);
     const uint32_t err = (uint32_t)mb[3];
     if (err & E2S_TAILERR_RANK) return fail(h, E2S_ERR_STATE, "GPU tail: a candidate names a read past the last one (the reference repeats stale text: use the host tail)");
-    if (err & E2S_TAILERR_CRASH) return E2S_ERR_REF_CRASH;      // substr throws in the reference
+    if (err & E2S_TAILERR_CRASH) return fail(h, E2S_ERR_REF_CRASH, "a right context starts beyond its read (-L longer than the shared context): the reference throws here");     // substr throws in the reference
     if (mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
     h->n_events = mb[0]; h->snp_bytes = mb[1]; h->n_variants = mb[2];
     h->variants_valid = true; h->tail_p = *p; h->snp_first_id = first_id;

@@ -50,7 +50,7 @@ typedef struct e2s_ctx* e2s_handle;
 /* ---- lifetime ---------------------------------------------------------------------------- */
 int  e2s_create(int device_id, e2s_handle* out);
 int  e2s_destroy(e2s_handle h);
-const char* e2s_last_error(e2s_handle h);   /* h may be NULL: last creation error */
+const char* e2s_last_error(e2s_handle h);   /* h may be NULL: this thread's last error of a call without a handle */
 const char* e2s_version(void);
 
 /* ---- EGSA shard ---------------------------------------------------------------------------
