@@ -940,11 +940,13 @@ def test_bench_two_rank_rehearsal_equals_one_rank():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opts", [dict(c=150, L=64), dict(c=45, L=1, R=5), dict(c=3, L=40, g=64, e=5), dict(c=20, L=14, R=200), dict(c=20, L=31, R=200)])
+@pytest.mark.parametrize("opts", [dict(c=150, L=64), dict(c=45, L=1, R=5), dict(c=3, L=40, g=64, e=5), dict(c=45, L=65, R=16), dict(c=45, L=14, R=60),
+                                  dict(c=45, L=90, R=20)])
 def test_gpu_tail_option_corners(H, tmp_path, opts):
     """the GPU tail at the edges of its domain: the longest lists (-c 150: one wave per block for the LDS rows), -L 1 and -L 64, a
-    gap bound longer than the contexts, right contexts cut short by the read's end -- `.snp` bytes against the oracle's; and
-    -L beyond the shared context of a suffix near its read's end, where the reference throws (H6): E2S_ERR_REF_CRASH, no output"""
+    gap bound longer than the contexts, -L 65 (one past what the GPU tail holds: the host tail takes over), long right contexts
+    -- `.snp` bytes against the oracle's; and an -L no prefix reaches, which leaves no candidate: the reference crashes before it
+    creates the output (H6), here E2S_ERR_REF_CRASH and no file"""
     reads, n1, e = synth.synth_case(4000, 100, seed=81, coverage=30)
     en = synth.egsa_to_numpy(e)
     out = {}
@@ -959,7 +961,7 @@ def test_gpu_tail_option_corners(H, tmp_path, opts):
                 r = tools.clust2snp(p, n1, handle=H, **opts)
                 assert r["n_candidates"] > 5
             except capi.E2SError as ex:
-                assert ex.code == 7 and "reference throws" in str(ex)
+                assert ex.code == 7 and "the reference crashes" in str(ex) and not os.path.exists(IO.snp_out_path(p))
                 out[tag] = None
                 continue
         else:
@@ -969,4 +971,4 @@ def test_gpu_tail_option_corners(H, tmp_path, opts):
                 continue
         out[tag] = open(IO.snp_out_path(p), "rb").read()
     assert out["hip"] == out["orc"]
-    assert (out["orc"] is None) == (opts.get("L") == 31) and (out["orc"] is None or len(out["orc"]) > 1000)
+    assert (out["orc"] is None) == (opts.get("L") == 90) and (out["orc"] is None or len(out["orc"]) > 1000)
