@@ -57,6 +57,7 @@ struct e2s_ctx {
     // reads resident in HBM + the GPU tail (e2s_tail.hip)
     bool have_reads = false, reads_owned = false; uint8_t* d_text = nullptr; uint64_t* d_rstart = nullptr; uint32_t* d_rlen = nullptr;
     uint64_t n_reads = 0; uint32_t reads_max_len = 0;
+    uint64_t text_bytes = 0;                                     // extent of d_text that the reads cover (the tail never loads past it)
     uint8_t* d_cons = nullptr; TailRec* d_trec = nullptr; uint64_t tail_cap = 0; unsigned long long* d_part = nullptr; uint64_t part_cap = 0;
     uint8_t* d_snp = nullptr; uint64_t snp_cap = 0, snp_bytes = 0, n_events = 0, n_variants = 0; bool variants_valid = false, snp_valid = false;
     e2s_tail_params tail_p{}; uint64_t snp_first_id = 1;
@@ -1576,6 +1577,15 @@ extern "C" int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t
     h->d_text = (uint8_t*)d_text; h->d_rstart = (uint64_t*)d_start; h->d_rlen = (uint32_t*)d_len;
     h->n_reads = n_reads; h->reads_max_len = max_len; h->have_reads = n_reads != 0; h->reads_owned = false;
     h->variants_valid = false;
+    h->text_bytes = n_reads * (uint64_t)max_len;                 // the dense matrix; with an index: what the reads cover
+    if (n_reads && d_start) {
+        unsigned long long* ext = (unsigned long long*)(h->d_scalars + 236);
+        CK(hipMemsetAsync(ext, 0, 8, h->stream));
+        e2s_launch_reads_extent(d_start, d_len, n_reads, ext, h->stream);
+        LCHK("e2s_launch_reads_extent");
+        CK(hipMemcpyAsync(&h->text_bytes, ext, 8, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+    }
     return E2S_OK;
 }
 
@@ -1585,6 +1595,7 @@ extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src) {
     release_reads(dst);
     dst->d_text = src->d_text; dst->d_rstart = src->d_rstart; dst->d_rlen = src->d_rlen; dst->n_reads = src->n_reads;
     dst->reads_max_len = src->reads_max_len; dst->have_reads = src->have_reads; dst->reads_owned = false; dst->variants_valid = false;
+    dst->text_bytes = src->text_bytes;
     return E2S_OK;
 }
 
@@ -1603,6 +1614,7 @@ extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_by
     CK(hipMemcpyAsync(h->d_rlen, len, n_reads * 4, hipMemcpyHostToDevice, h->stream));
     CK(hipStreamSynchronize(h->stream));
     h->n_reads = n_reads; h->reads_max_len = max_len; h->have_reads = true; h->variants_valid = false;
+    h->text_bytes = text_bytes;
     // reads of ONE length (what sequencers and the synthetic sets give) become a dense matrix: read r at r * len, no index arrays --
     // every left context then costs one random access instead of three
     bool uniform = max_len > 0;
@@ -1615,6 +1627,7 @@ extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_by
         CK(hipStreamSynchronize(h->stream));
         dev_free(h->d_text); dev_free(h->d_rstart); dev_free(h->d_rlen);
         h->d_text = dense; h->d_rstart = nullptr; h->d_rlen = nullptr;
+        h->text_bytes = n_reads * (uint64_t)max_len;
     }
     return E2S_OK;
 }
@@ -1632,6 +1645,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     if (h->n_cand == 0) return fail(h, E2S_ERR_REF_CRASH, "no candidate cluster: the reference crashes before it creates the output");
     if (p->k_left < 0) return fail(h, E2S_ERR_REF_CRASH, "negative -L: the reference throws here");                // cons(size_t(-n)) throws in the reference
     if (p->k_left < 1 || p->k_left > 64) return fail(h, E2S_ERR_STATE, "GPU tail: -L outside 1..64 (use the host tail, e2s_snp_from_packed)");
+    if (h->text_bytes < 4) return fail(h, E2S_ERR_STATE, "GPU tail: fewer than 4 bytes of reads (use the host tail, e2s_snp_from_packed)");
     CK(hipSetDevice(h->device));
     const uint64_t n = h->n_cand, ng = (n + 63) / 64;
     if (n > h->tail_cap) {
@@ -1661,7 +1675,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     CK(hipMemsetAsync(h->d_words + 28, 0, 4, h->stream));
     TailArgs a{};
     a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
-    a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len;
+    a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
     a.kl = p->k_left; a.kr = p->k_right; a.max_gap = p->max_gap; a.max_err = p->max_err;
     a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = h->d_words + 28;
     CK(hipEventRecord(h->ev[2], h->stream));
@@ -1700,7 +1714,7 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
         unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);
         TailArgs a{};
         a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
-        a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len;
+        a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
         a.kl = h->tail_p.k_left; a.kr = h->tail_p.k_right; a.max_gap = h->tail_p.max_gap; a.max_err = h->tail_p.max_err;
         a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = h->d_words + 28;
         e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, h->d_words + 28, h->stream);

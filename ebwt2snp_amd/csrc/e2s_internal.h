@@ -146,6 +146,7 @@ struct TailArgs {
     const uint8_t* stream; const uint32_t* off8; uint64_t n_cand; uint32_t pos_pack;      // packed candidates in SA order (device memory)
     const uint8_t* text; const uint64_t* rstart; const uint32_t* rlen; uint64_t n_reads;  // the reads: read r = text[rstart[r] .. +rlen[r])
     uint32_t stride;           // rstart == nullptr: every read is `stride` long and read r starts at r * stride (no index to look up)
+    uint64_t text_bytes;       // extent of the text (>= 4): no load reaches past it
     int kl, kr, max_gap, max_err;
     uint8_t* cons;             // [n_cand][2][64] consensus strings
     TailRec* rec;              // [n_cand]
@@ -156,6 +157,7 @@ struct TailArgs {
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st);
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, hipStream_t st);
+void e2s_launch_reads_extent(const uint64_t* rstart, const uint32_t* rlen, uint64_t n_reads, unsigned long long* out, hipStream_t st);   // *out = max(start + len), *out zeroed by the caller
 void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st);
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, uint8_t* out, unsigned long long out_cap,
                            hipStream_t st);

@@ -34,6 +34,60 @@ __device__ __forceinline__ u32 tl_pos(const uint8_t* p, u32 pw, u32 j) {
     return pw == 1u ? (u32)p[j] : pw == 2u ? (u32)p[2 * j] | ((u32)p[2 * j + 1] << 8) : ((const u32*)p)[j];
 }
 
+// base_to_int (include.hpp:265-279) of four characters at once: the class from bits 1-2 of the case-folded byte (A 0, C 1, G 3, T 2 ->
+// 0 1 2 3), kept only where the byte IS that letter -- its low three bits pick the one letter it could be from an 8-entry v_perm table
+__device__ __forceinline__ u32 tl_b2i4(u32 v) {
+    const u32 f = v & 0xDFDFDFDFu;
+    const u32 e = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, f & 0x07070707u);   // [FF 'A' FF 'C' 'T' FF FF 'G']
+    const u32 x = e ^ f;                                            // zero byte <=> a letter of ACGT
+    const u32 nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    const u32 ok = (~nz & 0x80808080u) >> 7;                        // 0x01 per valid byte
+    const u32 code = (f >> 1) & 0x03030303u;
+    return (code ^ (code >> 1)) & (ok | (ok << 1));
+}
+// The left contexts of a candidate into its LDS rows of 4 * LPR entries (character | base_to_int << 8): LPR lanes per row, an unaligned
+// dword each, four rows per instruction and candidate (gl = the lane's number inside the candidate's 4 * LPR lanes), BATCH loads
+// issued back to back before the first LDS write.  Byte loads (one lane per character) are bound by the rate of load instructions:
+// 10^7 random 31-byte rows take 0.50 ms that way and 0.24 ms as dwords on an MI355X (tools/gather_probe.hip), 0.22 ms being what
+// HBM gives; written as one load + one LDS store per iteration the compiler also waits for every load before issuing the next.
+// A dword may reach up to 3 bytes past its context: inside the text that is the next read; at the very end the load is moved back.
+template <u32 LPR>
+__device__ __forceinline__ void tl_gather_rows(const TailArgs& a, uint16_t* ctx, const u64* rbase, const u32* rhave, u32 nrows, u32 nr_max, u32 gl) {
+    constexpr u32 BATCH = 8;
+    const u32 q4 = (gl & (LPR - 1u)) * 4u, rsub = gl / LPR;
+    const u32 last = nrows ? nrows - 1u : 0u;
+    for (u32 j0 = 0; j0 < nr_max; j0 += 4u * BATCH) {
+        u32 w4[BATCH];
+#pragma unroll
+        for (u32 u = 0; u < BATCH; ++u) {
+            w4[u] = 0u;
+            if (j0 + 4u * u >= nr_max) break;                       // (wave-uniform)
+            const u32 j = j0 + 4u * u + rsub, jj = min(j, last);
+            const u32 have = rhave[jj];                             // (unconditional LDS reads, no branch around the load: a lane
+            const u64 base = rbase[jj];                             //  without characters reads the first dword of the text)
+            const bool ok = (j < nrows) & (q4 < have);
+            const u64 at = base + q4;
+            const u32 over = ok && at + 4ull > a.text_bytes ? (u32)(at + 4ull - a.text_bytes) : 0u;
+            const u32 v = *(const u32*)(a.text + (ok ? at - over : 0ull));
+            const u32 keep = have - q4;                             // characters of this dword that exist (>= 1 where ok)
+            const u32 mask = keep >= 4u ? ~0u : (1u << (8u * keep)) - 1u;
+            w4[u] = ok ? (v >> (8u * over)) & mask : 0u;
+        }
+#pragma unroll
+        for (u32 u = 0; u < BATCH; ++u) {
+            if (j0 + 4u * u >= nr_max) break;
+            const u32 j = j0 + 4u * u + rsub;
+            if (j < nrows) {
+                const u32 cls = tl_b2i4(w4[u]);
+                uint2 e;
+                e.x = __builtin_amdgcn_perm(cls, w4[u], 0x05010400u);   // [ch0 cls0 ch1 cls1]
+                e.y = __builtin_amdgcn_perm(cls, w4[u], 0x07030602u);   // [ch2 cls2 ch3 cls3]
+                *(uint2*)(ctx + (size_t)j * (4u * LPR) + q4) = e;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ---- K3a ----------------------------------------------------------------------------------------------------------------------
@@ -43,7 +97,7 @@ __device__ __forceinline__ u32 tl_pos(const uint8_t* p, u32 pw, u32 j) {
 // bytes, 64 / kw rows per wave instruction, kw = k_left rounded up to a power of two), and consensus and supports run on LDS.
 // Dynamic LDS per wave: 2 x list_cap rows of 64 x 2 B (character | its base_to_int) + (8 + 4) B of row base / length each.
 extern __shared__ __attribute__((aligned(16))) uint8_t s_tail[];
-__global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32 kw_shift) {
+__global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     __shared__ uint8_t s_ab[4][2][128];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
     const u64 c = (u64)blockIdx.x * (blockDim.x >> 6) + wave;      // (1, 2 or 4 waves per block: long lists need the LDS)
@@ -60,7 +114,6 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32
     uint8_t* const sb = s_ab[wave][1];
     u32 supp[2] = {0u, 0u};
     u32 bad = 0;
-    const u32 kw = 1u << kw_shift, rows_per = 64u >> kw_shift, row_of = lane >> kw_shift, col = lane & (kw - 1u);
     // rows 0 .. n0-1: allele 0, rows n0 .. n0+n1-1: allele 1 -- both gathered in ONE sweep (the lists lie side by side in the record)
     const u32 m0 = min(n0, list_cap), m1 = min(n1, list_cap), nrows = m0 + m1;
     const u32* idx = w + 4;
@@ -79,14 +132,7 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (u32 j0 = 0; j0 < nrows; j0 += rows_per) {                  // the characters: every load of the candidate in flight together
-        const u32 j = j0 + row_of;
-        if (j < nrows) {
-            const u32 have = rhave[j];
-            const u32 ch = col < have ? (u32)a.text[rbase[j] + col] : 0u;
-            ctx[(size_t)j * 64 + col] = (uint16_t)(ch | (tl_b2i(ch) << 8));   // base_to_int once per character, by all lanes at once
-        }
-    }
+    tl_gather_rows<16>(a, ctx, rbase, rhave, nrows, nrows, lane);   // rows of 64 entries, 16 lanes per row
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int s = 0; s < 2; ++s) {
@@ -167,6 +213,135 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap, u32
     }
 }
 
+// ---- K3a for k_left <= 32: TWO candidates per wave, one per half-wave ------------------------------------------------------------
+// A left context fills at most 32 lanes, so in k_consensus half of every vector instruction is idle, and the kernel is bound by the
+// issue of those instructions as much as by its chain of gathers (c3: ~950 vector + ~920 scalar instructions per candidate).  Here
+// lanes 0-31 serve candidate 2w, lanes 32-63 candidate 2w + 1: the same instruction stream, loops running to the longer of the two
+// lists, ballots read per half.  Results are those of k_consensus (same order of rows, same tie-breaks).
+// Dynamic LDS per wave: 2 candidates x 2 x list_cap rows of 32 x 2 B + (8 + 4) B of row base / length each.
+__device__ __forceinline__ u32 tl_half_pop(u64 m, u32 half) { return (u32)__popc(half ? (u32)(m >> 32) : (u32)m); }
+__global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap) {
+    __shared__ uint8_t s_ab[4][2][2][64];
+    const u32 lane = tl_lane(), wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
+    const u64 c0 = ((u64)blockIdx.x * (blockDim.x >> 6) + wave) * 2ull;
+    if (c0 >= a.n_cand) return;
+    const u64 c = c0 + half;
+    const bool valid = c < a.n_cand;
+    const size_t per_cand = (size_t)2 * list_cap * (64 + 8 + 4);
+    uint8_t* const mine = s_tail + ((size_t)wave * 2 + half) * per_cand;
+    uint16_t* const ctx = (uint16_t*)mine;                          // [2 * list_cap][32] of (character | base_to_int << 8)
+    u64* const rbase = (u64*)(mine + (size_t)2 * list_cap * 64);
+    u32* const rhave = (u32*)(rbase + 2 * list_cap);
+    const uint8_t* r = a.stream + (size_t)a.off8[valid ? c : c0] * 8;
+    const u32* w = (const u32*)r;
+    const u32 n0 = valid ? w[0] : 0u, n1 = valid ? w[1] : 0u, right_idx = w[2], right_pos = w[3];
+    const u32 kl = (u32)a.kl;
+    uint8_t* const sa = s_ab[wave][half][0];
+    uint8_t* const sb = s_ab[wave][half][1];
+    u32 bad = 0;
+    const u32 m0 = min(n0, list_cap), m1 = min(n1, list_cap), nrows = m0 + m1;
+    const u32 nr_max = max((u32)__builtin_amdgcn_readlane((int)nrows, 0), (u32)__builtin_amdgcn_readlane((int)nrows, 32));
+    const u32* idx = w + 4;
+    const uint8_t* pp = r + 16 + 4 * (size_t)(n0 + n1);
+    for (u32 j0 = 0; j0 < nr_max; j0 += 32u) {
+        const u32 j = j0 + hl;
+        if (j < nrows) {
+            const u32 e = j < m0 ? j : n0 + (j - m0);
+            const u32 rd = idx[e];
+            u64 base = 0; u32 have = 0;
+            if ((u64)rd >= a.n_reads) bad |= E2S_TAILERR_RANK;
+            else {
+                const u32 len = a.rstart ? a.rlen[rd] : a.stride, p0 = tl_pos(pp, a.pos_pack, e);
+                have = p0 < len ? min(len - p0, kl) : 0u;
+                base = (a.rstart ? a.rstart[rd] : (u64)rd * a.stride) + p0;
+            }
+            rbase[j] = base; rhave[j] = have;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    tl_gather_rows<8>(a, ctx, rbase, rhave, nrows, nr_max, hl);     // rows of 32 entries, 8 lanes per row
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32 supp0 = 0u, supp1 = 0u;
+    const bool colok = hl < kl;
+    for (int s = 0; s < 2; ++s) {
+        const u32 n = s ? m1 : m0;
+        const u32 n_max = max((u32)__builtin_amdgcn_readlane((int)n, 0), (u32)__builtin_amdgcn_readlane((int)n, 32));
+        const uint16_t* rows = ctx + (size_t)(s ? m0 : 0u) * 32;
+        u32 C = 'A', bc8 = 0u, cnt = 0u;                            // cons (include.hpp:334-371): as in k_consensus
+        for (u32 j = 0; j < n_max; ++j) {
+            const bool on = colok & (j < n);
+            const u32 v = on ? (u32)rows[(size_t)j * 32 + hl] : 0u;
+            const u32 ch = v & 0xFFu, b8 = (v >> 8) << 3;
+            cnt += on ? 1u << b8 : 0u;
+            if (on && ((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
+        }
+        u32 supp = 0u;
+        for (u32 j = 0; j < n_max; ++j) {
+            const bool on = colok & (j < n);
+            const u32 ch = on ? ((u32)rows[(size_t)j * 32 + hl] & 0xFFu) : 0u;
+            const u32 d = tl_half_pop(__ballot(on && C != ch), half);
+            if (j < n && (int)d <= a.max_err) ++supp;
+        }
+        if (s) supp1 = supp; else supp0 = supp;
+        (s ? sb : sa)[hl] = (uint8_t)C;
+        (s ? sb : sa)[32 + hl] = 0;
+        if (valid && colok) a.cons[c * 128 + (u64)s * 64 + hl] = (uint8_t)C;
+    }
+    bad = tl_half_pop(__ballot(bad & E2S_TAILERR_RANK), half) ? E2S_TAILERR_RANK : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool keep = supp0 > 0u && supp1 > 0u;
+    const u32 ca = sa[hl], cb = sb[hl];
+    const int none = (int)tl_half_pop(__ballot(colok && ca != cb), half);
+    int D = none, L = 0;
+    if (a.max_gap > 0) {
+        int best_ab = 0, best_ba = 0, ia = 0, ib = 0;
+        for (int i = 1; i <= a.max_gap; ++i) {
+            int mab, mba;
+            if ((u32)i <= kl) {
+                const u32 la = kl - (u32)i;
+                const u32 xi = min(hl + (u32)i, 63u);
+                mab = (int)tl_half_pop(__ballot(hl < la && ca != (u32)sb[xi]), half);
+                mba = (int)tl_half_pop(__ballot(hl < la && (u32)sa[xi] != cb), half);
+            } else mab = mba = none;
+            const int dab = mab + i, dba = mba + i;
+            if (i == 1 || dab < best_ab) { best_ab = dab; ia = i; }
+            if (i == 1 || dba < best_ba) { best_ba = dba; ib = i; }
+        }
+        if (!(none < best_ab && none < best_ba)) {
+            if (best_ab < best_ba) { D = best_ab - ia; L = ia; } else { D = best_ba - ib; L = -ib; }
+        }
+    }
+    u32 right_len = 0; u64 right_at = 0;
+    if (keep) {
+        if ((u64)right_idx >= a.n_reads) bad |= E2S_TAILERR_RANK;
+        else {
+            const u32 len = a.rstart ? a.rlen[right_idx] : a.stride;
+            if (right_pos > len) bad |= E2S_TAILERR_CRASH;
+            else {
+                const u32 avail = len - right_pos;
+                right_len = a.kr < 0 ? avail : min(avail, (u32)a.kr);
+                right_at = (a.rstart ? a.rstart[right_idx] : (u64)right_idx * a.stride) + right_pos;
+            }
+        }
+    }
+    const bool emit = keep && D <= 3;
+    if (hl == 0 && valid) {
+        const u32 kind = L != 0 ? 5u : 3u, tlen = L == 0 ? 3u : (u32)(L < 0 ? -L : L) + 1u, drl = tl_digits(right_len);
+        const u32 l1 = 1u + kind + 13u + 5u + drl + 1u + tlen + 1u + tl_digits(supp0) + 10u;
+        const u32 l3 = 1u + kind + 12u + 5u + drl + 1u + tlen + 1u + tl_digits(supp1) + 10u;
+        const u32 l2 = kl - (L < 0 ? (u32)(-L) : 0u) + right_len + 1u, l4 = kl - (L > 0 ? (u32)L : 0u) + right_len + 1u;
+        TailRec t;
+        t.emit = emit ? 1u : 0u; t.L = L; t.s0 = supp0; t.s1 = supp1; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
+        a.rec[c] = t;
+        if (keep) atomicAdd(&a.part[3 * (c >> 6) + 2], 1ull);
+        if (emit) { atomicAdd(&a.part[3 * (c >> 6)], 1ull); atomicAdd(&a.part[3 * (c >> 6) + 1], (u64)t.base_len); }
+        if (bad) atomicOr(a.err, bad);
+    }
+}
+
 // ---- K3b: exclusive scan of the per-group (events, text bytes) pairs; totals behind the last group -------------------------
 __global__ __launch_bounds__(1024) void k_tail_partials(const unsigned long long* part, unsigned long long* part_excl, u32 ng, u64 first_id,
                                                         unsigned long long* totals /* events, bytes, kept, error bits */, const unsigned long long* n_keep,
@@ -209,13 +384,15 @@ __device__ __forceinline__ u32 tl_put_num(uint8_t* b, u32 at, u64 v) {
     return at + d;
 }
 
-// A block takes a group of 64 candidates (the unit of the scan of event counts and text lengths): each of its 16 waves ranks the
-// group's events for itself (ballot + shuffles, no LDS, no barrier) and writes four of the candidates -- an event is a chain of
-// dependent steps (consensus letters -> header text -> stores), and short chains on many waves are what hides their latency
-// (four waves of 64 candidates each took 0.63 ms for 2.6x10^5 events, sixteen of 16 each 0.42 ms).
+// A block takes a group of 64 candidates (the unit of the scan of event counts and text lengths).  The header lines are serial
+// work (digits, pieces of varying length): ONE THREAD PER HEADER builds them -- wave 0 the 64 ">..._higher_path_..." lines, wave 1 the
+// 64 "lower" ones, every lane its own candidate's -- into LDS; then each of the 16 waves copies four events out, lanes = characters.
+// (First version: lane 0 of a wave built the two headers of one event while 63 lanes waited: ~700 vector instructions per event,
+// and the kernel was bound by their issue -- 0.42 ms for 2.6x10^5 events on c3.)
+constexpr u32 TL_HDR_STRIDE = 148;                                  // >= the longest header (141), 37 words: lanes hit different banks
 __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, uint8_t* out, u64 out_cap) {
-    __shared__ uint8_t s_hdr[16][2][128];
-    __shared__ uint8_t s_cab[16][2][64];
+    __shared__ __attribute__((aligned(4))) uint8_t s_hdr[2][64][TL_HDR_STRIDE];
+    __shared__ uint8_t s_hlen[2][64];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
     const u64 g = blockIdx.x;
     TailRec t; t.emit = 0; t.base_len = 0; t.L = 0; t.s0 = t.s1 = t.right_len = 0; t.right_at = 0;
@@ -232,64 +409,54 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
     const u64 my_rank = part_excl[2 * g] + e_before;                // events before this one
     const u64 my_off = part_excl[2 * g + 1] + (incl - bl) + 2ull * (tl_digit_sum_below(first_id + my_rank) - tl_digit_sum_below(first_id));
     const u32 kl = (u32)a.kl;
-    uint8_t* const h1 = s_hdr[wave][0];
-    uint8_t* const h3 = s_hdr[wave][1];
-    uint8_t* const la = s_cab[wave][0];
-    uint8_t* const lb = s_cab[wave][1];
+    if (wave < 2 && t.emit) {
+        const u32 line = wave;
+        const uint8_t* ca = a.cons + (g * 64 + lane) * 128;         // consensus of allele 0, of allele 1 at + 64
+        uint8_t* b = s_hdr[line][lane];
+        const int L = t.L;
+        u32 at = 0;
+        b[at++] = '>';
+        at = tl_put(b, at, L != 0 ? "INDEL" : "SNP");
+        at = tl_put(b, at, line ? "_lower_path_" : "_higher_path_");
+        at = tl_put_num(b, at, first_id + my_rank);
+        at = tl_put(b, at, "|P_1:");
+        at = tl_put_num(b, at, t.right_len);
+        b[at++] = '_';
+        if (L == 0) { b[at++] = ca[kl - 1]; b[at++] = '/'; b[at++] = ca[64 + kl - 1]; }          // last consensus letters (H20)
+        else if (L > 0) { for (u32 i = kl - (u32)L; i < kl; ++i) b[at++] = ca[i]; b[at++] = '/'; }
+        else { b[at++] = '/'; for (u32 i = kl - (u32)(-L); i < kl; ++i) b[at++] = ca[64 + i]; }
+        b[at++] = '|';
+        at = tl_put_num(b, at, line ? t.s1 : t.s0);
+        at = tl_put(b, at, "|nb_pol_1\n");
+        s_hlen[line][lane] = (uint8_t)at;
+    }
+    __syncthreads();
     for (u32 k = 0; k < 4; ++k) {
         const int src = (int)(wave * 4 + k);
         if (!((em >> src) & 1ull)) continue;                        // (wave-uniform)
         const u64 c2 = g * 64 + (u64)src;
         const int L = __shfl(t.L, src);
-        const u32 s0 = __shfl(t.s0, src), s1 = __shfl(t.s1, src), rl = __shfl(t.right_len, src);
-        const u64 rat = __shfl(t.right_at, src), o = __shfl(my_off, src), id = first_id + __shfl(my_rank, src);
+        const u32 rl = __shfl(t.right_len, src);
+        const u64 rat = __shfl(t.right_at, src), o = __shfl(my_off, src);
         const uint8_t* ca = a.cons + c2 * 128;
-        const uint8_t* cbp = ca + 64;
-        const u32 ach = lane < kl ? (u32)ca[lane] : 0u, bch = lane < kl ? (u32)cbp[lane] : 0u;   // the two consensus strings, one letter per lane
-        la[lane] = (uint8_t)ach; lb[lane] = (uint8_t)bch;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        u32 n1 = 0, n3 = 0;
-        if (lane == 0) {
-            for (int line = 0; line < 2; ++line) {
-                uint8_t* b = line ? h3 : h1;
-                u32 at = 0;
-                b[at++] = '>';
-                at = tl_put(b, at, L != 0 ? "INDEL" : "SNP");
-                at = tl_put(b, at, line ? "_lower_path_" : "_higher_path_");
-                at = tl_put_num(b, at, id);
-                at = tl_put(b, at, "|P_1:");
-                at = tl_put_num(b, at, rl);
-                b[at++] = '_';
-                if (L == 0) { b[at++] = la[kl - 1]; b[at++] = '/'; b[at++] = lb[kl - 1]; }         // last consensus letters (H20)
-                else if (L > 0) { for (u32 i = kl - (u32)L; i < kl; ++i) b[at++] = la[i]; b[at++] = '/'; }
-                else { b[at++] = '/'; for (u32 i = kl - (u32)(-L); i < kl; ++i) b[at++] = lb[i]; }
-                b[at++] = '|';
-                at = tl_put_num(b, at, line ? s1 : s0);
-                at = tl_put(b, at, "|nb_pol_1\n");
-                if (line) n3 = at; else n1 = at;
-            }
-        }
-        n1 = __shfl(n1, 0); n3 = __shfl(n3, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const u32 ach = lane < kl ? (u32)ca[lane] : 0u, bch = lane < kl ? (u32)ca[64 + lane] : 0u;   // the two consensus strings, one letter per lane
+        const u32 n1 = s_hlen[0][src], n3 = s_hlen[1][src];
         const u32 skip0 = L < 0 ? (u32)(-L) : 0u, skip1 = L > 0 ? (u32)L : 0u;
         const u32 l2 = kl - skip0 + rl + 1u, l4 = kl - skip1 + rl + 1u;
         if (o + n1 + l2 + n3 + l4 <= out_cap) {
             uint8_t* p = out + o;
-            for (u32 i = lane; i < n1; i += 64) p[i] = h1[i];
+            for (u32 i = lane; i < n1; i += 64) p[i] = s_hdr[0][src][i];
             p += n1;
             if (lane >= skip0 && lane < kl) p[lane - skip0] = (uint8_t)ach;
             for (u32 i = lane; i < rl; i += 64) p[kl - skip0 + i] = a.text[rat + i];
             if (lane == 0) p[kl - skip0 + rl] = '\n';
             p += l2;
-            for (u32 i = lane; i < n3; i += 64) p[i] = h3[i];
+            for (u32 i = lane; i < n3; i += 64) p[i] = s_hdr[1][src][i];
             p += n3;
             if (lane >= skip1 && lane < kl) p[lane - skip1] = (uint8_t)bch;
             for (u32 i = lane; i < rl; i += 64) p[kl - skip1 + i] = a.text[rat + i];
             if (lane == 0) p[kl - skip1 + rl] = '\n';
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -302,21 +469,39 @@ __global__ __launch_bounds__(256) void k_reads_compact(const uint8_t* text, cons
     uint8_t* dst = out + r * len;
     for (u32 i = lane; i < len; i += 64u) dst[i] = src[i];
 }
+__global__ __launch_bounds__(256) void k_reads_extent(const u64* rstart, const u32* rlen, u64 n_reads, unsigned long long* out) {
+    u64 m = 0;
+    for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n_reads; r += (u64)gridDim.x * 256) m = max(m, rstart[r] + rlen[r]);
+    for (int d = 32; d; d >>= 1) m = max(m, (u64)__shfl_xor((unsigned long long)m, d));
+    if (tl_lane() == 0 && m) atomicMax(out, (unsigned long long)m);
+}
+void e2s_launch_reads_extent(const uint64_t* rstart, const uint32_t* rlen, uint64_t n_reads, unsigned long long* out, hipStream_t st) {
+    if (!n_reads) return;
+    const uint64_t nb = (n_reads + 255) / 256;
+    hipLaunchKernelGGL(k_reads_extent, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, st, (const u64*)rstart, rlen, n_reads, out);
+}
 void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st) {
     if (!n_reads) return;
     hipLaunchKernelGGL(k_reads_compact, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, text, (const u64*)rstart, len, n_reads, out);
 }
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) {
     if (!a.n_cand) return;
-    uint32_t kw_shift = 0;
-    while ((1u << kw_shift) < (uint32_t)a.kl) ++kw_shift;          // k_left <= 64
     if (list_cap < 1) list_cap = 1;
+    static size_t lds_set[2] = {0, 0};
+    if (a.kl <= 32) {                                               // two candidates per wave
+        const size_t per_wave = (size_t)2 * 2 * list_cap * (64 + 8 + 4);
+        const unsigned wpb = 4 * per_wave <= 60 * 1024 ? 4u : 2 * per_wave <= 120 * 1024 ? 2u : 1u;
+        const size_t lds = wpb * per_wave;
+        if (lds > 48 * 1024 && lds > lds_set[1]) { (void)hipFuncSetAttribute((const void*)k_consensus_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[1] = lds; }
+        const unsigned long long waves = (a.n_cand + 1) / 2;
+        hipLaunchKernelGGL(k_consensus_pair, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, a, list_cap);
+        return;
+    }
     const size_t per_wave = (size_t)2 * list_cap * (128 + 8 + 4);
     const unsigned wpb = 4 * per_wave <= 60 * 1024 ? 4u : 2 * per_wave <= 120 * 1024 ? 2u : 1u;
     const size_t lds = wpb * per_wave;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) { (void)hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
-    hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, a, list_cap, kw_shift);
+    if (lds > 48 * 1024 && lds > lds_set[0]) { (void)hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[0] = lds; }
+    hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, a, list_cap);
 }
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, hipStream_t st) {
