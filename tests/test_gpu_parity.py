@@ -445,9 +445,7 @@ def test_fused_streaming_adversarial(H, tmp_path):
                 assert a[key] == b[key], early
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", [101, 102, 103, 104])
-def test_fused_streaming_fuzz_columns(H, tmp_path, seed):
+def _fuzz_columns(seed):
     """random EGSA columns (not from reads): runs of LCP >= k of every length with inner local minima, so that
     clusters begin and end at every lane / tile / worker offset of the plane kernels; bases skewed so that the
     per-sample counts sit around mcov_out; LCP values around k_right; '$' and lower-case symbols ('N' is left out:
@@ -488,6 +486,14 @@ def test_fused_streaming_fuzz_columns(H, tmp_path, seed):
     reads = np.full((2000, 100), 65, dtype=np.uint8)
     mcov = int(rnd.choice([3, 5]))
     Rc = int(rnd.choice([25, 30, 45]))
+    return en, reads, mcov, Rc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_fused_streaming_fuzz_columns(H, tmp_path, seed):
+    """the pipeline on _fuzz_columns against the oracle's candidates, with the three ways of starting the pre-filter"""
+    en, reads, mcov, Rc = _fuzz_columns(seed)
     oc, omcl = _oracle_candidates(tmp_path, reads, en, 1000, mcov=mcov, R=Rc, tag="fz%d" % seed)
     for early in (False, True, "arm"):                           # pre-filter inside find_candidates / after the scan / beside the scan
         got, mcl = _fused_candidates(H, en, 1000, mcov=mcov, R=Rc, early=early)
@@ -937,6 +943,43 @@ def test_bench_two_rank_rehearsal_equals_one_rank():
     for key in ("cluster_records", "clusters_file_records", "candidates", "snp_events", "snp_bytes", "max_clust_length"):
         assert a["config"][key] == b["config"][key], key
     assert a["config"]["snp_events"] > 1000 and a["roofline"]["frac"] > 0 and a["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,L", [(201, 31), (202, 31), (203, 40), (204, 17), (205, 64)])
+def test_gpu_tail_fuzz_columns(H, tmp_path, seed, L):
+    """the GPU tail on columns that no real index produces: positions and read numbers unrelated to the reads (mostly A, some lower
+    case), suffixes that start at the very end of a read -- of the LAST read, too, where a dword of the gather would reach past the
+    text and is moved back -- and left contexts that hang over a read's start; `.snp` bytes against the oracle's"""
+    en, _, mcov, Rc = _fuzz_columns(seed)
+    rnd = np.random.RandomState(seed)
+    n = en["lcp"].size
+    reads = np.full((2000, 100), 65, dtype=np.uint8)             # low entropy: contexts from unrelated places still agree often enough for
+    mut = rnd.rand(2000, 100) < 0.05                             # supports > 0 and distances <= 3 (SNPs and a few INDELs come out)
+    reads[mut] = rnd.choice(np.array([67, 71, 84, 97, 99, 103, 116], dtype=np.uint8), int(mut.sum()))
+    suff = en["suff"].copy()
+    far = rnd.rand(n) < 0.2
+    suff[far] = rnd.randint(96, 101, int(far.sum()))             # suffixes at / next to the read's end
+    text = en["text"].copy()
+    text[rnd.rand(n) < 0.1] = 1999                               # the last read, often
+    en = dict(en, suff=suff.astype(np.uint8), text=text)
+    out = {}
+    for tag in ("hip", "orc"):
+        os.makedirs(str(tmp_path / tag))
+        p = str(tmp_path / tag / "reads.fasta")
+        IO.write_fasta(p, reads)
+        IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+        if tag == "hip":
+            tools.ebwt2clust(p, handle=H)
+            r = tools.clust2snp(p, 1000, handle=H, L=L, R=Rc, m=mcov)
+            assert r["n_candidates"] > 50
+            H.call_variants(L, Rc, 10, 2)                               # (the GPU tail applies -- no fall-back to the host tail -- and gives the file's bytes)
+            assert H.fetch_snp().tobytes() == open(IO.snp_out_path(p), "rb").read()
+        else:
+            assert O.ebwt2clust(p)[0] == 0
+            assert O.clust2snp(p, O.c2s_opts(1000, L=L, R=Rc, m=mcov))[0] == 0
+        out[tag] = open(IO.snp_out_path(p), "rb").read()
+    assert out["hip"] == out["orc"] and out["orc"].count(b">SNP_higher") > 100 and out["orc"].count(b">INDEL_higher") > 0
 
 
 @pytest.mark.gpu

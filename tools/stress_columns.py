@@ -11,14 +11,8 @@ import test_gpu_parity as T
 import oracle_lib as O
 from ebwt2snp_amd import capi, egsa_io as IO
 
-src = open(T.__file__).read()
-body = src[src.index("def test_fused_streaming_fuzz_columns"):]
-gen = body[body.index("    rnd = np.random.RandomState(seed)"):body.index("    oc, omcl = _oracle_candidates")]
-ns = dict(np=np)
-exec("def g(seed):\n" + gen + "    return en, reads, mcov, Rc\n", ns)
-
 def run(seed):
-    en, reads, mcov, Rc = ns["g"](seed)
+    en, reads, mcov, Rc = T._fuzz_columns(seed)
     n = en["lcp"].size
     d = pathlib.Path(tempfile.mkdtemp())
     try:
