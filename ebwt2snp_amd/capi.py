@@ -238,6 +238,12 @@ class Handle:
         self._ck(self.L.e2s_fetch_clusters(self.h, _ptr(buf), n.value, C.byref(n)))
         return buf[:n.value * 10]
 
+    def fetch_clusters_into(self, out_ptr, cap_records):
+        """the records into the caller's host buffer (an address; pinned memory is written by one DMA); returns the number of records"""
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_fetch_clusters(self.h, C.c_void_p(out_ptr), cap_records, C.byref(n)))
+        return n.value
+
     def pack_clusters(self, async_=False):
         """build the `.clusters` image in HBM (async_: on the second stream, beside the per-cluster pass)"""
         self._ck(self.L.e2s_pack_clusters(self.h, 1 if async_ else 0))
@@ -359,6 +365,11 @@ class Handle:
         buf = np.zeros(max(n.value, 1), dtype=np.uint8)
         self._ck(self.L.e2s_fetch_snp(self.h, _ptr(buf), n.value, C.byref(n)))
         return buf[:n.value]
+
+    def fetch_snp_into(self, out_ptr, cap_bytes):
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_fetch_snp(self.h, C.c_void_p(out_ptr), cap_bytes, C.byref(n)))
+        return n.value
 
     def write_snp(self, fasta_path, out_path, k_left=31, k_right=30, max_gap=10, max_err=2):
         p = TailParams(k_left, k_right, max_gap, max_err)

@@ -879,6 +879,23 @@ static int stream_image(e2s_ctx* h, const uint8_t* img, uint64_t bytes, e2s_byte
     return E2S_OK;
 }
 
+// An image copied into the caller's host memory: one DMA where that memory is pinned (hipHostMalloc / hipHostRegister: PCIe speed),
+// otherwise through the pinned double buffer and a memcpy (a DMA into pageable memory is staged by the runtime anyway, in smaller pieces).
+static int copy_image_out(e2s_ctx* h, const uint8_t* img, uint64_t bytes, void* out) {
+    if (!bytes) return E2S_OK;
+    hipPointerAttribute_t at{};
+    const bool pinned = hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError();                          // (an ordinary pointer is reported as an error: not one of ours)
+    if (pinned) {
+        CK(hipMemcpyAsync(out, img, bytes, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+        return E2S_OK;
+    }
+    struct Dst { uint8_t* p; } dst{(uint8_t*)out};
+    auto copy = [](void* user, const void* data, size_t n) -> int { Dst* d = (Dst*)user; memcpy(d->p, data, n); d->p += n; return 0; };
+    return stream_image(h, img, bytes, copy, &dst);
+}
+
 extern "C" int e2s_stream_clusters(e2s_handle h, e2s_byte_sink sink, void* user, uint64_t* n_records) {
     dbg_entry("e2s_stream_clusters");
     if (!h || !sink) return E2S_ERR_ARG;
@@ -907,9 +924,7 @@ extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records,
     if (rc) return rc;
     *n_records = w;
     if (!out) return E2S_OK;
-    struct Dst { uint8_t* p; } dst{(uint8_t*)out};
-    auto copy = [](void* user, const void* data, size_t bytes) -> int { Dst* d = (Dst*)user; memcpy(d->p, data, bytes); d->p += bytes; return 0; };
-    rc = stream_image(h, h->d_img, std::min<uint64_t>(w, cap_records) * 10, copy, &dst);
+    rc = copy_image_out(h, h->d_img, std::min<uint64_t>(w, cap_records) * 10, out);
     if (rc) return rc;
     return w > cap_records ? E2S_ERR_CAPACITY : E2S_OK;
 }
@@ -1747,9 +1762,7 @@ extern "C" int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64
     if (!out) return E2S_OK;
     if (cap_bytes < h->snp_bytes) return fail(h, E2S_ERR_CAPACITY, "`.snp` output too small");
     CK(hipSetDevice(h->device));
-    struct Dst { uint8_t* p; } dst{(uint8_t*)out};
-    auto copy = [](void* user, const void* data, size_t n) -> int { Dst* d = (Dst*)user; memcpy(d->p, data, n); d->p += n; return 0; };
-    return stream_image(h, h->d_snp, h->snp_bytes, copy, &dst);
+    return copy_image_out(h, h->d_snp, h->snp_bytes, out);
 }
 
 extern "C" int e2s_last_timing(e2s_handle h, e2s_timing* out) {

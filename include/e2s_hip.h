@@ -144,7 +144,8 @@ int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_records);
  * e2s_stream_clusters wait for it (and build the image themselves if nobody has). */
 int e2s_pack_clusters(e2s_handle h, int async);
 int e2s_clusters_image(e2s_handle h, const void** d_image, uint64_t* n_records);
-/* The same bytes copied to the host. */
+/* The same bytes copied to the host: one DMA where `out` is pinned host memory (hipHostMalloc / hipHostRegister), through a pinned
+ * double buffer and a memcpy otherwise. */
 int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records, uint64_t* n_records);
 /* The same bytes handed to a sink chunk by chunk (whole records per call, in file order) straight out of pinned staging
  * buffers, the next chunk's copy running meanwhile: what the ebwt2clust executable writes its output file with.  The sink

@@ -774,6 +774,10 @@ def test_resident_job_images_equal_oracle(tmp_path):
         r = pipeline.resident_job(h, n1, n, prefilter=pf)
         assert h.fetch_clusters().tobytes() == want_cl and h.fetch_snp().tobytes() == want_snp, pf
         assert r["n_records"] * 10 == len(want_cl) and r["snp_bytes"] == len(want_snp) and r["n_events"] > 20
+    # a pinned destination is written by one DMA (no staging buffers): the same bytes
+    pc, ps = torch.zeros(len(want_cl) + 100, dtype=torch.uint8).pin_memory(), torch.zeros(len(want_snp) + 7, dtype=torch.uint8).pin_memory()
+    assert h.fetch_clusters_into(pc.data_ptr(), pc.numel() // 10) * 10 == len(want_cl) and h.fetch_snp_into(ps.data_ptr(), ps.numel()) == len(want_snp)
+    assert pc.numpy()[:len(want_cl)].tobytes() == want_cl and ps.numpy()[:len(want_snp)].tobytes() == want_snp
     h.close()
     rnd = np.random.RandomState(3)
     for world in (2, 3):
