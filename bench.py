@@ -290,10 +290,22 @@ def run_c5s(a, dev):
         if width != 1:
             x = x.reshape(-1)
         return np.ascontiguousarray(np.concatenate([x[-HL * width:], x, x[:1 * width]]))
-    bwt, lcp = padded(blk["bwt"]), padded(blk["lcp"])
+    # E2S_BENCH_C5S_PINNED=1: the source hands out pinned host memory.  Measured on two boxes (profiles/round2_c5s_upload_variants.txt):
+    # no faster than pageable memory here (20-21 GB/s against 19-24 on the same box, with or without the SDMA engines) -- the
+    # host-to-device rate of these boxes is not set by the staging copy
+    pinned = os.environ.get("E2S_BENCH_C5S_PINNED", "0") == "1"
+    keep = []
+
+    def host(x):
+        if not pinned:
+            return x
+        t = torch.from_numpy(x).pin_memory()
+        keep.append(t)
+        return t.numpy()
+    bwt, lcp = host(padded(blk["bwt"])), host(padded(blk["lcp"]))
     psa = np.zeros(m, dtype=np.dtype([("s", np.uint8), ("t", "<u4")]))      # [pos:1][da:4] per entry (BCR pairSA, include.hpp:159-188)
     psa["s"] = blk["pos"].cpu().numpy(); psa["t"] = blk["da"].cpu().numpy().astype(np.uint32)
-    psa = padded(torch.from_numpy(psa.view(np.uint8)), width=5)
+    psa = host(padded(torch.from_numpy(psa.view(np.uint8)), width=5))
     rd = reads.to(dev).contiguous()
     del blk
     torch.cuda.empty_cache(); torch.cuda.synchronize()
@@ -323,7 +335,8 @@ def run_c5s(a, dev):
                       "entries_total": n_total, "chunks": rep.n_chunks, "seconds_total": rep.seconds_total, "seconds_in_uploads": rep.seconds_upload,
                       "bytes_uploaded": n_total * 1 + n_total * 7, "upload_GBps_while_uploading": (n_total * 8) / max(rep.seconds_upload, 1e-9) / 1e9,
                       "clusters_file_records": rep.n_records, "clusters_bytes": cnt["cl"], "clusters_printed": rep.n_closed, "candidates": rep.n_candidates,
-                      "snp_events": rep.n_events, "snp_bytes": cnt["snp"], "max_clust_length": rep.max_clust_length, "input_build_s": round(t_build, 2)},
+                      "snp_events": rep.n_events, "snp_bytes": cnt["snp"], "max_clust_length": rep.max_clust_length, "input_build_s": round(t_build, 2),
+                      "host_memory": "pinned" if pinned else "pageable"},
            "note": "not the resident-HBM metric: an input of this size cannot be resident; compare with value_outputs_on_host / value_end_to_end of the default run"}
     print(json.dumps(out))
 
