@@ -782,6 +782,10 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 // segments (k_pack_seg_*), or from contiguous records loaded from a file -- and leaves through two pinned staging buffers: the
 // copy of one chunk runs while the sink consumes the previous one.  The pack can run on the handle's second stream beside the
 // per-cluster pass (e2s_pack_clusters with async != 0): it is bandwidth bound, that pass latency bound.
+// blocks of the records' pack when it runs on the second stream beside other kernels (E2S_PACK_BLOCKS; 0 = one per segment, the default).
+// Measured on c3: throttled to 256 / 512 / 768 / 1024 / 2048 blocks the step takes 3.18 / 2.83 / 2.75 / 2.83 / 2.83 ms against 2.82-2.93
+// unthrottled -- what the per-cluster pass gains, the tail loses when the pack reaches into it; inside the box's run-to-run noise.
+static uint32_t pack_blocks_beside() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_PACK_BLOCKS"); v = e ? atoi(e) : 0; } return (uint32_t)v; }
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
     h->img_valid = false; h->img_pending = false; h->img_records = 0;
     if (!h->n_rec) { h->img_valid = true; return E2S_OK; }
@@ -802,7 +806,8 @@ static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
         uint32_t* kept = (uint32_t*)(off + h->seg_blocks + 1);
         e2s_launch_pack_segments((const unsigned long long*)h->d_starts, h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, kept,
                                  (unsigned long long*)off, h->d_img, (unsigned long long*)(h->d_scalars + 220), h->stitched ? h->plan.n_tail : 0,
-                                 h->plan.tail_start[0], h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], st);
+                                 h->plan.tail_start[0], h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], st,
+                                 st == h->stream2 ? pack_blocks_beside() : 0u);
         LCHK("e2s_launch_pack_segments");
     } else {
         const uint64_t nb = e2s_pack_clusters_blocks(h->n_rec);

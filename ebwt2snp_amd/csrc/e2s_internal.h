@@ -181,7 +181,7 @@ void e2s_launch_pack_clusters(const unsigned long long* starts, const uint16_t* 
                               unsigned long long* prefix, uint8_t* out, unsigned long long* total, hipStream_t st);
 void e2s_launch_pack_segments(const unsigned long long* starts, const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_seg, int min_len,
                               uint32_t* kept, unsigned long long* off, uint8_t* out, unsigned long long* total, uint32_t n_tail, unsigned long long t0,
-                              uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st);
+                              uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st, uint32_t max_blocks);
 #define E2S_WRAP_CAP 1024
 int  e2s_scan_seg_resident_blocks(int xb);
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st);

@@ -847,7 +847,8 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(const u64* starts, const
     __shared__ __attribute__((aligned(16))) uint8_t s_img[PKS_REC * 10 + 32];
     __shared__ u32 s_w[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u32 b = blockIdx.x, n = desc[b].count;
+    for (u32 b = blockIdx.x; b < n_seg; b += gridDim.x) {        // (a grid smaller than n_seg: the throttled form, see the launcher)
+    const u32 n = desc[b].count;
     const u64* ps = starts + (u64)b * seg_cap;
     const uint16_t* pl = lens + (u64)b * seg_cap;
     u64 done = off[b];                                          // records of the image before the trip at hand
@@ -891,7 +892,8 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(const u64* starts, const
         done += m;
         __syncthreads();
     }
-    if (b == n_seg - 1 && tid == 0) {                            // the records the EOF rule adds (e2s_stitch_plan)
+    }
+    if (blockIdx.x == (n_seg - 1) % gridDim.x && tid == 0) {     // the records the EOF rule adds (e2s_stitch_plan)
         u64 at = off[n_seg];
         const u64 ts[2] = {t0, t1}; const uint16_t tl[2] = {l0, l1};
         for (u32 t = 0; t < n_tail; ++t) if ((int)tl[t] >= min_len) {
@@ -902,13 +904,16 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(const u64* starts, const
     }
 }
 void e2s_launch_pack_segments(const u64* starts, const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u32* kept, u64* off,
-                              uint8_t* out, u64* total, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1, hipStream_t st) {
+                              uint8_t* out, u64* total, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1, hipStream_t st, u32 max_blocks) {
     u32 n_tail_kept = 0;
     if (n_tail > 0 && (int)l0 >= min_len) ++n_tail_kept;
     if (n_tail > 1 && (int)l1 >= min_len) ++n_tail_kept;
     hipLaunchKernelGGL(k_pack_seg_count, dim3(n_seg), dim3(256), 0, st, lens, desc, seg_cap, min_len, kept);
     hipLaunchKernelGGL(k_pack_seg_scan, dim3(1), dim3(1024), 0, st, kept, n_seg, off, n_tail_kept, total);
-    hipLaunchKernelGGL(k_pack_seg_write, dim3(n_seg), dim3(256), 0, st, starts, lens, desc, seg_cap, n_seg, min_len, off, out, n_tail, t0, l0, t1, l1);
+    // max_blocks (0: one block per segment): an experiment knob -- the pack running beside the per-cluster pass throttled to a few blocks
+    // per CU, so that it does not saturate HBM under that latency-bound kernel (no net gain measured: e2s_capi.hip, pack_blocks_beside)
+    const u32 grid = max_blocks && max_blocks < n_seg ? max_blocks : n_seg;
+    hipLaunchKernelGGL(k_pack_seg_write, dim3(grid), dim3(256), 0, st, starts, lens, desc, seg_cap, n_seg, min_len, off, out, n_tail, t0, l0, t1, l1);
 }
 
 __global__ void k_apply_plan(u64* starts, uint16_t* lens, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_ends, u32 n_tail,
