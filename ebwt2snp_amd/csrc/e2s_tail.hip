@@ -24,6 +24,10 @@ __device__ __forceinline__ u32 tl_lane() { return __builtin_amdgcn_mbcnt_hi(~0u,
 // include.hpp:265-279: A/a 0, C/c 1, G/g 2, T/t 3, everything else 0 ('N' is rand() % 4 in the reference: mapped to 0)
 __device__ __forceinline__ u32 tl_b2i(u32 ch) { const u32 f = ch & 0xDFu; return f == 'C' ? 1u : f == 'G' ? 2u : f == 'T' ? 3u : 0u; }
 __device__ __forceinline__ u32 tl_digits(u64 v) { u32 d = 1; while (v >= 10ull) { v /= 10ull; ++d; } return d; }
+__device__ __forceinline__ u32 tl_digits32(u32 v) {                 // (no division: the usual values have one to three digits)
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u : v < 100000000u ? 8u
+         : v < 1000000000u ? 9u : 10u;
+}
 // sum of digits(v) over v in [0, x)
 __device__ __forceinline__ u64 tl_digit_sum_below(u64 x) {
     u64 s = x, p = 10ull;
@@ -50,7 +54,11 @@ __device__ __forceinline__ u32 tl_b2i4(u32 v) {
 // issued back to back before the first LDS write.  Byte loads (one lane per character) are bound by the rate of load instructions:
 // 10^7 random 31-byte rows take 0.50 ms that way and 0.24 ms as dwords on an MI355X (tools/gather_probe.hip), 0.22 ms being what
 // HBM gives; written as one load + one LDS store per iteration the compiler also waits for every load before issuing the next.
-// A dword may reach up to 3 bytes past its context: inside the text that is the next read; at the very end the load is moved back.
+// A dword may reach up to 3 bytes past its context: inside the text that is the next read.  A row whose dwords could reach past the END
+// of the text (the last read's last bytes) carries TL_ROW_NEAR_END in its length word: the dword pass leaves it alone and
+// tl_gather_rows_bytes fetches it one character per lane afterwards (wave-uniform branch, almost never taken).
+// An entry is (character | 8 * base_to_int << 8): the consensus loop shifts by the high byte as it is.
+constexpr u32 TL_ROW_NEAR_END = 0x80000000u;
 template <u32 LPR>
 __device__ __forceinline__ void tl_gather_rows(const TailArgs& a, uint16_t* ctx, const u64* rbase, const u32* rhave, u32 nrows, u32 nr_max, u32 gl) {
     constexpr u32 BATCH = 8;
@@ -65,25 +73,35 @@ __device__ __forceinline__ void tl_gather_rows(const TailArgs& a, uint16_t* ctx,
             const u32 j = j0 + 4u * u + rsub, jj = min(j, last);
             const u32 have = rhave[jj];                             // (unconditional LDS reads, no branch around the load: a lane
             const u64 base = rbase[jj];                             //  without characters reads the first dword of the text)
-            const bool ok = (j < nrows) & (q4 < have);
-            const u64 at = base + q4;
-            const u32 over = ok && at + 4ull > a.text_bytes ? (u32)(at + 4ull - a.text_bytes) : 0u;
-            const u32 v = *(const u32*)(a.text + (ok ? at - over : 0ull));
+            const bool ok = (j < nrows) & ((int)q4 < (int)have);    // (a near-end row's length word is negative)
+            const u32 v = *(const u32*)(a.text + (ok ? base + q4 : 0ull));
             const u32 keep = have - q4;                             // characters of this dword that exist (>= 1 where ok)
             const u32 mask = keep >= 4u ? ~0u : (1u << (8u * keep)) - 1u;
-            w4[u] = ok ? (v >> (8u * over)) & mask : 0u;
+            w4[u] = ok ? v & mask : 0u;
         }
 #pragma unroll
         for (u32 u = 0; u < BATCH; ++u) {
             if (j0 + 4u * u >= nr_max) break;
             const u32 j = j0 + 4u * u + rsub;
             if (j < nrows) {
-                const u32 cls = tl_b2i4(w4[u]);
+                const u32 cls8 = tl_b2i4(w4[u]) << 3;
                 uint2 e;
-                e.x = __builtin_amdgcn_perm(cls, w4[u], 0x05010400u);   // [ch0 cls0 ch1 cls1]
-                e.y = __builtin_amdgcn_perm(cls, w4[u], 0x07030602u);   // [ch2 cls2 ch3 cls3]
+                e.x = __builtin_amdgcn_perm(cls8, w4[u], 0x05010400u);   // [ch0 cls0 ch1 cls1]
+                e.y = __builtin_amdgcn_perm(cls8, w4[u], 0x07030602u);   // [ch2 cls2 ch3 cls3]
                 *(uint2*)(ctx + (size_t)j * (4u * LPR) + q4) = e;
             }
+        }
+    }
+}
+template <u32 LPR>
+__device__ __forceinline__ void tl_gather_rows_bytes(const TailArgs& a, uint16_t* ctx, const u64* rbase, const u32* rhave, u32 nrows, u32 nr_max, u32 gl) {
+    const u32 last = nrows ? nrows - 1u : 0u;
+    for (u32 j = 0; j < nr_max; ++j) {
+        const u32 hv = rhave[min(j, last)];
+        if (j < nrows && (hv & TL_ROW_NEAR_END)) {
+            const u32 have = hv & ~TL_ROW_NEAR_END;
+            const u32 ch = gl < have ? (u32)a.text[rbase[j] + gl] : 0u;
+            ctx[(size_t)j * (4u * LPR) + gl] = (uint16_t)(ch | (tl_b2i(ch) << 11));
         }
     }
 }
@@ -114,6 +132,7 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     uint8_t* const sb = s_ab[wave][1];
     u32 supp[2] = {0u, 0u};
     u32 bad = 0;
+    bool any_near = false;
     // rows 0 .. n0-1: allele 0, rows n0 .. n0+n1-1: allele 1 -- both gathered in ONE sweep (the lists lie side by side in the record)
     const u32 m0 = min(n0, list_cap), m1 = min(n1, list_cap), nrows = m0 + m1;
     const u32* idx = w + 4;
@@ -128,11 +147,15 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
             have = p0 < len ? min(len - p0, kl) : 0u;
             base = (a.rstart ? a.rstart[rd] : (u64)rd * a.stride) + p0;
         }
-        rbase[j] = base; rhave[j] = have;
+        const bool near = have != 0u && base + 64ull > a.text_bytes;
+        any_near |= near;
+        rbase[j] = base; rhave[j] = have | (near ? TL_ROW_NEAR_END : 0u);
     }
+    any_near = __ballot(any_near) != 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     tl_gather_rows<16>(a, ctx, rbase, rhave, nrows, nrows, lane);   // rows of 64 entries, 16 lanes per row
+    if (any_near) tl_gather_rows_bytes<16>(a, ctx, rbase, rhave, nrows, nrows, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int s = 0; s < 2; ++s) {
@@ -143,7 +166,7 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
         u32 C = 'A', bc8 = 0u, cnt = 0u;                            // bc8 = 8 * base_to_int(C)
         for (u32 j = 0; j < n; ++j) {
             const u32 v = lane < kl ? (u32)rows[(size_t)j * 64 + lane] : 0u;
-            const u32 ch = v & 0xFFu, b8 = (v >> 8) << 3;
+            const u32 ch = v & 0xFFu, b8 = v >> 8;
             cnt += 1u << b8;
             if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
         }
@@ -199,9 +222,9 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     }
     const bool emit = keep && D <= 3;                               // max_snvs_def: -v is parsed but unused (H5)
     if (lane == 0) {
-        const u32 kind = L != 0 ? 5u : 3u, tlen = L == 0 ? 3u : (u32)(L < 0 ? -L : L) + 1u, drl = tl_digits(right_len);
-        const u32 l1 = 1u + kind + 13u + 5u + drl + 1u + tlen + 1u + tl_digits(supp[0]) + 10u;
-        const u32 l3 = 1u + kind + 12u + 5u + drl + 1u + tlen + 1u + tl_digits(supp[1]) + 10u;
+        const u32 kind = L != 0 ? 5u : 3u, tlen = L == 0 ? 3u : (u32)(L < 0 ? -L : L) + 1u, drl = tl_digits32(right_len);
+        const u32 l1 = 1u + kind + 13u + 5u + drl + 1u + tlen + 1u + tl_digits32(supp[0]) + 10u;
+        const u32 l3 = 1u + kind + 12u + 5u + drl + 1u + tlen + 1u + tl_digits32(supp[1]) + 10u;
         const u32 l2 = kl - (L < 0 ? (u32)(-L) : 0u) + right_len + 1u, l4 = kl - (L > 0 ? (u32)L : 0u) + right_len + 1u;
         TailRec t;
         t.emit = emit ? 1u : 0u; t.L = L; t.s0 = supp[0]; t.s1 = supp[1]; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
@@ -239,6 +262,7 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     uint8_t* const sa = s_ab[wave][half][0];
     uint8_t* const sb = s_ab[wave][half][1];
     u32 bad = 0;
+    bool any_near = false;
     const u32 m0 = min(n0, list_cap), m1 = min(n1, list_cap), nrows = m0 + m1;
     const u32 nr_max = max((u32)__builtin_amdgcn_readlane((int)nrows, 0), (u32)__builtin_amdgcn_readlane((int)nrows, 32));
     const u32* idx = w + 4;
@@ -255,12 +279,16 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
                 have = p0 < len ? min(len - p0, kl) : 0u;
                 base = (a.rstart ? a.rstart[rd] : (u64)rd * a.stride) + p0;
             }
-            rbase[j] = base; rhave[j] = have;
+            const bool near = have != 0u && base + 32ull > a.text_bytes;
+            any_near |= near;
+            rbase[j] = base; rhave[j] = have | (near ? TL_ROW_NEAR_END : 0u);
         }
     }
+    any_near = __ballot(any_near) != 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     tl_gather_rows<8>(a, ctx, rbase, rhave, nrows, nr_max, hl);     // rows of 32 entries, 8 lanes per row
+    if (any_near) tl_gather_rows_bytes<8>(a, ctx, rbase, rhave, nrows, nr_max, hl);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     u32 supp0 = 0u, supp1 = 0u;
@@ -273,9 +301,10 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
         for (u32 j = 0; j < n_max; ++j) {
             const bool on = colok & (j < n);
             const u32 v = on ? (u32)rows[(size_t)j * 32 + hl] : 0u;
-            const u32 ch = v & 0xFFu, b8 = (v >> 8) << 3;
+            const u32 ch = v & 0xFFu, b8 = v >> 8;
             cnt += on ? 1u << b8 : 0u;
-            if (on && ((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
+            // (no `on` here: C's count is the largest at all times, so a lane without a row -- v = 0, class 0 -- never takes over)
+            if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
         }
         u32 supp = 0u;
         for (u32 j = 0; j < n_max; ++j) {
@@ -329,9 +358,9 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     }
     const bool emit = keep && D <= 3;
     if (hl == 0 && valid) {
-        const u32 kind = L != 0 ? 5u : 3u, tlen = L == 0 ? 3u : (u32)(L < 0 ? -L : L) + 1u, drl = tl_digits(right_len);
-        const u32 l1 = 1u + kind + 13u + 5u + drl + 1u + tlen + 1u + tl_digits(supp0) + 10u;
-        const u32 l3 = 1u + kind + 12u + 5u + drl + 1u + tlen + 1u + tl_digits(supp1) + 10u;
+        const u32 kind = L != 0 ? 5u : 3u, tlen = L == 0 ? 3u : (u32)(L < 0 ? -L : L) + 1u, drl = tl_digits32(right_len);
+        const u32 l1 = 1u + kind + 13u + 5u + drl + 1u + tlen + 1u + tl_digits32(supp0) + 10u;
+        const u32 l3 = 1u + kind + 12u + 5u + drl + 1u + tlen + 1u + tl_digits32(supp1) + 10u;
         const u32 l2 = kl - (L < 0 ? (u32)(-L) : 0u) + right_len + 1u, l4 = kl - (L > 0 ? (u32)L : 0u) + right_len + 1u;
         TailRec t;
         t.emit = emit ? 1u : 0u; t.L = L; t.s0 = supp0; t.s1 = supp1; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
