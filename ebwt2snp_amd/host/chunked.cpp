@@ -149,6 +149,7 @@ int scan_pass(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::
 
 // the tail of one chunk: GPU tail streamed to the sink, or -- where only the host tail reproduces the reference -- the packed
 // candidates appended to host buffers for one e2s_snp_from_packed at the end
+constexpr int E2S_SWITCH_TAILS = -1000;                         // internal: the GPU tail stopped applying after it had produced events
 struct TailState {
     e2s_tail_params tp; uint64_t events = 0, variants = 0, cands = 0;
     bool host_mode = false; std::vector<uint8_t> stream; std::vector<uint32_t> off8; uint32_t pw = 4;
@@ -164,7 +165,7 @@ int chunk_tail(e2s_handle h, uint64_t n_cand, e2s_byte_sink snp_sink, void* snp_
             return nb ? e2s_stream_snp(h, snp_sink, snp_user) : E2S_OK;
         }
         if (rc != E2S_ERR_STATE) return rc;
-        if (ts.events) return E2S_ERR_STATE;                     // (earlier chunks already wrote their events: cannot switch tails mid-way)
+        if (ts.events) return E2S_SWITCH_TAILS;                  // (earlier chunks already wrote their events: the caller starts over, if it can)
         ts.host_mode = true;
     }
     const void* st = nullptr; const uint32_t* of = nullptr; uint64_t n = 0, bytes = 0; uint32_t pw = 4;
@@ -202,7 +203,11 @@ int finish_tail(TailState& ts, const char* fasta_path, e2s_byte_sink snp_sink, v
 
 int file_sink(void* user, const void* data, size_t bytes) { return fwrite(data, 1, bytes, (FILE*)user) == bytes ? 0 : 1; }
 // a file that comes into being with its first byte (where the reference crashes before creating it, nothing must be left behind)
-struct LazyFile { FILE* f; const char* path; };
+struct LazyFile {
+    FILE* f; const char* path;
+    ~LazyFile() { if (f) fclose(f); }
+    void close() { if (f) { fclose(f); f = nullptr; } }
+};
 int lazy_file_sink(void* user, const void* data, size_t bytes) {
     LazyFile* c = (LazyFile*)user;
     if (!c->f) { c->f = fopen(c->path, "w"); if (!c->f) return 1; }
@@ -276,7 +281,9 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
         prm.consensus_reads = o->consensus_reads; prm.max_clust_length = mcl; prm.min_len = p->min_len;
         uint64_t n_cand = 0;
         RC(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand));
-        RC(chunk_tail(h, n_cand, snp_sink, snp_user, ts));
+        rc = chunk_tail(h, n_cand, snp_sink, snp_user, ts);
+        if (rc == E2S_SWITCH_TAILS) return E2S_ERR_STATE;         // (the sink has the earlier chunks' events already: see include/e2s_hip.h)
+        if (rc) return rc;
         pipe.done((size_t)r);
     }
     pipe.stop();
@@ -299,31 +306,48 @@ extern "C" int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_op
         while (a < b) { const uint64_t m = (a + b) / 2; if (start_of(m) < pos) a = m + 1; else b = m; }
         return a;
     };
-    ChunkPipe pipe(*p, *src, chunks, true);
-    RC(pipe.start());
-    int rc = e2s_upload_reads_fasta(pipe.handle(0), fasta_path, nullptr);
-    if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) return rc;
-    if (rc == E2S_OK) RC(e2s_share_reads(pipe.handle(1), pipe.handle(0)));
     TailState ts;
-    ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
-    LazyFile out{nullptr, out_path};
-    for (int r = 0; r < nr; ++r) {
-        e2s_handle h = nullptr;
-        RC(pipe.acquire((size_t)r, &h));
-        const uint64_t i0 = first_at_or_after(chunks[r].lo), i1 = r == nr - 1 ? n_records : first_at_or_after(chunks[r].hi);
-        RC(e2s_load_clusters(h, (const uint8_t*)recs + i0 * 10, i1 - i0));
-        e2s_c2s_params prm{};
-        prm.nr_reads1 = o->nr_reads1; prm.k_left = o->k_left; prm.k_right = o->k_right; prm.mcov_out = o->mcov_out;
-        prm.consensus_reads = o->consensus_reads; prm.max_clust_length = max_clust_length; prm.min_len = 0;
-        uint64_t n_cand = 0;
-        RC(e2s_find_candidates(h, &prm, i0, &n_cand));
-        RC(chunk_tail(h, n_cand, lazy_file_sink, &out, ts));
-        pipe.done((size_t)r);
+    double up_s = 0;
+    // one pass over the chunks; host_only: the host tail from the first chunk on (the second attempt, below)
+    auto pass = [&](bool host_only) -> int {
+        ts = TailState{};
+        ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
+        ts.host_mode = host_only;
+        ChunkPipe pipe(*p, *src, chunks, true);
+        RC(pipe.start());
+        if (!host_only) {
+            int rc = e2s_upload_reads_fasta(pipe.handle(0), fasta_path, nullptr);
+            if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) return rc;
+            if (rc == E2S_OK) RC(e2s_share_reads(pipe.handle(1), pipe.handle(0)));
+        }
+        LazyFile out{nullptr, out_path};
+        for (int r = 0; r < nr; ++r) {
+            e2s_handle h = nullptr;
+            RC(pipe.acquire((size_t)r, &h));
+            const uint64_t i0 = first_at_or_after(chunks[r].lo), i1 = r == nr - 1 ? n_records : first_at_or_after(chunks[r].hi);
+            RC(e2s_load_clusters(h, (const uint8_t*)recs + i0 * 10, i1 - i0));
+            e2s_c2s_params prm{};
+            prm.nr_reads1 = o->nr_reads1; prm.k_left = o->k_left; prm.k_right = o->k_right; prm.mcov_out = o->mcov_out;
+            prm.consensus_reads = o->consensus_reads; prm.max_clust_length = max_clust_length; prm.min_len = 0;
+            uint64_t n_cand = 0;
+            RC(e2s_find_candidates(h, &prm, i0, &n_cand));
+            RC(chunk_tail(h, n_cand, lazy_file_sink, &out, ts));
+            pipe.done((size_t)r);
+        }
+        pipe.stop();
+        up_s += pipe.upload_seconds();
+        out.close();
+        return finish_tail(ts, fasta_path, nullptr, nullptr, out_path);
+    };
+    int rc = pass(false);
+    if (rc == E2S_SWITCH_TAILS) {
+        // a later chunk needs the host tail (a read rank past the last read) after earlier ones wrote their events with the GPU tail: the
+        // host tail works on ALL candidates at once, so the partial file goes and the pass runs again, collecting the packed candidates
+        unlink(out_path);
+        if (getenv("E2S_CLI_TIMING")) fprintf(stderr, "[timing]   the GPU tail stopped applying after %llu events: the pass runs again with the host tail\n", (unsigned long long)ts.events);
+        rc = pass(true);
     }
-    pipe.stop();
-    if (out.f) fclose(out.f);
-    rc = finish_tail(ts, fasta_path, nullptr, nullptr, out_path);
-    fill_report(rep, nullptr, &ts, max_clust_length, 0, 0, chunks.size(), pipe.upload_seconds(), t0);
+    fill_report(rep, nullptr, &ts, max_clust_length, 0, 0, chunks.size(), up_s, t0);
     return rc;
 }
 

@@ -329,7 +329,9 @@ int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, i
                           uint64_t n_records, const char* fasta_path, const char* out_path, e2s_job_report* rep);
 /* both tools in one process: pass A streams the LCP column (scan, `.clusters` bytes to clusters_sink -- may be NULL --, statistics);
  * pass B streams all four columns (scan + pre-filter in one kernel, stitch with the descriptors of pass A, per-cluster pass, tail).
- * The reads: fasta_path, or (d_text, d_start, d_len, n_reads, max_len) already in HBM when fasta_path is NULL (e2s_attach_reads). */
+ * The reads: fasta_path, or (d_text, d_start, d_len, n_reads, max_len) already in HBM when fasta_path is NULL (e2s_attach_reads).
+ * E2S_ERR_STATE after part of the `.snp` text has reached snp_sink: a later chunk needs the host tail (a read rank past the last read),
+ * which works on all candidates at once -- e2s_clust2snp_chunked, which owns its output file, starts over by itself in that case. */
 int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src, const char* fasta_path,
                          const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len,
                          e2s_byte_sink clusters_sink, void* clusters_user, e2s_byte_sink snp_sink, void* snp_user, e2s_job_report* rep);

@@ -950,6 +950,39 @@ def test_bench_two_rank_rehearsal_equals_one_rank():
 
 
 @pytest.mark.gpu
+def test_chunked_clust2snp_switches_to_host_tail_midway(tmp_path):
+    """a read rank past the last read (the reference repeats stale text: only the host tail reproduces it) in a LATER chunk, after the
+    GPU tail has written the events of the earlier ones: bin/clust2snp starts over with the host tail -- the oracle's bytes"""
+    import subprocess
+    reads, n1, e = synth.synth_case(3000, 100, seed=5)
+    en = synth.egsa_to_numpy(e)
+    p = str(tmp_path / "reads.fasta")
+    IO.write_fasta(p, reads.numpy())
+    IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+    assert O.ebwt2clust(p)[0] == 0
+    rc, cands, _ = O.candidates(p, O.c2s_opts(n1))
+    c = cands[int(len(cands) * 0.8)]
+    at = np.nonzero((en["text"] == c["idx1"][0]) & (en["suff"] == c["pos1"][0] + 31))[0]   # (a candidate holds suffix position - k_left)
+    assert at.size == 1 and at[0] > 200000
+    text = en["text"].copy()
+    text[at[0]] = reads.shape[0] + 5
+    IO.write_bcr(p, text, en["suff"], en["lcp"], en["bwt"])
+    rc, cands, _ = O.candidates(p, O.c2s_opts(n1))
+    assert any(reads.shape[0] + 5 in c2["idx1"] for c2 in cands)
+    assert O.clust2snp(p, O.c2s_opts(n1))[0] == 0
+    want = open(IO.snp_out_path(p), "rb").read()
+    os.remove(IO.snp_out_path(p))
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "clust2snp")
+    for chunk in ("100000", "0"):
+        env = dict(os.environ, E2S_CHUNK_ENTRIES=chunk, E2S_CLI_TIMING="1")
+        r = subprocess.run([exe, "-i", p, "-n", str(n1)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-400:]
+        assert open(IO.snp_out_path(p), "rb").read() == want and len(want) > 5000, chunk
+        assert ("the pass runs again with the host tail" in r.stderr) == (chunk != "0")   # (one chunk: the host tail from the start)
+        os.remove(IO.snp_out_path(p))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,L", [(201, 31), (202, 31), (203, 40), (204, 17), (205, 64)])
 def test_gpu_tail_fuzz_columns(H, tmp_path, seed, L):
     """the GPU tail on columns that no real index produces: positions and read numbers unrelated to the reads (mostly A, some lower
