@@ -65,6 +65,9 @@ struct Shared {
     int cl_fd = -1; FILE* snp_f = nullptr; std::string snp_path;
     std::atomic<int> rc{0};
     std::vector<uint64_t> closed, cands, events; int mcl = 0;
+    // where only the host tail reproduces the reference (a read rank past the last read, -L outside 1..64, an irregular FASTA): every
+    // rank appends its packed candidates in rank order and ONE e2s_snp_from_packed runs at the end
+    bool host_tail = false; std::vector<uint8_t> pk_stream; std::vector<uint32_t> pk_off8; uint32_t pk_pw = 4;
     std::mutex log_m;
 };
 
@@ -143,7 +146,7 @@ void rank_main(Shared& S, int r) {
         memcpy(&allb[(size_t)q], all.data() + BLOB * (size_t)q, sizeof(e2s_boundary));
         memcpy(&alls[(size_t)q], all.data() + BLOB * (size_t)q + sizeof(e2s_boundary), sizeof(e2s_scan_stats));
     }
-    int mcl = 0; uint64_t n_cand = 0, nv = 0, ne = 0, nb = 0;
+    int mcl = 0; uint64_t n_cand = 0, nv = 0, ne = 0, nb = 0, need_host = 0;
     if (!S.rc.load()) {
         STEP(e2s_stitch(h, allb.data(), S.nranks, r), "stitch");
         uint64_t nc = 0, nrec = 0;
@@ -164,22 +167,41 @@ void rank_main(Shared& S, int r) {
         S.cands[(size_t)r] = n_cand;
         if (!S.rc.load() && n_cand) {
             e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
-            STEP(e2s_call_variants(h, &tp, 1, &nv, &ne, &nb), "tail (consensus, distance, text)");
+            const int trc = e2s_call_variants(h, &tp, 1, &nv, &ne, &nb);
+            if (trc == E2S_ERR_STATE) { need_host = 1; ne = 0; } else STEP(trc, "tail (consensus, distance, text)");
         }
     }
     // the second exchange: events per rank, for sequential ids
     std::vector<uint8_t> alle;
-    if (all_gather(S, r, &ne, 8, alle, d_send, d_recv, xs)) S.rc.store(E2S_ERR_HIP);
-    uint64_t before = 0;
-    for (int q = 0; q < r; ++q) { uint64_t v; memcpy(&v, alle.data() + 8 * (size_t)q, 8); before += v; }
-    S.events[(size_t)r] = ne;
-    if (!S.rc.load() && ne && before) STEP(e2s_renumber_snp(h, 1 + before, &nb), "renumber");
+    const uint64_t mine2[2] = {ne, need_host};
+    if (all_gather(S, r, mine2, 16, alle, d_send, d_recv, xs)) S.rc.store(E2S_ERR_HIP);
+    uint64_t before = 0; bool host_tail = false;
+    for (int q = 0; q < S.nranks; ++q) {
+        uint64_t v[2]; memcpy(v, alle.data() + 16 * (size_t)q, 16);
+        if (q < r) before += v[0];
+        host_tail |= v[1] != 0;
+    }
+    S.events[(size_t)r] = host_tail ? 0 : ne;
+    if (!S.rc.load() && !host_tail && ne && before) STEP(e2s_renumber_snp(h, 1 + before, &nb), "renumber");
     // ---- the files, rank by rank ----
     S.cl_turn.wait_for(r);
     if (!S.rc.load()) { uint64_t w = 0; STEP(e2s_stream_clusters(h, fd_sink, &S.cl_fd, &w), "write .clusters"); }
     S.cl_turn.next();
     S.snp_turn.wait_for(r);
-    if (!S.rc.load() && ne) {
+    if (!S.rc.load() && host_tail) {
+        S.host_tail = true;
+        const void* st = nullptr; const uint32_t* of = nullptr; uint64_t nc2 = 0, bytes = 0; uint32_t pw = 4;
+        if (n_cand) STEP(e2s_candidates_packed(h, &st, &of, &nc2, &bytes, &pw), "packed candidates");
+        if (!S.rc.load() && n_cand) {
+            const uint64_t base8 = S.pk_stream.size() / 8;
+            if (base8 + bytes / 8 >= (1ull << 32)) S.rc.store(E2S_ERR_CAPACITY);
+            else {
+                S.pk_stream.insert(S.pk_stream.end(), (const uint8_t*)st, (const uint8_t*)st + bytes);
+                for (uint64_t i = 0; i < nc2; ++i) S.pk_off8.push_back((uint32_t)(base8 + of[i]));
+                S.pk_pw = pw;
+            }
+        }
+    } else if (!S.rc.load() && ne) {
         if (!S.snp_f) S.snp_f = fopen(S.snp_path.c_str(), "w");   // (comes into being with the first event: nothing where the reference crashes)
         if (!S.snp_f) S.rc.store(E2S_ERR_IO); else STEP(e2s_stream_snp(h, file_sink, S.snp_f), "write .snp");
     }
@@ -264,7 +286,15 @@ int main(int argc, char** argv) {
     for (auto& c : S.comms) ncclCommDestroy(c);
     uint64_t closed = 0, cands = 0, events = 0;
     for (int r = 0; r < S.nranks; ++r) { closed += S.closed[(size_t)r]; cands += S.cands[(size_t)r]; events += S.events[(size_t)r]; }
+    if (!S.rc.load() && S.host_tail && !S.pk_off8.empty()) {
+        S.pk_off8.push_back((uint32_t)(S.pk_stream.size() / 8));
+        e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
+        uint64_t nv = 0;
+        const int trc = e2s_snp_from_packed(S.pk_stream.data(), S.pk_off8.data(), S.pk_off8.size() - 1, S.pk_pw, &tp, o.input.c_str(), S.snp_path.c_str(), &nv, &events);
+        if (trc) { std::cerr << "host tail failed (" << trc << ")" << std::endl; S.rc.store(trc == E2S_ERR_REF_CRASH ? 139 : trc); }
+    }
     const int rc = S.rc.load();
+    if (rc == 139) { std::cerr << "the reference crashes on this input in its tail; no .snp written" << std::endl; return 139; }
     if (rc == 136) { std::cerr << "no usable cluster record: the reference divides by zero here (SIGFPE)" << std::endl; return 136; }
     if (rc) return 2;
     std::cout << "Done. " << (unsigned int)closed << " clusters saved to output file." << std::endl;

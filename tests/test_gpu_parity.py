@@ -980,6 +980,18 @@ def test_chunked_clust2snp_switches_to_host_tail_midway(tmp_path):
         assert open(IO.snp_out_path(p), "rb").read() == want and len(want) > 5000, chunk
         assert ("the pass runs again with the host tail" in r.stderr) == (chunk != "0")   # (one chunk: the host tail from the start)
         os.remove(IO.snp_out_path(p))
+    # the multi-GPU driver: the rank that meets the bad read rank makes ALL ranks hand their packed candidates to one host tail
+    mg = os.path.join(os.path.dirname(exe), "ebwt2snp_mgpu")
+    for ranks, opts in ((1, []), (3, []), (4, ["-L", "65"])):
+        if opts:
+            assert O.clust2snp(p, O.c2s_opts(n1, L=65))[0] == 0
+            want = open(IO.snp_out_path(p), "rb").read()
+            os.remove(IO.snp_out_path(p))
+        r = subprocess.run([mg, "-i", p, "-n", str(n1), "-G", str(ranks)] + opts, env=dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if ranks > 1 else "0"),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (ranks, r.stdout[-500:], r.stderr[-500:])
+        assert open(IO.snp_out_path(p), "rb").read() == want and len(want) > 2000, (ranks, opts)
+        os.remove(IO.snp_out_path(p))
 
 
 @pytest.mark.gpu
