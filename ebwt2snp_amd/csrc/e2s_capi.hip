@@ -1703,8 +1703,10 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     LCHK("e2s_launch_consensus");
     e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, h->d_words + 28, h->stream);
     LCHK("e2s_launch_tail_partials");
-    e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
-    LCHK("e2s_launch_tail_write");
+    if (first_id) {                                              // first_id 0: the ids come later (e2s_renumber_snp writes the text, once)
+        e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
+        LCHK("e2s_launch_tail_write");
+    }
     CK(hipEventRecord(h->ev[5], h->stream));
     uint64_t* mb = (uint64_t*)(h->pin_mail + 3200);
     CK(hipMemcpyAsync(mb, totals, 32, hipMemcpyDeviceToHost, h->stream));
@@ -1714,8 +1716,8 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     const uint32_t err = (uint32_t)mb[3];
     if (err & E2S_TAILERR_RANK) return fail(h, E2S_ERR_STATE, "GPU tail: a candidate names a read past the last one (the reference repeats stale text: use the host tail)");
     if (err & E2S_TAILERR_CRASH) return fail(h, E2S_ERR_REF_CRASH, "a right context starts beyond its read (-L longer than the shared context): the reference throws here");     // substr throws in the reference
-    if (mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
-    h->n_events = mb[0]; h->snp_bytes = mb[1]; h->n_variants = mb[2];
+    if (first_id && mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
+    h->n_events = mb[0]; h->snp_bytes = first_id ? mb[1] : 0; h->n_variants = mb[2];
     h->variants_valid = true; h->tail_p = *p; h->snp_first_id = first_id;
     if (n_variants) *n_variants = h->n_variants;
     if (n_events) *n_events = h->n_events;
@@ -1727,6 +1729,7 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
     dbg_entry("e2s_renumber_snp");
     if (!h) return E2S_ERR_ARG;
     if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
+    if (!first_id) return E2S_ERR_ARG;
     CK(hipSetDevice(h->device));
     if (first_id != h->snp_first_id) {                           // the text again with other ids: consensus and distance results stay
         const uint64_t n = h->n_cand, ng = (n + 63) / 64;
@@ -1755,6 +1758,7 @@ extern "C" int e2s_stream_snp(e2s_handle h, e2s_byte_sink sink, void* user) {
     dbg_entry("e2s_stream_snp");
     if (!h || !sink) return E2S_ERR_ARG;
     if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
+    if (!h->snp_first_id) return fail(h, E2S_ERR_STATE, "the ids were deferred (first_id 0): e2s_renumber_snp writes the text");
     CK(hipSetDevice(h->device));
     return stream_image(h, h->d_snp, h->snp_bytes, sink, user);
 }
@@ -1763,6 +1767,7 @@ extern "C" int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64
     dbg_entry("e2s_fetch_snp");
     if (!h || !bytes) return E2S_ERR_ARG;
     if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
+    if (!h->snp_first_id) return fail(h, E2S_ERR_STATE, "the ids were deferred (first_id 0): e2s_renumber_snp writes the text");
     *bytes = h->snp_bytes;
     if (!out) return E2S_OK;
     if (cap_bytes < h->snp_bytes) return fail(h, E2S_ERR_CAPACITY, "`.snp` output too small");

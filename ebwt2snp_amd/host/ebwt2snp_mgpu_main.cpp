@@ -167,7 +167,7 @@ void rank_main(Shared& S, int r) {
         S.cands[(size_t)r] = n_cand;
         if (!S.rc.load() && n_cand) {
             e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
-            const int trc = e2s_call_variants(h, &tp, 1, &nv, &ne, &nb);
+            const int trc = e2s_call_variants(h, &tp, 0, &nv, &ne, &nb);   // (first_id 0: the text is written once, after the exchange below)
             if (trc == E2S_ERR_STATE) { need_host = 1; ne = 0; } else STEP(trc, "tail (consensus, distance, text)");
         }
     }
@@ -182,7 +182,7 @@ void rank_main(Shared& S, int r) {
         host_tail |= v[1] != 0;
     }
     S.events[(size_t)r] = host_tail ? 0 : ne;
-    if (!S.rc.load() && !host_tail && ne && before) STEP(e2s_renumber_snp(h, 1 + before, &nb), "renumber");
+    if (!S.rc.load() && !host_tail && n_cand) STEP(e2s_renumber_snp(h, 1 + before, &nb), "ids and text");
     // ---- the files, rank by rank ----
     S.cl_turn.wait_for(r);
     if (!S.rc.load()) { uint64_t w = 0; STEP(e2s_stream_clusters(h, fd_sink, &S.cl_fd, &w), "write .clusters"); }

@@ -54,10 +54,13 @@ def resident_job(h, n1, n_total, rank=0, world=1, exchange=exchange_none, k=16, 
     out = dict(n_ends=b.n_ends, n_cand=ncand, mcl=mcl, n_clust=n_clust)
     if tail:
         # (a shard without candidates has no events; only a JOB without candidates is where the reference crashes)
-        nv, ne, nb = h.call_variants(k_left, k_right, max_gap, max_err, first_id=1) if ncand else (0, 0, 0)
-        if ids_exchange is not None:
+        if ids_exchange is None:
+            nv, ne, nb = h.call_variants(k_left, k_right, max_gap, max_err, first_id=1) if ncand else (0, 0, 0)
+        else:
+            # several ranks: the ids follow from the event counts of the ranks before -- the text is written once, after that exchange
+            nv, ne, nb = h.call_variants(k_left, k_right, max_gap, max_err, first_id=0) if ncand else (0, 0, 0)
             before = ids_exchange(ne)
-            if before and ncand:
+            if ncand:
                 nb = h.renumber_snp(1 + before)
         out.update(n_variants=nv, n_events=ne, snp_bytes=nb)
         t("tail")

@@ -275,7 +275,9 @@ int e2s_upload_reads_fasta(e2s_handle h, const char* fasta_path, uint64_t* n_rea
  * host tail reproduces the reference (-L outside 1..64, a read rank past the last read): use e2s_snp_from_packed then. */
 int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_t first_id, uint64_t* n_variants, uint64_t* n_events, uint64_t* snp_bytes);
 /* The same events with ids counting from another first_id (several ranks: every rank learns how many events the ranks before it
- * hold only after its own e2s_call_variants); consensus and distance results are kept, only the text is written again. */
+ * hold only after its own e2s_call_variants); consensus and distance results are kept, only the text is written again.
+ * e2s_call_variants with first_id 0 defers the text altogether (snp_bytes comes back 0; fetch / stream refuse): with several ranks the
+ * text is then written ONCE, by e2s_renumber_snp after the exchange of the event counts. */
 int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_bytes);
 /* the image, copied out whole or handed to a sink chunk by chunk (as e2s_stream_clusters) */
 int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64_t* bytes);
