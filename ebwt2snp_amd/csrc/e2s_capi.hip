@@ -1677,7 +1677,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     }
     if (ng + 1 > h->part_cap) {
         dev_free(h->d_part); h->d_part = nullptr; h->part_cap = 0;
-        CK(hipMalloc((void**)&h->d_part, (ng + 64) * 5 * 8 + 64));       // raw sums (3 per group) | exclusive prefixes (2 per group)
+        CK(hipMalloc((void**)&h->d_part, 64 + (ng + 64) * 5 * 8 + 64));  // totals + error word (8 words) | raw sums (3 per group) | exclusive prefixes (2 per group)
         h->part_cap = ng + 63;
     }
     // the image is sized from a bound per event: two header lines (prefix, id, right length, type, support) and two DNA lines
@@ -1688,20 +1688,19 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
         CK(hipMalloc((void**)&h->d_snp, bound + bound / 8));
         h->snp_cap = bound + bound / 8;
     }
-    unsigned long long* part_raw = h->d_part; unsigned long long* part_excl = h->d_part + 3 * (h->part_cap + 1);
-    unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);       // events, bytes, kept, error bits
-    CK(hipMemsetAsync(part_raw, 0, ng * 24, h->stream));
-    CK(hipMemsetAsync(totals, 0, 48, h->stream));
-    CK(hipMemsetAsync(h->d_words + 28, 0, 4, h->stream));
+    unsigned long long* totals = h->d_part;                      // events, bytes, kept, error bits, n_keep, -, error word (u32), -
+    unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
+    uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
+    CK(hipMemsetAsync(h->d_part, 0, 64 + ng * 24, h->stream));   // (one clear for the totals, the error word and the groups' sums)
     TailArgs a{};
     a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
     a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
     a.kl = p->k_left; a.kr = p->k_right; a.max_gap = p->max_gap; a.max_err = p->max_err;
-    a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = h->d_words + 28;
+    a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = tail_err;
     CK(hipEventRecord(h->ev[2], h->stream));
     e2s_launch_consensus(a, h->list_cap, h->stream);
     LCHK("e2s_launch_consensus");
-    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, h->d_words + 28, h->stream);
+    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, h->stream);
     LCHK("e2s_launch_tail_partials");
     if (first_id) {                                              // first_id 0: the ids come later (e2s_renumber_snp writes the text, once)
         e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
@@ -1733,14 +1732,15 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
     CK(hipSetDevice(h->device));
     if (first_id != h->snp_first_id) {                           // the text again with other ids: consensus and distance results stay
         const uint64_t n = h->n_cand, ng = (n + 63) / 64;
-        unsigned long long* part_raw = h->d_part; unsigned long long* part_excl = h->d_part + 3 * (h->part_cap + 1);
-        unsigned long long* totals = (unsigned long long*)(h->d_scalars + 230);
+        unsigned long long* totals = h->d_part;
+        unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
+        uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
         TailArgs a{};
         a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
         a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
         a.kl = h->tail_p.k_left; a.kr = h->tail_p.k_right; a.max_gap = h->tail_p.max_gap; a.max_err = h->tail_p.max_err;
-        a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = h->d_words + 28;
-        e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, h->d_words + 28, h->stream);
+        a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = tail_err;
+        e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, h->stream);
         e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
         LCHK("e2s_launch_tail_write");
         uint64_t* mb = (uint64_t*)(h->pin_mail + 3200);

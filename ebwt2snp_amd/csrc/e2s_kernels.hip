@@ -1581,11 +1581,13 @@ void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, cons
                        fl_count, err_a, err_b, mail);
 }
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
-// ~2 keys per bucket up to 2^16 buckets (the single-block scan of the counts costs ~0.4 us per 1024 buckets; beyond
-// that longer buckets are cheaper than a longer scan)
+// ~2 keys per bucket up to 2^14 buckets, then up to 32 per bucket before the table grows again: the single-block scan of the counts
+// is a chain of global round trips (2^16 buckets: 50-70 us on c3, more than the three other ordering kernels together), while a key
+// ranks itself against its bucket out of L2
 uint32_t e2s_cand_order_buckets(unsigned long long n) {
     u32 nb = 256;
-    while (nb < 65536u && nb < E2S_KO_MAX_BUCKETS && (u64)nb * 2 < n) nb <<= 1;
+    while (nb < 16384u && (u64)nb * 2 < n) nb <<= 1;
+    while (nb < 65536u && nb < E2S_KO_MAX_BUCKETS && (u64)nb * 32 < n) nb <<= 1;
     return nb;
 }
 // counts_cleared: the caller has zeroed the first e2s_cand_order_buckets(n) + 1 words of `scratch` already (k_cand_init)
