@@ -1,11 +1,11 @@
-// e2s_tail.hip -- clust2snp's tail on the GPU: the reads resident in HBM, one wave per candidate.
+// e2s_tail.hip -- clust2snp's tail on the GPU: the reads resident in HBM, a wave (k_left > 32) or a half-wave per candidate.
 //
-//   K3a k_consensus      extract_variants: the <= c + c left contexts of a candidate gathered from the reads, the two
-//                        consensus strings with cons' order-dependent tie-break (include.hpp:334-371), the supports
-//                        (clust2snp.cpp:544-593), the right context, and distance() (clust2snp.cpp:254-302)
-//   K3b k_tail_partials  exclusive scan of the per-group event counts / text lengths (one block)
-//   K3c k_tail_write     to_file (clust2snp.cpp:633-780): the KisSNP2 text of every event, ids sequential, written into
-//                        one image in HBM at offsets that follow from the scan
+//   K3a k_consensus[_pair]  extract_variants: the <= c + c left contexts of a candidate gathered from the reads, the two
+//                           consensus strings with cons' order-dependent tie-break (include.hpp:334-371), the supports
+//                           (clust2snp.cpp:544-593), the right context, and distance() (clust2snp.cpp:254-302)
+//   K3b k_tail_partials     exclusive scan of the per-group event counts / text lengths (one block)
+//   K3c k_tail_write        to_file (clust2snp.cpp:633-780): the KisSNP2 text of every event, ids sequential, written into
+//                           one image in HBM at offsets that follow from the scan
 //
 // Exactness: every step mirrors ebwt2snp_amd/host/snp_tail.cpp, which is pinned byte for byte to the reference's `.snp`;
 // what the GPU form cannot reproduce (a read rank past the last read, where the reference repeats stale text; k_left outside
@@ -49,7 +49,7 @@ __device__ __forceinline__ u32 tl_b2i4(u32 v) {
     const u32 code = (f >> 1) & 0x03030303u;
     return (code ^ (code >> 1)) & (ok | (ok << 1));
 }
-// The left contexts of a candidate into its LDS rows of 4 * LPR entries (character | base_to_int << 8): LPR lanes per row, an unaligned
+// The left contexts of a candidate into its LDS rows of 4 * LPR entries: LPR lanes per row, an unaligned
 // dword each, four rows per instruction and candidate (gl = the lane's number inside the candidate's 4 * LPR lanes), BATCH loads
 // issued back to back before the first LDS write.  Byte loads (one lane per character) are bound by the rate of load instructions:
 // 10^7 random 31-byte rows take 0.50 ms that way and 0.24 ms as dwords on an MI355X (tools/gather_probe.hip), 0.22 ms being what
@@ -108,12 +108,12 @@ __device__ __forceinline__ void tl_gather_rows_bytes(const TailArgs& a, uint16_t
 
 }  // namespace
 
-// ---- K3a ----------------------------------------------------------------------------------------------------------------------
+// ---- K3a, k_left 33..64 --------------------------------------------------------------------------------------------------------
 // One wave per candidate.  The work is a chain of dependent gathers (candidate record -> read index -> text), so nothing is
 // fetched one item at a time: lane j fetches list entry j and its read's start / length (one round trip for the whole list),
-// then the n x k_left characters of an allele's left contexts are gathered by all 64 lanes at once into LDS (rows of 64
-// bytes, 64 / kw rows per wave instruction, kw = k_left rounded up to a power of two), and consensus and supports run on LDS.
-// Dynamic LDS per wave: 2 x list_cap rows of 64 x 2 B (character | its base_to_int) + (8 + 4) B of row base / length each.
+// then the n x k_left characters of both alleles' left contexts are gathered by all 64 lanes at once into LDS rows of 64 entries
+// (tl_gather_rows: 16 lanes per row, a dword each), and consensus and supports run on LDS.
+// Dynamic LDS per wave: 2 x list_cap rows of 64 x 2 B (character | 8 * its base_to_int) + (8 + 4) B of row base / length each.
 extern __shared__ __attribute__((aligned(16))) uint8_t s_tail[];
 __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     __shared__ uint8_t s_ab[4][2][128];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     const u64 c = (u64)blockIdx.x * (blockDim.x >> 6) + wave;      // (1, 2 or 4 waves per block: long lists need the LDS)
     if (c >= a.n_cand) return;
     const size_t per_wave = (size_t)2 * list_cap * (128 + 8 + 4);
-    uint16_t* const ctx = (uint16_t*)(s_tail + wave * per_wave);    // [2 * list_cap][64] of (character | base_to_int << 8): allele 0's rows, then allele 1's
+    uint16_t* const ctx = (uint16_t*)(s_tail + wave * per_wave);    // [2 * list_cap][64] of (character | 8 * base_to_int << 8): allele 0's rows, then allele 1's
     u64* const rbase = (u64*)(s_tail + wave * per_wave + (size_t)2 * list_cap * 128);   // text offset of row j's first character
     u32* const rhave = (u32*)(rbase + 2 * list_cap);                // characters of row j that exist (the rest read as 0)
     const uint8_t* r = a.stream + (size_t)a.off8[c] * 8;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     const bool valid = c < a.n_cand;
     const size_t per_cand = (size_t)2 * list_cap * (64 + 8 + 4);
     uint8_t* const mine = s_tail + ((size_t)wave * 2 + half) * per_cand;
-    uint16_t* const ctx = (uint16_t*)mine;                          // [2 * list_cap][32] of (character | base_to_int << 8)
+    uint16_t* const ctx = (uint16_t*)mine;                          // [2 * list_cap][32] of (character | 8 * base_to_int << 8)
     u64* const rbase = (u64*)(mine + (size_t)2 * list_cap * 64);
     u32* const rhave = (u32*)(rbase + 2 * list_cap);
     const uint8_t* r = a.stream + (size_t)a.off8[valid ? c : c0] * 8;
