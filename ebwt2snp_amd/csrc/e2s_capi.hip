@@ -60,7 +60,7 @@ struct e2s_ctx {
     uint64_t text_bytes = 0;                                     // extent of d_text that the reads cover (the tail never loads past it)
     uint8_t* d_cons = nullptr; TailRec* d_trec = nullptr; uint64_t tail_cap = 0; unsigned long long* d_part = nullptr; uint64_t part_cap = 0;
     uint8_t* d_snp = nullptr; uint64_t snp_cap = 0, snp_bytes = 0, n_events = 0, n_variants = 0; bool variants_valid = false, snp_valid = false;
-    e2s_tail_params tail_p{}; uint64_t snp_first_id = 1;
+    e2s_tail_params tail_p{}; uint64_t snp_first_id = 1, snp_first_id_scan = 1, snp_bytes_at_first = 0;
     std::vector<uint8_t> host_fixed; std::vector<uint32_t> host_ident; bool host_fixed_valid = false;   // fixed-stride view, built on demand
     void* d_rank = nullptr; uint32_t* d_order = nullptr;           // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
@@ -100,6 +100,12 @@ struct e2s_ctx {
         }                                                                                                \
     } while (0)
 
+// sum of digits(v) over v in [0, x) (as tl_digit_sum_below in e2s_tail.hip: the ids' share of the `.snp` text in closed form)
+static uint64_t digit_sum_below(uint64_t x) {
+    uint64_t s = x, p = 10;
+    for (int k = 1; k < 20; ++k) { if (x > p) s += x - p; else break; if (k < 19) p *= 10; }
+    return s;
+}
 static int fail(e2s_handle h, int code, const std::string& msg) { if (h) h->err = msg; else g_create_error = msg; return code; }
 
 // Teardown and timing calls whose result cannot change what the caller does next: the result is dropped on purpose, in one place.
@@ -1717,6 +1723,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     if (err & E2S_TAILERR_CRASH) return fail(h, E2S_ERR_REF_CRASH, "a right context starts beyond its read (-L longer than the shared context): the reference throws here");     // substr throws in the reference
     if (first_id && mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
     h->n_events = mb[0]; h->snp_bytes = first_id ? mb[1] : 0; h->n_variants = mb[2];
+    h->snp_bytes_at_first = mb[1]; h->snp_first_id_scan = first_id;      // (e2s_renumber_snp derives other ids' sizes from these)
     h->variants_valid = true; h->tail_p = *p; h->snp_first_id = first_id;
     if (n_variants) *n_variants = h->n_variants;
     if (n_events) *n_events = h->n_events;
@@ -1730,25 +1737,24 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
     if (!h->variants_valid) return fail(h, E2S_ERR_STATE, "e2s_call_variants has not run");
     if (!first_id) return E2S_ERR_ARG;
     CK(hipSetDevice(h->device));
-    if (first_id != h->snp_first_id) {                           // the text again with other ids: consensus and distance results stay
-        const uint64_t n = h->n_cand, ng = (n + 63) / 64;
-        unsigned long long* totals = h->d_part;
+    if (first_id != h->snp_first_id) {                           // the text (again) with these ids: consensus and distance results stay
+        // the size of the image follows from the one the scan of the groups left (ids from snp_first_id) without asking the device:
+        // only the id digits differ, twice per event -- no host round trip here, the text is written behind whatever follows on the stream
+        const uint64_t ne = h->n_events;
+        const uint64_t text = h->snp_bytes_at_first - 2 * (digit_sum_below(h->snp_first_id_scan + ne) - digit_sum_below(h->snp_first_id_scan));
+        const uint64_t bytes = text + 2 * (digit_sum_below(first_id + ne) - digit_sum_below(first_id));
+        if (bytes > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
+        const uint64_t n = h->n_cand;
         unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
-        uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
         TailArgs a{};
         a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
         a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
         a.kl = h->tail_p.k_left; a.kr = h->tail_p.k_right; a.max_gap = h->tail_p.max_gap; a.max_err = h->tail_p.max_err;
-        a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = tail_err;
-        e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, h->stream);
+        a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = h->d_part + 4; a.err = (uint32_t*)(h->d_part + 6);
         e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
         LCHK("e2s_launch_tail_write");
-        uint64_t* mb = (uint64_t*)(h->pin_mail + 3200);
-        CK(hipMemcpyAsync(mb, totals, 32, hipMemcpyDeviceToHost, h->stream));
-        CK(wait_stream(h));
         CK(hipGetLastError());
-        if (mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
-        h->snp_bytes = mb[1]; h->snp_first_id = first_id;
+        h->snp_bytes = bytes; h->snp_first_id = first_id;
     }
     if (snp_bytes) *snp_bytes = h->snp_bytes;
     return E2S_OK;
