@@ -80,11 +80,13 @@ def _floor_log2(x):
     return h
 
 
-def build_egsa(reads, device=None):
-    """Exact EGSA of a fixed-length read set.
+def build_egsa(reads, device=None, lengths=None):
+    """Exact EGSA of a read set.
 
     reads: uint8 [R2, L] ASCII (ACGT only).  Returns dict of torch tensors in SA order:
     text int64, suff int64, lcp int64, bwt uint8, each of n = R2*(L+1) entries.
+    lengths (optional, int64 [R2], 0 <= lengths[r] <= L): reads of different lengths -- read r is reads[r, :lengths[r]],
+    the rest of its row is ignored; n = sum(lengths + 1).
     """
     if device is None:
         device = reads.device
@@ -94,11 +96,20 @@ def build_egsa(reads, device=None):
     for c, v in ((65, 1), (67, 2), (71, 3), (84, 4)):
         lut[c] = v
     codes1 = lut[reads.long()]
+    if lengths is not None:
+        lengths = torch.as_tensor(lengths, dtype=torch.int64, device=device)
+        codes1 = torch.where(torch.arange(L, device=device)[None, :] < lengths[:, None], codes1, torch.zeros_like(codes1))
     W = (L + _CH - 1) // _CH
     Pq = _pack_positions(codes1, W)
     del codes1
-    n = R2 * (L + 1)
-    perm = torch.arange(n, device=device)
+    if lengths is None:
+        n = R2 * (L + 1)
+        perm = torch.arange(n, device=device)
+    else:
+        # the suffixes that exist, in (read, offset) order: flat indices r * (L + 1) + p with p <= lengths[r]
+        ok = torch.arange(L + 1, device=device)[None, :] <= lengths[:, None]
+        perm = torch.nonzero(ok.reshape(-1))[:, 0]
+        n = int(perm.numel())
     # LSD radix over the packed words; stable sorts keep ties in (read, offset) order, which is
     # the terminator order: identical suffixes of different reads sort by read index.
     for k in reversed(range(W)):
@@ -123,7 +134,7 @@ def build_egsa(reads, device=None):
         lcp[1:] += torch.where(alive, part, torch.zeros_like(part))
         alive = alive & ~diff
         del key, a, b, x, diff, part
-    rem = L - suff                                   # suffix length without terminator
+    rem = (L if lengths is None else lengths[text]) - suff   # suffix length without terminator
     cap = torch.minimum(rem[:-1], rem[1:])
     lcp[1:] = torch.minimum(lcp[1:], cap)
     prev = torch.clamp(suff - 1, min=0)
@@ -161,6 +172,30 @@ def synth_case(n_reads_per_indiv, read_len, seed=1, device="cpu", coverage=20, t
     if tail_lcp0:
         e["lcp"][-1] = 0
     return reads, n1, e
+
+
+def ragged_lengths(n_reads, read_len, seed, k_left=31):
+    """lengths of a trimmed read set (what real FASTA input looks like): most reads between 40 % and 100 % of read_len, one in
+    sixteen shorter than the left context (-L) altogether, the last read the shortest of all."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + 77)
+    lo = max(2, (2 * read_len) // 5)
+    ln = torch.randint(lo, read_len + 1, (n_reads,), generator=g)
+    short = torch.rand(n_reads, generator=g) < (1.0 / 16.0)
+    ln = torch.where(short, torch.randint(4, max(5, k_left), (n_reads,), generator=g), ln)
+    ln[-1] = 3
+    return ln
+
+
+def synth_case_ragged(n_reads_per_indiv, read_len, seed=1, device="cpu", coverage=20, tail_lcp0=True):
+    """as synth_case with reads of different lengths.  Returns (list of bytes, nr_reads1, EGSA dict, lengths int64 [2R])."""
+    reads, n1 = make_reads(n_reads_per_indiv, read_len, coverage=coverage, seed=seed, device=device)
+    ln = ragged_lengths(reads.shape[0], read_len, seed)
+    e = build_egsa(reads, device=device, lengths=ln)
+    if tail_lcp0:
+        e["lcp"][-1] = 0
+    rn = reads.cpu().numpy()
+    return [rn[r, :int(ln[r])].tobytes() for r in range(rn.shape[0])], n1, e, ln
 
 
 def egsa_to_numpy(e, x=1, y=4, z=1):

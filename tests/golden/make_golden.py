@@ -147,10 +147,18 @@ E2E = [
     ("tail_bcr", 1000, 100, 8, False, (1, 4, 1), {}, {}, False, 20, False),
     ("tail_gesa", 1000, 100, 9, True, (1, 4, 1), {}, {}, False, 20, False),
     ("indel_bcr", 3000, 100, 12, False, (1, 4, 1), {}, {}, True, 20, False),
+    # reads of DIFFERENT lengths (trimmed reads: 40-100 % of L, one in sixteen shorter than -L, the last read the shortest; clust2snp.cpp:147-212
+    # reads whatever the FASTA holds): a 13th field = the FASTA line width (0: one line per read)
+    ("rag_bcr", 1500, 100, 21, False, (1, 4, 1), {}, {}, True, 30, False, 0),
+    ("rag150_gesa", 1500, 150, 22, True, (1, 4, 1), {}, {}, False, 30, False, 70),
+    ("rag_opts_bcr", 1200, 120, 23, False, (1, 4, 1), {}, {"L": 20, "R": 25, "m": 3}, True, 30, False, 0),
 ]
 
 
-def e2e_inputs(R, L, seed, cov, tail, xyz):
+def e2e_inputs(R, L, seed, cov, tail, xyz, ragged=False):
+    if ragged:
+        reads, n1, e, _ = synth.synth_case_ragged(R, L, seed=seed, coverage=cov, tail_lcp0=tail)
+        return reads, n1, synth.egsa_to_numpy(e, *xyz)
     reads, n1, e = synth.synth_case(R, L, seed=seed, coverage=cov, tail_lcp0=tail)
     en = synth.egsa_to_numpy(e, *xyz)
     return reads.numpy(), n1, en
@@ -158,14 +166,17 @@ def e2e_inputs(R, L, seed, cov, tail, xyz):
 
 def input_digest(reads, en):
     h = hashlib.sha256()
-    h.update(reads.tobytes())
+    h.update(b"\n".join(reads) if isinstance(reads, list) else reads.tobytes())
     for k in ("text", "suff", "lcp", "bwt"):
         h.update(en[k].astype(np.uint64).tobytes())
     return h.hexdigest()
 
 
-def run_e2e(name, R, L, seed, gesa, xyz, ea, ca, tail, cov, store, wd):
-    reads, n1, en = e2e_inputs(R, L, seed, cov, tail, xyz)
+def run_e2e(name, R, L, seed, gesa, xyz, ea, ca, tail, cov, store, *rest):
+    wd = rest[-1]
+    ragged = len(rest) > 1
+    width = rest[0] if ragged else 0
+    reads, n1, en = e2e_inputs(R, L, seed, cov, tail, xyz, ragged)
     x, y, z = xyz
     res = {}
     for tag in ("ref", "orc"):
@@ -173,7 +184,7 @@ def run_e2e(name, R, L, seed, gesa, xyz, ea, ca, tail, cov, store, wd):
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d)
         p = os.path.join(d, "reads.fasta")
-        IO.write_fasta(p, reads)
+        IO.write_fasta(p, reads, width=width or None)
         (IO.write_gesa if gesa else IO.write_bcr)(p, en["text"], en["suff"], en["lcp"], en["bwt"], x, y, z)
         if tag == "ref":
             a = []
@@ -206,6 +217,8 @@ def run_e2e(name, R, L, seed, gesa, xyz, ea, ca, tail, cov, store, wd):
                 clusters_sha256=sha(r["clusters"]), n_records=len(r["clusters"]) // 10, n_printed=r["n_printed"],
                 max_clust_length=r["mcl"], n_candidates=r["ncand"], snp_file=name + ".snp",
                 n_events=r["snp"].count(b">") // 2, n_indel_events=r["snp"].count(b">INDEL_higher"))
+    if ragged:
+        meta.update(ragged=True, fasta_width=width, min_read_len=min(len(q) for q in reads), max_read_len=max(len(q) for q in reads))
     with open(os.path.join(HERE, name + ".snp"), "wb") as f:
         f.write(r["snp"])
     if store:

@@ -39,13 +39,16 @@ def e2e_inputs(meta):
         z = np.load(os.path.join(GOLD, meta["inputs_file"]))
         reads = z["reads"]
         en = {k: z[k] for k in ("text", "suff", "lcp", "bwt")}
+    elif meta.get("ragged"):
+        reads, n1, e, _ = synth.synth_case_ragged(meta["R"], meta["L"], seed=meta["seed"], coverage=meta["coverage"], tail_lcp0=meta["tail_lcp0"])
+        en = synth.egsa_to_numpy(e, *meta["xyz"])
     else:
         r, n1, e = synth.synth_case(meta["R"], meta["L"], seed=meta["seed"], coverage=meta["coverage"],
                                     tail_lcp0=meta["tail_lcp0"])
         reads = r.numpy()
         en = synth.egsa_to_numpy(e, *meta["xyz"])
     h = hashlib.sha256()
-    h.update(reads.tobytes())
+    h.update(b"\n".join(reads) if isinstance(reads, list) else reads.tobytes())
     for k in ("text", "suff", "lcp", "bwt"):
         h.update(en[k].astype(np.uint64).tobytes())
     assert h.hexdigest() == meta["input_sha256"], "synthetic generator drifted from the golden inputs"
@@ -54,7 +57,7 @@ def e2e_inputs(meta):
 
 def write_case_files(meta, reads, en, d, name="reads.fasta"):
     p = os.path.join(d, name)
-    IO.write_fasta(p, reads)
+    IO.write_fasta(p, reads, width=meta.get("fasta_width") or None)
     x, y, z = meta["xyz"]
     (IO.write_gesa if meta["gesa"] else IO.write_bcr)(p, en["text"], en["suff"], en["lcp"], en["bwt"], x, y, z)
     return p

@@ -1064,3 +1064,72 @@ def test_gpu_tail_option_corners(H, tmp_path, opts):
         out[tag] = open(IO.snp_out_path(p), "rb").read()
     assert out["hip"] == out["orc"]
     assert (out["orc"] is None) == (opts.get("L") == 90) and (out["orc"] is None or len(out["orc"]) > 1000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,L", [(211, 31), (212, 20), (213, 40)])
+def test_gpu_tail_fuzz_ragged_reads(H, tmp_path, seed, L):
+    """reads of DIFFERENT lengths on the GPU tail -- the (start, length) index path of k_consensus[_pair], which reads of one length
+    never take: fuzzed columns as above over reads of 1..100 characters (the last read the shortest), every suffix position clamped
+    to its own read's length (beyond it the reference reads past a std::string: undefined), many of them AT the read's end.  The
+    `.snp` bytes against the oracle's (a) through the FASTA index (e2s_upload_reads_fasta) and (b) with the reads attached as device
+    arrays whose rows are NOT laid end to end (gaps, shuffled order: e2s_attach_reads with d_start / d_len)"""
+    import torch
+    en, _, mcov, Rc = _fuzz_columns(seed)
+    rnd = np.random.RandomState(seed)
+    n = en["lcp"].size
+    nreads = 2000
+    lens = rnd.randint(40, 101, nreads)
+    short = rnd.rand(nreads) < 0.1
+    lens[short] = rnd.randint(1, L + 2, int(short.sum()))        # shorter than the left context, or just long enough
+    lens[-1] = 1
+    full = np.full((nreads, 100), 65, dtype=np.uint8)
+    mut = rnd.rand(nreads, 100) < 0.05
+    full[mut] = rnd.choice(np.array([67, 71, 84, 97, 99, 103, 116], dtype=np.uint8), int(mut.sum()))
+    reads = [full[r, :lens[r]].tobytes() for r in range(nreads)]
+    text = en["text"].copy()
+    text[rnd.rand(n) < 0.1] = nreads - 1                         # the last (shortest) read, often
+    suff = en["suff"].astype(np.int64)
+    far = rnd.rand(n) < 0.2
+    suff[far] = 1000                                             # -> clamped to the read's end below
+    suff = np.minimum(suff, lens[np.minimum(text, nreads - 1)]).astype(np.uint8)
+    en = dict(en, suff=suff, text=text)
+    out = {}
+    for tag in ("hip", "orc"):
+        os.makedirs(str(tmp_path / tag))
+        p = str(tmp_path / tag / "reads.fasta")
+        IO.write_fasta(p, reads)
+        IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+        if tag == "hip":
+            tools.ebwt2clust(p, handle=H)
+            r = tools.clust2snp(p, 1000, handle=H, L=L, R=Rc, m=mcov)
+            assert r["n_candidates"] > 50
+            H.call_variants(L, Rc, 10, 2)                        # the GPU tail applies (no fall-back to the host tail) ...
+            assert H.fetch_snp().tobytes() == open(IO.snp_out_path(p), "rb").read()
+            # ... and the same candidates over reads attached as device arrays: rows in shuffled order with gaps between them
+            order = rnd.permutation(nreads)
+            start = np.zeros(nreads, dtype=np.uint64)
+            at = 3
+            for q in order:
+                start[q] = at
+                at += int(lens[q]) + int(rnd.randint(0, 7))
+            buf = np.full(at + 8, ord("N"), dtype=np.uint8)
+            for q in range(nreads):
+                buf[int(start[q]):int(start[q]) + int(lens[q])] = np.frombuffer(reads[q], dtype=np.uint8)
+            d_text, d_start, d_len = (torch.from_numpy(x).cuda() for x in (buf, start.view(np.int64), lens.astype(np.int32)))
+            torch.cuda.synchronize()
+            h2 = capi.Handle(0)
+            tools._open_shard(h2, p, 1, 4, 1)
+            h2.attach_reads(d_text.data_ptr(), d_start.data_ptr(), d_len.data_ptr(), nreads, int(lens.max()), keep=(d_text, d_start, d_len))
+            recs = np.fromfile(p + ".clusters", dtype=np.uint8)
+            h2.load_clusters(recs)
+            mcl, _, _ = capi.auto_max_clust_length([h2.hist()], mcov, 0.99)
+            assert h2.find_candidates(capi.C2SParams(1000, L, Rc, mcov, 20, mcl, 0)) == r["n_candidates"]
+            h2.call_variants(L, Rc, 10, 2)
+            assert h2.fetch_snp().tobytes() == open(IO.snp_out_path(p), "rb").read()
+            h2.close()
+        else:
+            assert O.ebwt2clust(p)[0] == 0
+            assert O.clust2snp(p, O.c2s_opts(1000, L=L, R=Rc, m=mcov))[0] == 0
+        out[tag] = open(IO.snp_out_path(p), "rb").read()
+    assert out["hip"] == out["orc"] and out["orc"].count(b">SNP_higher") > 50
