@@ -86,11 +86,16 @@ def tile_reads(reads, n1, copies):
 
 def pick_cut(lcp, approx):
     """an SA position near `approx` that lies strictly inside a cluster (both neighbours share >= 16)"""
-    w = lcp[approx:approx + 100000].to(torch.int32)
-    # c-1, c, c+1 all >= 16 and c-1 not a local minimum: the cluster runs through the cut
-    inside = (w[1:-2] >= 16) & (w[2:-1] >= 16) & (w[3:] >= 16) & (w[1:-2] >= w[:-3])
-    idx = torch.nonzero(inside)[0].item()
-    return approx + idx + 2
+    # (window after window: a cut may fall into a stretch without clusters -- the 2x10^6 terminator-only suffixes that open every block)
+    while True:
+        w = lcp[approx:approx + 100000].to(torch.int32)
+        assert w.numel() > 4, "no cluster to cut through"
+        # c-1, c, c+1 all >= 16 and c-1 not a local minimum: the cluster runs through the cut
+        inside = (w[1:-2] >= 16) & (w[2:-1] >= 16) & (w[3:] >= 16) & (w[1:-2] >= w[:-3])
+        nz = torch.nonzero(inside)
+        if nz.numel():
+            return approx + int(nz[0].item()) + 2
+        approx += 99990
 
 
 def shard_weak(blk, m, rank, world):
@@ -168,8 +173,51 @@ def _exchange(blob, world, dist, dev):
     return [raw[i * n:(i + 1) * n] for i in range(world)]
 
 
-def run_step(h, n1, n_total, world, rank, dist, dev, fused=True, on_host=False):
+def emulate_peers(blk, m, n1, rd, L, er, en_, local):
+    """what the other ranks of an en_-way strong cut would publish: every rank's descriptor + statistics blob (one scan of its
+    range each) and the events of the ranks before `er` (their whole step, with the gathered blobs)"""
+    import ctypes
+    blobs, events = [], []
+    for q in range(en_):
+        arrs, g0, n_own, hl, hr = shard_strong(blk, m, q, en_)
+        torch.cuda.synchronize()
+        h = capi.Handle(local)
+        h.attach_soa(capi.Handle.desc(m, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr), arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(),
+                     arrs["pos"].data_ptr(), arrs["da"].data_ptr(), keep=tuple(arrs.values()))
+        h.cluster_scan(16, 2, 0)
+        blobs.append(bytes(h.boundary()) + bytes(h.scan_stats()))
+        h.close()
+        del arrs
+    for q in range(er):
+        arrs, g0, n_own, hl, hr = shard_strong(blk, m, q, en_)
+        torch.cuda.synchronize()
+        h = capi.Handle(local)
+        h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
+        h.attach_soa(capi.Handle.desc(m, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr), arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(),
+                     arrs["pos"].data_ptr(), arrs["da"].data_ptr(), keep=tuple(arrs.values()))
+        r = pipeline.resident_job(h, n1, m, q, en_, lambda blob: blobs, ids_exchange=lambda ne: sum(events))
+        events.append(int(r["n_events"]))
+        h.close()
+        del arrs
+    torch.cuda.empty_cache()
+    return dict(blobs=blobs, events_before=sum(events))
+
+
+def run_step(h, n1, n_total, world, rank, dist, dev, fused=True, on_host=False, emul=None):
     _T[0] = time.perf_counter()
+    if emul is not None:
+        # one rank of an N-way cut: its own blob really travels (a one-rank RCCL all-gather, when a process group exists), the
+        # peers' blobs are the cached ones
+        def ex(blob):
+            mine = _exchange(blob, 1, dist, dev)[0] if dist is not None else blob
+            return emul["blobs"][:emul["rank"]] + [mine] + emul["blobs"][emul["rank"] + 1:]
+
+        def ids(ne):
+            if dist is not None:
+                _exchange(np.uint64(ne).tobytes(), 1, dist, dev)
+            return emul["events_before"]
+        r = pipeline.resident_job(h, n1, n_total, emul["rank"], emul["world"], ex, fused=fused, ids_exchange=ids, tick=_tick)
+        return r
     ex = pipeline.exchange_none if dist is None else (lambda blob: _exchange(blob, world, dist, dev))
     ids = None
     if dist is not None:
@@ -377,7 +425,20 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         reads, n1_block, blk0 = build_block(R, L, dev)
     blk, n1 = tile_block(blk0, n1_block, copies)
     m = blk["lcp"].numel()
-    if world == 1:
+    emul = None
+    if a.emulate_rank:
+        # ONE rank of the N-way strong cut (BASELINE.json configs[3]) on this GPU, with the N-rank bookkeeping: the other ranks'
+        # descriptors, statistics and event counts are worked out once, before the timed region (emulate_peers), and every exchange
+        # of the timed step is a real one-rank RCCL all-gather whose result is completed with those cached blobs
+        er, en_ = (int(v) for v in a.emulate_rank.split("/"))
+        assert 0 <= er < en_ and world == 1
+        emul = dict(rank=er, world=en_)
+        emul.update(emulate_peers(blk, m, n1, tile_reads(reads.to(dev), n1_block, copies), L, er, en_, local))
+        arrs, g0, n_own, hl, hr = shard_strong(blk, m, er, en_)
+        n_total = m
+        del blk
+        torch.cuda.empty_cache()
+    elif world == 1:
         arrs, g0, n_own, hl, hr, n_total = blk, 0, m, 0, 0, m      # (no copy)
     elif scaling == "strong":
         arrs, g0, n_own, hl, hr = shard_strong(blk, m, rank, world)
@@ -405,13 +466,13 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         """W untimed + K timed steps of the whole job, bracketed by barrier + synchronize; max over ranks"""
         info = None
         for _ in range(n_warm):
-            info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host)
+            info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host, emul=emul)
         r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[], tail_ms=[])
         barrier()
         PHASES.clear()
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host)
+            info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host, emul=emul)
             tm = h.timing()
             r["scan_ms"].append(tm.scan_main_ms); r["cand_ms"].append(tm.cand_main_ms); r["scan_all_ms"].append(tm.scan_ms)
             r["hist_ms"].append(tm.hist_ms); r["tail_ms"].append(tm.tail_ms)
@@ -426,8 +487,8 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         return r
 
     prim = measure(True, warmup, steps)
-    other = measure(False, min(warmup, 2) + 1, max(3, steps // 2)) if SECOND_LEG else None
-    host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True)
+    other = measure(False, min(warmup, 2) + 1, max(3, steps // 2)) if SECOND_LEG and emul is None else None
+    host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True) if emul is None else None
     info = prim["info"]
     keys = ("n_ends", "n_cand", "mcl", "n_events", "snp_bytes", "n_records")
     if other is not None:
@@ -470,12 +531,18 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             # written.  SURVEY 8d prices the reference's access pattern (7 B/entry + 10 B/record); this design never reads DA / pos for
             # the 99.7 % of clusters its pre-filter rejects, so against THAT figure the kernel would read 'frac_vs_survey_bytes' > 1
             "roofline": roof("k_scan_seg<1,true>", fused_bytes, fused_ms),
-            "value_outputs_on_host": n_total * host["steps"] / host["elapsed"],
+            "value_outputs_on_host": n_total * host["steps"] / host["elapsed"] if host else None,
             "tail_ms": float(np.mean(prim["tail_ms"])),
         }
+        if emul is not None:
+            res["kernel_ms"] = {"scan+prefilter+fix+stats": float(np.mean(prim["scan_all_ms"])), "scan_kernel": fused_ms,
+                                "per_cluster_pass_to_K2b_end": float(np.mean(prim["cand_ms"])), "tail": float(np.mean(prim["tail_ms"]))}
+            res["rank_entries"] = n_own
+            res["target_ms_for_6x_at_8"] = None
         res["roofline"].update({"survey_8d_bytes": ref_pattern_bytes + n_own, "frac_vs_survey_bytes": (ref_pattern_bytes + n_own) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "frac_uses": "algorithmic_bytes (2 B/entry + 10 B/record)", "hist_ms": float(np.mean(prim["hist_ms"]))})
-        res["config"]["outputs_on_host_phase_ms"] = {k2: round(v / host["steps"] * 1e3, 4) for k2, v in host["phases"].items()}
+        if host:
+            res["config"]["outputs_on_host_phase_ms"] = {k2: round(v / host["steps"] * 1e3, 4) for k2, v in host["phases"].items()}
         if other is not None:
             scan_ms, pf_ms = float(np.mean(other["scan_ms"])), float(np.mean(other["cand_ms"]))
             # the north-star kernel -- ebwt2clust's scan alone -- and the pre-filter as a kernel of its own
@@ -505,6 +572,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample", type=int, default=100000000, help="entries of the CPU baseline sample (0 = skip)")
     ap.add_argument("--second-workload", default="c2", help="a second, shorter leg on this workload ('' = none; N = 1 only)")
+    ap.add_argument("--emulate-rank", default="", help="R/N: time rank R of the N-way STRONG cut of the workload on this one GPU (N-rank bookkeeping, "
+                    "one-rank RCCL exchanges; the peers' descriptors are computed before the timed region).  Not the driver's metric: a readiness check")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -517,7 +586,10 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
     dist = None
-    if world > 1 or (FORCE_DIST and "RANK" in os.environ):
+    if a.emulate_rank and world == 1 and "RANK" not in os.environ and os.environ.get("E2S_BENCH_EMUL_NO_RCCL", "0") != "1":
+        # a one-rank RCCL process group in this very process: the exchanges of the emulated rank are real collectives
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000)))
+    if world > 1 or ((FORCE_DIST or a.emulate_rank) and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
@@ -538,6 +610,18 @@ def main():
         return
 
     res = measure_workload(a, a.workload, world, rank, local, dist, dev, a.steps, a.warmup, a.scaling, with_cpu=False)
+    if a.emulate_rank:
+        er, en_ = (int(v) for v in a.emulate_rank.split("/"))
+        res.pop("value_outputs_on_host", None)
+        out = {"what": "rank %d of the %d-way STRONG cut of %s on one GPU (BASELINE.json configs[3] readiness): N-rank bookkeeping, %s" % (
+                   er, en_, a.workload, "both exchanges as one-rank RCCL all-gathers" if dist is not None else "exchanges skipped (no process group)"),
+               "emulated_rank": er, "emulated_world": en_, "ms_per_step": res["ms_per_step"], "steps": a.steps, "warmup": a.warmup,
+               }
+        out.update({k2: v for k2, v in res.items() if k2 not in ("value", "ms_per_step")})
+        print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     second = None
     if world == 1 and a.second_workload and a.second_workload != a.workload and a.second_workload in WORKLOADS:
         second = measure_workload(a, a.second_workload, world, rank, local, dist, dev, a.steps, a.warmup, "weak", with_cpu=True)
