@@ -80,6 +80,10 @@ struct e2s_ctx {
     // segmented record storage (scan_mode 0): segment b = d_starts/d_lens[b*seg_cap ...), SegDesc per block
     bool segmented = false; uint32_t seg_cap = 0, seg_blocks = 0; SegDesc* d_seg_desc = nullptr; uint64_t* d_seg_off = nullptr;
     uint32_t seg_blocks_cap = 0;
+    // the scan that writes the image itself (k_scan_seg<1, FUSED, true>): records live in d_img only, statistics come with the mail
+    bool img_mode = false; uint64_t img_scan_records = 0; uint32_t img_skip = 0;     // img_skip: the shard's record 0 turned out shorter than min_len
+    uint8_t* d_imgst = nullptr; size_t imgst_bytes = 0; int img_waves[2] = {0, 0};      // ticket | statistics | status words A, B | per-wave reports
+    std::vector<uint64_t> wrap_pairs;                             // img_mode: (start, u16 length) of records whose true length wrapped
     uint64_t first_rec_addr = E2S_NONE;
     uint64_t* d_cstarts = nullptr; uint16_t* d_clens = nullptr; uint64_t ccap = 0; bool compact_valid = false;   // contiguous copy, on demand
     uint8_t* pin_mail = nullptr;                 // 4 KB pinned mailbox for small downloads / uploads
@@ -165,7 +169,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
         return E2S_ERR_HIP;
     }
     if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&h->d_wrap, E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, 4096) != hipSuccess ||   // ScanMail | statistics at +256
+        hipMalloc(&h->d_wrap, 2 * E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, 4096) != hipSuccess ||   // ScanMail | statistics at +256
         hipHostMalloc((void**)&h->pin_mail, 4096, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         e2s_destroy(h);
@@ -241,7 +245,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     release_reads(h);
     dev_free(h->d_cons); dev_free(h->d_trec); dev_free(h->d_part); dev_free(h->d_snp);
     for (auto& ev : h->ev) if (ev) ev_destroy(ev);
-    dev_free(h->d_img); dev_free(h->d_img_scratch);
+    dev_free(h->d_img); dev_free(h->d_img_scratch); dev_free(h->d_imgst);
     for (auto& p : h->pin_io) if (p) pin_free(p);
     for (auto& e : h->ev_io) if (e) ev_destroy(e);
     if (h->ev_wait) ev_destroy(h->ev_wait);
@@ -459,8 +463,32 @@ static int ensure_records(e2s_ctx* h, uint64_t cap) {
 
 // contiguous record arrays for consumers that index records by rank (file output, record-driven pass).
 // scan_mode 0 keeps records in per-block segments; this gathers them once, on demand, tail records included.
-static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_t** lens) {
+static int pack_image(e2s_ctx* h, uint64_t* n_records);
+static const uint8_t* image_ptr(const e2s_ctx* h) { return h->d_img ? h->d_img + (h->img_mode ? 10ull * h->img_skip : 0ull) : nullptr; }
+static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_t** lens, uint64_t* n) {
+    *n = h->n_rec;
     if (!h->segmented) { *starts = h->d_starts; *lens = h->d_lens; return E2S_OK; }
+    if (h->img_mode) {
+        // the records live in the packed image only (those append_entry keeps: the others matter to nobody downstream)
+        uint64_t nr = 0;
+        int rc = pack_image(h, &nr);
+        if (rc) return rc;
+        *n = nr;
+        if (!h->compact_valid) {
+            if (nr + 8 > h->ccap) {
+                dev_free(h->d_cstarts); dev_free(h->d_clens); h->d_cstarts = nullptr; h->d_clens = nullptr; h->ccap = 0;
+                CK(hipMalloc((void**)&h->d_cstarts, (nr + 8) * 8));
+                CK(hipMalloc((void**)&h->d_clens, (nr + 8) * 2 + 64));
+                h->ccap = nr + 8;
+            }
+            e2s_launch_unpack_clusters(image_ptr(h), nr, (unsigned long long*)h->d_cstarts, h->d_clens, h->d_words + 28, h->stream);   // (ordering word: unused here)
+            CK(hipStreamSynchronize(h->stream));
+            CK(hipGetLastError());
+            h->compact_valid = true;
+        }
+        *starts = h->d_cstarts; *lens = h->d_clens;
+        return E2S_OK;
+    }
     if (!h->compact_valid) {
         if (h->n_rec + 8 > h->ccap) {
             dev_free(h->d_cstarts); dev_free(h->d_clens); h->d_cstarts = nullptr; h->d_clens = nullptr; h->ccap = 0;
@@ -481,6 +509,108 @@ static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_
         h->compact_valid = true;
     }
     *starts = h->d_cstarts; *lens = h->d_clens;
+    return E2S_OK;
+}
+
+// the statistics the scan phase leaves behind the mail (k_hist_seg / k_scan_img_fin layout) -> e2s_scan_stats
+static void take_scan_stats(e2s_ctx* h, const ScanMail& mail, int min_len) {
+    const uint64_t* buf = (const uint64_t*)(h->pin_mail + 256);
+    e2s_scan_stats& rs = h->raw_stats;
+    memset(&rs, 0, sizeof(rs));
+    memcpy(rs.hist.freq, buf, (E2S_MAX_CLUST_LEN + 1) * 8);
+    rs.hist.n_records = buf[E2S_MAX_CLUST_LEN + 1];
+    rs.hist.n_bases = buf[E2S_MAX_CLUST_LEN + 2];
+    const uint64_t at = buf[E2S_MAX_CLUST_LEN + 4];
+    rs.last_none = at == ~0ull ? 1u : 0u;
+    rs.last_is_first = (!rs.last_none && at == mail.first_rec_addr) ? 1u : 0u;
+    rs.hist.last_len = rs.last_none ? 0 : buf[E2S_MAX_CLUST_LEN + 3];
+    rs.min_len = min_len;
+    h->raw_stats_valid = true;
+    ev_ms(&h->tm.hist_ms, h->ev[3], h->ev[1]);                  // the scan's follow-up kernel(s)
+}
+
+static int ensure_image(e2s_ctx* h, uint64_t records) {
+    if (records <= h->img_cap && h->d_img) return E2S_OK;
+    dev_free(h->d_img); dev_free(h->d_img_scratch); h->d_img = nullptr; h->d_img_scratch = nullptr; h->img_cap = 0;
+    const uint64_t cap = records + records / 8 + 4096;
+    CK(hipMalloc((void**)&h->d_img, cap * 10 + 64));
+    CK(hipMalloc((void**)&h->d_img_scratch, std::max<uint64_t>(e2s_pack_clusters_blocks(cap) * 12 + 64, (uint64_t)(8192 + 2) * 12 + 64)));
+    h->img_cap = cap;
+    return E2S_OK;
+}
+
+// The scan that writes the `.clusters` image and the statistics itself (k_scan_seg<1, FUSED, true>: byte LCPs, 16-byte aligned
+// columns): one kernel + one block that gathers the mail.  *done stays false where the input is denser than the chunks' staging
+// buffers or the image's estimate (E2S_DEVERR_SEGFULL): the caller then takes the segment path, which handles everything.
+static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail, bool* done) {
+    *done = false;
+    const uint64_t n_tiles = (h->n_prov + 4095) / 4096;
+    const uint64_t n_chunks = (n_tiles + E2S_IMG_TILES - 1) / E2S_IMG_TILES;
+    if (n_chunks + E2S_IMG_GRANT >= (1ull << 31)) return E2S_OK;                          // (2^46 entries: not on one GPU)
+    static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
+    const bool fused = h->pf_armed && fused_env && prefilter_eligible(h);
+    int& resident = h->img_waves[fused ? 1 : 0];
+    if (!resident) {
+        resident = e2s_scan_img_resident_waves(fused);
+        if (const char* ev = getenv("E2S_SCAN_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < resident) resident = cap; }
+        if (resident < 4) resident = 4;
+    }
+    const uint64_t grants = (n_chunks + E2S_IMG_GRANT - 1) / E2S_IMG_GRANT;
+    const uint32_t n_waves = (uint32_t)(((std::min<uint64_t>(grants, (uint64_t)resident) + 3) / 4) * 4);
+    int rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096));
+    if (rc) return rc;
+    // ticket (64 B) | statistics (153 x 8, padded) | status words A | B | the waves' reports
+    const size_t off_stats = 64, off_a = off_stats + 160 * 8, off_b = off_a + n_chunks * 8, off_slots = (off_b + n_chunks * 8 + 63) & ~(size_t)63;
+    const size_t need = off_slots + (size_t)n_waves * sizeof(ImgSlot);
+    if (need > h->imgst_bytes) {
+        dev_free(h->d_imgst); h->d_imgst = nullptr; h->imgst_bytes = 0;
+        CK(hipMalloc((void**)&h->d_imgst, need + need / 4));
+        h->imgst_bytes = need + need / 4;
+    }
+    SegArgs sa{};
+    sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
+    sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;
+    sa.k_u32 = a.k_u32; sa.kb = a.kb; sa.hge = a.hge;
+    sa.n_tiles = n_tiles;
+    sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
+    ImgArgs g{};
+    g.img = h->d_img; g.img_cap = h->img_cap - 2;               // (room for the records the EOF rule adds)
+    g.ticket = (unsigned long long*)h->d_imgst; g.stats = (unsigned long long*)(h->d_imgst + off_stats);
+    g.st_a = (unsigned long long*)(h->d_imgst + off_a); g.st_b = (unsigned long long*)(h->d_imgst + off_b);
+    g.slots = (ImgSlot*)(h->d_imgst + off_slots);
+    g.n_chunks = (uint32_t)n_chunks; g.n_waves = n_waves; g.min_len = min_len; g.err = a.err;
+    FilterArgs fa{};
+    if (h->pf_armed) {                                          // e2s_prefilter_arm
+        h->pf_armed = false;
+        if (fused) {
+            h->pf_inflight = false;
+            if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa, true))) return rc;
+        } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
+    }
+    if (!fused) CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
+    CK(hipMemsetAsync(h->d_imgst, 0, off_slots, h->stream));
+    h->scan_start_ev = fused ? 6 : 0;
+    CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
+    e2s_launch_scan_img(sa, fused ? &fa : nullptr, g, h->stream);
+    if (fused) { h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true; h->pf_gen = h->scan_gen; }
+    LCHK("e2s_launch_scan_img");
+    CK(hipEventRecord(h->ev[3], h->stream));
+    static_assert(sizeof(ScanMail) <= 256, "mail layout");
+    uint64_t* dh = (uint64_t*)((uint8_t*)h->d_mail + 256);
+    e2s_launch_scan_img_fin(sa, g, a.flags, a.tailv, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, (unsigned long long*)dh, h->stream);
+    CK(hipEventRecord(h->ev[1], h->stream));
+    LCHK("e2s_launch_scan_img_fin");
+    CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
+    CK(wait_stream(h));
+    CK(hipGetLastError());
+    mail = *(const ScanMail*)h->pin_mail;
+    if (mail.err & E2S_DEVERR_STALL) return fail(h, E2S_ERR_HIP, "scan: a chunk's status word never arrived");
+    if (mail.err & E2S_DEVERR_SEGFULL) return E2S_OK;           // too dense for this path
+    h->segmented = true; h->img_mode = true; h->img_scan_records = mail.img_records; h->img_skip = 0;
+    h->first_rec_addr = mail.first_rec_addr;
+    h->n_ends = mail.total_ends;
+    take_scan_stats(h, mail, min_len);
+    *done = true;
     return E2S_OK;
 }
 
@@ -515,8 +645,12 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
     int rc;
     ScanMail mail{};
+    h->img_mode = false;
+    bool img_done = false;
+    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 1;
+    if (img_env && h->xb == 1 && ((uintptr_t)h->lcp & 15u) == 0 && (rc = scan_image(h, a, min_len, mail, &img_done))) return rc;
 
-    {
+    if (!img_done) {
         // ---- segmented single-pass scan: wave workers over contiguous tile ranges ----
         const uint64_t row_entries = (uint64_t)64 * (E2S_SPAN_BYTES / h->xb);   // entries per wave-tile (64 lanes x 64 B)
         SegArgs sa{};
@@ -604,21 +738,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
         h->first_rec_addr = mail.first_rec_addr;
         h->n_ends = mail.total_ends;
-        {
-            const uint64_t* buf = (const uint64_t*)(h->pin_mail + 256);
-            e2s_scan_stats& rs = h->raw_stats;
-            memset(&rs, 0, sizeof(rs));
-            memcpy(rs.hist.freq, buf, (E2S_MAX_CLUST_LEN + 1) * 8);
-            rs.hist.n_records = buf[E2S_MAX_CLUST_LEN + 1];
-            rs.hist.n_bases = buf[E2S_MAX_CLUST_LEN + 2];
-            const uint64_t at = buf[E2S_MAX_CLUST_LEN + 4];
-            rs.last_none = at == ~0ull ? 1u : 0u;
-            rs.last_is_first = (!rs.last_none && at == mail.first_rec_addr) ? 1u : 0u;
-            rs.hist.last_len = rs.last_none ? 0 : buf[E2S_MAX_CLUST_LEN + 3];
-            rs.min_len = min_len;
-            h->raw_stats_valid = true;
-            ev_ms(&h->tm.hist_ms, h->ev[3], h->ev[1]);     // k_seg_fix + the statistics
-        }
+        take_scan_stats(h, mail, min_len);
     }
     h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
     h->tail_lcp = mail.tail_lcp; h->tail_prev_lcp = mail.tail_prev_lcp;
@@ -630,10 +750,15 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
 
     // records whose uint16_t length wrapped: the per-cluster pass must take them from the record list
     // (addresses into d_starts/d_lens: ranks for the contiguous layout, segment slots for the segmented one)
-    h->wrap_ranks.clear(); h->wrap_overflow = wrap_n > E2S_WRAP_CAP; h->first_wrapped = false;
+    h->wrap_ranks.clear(); h->wrap_pairs.clear(); h->wrap_overflow = wrap_n > E2S_WRAP_CAP; h->first_wrapped = false;
     if (wrap_n && !h->wrap_overflow) {
-        h->wrap_ranks.resize(wrap_n);
-        CK(hipMemcpy(h->wrap_ranks.data(), h->d_wrap, wrap_n * 8, hipMemcpyDeviceToHost));
+        if (h->img_mode) {                                      // (start, u16 length) pairs
+            h->wrap_pairs.resize(2 * (size_t)wrap_n);
+            CK(hipMemcpy(h->wrap_pairs.data(), h->d_wrap, (size_t)wrap_n * 16, hipMemcpyDeviceToHost));
+        } else {
+            h->wrap_ranks.resize(wrap_n);
+            CK(hipMemcpy(h->wrap_ranks.data(), h->d_wrap, wrap_n * 8, hipMemcpyDeviceToHost));
+        }
     }
     h->first_end_pos = h->n_ends ? mail.first_end_pos : E2S_NONE;
     h->open_start = mail.open_start; h->last_end_start = mail.last_end_start; h->first_len_prov = (uint16_t)mail.first_len_prov;
@@ -746,6 +871,27 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     if (pl.patch_first) h->first_wrapped = h->first_end_pos != E2S_NONE && h->first_end_pos - pl.first_start + 1 >= 65536;
     h->n_rec = h->n_ends;
     h->n_closed = h->n_ends;
+    if (h->img_mode) {
+        // the image is the scan's: record 0 of a shard that began inside a cluster is finished in its reserved slot -- or skipped, if
+        // append_entry drops it (the image then begins one record later) -- and the records the EOF rule adds follow the last one
+        const bool keep_first = !pl.patch_first || (int)pl.first_len >= h->min_len;
+        h->img_skip = (pl.patch_first && !keep_first) ? 1u : 0u;
+        uint64_t ts[2] = {0, 0}; uint16_t tl[2] = {0, 0}; uint32_t nt = 0;
+        for (uint32_t t = 0; t < pl.n_tail; ++t) if ((int)pl.tail_len[t] >= h->min_len) { ts[nt] = pl.tail_start[t]; tl[nt] = pl.tail_len[t]; ++nt; }
+        if (h->img_scan_records + nt > h->img_cap) return fail(h, E2S_ERR_CAPACITY, "image overflow at the tail");
+        if ((pl.patch_first && keep_first) || nt) {
+            e2s_launch_img_patch(h->d_img, (pl.patch_first && keep_first) ? 1u : 0u, pl.first_start, pl.first_len, h->img_scan_records, nt, ts[0], tl[0], ts[1], tl[1],
+                                 h->stream);
+            LCHK("e2s_launch_img_patch");
+        }
+        h->compact_valid = false;
+        h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
+        h->plan = pl;
+        h->stitched = true;
+        drop_image(h);
+        h->img_records = h->img_scan_records - h->img_skip + nt; h->img_valid = true;      // nothing to pack
+        return E2S_OK;
+    }
     if (h->segmented) {
         // record 0 lives at the head of the first non-empty segment; the tail records stay on the host
         // (hist and the per-cluster pass take them from the plan, records_contiguous() appends them)
@@ -793,15 +939,10 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 // unthrottled -- what the per-cluster pass gains, the tail loses when the pack reaches into it; inside the box's run-to-run noise.
 static uint32_t pack_blocks_beside() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_PACK_BLOCKS"); v = e ? atoi(e) : 0; } return (uint32_t)v; }
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
+    if (h->img_mode && h->stitched) { h->img_valid = true; h->img_pending = false; return E2S_OK; }   // the scan wrote it, e2s_stitch finished it
     h->img_valid = false; h->img_pending = false; h->img_records = 0;
     if (!h->n_rec) { h->img_valid = true; return E2S_OK; }
-    if (h->n_rec > h->img_cap) {
-        dev_free(h->d_img); dev_free(h->d_img_scratch); h->d_img = nullptr; h->d_img_scratch = nullptr; h->img_cap = 0;
-        const uint64_t cap = h->n_rec + h->n_rec / 8 + 4096;
-        CK(hipMalloc((void**)&h->d_img, cap * 10 + 16));
-        CK(hipMalloc((void**)&h->d_img_scratch, std::max<uint64_t>(e2s_pack_clusters_blocks(cap) * 12 + 64, (uint64_t)(8192 + 2) * 12 + 64)));
-        h->img_cap = cap;
-    }
+    { int rc = ensure_image(h, h->n_rec); if (rc) return rc; }
     if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
     if (st != h->stream) {                                       // after everything that shaped the records (stitch patch) ...
         CK(hipEventRecord(h->ev_img, h->stream));
@@ -860,7 +1001,7 @@ extern "C" int e2s_clusters_image(e2s_handle h, const void** d_image, uint64_t* 
     CK(hipSetDevice(h->device));
     int rc = pack_image(h, n_records);
     if (rc) return rc;
-    if (d_image) *d_image = h->d_img;
+    if (d_image) *d_image = image_ptr(h);
     return E2S_OK;
 }
 
@@ -920,7 +1061,7 @@ extern "C" int e2s_stream_clusters(e2s_handle h, e2s_byte_sink sink, void* user,
     if (rc) return rc;
     if (n_records) *n_records = w;
     const double t1 = now();
-    rc = stream_image(h, h->d_img, w * 10, sink, user);
+    rc = stream_image(h, image_ptr(h), w * 10, sink, user);
     if (timing) fprintf(stderr, "[timing]   records: packed on the GPU %.2f ms, streamed to the sink %.2f ms\n", t1 - t0, now() - t1);
     return rc;
 }
@@ -935,7 +1076,7 @@ extern "C" int e2s_fetch_clusters(e2s_handle h, void* out, uint64_t cap_records,
     if (rc) return rc;
     *n_records = w;
     if (!out) return E2S_OK;
-    rc = copy_image_out(h, h->d_img, std::min<uint64_t>(w, cap_records) * 10, out);
+    rc = copy_image_out(h, image_ptr(h), std::min<uint64_t>(w, cap_records) * 10, out);
     if (rc) return rc;
     return w > cap_records ? E2S_ERR_CAPACITY : E2S_OK;
 }
@@ -968,7 +1109,7 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
         CK(e1);
     }
     h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;
-    h->min_len = 0; h->segmented = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};
+    h->min_len = 0; h->segmented = false; h->img_mode = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};
     drop_image(h);
     h->wrap_ranks.clear(); h->wrap_overflow = false; h->first_wrapped = false;
     h->scanned = true; h->stitched = true; h->records_from_file = true;
@@ -1312,6 +1453,7 @@ static int cand_seeds(e2s_ctx* h, const CandArgs& a, bool streaming, uint64_t* n
     if (streaming) {
         for (uint32_t t = 0; t < h->plan.n_tail; ++t) seed(h->plan.tail_start[t], h->plan.tail_len[t]);
         if (h->first_wrapped) seed(h->plan.first_start, h->plan.first_len);
+        for (size_t i = 0; i + 1 < h->wrap_pairs.size(); i += 2) seed(h->wrap_pairs[i], (uint16_t)h->wrap_pairs[i + 1]);   // (the image scan lists them as they are)
         for (uint64_t r : h->wrap_ranks) {                          // rare: a cluster of 65536+ entries
             uint64_t st = 0; uint16_t ln = 0;
             CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
@@ -1364,10 +1506,10 @@ static int cand_streaming_pass(e2s_ctx* h, const CandArgs& a, const FilterArgs& 
 // pre-filter, way 2: records that are not the streaming pass's to recompute (a `.clusters` file, wide or unaligned columns, a
 // window too dense for the plane kernels' queue): one thread per record on the records as they are
 static int cand_record_pass(e2s_ctx* h, const CandArgs& a, const e2s_c2s_params* p, bool defw) {
-    const uint64_t* ds; const uint16_t* dl;
-    int rc = records_contiguous(h, &ds, &dl);
+    const uint64_t* ds; const uint16_t* dl; uint64_t nrec = 0;
+    int rc = records_contiguous(h, &ds, &dl, &nrec);
     if (rc) return rc;
-    e2s_launch_record_prefilter((const unsigned long long*)ds, dl, h->n_rec, h->bwt, h->prov_lo, h->prov_lo + h->n_prov, (uint32_t)p->mcov_out,
+    e2s_launch_record_prefilter((const unsigned long long*)ds, dl, nrec, h->bwt, h->prov_lo, h->prov_lo + h->n_prov, (uint32_t)p->mcov_out,
                                 a.len_lo, a.len_hi, (unsigned long long*)h->d_fl_starts, h->d_fl_lens, h->fl_cap,
                                 (unsigned long long*)(h->d_scalars + 2), h->stream);
     LCHK("e2s_launch_record_prefilter");

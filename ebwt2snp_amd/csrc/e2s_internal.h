@@ -70,6 +70,36 @@ struct SegArgs {
     unsigned long long* wrap_list; uint32_t* wrap_count;        // addresses (b*seg_cap + i) of records with true length >= 65536
 };
 
+// ---- the scan that writes the `.clusters` image itself (k_scan_seg<1, FUSED, true>): the work is cut into CHUNKS of a few
+// wave-tiles handed out by a ticket counter; a wave stages the records that END in its chunk in LDS (4 bytes each), learns the
+// start of a cluster that reaches into the chunk from the chunk before (status word A), counts the records append_entry keeps,
+// chains that count with a decoupled look-back (status word B) and writes its piece of the packed 10-byte image -- and its share
+// of the statistics -- itself.  No segments, no pack, no histogram kernel.
+#define E2S_IMG_TILES 8u             // wave-tiles per chunk: offsets inside a chunk (+ the tile before it) fit 16 bits
+#define E2S_IMG_GRANT 2u             // consecutive chunks per ticket
+#define E2S_IMG_CAP 3072u            // records a chunk may stage (12 KB of LDS per wave): ~0.09 per entry, 2.5 x the usual density
+#define E2S_DEVERR_STALL 16u         // a status word never arrived (should not happen: every wait has an exit)
+struct ImgSlot {                     // per wave, written once when the wave runs out of tickets; reduced by k_scan_img_fin
+    unsigned long long raw_ends;     // clusters that END in the wave's chunks (before the min_len filter)
+    unsigned long long first_end_pos;            // smallest SA position of such an end (~0: none)
+    unsigned long long last_c1;      // 1 + index of the wave's last chunk with an end, and that end's cluster start (~0: began before the shard)
+    unsigned long long last_start;
+    unsigned long long kept_c1;      // 1 + index of its last chunk with a record the statistics count, that record's length, and whether it is the
+    unsigned long long kept_len;     //   shard's provisional record 0
+    unsigned long long kept_is_rec0;
+    unsigned long long reserved;
+};
+struct ImgArgs {
+    uint8_t* img; unsigned long long img_cap;                    // packed 10-byte records; capacity in records
+    unsigned long long* st_a; unsigned long long* st_b;          // per chunk: [valid:1][state:2][start:48] / [flag:2][count:62]; zero before the launch
+    unsigned long long* ticket;                                  // zero before the launch
+    uint32_t n_chunks; uint32_t n_waves;
+    int min_len;
+    ImgSlot* slots;                                              // [n_waves]
+    unsigned long long* stats;                                   // [151 freq | n_records | n_bases]: zero before the launch
+    uint32_t* err;
+};
+
 // everything the host needs after a scan, gathered by k_scan_mail so that ONE small download suffices
 struct ScanMail {
     uint64_t total_ends, first_end_pos, open_start, last_end_start;
@@ -77,6 +107,7 @@ struct ScanMail {
     uint32_t begins_inside, open_after, end_before_last, err;
     uint32_t wrap_count, first_len_prov, tail_lcp, tail_prev_lcp;
     uint32_t last_text, last_suff, last_lcp, last_bwt;      // the last provided entry (EOF phantom model)
+    uint64_t img_records;                                    // records in the image the scan wrote itself (ImgArgs), the provisional record 0 included
 };
 
 struct CandHeader {           // == e2s_cand_header
@@ -190,6 +221,12 @@ void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_
 void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsigned long long* seg_off, uint32_t* err,
                         const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* hist_zero,
                         hipStream_t st);
+int  e2s_scan_img_resident_waves(bool fused);
+void e2s_launch_scan_img(const SegArgs& a, const FilterArgs* f, const ImgArgs& g, hipStream_t st);
+void e2s_launch_scan_img_fin(const SegArgs& a, const ImgArgs& g, uint32_t* flags, uint32_t* tailv, uint32_t* err, const uint8_t* bwt, const void* pos,
+                             const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out, hipStream_t st);
+void e2s_launch_img_patch(uint8_t* img, uint32_t patch_first, unsigned long long first_start, uint16_t first_len, unsigned long long n_at, uint32_t n_tail,
+                          unsigned long long t0, uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st);
 void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, unsigned long long* out_starts, uint16_t* out_lens, hipStream_t st);
 void e2s_launch_unpack_clusters(const uint8_t* packed, unsigned long long n, unsigned long long* starts, uint16_t* lens, uint32_t* err, hipStream_t st);
 void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out,
