@@ -65,7 +65,7 @@ struct e2s_ctx {
     void* d_rank = nullptr; uint32_t* d_order = nullptr;           // d_rank: scratch of the candidate ordering
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
     uint8_t* d_img = nullptr; uint8_t* d_img_scratch = nullptr; uint64_t img_cap = 0;     // `.clusters` image (e2s_pack_clusters, e2s_stream_clusters)
-    bool img_valid = false, img_pending = false; uint64_t img_records = 0; hipEvent_t ev_img = nullptr;
+    bool img_valid = false, img_pending = false, img_total_known = false; uint64_t img_records = 0; hipEvent_t ev_img = nullptr;
     uint8_t* pin_io[2] = {nullptr, nullptr}; uint64_t pin_io_cap = 0; hipEvent_t ev_io[2] = {nullptr, nullptr};
     int scan_start_ev = 0; bool pf_fused = false;                // which event began the last scan; the in-flight pre-filter ran inside it
     bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
@@ -80,6 +80,8 @@ struct e2s_ctx {
     // segmented record storage (scan_mode 0): segment b = d_starts/d_lens[b*seg_cap ...), SegDesc per block
     bool segmented = false; uint32_t seg_cap = 0, seg_blocks = 0; SegDesc* d_seg_desc = nullptr; uint64_t* d_seg_off = nullptr;
     uint32_t seg_blocks_cap = 0;
+    SegArgs seg_args{}; uint32_t seg_row_entries = 4096; uint64_t* d_kept_off = nullptr;     // the last segmented scan's arguments (compaction, image layout)
+    uint64_t* d_scan_stats = nullptr;                            // [151 freq | n_records | n_bases] tallied by the scan kernel (in front of d_words)
     // the scan that writes the image itself (k_scan_seg<1, FUSED, true>): records live in d_img only, statistics come with the mail
     bool img_mode = false; uint64_t img_scan_records = 0; uint32_t img_skip = 0;     // img_skip: the shard's record 0 turned out shorter than min_len
     uint8_t* d_imgst = nullptr; size_t imgst_bytes = 0; int img_waves[2] = {0, 0};      // ticket | statistics | status words A, B | per-wave reports
@@ -168,13 +170,15 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
         e2s_destroy(h);
         return E2S_ERR_HIP;
     }
-    if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_words, 64 * sizeof(uint32_t)) != hipSuccess ||
+    // the scan's statistics (160 x 8 B) sit in front of the control words: ONE clear before a scan covers both
+    if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&h->d_scan_stats, 160 * 8 + 64 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&h->d_wrap, 2 * E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, 4096) != hipSuccess ||   // ScanMail | statistics at +256
         hipHostMalloc((void**)&h->pin_mail, 4096, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         e2s_destroy(h);
         return E2S_ERR_HIP;
     }
+    h->d_words = (uint32_t*)(h->d_scan_stats + 160);
     *out = h;
     return E2S_OK;
 }
@@ -236,7 +240,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);      // (a failed stream is torn down all the same)
     release_shard(h);
     dev_free(h->d_starts); dev_free(h->d_lens);
-    dev_free(h->d_scalars); dev_free(h->d_words);
+    dev_free(h->d_scalars); dev_free(h->d_scan_stats); dev_free(h->d_kept_off);
     dev_free(h->d_wrap); dev_free(h->d_fl_starts); dev_free(h->d_fl_lens);
     if (h->pin_cand) pin_free(h->pin_cand);
     if (h->pin_mail) pin_free(h->pin_mail);
@@ -464,7 +468,7 @@ static int ensure_records(e2s_ctx* h, uint64_t cap) {
 // contiguous record arrays for consumers that index records by rank (file output, record-driven pass).
 // scan_mode 0 keeps records in per-block segments; this gathers them once, on demand, tail records included.
 static int pack_image(e2s_ctx* h, uint64_t* n_records);
-static const uint8_t* image_ptr(const e2s_ctx* h) { return h->d_img ? h->d_img + (h->img_mode ? 10ull * h->img_skip : 0ull) : nullptr; }
+static const uint8_t* image_ptr(const e2s_ctx* h) { return h->d_img ? h->d_img + ((h->segmented && !h->records_from_file) ? 10ull * h->img_skip : 0ull) : nullptr; }
 static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_t** lens, uint64_t* n) {
     *n = h->n_rec;
     if (!h->segmented) { *starts = h->d_starts; *lens = h->d_lens; return E2S_OK; }
@@ -496,9 +500,8 @@ static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_
             CK(hipMalloc((void**)&h->d_clens, (h->n_rec + 8) * 2 + 64));
             h->ccap = h->n_rec + 8;
         }
-        SegArgs sa{};
-        sa.starts = h->d_starts; sa.lens = h->d_lens; sa.seg_cap = h->seg_cap; sa.desc = h->d_seg_desc; sa.n_blocks = h->seg_blocks;
-        if (h->n_ends) e2s_launch_seg_compact(sa, (const unsigned long long*)h->d_seg_off, (unsigned long long*)h->d_cstarts, h->d_clens, h->stream);
+        if (h->n_ends) e2s_launch_seg_compact(h->seg_args, (const unsigned long long*)h->d_seg_off, h->seg_row_entries, (unsigned long long*)h->d_cstarts, h->d_clens,
+                                              h->stream);
         if (h->stitched && h->plan.n_tail) {
             e2s_launch_apply_plan((unsigned long long*)h->d_cstarts, h->d_clens, 0, 0, 0, h->n_ends, h->plan.n_tail, h->plan.tail_start[0],
                                   h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], h->stream);
@@ -546,7 +549,7 @@ static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail
     *done = false;
     const uint64_t n_tiles = (h->n_prov + 4095) / 4096;
     const uint64_t n_chunks = (n_tiles + E2S_IMG_TILES - 1) / E2S_IMG_TILES;
-    if (n_chunks + E2S_IMG_GRANT >= (1ull << 31)) return E2S_OK;                          // (2^46 entries: not on one GPU)
+    if (n_chunks + E2S_IMG_COUNTERS >= (1ull << 31)) return E2S_OK;                       // (2^46 entries: not on one GPU)
     static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
     const bool fused = h->pf_armed && fused_env && prefilter_eligible(h);
     int& resident = h->img_waves[fused ? 1 : 0];
@@ -555,12 +558,12 @@ static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail
         if (const char* ev = getenv("E2S_SCAN_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < resident) resident = cap; }
         if (resident < 4) resident = 4;
     }
-    const uint64_t grants = (n_chunks + E2S_IMG_GRANT - 1) / E2S_IMG_GRANT;
-    const uint32_t n_waves = (uint32_t)(((std::min<uint64_t>(grants, (uint64_t)resident) + 3) / 4) * 4);
+    const uint32_t n_waves = (uint32_t)(((std::max<uint64_t>(std::min<uint64_t>(n_chunks, (uint64_t)resident), E2S_IMG_COUNTERS) + 3) / 4) * 4);   // (every counter has a wave)
     int rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096));
     if (rc) return rc;
-    // ticket (64 B) | statistics (153 x 8, padded) | status words A | B | the waves' reports
-    const size_t off_stats = 64, off_a = off_stats + 160 * 8, off_b = off_a + n_chunks * 8, off_slots = (off_b + n_chunks * 8 + 63) & ~(size_t)63;
+    // ticket counters (64 B each) | statistics (153 x 8, padded) | status words A | B | the waves' reports
+    static_assert(E2S_IMG_COUNTERS >= 1 && E2S_IMG_COUNTERS <= 16, "ticket counters");
+    const size_t off_stats = 64 * E2S_IMG_COUNTERS, off_a = off_stats + 160 * 8, off_b = off_a + n_chunks * 8, off_slots = (off_b + n_chunks * 8 + 63) & ~(size_t)63;
     const size_t need = off_slots + (size_t)n_waves * sizeof(ImgSlot);
     if (need > h->imgst_bytes) {
         dev_free(h->d_imgst); h->d_imgst = nullptr; h->imgst_bytes = 0;
@@ -575,10 +578,10 @@ static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail
     sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
     ImgArgs g{};
     g.img = h->d_img; g.img_cap = h->img_cap - 2;               // (room for the records the EOF rule adds)
-    g.ticket = (unsigned long long*)h->d_imgst; g.stats = (unsigned long long*)(h->d_imgst + off_stats);
+    g.ticket = (unsigned long long*)h->d_imgst;
     g.st_a = (unsigned long long*)(h->d_imgst + off_a); g.st_b = (unsigned long long*)(h->d_imgst + off_b);
     g.slots = (ImgSlot*)(h->d_imgst + off_slots);
-    g.n_chunks = (uint32_t)n_chunks; g.n_waves = n_waves; g.min_len = min_len; g.err = a.err;
+    g.n_chunks = (uint32_t)n_chunks; g.n_waves = n_waves; g.err = a.err;
     FilterArgs fa{};
     if (h->pf_armed) {                                          // e2s_prefilter_arm
         h->pf_armed = false;
@@ -587,7 +590,8 @@ static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail
             if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa, true))) return rc;
         } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
     }
-    if (!fused) CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
+    sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
+    if (!fused) CK(hipMemsetAsync(h->d_scan_stats, 0, 160 * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
     CK(hipMemsetAsync(h->d_imgst, 0, off_slots, h->stream));
     h->scan_start_ev = fused ? 6 : 0;
     CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
@@ -647,7 +651,9 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     ScanMail mail{};
     h->img_mode = false;
     bool img_done = false;
-    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 1;
+    // E2S_SCAN_IMG=1: the scan that writes the image itself (tickets + decoupled look-back).  Measured slower than segments + one
+    // layout kernel on this chip (its waves wait for the chunks before them), so it is the opt-in
+    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 0;
     if (img_env && h->xb == 1 && ((uintptr_t)h->lcp & 15u) == 0 && (rc = scan_image(h, a, min_len, mail, &img_done))) return rc;
 
     if (!img_done) {
@@ -682,17 +688,20 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
         if (nb > 8192) return fail(h, E2S_ERR_STATE, "more scan workers than k_seg_fix handles");
         sa.n_blocks = (uint32_t)nb;
         if (nb + 1 > h->seg_blocks_cap) {
-            dev_free(h->d_seg_desc); dev_free(h->d_seg_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->seg_blocks_cap = 0;
+            dev_free(h->d_seg_desc); dev_free(h->d_seg_off); dev_free(h->d_kept_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->d_kept_off = nullptr;
+            h->seg_blocks_cap = 0;
             CK(hipMalloc((void**)&h->d_seg_desc, (nb + 1) * sizeof(SegDesc)));
             CK(hipMalloc((void**)&h->d_seg_off, (nb + 2) * 8));
+            CK(hipMalloc((void**)&h->d_kept_off, (nb + 2) * 8));
             h->seg_blocks_cap = (uint32_t)(nb + 1);
         }
+        sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
         const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
         uint64_t seg_cap = (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
             if ((rc = ensure_records(h, nb * seg_cap))) return rc;
-            sa.seg_cap = (uint32_t)seg_cap; sa.starts = h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
+            sa.seg_cap = (uint32_t)seg_cap; sa.starts32 = (uint32_t*)h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
             sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
             FilterArgs fa{};
             bool fuse_now = false;
@@ -704,7 +713,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
                     fuse_now = true;
                 } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
             }
-            if (!fuse_now) CK(hipMemsetAsync(h->d_words, 0, 16 * sizeof(uint32_t), h->stream));
+            if (!fuse_now) CK(hipMemsetAsync(h->d_scan_stats, 0, 160 * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
             // three timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix + the
             // statistics.  With the pre-filter inside the scan kernel the start event is the per-cluster pass's (ev[6]).
             h->scan_start_ev = fuse_now ? 6 : 0;
@@ -716,17 +725,14 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             } else e2s_launch_scan_seg(sa, h->xb, h->stream);
             LCHK("e2s_launch_scan_seg");
             CK(hipEventRecord(h->ev[3], h->stream));
-            // k_seg_fix also evaluates the shard's boundary flags and clears the statistics buffer (fewer launches)
+            // k_seg_fix: the shard's boundary flags, the records that began in an earlier block, the offsets of the kept records in the
+            // image, and the statistics the scan kernel tallied (e2s_scan_stats_desc / e2s_cluster_hist: no kernel of their own)
             static_assert(sizeof(ScanMail) <= 256, "mail layout");
             uint64_t* dh = (uint64_t*)((uint8_t*)h->d_mail + 256);
-            e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb,
-                               h->d_mail, (unsigned long long*)dh, h->stream);
+            e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, (unsigned long long*)h->d_kept_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb,
+                               h->zb, h->d_mail, (unsigned long long*)dh, h->stream);
+            CK(hipEventRecord(h->ev[1], h->stream));
             LCHK("e2s_launch_seg_fix");
-            // statistics of the records in the same phase (no second round trip): e2s_scan_stats_desc / e2s_cluster_hist
-            e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, sa.seg_cap, sa.n_blocks, min_len, (unsigned long long*)dh,
-                                (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
-            CK(hipEventRecord(h->ev[1], h->stream));                // (no event between the two follow-up kernels: each costs stream time)
-            LCHK("e2s_launch_hist_seg");
             CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
             CK(wait_stream(h));
             CK(hipGetLastError());
@@ -736,6 +742,7 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
             seg_cap = range_entries + 16;                           // worst case: rerun with room for everything
         }
         h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
+        h->seg_args = sa; h->seg_row_entries = (uint32_t)row_entries; h->img_scan_records = mail.img_records; h->img_skip = 0;
         h->first_rec_addr = mail.first_rec_addr;
         h->n_ends = mail.total_ends;
         take_scan_stats(h, mail, min_len);
@@ -896,10 +903,11 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
         // record 0 lives at the head of the first non-empty segment; the tail records stay on the host
         // (hist and the per-cluster pass take them from the plan, records_contiguous() appends them)
         if (pl.patch_first && h->first_rec_addr != E2S_NONE) {
-            e2s_launch_apply_plan((unsigned long long*)h->d_starts + h->first_rec_addr, h->d_lens + h->first_rec_addr, 1, pl.first_start,
-                                  pl.first_len, 0, 0, 0, 0, 0, 0, h->stream);
-            LCHK("e2s_launch_apply_plan");
+            e2s_launch_seg_patch(h->d_seg_desc + h->first_rec_addr / h->seg_cap, h->d_lens + h->first_rec_addr, pl.first_start, pl.first_len, h->stream);
+            LCHK("e2s_launch_seg_patch");
         }
+        // (that record holds slot 0 of the image; where append_entry drops it the image begins one record later)
+        h->img_skip = (pl.patch_first && (int)pl.first_len < h->min_len) ? 1u : 0u;
         h->compact_valid = false;
     } else {
         if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
@@ -940,7 +948,7 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 static uint32_t pack_blocks_beside() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_PACK_BLOCKS"); v = e ? atoi(e) : 0; } return (uint32_t)v; }
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
     if (h->img_mode && h->stitched) { h->img_valid = true; h->img_pending = false; return E2S_OK; }   // the scan wrote it, e2s_stitch finished it
-    h->img_valid = false; h->img_pending = false; h->img_records = 0;
+    h->img_valid = false; h->img_pending = false; h->img_records = 0; h->img_total_known = false;
     if (!h->n_rec) { h->img_valid = true; return E2S_OK; }
     { int rc = ensure_image(h, h->n_rec); if (rc) return rc; }
     if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
@@ -949,13 +957,19 @@ static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
         CK(hipStreamWaitEvent(st, h->ev_img, 0));
     }
     if (h->segmented) {
-        uint64_t* off = (uint64_t*)h->d_img_scratch;             // [n_seg + 1] record offsets, then the kept counts
-        uint32_t* kept = (uint32_t*)(off + h->seg_blocks + 1);
-        e2s_launch_pack_segments((const unsigned long long*)h->d_starts, h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, kept,
-                                 (unsigned long long*)off, h->d_img, (unsigned long long*)(h->d_scalars + 220), h->stitched ? h->plan.n_tail : 0,
+        // the scan counted what append_entry keeps, k_seg_fix scanned the counts: one kernel lays the image out, and its size is known here
+        uint32_t nt = 0;
+        if (h->stitched) for (uint32_t t = 0; t < h->plan.n_tail; ++t) if ((int)h->plan.tail_len[t] >= h->min_len) ++nt;
+        { int rc = ensure_image(h, h->img_scan_records + 2); if (rc) return rc; }
+        const uint32_t slot0_b = (h->stitched && h->plan.patch_first && h->first_rec_addr != E2S_NONE) ? (uint32_t)(h->first_rec_addr / h->seg_cap) : 0xFFFFFFFFu;
+        e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, slot0_b, (const unsigned long long*)h->d_kept_off, h->d_img, h->stitched ? h->plan.n_tail : 0,
                                  h->plan.tail_start[0], h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], st,
                                  st == h->stream2 ? pack_blocks_beside() : 0u);
         LCHK("e2s_launch_pack_segments");
+        CK(hipEventRecord(h->ev_img, st));
+        h->img_records = h->img_scan_records - h->img_skip + nt;
+        h->img_pending = true; h->img_total_known = true;
+        return E2S_OK;
     } else {
         const uint64_t nb = e2s_pack_clusters_blocks(h->n_rec);
         uint64_t* prefix = (uint64_t*)h->d_img_scratch;
@@ -973,7 +987,7 @@ static int pack_image_finish(e2s_ctx* h, uint64_t* n_records) {
     if (h->img_pending) {
         CK(hipEventSynchronize(h->ev_img));
         CK(hipGetLastError());
-        h->img_records = *(const uint64_t*)(h->pin_mail + 3080);
+        if (!h->img_total_known) h->img_records = *(const uint64_t*)(h->pin_mail + 3080);
         h->img_pending = false; h->img_valid = true;
     }
     if (n_records) *n_records = h->img_records;
@@ -1126,20 +1140,15 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
         if (rc) return rc;
         return e2s_hist_after_stitch(&h->raw_stats, &b, &h->plan, out);
     }
+    if (h->segmented) return fail(h, E2S_ERR_STATE, "the scan's statistics are missing");       // (the scan tallies them itself: never reached)
     CK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
     uint64_t* dh = h->d_scalars + 8;
     CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 5) * 8, h->stream));
     CK(hipEventRecord(h->ev[4], h->stream));
-    if (h->segmented) {
-        if (h->n_ends) e2s_launch_hist_seg(h->d_lens, h->d_seg_desc, h->seg_cap, h->seg_blocks, h->min_len, (unsigned long long*)dh,
-                                           (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
-        CK(hipEventRecord(h->ev[5], h->stream));
-    } else {
-        if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
-        CK(hipEventRecord(h->ev[5], h->stream));
-        if (h->n_rec) e2s_launch_hist_tail(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
-    }
+    if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
+    CK(hipEventRecord(h->ev[5], h->stream));
+    if (h->n_rec) e2s_launch_hist_tail(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
     uint64_t* buf = (uint64_t*)(h->pin_mail + 256);
     CK(hipMemcpyAsync(buf, dh, (E2S_MAX_CLUST_LEN + 4) * 8, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
@@ -1149,15 +1158,6 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     out->n_records = buf[E2S_MAX_CLUST_LEN + 1];
     out->n_bases = buf[E2S_MAX_CLUST_LEN + 2];
     out->last_len = out->n_records ? buf[E2S_MAX_CLUST_LEN + 3] : 0;      // the record the reference counts twice (H4)
-    if (h->segmented) {                                                     // the EOF tail records live in the stitch plan
-        for (uint32_t t = 0; t < h->plan.n_tail; ++t) {
-            const int l = h->plan.tail_len[t];
-            if (l >= h->min_len) {
-                out->n_records++; out->n_bases += (uint64_t)l; out->last_len = (uint64_t)l;
-                if (l <= E2S_MAX_CLUST_LEN) out->freq[l]++;
-            }
-        }
-    }
     return E2S_OK;
 }
 
@@ -1312,7 +1312,7 @@ static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_r
     // cleared -- and, for the scan that carries the pre-filter, the scan's words as well
     static_assert(E2S_SEED_SLOTS <= 256, "k_phase_init");
     e2s_launch_phase_init((unsigned long long*)(h->d_scalars + 2), E2S_SEED_SLOTS, h->d_fl_lens, (uint32_t)E2S_SEED_SLOTS, h->d_words + 20, 1,
-                          scan_words ? h->d_words : nullptr, 16, st);
+                          scan_words ? h->d_words : nullptr, 16, scan_words ? (unsigned long long*)h->d_scan_stats : nullptr, 160, st);
     LCHK("e2s_launch_phase_init");
     filter_args(h, mcov_out, c2s_len_lo(mcov_out, min_len), (int)E2S_MAX_CLUST_LEN, f);
     return E2S_OK;
@@ -1456,8 +1456,17 @@ static int cand_seeds(e2s_ctx* h, const CandArgs& a, bool streaming, uint64_t* n
         for (size_t i = 0; i + 1 < h->wrap_pairs.size(); i += 2) seed(h->wrap_pairs[i], (uint16_t)h->wrap_pairs[i + 1]);   // (the image scan lists them as they are)
         for (uint64_t r : h->wrap_ranks) {                          // rare: a cluster of 65536+ entries
             uint64_t st = 0; uint16_t ln = 0;
-            CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
             CK(hipMemcpy(&ln, h->d_lens + r, 2, hipMemcpyDeviceToHost));
+            if (h->segmented) {                                     // segment slot: start = first entry of the worker's range + offset, or what k_seg_fix found
+                const uint32_t b = (uint32_t)(r / h->seg_cap);
+                SegDesc sd;
+                CK(hipMemcpy(&sd, h->d_seg_desc + b, sizeof(sd), hipMemcpyDeviceToHost));
+                uint32_t s32 = 0;
+                CK(hipMemcpy(&s32, (const uint32_t*)h->d_starts + r, 4, hipMemcpyDeviceToHost));
+                const SegArgs& sa = h->seg_args;
+                const uint64_t rb = sa.prov_lo + ((uint64_t)b * sa.tiles_per_block + std::min<uint32_t>(b, sa.tiles_rem)) * (uint64_t)h->seg_row_entries;
+                st = (r % h->seg_cap == 0 && sd.first_unknown) ? sd.first_start : rb + s32;
+            } else CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
             seed(st, ln);
         }
     }

@@ -57,6 +57,11 @@ struct SegDesc {                 // per block, written by k_scan_seg
     uint32_t overflow;           // the segment was too small
     uint64_t open_start;         // its start if it lies in this block's range, else ~0
     uint64_t first_end_pos;      // SA position of the block's first end (valid if count > 0)
+    uint32_t kept;               // records append_entry keeps (record 0 not counted while its start is unknown: k_seg_fix adds it)
+    uint32_t last_kept1;         // 1 + index of the last of them, and its length
+    uint32_t last_kept_len;
+    uint32_t reserved;
+    uint64_t first_start;        // record 0's start where it lies before the block's range (k_seg_fix, e2s_stitch)
 };
 
 struct SegArgs {
@@ -65,8 +70,9 @@ struct SegArgs {
     uint32_t k_u32, kb, hge;
     uint64_t n_tiles; uint32_t tiles_per_block; uint32_t n_blocks;   // worker b owns tiles_per_block tiles, +1 for b < tiles_rem
     uint32_t tiles_rem;
-    uint64_t* starts; uint16_t* lens; uint32_t seg_cap;        // segment b = [b*seg_cap, (b+1)*seg_cap)
+    uint32_t* starts32; uint16_t* lens; uint32_t seg_cap;      // segment b = [b*seg_cap, (b+1)*seg_cap): start - first entry of worker b's range, length
     SegDesc* desc;
+    int min_len; unsigned long long* stats;                     // [151 freq | n_records | n_bases] of the records append_entry keeps: zero before the launch
     unsigned long long* wrap_list; uint32_t* wrap_count;        // addresses (b*seg_cap + i) of records with true length >= 65536
 };
 
@@ -75,9 +81,16 @@ struct SegArgs {
 // start of a cluster that reaches into the chunk from the chunk before (status word A), counts the records append_entry keeps,
 // chains that count with a decoupled look-back (status word B) and writes its piece of the packed 10-byte image -- and its share
 // of the statistics -- itself.  No segments, no pack, no histogram kernel.
+#ifndef E2S_IMG_TILES
 #define E2S_IMG_TILES 8u             // wave-tiles per chunk: offsets inside a chunk (+ the tile before it) fit 16 bits
-#define E2S_IMG_GRANT 2u             // consecutive chunks per ticket
-#define E2S_IMG_CAP 3072u            // records a chunk may stage (12 KB of LDS per wave): ~0.09 per entry, 2.5 x the usual density
+#endif
+#ifndef E2S_IMG_COUNTERS
+#define E2S_IMG_COUNTERS 4u          // interleaved ticket counters
+#endif
+#ifndef E2S_IMG_CAP
+#define E2S_IMG_CAP 3072u
+#endif
+//                                      records a chunk may stage (12 KB of LDS per wave): ~0.09 per entry, 2.5 x the usual density
 #define E2S_DEVERR_STALL 16u         // a status word never arrived (should not happen: every wait has an exit)
 struct ImgSlot {                     // per wave, written once when the wave runs out of tickets; reduced by k_scan_img_fin
     unsigned long long raw_ends;     // clusters that END in the wave's chunks (before the min_len filter)
@@ -92,11 +105,9 @@ struct ImgSlot {                     // per wave, written once when the wave run
 struct ImgArgs {
     uint8_t* img; unsigned long long img_cap;                    // packed 10-byte records; capacity in records
     unsigned long long* st_a; unsigned long long* st_b;          // per chunk: [valid:1][state:2][start:48] / [flag:2][count:62]; zero before the launch
-    unsigned long long* ticket;                                  // zero before the launch
+    unsigned long long* ticket;                                  // E2S_IMG_COUNTERS counters, 64 bytes apart; zero before the launch
     uint32_t n_chunks; uint32_t n_waves;
-    int min_len;
     ImgSlot* slots;                                              // [n_waves]
-    unsigned long long* stats;                                   // [151 freq | n_records | n_bases]: zero before the launch
     uint32_t* err;
 };
 
@@ -195,7 +206,7 @@ void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_exc
 
 void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st);
 void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
-                           uint32_t* w1, uint32_t n1, hipStream_t st);   // n_lens, n0, n1 <= 256
+                           uint32_t* w1, uint32_t n1, unsigned long long* z, uint32_t nz, hipStream_t st);   // n_lens, n0, n1, nz <= 256
 void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* stream8_count, uint32_t* err, const unsigned long long* seed_starts,
                           const uint16_t* seed_lens, uint32_t n_seed_slots, unsigned long long* fl_starts, uint16_t* fl_lens,
                           unsigned long long* fl_count, bool set_fl_count, uint32_t* ko_cnt, uint32_t n_ko, hipStream_t st);   // n_seed_slots <= 256
@@ -210,16 +221,16 @@ void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsig
 unsigned long long e2s_pack_clusters_blocks(unsigned long long n);
 void e2s_launch_pack_clusters(const unsigned long long* starts, const uint16_t* lens, unsigned long long n, int min_len, uint32_t* cnt,
                               unsigned long long* prefix, uint8_t* out, unsigned long long* total, hipStream_t st);
-void e2s_launch_pack_segments(const unsigned long long* starts, const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_seg, int min_len,
-                              uint32_t* kept, unsigned long long* off, uint8_t* out, unsigned long long* total, uint32_t n_tail, unsigned long long t0,
-                              uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st, uint32_t max_blocks);
+void e2s_launch_pack_segments(const SegArgs& a, uint32_t row_entries, uint32_t slot0_b, const unsigned long long* kept_off, uint8_t* out, uint32_t n_tail,
+                              unsigned long long t0, uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st, uint32_t max_blocks);
+void e2s_launch_seg_patch(SegDesc* d, uint16_t* len0, unsigned long long first_start, uint16_t first_len, hipStream_t st);
 #define E2S_WRAP_CAP 1024
 int  e2s_scan_seg_resident_blocks(int xb);
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st);
 int  e2s_scan_seg_fused_resident_blocks();
 void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_t st);
-void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsigned long long* seg_off, uint32_t* err,
-                        const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* hist_zero,
+void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsigned long long* seg_off, unsigned long long* kept_off, uint32_t* err,
+                        const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out,
                         hipStream_t st);
 int  e2s_scan_img_resident_waves(bool fused);
 void e2s_launch_scan_img(const SegArgs& a, const FilterArgs* f, const ImgArgs& g, hipStream_t st);
@@ -227,10 +238,9 @@ void e2s_launch_scan_img_fin(const SegArgs& a, const ImgArgs& g, uint32_t* flags
                              const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out, hipStream_t st);
 void e2s_launch_img_patch(uint8_t* img, uint32_t patch_first, unsigned long long first_start, uint16_t first_len, unsigned long long n_at, uint32_t n_tail,
                           unsigned long long t0, uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st);
-void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, unsigned long long* out_starts, uint16_t* out_lens, hipStream_t st);
+void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, uint32_t row_entries, unsigned long long* out_starts, uint16_t* out_lens,
+                            hipStream_t st);
 void e2s_launch_unpack_clusters(const uint8_t* packed, unsigned long long n, unsigned long long* starts, uint16_t* lens, uint32_t* err, hipStream_t st);
-void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, uint32_t seg_cap, uint32_t n_blocks, int min_len, unsigned long long* out,
-                         unsigned long long* out_last, hipStream_t st);
 void e2s_launch_apply_plan(unsigned long long* starts, uint16_t* lens, uint32_t patch_first, unsigned long long first_start,
                            uint16_t first_len, unsigned long long n_ends, uint32_t n_tail, unsigned long long t0, uint16_t l0,
                            unsigned long long t1, uint16_t l1, hipStream_t st);

@@ -140,6 +140,9 @@ __device__ __forceinline__ u32 pf_merge(u32 x, u32 y) { return (((x & 0xFFFFFFu)
 // The statistics of the kept records (statistics(), clust2snp.cpp:889-909) are counted on the way: per-block LDS histogram
 // replicas, flushed once.  A shard that begins inside a cluster keeps slot 0 of the image for that record whatever its
 // provisional length says (e2s_stitch knows the true one).
+#ifndef E2S_IMG_ABL
+#define E2S_IMG_ABL 0
+#endif
 constexpr u64 IMG_A_VALID = 1ull << 63, IMG_A_OPEN = 1ull << 61, IMG_A_PASS = 2ull << 61, IMG_POS_MASK = (1ull << 48) - 1ull;
 constexpr u64 IMG_B_AGG = 1ull << 62, IMG_B_INCL = 2ull << 62, IMG_CNT_MASK = (1ull << 62) - 1ull;
 constexpr u32 IMG_SPIN_LIMIT = 1u << 24;                   // (a status word arrives within microseconds; ~10 s of polling means a bug, not a wait)
@@ -176,37 +179,35 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     const u32 wslot = threadIdx.x >> 6;
     // IMG: a chunk's records, the block's histogram replicas (4 per wave: lengths concentrate on a few values), two 64-bit sums
     __shared__ u32 s_cbuf[IMG ? 4 : 1][IMG ? E2S_IMG_CAP + 2u : 1u];
-    __shared__ u32 s_hist[IMG ? 16 : 1][IMG ? E2S_MAX_CLUST_LEN_K + 2 : 1];
+    __shared__ u32 s_hist[16][E2S_MAX_CLUST_LEN_K + 2];
     __shared__ u64 s_acc[2];
     u32* const cbuf = s_cbuf[IMG ? wslot : 0];
-    if constexpr (IMG) {
-        for (u32 i = threadIdx.x; i < 16u * (E2S_MAX_CLUST_LEN_K + 2); i += 256u) (&s_hist[0][0])[i] = 0u;
-        if (threadIdx.x < 2) s_acc[threadIdx.x] = 0ull;
-        __syncthreads();
-    }
+    for (u32 i = threadIdx.x; i < 16u * (E2S_MAX_CLUST_LEN_K + 2); i += 256u) (&s_hist[0][0])[i] = 0u;
+    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0ull;
+    __syncthreads();
     // IMG: what the wave reports once (ImgSlot) and its lanes' share of the statistics
     u64 w_raw = 0, w_first_end = ~0ull, w_last_c1 = 0, w_last_start = ~0ull, w_kept_c1 = 0, w_kept_len = 0, w_kept_rec0 = 0;
     u64 l_nrec = 0, l_nb = 0;
     u32 qn = 0;                                                 // (FUSED) flagged clusters queued in LDS: wave state, kept from range to range
     __shared__ u64 s_q[FUSED ? 4 : 1][FUSED ? F2_Q : 1];
     u64* const q = s_q[FUSED ? wslot : 0];
-    u32 grant = 0, granted = 0;                                 // IMG: a ticket grants E2S_IMG_GRANT consecutive chunks (an atomic on one word
-    for (;;) {                                                  //      per chunk would approach what a global word takes on 3x10^9 entries)
+    // IMG: ONE chunk per ticket.  (Two consecutive chunks per ticket -- half the atomics -- chain the waves into a line: the first chunk
+    // of ticket t waits for the second chunk of ticket t - 1, which its wave only starts after the first: 49 ms instead of 0.06 on c2.)
+    // The counters are E2S_IMG_COUNTERS interleaved ones (chunk = counter + COUNTERS * value; a wave draws from counter wave % COUNTERS),
+    // so that no single word takes one atomic per chunk of the whole chip.  Every wait still ends: the smallest chunk nobody holds yet
+    // belongs to a counter whose waves hold only smaller chunks, and those never wait for anything that is not held.
+    const u32 my_counter = (blockIdx.x * 4u + wslot) % E2S_IMG_COUNTERS;
+    for (;;) {
     u32 b; u64 t0, t1;                                          // (one trip without IMG)
     if constexpr (IMG) {
-        if (granted == 0u) {
-            u32 tk = 0;
-            if (lane == 0) tk = (u32)atomicAdd(g.ticket, 1ull);
-            grant = (u32)__builtin_amdgcn_readfirstlane((int)tk) * E2S_IMG_GRANT;
-            granted = E2S_IMG_GRANT;
-        }
-        const u32 c = grant;
-        ++grant; --granted;
+        u32 tk = 0;
+        if (lane == 0) tk = (u32)atomicAdd(g.ticket + 8u * my_counter, 1ull);    // (the counters lie 64 bytes apart)
+        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)tk) * E2S_IMG_COUNTERS + my_counter;
         if (c >= g.n_chunks) break;
         b = c; t0 = (u64)c * E2S_IMG_TILES; t1 = min(t0 + (u64)E2S_IMG_TILES, a.n_tiles);
     } else {
         b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // worker (= segment) index
-        if (b >= a.n_blocks) return;
+        if (b >= a.n_blocks) break;                             // (every wave of the block meets at the barrier below)
         t0 = (u64)b * a.tiles_per_block + min(b, a.tiles_rem);
         t1 = min(t0 + (u64)a.tiles_per_block + (b < a.tiles_rem ? 1u : 0u), a.n_tiles);
     }
@@ -216,8 +217,21 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     const u64 torg = (FUSED && t0 > 0) ? t0 - 1 : t0;           // first tile processed: offsets count from it
     const u64 g_range = a.prov_lo + torg * TILE;                // SA position of offset 0
     const u64 seg = (u64)b * a.seg_cap;
-    uint64_t* const seg_starts = a.starts + seg;                // worker-uniform bases: stores use a 32-bit record offset
+    // a segment holds (start - first entry of the worker's range : u32, length : u16) -- 6 bytes per record instead of the image's 10:
+    // the segments are an intermediate, read once more by the kernel that lays the image out
+    u32* const seg_starts = a.starts32 + seg;                   // worker-uniform bases: stores use a 32-bit record offset
     uint16_t* const seg_lens = a.lens + seg;
+    const u32 shift1 = (u32)((t0 - torg) * TILE) + 1u;          // 1 + offset of the range's first entry from the origin of the offsets
+    // what append_entry keeps (ebwt2clust.cpp:54-63) and statistics() counts (clust2snp.cpp:889-909), tallied as the records leave
+    u32 l_kept = 0, lk1 = 0, lk_len = 0;                        // per lane: kept records, 1 + rank of the last one, its length
+    u32* const hrow = s_hist[wslot * 4u + (lane & 3u)];
+    auto tally = [&](const u32 rank, const u32 len16) {
+        if ((int)len16 >= a.min_len) {
+            ++l_kept; ++l_nrec; l_nb += (u64)len16;
+            if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&hrow[len16], 1u);
+            if (rank + 1u > lk1) { lk1 = rank + 1u; lk_len = len16; }
+        }
+    };
 
     // a lane reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of the wave
     // cover one 4 KiB stretch between them) plus the words just before and after its span
@@ -499,16 +513,18 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                     for (u32 r = lane; r < tile_total; r += 64u) {          // dense, rank-ordered stores
                         const u64 v = st_rec[r];
                         const u32 s1 = (u32)v, e = (u32)(v >> 32);
-                        seg_starts[run + r] = g_range + (s1 - 1u);
+                        seg_starts[run + r] = s1 - shift1;
                         seg_lens[run + r] = (uint16_t)(e + 2u - s1);
+                        tally(run + r, e + 2u - s1);
                     }
                 } else {                                                    // no start seen in the range before this tile
                     for (u32 r = lane; r < tile_total; r += 64u) {
                         const u64 v = st_rec[r];
                         const u32 s1 = (u32)v, e = (u32)(v >> 32);
                         if (s1 != 0u) {
-                            seg_starts[run + r] = g_range + (s1 - 1u);
+                            seg_starts[run + r] = s1 - shift1;
                             seg_lens[run + r] = (uint16_t)(e + 2u - s1);
+                            tally(run + r, e + 2u - s1);
                         } else {
                             seg_lens[run + r] = (uint16_t)((g_range + e + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
                             unknown = 1;
@@ -538,8 +554,9 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                         if (rk < a.seg_cap) {
                             if (st1 != 0u) {
                                 const u32 len = off + 2u - st1;
-                                seg_starts[rk] = g_range + (st1 - 1u);
+                                seg_starts[rk] = st1 - shift1;
                                 seg_lens[rk] = (uint16_t)len;
+                                tally(rk, len & 0xFFFFu);
                                 if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
                             } else {
                                 seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);       // finished by k_seg_fix / e2s_stitch
@@ -632,6 +649,11 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     const u64 unk_m = __ballot(unknown != 0);
     const u64 fe_m = __ballot(first_end != ~0ull);
     const u64 fe = __shfl(first_end, fe_m ? __ffsll((long long)fe_m) - 1 : 0);
+    u32 kept_w = l_kept, lk1_w = lk1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kept_w += (u32)__shfl_xor((int)kept_w, o); lk1_w = max(lk1_w, (u32)__shfl_xor((int)lk1_w, o)); }
+    const u64 lk_m = __ballot(lk1 == lk1_w && lk1 != 0u);
+    const u32 lk_len_w = lk_m ? (u32)__shfl((int)lk_len, __ffsll((long long)lk_m) - 1) : 0u;
     if (lane == 0) {
         SegDesc d;
         d.count = min(run, a.seg_cap);
@@ -641,6 +663,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         if (state == 0u) { d.open_after = (t0 < t1) ? in0 : 0u; d.open_start = ~0ull; }         // no event at all
         else if (state == 1u) { d.open_after = 0; d.open_start = ~0ull; }
         else { d.open_after = 1; d.open_start = g_range + (open1 - 1u); }
+        d.kept = kept_w; d.last_kept1 = lk1_w; d.last_kept_len = lk_len_w; d.first_start = ~0ull;
         a.desc[b] = d;
     }
     break;
@@ -665,7 +688,12 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     if (unk0) {
         const u64 e0 = g_range + (u64)(v0 >> 16);
         u64 st = ~0ull;
+#if (E2S_IMG_ABL & 4)
+        st = g_range;
+        for (int64_t q = -1; q >= 0; --q) {
+#else
         for (int64_t q = (int64_t)c - 1; q >= 0; --q) {
+#endif
             const u64 v = img_wait(&g.st_a[q], lane, g.err, [](u64 x) { return (x & IMG_A_VALID) != 0ull; });
             if ((v & (3ull << 61)) == IMG_A_PASS) continue;
             if ((v & (3ull << 61)) == IMG_A_OPEN) st = v & IMG_POS_MASK;
@@ -683,16 +711,19 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     }
     // what append_entry keeps (and statistics() counts); the last such record of the chunk
     u32 kept = 0, lk_at = ~0u, lk_len = 0;
-    u32* const hrow = s_hist[IMG ? (wslot * 4u + (lane & 3u)) : 0u];
     auto rec_len = [&](u32 r, u32 v) -> u32 { return (r == 0u && unk0) ? r0_len : (((v >> 16) + 2u - (v & 0xFFFFu)) & 0xFFFFu); };
     for (u32 q0 = 0; q0 < m; q0 += 64u) {
         const u32 r = q0 + lane;
         const bool valid = r < m;
         const u32 v = valid ? cbuf[r] : 0u;
         const u32 len = rec_len(r, v);
-        const bool sk = valid && (int)len >= g.min_len;
+        const bool sk = valid && (int)len >= a.min_len;
         const bool ik = sk || (valid && r == 0u && r0_shard);
+#if (E2S_IMG_ABL & 8)
+        if (sk) { ++l_nrec; l_nb += (u64)len; }
+#else
         if (sk) { ++l_nrec; l_nb += (u64)len; if (len <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&hrow[len], 1u); }
+#endif
         kept += (u32)__popcll(__ballot(ik));
         const u64 skm = __ballot(sk);
         if (skm) { const int top = 63 - __clzll(skm); lk_at = q0 + (u32)top; lk_len = (u32)__builtin_amdgcn_readlane((int)len, top); }
@@ -700,7 +731,12 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // the chunk's offset in the image: decoupled look-back over the status words B
     if (lane == 0) img_store(&g.st_b[c], IMG_B_AGG | (u64)kept);
     u64 P = 0;
+#if (E2S_IMG_ABL & 2)
+    P = (u64)c * 100ull;
+    for (int64_t q = -1; q >= 0;) {
+#else
     for (int64_t q = (int64_t)c - 1; q >= 0;) {
+#endif
         const int64_t qi = q - (int64_t)lane;                       // lane 0 looks at the nearest chunk
         u64 v = IMG_B_INCL;                                         // (before the first chunk: nothing)
         bool done = false;
@@ -732,16 +768,20 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
             const bool valid = r < m;
             const u32 v = valid ? cbuf[r] : 0u;
             const u32 len = rec_len(r, v);
-            const bool ik = valid && ((int)len >= g.min_len || (r == 0u && r0_shard));
+            const bool ik = valid && ((int)len >= a.min_len || (r == 0u && r0_shard));
             const u64 km = __ballot(ik);
             if (ik) {
                 const u64 idx = at + (u64)__popcll(km & ((1ull << lane) - 1ull));
                 const u64 stv = (r == 0u && unk0) ? r0_start : g_range + (u64)((v & 0xFFFFu) - 1u);
+#if !(E2S_IMG_ABL & 1)                                        // (diagnostic builds, bits: 1 no image stores, 2 no look-back, 4 no wait for A, 8 no histogram)
                 if (idx < g.img_cap) {
                     uint8_t* o = g.img + idx * 10ull;
                     *(u64_a2*)o = stv;
                     *(uint16_t*)(o + 8) = (uint16_t)len;
                 } else atomicOr(g.err, E2S_DEVERR_SEGFULL);
+#else
+                if (idx == 0x123456789ull) g.img[0] = (uint8_t)stv;
+#endif
             }
             at += (u64)__popcll(km);
         }
@@ -770,7 +810,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                 }
             }
         }
-        // the wave's report and the block's share of the statistics
+        // the wave's report
         const u32 w = blockIdx.x * 4u + wslot;
         if (lane == 0 && w < g.n_waves) {
             ImgSlot sl;
@@ -778,18 +818,19 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
             sl.kept_c1 = w_kept_c1; sl.kept_len = w_kept_len; sl.kept_is_rec0 = w_kept_rec0; sl.reserved = 0;
             g.slots[w] = sl;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { l_nrec += __shfl_xor((unsigned long long)l_nrec, o); l_nb += __shfl_xor((unsigned long long)l_nb, o); }
-        if (lane == 0 && l_nrec) { atomicAdd((unsigned long long*)&s_acc[0], (unsigned long long)l_nrec); atomicAdd((unsigned long long*)&s_acc[1], (unsigned long long)l_nb); }
-        __syncthreads();
-        for (u32 i = threadIdx.x; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 256u) {
-            u32 v = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v += s_hist[IMG ? r : 0][IMG ? i : 0];
-            if (v) atomicAdd(&g.stats[i], (unsigned long long)v);
-        }
-        if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&g.stats[E2S_MAX_CLUST_LEN_K + 1], (unsigned long long)s_acc[0]); atomicAdd(&g.stats[E2S_MAX_CLUST_LEN_K + 2], (unsigned long long)s_acc[1]); }
     }
+    // the block's share of the statistics: one flush of the histogram replicas and the two sums
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { l_nrec += __shfl_xor((unsigned long long)l_nrec, o); l_nb += __shfl_xor((unsigned long long)l_nb, o); }
+    if (lane == 0 && l_nrec) { atomicAdd((unsigned long long*)&s_acc[0], (unsigned long long)l_nrec); atomicAdd((unsigned long long*)&s_acc[1], (unsigned long long)l_nb); }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 256u) {
+        u32 v = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += s_hist[r][i];
+        if (v) atomicAdd(&a.stats[i], (unsigned long long)v);
+    }
+    if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 1], (unsigned long long)s_acc[0]); atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 2], (unsigned long long)s_acc[1]); }
 }
 
 // shard descriptors: begins_inside / open_after / end_before_last and the two last LCP values, evaluated scalar-ly on the
@@ -838,23 +879,32 @@ __device__ void shard_flags_eval(const void* lcp, u64 n_prov, u64 prov_lo, u64 o
     tailv2[1] = L(last - 1);
 }
 
-// One block ties the segments together: record offsets (exclusive scan of the per-block counts), the records
-// whose start lies in an earlier block, and the ScanMail the host downloads.
+// One block ties the segments together: offsets of the records in rank order and of the KEPT records in the image (exclusive scans of
+// the per-worker counts), the records whose start lies in an earlier block -- with their share of the kept counts and the
+// statistics, which the scan could not tally without their length --, the statistics themselves (the scan's block-wise sums plus
+// those shares), and the ScanMail the host downloads.
 constexpr int SEGFIX_MAX = 8192;             // scan workers (= resident waves: 256 CUs x <= 32)
-__global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* tailv, u64* seg_off, u32* err,
+__device__ __forceinline__ u64 seg_range_base(const SegArgs& a, u32 b, u32 row_entries) {      // SA position of the first entry of worker b's range
+    return a.prov_lo + ((u64)b * a.tiles_per_block + min(b, a.tiles_rem)) * (u64)row_entries;
+}
+__global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err,
                                                   const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out,
-                                                  u64* hist_zero) {
+                                                  u64* stats_out) {
     __shared__ u32 s_cnt[SEGFIX_MAX];
+    __shared__ u32 s_kept[SEGFIX_MAX];
     __shared__ u64 s_open[SEGFIX_MAX];       // open_start | PASS (inside one cluster throughout) | NONE (closed after the block)
-    __shared__ u32 s_part[1024];
-    __shared__ u32 s_first, s_last, s_err;
+    __shared__ u32 s_part[1024], s_kpart[1024];
+    __shared__ u32 s_first, s_last, s_err, s_lastk;
+    __shared__ u32 s_hadj[E2S_MAX_CLUST_LEN_K + 2];
+    __shared__ u64 s_nadj[2];
     const u64 NONE = ~0ull, PASS = ~0ull - 1;
     const u32 tid = threadIdx.x, nb = a.n_blocks;
+    const u32 row_entries = 64u * (64u / (u32)xb);
     __shared__ u32 s_flags[4], s_tailv[2];
-    if (tid == 0) { s_first = 0xFFFFFFFFu; s_last = 0; s_err = 0; }
-    // the shard's boundary flags (an otherwise idle thread, while the others fetch descriptors) and a clean statistics buffer
+    if (tid == 0) { s_first = 0xFFFFFFFFu; s_last = 0; s_err = 0; s_lastk = 0; s_nadj[0] = 0; s_nadj[1] = 0; }
+    for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 2); i += 1024u) s_hadj[i] = 0u;
+    // the shard's boundary flags (an otherwise idle thread, while the others fetch descriptors)
     if (tid == 1023) shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, (u32)xb, s_flags, s_tailv);
-    if (hist_zero) for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 6); i += 1024) hist_zero[i] = 0ull;
     __syncthreads();
     // every descriptor this thread looks at is loaded up front (<= 8, all in flight together: the loop used to pay
     // one global-memory latency per trip, twice)
@@ -875,6 +925,7 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
             d_cnt[q] = in ? d[q].count : 0u; d_unk[q] = d[q].first_unknown; d_fend[q] = d[q].first_end_pos;
             if (in) {
                 s_cnt[b] = d[q].count;
+                s_kept[b] = d[q].kept;
                 s_open[b] = !d[q].open_after ? NONE : (d[q].open_start != NONE ? d[q].open_start : PASS);
                 if (d[q].overflow) ferr = E2S_DEVERR_SEGFULL;
                 if (d[q].count) { fmin = min(fmin, b); fmax = max(fmax, b); }
@@ -889,44 +940,65 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         }
     }
     __syncthreads();
-    // exclusive scan of the counts: each thread owns a contiguous chunk
-    const u32 per = (nb + 1023) / 1024, lo = min(nb, tid * per), hi = min(nb, lo + per);
-    u32 sum = 0;
-    for (u32 b = lo; b < hi; ++b) sum += s_cnt[b];
-    s_part[tid] = sum;
-    __syncthreads();
-    if (tid < 64) {                           // 1024 partials: 16 per lane, wave scan
-        u32 loc = 0;
-        for (int i = 0; i < 16; ++i) loc += s_part[tid * 16 + i];
-        const u32 inc = wave_incl_scan(loc);
-        u32 run = inc - loc;
-        for (int i = 0; i < 16; ++i) { const u32 v = s_part[tid * 16 + i]; s_part[tid * 16 + i] = run; run += v; }
-    }
-    __syncthreads();
-    u64 run = s_part[tid];
-    for (u32 b = lo; b < hi; ++b) {
-        seg_off[b] = run;
-        run += s_cnt[b];
-    }
-    if (hi == nb && lo < nb) seg_off[nb] = run;
-    if (nb == 0 && tid == 0) seg_off[0] = 0;
     // the open start a block inherits: nearest earlier block that is not inside one cluster throughout
     auto carry_into = [&](u32 b) -> u64 {
         for (u32 q = b; q-- > 0;) { const u64 v = s_open[q]; if (v != PASS) return v; }
         return NONE;
     };
+    // record 0 of a block whose cluster began in an earlier block: start and length -- and whether append_entry keeps it.  The one
+    // that began in an earlier SHARD stays provisional (e2s_stitch finishes it) and keeps a slot in the image whatever its length.
 #pragma unroll
     for (int q = 0; q < DPT; ++q) {
         const u32 b = tid + (u32)q * 1024u;
         if (b >= nb || !d_cnt[q] || !d_unk[q]) continue;
         const u64 carry = carry_into(b);
-        if (carry == NONE) continue;                                // begins in an earlier shard: e2s_stitch
         const u64 seg = (u64)b * a.seg_cap;
-        const u64 true_len = d_fend[q] - carry + 1;
-        a.starts[seg] = carry;
-        a.lens[seg] = (uint16_t)(true_len & 0xFFFFull);
-        if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
+        u32 len16; bool slot;
+        if (carry == NONE) { len16 = (u32)a.lens[seg]; slot = true; }          // begins in an earlier shard: e2s_stitch
+        else {
+            const u64 true_len = d_fend[q] - carry + 1;
+            len16 = (u32)(true_len & 0xFFFFull);
+            a.desc[b].first_start = carry;
+            a.lens[seg] = (uint16_t)len16;
+            if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
+            slot = (int)len16 >= a.min_len;
+        }
+        if ((int)len16 >= a.min_len) {                          // what the statistics count: the length as stored
+            atomicAdd((unsigned long long*)&s_nadj[0], 1ull); atomicAdd((unsigned long long*)&s_nadj[1], (unsigned long long)len16);
+            if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&s_hadj[len16], 1u);
+        }
+        if (slot) s_kept[b] += 1u;                              // (this thread owns block b)
     }
+    __syncthreads();
+    // exclusive scans of the raw and the kept counts: each thread owns a contiguous chunk
+    const u32 per = (nb + 1023) / 1024, lo = min(nb, tid * per), hi = min(nb, lo + per);
+    u32 sum = 0, ksum = 0;
+    for (u32 b = lo; b < hi; ++b) { sum += s_cnt[b]; ksum += s_kept[b]; if (s_kept[b]) atomicMax(&s_lastk, b + 1u); }
+    s_part[tid] = sum; s_kpart[tid] = ksum;
+    __syncthreads();
+    if (tid < 64) {                           // 1024 partials: 16 per lane, wave scan
+        u32 loc = 0, kloc = 0;
+        for (int i = 0; i < 16; ++i) { loc += s_part[tid * 16 + i]; kloc += s_kpart[tid * 16 + i]; }
+        const u32 inc = wave_incl_scan(loc), kinc = wave_incl_scan(kloc);
+        u32 run = inc - loc, krun = kinc - kloc;
+        for (int i = 0; i < 16; ++i) {
+            const u32 v = s_part[tid * 16 + i], kv = s_kpart[tid * 16 + i];
+            s_part[tid * 16 + i] = run; s_kpart[tid * 16 + i] = krun;
+            run += v; krun += kv;
+        }
+    }
+    __syncthreads();
+    {
+        u64 run = s_part[tid], krun = s_kpart[tid];
+        for (u32 b = lo; b < hi; ++b) {
+            seg_off[b] = run; kept_off[b] = krun;
+            run += s_cnt[b]; krun += s_kept[b];
+        }
+        if (hi == nb && lo < nb) { seg_off[nb] = run; kept_off[nb] = krun; }
+        if (nb == 0 && tid == 0) { seg_off[0] = 0; kept_off[0] = 0; }
+    }
+    // the statistics: the scan's sums plus the records finished above
+    for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 1024u) stats_out[i] = a.stats[i] + (u64)s_hadj[i];
     __syncthreads();
     if (tid == 0) {
         ScanMail m;
@@ -937,9 +1009,15 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         // in flight together instead of queueing behind one another's branches
         const u64 li = a.n_prov - 1;
         const u64 total = nb ? seg_off[nb] : 0;                      // written above by the thread that owns the last chunk
+        const u64 ktotal = nb ? kept_off[nb] : 0;
+        // (what other threads of this block wrote above is read back past the L1: volatile)
+        const volatile SegDesc* vdesc = a.desc; const volatile uint16_t* vlens = a.lens;
+        SegDesc dl = a.desc[any ? s_last : 0];
+        dl.first_start = vdesc[any ? s_last : 0].first_start;
+        const SegDesc dk = a.desc[s_lastk ? s_lastk - 1u : 0u];
         const u64 v_first_end = a.desc[any ? s_first : 0].first_end_pos;
-        const u64 v_last_start = a.starts[any ? last_addr : 0];
-        const u32 v_first_len = a.lens[any ? first_addr : 0];
+        const u32 v_last_st32 = a.starts32[any ? last_addr : 0];
+        const u32 v_first_len = vlens[any ? first_addr : 0];
         const u32 v_text = da ? (yb == 1 ? (u32)((const uint8_t*)da)[li] : yb == 2 ? (u32)((const uint16_t*)da)[li] : ((const u32*)da)[li]) : 0u;
         const u32 v_suff = pos ? (zb == 1 ? (u32)((const uint8_t*)pos)[li] : zb == 2 ? (u32)((const uint16_t*)pos)[li] : ((const u32*)pos)[li]) : 0u;
         const u32 v_lcp = xb == 1 ? (u32)((const uint8_t*)a.lcp)[li] : xb == 2 ? (u32)((const uint16_t*)a.lcp)[li] : ((const u32*)a.lcp)[li];
@@ -958,10 +1036,34 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         m.tail_lcp = tv0; m.tail_prev_lcp = tv1;
         const u64 carry = carry_into(nb);
         m.open_start = (f1 && carry != NONE) ? carry : NONE;
+        // the start of the shard's last record: in its block's range, or -- record 0 of that block -- what was found above
+        const bool last_is_r0 = any && s_cnt[s_last] == 1u && dl.first_unknown;
+        const u64 v_last_start = last_is_r0 ? dl.first_start : seg_range_base(a, s_last, row_entries) + v_last_st32;
         m.last_end_start = (total > 0 && !(total == 1 && f0)) ? v_last_start : NONE;
         m.first_len_prov = total > 0 ? v_first_len : 0u;
         m.last_text = v_text; m.last_suff = v_suff; m.last_lcp = v_lcp; m.last_bwt = v_bwt;
+        m.img_records = ktotal;
         *out = m;
+        // the two sums, and the last record the statistics count (the reference counts it twice, H4) with the place it lives at
+        stats_out[E2S_MAX_CLUST_LEN_K + 1] = a.stats[E2S_MAX_CLUST_LEN_K + 1] + s_nadj[0];
+        stats_out[E2S_MAX_CLUST_LEN_K + 2] = a.stats[E2S_MAX_CLUST_LEN_K + 2] + s_nadj[1];
+        u64 last_len = 0, at = NONE;
+        if (s_lastk) {
+            const u32 bk = s_lastk - 1u;
+            if (dk.last_kept1) { last_len = dk.last_kept_len; at = (u64)bk * a.seg_cap + dk.last_kept1 - 1u; }
+            else { last_len = vlens[(u64)bk * a.seg_cap]; at = (u64)bk * a.seg_cap; }       // only its record 0, finished above
+            // (a provisional record 0 that holds a slot without reaching min_len is not what the statistics end with)
+            if ((int)last_len < a.min_len) {
+                last_len = 0; at = NONE;
+                for (u32 b2 = bk; b2-- > 0;) {
+                    const SegDesc d2 = a.desc[b2];
+                    if (d2.last_kept1) { last_len = d2.last_kept_len; at = (u64)b2 * a.seg_cap + d2.last_kept1 - 1u; break; }
+                    if (s_kept[b2] && (int)vlens[(u64)b2 * a.seg_cap] >= a.min_len) { last_len = vlens[(u64)b2 * a.seg_cap]; at = (u64)b2 * a.seg_cap; break; }
+                }
+            }
+        }
+        stats_out[E2S_MAX_CLUST_LEN_K + 3] = last_len;
+        stats_out[E2S_MAX_CLUST_LEN_K + 4] = at;
     }
 }
 
@@ -998,7 +1100,7 @@ __global__ __launch_bounds__(1024) void k_scan_img_fin(SegArgs a, ImgArgs g, u32
         if (s_last_c1 && sl.last_c1 == s_last_c1) s_last_start = sl.last_start;
         if (s_kept_c1 && sl.kept_c1 == s_kept_c1) { s_kept_len = sl.kept_len; s_kept_rec0 = sl.kept_is_rec0; }
     }
-    for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 3); i += 1024u) stats_out[i] = g.stats[i];
+    for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 3); i += 1024u) stats_out[i] = a.stats[i];
     __syncthreads();
     if (tid == 0) {
         ScanMail m;
@@ -1053,11 +1155,15 @@ void e2s_launch_img_patch(uint8_t* img, uint32_t patch_first, unsigned long long
 }
 
 // segments -> contiguous record arrays (only for consumers that index records by rank)
-__global__ __launch_bounds__(256) void k_seg_compact(SegArgs a, const u64* seg_off, u64* out_starts, uint16_t* out_lens) {
+__global__ __launch_bounds__(256) void k_seg_compact(SegArgs a, const u64* seg_off, u32 row_entries, u64* out_starts, uint16_t* out_lens) {
     const u32 b = blockIdx.x;
-    const u32 n = a.desc[b].count;
-    const u64 src = (u64)b * a.seg_cap, dst = seg_off[b];
-    for (u32 i = threadIdx.x; i < n; i += 256) { out_starts[dst + i] = a.starts[src + i]; out_lens[dst + i] = a.lens[src + i]; }
+    const SegDesc d = a.desc[b];
+    const u32 n = d.count;
+    const u64 src = (u64)b * a.seg_cap, dst = seg_off[b], rb = seg_range_base(a, b, row_entries);
+    for (u32 i = threadIdx.x; i < n; i += 256) {
+        out_starts[dst + i] = (i == 0u && d.first_unknown) ? d.first_start : rb + a.starts32[src + i];
+        out_lens[dst + i] = a.lens[src + i];
+    }
 }
 
 // one thread per tile: finish the record whose start lies in an earlier tile.  Records whose true length
@@ -1124,60 +1230,26 @@ __global__ __launch_bounds__(256) void k_pack_write(const u64* starts, const uin
     if (blockIdx.x == n_blocks - 1 && tid == 0) *total = prefix[blockIdx.x] + cnt[blockIdx.x];
 }
 
-// ---- the same image straight from the scan's segmented storage (no contiguous copy first): kept records per segment, a scan of
-// the <= 8192 counts, then every segment packs itself at its offset; the EOF tail records of the stitch plan follow the last one.
-__global__ __launch_bounds__(256) void k_pack_seg_count(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, int min_len, u32* kept) {
-    __shared__ u32 s_c;
-    if (threadIdx.x == 0) s_c = 0;
-    __syncthreads();
-    const u32 b = blockIdx.x, n = desc[b].count;
-    const uint16_t* p = lens + (u64)b * seg_cap;
-    u32 c = 0;
-    const u32 nv = n >> 3;
-    for (u32 i = threadIdx.x; i < nv; i += 256u) {
-        const uint4 v = *(const uint4*)(p + 8u * i);
-        c += ((int)(v.x & 0xFFFFu) >= min_len) + ((int)(v.x >> 16) >= min_len) + ((int)(v.y & 0xFFFFu) >= min_len) + ((int)(v.y >> 16) >= min_len) +
-             ((int)(v.z & 0xFFFFu) >= min_len) + ((int)(v.z >> 16) >= min_len) + ((int)(v.w & 0xFFFFu) >= min_len) + ((int)(v.w >> 16) >= min_len);
-    }
-    const u32 r = (nv << 3) + threadIdx.x;
-    if (r < n && (int)p[r] >= min_len) ++c;
-    for (int o = 32; o; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_c, c);
-    __syncthreads();
-    if (threadIdx.x == 0) kept[b] = s_c;
-}
-__global__ __launch_bounds__(1024) void k_pack_seg_scan(const u32* kept, u32 n_seg, u64* off, u32 n_tail_kept, u64* total) {
-    __shared__ u64 s_v[1024];
-    __shared__ u64 s_run;
-    const u32 tid = threadIdx.x;
-    if (tid == 0) s_run = 0;
-    __syncthreads();
-    for (u32 g0 = 0; g0 < n_seg; g0 += 1024) {
-        const u32 g = g0 + tid;
-        const u64 v = g < n_seg ? (u64)kept[g] : 0ull;
-        s_v[tid] = v;
-        __syncthreads();
-        for (u32 d = 1; d < 1024; d <<= 1) { const u64 x = tid >= d ? s_v[tid - d] : 0ull; __syncthreads(); s_v[tid] += x; __syncthreads(); }
-        if (g < n_seg) off[g] = s_run + s_v[tid] - v;
-        __syncthreads();
-        if (tid == 1023) s_run += s_v[1023];
-        __syncthreads();
-    }
-    if (tid == 0) { off[n_seg] = s_run; *total = s_run + n_tail_kept; }
-}
+// ---- the same image straight from the scan's segments: the scan has counted what append_entry keeps per segment and k_seg_fix has
+// scanned those counts, so ONE kernel lays the image out -- every segment packs itself at its offset (6-byte segment records in,
+// 10-byte file records out); the EOF tail records of the stitch plan follow the last one.
 // One block per segment, 1024 records per trip.  Ranks come from ballots (a lane looks at ONE record, so the loads are
 // coalesced); the records are laid out in LDS at the image's own alignment (LDS offset = byte offset in the image mod 16), so the
 // image leaves in whole 16-byte units -- the first version wrote it 2 bytes per lane and took 4 ms for 1.07 GB.
+// slot0_b: the segment whose record 0 holds slot 0 of the image whatever its length (a shard that begins inside a cluster; ~0: none).
 constexpr int PKS_REC = 1024;                                // records per trip (4 waves x 4 x 64)
-__global__ __launch_bounds__(256) void k_pack_seg_write(const u64* starts, const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len,
-                                                        const u64* off, uint8_t* out, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1) {
+__global__ __launch_bounds__(256) void k_pack_seg_write(SegArgs a, u32 row_entries, u32 slot0_b, const u64* off, uint8_t* out, u32 n_tail, u64 t0, uint16_t l0, u64 t1,
+                                                        uint16_t l1) {
     __shared__ __attribute__((aligned(16))) uint8_t s_img[PKS_REC * 10 + 32];
     __shared__ u32 s_w[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 n_seg = a.n_blocks; const int min_len = a.min_len;
     for (u32 b = blockIdx.x; b < n_seg; b += gridDim.x) {        // (a grid smaller than n_seg: the throttled form, see the launcher)
-    const u32 n = desc[b].count;
-    const u64* ps = starts + (u64)b * seg_cap;
-    const uint16_t* pl = lens + (u64)b * seg_cap;
+    const SegDesc d = a.desc[b];
+    const u32 n = d.count;
+    const u32* ps = a.starts32 + (u64)b * a.seg_cap;
+    const uint16_t* pl = a.lens + (u64)b * a.seg_cap;
+    const u64 rb = seg_range_base(a, b, row_entries);
     u64 done = off[b];                                          // records of the image before the trip at hand
     for (u32 c0 = 0; c0 < n; c0 += PKS_REC) {
         // wave w looks at records c0 + 256 w + 64 q + lane, q = 0..3
@@ -1186,8 +1258,8 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(const u64* starts, const
         for (int q = 0; q < 4; ++q) {
             const u32 i = c0 + 256u * wave + 64u * q + lane;
             ln[q] = i < n ? (u32)pl[i] : 0u;
-            st[q] = i < n ? ps[i] : 0ull;
-            keep[q] = (i < n && (int)ln[q] >= min_len) ? 1u : 0u;
+            st[q] = i < n ? ((i == 0u && d.first_unknown) ? d.first_start : rb + (u64)ps[i]) : 0ull;
+            keep[q] = (i < n && ((int)ln[q] >= min_len || (i == 0u && b == slot0_b))) ? 1u : 0u;
             cnt += (u32)__popcll(__ballot(keep[q] != 0u));
         }
         if (lane == 0) s_w[wave] = cnt;
@@ -1230,17 +1302,21 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(const u64* starts, const
         }
     }
 }
-void e2s_launch_pack_segments(const u64* starts, const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u32* kept, u64* off,
-                              uint8_t* out, u64* total, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1, hipStream_t st, u32 max_blocks) {
-    u32 n_tail_kept = 0;
-    if (n_tail > 0 && (int)l0 >= min_len) ++n_tail_kept;
-    if (n_tail > 1 && (int)l1 >= min_len) ++n_tail_kept;
-    hipLaunchKernelGGL(k_pack_seg_count, dim3(n_seg), dim3(256), 0, st, lens, desc, seg_cap, min_len, kept);
-    hipLaunchKernelGGL(k_pack_seg_scan, dim3(1), dim3(1024), 0, st, kept, n_seg, off, n_tail_kept, total);
+void e2s_launch_pack_segments(const SegArgs& a, u32 row_entries, u32 slot0_b, const u64* kept_off, uint8_t* out, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1,
+                              hipStream_t st, u32 max_blocks) {
     // max_blocks (0: one block per segment): an experiment knob -- the pack running beside the per-cluster pass throttled to a few blocks
     // per CU, so that it does not saturate HBM under that latency-bound kernel (no net gain measured: e2s_capi.hip, pack_blocks_beside)
+    const u32 n_seg = a.n_blocks;
     const u32 grid = max_blocks && max_blocks < n_seg ? max_blocks : n_seg;
-    hipLaunchKernelGGL(k_pack_seg_write, dim3(grid), dim3(256), 0, st, starts, lens, desc, seg_cap, n_seg, min_len, off, out, n_tail, t0, l0, t1, l1);
+    hipLaunchKernelGGL(k_pack_seg_write, dim3(grid), dim3(256), 0, st, a, row_entries, slot0_b, kept_off, out, n_tail, t0, l0, t1, l1);
+}
+// e2s_stitch on the segments: record 0 of a shard that began inside a cluster gets its start and length from the stitch plan
+__global__ void k_seg_patch(SegDesc* d, uint16_t* len0, u64 first_start, uint16_t first_len) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    d->first_start = first_start; d->first_unknown = 1u; *len0 = first_len;
+}
+void e2s_launch_seg_patch(SegDesc* d, uint16_t* len0, unsigned long long first_start, uint16_t first_len, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_patch, dim3(1), dim3(64), 0, st, d, len0, (u64)first_start, first_len);
 }
 
 __global__ void k_apply_plan(u64* starts, uint16_t* lens, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_ends, u32 n_tail,
@@ -1317,54 +1393,6 @@ void e2s_launch_unpack_clusters(const uint8_t* packed, u64 n, u64* starts, uint1
     hipLaunchKernelGGL(k_unpack_clusters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed, n, starts, lens, err);
 }
 
-// the same over the segmented record storage of scan_mode 0.  A segment holds only ~10^3 lengths, so a wave takes
-// a whole segment with 16-byte loads (8 lengths per lane) and the 16 waves of a block keep as many segments in
-// flight: the first version walked the segments block by block, one global-memory latency each (31 us for 13 MB).
-// Per wave 4 histogram replicas in LDS (lengths concentrate on a few values).  Segments are 16-byte aligned
-// (seg_cap is a multiple of 8).
-__global__ __launch_bounds__(1024) void k_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_seg, int min_len, u64* out, u64* out_last) {
-    constexpr int REP = 4, NB = E2S_MAX_CLUST_LEN_K + 1, NWV = 16;
-    __shared__ u32 s_freq[NWV * REP][NB + 1];
-    __shared__ u64 s_acc[2];
-    for (int i = threadIdx.x; i < NWV * REP * (NB + 1); i += 1024) (&s_freq[0][0])[i] = 0;
-    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
-    __syncthreads();
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 1023 && out_last) {   // the last record that survives the min_len filter (H4), and where it lives
-        u64 v = 0, at = ~0ull; bool found = false;
-        for (u32 b = n_seg; b-- > 0 && !found;) {
-            const uint16_t* p = lens + (u64)b * seg_cap;
-            for (u32 i = desc[b].count; i-- > 0;) if ((int)p[i] >= min_len) { v = p[i]; at = (u64)b * seg_cap + i; found = true; break; }
-        }
-        out_last[0] = v; out_last[1] = at;
-    }
-    u32* const my = s_freq[wave * REP + (lane & (REP - 1))];
-    u64 nrec = 0, nb = 0;
-    auto take = [&](u32 l) { if ((int)l >= min_len) { nrec++; nb += (u64)l; if (l <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&my[l], 1u); } };
-    for (u32 b = blockIdx.x * NWV + wave; b < n_seg; b += gridDim.x * NWV) {
-        const u32 n = desc[b].count;
-        const uint16_t* p = lens + (u64)b * seg_cap;
-        const u32 nv = n >> 3;                                   // whole groups of 8 lengths
-        for (u32 i = lane; i < nv; i += 64u) {
-            const uint4 v = *(const uint4*)(p + 8u * i);
-            take(v.x & 0xFFFFu); take(v.x >> 16); take(v.y & 0xFFFFu); take(v.y >> 16);
-            take(v.z & 0xFFFFu); take(v.z >> 16); take(v.w & 0xFFFFu); take(v.w >> 16);
-        }
-        const u32 r = (nv << 3) + lane;
-        if (r < n) take((u32)p[r]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { nrec += __shfl_xor(nrec, o); nb += __shfl_xor(nb, o); }
-    if (lane == 0) { atomicAdd((u64*)&s_acc[0], nrec); atomicAdd((u64*)&s_acc[1], nb); }
-    __syncthreads();
-    for (int i = threadIdx.x; i < NB; i += 1024) {
-        u32 v = 0;
-#pragma unroll 8
-        for (int r = 0; r < NWV * REP; ++r) v += s_freq[r][i];
-        if (v) atomicAdd(&out[i], (u64)v);
-    }
-    if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 1], s_acc[0]); atomicAdd(&out[E2S_MAX_CLUST_LEN_K + 2], s_acc[1]); }
-}
 // ----------------------------------------------------------------------------------------------
 // K2: per-cluster pass.  One wave per cluster record, lane i <-> entry start+i (clusters are
 // at most 150 entries: three 64-entry chunks).  find_variants, clust2snp.cpp:367-500.
@@ -2008,16 +2036,12 @@ void e2s_launch_scan_img_fin(const SegArgs& a, const ImgArgs& g, u32* flags, u32
                              int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out, hipStream_t st) {
     hipLaunchKernelGGL(k_scan_img_fin, dim3(1), dim3(1024), 0, st, a, g, flags, tailv, err, bwt, pos, da, xb, yb, zb, out, (u64*)stats_out);
 }
-void e2s_launch_seg_fix(const SegArgs& a, u32* flags, u32* tailv, u64* seg_off, u32* err, const uint8_t* bwt, const void* pos,
-                        const void* da, int xb, int yb, int zb, ScanMail* out, u64* hist_zero, hipStream_t st) {
-    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, err, bwt, pos, da, xb, yb, zb, out, hist_zero);
+void e2s_launch_seg_fix(const SegArgs& a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err, const uint8_t* bwt, const void* pos,
+                        const void* da, int xb, int yb, int zb, ScanMail* out, u64* stats_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, kept_off, err, bwt, pos, da, xb, yb, zb, out, stats_out);
 }
-void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u64* out_starts, uint16_t* out_lens, hipStream_t st) {
-    hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, out_starts, out_lens);
-}
-void e2s_launch_hist_seg(const uint16_t* lens, const SegDesc* desc, u32 seg_cap, u32 n_blocks, int min_len, u64* out, u64* out_last, hipStream_t st) {
-    const unsigned want = (n_blocks + 15u) / 16u;                 // 16 waves per block, a segment per wave and trip
-    hipLaunchKernelGGL(k_hist_seg, dim3(want < 256u ? (want ? want : 1u) : 256u), dim3(1024), 0, st, lens, desc, seg_cap, n_blocks, min_len, out, out_last);
+void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u32 row_entries, u64* out_starts, uint16_t* out_lens, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, row_entries, out_starts, out_lens);
 }
 u64 e2s_pack_clusters_blocks(u64 n) { return (n + PK_BLOCK - 1) / PK_BLOCK; }
 // scratch: cnt[blocks] (u32) and prefix[blocks] (u64); out: 10 bytes per record; total: records written
@@ -2132,12 +2156,13 @@ void e2s_launch_record_prefilter(const unsigned long long* starts, const uint16_
                        len_hi, (u64*)fl_starts, fl_lens, (u64)fl_cap, fl_count);
 }
 // one launch instead of a handful of tiny memsets / copies before a phase (each costs a few microseconds of stream time)
-__global__ void k_phase_init(u64* count, u64 count_value, uint16_t* lens, u32 n_lens, u32* w0, u32 n0, u32* w1, u32 n1) {
+__global__ void k_phase_init(u64* count, u64 count_value, uint16_t* lens, u32 n_lens, u32* w0, u32 n0, u32* w1, u32 n1, u64* z, u32 nz) {
     const u32 t = threadIdx.x;
     if (t == 0 && count) *count = count_value;
     if (lens && t < n_lens) lens[t] = 0;
     if (w0 && t < n0) w0[t] = 0;
     if (w1 && t < n1) w1[t] = 0;
+    if (z && t < nz) z[t] = 0ull;
 }
 // the per-cluster pass's counters cleared and the seed clusters (read from the pinned mailbox) placed into the reserved head
 // of the flagged list, in one launch
@@ -2156,8 +2181,8 @@ void e2s_launch_cand_init(unsigned long long* cand_count, unsigned long long* st
                        n_seed_slots, (u64*)fl_starts, fl_lens, (u64*)fl_count, set_fl_count ? 1u : 0u, ko_cnt, n_ko);
 }
 void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
-                           uint32_t* w1, uint32_t n1, hipStream_t st) {
-    hipLaunchKernelGGL(k_phase_init, dim3(1), dim3(256), 0, st, (u64*)count, (u64)count_value, lens, n_lens, w0, n0, w1, n1);
+                           uint32_t* w1, uint32_t n1, unsigned long long* z, uint32_t nz, hipStream_t st) {
+    hipLaunchKernelGGL(k_phase_init, dim3(1), dim3(256), 0, st, (u64*)count, (u64)count_value, lens, n_lens, w0, n0, w1, n1, (u64*)z, nz);
 }
 __global__ void k_snapshot(const unsigned long long* src, unsigned long long* dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
 void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst, hipStream_t st) {

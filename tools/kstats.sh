@@ -9,7 +9,7 @@ import csv,sys
 tot=0
 for r in csv.DictReader(open(sys.argv[1])):
     n=r['Name']
-    if any(k in n for k in ('k_scan','k_seg','k_hist','k_cluster','k_flagged','k_ko','k_cand','k_shard','k_apply','k_tile')):
+    if any(k in n for k in ('k_scan','k_seg','k_hist','k_cluster','k_flagged','k_ko','k_cand','k_shard','k_apply','k_tile','k_img','k_pack','k_consensus','k_tail','k_phase','k_unpack')):
         print('%-28s calls %s avg %.1f us' % (n.split('(')[0][-28:], r['Calls'], float(r['AverageNs'])/1e3)); tot+=float(r['AverageNs'])/1e3
 print('sum of averages %.1f us' % tot)
 PY
