@@ -14,7 +14,7 @@ all: lib bins oracle
 lib: $(LIB)
 
 LIBSRC   = $(CSRC)/e2s_kernels.hip $(CSRC)/e2s_tail.hip $(CSRC)/e2s_capi.hip $(HOST)/snp_tail.cpp $(HOST)/fasta_index.cpp $(HOST)/reads_upload.cpp $(HOST)/chunked.cpp
-$(LIB): $(LIBSRC) $(CSRC)/e2s_internal.h $(CSRC)/e2s_swar.h $(HOST)/fasta_index.hpp include/e2s_hip.h
+$(LIB): $(LIBSRC) $(CSRC)/e2s_internal.h $(CSRC)/e2s_swar.h $(CSRC)/e2s_plan.h $(HOST)/fasta_index.hpp include/e2s_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIBSRC) -lpthread
 
 bins: bin/ebwt2clust bin/clust2snp bin/ebwt2snp_mgpu

@@ -146,6 +146,7 @@ REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
 # with a single rank, to exercise it on a one-GPU box
 FORCE_DIST = os.environ.get("E2S_BENCH_FORCE_DIST", "0") == "1"
 SECOND_LEG = os.environ.get("E2S_BENCH_SECOND_LEG", "1") == "1"      # also time the two kernels apart (reported as other_mode)
+NATIVE = os.environ.get("E2S_BENCH_NATIVE", "1") == "1"              # e2s_resident_job (one enqueue, one wait); 0: the stepwise calls
 
 
 def _exchange(blob, world, dist, dev):
@@ -200,7 +201,59 @@ def emulate_peers(blk, m, n1, rd, L, er, en_, local):
         h.close()
         del arrs
     torch.cuda.empty_cache()
-    return dict(blobs=blobs, events_before=sum(events))
+    return dict(blobs=blobs, events_before=sum(events), events_list=events)
+
+
+class _DevView:
+    """a raw device pointer as a __cuda_array_interface__ object (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+_VIEWS = {}
+
+
+def _dev_bytes(ptr, n, dev):
+    t = _VIEWS.get((ptr, n))
+    if t is None:
+        t = _VIEWS[(ptr, n)] = torch.as_tensor(_DevView(ptr, n), device=dev)
+    return t
+
+
+def make_allgather(world, rank, dist, dev, emul=None):
+    """the exchange of e2s_resident_job: an all-gather ENQUEUED on the handle's stream (RCCL through torch.distributed with the handle's
+    stream current; gloo in the rehearsal, through the host; one rank of an emulated job: its own share really travels, the peers'
+    shares are the cached ones)"""
+    def ag(d_send, d_recv, nbytes, stream):
+        key = ("stream", stream)
+        ext = _VIEWS.get(key)
+        if ext is None:
+            ext = _VIEWS[key] = torch.cuda.ExternalStream(stream, device=dev)
+        src = _dev_bytes(d_send, nbytes, dev)
+        dst = _dev_bytes(d_recv, nbytes * world, dev)
+        if emul is not None:
+            with torch.cuda.stream(ext):
+                if dist is not None:
+                    scratch = _VIEWS.get(("scratch", nbytes))
+                    if scratch is None:
+                        scratch = _VIEWS[("scratch", nbytes)] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    dist.all_gather_into_tensor(scratch, src)              # (a one-rank RCCL all-gather: the cost of the collective)
+                peers = emul["dev_blobs"][nbytes]
+                dst.copy_(peers, non_blocking=True)
+                dst[rank * nbytes:(rank + 1) * nbytes].copy_(src, non_blocking=True)
+            return
+        if REHEARSAL:                                              # gloo: through the host (not a measurement)
+            ext.synchronize()
+            out = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, src.cpu())
+            with torch.cuda.stream(ext):
+                dst.copy_(out)
+            ext.synchronize()
+            return
+        with torch.cuda.stream(ext):
+            dist.all_gather_into_tensor(dst, src)
+    return ag
 
 
 def run_step(h, n1, n_total, world, rank, dist, dev, fused=True, on_host=False, emul=None):
@@ -216,7 +269,19 @@ def run_step(h, n1, n_total, world, rank, dist, dev, fused=True, on_host=False, 
             if dist is not None:
                 _exchange(np.uint64(ne).tobytes(), 1, dist, dev)
             return emul["events_before"]
-        r = pipeline.resident_job(h, n1, n_total, emul["rank"], emul["world"], ex, fused=fused, ids_exchange=ids, tick=_tick)
+        if "ag" not in emul:
+            W = emul["world"]
+            b1 = np.zeros((W, capi.JOB_BLOB_BYTES), dtype=np.uint8)
+            for q, bl in enumerate(emul["blobs"]):
+                b1[q, :len(bl)] = np.frombuffer(bl, dtype=np.uint8)
+            b2 = np.zeros((W, 2), dtype=np.uint64)
+            b2[:, 1] = 1                                            # every peer is fine; the events of the ranks before this one:
+            ev = emul["events_list"]
+            b2[:len(ev), 0] = ev
+            emul["dev_blobs"] = {capi.JOB_BLOB_BYTES: torch.from_numpy(b1.reshape(-1)).to(dev), 16: torch.from_numpy(b2.view(np.uint8).reshape(-1)).to(dev)}
+            emul["ag"] = make_allgather(W, emul["rank"], dist, dev, emul)
+        r = pipeline.resident_job(h, n1, n_total, emul["rank"], emul["world"], ex, fused=fused, ids_exchange=ids, tick=_tick, allgather=emul["ag"],
+                                  native=None if NATIVE else False)
         return r
     ex = pipeline.exchange_none if dist is None else (lambda blob: _exchange(blob, world, dist, dev))
     ids = None
@@ -224,7 +289,12 @@ def run_step(h, n1, n_total, world, rank, dist, dev, fused=True, on_host=False, 
         def ids(ne):
             parts = _exchange(np.uint64(ne).tobytes(), world, dist, dev)
             return int(sum(np.frombuffer(p, dtype=np.uint64)[0] for p in parts[:rank]))
-    r = pipeline.resident_job(h, n1, n_total, rank, world, ex, fused=fused, ids_exchange=ids, tick=_tick)
+    ag = None
+    if dist is not None:
+        ag = _VIEWS.get("ag")
+        if ag is None:
+            ag = _VIEWS["ag"] = make_allgather(world, rank, dist, dev)
+    r = pipeline.resident_job(h, n1, n_total, rank, world, ex, fused=fused, ids_exchange=ids, tick=_tick, allgather=ag, native=None if NATIVE else False)
     if on_host:                                                    # both images over PCIe into (pinned, reused) host memory
         need = (int(r["n_records"]) * 10, int(r.get("snp_bytes", 0)))
         for i, nb in enumerate(need):
@@ -525,6 +595,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
                        "cluster_records": tot["n_ends"], "clusters_file_records": tot["n_records"], "candidates": tot["n_cand"],
                        "snp_events": tot["n_events"], "snp_bytes": tot["snp_bytes"], "max_clust_length": info["mcl"],
                        "input_build_s": round(t_build, 2),
+                       "one_enqueue_one_wait": bool(info.get("native", False)),      # e2s_resident_job ran the timed steps (else: the stepwise calls)
                        "step": "arm -> scan+pre-filter -> stitch -> statistics -> .clusters image (2nd stream) || candidates -> GPU tail -> .snp image; inputs and outputs in HBM",
                        "host_phase_ms": {k2: round(v / steps * 1e3, 4) for k2, v in prim["phases"].items()}},
             # the dominant kernel of the timed step.  Algorithmic bytes: LCP 1 + BWT 1 per entry read once, 10 B per record

@@ -83,7 +83,7 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize",
            "e2s_pack_clusters", "e2s_clusters_image", "e2s_upload_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_renumber_snp", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp",
-           "e2s_ebwt2clust_chunked", "e2s_clust2snp_chunked", "e2s_ebwt2snp_chunked", "e2s_hist_of_records"]
+           "e2s_ebwt2clust_chunked", "e2s_clust2snp_chunked", "e2s_ebwt2snp_chunked", "e2s_hist_of_records", "e2s_resident_job"]
 
 _lib = None
 
@@ -366,6 +366,11 @@ class Handle:
         self._ck(self.L.e2s_fetch_snp(self.h, _ptr(buf), n.value, C.byref(n)))
         return buf[:n.value]
 
+    def snp_size(self):
+        n = C.c_uint64(0)
+        self._ck(self.L.e2s_fetch_snp(self.h, None, 0, C.byref(n)))
+        return n.value
+
     def fetch_snp_into(self, out_ptr, cap_bytes):
         n = C.c_uint64(0)
         self._ck(self.L.e2s_fetch_snp(self.h, C.c_void_p(out_ptr), cap_bytes, C.byref(n)))
@@ -389,6 +394,10 @@ class Handle:
 
     def synchronize(self):
         self._ck(self.L.e2s_synchronize(self.h))
+
+
+ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)     # e2s_allgather_fn
+JOB_BLOB_BYTES = 1344
 
 
 class EgsaSource(C.Structure):
@@ -415,6 +424,34 @@ class JobReport(C.Structure):
     _fields_ = [("n_closed", C.c_uint64), ("n_records", C.c_uint64), ("max_clust_length", C.c_int32), ("n_chunks", C.c_int32),
                 ("n_clust", C.c_uint64), ("n_bases", C.c_uint64), ("n_candidates", C.c_uint64), ("n_variants", C.c_uint64),
                 ("n_events", C.c_uint64), ("hist", Hist), ("seconds_upload", C.c_double), ("seconds_total", C.c_double)]
+
+
+class ResidentParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("min_len", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("o", C2SOptions), ("want_image", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+def resident_job(h, n1, rank=0, world=1, allgather=None, k=16, min_len=2, mcov=5, pval=0.99, k_left=31, k_right=30, max_gap=10, max_err=2,
+                 cons_reads=20, want_image=True):
+    """e2s_resident_job on Handle h: the whole step enqueued at once, one wait.  allgather(d_send, d_recv, nbytes_per_rank, stream) -> None
+    enqueues an all-gather on the given HIP stream (world > 1).  Returns JobReport; raises E2SError (ERR_STATE: not applicable, nothing ran;
+    ERR_CAPACITY: rerun through the stepwise calls)."""
+    L = lib()
+    L.e2s_resident_job.argtypes = [C.c_void_p, C.POINTER(ResidentParams), ALLGATHER, C.c_void_p, C.POINTER(JobReport)]
+    p = ResidentParams(k, min_len, rank, world, C2SOptions(n1, k_left, k_right, mcov, cons_reads, max_gap, max_err, pval), 1 if want_image else 0, 0)
+    rep = JobReport()
+
+    def _ag(_user, d_send, d_recv, nbytes, stream):
+        try:
+            allgather(d_send, d_recv, nbytes, stream)
+            return 0
+        except Exception:                                          # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = ALLGATHER(_ag) if allgather is not None else ALLGATHER(0)
+    h._ck(L.e2s_resident_job(h.h, C.byref(p), cb, None, C.byref(rep)))
+    return rep
 
 
 def ebwt2snp_chunked(get, n_total, chunk_entries, n1, d_text, n_reads, read_len, clusters_sink=None, snp_sink=None, device=0, k=16, min_len=2,

@@ -10,6 +10,7 @@
 
 #include "../../include/e2s_hip.h"
 #include "e2s_internal.h"
+#include "e2s_plan.h"
 
 static_assert(sizeof(CandHeader) == sizeof(e2s_cand_header), "candidate header layout");
 static_assert(E2S_MAX_CLUST_LEN == E2S_MAX_CLUST_LEN_K, "max cluster length");
@@ -66,6 +67,7 @@ struct e2s_ctx {
     e2s_scan_stats raw_stats{}; bool raw_stats_valid = false;   // statistics computed in the scan phase
     uint8_t* d_img = nullptr; uint8_t* d_img_scratch = nullptr; uint64_t img_cap = 0;     // `.clusters` image (e2s_pack_clusters, e2s_stream_clusters)
     bool img_valid = false, img_pending = false, img_total_known = false; uint64_t img_records = 0; hipEvent_t ev_img = nullptr;
+    bool img_prestitch = false; hipStream_t img_stream = nullptr;   // laid out before e2s_stitch (which then finishes it in place), on this stream
     uint8_t* pin_io[2] = {nullptr, nullptr}; uint64_t pin_io_cap = 0; hipEvent_t ev_io[2] = {nullptr, nullptr};
     int scan_start_ev = 0; bool pf_fused = false;                // which event began the last scan; the in-flight pre-filter ran inside it
     bool pf_inflight = false; int pf_mcov = 0, pf_len_lo = 0;     // a pre-filter launched ahead of e2s_find_candidates
@@ -82,6 +84,7 @@ struct e2s_ctx {
     uint32_t seg_blocks_cap = 0;
     SegArgs seg_args{}; uint32_t seg_row_entries = 4096; uint64_t* d_kept_off = nullptr;     // the last segmented scan's arguments (compaction, image layout)
     uint64_t* d_scan_stats = nullptr;                            // [151 freq | n_records | n_bases] tallied by the scan kernel (in front of d_words)
+    uint8_t* d_xchg = nullptr; size_t xchg_bytes = 0;            // e2s_resident_job: the two exchanges' send / receive buffers
     // the scan that writes the image itself (k_scan_seg<1, FUSED, true>): records live in d_img only, statistics come with the mail
     bool img_mode = false; uint64_t img_scan_records = 0; uint32_t img_skip = 0;     // img_skip: the shard's record 0 turned out shorter than min_len
     uint8_t* d_imgst = nullptr; size_t imgst_bytes = 0; int img_waves[2] = {0, 0};      // ticket | statistics | status words A, B | per-wave reports
@@ -240,7 +243,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);      // (a failed stream is torn down all the same)
     release_shard(h);
     dev_free(h->d_starts); dev_free(h->d_lens);
-    dev_free(h->d_scalars); dev_free(h->d_scan_stats); dev_free(h->d_kept_off);
+    dev_free(h->d_scalars); dev_free(h->d_scan_stats); dev_free(h->d_kept_off); dev_free(h->d_xchg);
     dev_free(h->d_wrap); dev_free(h->d_fl_starts); dev_free(h->d_fl_lens);
     if (h->pin_cand) pin_free(h->pin_cand);
     if (h->pin_mail) pin_free(h->pin_mail);
@@ -618,20 +621,12 @@ static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail
     return E2S_OK;
 }
 
-extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode) {
-    dbg_entry("e2s_cluster_scan");
-    if (!h) return E2S_ERR_ARG;
-    if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
-    if (scan_mode != 0) return fail(h, E2S_ERR_ARG, "scan_mode must be 0 (kept in the signature for ABI stability)");
-    CK(hipSetDevice(h->device));
+// ---- e2s_cluster_scan in pieces: arguments, launch (everything up to the copy of the mail, no wait), finish (the handle's state from
+// the mail).  e2s_cluster_scan = launch, wait, finish, with a rerun where the segments overflowed; the resident job (e2s_resident_job)
+// launches, goes on enqueueing the per-cluster pass and the tail behind it, and finishes when the whole step has run.
+static void scan_args(e2s_ctx* h, int k, ScanArgs& a) {
     const e2s_shard_desc& d = h->d;
-    h->k = k; h->min_len = min_len;
-    h->scanned = h->stitched = false; h->records_from_file = false; h->compact_valid = false;
-    drop_image(h);
-    drop_prefilter(h);                                          // (a result of an earlier scan: other k, other data)
-    ++h->scan_gen;
-
-    ScanArgs a{};
+    a = ScanArgs{};
     a.lcp = h->lcp; a.n_prov = h->n_prov; a.prov_lo = h->prov_lo; a.prov_is_global0 = h->prov_lo == 0;
     a.own_lo = d.halo_left;
     a.start_hi = (uint64_t)d.halo_left + d.n_entries;
@@ -647,102 +642,108 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     a.total_ends = h->d_scalars + 0;
     a.first_end_pos = h->d_scalars + 3;
     a.err = h->d_words + 1; a.flags = h->d_words + 2; a.tailv = h->d_words + 8;
-    int rc;
-    ScanMail mail{};
+}
+static void scan_begin(e2s_ctx* h, int k, int min_len) {
+    h->k = k; h->min_len = min_len;
+    h->scanned = h->stitched = false; h->records_from_file = false; h->compact_valid = false;
+    drop_image(h);
+    drop_prefilter(h);                                          // (a result of an earlier scan: other k, other data)
+    ++h->scan_gen;
     h->img_mode = false;
-    bool img_done = false;
-    // E2S_SCAN_IMG=1: the scan that writes the image itself (tickets + decoupled look-back).  Measured slower than segments + one
-    // layout kernel on this chip (DESIGN.md section 4: its waves wait for the chunks before them), so it is the opt-in
-    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 0;
-    if (img_env && h->xb == 1 && ((uintptr_t)h->lcp & 15u) == 0 && (rc = scan_image(h, a, min_len, mail, &img_done))) return rc;
+}
 
-    if (!img_done) {
-        // ---- segmented single-pass scan: wave workers over contiguous tile ranges ----
-        const uint64_t row_entries = (uint64_t)64 * (E2S_SPAN_BYTES / h->xb);   // entries per wave-tile (64 lanes x 64 B)
-        SegArgs sa{};
-        sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
-        sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;
-        sa.k_u32 = a.k_u32; sa.kb = a.kb; sa.hge = a.hge;
-        sa.n_tiles = (h->n_prov + row_entries - 1) / row_entries;
-        static int resident[5] = {0, 0, 0, 0, 0};
-        if (!resident[h->xb]) {
-            resident[h->xb] = e2s_scan_seg_resident_blocks(h->xb);
-            if (const char* ev = getenv("E2S_SCAN_WORKERS")) {        // tuning aid: cap the number of scan workers
-                const int cap = atoi(ev);
-                if (cap > 0 && cap < resident[h->xb]) resident[h->xb] = cap;
-            }
+// the segmented scan: wave workers over contiguous tile ranges.  seg_cap 0 = the usual estimate; first: the armed pre-filter is taken along.
+// blob != nullptr: k_seg_fix also leaves this rank's share of the job's first all-gather there.
+static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t seg_cap, bool first, uint8_t* blob) {
+    int rc;
+    const e2s_shard_desc& d = h->d;
+    const uint64_t row_entries = (uint64_t)64 * (E2S_SPAN_BYTES / h->xb);   // entries per wave-tile (64 lanes x 64 B)
+    SegArgs sa{};
+    sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
+    sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;
+    sa.k_u32 = a.k_u32; sa.kb = a.kb; sa.hge = a.hge;
+    sa.n_tiles = (h->n_prov + row_entries - 1) / row_entries;
+    static int resident[5] = {0, 0, 0, 0, 0};
+    if (!resident[h->xb]) {
+        resident[h->xb] = e2s_scan_seg_resident_blocks(h->xb);
+        if (const char* ev = getenv("E2S_SCAN_WORKERS")) {        // tuning aid: cap the number of scan workers
+            const int cap = atoi(ev);
+            if (cap > 0 && cap < resident[h->xb]) resident[h->xb] = cap;
         }
-        // as many workers as waves fit on the chip (a whole number per SIMD), tiles dealt out evenly: the kernel is
-        // VALU bound, so a SIMD holding one worker more, or workers one tile longer, finishes that much later
-        uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
-        // e2s_prefilter_arm: the pre-filter runs inside the scan kernel (E2S_FUSED=0: beside it, on the second stream)
-        static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
-        const bool fused = h->pf_armed && fused_env && prefilter_eligible(h);
+    }
+    // as many workers as waves fit on the chip (a whole number per SIMD), tiles dealt out evenly
+    uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
+    // e2s_prefilter_arm: the pre-filter runs inside the scan kernel (E2S_FUSED=0: beside it, on the second stream)
+    static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
+    const bool armed = first && h->pf_armed;
+    const bool fused = armed && fused_env && prefilter_eligible(h);
+    if (fused) {
+        static const int fused_resident = e2s_scan_seg_fused_resident_blocks();
+        nb = std::min<uint64_t>(nb, (uint64_t)std::max(fused_resident, 4));
+    } else if (armed) nb = std::min<uint64_t>(nb, 4096);         // leave registers for the pre-filter's waves beside it
+    if (nb == 0) nb = 1;
+    sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
+    sa.tiles_rem = (uint32_t)(sa.n_tiles % nb);
+    if (nb > 8192) return fail(h, E2S_ERR_STATE, "more scan workers than k_seg_fix handles");
+    sa.n_blocks = (uint32_t)nb;
+    if (nb + 1 > h->seg_blocks_cap) {
+        dev_free(h->d_seg_desc); dev_free(h->d_seg_off); dev_free(h->d_kept_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->d_kept_off = nullptr;
+        h->seg_blocks_cap = 0;
+        CK(hipMalloc((void**)&h->d_seg_desc, (nb + 1) * sizeof(SegDesc)));
+        CK(hipMalloc((void**)&h->d_seg_off, (nb + 2) * 8));
+        CK(hipMalloc((void**)&h->d_kept_off, (nb + 2) * 8));
+        h->seg_blocks_cap = (uint32_t)(nb + 1);
+    }
+    sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
+    const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
+    if (!seg_cap) seg_cap = (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
+    else if (seg_cap == ~0ull) seg_cap = range_entries + 16;          // worst case: room for everything
+    if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
+    if ((rc = ensure_records(h, nb * seg_cap))) return rc;
+    sa.seg_cap = (uint32_t)seg_cap; sa.starts32 = (uint32_t*)h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
+    sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
+    FilterArgs fa{};
+    bool fuse_now = false;
+    if (armed) {                                                 // e2s_prefilter_arm
+        h->pf_armed = false;
         if (fused) {
-            static const int fused_resident = e2s_scan_seg_fused_resident_blocks();
-            nb = std::min<uint64_t>(nb, (uint64_t)std::max(fused_resident, 4));
-        } else if (h->pf_armed) nb = std::min<uint64_t>(nb, 4096);   // leave registers for the pre-filter's waves beside it
-        if (nb == 0) nb = 1;
-        sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
-        sa.tiles_rem = (uint32_t)(sa.n_tiles % nb);
-        if (nb > 8192) return fail(h, E2S_ERR_STATE, "more scan workers than k_seg_fix handles");
-        sa.n_blocks = (uint32_t)nb;
-        if (nb + 1 > h->seg_blocks_cap) {
-            dev_free(h->d_seg_desc); dev_free(h->d_seg_off); dev_free(h->d_kept_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->d_kept_off = nullptr;
-            h->seg_blocks_cap = 0;
-            CK(hipMalloc((void**)&h->d_seg_desc, (nb + 1) * sizeof(SegDesc)));
-            CK(hipMalloc((void**)&h->d_seg_off, (nb + 2) * 8));
-            CK(hipMalloc((void**)&h->d_kept_off, (nb + 2) * 8));
-            h->seg_blocks_cap = (uint32_t)(nb + 1);
-        }
-        sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
-        const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
-        uint64_t seg_cap = (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
-            if ((rc = ensure_records(h, nb * seg_cap))) return rc;
-            sa.seg_cap = (uint32_t)seg_cap; sa.starts32 = (uint32_t*)h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
-            sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
-            FilterArgs fa{};
-            bool fuse_now = false;
-            if (attempt == 0 && h->pf_armed) {                      // e2s_prefilter_arm
-                h->pf_armed = false;
-                if (fused) {
-                    h->pf_inflight = false;
-                    if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa, true))) return rc;
-                    fuse_now = true;
-                } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
-            }
-            if (!fuse_now) CK(hipMemsetAsync(h->d_scan_stats, 0, 160 * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
-            // three timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix + the
-            // statistics.  With the pre-filter inside the scan kernel the start event is the per-cluster pass's (ev[6]).
-            h->scan_start_ev = fuse_now ? 6 : 0;
-            CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
-            if (fuse_now) {
-                // (a rerun after a segment overflow scans alone: the pre-filter's list does not depend on the segments)
-                e2s_launch_scan_seg_fused(sa, fa, h->stream);
-                h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true; h->pf_gen = h->scan_gen;
-            } else e2s_launch_scan_seg(sa, h->xb, h->stream);
-            LCHK("e2s_launch_scan_seg");
-            CK(hipEventRecord(h->ev[3], h->stream));
-            // k_seg_fix: the shard's boundary flags, the records that began in an earlier block, the offsets of the kept records in the
-            // image, and the statistics the scan kernel tallied (e2s_scan_stats_desc / e2s_cluster_hist: no kernel of their own)
-            static_assert(sizeof(ScanMail) <= 256, "mail layout");
-            uint64_t* dh = (uint64_t*)((uint8_t*)h->d_mail + 256);
-            e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, (unsigned long long*)h->d_kept_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb,
-                               h->zb, h->d_mail, (unsigned long long*)dh, h->stream);
-            CK(hipEventRecord(h->ev[1], h->stream));
-            LCHK("e2s_launch_seg_fix");
-            CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
-            CK(wait_stream(h));
-            CK(hipGetLastError());
-            mail = *(const ScanMail*)h->pin_mail;
-            if (!(mail.err & E2S_DEVERR_SEGFULL)) break;
-            if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record segment overflow");
-            seg_cap = range_entries + 16;                           // worst case: rerun with room for everything
-        }
-        h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
-        h->seg_args = sa; h->seg_row_entries = (uint32_t)row_entries; h->img_scan_records = mail.img_records; h->img_skip = 0;
+            h->pf_inflight = false;
+            if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa, true))) return rc;
+            fuse_now = true;
+        } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
+    }
+    if (!fuse_now) CK(hipMemsetAsync(h->d_scan_stats, 0, 160 * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
+    // three timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix.
+    // With the pre-filter inside the scan kernel the start event is the per-cluster pass's (ev[6]).
+    h->scan_start_ev = fuse_now ? 6 : 0;
+    CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
+    if (fuse_now) {
+        // (a rerun after a segment overflow scans alone: the pre-filter's list does not depend on the segments)
+        e2s_launch_scan_seg_fused(sa, fa, h->stream);
+        h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true; h->pf_gen = h->scan_gen;
+    } else e2s_launch_scan_seg(sa, h->xb, h->stream);
+    LCHK("e2s_launch_scan_seg");
+    CK(hipEventRecord(h->ev[3], h->stream));
+    // k_seg_fix: the shard's boundary flags, the records that began in an earlier block, the offsets of the kept records in the
+    // image, and the statistics the scan kernel tallied (e2s_scan_stats_desc / e2s_cluster_hist: no kernel of their own)
+    static_assert(sizeof(ScanMail) <= 256, "mail layout");
+    uint64_t* dh = (uint64_t*)((uint8_t*)h->d_mail + 256);
+    const bool last_rank = d.global_offset + d.n_entries == d.n_total;
+    e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, (unsigned long long*)h->d_kept_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb,
+                       h->zb, h->d_mail, (unsigned long long*)dh, blob, last_rank ? 1 : 0, h->tail_bwt_given ? (int)h->tail_bwt_arg : -1, h->stream);
+    CK(hipEventRecord(h->ev[1], h->stream));
+    LCHK("e2s_launch_seg_fix");
+    CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
+    h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
+    h->seg_args = sa; h->seg_row_entries = (uint32_t)row_entries;
+    return E2S_OK;
+}
+
+// the handle's state from the mail of a scan that has run (either form)
+static int scan_finish(e2s_ctx* h, const ScanMail& mail, int min_len) {
+    const e2s_shard_desc& d = h->d;
+    if (!h->img_mode) {
+        h->img_scan_records = mail.img_records; h->img_skip = 0;
         h->first_rec_addr = mail.first_rec_addr;
         h->n_ends = mail.total_ends;
         take_scan_stats(h, mail, min_len);
@@ -784,6 +785,35 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     return E2S_OK;
 }
 
+extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode) {
+    dbg_entry("e2s_cluster_scan");
+    if (!h) return E2S_ERR_ARG;
+    if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
+    if (scan_mode != 0) return fail(h, E2S_ERR_ARG, "scan_mode must be 0 (kept in the signature for ABI stability)");
+    CK(hipSetDevice(h->device));
+    scan_begin(h, k, min_len);
+    ScanArgs a;
+    scan_args(h, k, a);
+    int rc;
+    ScanMail mail{};
+    bool img_done = false;
+    // E2S_SCAN_IMG=1: the scan that writes the image itself (tickets + decoupled look-back).  Measured slower than segments + one
+    // layout kernel on this chip (DESIGN.md section 4: its waves wait for the chunks before them), so it is the opt-in
+    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 0;
+    if (img_env && h->xb == 1 && ((uintptr_t)h->lcp & 15u) == 0 && (rc = scan_image(h, a, min_len, mail, &img_done))) return rc;
+    if (!img_done) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = seg_scan_launch(h, a, min_len, attempt ? ~0ull : 0ull, attempt == 0, nullptr))) return rc;
+            CK(wait_stream(h));
+            CK(hipGetLastError());
+            mail = *(const ScanMail*)h->pin_mail;
+            if (!(mail.err & E2S_DEVERR_SEGFULL)) break;
+            if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record segment overflow");
+        }
+    }
+    return scan_finish(h, mail, min_len);
+}
+
 extern "C" int e2s_boundary_desc(e2s_handle h, e2s_boundary* out) {
     dbg_entry("e2s_boundary_desc");
     if (!h || !out) return E2S_ERR_ARG;
@@ -803,65 +833,11 @@ extern "C" int e2s_boundary_desc(e2s_handle h, e2s_boundary* out) {
     return E2S_OK;
 }
 
-// start of the cluster that is open when rank r begins (walk back over pass-through shards)
-static uint64_t incoming_start(const e2s_boundary* all, int r) {
-    for (int q = r - 1; q >= 0; --q) {
-        if (all[q].open_start != E2S_NONE) return all[q].open_start;
-        if (!all[q].pass_through) return E2S_NONE;
-    }
-    return E2S_NONE;
-}
-
 extern "C" int e2s_stitch_plan(const e2s_boundary* all, int nranks, int rank, uint64_t n, int k, int lcp_bytes,
                                e2s_stitch_plan_t* out) {
     dbg_entry("e2s_stitch_plan");
     if (!all || !out || nranks < 1 || rank < 0 || rank >= nranks) return E2S_ERR_ARG;
-    memset(out, 0, sizeof(*out));
-    const e2s_boundary& me = all[rank];
-    const uint32_t ku = (uint32_t)k;
-    uint64_t inc = E2S_NONE;
-    if (me.begins_inside) {
-        inc = incoming_start(all, rank);
-        if (inc == E2S_NONE) return E2S_ERR_INPUT;               // descriptors do not fit together
-        if (me.n_ends > 0) {
-            out->patch_first = 1;
-            out->first_start = inc;
-            out->first_len = (uint16_t)((me.first_end_low16 - (uint32_t)(inc & 0xFFFF)) & 0xFFFF);
-        }
-    }
-    if (rank != nranks - 1) return E2S_OK;
-    // ---- last rank: the reference's EOF phantom (hazard H1; slot model, see oracle/e2s_oracle.c) ----
-    const uint64_t xmask = lcp_bytes >= 8 ? ~0ull : ((1ull << (8 * lcp_bytes)) - 1ull);
-    uint64_t slot = (((uint64_t)me.tail_lcp) & ~0xFFull) | (uint64_t)(me.tail_bwt & 0xFF);
-    if (n >= 3 && me.end_before_last) {
-        // append_entry ran right before the phantom read: the slot holds that cluster's start
-        uint64_t s = me.last_end_start;
-        if (s == E2S_NONE) s = inc;                              // it was this shard's only end and began earlier
-        if (s == E2S_NONE) return E2S_ERR_INPUT;
-        slot = s;
-    }
-    const uint32_t P = (uint32_t)(slot & xmask);
-    out->phantom_lcp = P;
-    const bool open_last = me.open_after != 0;                   // open(n-1)
-    uint64_t cur = E2S_NONE;
-    if (open_last) cur = (me.open_start != E2S_NONE) ? me.open_start : incoming_start(all, rank);
-    int nt = 0;
-    if (n == 1) {
-        // no loop iteration: start = ge(0) ? 0 : (P >= k ? 1 : null); tail flush with i = 1 (ebwt2clust.cpp:83-84,127-131)
-        if (open_last) { out->tail_start[nt] = 0; out->tail_len[nt++] = 2; }
-        else if (P >= ku) { out->tail_start[nt] = 1; out->tail_len[nt++] = 1; }
-    } else if (open_last) {
-        if (cur == E2S_NONE) return E2S_ERR_INPUT;
-        const bool gt = me.tail_prev_lcp > me.tail_lcp;
-        if ((gt && me.tail_lcp <= P) || P < ku) {                // the cluster ends at n-1 (ebwt2clust.cpp:98-106)
-            out->tail_start[nt] = cur; out->tail_len[nt++] = (uint16_t)((n - 1 - cur + 1) & 0xFFFF);
-            if (P >= ku) { out->tail_start[nt] = n; out->tail_len[nt++] = 1; }     // the phantom opens (n,1) (:116-118)
-        } else {                                                 // still open after the loop: the flush includes index n
-            out->tail_start[nt] = cur; out->tail_len[nt++] = (uint16_t)((n - cur + 1) & 0xFFFF);
-        }
-    } else if (P >= ku) { out->tail_start[nt] = n; out->tail_len[nt++] = 1; }
-    out->n_tail = (uint32_t)nt;
-    return E2S_OK;
+    return e2s_plan_core(all, nranks, rank, n, k, lcp_bytes, out);      // (e2s_plan.h: one source for the host and for k_job_plan)
 }
 
 extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int rank) {
@@ -909,6 +885,26 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
         // (that record holds slot 0 of the image; where append_entry drops it the image begins one record later)
         h->img_skip = (pl.patch_first && (int)pl.first_len < h->min_len) ? 1u : 0u;
         h->compact_valid = false;
+        if (h->img_prestitch && (h->img_pending || h->img_valid)) {
+            // the image was laid out before this call (e2s_pack_clusters right after the scan): finish it in place, behind the layout kernel
+            const bool keep_first = pl.patch_first && !h->img_skip;
+            uint64_t ts[2] = {0, 0}; uint16_t tl[2] = {0, 0}; uint32_t nt = 0;
+            for (uint32_t t = 0; t < pl.n_tail; ++t) if ((int)pl.tail_len[t] >= h->min_len) { ts[nt] = pl.tail_start[t]; tl[nt] = pl.tail_len[t]; ++nt; }
+            if ((rc = ensure_image(h, 2))) return rc;           // (a shard without a single end: room for the EOF records)
+            if (h->img_scan_records + nt > h->img_cap) return fail(h, E2S_ERR_CAPACITY, "image overflow at the tail");
+            hipStream_t ist = h->img_stream ? h->img_stream : h->stream;
+            if (keep_first || nt) {
+                if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
+                e2s_launch_img_patch(h->d_img, keep_first ? 1u : 0u, pl.first_start, pl.first_len, h->img_scan_records, nt, ts[0], tl[0], ts[1], tl[1], ist);
+                CK(hipEventRecord(h->ev_img, ist));
+                h->img_pending = true; h->img_valid = false;
+            }
+            h->img_records = h->img_scan_records - h->img_skip + nt; h->img_total_known = true; h->img_prestitch = false;
+            h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
+            h->plan = pl;
+            h->stitched = true;
+            return E2S_OK;
+        }
     } else {
         if (h->n_rec + pl.n_tail + 1 > h->cap) return fail(h, E2S_ERR_CAPACITY, "record buffer overflow at the tail");
         if (pl.patch_first || pl.n_tail) {
@@ -948,9 +944,10 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 static uint32_t pack_blocks_beside() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_PACK_BLOCKS"); v = e ? atoi(e) : 0; } return (uint32_t)v; }
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
     if (h->img_mode && h->stitched) { h->img_valid = true; h->img_pending = false; return E2S_OK; }   // the scan wrote it, e2s_stitch finished it
-    h->img_valid = false; h->img_pending = false; h->img_records = 0; h->img_total_known = false;
-    if (!h->n_rec) { h->img_valid = true; return E2S_OK; }
-    { int rc = ensure_image(h, h->n_rec); if (rc) return rc; }
+    h->img_valid = false; h->img_pending = false; h->img_records = 0; h->img_total_known = false; h->img_prestitch = false; h->img_stream = st;
+    const uint64_t n_raw = h->stitched ? h->n_rec : h->n_ends;
+    if (!n_raw) { h->img_valid = true; h->img_prestitch = !h->stitched; return E2S_OK; }
+    { int rc = ensure_image(h, n_raw + 2); if (rc) return rc; }
     if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
     if (st != h->stream) {                                       // after everything that shaped the records (stitch patch) ...
         CK(hipEventRecord(h->ev_img, h->stream));
@@ -961,8 +958,12 @@ static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
         uint32_t nt = 0;
         if (h->stitched) for (uint32_t t = 0; t < h->plan.n_tail; ++t) if ((int)h->plan.tail_len[t] >= h->min_len) ++nt;
         { int rc = ensure_image(h, h->img_scan_records + 2); if (rc) return rc; }
-        const uint32_t slot0_b = (h->stitched && h->plan.patch_first && h->first_rec_addr != E2S_NONE) ? (uint32_t)(h->first_rec_addr / h->seg_cap) : 0xFFFFFFFFu;
-        e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, slot0_b, (const unsigned long long*)h->d_kept_off, h->d_img, h->stitched ? h->plan.n_tail : 0,
+        // (before e2s_stitch: record 0 of a shard that begins inside a cluster holds its slot, the stitch finishes it and appends the EOF records)
+        const bool slot0 = h->stitched ? h->plan.patch_first != 0 : (h->begins_inside && h->n_ends);
+        const uint32_t slot0_b = (slot0 && h->first_rec_addr != E2S_NONE) ? (uint32_t)(h->first_rec_addr / h->seg_cap) : 0xFFFFFFFFu;
+        h->img_prestitch = !h->stitched;
+        e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, slot0_b, (const unsigned long long*)h->d_kept_off, h->d_img, h->img_cap, nullptr,
+                                 h->stitched ? h->plan.n_tail : 0,
                                  h->plan.tail_start[0], h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], st,
                                  st == h->stream2 ? pack_blocks_beside() : 0u);
         LCHK("e2s_launch_pack_segments");
@@ -1001,8 +1002,11 @@ static int pack_image(e2s_ctx* h, uint64_t* n_records) {
 extern "C" int e2s_pack_clusters(e2s_handle h, int async) {
     dbg_entry("e2s_pack_clusters");
     if (!h) return E2S_ERR_ARG;
-    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_stitch has not run");
+    // (right after e2s_cluster_scan the image is laid out while the ranks exchange their descriptors; e2s_stitch finishes it in place)
+    if (!h->stitched && !(h->scanned && h->segmented && !h->records_from_file)) return fail(h, E2S_ERR_STATE, "neither e2s_cluster_scan nor e2s_stitch has run");
     CK(hipSetDevice(h->device));
+    if (h->img_valid || h->img_pending) return async ? E2S_OK : pack_image_finish(h, nullptr);     // already there / on its way
+    if (!h->stitched && h->img_mode) return E2S_OK;             // (the scan wrote it)
     int rc = pack_image_launch(h, async ? h->stream2 : h->stream);
     if (rc || async) return rc;
     return pack_image_finish(h, nullptr);
@@ -1171,28 +1175,14 @@ extern "C" int e2s_scan_stats_desc(e2s_handle h, e2s_scan_stats* out) {
 extern "C" int e2s_hist_after_stitch(const e2s_scan_stats* raw, const e2s_boundary* b, const e2s_stitch_plan_t* plan, e2s_hist* out) {
     if (!raw || !b || !plan || !out) return E2S_ERR_ARG;
     *out = raw->hist;
-    const int min_len = raw->min_len;
-    auto add = [&](int l, int sign) {
-        if (l < min_len) return;
-        out->n_records += (uint64_t)(int64_t)sign; out->n_bases += (uint64_t)((int64_t)sign * l);
-        if (l <= E2S_MAX_CLUST_LEN) out->freq[l] += (uint64_t)(int64_t)sign;
-    };
-    if (plan->patch_first) {                                     // record 0: provisional length out, stitched length in
-        const int oldl = (int)(b->first_end_low16 & 0xFFFFu), newl = (int)plan->first_len;
-        add(oldl, -1);
-        add(newl, +1);
-        if (raw->last_none || raw->last_is_first) out->last_len = newl >= min_len ? (uint64_t)newl : 0;
-    }
-    for (uint32_t t = 0; t < plan->n_tail; ++t) {                // the EOF tail records live in the stitch plan
-        const int l = plan->tail_len[t];
-        if (l >= min_len) { add(l, +1); out->last_len = (uint64_t)l; }
-    }
-    if (!out->n_records) out->last_len = 0;
+    e2s_stat_delta d;
+    e2s_hist_delta_core(raw, b, plan, &d);                        // (e2s_plan.h)
+    for (int i = 0; i < d.n; ++i) if (d.len[i] <= E2S_MAX_CLUST_LEN) out->freq[d.len[i]] += (uint64_t)(int64_t)d.sign[i];
+    out->n_records = d.n_records; out->n_bases = d.n_bases; out->last_len = d.last_len;
     return E2S_OK;
 }
 
-// statistics(), clust2snp.cpp:877-966, host part.  The oracle build (-Ofast) divides in the first test
-// and multiplies by the hoisted reciprocal inside the loop; reproduced here (H19).
+// statistics(), clust2snp.cpp:877-966, host part (e2s_plan.h: e2s_auto_len_core, shared with the device).
 extern "C" int e2s_auto_max_clust_length(const e2s_hist* parts, int nparts, int mcov_out, double pval,
                                          int* max_clust_length, uint64_t* n_clust, uint64_t* n_bases) {
     dbg_entry("e2s_auto_max_clust_length");
@@ -1204,31 +1194,12 @@ extern "C" int e2s_auto_max_clust_length(const e2s_hist* parts, int nparts, int 
         nrec += parts[p].n_records; nb += parts[p].n_bases;
         if (parts[p].n_records) last_len = parts[p].last_len;
     }
-    if (nrec == 0) return fail(nullptr, E2S_ERR_REF_CRASH, "no cluster record: the reference divides by zero here");   // empty .clusters: SIGFPE in the reference (H6)
-    // H4: `while(not clusters.eof())` counts the last record twice
-    if (last_len <= E2S_MAX_CLUST_LEN) freq[last_len]++;
-    nrec += 1; nb += last_len;
-    uint64_t mx = 0;
-    for (uint64_t i = 1; i <= E2S_MAX_CLUST_LEN; ++i) mx = std::max(mx, freq[i] * i);
-    if (mx == 0) return fail(nullptr, E2S_ERR_REF_CRASH, "no cluster of length <= 150: the reference divides by zero here");   // clust2snp.cpp:921 divides by max
-    int mcl = 2 * mcov_out;
-    if (mcl < 0 || mcl > E2S_MAX_CLUST_LEN) return fail(nullptr, E2S_ERR_REF_CRASH, "the automatic -c falls outside the histogram: the reference reads past it here");
-    uint64_t cum = freq[mcl] * (uint64_t)mcl;
-    const double dnb = (double)nb;
-    if ((double)cum / dnb < pval) {
-        const double r = 1.0 / dnb;
-        uint64_t c = (uint64_t)mcl;
-        while (c < E2S_MAX_CLUST_LEN) {
-            ++c;
-            cum += freq[c] * c;
-            if (!((double)cum * r < pval)) break;
-        }
-        mcl = (int)c;
+    switch (e2s_auto_len_core(freq, nrec, nb, last_len, mcov_out, pval, max_clust_length, n_clust, n_bases)) {
+        case 1: return fail(nullptr, E2S_ERR_REF_CRASH, "no cluster record: the reference divides by zero here");   // empty .clusters: SIGFPE in the reference (H6)
+        case 2: return fail(nullptr, E2S_ERR_REF_CRASH, "no cluster of length <= 150: the reference divides by zero here");   // clust2snp.cpp:921 divides by max
+        case 3: return fail(nullptr, E2S_ERR_REF_CRASH, "the automatic -c falls outside the histogram: the reference reads past it here");
+        default: return E2S_OK;
     }
-    *max_clust_length = mcl;
-    if (n_clust) *n_clust = nrec;
-    if (n_bases) *n_bases = nb;
-    return E2S_OK;
 }
 
 static uint32_t list_cap_of(const e2s_c2s_params* p) {
@@ -1530,7 +1501,7 @@ static int cand_record_pass(e2s_ctx* h, const CandArgs& a, const e2s_c2s_params*
 
 // SA order and offsets follow without a host round trip (the kernels read the candidate count on the device); the last kernel
 // writes counts and error words into the pinned mailbox
-static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a) {
+static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nullptr) {
     const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
     e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
                           h->d_order, h->stream, true);
@@ -1539,9 +1510,23 @@ static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a) {
     CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
     e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
                             (uint32_t*)(a.host_stream + h->stream_ord_off), (const unsigned long long*)(h->d_scalars + 2), h->d_words + 1,
-                            h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 1024), h->stream);
+                            h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 3328), bad, h->fl_cap, a.stream8_cap, h->stream);
     LCHK("e2s_launch_cand_offsets");
     return E2S_OK;
+}
+
+// the handle's state once a per-cluster pass has delivered `count` candidates (everything arrived with the mailbox)
+static void cand_accept(e2s_ctx* h, const CandArgs& a, uint64_t count, int pf_end_ev) {
+    const e2s_shard_desc& d = h->d;
+    h->n_cand = count;
+    h->host_fixed_valid = false;
+    h->cand_downloaded = count != 0;
+    h->pin_order = h->pin_cand ? (uint32_t*)(h->pin_cand + h->stream_ord_off) : nullptr;
+    h->cand_host_valid = !h->cand_dev;
+    ev_ms(&h->tm.cand_ms, h->ev[6], h->ev[7]);
+    ev_ms(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev]);   // the pre-filter (inside the scan kernel: that kernel)
+    h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
+    h->tm.cand_bytes_written = count * a.stride;
 }
 
 extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64_t record_index_base, uint64_t* n_cand) {
@@ -1603,7 +1588,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         if ((rc = cand_order_and_mail(h, a))) return rc;
         CK(wait_stream(h));
         CK(hipGetLastError());
-        const uint64_t* mb = (const uint64_t*)(h->pin_mail + 1024);
+        const uint64_t* mb = (const uint64_t*)(h->pin_mail + 3328);
         count = mb[0];
         const uint64_t flagged = mb[1];
         const uint32_t err = ((const uint32_t*)(mb + 2))[0] | ((const uint32_t*)(mb + 2))[1];     // K2b's word | the pre-filter's
@@ -1627,15 +1612,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         want = count + 1024;
     }
     if (!done) return fail(h, E2S_ERR_CAPACITY, "candidate / flagged buffer overflow");
-    h->n_cand = count;
-    h->host_fixed_valid = false;
-    h->cand_downloaded = count != 0;                             // everything arrived with the mailbox wait above
-    h->pin_order = h->pin_cand ? (uint32_t*)(h->pin_cand + h->stream_ord_off) : nullptr;
-    h->cand_host_valid = !h->cand_dev;
-    ev_ms(&h->tm.cand_ms, h->ev[6], h->ev[7]);
-    ev_ms(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev]);   // the pre-filter (inside the scan kernel: that kernel)
-    h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
-    h->tm.cand_bytes_written = count * a.stride;
+    cand_accept(h, a, count, pf_end_ev);
     if (n_cand) *n_cand = count;
     return E2S_OK;
 }
@@ -1809,22 +1786,17 @@ extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_by
     return E2S_OK;
 }
 
-extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_t first_id, uint64_t* n_variants, uint64_t* n_events, uint64_t* snp_bytes) {
-    dbg_entry("e2s_call_variants");
-    if (!h || !p) return E2S_ERR_ARG;
-    if (n_variants) *n_variants = 0;
-    if (n_events) *n_events = 0;
-    if (snp_bytes) *snp_bytes = 0;
+// what the GPU tail needs before it can run at all (both e2s_call_variants and the resident job)
+static int tail_applicable(e2s_ctx* h, const e2s_tail_params* p) {
     if (!h->have_reads) return fail(h, E2S_ERR_STATE, "no reads resident (e2s_upload_reads / e2s_attach_reads)");
-    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
-    if (h->n_cand && !h->cand_dev) return fail(h, E2S_ERR_STATE, "the candidates were delivered to the host: make the reads resident BEFORE e2s_find_candidates");
-    // zero candidates: the reference indexes an empty vector (clust2snp.cpp:531) and dies before creating the file
-    if (h->n_cand == 0) return fail(h, E2S_ERR_REF_CRASH, "no candidate cluster: the reference crashes before it creates the output");
     if (p->k_left < 0) return fail(h, E2S_ERR_REF_CRASH, "negative -L: the reference throws here");                // cons(size_t(-n)) throws in the reference
     if (p->k_left < 1 || p->k_left > 64) return fail(h, E2S_ERR_STATE, "GPU tail: -L outside 1..64 (use the host tail, e2s_snp_from_packed)");
     if (h->text_bytes < 4) return fail(h, E2S_ERR_STATE, "GPU tail: fewer than 4 bytes of reads (use the host tail, e2s_snp_from_packed)");
-    CK(hipSetDevice(h->device));
-    const uint64_t n = h->n_cand, ng = (n + 63) / 64;
+    return E2S_OK;
+}
+// buffers for up to n candidates and the kernels' arguments (a.n_cand = n: the launches' extent)
+static int tail_prepare(e2s_ctx* h, const e2s_tail_params* p, uint64_t n, TailArgs& a) {
+    const uint64_t ng = (n + 63) / 64;
     if (n > h->tail_cap) {
         dev_free(h->d_cons); dev_free(h->d_trec); h->d_cons = nullptr; h->d_trec = nullptr; h->tail_cap = 0;
         const uint64_t c2 = n + n / 4 + 1024;
@@ -1846,21 +1818,54 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
         h->snp_cap = bound + bound / 8;
     }
     unsigned long long* totals = h->d_part;                      // events, bytes, kept, error bits, n_keep, -, error word (u32), -
-    unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
-    uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
-    CK(hipMemsetAsync(h->d_part, 0, 64 + ng * 24, h->stream));   // (one clear for the totals, the error word and the groups' sums)
-    TailArgs a{};
+    unsigned long long* part_raw = h->d_part + 8;
+    a = TailArgs{};
     a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
     a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
     a.kl = p->k_left; a.kr = p->k_right; a.max_gap = p->max_gap; a.max_err = p->max_err;
-    a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = tail_err;
+    a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = (uint32_t*)(h->d_part + 6);
+    return E2S_OK;
+}
+// the handle's state from the totals of a tail that has run: events, bytes of the text with ids from first_id, candidates kept, error bits
+static int tail_accept(e2s_ctx* h, const e2s_tail_params* p, uint64_t first_id, uint64_t events, uint64_t bytes, uint64_t kept, uint32_t err) {
+    ev_ms(&h->tm.tail_ms, h->ev[2], h->ev[5]);
+    if (err & E2S_TAILERR_RANK) return fail(h, E2S_ERR_STATE, "GPU tail: a candidate names a read past the last one (the reference repeats stale text: use the host tail)");
+    if (err & E2S_TAILERR_CRASH) return fail(h, E2S_ERR_REF_CRASH, "a right context starts beyond its read (-L longer than the shared context): the reference throws here");     // substr throws in the reference
+    if (first_id && bytes > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
+    h->n_events = events; h->snp_bytes = first_id ? bytes : 0; h->n_variants = kept;
+    h->snp_bytes_at_first = bytes; h->snp_first_id_scan = first_id;      // (e2s_renumber_snp derives other ids' sizes from these)
+    h->variants_valid = true; h->tail_p = *p; h->snp_first_id = first_id;
+    return E2S_OK;
+}
+
+extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_t first_id, uint64_t* n_variants, uint64_t* n_events, uint64_t* snp_bytes) {
+    dbg_entry("e2s_call_variants");
+    if (!h || !p) return E2S_ERR_ARG;
+    if (n_variants) *n_variants = 0;
+    if (n_events) *n_events = 0;
+    if (snp_bytes) *snp_bytes = 0;
+    if (!h->have_reads) return fail(h, E2S_ERR_STATE, "no reads resident (e2s_upload_reads / e2s_attach_reads)");
+    if (!h->stitched) return fail(h, E2S_ERR_STATE, "e2s_find_candidates has not run");
+    if (h->n_cand && !h->cand_dev) return fail(h, E2S_ERR_STATE, "the candidates were delivered to the host: make the reads resident BEFORE e2s_find_candidates");
+    // zero candidates: the reference indexes an empty vector (clust2snp.cpp:531) and dies before creating the file
+    if (h->n_cand == 0) return fail(h, E2S_ERR_REF_CRASH, "no candidate cluster: the reference crashes before it creates the output");
+    int rc = tail_applicable(h, p);
+    if (rc) return rc;
+    CK(hipSetDevice(h->device));
+    const uint64_t n = h->n_cand, ng = (n + 63) / 64;
+    TailArgs a;
+    if ((rc = tail_prepare(h, p, n, a))) return rc;
+    unsigned long long* totals = h->d_part;
+    unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
+    uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
+    CK(hipMemsetAsync(h->d_part, 0, 64 + ng * 24, h->stream));   // (one clear for the totals, the error word and the groups' sums)
     CK(hipEventRecord(h->ev[2], h->stream));
     e2s_launch_consensus(a, h->list_cap, h->stream);
     LCHK("e2s_launch_consensus");
-    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, h->stream);
+    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, nullptr, nullptr, nullptr, nullptr, nullptr, h->stream);
     LCHK("e2s_launch_tail_partials");
     if (first_id) {                                              // first_id 0: the ids come later (e2s_renumber_snp writes the text, once)
-        e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
+        e2s_launch_tail_write(a, part_excl, first_id, nullptr, h->d_snp, h->snp_cap, h->stream);
         LCHK("e2s_launch_tail_write");
     }
     CK(hipEventRecord(h->ev[5], h->stream));
@@ -1868,14 +1873,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     CK(hipMemcpyAsync(mb, totals, 32, hipMemcpyDeviceToHost, h->stream));
     CK(wait_stream(h));
     CK(hipGetLastError());
-    ev_ms(&h->tm.tail_ms, h->ev[2], h->ev[5]);
-    const uint32_t err = (uint32_t)mb[3];
-    if (err & E2S_TAILERR_RANK) return fail(h, E2S_ERR_STATE, "GPU tail: a candidate names a read past the last one (the reference repeats stale text: use the host tail)");
-    if (err & E2S_TAILERR_CRASH) return fail(h, E2S_ERR_REF_CRASH, "a right context starts beyond its read (-L longer than the shared context): the reference throws here");     // substr throws in the reference
-    if (first_id && mb[1] > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
-    h->n_events = mb[0]; h->snp_bytes = first_id ? mb[1] : 0; h->n_variants = mb[2];
-    h->snp_bytes_at_first = mb[1]; h->snp_first_id_scan = first_id;      // (e2s_renumber_snp derives other ids' sizes from these)
-    h->variants_valid = true; h->tail_p = *p; h->snp_first_id = first_id;
+    if ((rc = tail_accept(h, p, first_id, mb[0], mb[1], mb[2], (uint32_t)mb[3]))) return rc;
     if (n_variants) *n_variants = h->n_variants;
     if (n_events) *n_events = h->n_events;
     if (snp_bytes) *snp_bytes = h->snp_bytes;
@@ -1902,7 +1900,7 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
         a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
         a.kl = h->tail_p.k_left; a.kr = h->tail_p.k_right; a.max_gap = h->tail_p.max_gap; a.max_err = h->tail_p.max_err;
         a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = h->d_part + 4; a.err = (uint32_t*)(h->d_part + 6);
-        e2s_launch_tail_write(a, part_excl, first_id, h->d_snp, h->snp_cap, h->stream);
+        e2s_launch_tail_write(a, part_excl, first_id, nullptr, h->d_snp, h->snp_cap, h->stream);
         LCHK("e2s_launch_tail_write");
         CK(hipGetLastError());
         h->snp_bytes = bytes; h->snp_first_id = first_id;
@@ -1930,6 +1928,169 @@ extern "C" int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64
     if (cap_bytes < h->snp_bytes) return fail(h, E2S_ERR_CAPACITY, "`.snp` output too small");
     CK(hipSetDevice(h->device));
     return copy_image_out(h, h->d_snp, h->snp_bytes, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the resident job: one enqueue, one wait (include/e2s_hip.h)
+// ---------------------------------------------------------------------------------------------
+static_assert(E2S_JOB_BLOB == E2S_JOB_BLOB_BYTES && sizeof(e2s_boundary) + sizeof(e2s_scan_stats) <= E2S_JOB_BLOB, "exchange blob");
+static_assert(sizeof(JobDev) <= 256, "job record");
+extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_allgather_fn allgather, void* user, e2s_job_report* rep) {
+    dbg_entry("e2s_resident_job");
+    if (!h || !p) return E2S_ERR_ARG;
+    if (p->world < 1 || p->rank < 0 || p->rank >= p->world || (p->world > 1 && !allgather)) return fail(h, E2S_ERR_ARG, "rank / world / exchange");
+    if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
+    // ---- does this form apply?  (decided before anything is enqueued; otherwise: the stepwise calls)
+    static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
+    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 0;
+    static const int job_env = getenv("E2S_RESIDENT_JOB") ? atoi(getenv("E2S_RESIDENT_JOB")) : 1;
+    const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt | (uintptr_t)h->da) & 15u) == 0;
+    if (!job_env || !fused_env || img_env || p->world > E2S_JOB_MAX_RANKS || h->xb != 1 || h->yb != 4 || !aligned || !h->bwt || !h->pos || !h->da)
+        return fail(h, E2S_ERR_STATE, "resident job: not applicable to this shard (wide or unaligned columns, a missing column, or switched off): use the stepwise calls");
+    const e2s_tail_params tp{p->o.k_left, p->o.k_right, p->o.max_gap, p->o.max_err};
+    int rc = tail_applicable(h, &tp);
+    if (rc) return rc;
+    CK(hipSetDevice(h->device));
+    const e2s_shard_desc& d = h->d;
+    const bool last_rank = d.global_offset + d.n_entries == d.n_total;
+    if (last_rank != (p->rank == p->world - 1)) return fail(h, E2S_ERR_ARG, "rank order must be SA order: only the last rank may hold the EGSA's end");
+    const int W = p->world;
+    // exchange buffers: [my blob][W blobs][my (events, ok)][W pairs]
+    const size_t off_recv = E2S_JOB_BLOB, off_send2 = off_recv + (size_t)W * E2S_JOB_BLOB, off_recv2 = off_send2 + 64, xneed = off_recv2 + (size_t)W * 16 + 64;
+    if (xneed > h->xchg_bytes) {
+        dev_free(h->d_xchg); h->d_xchg = nullptr; h->xchg_bytes = 0;
+        CK(hipMalloc((void**)&h->d_xchg, xneed));
+        h->xchg_bytes = xneed;
+    }
+    uint8_t* const blob = h->d_xchg; uint8_t* const recv = W > 1 ? h->d_xchg + off_recv : blob;
+    unsigned long long* const blob2 = (unsigned long long*)(h->d_xchg + off_send2); unsigned long long* const recv2 = (unsigned long long*)(h->d_xchg + off_recv2);
+    ScanMail* const d_scan_mail = h->d_mail;
+    JobDev* const d_jd = (JobDev*)((uint8_t*)h->d_mail + 1536);
+    uint32_t* const d_cand_bad = h->d_words + 30;
+
+    // ---- scan + pre-filter in one kernel, k_seg_fix (which also leaves this rank's blob)
+    scan_begin(h, p->k, p->min_len);
+    ScanArgs a;
+    scan_args(h, p->k, a);
+    h->pf_armed = true; h->pf_arm_mcov = p->o.mcov_out;
+    if ((rc = seg_scan_launch(h, a, p->min_len, 0, true, blob))) return rc;
+    if (!h->pf_fused) return fail(h, E2S_ERR_STATE, "resident job: the pre-filter did not go into the scan kernel");       // (cannot happen: checked above)
+    // ---- the `.clusters` image: laid out on the second stream right behind k_seg_fix (its offsets), finished from the plan below
+    if (p->want_image) {
+        if ((rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096)))) return rc;
+        if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
+        CK(hipEventRecord(h->ev_img, h->stream));
+        CK(hipStreamWaitEvent(h->stream2, h->ev_img, 0));
+        e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, 0xFFFFFFFFu, (const unsigned long long*)h->d_kept_off, h->d_img, h->img_cap - 2, d_scan_mail, 0, 0, 0, 0, 0,
+                                 h->stream2, pack_blocks_beside());
+        LCHK("e2s_launch_pack_segments");
+    }
+    // ---- exchange 1, then everything the host used to do between the scan and the per-cluster pass, on the device
+    if (W > 1 && allgather(user, blob, recv, E2S_JOB_BLOB, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
+    e2s_c2s_params cp{p->o.nr_reads1, p->o.k_left, p->o.k_right, p->o.mcov_out, p->o.consensus_reads, (int)E2S_MAX_CLUST_LEN, p->min_len};
+    CandArgs ca;
+    if ((rc = cand_args(h, &cp, (uint64_t)p->rank << 40, ca))) return rc;
+    h->variants_valid = false; h->cand_host_valid = false;
+    ca.len_hi_dev = &d_jd->len_hi;
+    if ((rc = cand_buffers(h, ca, std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap)))) return rc;
+    ca.starts = h->d_fl_starts; ca.lens = h->d_fl_lens; ca.n_rec = h->fl_cap;
+    JobPlanArgs pa{};
+    pa.blobs = recv; pa.world = W; pa.rank = p->rank; pa.n_total = d.n_total; pa.k = p->k; pa.lcp_bytes = d.lcp_bytes; pa.mcov = p->o.mcov_out; pa.pval = p->o.pval;
+    pa.min_len = p->min_len; pa.len_lo = ca.len_lo;
+    pa.mail = d_scan_mail; pa.seg = h->seg_args; pa.row_entries = h->seg_row_entries; pa.out = d_jd;
+    pa.fl_starts = (unsigned long long*)h->d_fl_starts; pa.fl_lens = h->d_fl_lens;
+    pa.cand_count = (unsigned long long*)(h->d_scalars + 1); pa.stream8_count = ca.stream8_count; pa.cand_err = h->d_words + 1;
+    pa.ko_cnt = (uint32_t*)h->d_rank; pa.n_ko = e2s_cand_order_buckets(h->cand_cap) + 1u;
+    e2s_launch_job_plan(pa, h->stream);
+    LCHK("e2s_launch_job_plan");
+    if (p->want_image) {                                        // the image finished in place, behind its layout kernel
+        CK(hipEventRecord(h->ev_img, h->stream));
+        CK(hipStreamWaitEvent(h->stream2, h->ev_img, 0));
+        e2s_launch_img_patch_dev(h->d_img, h->img_cap, d_jd, d_scan_mail, p->min_len, h->stream2);
+        CK(hipEventRecord(h->ev_img, h->stream2));
+    }
+    // ---- the per-cluster pass over the clusters the pre-filter let through (the list is on the stream already), SA order, offsets
+    const bool defw = h->xb == 1 && h->yb == 4 && h->zb == 1;
+    h->pf_inflight = false; h->pf_fused = false;
+    e2s_launch_flagged_lists(ca, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
+    LCHK("e2s_launch_flagged_lists");
+    CK(hipEventRecord(h->ev[7], h->stream));
+    if ((rc = cand_order_and_mail(h, ca, d_cand_bad))) return rc;
+    // ---- the tail, sized for the candidate slots there are; the kernels read the count on the device
+    const uint64_t ncap = h->cand_cap, ng = (ncap + 63) / 64;
+    TailArgs ta;
+    if ((rc = tail_prepare(h, &tp, ncap, ta))) return rc;
+    ta.n_cand_dev = (const unsigned long long*)(h->d_scalars + 1);
+    unsigned long long* totals = h->d_part;
+    unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
+    uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
+    CK(hipMemsetAsync(h->d_part, 0, 64 + ng * 24, h->stream));
+    CK(hipEventRecord(h->ev[2], h->stream));
+    e2s_launch_consensus(ta, h->list_cap, h->stream);
+    LCHK("e2s_launch_consensus");
+    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, 1, totals, totals + 4, tail_err, d_jd, blob2, &d_scan_mail->err, &d_jd->stat_rc, d_cand_bad, h->stream);
+    LCHK("e2s_launch_tail_partials");
+    if (W > 1) {                                                // exchange 2: (events, ok) -> this rank's first id
+        if (allgather(user, blob2, recv2, 16, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
+        e2s_launch_job_ids(recv2, W, p->rank, d_jd, h->stream);
+    }
+    e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream);
+    LCHK("e2s_launch_tail_write");
+    CK(hipEventRecord(h->ev[5], h->stream));
+    JobDev* const jdh = (JobDev*)(h->pin_mail + 1536);
+    CK(hipMemcpyAsync(jdh, d_jd, sizeof(JobDev), hipMemcpyDeviceToHost, h->stream));
+    CK(hipMemcpyAsync(h->pin_mail + 1536 + 256, blob2, 16, hipMemcpyDeviceToHost, h->stream));
+    CK(wait_stream(h));                                         // ---- the ONE wait of the step
+    CK(hipGetLastError());
+
+    // ---- the handle's state, as the stepwise calls leave it
+    const ScanMail mail = *(const ScanMail*)h->pin_mail;
+    const JobDev jd = *jdh;
+    const bool my_ok = ((const unsigned long long*)(h->pin_mail + 1536 + 256))[1] != 0ull;
+    bool redo = !my_ok || jd.peers_not_ok || (mail.err & E2S_DEVERR_SEGFULL) || (jd.stat_rc & (E2S_JOBERR_PLAN | E2S_JOBERR_SEEDS));
+    if (mail.err & E2S_DEVERR_SEGFULL) { h->scanned = false; return fail(h, E2S_ERR_CAPACITY, "resident job: a record segment overflowed: run the step through the stepwise calls"); }
+    if ((rc = scan_finish(h, mail, p->min_len))) return rc;
+    if (h->wrap_overflow) redo = true;
+    // e2s_stitch
+    h->plan = jd.plan;
+    h->first_wrapped = jd.first_wrapped != 0;
+    h->n_rec = h->n_ends + jd.plan.n_tail; h->n_closed = h->n_rec;
+    h->img_skip = jd.img_skip; h->compact_valid = false; h->stitched = true;
+    if (p->want_image) {
+        h->img_records = jd.img_records; h->img_total_known = true; h->img_prestitch = false; h->img_stream = h->stream2;
+        h->img_pending = true; h->img_valid = false;
+        if (mail.img_records + jd.n_tail_kept > h->img_cap - 2) { drop_image(h); redo = true; }
+    }
+    // statistics(): the reference's crashes first (every rank sees the same merged statistics)
+    switch (jd.stat_rc & 3u) {
+        case 1: return fail(h, E2S_ERR_REF_CRASH, "no cluster record: the reference divides by zero here");
+        case 2: return fail(h, E2S_ERR_REF_CRASH, "no cluster of length <= 150: the reference divides by zero here");
+        case 3: return fail(h, E2S_ERR_REF_CRASH, "the automatic -c falls outside the histogram: the reference reads past it here");
+        default: break;
+    }
+    // e2s_find_candidates
+    const uint64_t* cm = (const uint64_t*)(h->pin_mail + 3328);
+    const uint64_t count = cm[0], flagged = cm[1];
+    const uint32_t cerr = ((const uint32_t*)(cm + 2))[0] | ((const uint32_t*)(cm + 2))[1];
+    if (cerr & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
+    if ((cerr & E2S_DEVERR_DENSE) || cm[3] * 8 > h->stream_cap_bytes || flagged > h->fl_cap || count > h->cand_cap) redo = true;
+    if (cm[3] * 8 > h->stream_cap_bytes) h->stream_per_cand = ca.stride;
+    if (redo) {
+        // (the stepwise calls size every buffer for what they find; the job fits the next time)
+        h->n_cand = 0; h->variants_valid = false;
+        return fail(h, E2S_ERR_CAPACITY, "resident job: a buffer was too small or the input needs the stepwise path (on some rank of the job): run the step through the stepwise calls");
+    }
+    h->n_flagged = flagged; h->stream8_used = cm[3];
+    cand_accept(h, ca, count, 3);
+    // e2s_call_variants (a shard without candidates has no events; only a JOB without candidates is where the reference crashes)
+    if (count == 0 && W == 1) return fail(h, E2S_ERR_REF_CRASH, "no candidate cluster: the reference crashes before it creates the output");
+    if ((rc = tail_accept(h, &tp, jd.first_id, jd.events, jd.snp_bytes, jd.n_keep, jd.tail_err))) return rc;
+    if (rep) {
+        memset(rep, 0, sizeof(*rep));
+        rep->n_closed = h->n_closed; rep->n_records = p->want_image ? h->img_records : 0; rep->max_clust_length = jd.mcl; rep->n_chunks = 1;
+        rep->n_clust = jd.n_clust; rep->n_bases = jd.n_bases; rep->n_candidates = count; rep->n_variants = h->n_variants; rep->n_events = h->n_events;
+    }
+    return E2S_OK;
 }
 
 extern "C" int e2s_last_timing(e2s_handle h, e2s_timing* out) {

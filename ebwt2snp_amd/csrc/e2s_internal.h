@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/e2s_hip.h"
 
 #define E2S_SCAN_BLOCK 256
 #define E2S_SCAN_ROWS 4
@@ -151,6 +152,7 @@ struct CandArgs {
     uint32_t blocks_hint;                           // k_flagged_lists: blocks to launch (0: 1024)
     uint64_t record_index_base;
     uint32_t* err;
+    const int* len_hi_dev;                          // k_flagged_lists: the upper length bound lives on the device (the resident job: max_clust_length is worked out there)
 };
 
 
@@ -195,14 +197,33 @@ struct TailArgs {
     unsigned long long* part;  // [groups of 64 candidates][3]: events, text bytes without id digits, candidates kept
     unsigned long long* n_keep;
     uint32_t* err;
+    const unsigned long long* n_cand_dev;                        // != nullptr: the number of candidates lives on the device (n_cand = the launch's capacity)
+};
+
+// ---- the resident job without host round trips (e2s_resident_job): what one rank publishes, what the plan kernel derives ----
+#define E2S_JOB_BLOB 1344u                  // e2s_boundary (72 B) + e2s_scan_stats (1248 B), padded: one rank's share of the first all-gather
+#define E2S_JOB_MAX_RANKS 64
+#define E2S_JOBERR_PLAN 16u                 // stat_rc: the gathered descriptors do not fit together
+#define E2S_JOBERR_SEEDS 32u                //          more wrapped clusters than seed slots
+struct JobDev {                             // device copy at d_mail + 1536; reaches the host with the mail
+    e2s_stitch_plan_t plan;                 // this rank's
+    int32_t mcl; uint32_t stat_rc;          // max_clust_length; e2s_auto_len_core's code | E2S_JOBERR_*
+    uint64_t n_clust, n_bases;              // statistics() incl. the H4 double count
+    uint64_t img_records; uint32_t img_skip, n_tail_kept;
+    int32_t len_hi; uint32_t first_wrapped;
+    uint64_t first_id, events, snp_bytes, n_keep;     // the tail: ids from first_id, events of this rank, bytes of its text, candidates kept
+    uint32_t tail_err, peers_not_ok;        // E2S_TAILERR_* of this rank; a rank of the job reported a problem in the second all-gather
+    uint64_t events_before;
 };
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st);
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
-                              unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, hipStream_t st);
+                              unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, JobDev* jd, unsigned long long* blob2,
+                              const uint32_t* bad_a, const uint32_t* bad_b, const uint32_t* bad_c, hipStream_t st);
+void e2s_launch_job_ids(const unsigned long long* blobs2, int world, int rank, JobDev* jd, hipStream_t st);
 void e2s_launch_reads_extent(const uint64_t* rstart, const uint32_t* rlen, uint64_t n_reads, unsigned long long* out, hipStream_t st);   // *out = max(start + len), *out zeroed by the caller
 void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st);
-void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, uint8_t* out, unsigned long long out_cap,
-                           hipStream_t st);
+void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, const unsigned long long* first_id_dev,
+                           uint8_t* out, unsigned long long out_cap, hipStream_t st);
 
 void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st);
 void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
@@ -221,8 +242,9 @@ void e2s_launch_tile_scan(const uint32_t* cnt, unsigned long long* prefix, unsig
 unsigned long long e2s_pack_clusters_blocks(unsigned long long n);
 void e2s_launch_pack_clusters(const unsigned long long* starts, const uint16_t* lens, unsigned long long n, int min_len, uint32_t* cnt,
                               unsigned long long* prefix, uint8_t* out, unsigned long long* total, hipStream_t st);
-void e2s_launch_pack_segments(const SegArgs& a, uint32_t row_entries, uint32_t slot0_b, const unsigned long long* kept_off, uint8_t* out, uint32_t n_tail,
-                              unsigned long long t0, uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st, uint32_t max_blocks);
+void e2s_launch_pack_segments(const SegArgs& a, uint32_t row_entries, uint32_t slot0_b, const unsigned long long* kept_off, uint8_t* out, unsigned long long out_cap,
+                              const ScanMail* mail, uint32_t n_tail, unsigned long long t0, uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st,
+                              uint32_t max_blocks);
 void e2s_launch_seg_patch(SegDesc* d, uint16_t* len0, unsigned long long first_start, uint16_t first_len, hipStream_t st);
 #define E2S_WRAP_CAP 1024
 int  e2s_scan_seg_resident_blocks(int xb);
@@ -231,11 +253,20 @@ int  e2s_scan_seg_fused_resident_blocks();
 void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_t st);
 void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsigned long long* seg_off, unsigned long long* kept_off, uint32_t* err,
                         const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out,
-                        hipStream_t st);
+                        uint8_t* blob, int is_last_rank, int tail_bwt_arg, hipStream_t st);
 int  e2s_scan_img_resident_waves(bool fused);
 void e2s_launch_scan_img(const SegArgs& a, const FilterArgs* f, const ImgArgs& g, hipStream_t st);
 void e2s_launch_scan_img_fin(const SegArgs& a, const ImgArgs& g, uint32_t* flags, uint32_t* tailv, uint32_t* err, const uint8_t* bwt, const void* pos,
                              const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out, hipStream_t st);
+struct JobPlanArgs {
+    const uint8_t* blobs; int world, rank; uint64_t n_total; int k, lcp_bytes, mcov; double pval; int min_len, len_lo;
+    const ScanMail* mail; SegArgs seg; uint32_t row_entries;
+    JobDev* out;
+    unsigned long long* fl_starts; uint16_t* fl_lens;            // seed slots: the head of the flagged list
+    unsigned long long* cand_count; unsigned long long* stream8_count; uint32_t* cand_err; uint32_t* ko_cnt; uint32_t n_ko;
+};
+void e2s_launch_job_plan(const JobPlanArgs& a, hipStream_t st);
+void e2s_launch_img_patch_dev(uint8_t* img, unsigned long long cap, const JobDev* jd, const ScanMail* mail, int min_len, hipStream_t st);
 void e2s_launch_img_patch(uint8_t* img, uint32_t patch_first, unsigned long long first_start, uint16_t first_len, unsigned long long n_at, uint32_t n_tail,
                           unsigned long long t0, uint16_t l0, unsigned long long t1, uint16_t l1, hipStream_t st);
 void e2s_launch_seg_compact(const SegArgs& a, const unsigned long long* seg_off, uint32_t row_entries, unsigned long long* out_starts, uint16_t* out_lens,
@@ -249,7 +280,7 @@ constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
 size_t e2s_cand_order_scratch_bytes(unsigned long long n);
 void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* n_dev,
                              const unsigned long long* stream8_count, uint32_t* off_out, const unsigned long long* fl_count, const uint32_t* err_a,
-                             const uint32_t* err_b, unsigned long long* mail, hipStream_t st);
+                             const uint32_t* err_b, unsigned long long* mail, uint32_t* bad, unsigned long long fl_cap, unsigned long long stream8_cap, hipStream_t st);
 uint32_t e2s_cand_order_buckets(unsigned long long n);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,
                            unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st, bool counts_cleared = false);

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "e2s_internal.h"
+#include "e2s_plan.h"
 #include <type_traits>
 #include "e2s_swar.h"
 
@@ -834,13 +835,24 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
 }
 
 // shard descriptors: begins_inside / open_after / end_before_last and the two last LCP values, evaluated scalar-ly on the
-// boundary entries (one thread)
+// boundary entries (one thread).  The nine entries the rules can look at -- three before the first owned entry to one after it,
+// three before the last owned entry to one after it -- are loaded up front, all in flight together: evaluated lazily the rules
+// were a chain of ~10 dependent global loads (~20 us with every other thread of the block waiting at the barrier).
 __device__ void shard_flags_eval(const void* lcp, u64 n_prov, u64 prov_lo, u64 own_lo, u64 start_hi, u64 end_hi, u32 k, u32 hge, u32 xb,
                                  u32* flags3, u32* tailv2) {
-    auto L = [&](int64_t i) -> u32 {            // local index -> LCP, 0 outside the provided range
+    auto ld = [&](int64_t i) -> u32 {           // local index -> LCP, 0 outside the provided range
         if (i < 0 || i >= (int64_t)n_prov) return 0u;
         const uint8_t* p = (const uint8_t*)lcp + i * xb;
         return xb == 1 ? (u32)p[0] : xb == 2 ? (u32)*(const uint16_t*)p : *(const u32*)p;
+    };
+    const int64_t lo = (int64_t)own_lo, last = (int64_t)start_hi - 1;   // first / last owned entry
+    u32 A[5], B[5];                             // A[j] = L(lo - 3 + j), B[j] = L(last - 3 + j)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { A[j] = ld(lo - 3 + j); B[j] = ld(last - 3 + j); }
+    auto L = [&](int64_t i) -> u32 {
+        if (i >= lo - 3 && i <= lo + 1) return A[i - (lo - 3)];
+        if (i >= last - 3 && i <= last + 1) return B[i - (last - 3)];
+        return ld(i);                           // (never: the rules below reach two entries back and one ahead)
     };
     const bool never = hge == 0;
     auto ge = [&](int64_t i) { return !never && L(i) >= k; };
@@ -862,7 +874,6 @@ __device__ void shard_flags_eval(const void* lcp, u64 n_prov, u64 prov_lo, u64 o
         if (g == 0) return true;
         return !open(i - 1) || endf(i - 1);
     };
-    const int64_t lo = (int64_t)own_lo, last = (int64_t)start_hi - 1;   // last owned entry
     u32 begins_inside = 0, open_after = 0, end_before_last = 0;
     if (start_hi > own_lo) {
         begins_inside = (open(lo) && !startf(lo)) ? 1u : 0u;
@@ -887,9 +898,11 @@ constexpr int SEGFIX_MAX = 8192;             // scan workers (= resident waves: 
 __device__ __forceinline__ u64 seg_range_base(const SegArgs& a, u32 b, u32 row_entries) {      // SA position of the first entry of worker b's range
     return a.prov_lo + ((u64)b * a.tiles_per_block + min(b, a.tiles_rem)) * (u64)row_entries;
 }
+// blob (the resident job): this rank's share of the first all-gather -- e2s_boundary + e2s_scan_stats exactly as e2s_boundary_desc /
+// e2s_scan_stats_desc hand them out (tail_bwt_arg >= 0: the BWT byte of the shard's last entry given by the caller, e2s_upload_lcp).
 __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err,
                                                   const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out,
-                                                  u64* stats_out) {
+                                                  u64* stats_out, uint8_t* blob, int is_last_rank, int tail_bwt_arg) {
     __shared__ u32 s_cnt[SEGFIX_MAX];
     __shared__ u32 s_kept[SEGFIX_MAX];
     __shared__ u64 s_open[SEGFIX_MAX];       // open_start | PASS (inside one cluster throughout) | NONE (closed after the block)
@@ -998,7 +1011,11 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         if (nb == 0 && tid == 0) { seg_off[0] = 0; kept_off[0] = 0; }
     }
     // the statistics: the scan's sums plus the records finished above
-    for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 1024u) stats_out[i] = a.stats[i] + (u64)s_hadj[i];
+    for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 1024u) {
+        const u64 v = a.stats[i] + (u64)s_hadj[i];
+        stats_out[i] = v;
+        if (blob) ((e2s_scan_stats*)(blob + sizeof(e2s_boundary)))->hist.freq[i] = v;
+    }
     __syncthreads();
     if (tid == 0) {
         ScanMail m;
@@ -1064,7 +1081,115 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         }
         stats_out[E2S_MAX_CLUST_LEN_K + 3] = last_len;
         stats_out[E2S_MAX_CLUST_LEN_K + 4] = at;
+        if (blob) {
+            e2s_boundary b = {};
+            b.n_ends = m.total_ends; b.open_start = m.open_start; b.last_end_start = m.last_end_start;
+            b.begins_inside = m.begins_inside; b.open_after = m.open_after;
+            b.pass_through = (m.total_ends == 0 && m.begins_inside && m.open_after) ? 1u : 0u;
+            b.end_before_last = m.end_before_last; b.first_end_low16 = m.first_len_prov & 0xFFFFu;
+            b.tail_lcp = m.tail_lcp; b.tail_prev_lcp = m.tail_prev_lcp;
+            b.tail_bwt = is_last_rank ? (tail_bwt_arg >= 0 ? (u32)tail_bwt_arg : (m.last_bwt & 0xFFu)) : 0u;
+            *(e2s_boundary*)blob = b;
+            e2s_scan_stats* st = (e2s_scan_stats*)(blob + sizeof(e2s_boundary));
+            st->hist.n_records = stats_out[E2S_MAX_CLUST_LEN_K + 1]; st->hist.n_bases = stats_out[E2S_MAX_CLUST_LEN_K + 2];
+            st->last_none = at == NONE ? 1u : 0u;
+            st->last_is_first = (at != NONE && at == m.first_rec_addr) ? 1u : 0u;
+            st->hist.last_len = at == NONE ? 0ull : last_len;
+            st->min_len = a.min_len; st->reserved = 0;
+        }
     }
+}
+
+// ---- the resident job's plan, on the device (e2s_resident_job): every rank's stitch plan and statistics after the stitch, the merged
+// histogram, statistics()'s auto-detection of max_clust_length -- the pure functions of e2s_plan.h, the same code the host entry points
+// run -- and what follows from THIS rank's plan: record 0 finished in its segment, the seed clusters (EOF tail records, wrapped
+// lengths) at the head of the flagged list, the per-cluster pass's counters cleared.  One block.
+__global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
+    __shared__ e2s_boundary s_all[E2S_JOB_MAX_RANKS];
+    __shared__ e2s_stitch_plan_t s_plan[E2S_JOB_MAX_RANKS];
+    __shared__ e2s_stat_delta s_delta[E2S_JOB_MAX_RANKS];
+    __shared__ int s_rc[E2S_JOB_MAX_RANKS];
+    __shared__ uint64_t s_freq[E2S_MAX_CLUST_LEN_K + 1];
+    const u32 tid = threadIdx.x;
+    const int W = a.world;
+    for (u32 i = tid; i < (u32)W * (sizeof(e2s_boundary) / 8); i += 256u) {
+        const u32 r = i / (sizeof(e2s_boundary) / 8), w = i % (sizeof(e2s_boundary) / 8);
+        ((u64*)&s_all[r])[w] = ((const u64*)(a.blobs + (size_t)r * E2S_JOB_BLOB))[w];
+    }
+    // the per-cluster pass's counters (k_cand_init's part)
+    if (tid == 0) { *a.cand_count = 0; *a.stream8_count = 0; *a.cand_err = 0; }
+    for (u32 i = tid; i < a.n_ko; i += 256u) a.ko_cnt[i] = 0u;
+    __syncthreads();
+    auto stats_of = [&](int r) { return (const e2s_scan_stats*)(a.blobs + (size_t)r * E2S_JOB_BLOB + sizeof(e2s_boundary)); };
+    if ((int)tid < W) {
+        s_rc[tid] = e2s_plan_core(s_all, W, (int)tid, a.n_total, a.k, a.lcp_bytes, &s_plan[tid]);
+        e2s_hist_delta_core(stats_of((int)tid), &s_all[tid], &s_plan[tid], &s_delta[tid]);
+    }
+    for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 256u) {
+        u64 f = 0;
+        for (int r = 0; r < W; ++r) f += stats_of(r)->hist.freq[i];
+        s_freq[i] = f;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    JobDev jd = {};
+    u32 rc = 0;
+    u64 nrec = 0, nb = 0, last_len = 0;
+    for (int r = 0; r < W; ++r) {
+        if (s_rc[r]) rc |= E2S_JOBERR_PLAN;
+        const e2s_stat_delta& d = s_delta[r];
+        for (int i = 0; i < d.n; ++i) if (d.len[i] <= E2S_MAX_CLUST_LEN_K) s_freq[d.len[i]] += (u64)(int64_t)d.sign[i];
+        nrec += d.n_records; nb += d.n_bases;
+        if (d.n_records) last_len = d.last_len;
+    }
+    int mcl = 0; uint64_t n_clust = 0, n_bases = 0;
+    rc |= (u32)e2s_auto_len_core(s_freq, nrec, nb, last_len, a.mcov, a.pval, &mcl, &n_clust, &n_bases);
+    const e2s_stitch_plan_t pl = s_plan[a.rank];
+    const ScanMail m = *a.mail;
+    jd.plan = pl; jd.mcl = mcl; jd.n_clust = n_clust; jd.n_bases = n_bases;
+    jd.len_hi = mcl < E2S_MAX_CLUST_LEN_K ? mcl : E2S_MAX_CLUST_LEN_K;
+    // this rank's record 0, finished where it lives (e2s_stitch: k_seg_patch)
+    if (pl.patch_first && m.first_rec_addr != ~0ull) {
+        SegDesc* d = a.seg.desc + m.first_rec_addr / a.seg.seg_cap;
+        d->first_start = pl.first_start; d->first_unknown = 1u; a.seg.lens[m.first_rec_addr] = pl.first_len;
+    }
+    jd.img_skip = (pl.patch_first && (int)pl.first_len < a.min_len) ? 1u : 0u;
+    u32 nt = 0;
+    for (u32 t = 0; t < pl.n_tail; ++t) if ((int)pl.tail_len[t] >= a.min_len) ++nt;
+    jd.n_tail_kept = nt;
+    jd.img_records = m.img_records - jd.img_skip + nt;
+    jd.first_wrapped = (pl.patch_first && m.first_end_pos != ~0ull && m.first_end_pos - pl.first_start + 1 >= 65536ull) ? 1u : 0u;
+    // seed clusters: what the streaming pre-filter cannot see (cand_seeds on the host path)
+    u32 ns = 0;
+    auto seed = [&](u64 st, u32 ln) {
+        if ((int)ln >= a.len_lo && (int)ln <= jd.len_hi) { if (ns < 64u) { a.fl_starts[ns] = st; a.fl_lens[ns] = (uint16_t)ln; } ++ns; }
+    };
+    for (u32 t = 0; t < pl.n_tail; ++t) seed(pl.tail_start[t], pl.tail_len[t]);
+    if (jd.first_wrapped) seed(pl.first_start, pl.first_len);
+    const u32 nw = m.wrap_count < (u32)E2S_WRAP_CAP ? m.wrap_count : (u32)E2S_WRAP_CAP;
+    for (u32 i = 0; i < nw; ++i) {
+        const u64 r = a.seg.wrap_list[i];
+        const u32 b = (u32)(r / a.seg.seg_cap);
+        const SegDesc d = a.seg.desc[b];
+        const u64 st = (r % a.seg.seg_cap == 0 && d.first_unknown) ? d.first_start : seg_range_base(a.seg, b, a.row_entries) + a.seg.starts32[r];
+        seed(st, a.seg.lens[r]);
+    }
+    if (ns > 64u || m.wrap_count > (u32)E2S_WRAP_CAP) rc |= E2S_JOBERR_SEEDS;
+    jd.stat_rc = rc;
+    *a.out = jd;
+}
+void e2s_launch_job_plan(const JobPlanArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_job_plan, dim3(1), dim3(256), 0, st, a); }
+// the image finished in place from the device's plan (e2s_stitch on a pre-stitch image: k_img_patch with host arguments)
+__global__ void k_img_patch_dev(uint8_t* img, u64 cap, const JobDev* jd, const ScanMail* mail, int min_len) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const e2s_stitch_plan_t pl = jd->plan;
+    auto put = [&](u64 idx, u64 st, uint16_t ln) { if (idx < cap) { uint8_t* o = img + idx * 10ull; *(u64_a2*)o = st; *(uint16_t*)(o + 8) = ln; } };
+    if (pl.patch_first && !jd->img_skip) put(0, pl.first_start, pl.first_len);
+    u64 at = mail->img_records;
+    for (u32 t = 0; t < pl.n_tail; ++t) if ((int)pl.tail_len[t] >= min_len) put(at++, pl.tail_start[t], pl.tail_len[t]);
+}
+void e2s_launch_img_patch_dev(uint8_t* img, unsigned long long cap, const JobDev* jd, const ScanMail* mail, int min_len, hipStream_t st) {
+    hipLaunchKernelGGL(k_img_patch_dev, dim3(1), dim3(64), 0, st, img, (u64)cap, jd, mail, min_len);
 }
 
 // The same for the scan that wrote the image itself (ImgArgs): the waves' reports are reduced, the status words give the image's
@@ -1238,8 +1363,11 @@ __global__ __launch_bounds__(256) void k_pack_write(const u64* starts, const uin
 // image leaves in whole 16-byte units -- the first version wrote it 2 bytes per lane and took 4 ms for 1.07 GB.
 // slot0_b: the segment whose record 0 holds slot 0 of the image whatever its length (a shard that begins inside a cluster; ~0: none).
 constexpr int PKS_REC = 1024;                                // records per trip (4 waves x 4 x 64)
-__global__ __launch_bounds__(256) void k_pack_seg_write(SegArgs a, u32 row_entries, u32 slot0_b, const u64* off, uint8_t* out, u32 n_tail, u64 t0, uint16_t l0, u64 t1,
-                                                        uint16_t l1) {
+// mail (the resident job: the host has not seen the scan's mail yet): slot0_b is worked out from it here.  out_cap: records the image
+// has room for -- a trip that would reach past it is dropped (the host sees the size in the mail and reports the overflow).
+__global__ __launch_bounds__(256) void k_pack_seg_write(SegArgs a, u32 row_entries, u32 slot0_b, const u64* off, uint8_t* out, u64 out_cap, const ScanMail* mail,
+                                                        u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1) {
+    if (mail) slot0_b = (mail->begins_inside && mail->total_ends && mail->first_rec_addr != ~0ull) ? (u32)(mail->first_rec_addr / a.seg_cap) : 0xFFFFFFFFu;
     __shared__ __attribute__((aligned(16))) uint8_t s_img[PKS_REC * 10 + 32];
     __shared__ u32 s_w[4];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1283,6 +1411,7 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(SegArgs a, u32 row_entri
         // the 16-byte units [D & ~15, ...) that the trip's bytes [D, D + 10 m) touch: whole units as one store, the two partial ones by 2 bytes
         const u32 nbytes = m * 10u, units = (sh + nbytes + 15u) >> 4;
         uint8_t* const g0 = out + (D & ~15ull);
+        if (done + m <= out_cap)
         for (u32 u = tid; u < units; u += 256u) {
             const u32 lo = u << 4, hi = lo + 16u;
             if (lo >= sh && hi <= sh + nbytes) *(uint4*)(g0 + lo) = *(const uint4*)(s_img + lo);
@@ -1292,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(SegArgs a, u32 row_entri
         __syncthreads();
     }
     }
-    if (blockIdx.x == (n_seg - 1) % gridDim.x && tid == 0) {     // the records the EOF rule adds (e2s_stitch_plan)
+    if (blockIdx.x == (n_seg - 1) % gridDim.x && tid == 0 && off[n_seg] + n_tail <= out_cap) {     // the records the EOF rule adds (e2s_stitch_plan)
         u64 at = off[n_seg];
         const u64 ts[2] = {t0, t1}; const uint16_t tl[2] = {l0, l1};
         for (u32 t = 0; t < n_tail; ++t) if ((int)tl[t] >= min_len) {
@@ -1302,13 +1431,13 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(SegArgs a, u32 row_entri
         }
     }
 }
-void e2s_launch_pack_segments(const SegArgs& a, u32 row_entries, u32 slot0_b, const u64* kept_off, uint8_t* out, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1,
-                              hipStream_t st, u32 max_blocks) {
+void e2s_launch_pack_segments(const SegArgs& a, u32 row_entries, u32 slot0_b, const u64* kept_off, uint8_t* out, u64 out_cap, const ScanMail* mail, u32 n_tail, u64 t0,
+                              uint16_t l0, u64 t1, uint16_t l1, hipStream_t st, u32 max_blocks) {
     // max_blocks (0: one block per segment): an experiment knob -- the pack running beside the per-cluster pass throttled to a few blocks
     // per CU, so that it does not saturate HBM under that latency-bound kernel (no net gain measured: e2s_capi.hip, pack_blocks_beside)
     const u32 n_seg = a.n_blocks;
     const u32 grid = max_blocks && max_blocks < n_seg ? max_blocks : n_seg;
-    hipLaunchKernelGGL(k_pack_seg_write, dim3(grid), dim3(256), 0, st, a, row_entries, slot0_b, kept_off, out, n_tail, t0, l0, t1, l1);
+    hipLaunchKernelGGL(k_pack_seg_write, dim3(grid), dim3(256), 0, st, a, row_entries, slot0_b, kept_off, out, out_cap, mail, n_tail, t0, l0, t1, l1);
 }
 // e2s_stitch on the segments: record 0 of a shard that began inside a cluster gets its start and length from the stitch plan
 __global__ void k_seg_patch(SegDesc* d, uint16_t* len0, u64 first_start, uint16_t first_len) {
@@ -1805,6 +1934,7 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
         if (tid == 0) { s_nstage = 0; s_used8 = 0; }
         __syncthreads();
     };
+    if (a.len_hi_dev) a.len_hi = *a.len_hi_dev;                  // (the resident job: max_clust_length was worked out on the device)
     const u64 n = min((u64)*n_dev, a.n_rec);                     // this launch handles list entries [*lo_dev, *n_dev)
     const u64 first = lo_dev ? (u64)*lo_dev : 0ull;
     const u64 per_round = (u64)gridDim.x * 4;
@@ -1920,20 +2050,24 @@ __global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, const unsign
     for (u32 t = lo; t < hi; ++t) r += gkeys[t] < k ? 1u : 0u;
     order[r] = gidx[j];
 }
+// bad (the resident job): 1 where the pass overflowed a buffer or left an error bit -- what the host checks in the mail, for the tail's kernels
 __global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
-                               const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail) {
+                               const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, u32* bad, u64 fl_cap, u64 stream8_cap) {
+    const u64 cap = n;
     n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) off_out[i] = slot_off8[order[i]];
     else if (i == n) {
         off_out[n] = (u32)*stream8_count;
         if (mail) { mail[0] = *n_dev; mail[1] = *fl_count; mail[2] = (unsigned long long)*err_a | ((unsigned long long)*err_b << 32); mail[3] = *stream8_count; }
+        if (bad) *bad = (*n_dev > cap || *fl_count > fl_cap || *stream8_count > stream8_cap || *err_a != 0u || *err_b != 0u) ? 1u : 0u;
     }
 }
 void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
-                             const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, hipStream_t st) {
+                             const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, u32* bad, u64 fl_cap, u64 stream8_cap,
+                             hipStream_t st) {
     hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out,
-                       fl_count, err_a, err_b, mail);
+                       fl_count, err_a, err_b, mail, bad, fl_cap, stream8_cap);
 }
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
 // ~2 keys per bucket up to 2^14 buckets, then up to 32 per bucket before the table grows again: the single-block scan of the counts
@@ -2037,8 +2171,9 @@ void e2s_launch_scan_img_fin(const SegArgs& a, const ImgArgs& g, u32* flags, u32
     hipLaunchKernelGGL(k_scan_img_fin, dim3(1), dim3(1024), 0, st, a, g, flags, tailv, err, bwt, pos, da, xb, yb, zb, out, (u64*)stats_out);
 }
 void e2s_launch_seg_fix(const SegArgs& a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err, const uint8_t* bwt, const void* pos,
-                        const void* da, int xb, int yb, int zb, ScanMail* out, u64* stats_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, kept_off, err, bwt, pos, da, xb, yb, zb, out, stats_out);
+                        const void* da, int xb, int yb, int zb, ScanMail* out, u64* stats_out, uint8_t* blob, int is_last_rank, int tail_bwt_arg, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, kept_off, err, bwt, pos, da, xb, yb, zb, out, stats_out, blob, is_last_rank,
+                       tail_bwt_arg);
 }
 void e2s_launch_seg_compact(const SegArgs& a, const u64* seg_off, u32 row_entries, u64* out_starts, uint16_t* out_lens, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_compact, dim3(a.n_blocks), dim3(256), 0, st, a, seg_off, row_entries, out_starts, out_lens);

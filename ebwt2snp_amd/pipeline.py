@@ -1,8 +1,8 @@
 """The resident job -- both tools back to back on an EGSA shard that already lives in HBM -- as one function over the C ABI.
 What bench.py times and what the full-size parity tests run; the executables do the same through files.
 
-  arm -> scan (+ pre-filter in the same kernel) -> [descriptor exchange] -> stitch -> statistics -> `.clusters` image (second
-  stream) || per-cluster pass -> tail on the GPU (consensus, distance, KisSNP2 text) -> both images in HBM
+  arm -> scan (+ pre-filter in the same kernel) -> `.clusters` image laid out on the second stream || [descriptor exchange] -> stitch
+  (finishes the image in place) -> statistics -> per-cluster pass -> tail on the GPU (consensus, distance, KisSNP2 text) -> both images in HBM
 """
 import ctypes
 
@@ -16,16 +16,41 @@ def exchange_none(blob):
 
 
 def resident_job(h, n1, n_total, rank=0, world=1, exchange=exchange_none, k=16, min_len=2, mcov=5, pval=0.99, k_left=31, k_right=30,
-                 max_gap=10, max_err=2, cons_reads=20, fused=True, tail=True, pack=True, ids_exchange=None, tick=None, prefilter=None):
-    """One pass of the hot path.  exchange(blob) -> list of every rank's blob (ONE all-gather of descriptor + statistics);
-    ids_exchange(n_events) -> events on the ranks before this one (a second, 8-byte exchange: `.snp` ids are sequential).
+                 max_gap=10, max_err=2, cons_reads=20, fused=True, tail=True, pack=True, ids_exchange=None, tick=None, prefilter=None,
+                 allgather=None, native=None):
+    """One pass of the hot path.  Two forms:
+      * e2s_resident_job (native: the whole step enqueued at once, plans and statistics on the device, ONE wait) -- taken when the
+        pre-filter goes into the scan kernel, both outputs are wanted and, for world > 1, `allgather(d_send, d_recv, nbytes, stream)` is
+        given (an all-gather ENQUEUED on the handle's stream); where it does not apply (ERR_STATE) or a buffer was too small
+        (ERR_CAPACITY, on every rank alike) the step runs through
+      * the stepwise calls: exchange(blob) -> list of every rank's blob (ONE all-gather of descriptor + statistics);
+        ids_exchange(n_events) -> events on the ranks before this one (a second, 16-byte exchange: `.snp` ids are sequential).
     prefilter: "arm" (inside the scan kernel; = fused), "begin" (a kernel of its own right after the scan; = not fused) or
     "inside" (run by e2s_find_candidates).  Returns a dict of counts; the images stay in HBM (h.clusters_image(), h.fetch_snp())."""
     t = tick or (lambda name: None)
     prefilter = prefilter or ("arm" if fused else "begin")
+    if native is None:
+        native = prefilter == "arm" and tail and pack and (world == 1 or allgather is not None)
+    if native:
+        try:
+            rep = capi.resident_job(h, n1, rank, world, allgather, k, min_len, mcov, pval, k_left, k_right, max_gap, max_err, cons_reads, want_image=pack)
+            t("native job")
+            out = dict(n_ends=h.boundary().n_ends, n_cand=rep.n_candidates, mcl=rep.max_clust_length, n_clust=rep.n_clust, n_variants=rep.n_variants,
+                       n_events=rep.n_events, snp_bytes=h.snp_size() if rep.n_candidates else 0, native=True)
+            if pack:
+                _, nrec = h.clusters_image()
+                out["n_records"] = nrec
+                t("image")
+            return out
+        except capi.E2SError as ex:
+            if ex.code not in (3, 4):                              # ERR_STATE: does not apply here; ERR_CAPACITY: every rank reruns stepwise
+                raise
+            t("native job (redo stepwise)")
     if prefilter == "arm":
         h.prefilter_arm(mcov)                                      # the pre-filter runs inside the scan kernel
     h.cluster_scan(k, min_len, 0)                                  # scan + statistics of the shard's own records
+    if pack:
+        h.pack_clusters(async_=True)                               # the `.clusters` image laid out on the second stream beside everything below
     if prefilter == "begin":
         h.prefilter_begin(mcov, min_len)                           # ... or beside the exchange and the statistics below
     t("scan")
@@ -46,8 +71,6 @@ def resident_job(h, n1, n_total, rank=0, world=1, exchange=exchange_none, k=16, 
         t("stitch")
         mcl, n_clust, _ = capi.auto_max_clust_length([h.hist()], mcov, pval)
     t("hist")
-    if pack:
-        h.pack_clusters(async_=True)                               # the `.clusters` image, on the second stream beside the next phase
     prm = capi.C2SParams(n1, k_left, k_right, mcov, cons_reads, mcl, min_len)
     ncand = h.find_candidates(prm, rank << 40)
     t("candidates")

@@ -340,6 +340,34 @@ int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, co
 /* host-only: the partial statistics of packed 10-byte records (clust2snp.cpp:889-909 without the H4 double count), worker threads */
 int e2s_hist_of_records(const void* recs, uint64_t n_records, e2s_hist* out);
 
+/* ---- both tools back to back on a RESIDENT shard, without a host round trip between the phases ------------------------------
+ * cluster_lm (ebwt2clust.cpp:68-139) with clust2snp's pre-filter in the same kernel -> [exchange of the ranks' descriptors + statistics]
+ * -> the boundary stitch and statistics() (clust2snp.cpp:877-966) -> find_events / find_variants (clust2snp.cpp:788-857, 367-500) ->
+ * extract_variants + distance + to_file on the GPU (clust2snp.cpp:505-780) with ids sequential over the ranks -- ALL ENQUEUED AT ONCE:
+ * the stitch plans, the merged statistics and max_clust_length are worked out on the device by the very functions behind
+ * e2s_stitch_plan / e2s_hist_after_stitch / e2s_auto_max_clust_length (csrc/e2s_plan.h: one source, host and device), every kernel
+ * takes its counts from device memory, and the host waits once, at the end.  What e2s_cluster_scan + e2s_stitch +
+ * e2s_find_candidates + e2s_call_variants (+ e2s_pack_clusters) leave behind is left behind here too: images, counts, timings.
+ *
+ * The two exchanges are the caller's: an all-gather of bytes_per_rank bytes from d_send into d_recv (rank order), ENQUEUED on the
+ * given HIP stream (hipStream_t as void*) -- ncclAllGather, or anything that orders itself after the stream's work.  world == 1:
+ * never called.  The first carries E2S_JOB_BLOB_BYTES per rank (e2s_boundary + e2s_scan_stats), the second 16 (events, ok).
+ * Every rank of a job must call e2s_resident_job with the same options.
+ * Returns E2S_ERR_STATE, BEFORE anything is enqueued, where this form does not apply (the reads not resident, -L outside 1..64, wide or
+ * unaligned columns: conditions the ranks of a job share): use the stepwise calls.  E2S_ERR_CAPACITY after the whole step has run --
+ * on EVERY rank of the job, they tell each other in the second exchange -- where a buffer of some rank was too small or its input
+ * needs a path only the stepwise calls have: run the step again through them (they size the buffers; later jobs fit).             */
+#define E2S_JOB_BLOB_BYTES 1344
+typedef int (*e2s_allgather_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
+typedef struct {
+    int32_t k, min_len;                  /* ebwt2clust -k -m */
+    int32_t rank, world;                 /* this shard's place in SA order; world <= 64 */
+    e2s_c2s_options o;                   /* clust2snp's options */
+    int32_t want_image;                  /* != 0: the `.clusters` image is laid out on the second stream beside the rest (e2s_clusters_image waits for it) */
+    int32_t reserved;
+} e2s_resident_params;
+int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_allgather_fn allgather, void* user, e2s_job_report* rep);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 typedef struct {
     float scan_ms;        /* e2s_cluster_scan kernels incl. the statistics (HIP events on the handle's stream) */

@@ -12,7 +12,7 @@ for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", ""), "dma"))
 ev.sort()
-idx = [i for i, e in enumerate(ev) if e[2].startswith("k_scan_seg<1, true>")]
+idx = [i for i, e in enumerate(ev) if e[2].startswith("k_scan_seg<1, true")]
 i0, i1 = idx[which], idx[which + 1]
 t0 = ev[i0][0]
 last_end = t0
