@@ -654,7 +654,7 @@ static void scan_begin(e2s_ctx* h, int k, int min_len) {
 
 // the segmented scan: wave workers over contiguous tile ranges.  seg_cap 0 = the usual estimate; first: the armed pre-filter is taken along.
 // blob != nullptr: k_seg_fix also leaves this rank's share of the job's first all-gather there.
-static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t seg_cap, bool first, uint8_t* blob) {
+static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t seg_cap, bool first, uint8_t* blob, bool copy_mail = true) {
     int rc;
     const e2s_shard_desc& d = h->d;
     const uint64_t row_entries = (uint64_t)64 * (E2S_SPAN_BYTES / h->xb);   // entries per wave-tile (64 lanes x 64 B)
@@ -733,7 +733,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
                        h->zb, h->d_mail, (unsigned long long*)dh, blob, last_rank ? 1 : 0, h->tail_bwt_given ? (int)h->tail_bwt_arg : -1, h->stream);
     CK(hipEventRecord(h->ev[1], h->stream));
     LCHK("e2s_launch_seg_fix");
-    CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
+    if (copy_mail) CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
     h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
     h->seg_args = sa; h->seg_row_entries = (uint32_t)row_entries;
     return E2S_OK;
@@ -1501,7 +1501,7 @@ static int cand_record_pass(e2s_ctx* h, const CandArgs& a, const e2s_c2s_params*
 
 // SA order and offsets follow without a host round trip (the kernels read the candidate count on the device); the last kernel
 // writes counts and error words into the pinned mailbox
-static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nullptr) {
+static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nullptr, unsigned long long* zero = nullptr, uint64_t n_zero = 0) {
     const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
     e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
                           h->d_order, h->stream, true);
@@ -1510,7 +1510,7 @@ static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nu
     CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
     e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
                             (uint32_t*)(a.host_stream + h->stream_ord_off), (const unsigned long long*)(h->d_scalars + 2), h->d_words + 1,
-                            h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 3328), bad, h->fl_cap, a.stream8_cap, h->stream);
+                            h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 3328), bad, h->fl_cap, a.stream8_cap, zero, n_zero, h->stream);
     LCHK("e2s_launch_cand_offsets");
     return E2S_OK;
 }
@@ -1973,7 +1973,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     ScanArgs a;
     scan_args(h, p->k, a);
     h->pf_armed = true; h->pf_arm_mcov = p->o.mcov_out;
-    if ((rc = seg_scan_launch(h, a, p->min_len, 0, true, blob))) return rc;
+    if ((rc = seg_scan_launch(h, a, p->min_len, 0, true, blob, false))) return rc;      // (the mail travels once, at the end, with everything else)
     if (!h->pf_fused) return fail(h, E2S_ERR_STATE, "resident job: the pre-filter did not go into the scan kernel");       // (cannot happen: checked above)
     // ---- the `.clusters` image: laid out on the second stream right behind k_seg_fix (its offsets), finished from the plan below
     if (p->want_image) {
@@ -2015,7 +2015,6 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     e2s_launch_flagged_lists(ca, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
     LCHK("e2s_launch_flagged_lists");
     CK(hipEventRecord(h->ev[7], h->stream));
-    if ((rc = cand_order_and_mail(h, ca, d_cand_bad))) return rc;
     // ---- the tail, sized for the candidate slots there are; the kernels read the count on the device
     const uint64_t ncap = h->cand_cap, ng = (ncap + 63) / 64;
     TailArgs ta;
@@ -2024,7 +2023,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     unsigned long long* totals = h->d_part;
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
-    CK(hipMemsetAsync(h->d_part, 0, 64 + ng * 24, h->stream));
+    if ((rc = cand_order_and_mail(h, ca, d_cand_bad, h->d_part, 8 + ng * 3))) return rc;      // (the last kernel of the pass also clears the tail's sums)
     CK(hipEventRecord(h->ev[2], h->stream));
     e2s_launch_consensus(ta, h->list_cap, h->stream);
     LCHK("e2s_launch_consensus");
@@ -2037,16 +2036,16 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream);
     LCHK("e2s_launch_tail_write");
     CK(hipEventRecord(h->ev[5], h->stream));
+    static_assert(256 + (E2S_MAX_CLUST_LEN + 5) * 8 <= 1536, "the scan's mail and statistics end before the job record");
     JobDev* const jdh = (JobDev*)(h->pin_mail + 1536);
-    CK(hipMemcpyAsync(jdh, d_jd, sizeof(JobDev), hipMemcpyDeviceToHost, h->stream));
-    CK(hipMemcpyAsync(h->pin_mail + 1536 + 256, blob2, 16, hipMemcpyDeviceToHost, h->stream));
+    CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 1536 + sizeof(JobDev), hipMemcpyDeviceToHost, h->stream));    // the scan's mail + statistics + the job record: one copy
     CK(wait_stream(h));                                         // ---- the ONE wait of the step
     CK(hipGetLastError());
 
     // ---- the handle's state, as the stepwise calls leave it
     const ScanMail mail = *(const ScanMail*)h->pin_mail;
     const JobDev jd = *jdh;
-    const bool my_ok = ((const unsigned long long*)(h->pin_mail + 1536 + 256))[1] != 0ull;
+    const bool my_ok = jd.my_ok != 0u;
     bool redo = !my_ok || jd.peers_not_ok || (mail.err & E2S_DEVERR_SEGFULL) || (jd.stat_rc & (E2S_JOBERR_PLAN | E2S_JOBERR_SEEDS));
     if (mail.err & E2S_DEVERR_SEGFULL) { h->scanned = false; return fail(h, E2S_ERR_CAPACITY, "resident job: a record segment overflowed: run the step through the stepwise calls"); }
     if ((rc = scan_finish(h, mail, p->min_len))) return rc;
@@ -2089,6 +2088,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
         memset(rep, 0, sizeof(*rep));
         rep->n_closed = h->n_closed; rep->n_records = p->want_image ? h->img_records : 0; rep->max_clust_length = jd.mcl; rep->n_chunks = 1;
         rep->n_clust = jd.n_clust; rep->n_bases = jd.n_bases; rep->n_candidates = count; rep->n_variants = h->n_variants; rep->n_events = h->n_events;
+        rep->snp_bytes = h->snp_bytes; rep->n_ends = h->n_ends;
     }
     return E2S_OK;
 }

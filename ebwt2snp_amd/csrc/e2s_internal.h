@@ -214,6 +214,7 @@ struct JobDev {                             // device copy at d_mail + 1536; rea
     uint64_t first_id, events, snp_bytes, n_keep;     // the tail: ids from first_id, events of this rank, bytes of its text, candidates kept
     uint32_t tail_err, peers_not_ok;        // E2S_TAILERR_* of this rank; a rank of the job reported a problem in the second all-gather
     uint64_t events_before;
+    uint32_t my_ok, reserved;               // this rank's verdict on its own step (what it sends in the second all-gather)
 };
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st);
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
@@ -280,7 +281,8 @@ constexpr uint32_t E2S_KO_MAX_BUCKETS = 1u << 18;
 size_t e2s_cand_order_scratch_bytes(unsigned long long n);
 void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* n_dev,
                              const unsigned long long* stream8_count, uint32_t* off_out, const unsigned long long* fl_count, const uint32_t* err_a,
-                             const uint32_t* err_b, unsigned long long* mail, uint32_t* bad, unsigned long long fl_cap, unsigned long long stream8_cap, hipStream_t st);
+                             const uint32_t* err_b, unsigned long long* mail, uint32_t* bad, unsigned long long fl_cap, unsigned long long stream8_cap,
+                             unsigned long long* zero, unsigned long long n_zero, hipStream_t st);
 uint32_t e2s_cand_order_buckets(unsigned long long n);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,
                            unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st, bool counts_cleared = false);

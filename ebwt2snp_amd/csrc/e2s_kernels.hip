@@ -960,6 +960,7 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
     };
     // record 0 of a block whose cluster began in an earlier block: start and length -- and whether append_entry keeps it.  The one
     // that began in an earlier SHARD stays provisional (e2s_stitch finishes it) and keeps a slot in the image whatever its length.
+    u64 t_nadj = 0, t_badj = 0;
 #pragma unroll
     for (int q = 0; q < DPT; ++q) {
         const u32 b = tid + (u32)q * 1024u;
@@ -977,17 +978,24 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
             slot = (int)len16 >= a.min_len;
         }
         if ((int)len16 >= a.min_len) {                          // what the statistics count: the length as stored
-            atomicAdd((unsigned long long*)&s_nadj[0], 1ull); atomicAdd((unsigned long long*)&s_nadj[1], (unsigned long long)len16);
+            ++t_nadj; t_badj += (u64)len16;
             if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&s_hadj[len16], 1u);
         }
         if (slot) s_kept[b] += 1u;                              // (this thread owns block b)
     }
+    // (one LDS atomic per wave: ~3000 of them on one address were a third of this kernel's time)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { t_nadj += __shfl_xor((unsigned long long)t_nadj, o); t_badj += __shfl_xor((unsigned long long)t_badj, o); }
+    if ((tid & 63u) == 0 && t_nadj) { atomicAdd((unsigned long long*)&s_nadj[0], (unsigned long long)t_nadj); atomicAdd((unsigned long long*)&s_nadj[1], (unsigned long long)t_badj); }
     __syncthreads();
     // exclusive scans of the raw and the kept counts: each thread owns a contiguous chunk
     const u32 per = (nb + 1023) / 1024, lo = min(nb, tid * per), hi = min(nb, lo + per);
-    u32 sum = 0, ksum = 0;
-    for (u32 b = lo; b < hi; ++b) { sum += s_cnt[b]; ksum += s_kept[b]; if (s_kept[b]) atomicMax(&s_lastk, b + 1u); }
+    u32 sum = 0, ksum = 0, lastk = 0;
+    for (u32 b = lo; b < hi; ++b) { sum += s_cnt[b]; ksum += s_kept[b]; if (s_kept[b]) lastk = b + 1u; }
     s_part[tid] = sum; s_kpart[tid] = ksum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lastk = max(lastk, (u32)__shfl_xor((int)lastk, o));
+    if ((tid & 63u) == 0 && lastk) atomicMax(&s_lastk, lastk);
     __syncthreads();
     if (tid < 64) {                           // 1024 partials: 16 per lane, wave scan
         u32 loc = 0, kloc = 0;
@@ -1105,30 +1113,37 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
 // run -- and what follows from THIS rank's plan: record 0 finished in its segment, the seed clusters (EOF tail records, wrapped
 // lengths) at the head of the flagged list, the per-cluster pass's counters cleared.  One block.
 __global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
+    // the gathered blobs and the scan's mail are staged in LDS by all threads at once (ONE global round trip); everything below reads LDS
+    __shared__ __attribute__((aligned(16))) uint8_t s_blob[E2S_JOB_MAX_RANKS * E2S_JOB_BLOB];
     __shared__ e2s_boundary s_all[E2S_JOB_MAX_RANKS];
     __shared__ e2s_stitch_plan_t s_plan[E2S_JOB_MAX_RANKS];
     __shared__ e2s_stat_delta s_delta[E2S_JOB_MAX_RANKS];
     __shared__ int s_rc[E2S_JOB_MAX_RANKS];
     __shared__ uint64_t s_freq[E2S_MAX_CLUST_LEN_K + 1];
+    __shared__ ScanMail s_mail;
     const u32 tid = threadIdx.x;
     const int W = a.world;
-    for (u32 i = tid; i < (u32)W * (sizeof(e2s_boundary) / 8); i += 256u) {
-        const u32 r = i / (sizeof(e2s_boundary) / 8), w = i % (sizeof(e2s_boundary) / 8);
-        ((u64*)&s_all[r])[w] = ((const u64*)(a.blobs + (size_t)r * E2S_JOB_BLOB))[w];
-    }
-    // the per-cluster pass's counters (k_cand_init's part)
-    if (tid == 0) { *a.cand_count = 0; *a.stream8_count = 0; *a.cand_err = 0; }
+    static_assert(E2S_JOB_BLOB % 16 == 0 && sizeof(ScanMail) % 8 == 0, "staging by words");
+    for (u32 i = tid; i < (u32)W * (E2S_JOB_BLOB / 16u); i += 256u) ((uint4*)s_blob)[i] = ((const uint4*)a.blobs)[i];
+    if (tid < sizeof(ScanMail) / 8) ((u64*)&s_mail)[tid] = ((const u64*)a.mail)[tid];
+    // the per-cluster pass's counters (k_cand_init's part; the ordering pass's bucket counts are left clean by k_cand_offsets)
+    if (tid == 255) { *a.cand_count = 0; *a.stream8_count = 0; *a.cand_err = 0; }
     for (u32 i = tid; i < a.n_ko; i += 256u) a.ko_cnt[i] = 0u;
     __syncthreads();
-    auto stats_of = [&](int r) { return (const e2s_scan_stats*)(a.blobs + (size_t)r * E2S_JOB_BLOB + sizeof(e2s_boundary)); };
+    for (u32 i = tid; i < (u32)W * (sizeof(e2s_boundary) / 8); i += 256u) {
+        const u32 r = i / (sizeof(e2s_boundary) / 8), w = i % (sizeof(e2s_boundary) / 8);
+        ((u64*)&s_all[r])[w] = ((const u64*)(s_blob + (size_t)r * E2S_JOB_BLOB))[w];
+    }
+    __syncthreads();
+    auto stats_of = [&](int r) { return (const e2s_scan_stats*)(s_blob + (size_t)r * E2S_JOB_BLOB + sizeof(e2s_boundary)); };
     if ((int)tid < W) {
         s_rc[tid] = e2s_plan_core(s_all, W, (int)tid, a.n_total, a.k, a.lcp_bytes, &s_plan[tid]);
         e2s_hist_delta_core(stats_of((int)tid), &s_all[tid], &s_plan[tid], &s_delta[tid]);
     }
-    for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 256u) {
+    if (tid >= 64u && tid - 64u <= (u32)E2S_MAX_CLUST_LEN_K) {                       // (the waves after the first: the first one is busy with the plans)
         u64 f = 0;
-        for (int r = 0; r < W; ++r) f += stats_of(r)->hist.freq[i];
-        s_freq[i] = f;
+        for (int r = 0; r < W; ++r) f += stats_of(r)->hist.freq[tid - 64u];
+        s_freq[tid - 64u] = f;
     }
     __syncthreads();
     if (tid != 0) return;
@@ -1145,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
     int mcl = 0; uint64_t n_clust = 0, n_bases = 0;
     rc |= (u32)e2s_auto_len_core(s_freq, nrec, nb, last_len, a.mcov, a.pval, &mcl, &n_clust, &n_bases);
     const e2s_stitch_plan_t pl = s_plan[a.rank];
-    const ScanMail m = *a.mail;
+    const ScanMail& m = s_mail;
     jd.plan = pl; jd.mcl = mcl; jd.n_clust = n_clust; jd.n_bases = n_bases;
     jd.len_hi = mcl < E2S_MAX_CLUST_LEN_K ? mcl : E2S_MAX_CLUST_LEN_K;
     // this rank's record 0, finished where it lives (e2s_stitch: k_seg_patch)
@@ -2052,10 +2067,12 @@ __global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, const unsign
 }
 // bad (the resident job): 1 where the pass overflowed a buffer or left an error bit -- what the host checks in the mail, for the tail's kernels
 __global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
-                               const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, u32* bad, u64 fl_cap, u64 stream8_cap) {
+                               const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, u32* bad, u64 fl_cap, u64 stream8_cap,
+                               unsigned long long* zero, u64 n_zero) {
     const u64 cap = n;
     n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (u64 z = i; z < n_zero; z += (u64)gridDim.x * blockDim.x) zero[z] = 0ull;     // (the resident job: the tail's sums, cleared here instead of by a memset)
     if (i < n) off_out[i] = slot_off8[order[i]];
     else if (i == n) {
         off_out[n] = (u32)*stream8_count;
@@ -2065,9 +2082,9 @@ __global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, co
 }
 void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
                              const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, u32* bad, u64 fl_cap, u64 stream8_cap,
-                             hipStream_t st) {
+                             unsigned long long* zero, u64 n_zero, hipStream_t st) {
     hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out,
-                       fl_count, err_a, err_b, mail, bad, fl_cap, stream8_cap);
+                       fl_count, err_a, err_b, mail, bad, fl_cap, stream8_cap, zero, n_zero);
 }
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
 // ~2 keys per bucket up to 2^14 buckets, then up to 32 per bucket before the table grows again: the single-block scan of the counts

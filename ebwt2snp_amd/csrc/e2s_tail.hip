@@ -412,7 +412,9 @@ __global__ __launch_bounds__(1024) void k_tail_partials(const unsigned long long
             totals[3] = (u64)*err;
             if (jd) {
                 jd->events = re; jd->snp_bytes = totals[1]; jd->n_keep = k; jd->tail_err = *err; jd->first_id = first_id; jd->events_before = 0; jd->peers_not_ok = 0;
-                if (blob2) { blob2[0] = re; blob2[1] = (*err == 0u && *bad_a == 0u && *bad_b == 0u && *bad_c == 0u) ? 1ull : 0ull; }
+                const u32 ok = (*err == 0u && *bad_a == 0u && *bad_b == 0u && *bad_c == 0u) ? 1u : 0u;
+                jd->my_ok = ok;
+                if (blob2) { blob2[0] = re; blob2[1] = (u64)ok; }
             }
         }
     }
