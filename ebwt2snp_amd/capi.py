@@ -437,21 +437,25 @@ def resident_job(h, n1, rank=0, world=1, allgather=None, k=16, min_len=2, mcov=5
     """e2s_resident_job on Handle h: the whole step enqueued at once, one wait.  allgather(d_send, d_recv, nbytes_per_rank, stream) -> None
     enqueues an all-gather on the given HIP stream (world > 1).  Returns JobReport; raises E2SError (ERR_STATE: not applicable, nothing ran;
     ERR_CAPACITY: rerun through the stepwise calls)."""
-    L = lib()
-    L.e2s_resident_job.argtypes = [C.c_void_p, C.POINTER(ResidentParams), ALLGATHER, C.c_void_p, C.POINTER(JobReport)]
-    p = ResidentParams(k, min_len, rank, world, C2SOptions(n1, k_left, k_right, mcov, cons_reads, max_gap, max_err, pval), 1 if want_image else 0, 0)
-    rep = JobReport()
+    key = (n1, rank, world, allgather, k, min_len, mcov, pval, k_left, k_right, max_gap, max_err, cons_reads, want_image)
+    c = getattr(h, "_job_cache", None)
+    if c is None or c[0] != key:                                   # (a job repeated on a handle: the ctypes objects are built once)
+        L = lib()
+        L.e2s_resident_job.argtypes = [C.c_void_p, C.POINTER(ResidentParams), ALLGATHER, C.c_void_p, C.POINTER(JobReport)]
+        p = ResidentParams(k, min_len, rank, world, C2SOptions(n1, k_left, k_right, mcov, cons_reads, max_gap, max_err, pval), 1 if want_image else 0, 0)
 
-    def _ag(_user, d_send, d_recv, nbytes, stream):
-        try:
-            allgather(d_send, d_recv, nbytes, stream)
-            return 0
-        except Exception:                                          # pragma: no cover
-            import traceback
-            traceback.print_exc()
-            return 1
-    cb = ALLGATHER(_ag) if allgather is not None else ALLGATHER(0)
-    h._ck(L.e2s_resident_job(h.h, C.byref(p), cb, None, C.byref(rep)))
+        def _ag(_user, d_send, d_recv, nbytes, stream):
+            try:
+                allgather(d_send, d_recv, nbytes, stream)
+                return 0
+            except Exception:                                      # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLGATHER(_ag) if allgather is not None else ALLGATHER(0)
+        c = h._job_cache = (key, L.e2s_resident_job, C.byref(p), cb, JobReport(), p)
+    rep = c[4]
+    h._ck(c[1](h.h, c[2], c[3], None, C.byref(rep)))
     return rep
 
 

@@ -84,6 +84,7 @@ struct e2s_ctx {
     uint32_t seg_blocks_cap = 0;
     SegArgs seg_args{}; uint32_t seg_row_entries = 4096; uint64_t* d_kept_off = nullptr;     // the last segmented scan's arguments (compaction, image layout)
     uint64_t* d_scan_stats = nullptr;                            // [151 freq | n_records | n_bases] tallied by the scan kernel (in front of d_words)
+    bool ko_clean = false;                                       // the ordering pass's bucket counts are zero (its last kernel leaves them so)
     uint8_t* d_xchg = nullptr; size_t xchg_bytes = 0;            // e2s_resident_job: the two exchanges' send / receive buffers
     // the scan that writes the image itself (k_scan_seg<1, FUSED, true>): records live in d_img only, statistics come with the mail
     bool img_mode = false; uint64_t img_scan_records = 0; uint32_t img_skip = 0;     // img_skip: the shard's record 0 turned out shorter than min_len
@@ -161,12 +162,16 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     e2s_ctx* h = new e2s_ctx();
     h->device = device_id;
     if (const char* ev = getenv("E2S_STREAM_PER_CAND")) h->stream_per_cand = (uint32_t)std::max(8, atoi(ev));   // (tests: force the overflow path)
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+    // the handle's stream at the highest priority, the second stream (image layout beside the per-cluster pass, a pre-filter beside the
+    // scan) at the lowest: where both have work ready, the critical path's blocks are dispatched first
+    int prio_lo = 0, prio_hi = 0;
+    if (hipSetDevice(device_id) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) {
         g_create_error = std::string("hipSetDevice/hipStreamCreate: ") + hipGetErrorString(e);
         delete h;
         return E2S_ERR_HIP;
     }
-    bool ok = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess;   // (a null stream2 would be the default stream)
+    bool ok = hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) == hipSuccess;   // (a null stream2 would be the default stream)
     for (auto& ev : h->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
     if (!ok) {
         g_create_error = "hipStreamCreate / hipEventCreate failed";
@@ -1385,7 +1390,7 @@ static int cand_buffers(e2s_ctx* h, CandArgs& a, uint64_t want) {
         CK(hipMalloc((void**)&h->d_slot_off8, (want + 8) * 4));
         CK(hipMalloc((void**)&h->d_rank, e2s_cand_order_scratch_bytes(want)));
         CK(hipMalloc((void**)&h->d_order, want * 4));
-        h->cand_cap = want;
+        h->cand_cap = want; h->ko_clean = false;
     }
     const size_t rec_bytes = std::min((size_t)h->cand_cap * a.stride, std::max((size_t)h->cand_cap * h->stream_per_cand, (size_t)1 << 16)) & ~(size_t)7;
     const size_t ord_off = (rec_bytes + 63) & ~(size_t)63;
@@ -1510,7 +1515,9 @@ static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nu
     CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
     e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
                             (uint32_t*)(a.host_stream + h->stream_ord_off), (const unsigned long long*)(h->d_scalars + 2), h->d_words + 1,
-                            h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 3328), bad, h->fl_cap, a.stream8_cap, zero, n_zero, h->stream);
+                            h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 3328), bad, h->fl_cap, a.stream8_cap, zero, n_zero, (uint32_t*)h->d_rank,
+                            e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);
+    h->ko_clean = true;                                         // (k_cand_offsets leaves the bucket counts at zero)
     LCHK("e2s_launch_cand_offsets");
     return E2S_OK;
 }
@@ -1535,7 +1542,6 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     if (!h->stitched) return fail(h, E2S_ERR_STATE, "no cluster records (run e2s_stitch or e2s_load_clusters)");
     if (!h->bwt || !h->pos || !h->da) return fail(h, E2S_ERR_STATE, "the per-cluster pass needs all four EGSA arrays");
     CK(hipSetDevice(h->device));
-    const e2s_shard_desc& d = h->d;
     CandArgs a;
     int rc = cand_args(h, p, record_index_base, a);
     if (rc) return rc;
@@ -1975,16 +1981,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     h->pf_armed = true; h->pf_arm_mcov = p->o.mcov_out;
     if ((rc = seg_scan_launch(h, a, p->min_len, 0, true, blob, false))) return rc;      // (the mail travels once, at the end, with everything else)
     if (!h->pf_fused) return fail(h, E2S_ERR_STATE, "resident job: the pre-filter did not go into the scan kernel");       // (cannot happen: checked above)
-    // ---- the `.clusters` image: laid out on the second stream right behind k_seg_fix (its offsets), finished from the plan below
-    if (p->want_image) {
-        if ((rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096)))) return rc;
-        if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
-        CK(hipEventRecord(h->ev_img, h->stream));
-        CK(hipStreamWaitEvent(h->stream2, h->ev_img, 0));
-        e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, 0xFFFFFFFFu, (const unsigned long long*)h->d_kept_off, h->d_img, h->img_cap - 2, d_scan_mail, 0, 0, 0, 0, 0,
-                                 h->stream2, pack_blocks_beside());
-        LCHK("e2s_launch_pack_segments");
-    }
+    if (p->want_image && (rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096)))) return rc;
     // ---- exchange 1, then everything the host used to do between the scan and the per-cluster pass, on the device
     if (W > 1 && allgather(user, blob, recv, E2S_JOB_BLOB, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
     e2s_c2s_params cp{p->o.nr_reads1, p->o.k_left, p->o.k_right, p->o.mcov_out, p->o.consensus_reads, (int)E2S_MAX_CLUST_LEN, p->min_len};
@@ -2001,11 +1998,19 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     pa.fl_starts = (unsigned long long*)h->d_fl_starts; pa.fl_lens = h->d_fl_lens;
     pa.cand_count = (unsigned long long*)(h->d_scalars + 1); pa.stream8_count = ca.stream8_count; pa.cand_err = h->d_words + 1;
     pa.ko_cnt = (uint32_t*)h->d_rank; pa.n_ko = e2s_cand_order_buckets(h->cand_cap) + 1u;
+    if (!h->ko_clean) CK(hipMemsetAsync(h->d_rank, 0, (size_t)pa.n_ko * 4, h->stream));      // (a fresh buffer / an aborted pass: otherwise the last pass left them clean)
+    h->ko_clean = false;
     e2s_launch_job_plan(pa, h->stream);
     LCHK("e2s_launch_job_plan");
-    if (p->want_image) {                                        // the image finished in place, behind its layout kernel
+    // ---- the `.clusters` image on the second stream, beside the per-cluster pass: laid out from the segments (offsets: k_seg_fix), then
+    // finished in place from the plan.  (Started right behind k_seg_fix it saturated HBM under the plan's one block: 45-65 us for it.)
+    if (p->want_image) {
+        if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
         CK(hipEventRecord(h->ev_img, h->stream));
         CK(hipStreamWaitEvent(h->stream2, h->ev_img, 0));
+        e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, 0xFFFFFFFFu, (const unsigned long long*)h->d_kept_off, h->d_img, h->img_cap - 2, d_scan_mail, 0, 0, 0, 0, 0,
+                                 h->stream2, pack_blocks_beside());
+        LCHK("e2s_launch_pack_segments");
         e2s_launch_img_patch_dev(h->d_img, h->img_cap, d_jd, d_scan_mail, p->min_len, h->stream2);
         CK(hipEventRecord(h->ev_img, h->stream2));
     }

@@ -282,7 +282,7 @@ size_t e2s_cand_order_scratch_bytes(unsigned long long n);
 void e2s_launch_cand_offsets(const uint32_t* order, const uint32_t* slot_off8, unsigned long long n, const unsigned long long* n_dev,
                              const unsigned long long* stream8_count, uint32_t* off_out, const unsigned long long* fl_count, const uint32_t* err_a,
                              const uint32_t* err_b, unsigned long long* mail, uint32_t* bad, unsigned long long fl_cap, unsigned long long stream8_cap,
-                             unsigned long long* zero, unsigned long long n_zero, hipStream_t st);
+                             unsigned long long* zero, unsigned long long n_zero, uint32_t* ko_cnt, uint32_t n_ko, hipStream_t st);
 uint32_t e2s_cand_order_buckets(unsigned long long n);
 void e2s_launch_cand_order(const unsigned long long* keys, unsigned long long n, const unsigned long long* n_dev, unsigned long long key_lo,
                            unsigned long long key_span, void* scratch, uint32_t* order, hipStream_t st, bool counts_cleared = false);

@@ -1113,22 +1113,24 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
 // run -- and what follows from THIS rank's plan: record 0 finished in its segment, the seed clusters (EOF tail records, wrapped
 // lengths) at the head of the flagged list, the per-cluster pass's counters cleared.  One block.
 __global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
-    // the gathered blobs and the scan's mail are staged in LDS by all threads at once (ONE global round trip); everything below reads LDS
-    __shared__ __attribute__((aligned(16))) uint8_t s_blob[E2S_JOB_MAX_RANKS * E2S_JOB_BLOB];
-    __shared__ e2s_boundary s_all[E2S_JOB_MAX_RANKS];
-    __shared__ e2s_stitch_plan_t s_plan[E2S_JOB_MAX_RANKS];
-    __shared__ e2s_stat_delta s_delta[E2S_JOB_MAX_RANKS];
-    __shared__ int s_rc[E2S_JOB_MAX_RANKS];
+    // the gathered blobs and the scan's mail are staged in LDS by all threads at once (ONE global round trip); everything below reads LDS.
+    // Dynamic LDS, sized for the ranks there are (with room for 64 the block waited for a CU with 100 KB free while the image's layout
+    // kernel ran beside it: 65 us instead of 15)
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_plan_lds[];
     __shared__ uint64_t s_freq[E2S_MAX_CLUST_LEN_K + 1];
     __shared__ ScanMail s_mail;
     const u32 tid = threadIdx.x;
     const int W = a.world;
+    uint8_t* const s_blob = s_plan_lds;
+    e2s_boundary* const s_all = (e2s_boundary*)(s_blob + (size_t)W * E2S_JOB_BLOB);
+    e2s_stitch_plan_t* const s_plan = (e2s_stitch_plan_t*)(s_all + W);
+    e2s_stat_delta* const s_delta = (e2s_stat_delta*)(s_plan + W);
+    int* const s_rc = (int*)(s_delta + W);
     static_assert(E2S_JOB_BLOB % 16 == 0 && sizeof(ScanMail) % 8 == 0, "staging by words");
     for (u32 i = tid; i < (u32)W * (E2S_JOB_BLOB / 16u); i += 256u) ((uint4*)s_blob)[i] = ((const uint4*)a.blobs)[i];
     if (tid < sizeof(ScanMail) / 8) ((u64*)&s_mail)[tid] = ((const u64*)a.mail)[tid];
-    // the per-cluster pass's counters (k_cand_init's part; the ordering pass's bucket counts are left clean by k_cand_offsets)
+    // the per-cluster pass's counters (k_cand_init's part; the ordering pass's bucket counts were left clean by k_cand_offsets)
     if (tid == 255) { *a.cand_count = 0; *a.stream8_count = 0; *a.cand_err = 0; }
-    for (u32 i = tid; i < a.n_ko; i += 256u) a.ko_cnt[i] = 0u;
     __syncthreads();
     for (u32 i = tid; i < (u32)W * (sizeof(e2s_boundary) / 8); i += 256u) {
         const u32 r = i / (sizeof(e2s_boundary) / 8), w = i % (sizeof(e2s_boundary) / 8);
@@ -1146,19 +1148,78 @@ __global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
         s_freq[tid - 64u] = f;
     }
     __syncthreads();
-    if (tid != 0) return;
-    JobDev jd = {};
+    if (tid >= 64u) return;
     u32 rc = 0;
     u64 nrec = 0, nb = 0, last_len = 0;
-    for (int r = 0; r < W; ++r) {
-        if (s_rc[r]) rc |= E2S_JOBERR_PLAN;
-        const e2s_stat_delta& d = s_delta[r];
-        for (int i = 0; i < d.n; ++i) if (d.len[i] <= E2S_MAX_CLUST_LEN_K) s_freq[d.len[i]] += (u64)(int64_t)d.sign[i];
-        nrec += d.n_records; nb += d.n_bases;
-        if (d.n_records) last_len = d.last_len;
+    if (tid == 0) {
+        for (int r = 0; r < W; ++r) {
+            if (s_rc[r]) rc |= E2S_JOBERR_PLAN;
+            const e2s_stat_delta& d = s_delta[r];
+            for (int i = 0; i < d.n; ++i) if (d.len[i] <= E2S_MAX_CLUST_LEN_K) s_freq[d.len[i]] += (u64)(int64_t)d.sign[i];
+            nrec += d.n_records; nb += d.n_bases;
+            if (d.n_records) last_len = d.last_len;
+        }
+        if (nrec && last_len <= (u64)E2S_MAX_CLUST_LEN_K) s_freq[last_len]++;        // H4: the last record counted twice (e2s_auto_len_core)
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // statistics()'s auto-detection (e2s_auto_len_core, e2s_plan.h) with the histogram's 151 terms spread over the wave -- three bins a
+    // lane, exact integer prefix sums, the same two floating-point tests ((double)cum / n_bases < pval once, then (double)cum * (1 /
+    // n_bases) < pval per length: the -Ofast arithmetic of the reference build, H19); serially, one thread spent ~20 us in LDS latency
+    nrec = wave_first64(nrec); nb = wave_first64(nb); last_len = wave_first64(last_len);
     int mcl = 0; uint64_t n_clust = 0, n_bases = 0;
-    rc |= (u32)e2s_auto_len_core(s_freq, nrec, nb, last_len, a.mcov, a.pval, &mcl, &n_clust, &n_bases);
+    {
+        u32 arc = 0;
+        if (nrec == 0) arc = 1;
+        else {
+            n_clust = nrec + 1; n_bases = nb + last_len;
+            u64 term[3], incl[3];
+            u64 run = 0, tmax = 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const u32 i = 3u * tid + (u32)q;
+                term[q] = i <= (u32)E2S_MAX_CLUST_LEN_K ? s_freq[i] * (u64)i : 0ull;
+                run += term[q]; incl[q] = run;
+                if (i >= 1u) tmax = max(tmax, term[q]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tmax = max(tmax, (u64)__shfl_xor((unsigned long long)tmax, o));
+            u64 scan = run;                                     // inclusive scan of the lanes' sums
+            for (u32 dd = 1; dd < 64u; dd <<= 1) { const u64 v = __shfl_up((unsigned long long)scan, dd); if (tid >= dd) scan += v; }
+            const u64 base = scan - run;
+            const int mcl0 = 2 * a.mcov;
+            if (tmax == 0) arc = 2;
+            else if (mcl0 < 0 || mcl0 > E2S_MAX_CLUST_LEN_K) arc = 3;
+            else {
+                // cum(c) = sum of the terms mcl0 .. c = P(c) - P(mcl0 - 1)
+                const u32 lm = (u32)mcl0 / 3u, qm = (u32)mcl0 % 3u;
+                u64 pm = 0, tm = 0;                              // P(mcl0), term(mcl0) from their lane
+                { const u64 cand = base + (qm == 0 ? incl[0] : qm == 1 ? incl[1] : incl[2]), ct = qm == 0 ? term[0] : qm == 1 ? term[1] : term[2];
+                  pm = __shfl((unsigned long long)cand, (int)lm); tm = __shfl((unsigned long long)ct, (int)lm); }
+                const u64 pbefore = pm - tm;
+                const double dnb = (double)n_bases;
+                mcl = mcl0;
+                if ((double)tm / dnb < a.pval) {
+                    const double rr = 1.0 / dnb;
+                    u32 first = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const u32 c = 3u * tid + (u32)q;
+                        const bool in = c > (u32)mcl0 && c <= (u32)E2S_MAX_CLUST_LEN_K;
+                        const u64 cum = base + incl[q] - pbefore;
+                        const bool brk = in && !((double)cum * rr < a.pval);
+                        if (brk) first = min(first, c);
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) first = min(first, (u32)__shfl_xor((int)first, o));
+                    mcl = first == 0xFFFFFFFFu ? E2S_MAX_CLUST_LEN_K : (int)first;
+                }
+            }
+        }
+        rc |= arc;
+    }
+    if (tid != 0) return;
+    JobDev jd = {};
     const e2s_stitch_plan_t pl = s_plan[a.rank];
     const ScanMail& m = s_mail;
     jd.plan = pl; jd.mcl = mcl; jd.n_clust = n_clust; jd.n_bases = n_bases;
@@ -1193,7 +1254,11 @@ __global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
     jd.stat_rc = rc;
     *a.out = jd;
 }
-void e2s_launch_job_plan(const JobPlanArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_job_plan, dim3(1), dim3(256), 0, st, a); }
+void e2s_launch_job_plan(const JobPlanArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)a.world * (E2S_JOB_BLOB + sizeof(e2s_boundary) + sizeof(e2s_stitch_plan_t) + sizeof(e2s_stat_delta) + sizeof(int)) + 64;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_job_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_job_plan, dim3(1), dim3(256), lds, st, a);
+}
 // the image finished in place from the device's plan (e2s_stitch on a pre-stitch image: k_img_patch with host arguments)
 __global__ void k_img_patch_dev(uint8_t* img, u64 cap, const JobDev* jd, const ScanMail* mail, int min_len) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -2068,11 +2133,12 @@ __global__ void k_ko_rank(const u64* gkeys, const u32* gidx, u64 n, const unsign
 // bad (the resident job): 1 where the pass overflowed a buffer or left an error bit -- what the host checks in the mail, for the tail's kernels
 __global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
                                const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, u32* bad, u64 fl_cap, u64 stream8_cap,
-                               unsigned long long* zero, u64 n_zero) {
+                               unsigned long long* zero, u64 n_zero, u32* ko_cnt, u32 n_ko) {
     const u64 cap = n;
     n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     for (u64 z = i; z < n_zero; z += (u64)gridDim.x * blockDim.x) zero[z] = 0ull;     // (the resident job: the tail's sums, cleared here instead of by a memset)
+    for (u64 z = i; z < n_ko; z += (u64)gridDim.x * blockDim.x) ko_cnt[z] = 0u;       // the ordering pass's bucket counts: left clean for the next pass
     if (i < n) off_out[i] = slot_off8[order[i]];
     else if (i == n) {
         off_out[n] = (u32)*stream8_count;
@@ -2082,9 +2148,9 @@ __global__ void k_cand_offsets(const u32* order, const u32* slot_off8, u64 n, co
 }
 void e2s_launch_cand_offsets(const u32* order, const u32* slot_off8, u64 n, const unsigned long long* n_dev, const unsigned long long* stream8_count, u32* off_out,
                              const unsigned long long* fl_count, const u32* err_a, const u32* err_b, unsigned long long* mail, u32* bad, u64 fl_cap, u64 stream8_cap,
-                             unsigned long long* zero, u64 n_zero, hipStream_t st) {
+                             unsigned long long* zero, u64 n_zero, u32* ko_cnt, u32 n_ko, hipStream_t st) {
     hipLaunchKernelGGL(k_cand_offsets, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, order, slot_off8, n, n_dev, stream8_count, off_out,
-                       fl_count, err_a, err_b, mail, bad, fl_cap, stream8_cap, zero, n_zero);
+                       fl_count, err_a, err_b, mail, bad, fl_cap, stream8_cap, zero, n_zero, ko_cnt, n_ko);
 }
 size_t e2s_cand_order_scratch_bytes(u64 n) { return ((size_t)E2S_KO_MAX_BUCKETS + 2 + 2 * n + 2) * 4 + n * 8; }
 // ~2 keys per bucket up to 2^14 buckets, then up to 32 per bucket before the table grows again: the single-block scan of the counts
