@@ -146,6 +146,8 @@ static void dbg_entry(const char* name) {
 extern "C" const char* e2s_version(void) { return "ebwt2snp_amd 0.1 (gfx950)"; }
 
 extern "C" const char* e2s_last_error(e2s_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+// (private, ebwt2snp_amd/host/reads_upload.cpp) the outcome of a handle-less host call becomes the handle's message
+extern "C" void e2s_internal_set_error(e2s_handle h, const char* msg) { if (h) h->err = msg ? msg : ""; }
 
 extern "C" int e2s_create(int device_id, e2s_handle* out) {
     dbg_entry("e2s_create");
@@ -1956,10 +1958,11 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     const e2s_tail_params tp{p->o.k_left, p->o.k_right, p->o.max_gap, p->o.max_err};
     int rc = tail_applicable(h, &tp);
     if (rc) return rc;
-    CK(hipSetDevice(h->device));
     const e2s_shard_desc& d = h->d;
     const bool last_rank = d.global_offset + d.n_entries == d.n_total;
     if (last_rank != (p->rank == p->world - 1)) return fail(h, E2S_ERR_ARG, "rank order must be SA order: only the last rank may hold the EGSA's end");
+    if (p->probe_only) return E2S_OK;
+    CK(hipSetDevice(h->device));
     const int W = p->world;
     // exchange buffers: [my blob][W blobs][my (events, ok)][W pairs]
     const size_t off_recv = E2S_JOB_BLOB, off_send2 = off_recv + (size_t)W * E2S_JOB_BLOB, off_recv2 = off_send2 + 64, xneed = off_recv2 + (size_t)W * 16 + 64;
@@ -1981,9 +1984,8 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     h->pf_armed = true; h->pf_arm_mcov = p->o.mcov_out;
     if ((rc = seg_scan_launch(h, a, p->min_len, 0, true, blob, false))) return rc;      // (the mail travels once, at the end, with everything else)
     if (!h->pf_fused) return fail(h, E2S_ERR_STATE, "resident job: the pre-filter did not go into the scan kernel");       // (cannot happen: checked above)
+    // (every buffer of the step is in place BEFORE the first exchange: a rank that cannot allocate leaves here, where no other rank waits for it)
     if (p->want_image && (rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096)))) return rc;
-    // ---- exchange 1, then everything the host used to do between the scan and the per-cluster pass, on the device
-    if (W > 1 && allgather(user, blob, recv, E2S_JOB_BLOB, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
     e2s_c2s_params cp{p->o.nr_reads1, p->o.k_left, p->o.k_right, p->o.mcov_out, p->o.consensus_reads, (int)E2S_MAX_CLUST_LEN, p->min_len};
     CandArgs ca;
     if ((rc = cand_args(h, &cp, (uint64_t)p->rank << 40, ca))) return rc;
@@ -1991,6 +1993,12 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     ca.len_hi_dev = &d_jd->len_hi;
     if ((rc = cand_buffers(h, ca, std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap)))) return rc;
     ca.starts = h->d_fl_starts; ca.lens = h->d_fl_lens; ca.n_rec = h->fl_cap;
+    const uint64_t ncap = h->cand_cap, ng = (ncap + 63) / 64;
+    TailArgs ta;
+    if ((rc = tail_prepare(h, &tp, ncap, ta))) return rc;
+    ta.n_cand_dev = (const unsigned long long*)(h->d_scalars + 1);
+    // ---- exchange 1, then everything the host used to do between the scan and the per-cluster pass, on the device
+    if (W > 1 && allgather(user, blob, recv, E2S_JOB_BLOB, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
     JobPlanArgs pa{};
     pa.blobs = recv; pa.world = W; pa.rank = p->rank; pa.n_total = d.n_total; pa.k = p->k; pa.lcp_bytes = d.lcp_bytes; pa.mcov = p->o.mcov_out; pa.pval = p->o.pval;
     pa.min_len = p->min_len; pa.len_lo = ca.len_lo;
@@ -2021,10 +2029,6 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     LCHK("e2s_launch_flagged_lists");
     CK(hipEventRecord(h->ev[7], h->stream));
     // ---- the tail, sized for the candidate slots there are; the kernels read the count on the device
-    const uint64_t ncap = h->cand_cap, ng = (ncap + 63) / 64;
-    TailArgs ta;
-    if ((rc = tail_prepare(h, &tp, ncap, ta))) return rc;
-    ta.n_cand_dev = (const unsigned long long*)(h->d_scalars + 1);
     unsigned long long* totals = h->d_part;
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);

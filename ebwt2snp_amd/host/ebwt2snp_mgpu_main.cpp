@@ -4,12 +4,16 @@
 //
 // What it replaces: running `ebwt2clust -i F` and then `clust2snp -i F -n N` (ebwt2clust.cpp:141-198, clust2snp.cpp:969-1085;
 // pipeline.sh:115,122); it writes the same two files, <F>.clusters and <F minus .fast*>.snp, byte for byte.
-// One thread per GPU.  Rank r owns the r-th contiguous SA range (left halo 152, right halo 1) and keeps it -- and all reads --
-// resident in HBM.  After the scan every rank publishes its 88-byte boundary descriptor and the 1.2-KB statistics the scan left
-// with ONE ncclAllGather (RCCL; xGMI between the GPUs); stitch plans and the statistics step are pure host functions of the
-// gathered array (e2s_stitch, e2s_auto_max_clust_length_ranks), so every rank derives the same max_clust_length.  The `.snp`
-// ids are sequential over the ranks: a second, 8-byte all-gather tells a rank how many events the ranks before it hold.
-// The files are written rank by rank.  -G 1 runs the same code with a one-rank communicator.
+// One thread per GPU.  Rank r owns the r-th contiguous SA range (left halo 152, right halo 1) and keeps it -- and all reads, uploaded
+// from ONE index of the FASTA built by the main thread -- resident in HBM.  The step itself is e2s_resident_job: scan, exchange,
+// stitch + statistics, per-cluster pass, tail, all enqueued at once, the two exchanges being ncclAllGather calls on the rank's stream
+// (RCCL; xGMI between the GPUs): 1.3 KB of descriptor + statistics per rank, then 16 bytes (events, ok) for the `.snp` ids, which are
+// sequential over the ranks.  Where that form does not apply (or a buffer was too small: every rank learns it in the second
+// exchange) the ranks run the stepwise calls with the same two exchanges.  Both files are written by all ranks AT ONCE, each at
+// its own offset (pwrite): the sizes are exchanged through the process's memory.
+// No rank ever waits for one that failed: before every exchange the ranks agree -- a barrier over their status in this process --
+// whether all of them are still in; if not, all leave.  (E2S_MGPU_FAIL_RANK=r, E2S_MGPU_FAIL_AT=setup|job: inject a failure: tests.)
+// -G 1 runs the same code with a one-rank communicator.
 // E2S_MGPU_SHARED_DEVICE=1 puts every rank on GPU 0 and exchanges through host memory (RCCL refuses two ranks on one device):
 // a rehearsal of the N-rank logic on a one-GPU box, not a way to run jobs.
 #include <fcntl.h>
@@ -35,7 +39,7 @@ struct Opts {
     int k_left = 31, k_right = 30, max_gap = 10, consensus_reads = 20, max_err = 2, mcov_out = 5; double pval = 0.99;
 };
 
-// a barrier for the rehearsal mode and the turn-taking of the writers
+// a barrier over the ranks' threads: the rehearsal's exchanges, the agreement before every collective, the sizes of the outputs
 class Barrier {
   public:
     explicit Barrier(int n) : n_(n) {}
@@ -47,46 +51,56 @@ class Barrier {
   private:
     int n_, cnt_ = 0, gen_ = 0; std::mutex m_; std::condition_variable cv_;
 };
-class Turn {
-  public:
-    void wait_for(int r) { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&]() { return turn_ == r || fail_; }); }
-    void next() { { std::lock_guard<std::mutex> lk(m_); ++turn_; } cv_.notify_all(); }
-    void abort() { { std::lock_guard<std::mutex> lk(m_); fail_ = true; } cv_.notify_all(); }
-  private:
-    int turn_ = 0; bool fail_ = false; std::mutex m_; std::condition_variable cv_;
-};
 
 struct Shared {
     Opts o; EgsaFiles* F; int nranks; bool shared_device;
     std::vector<ncclComm_t> comms;
     std::vector<uint8_t> host_blob;           // rehearsal: the exchange through host memory
-    std::vector<uint64_t> host_events;
-    Barrier* bar; Turn cl_turn, snp_turn;
-    int cl_fd = -1; FILE* snp_f = nullptr; std::string snp_path;
+    Barrier* bar;
+    // the reads, indexed once
+    const void* rd_text = nullptr; uint64_t rd_bytes = 0, rd_n = 0; const uint64_t* rd_start = nullptr; const uint32_t* rd_len = nullptr; uint32_t rd_max = 0;
+    bool reads_ok = false;
+    int cl_fd = -1, snp_fd = -1; std::string snp_path;
     std::atomic<int> rc{0};
-    std::vector<uint64_t> closed, cands, events; int mcl = 0;
+    std::atomic<int> crash{0};                // 136 / 139: the reference's clust2snp dies on this input (SIGFPE / SIGSEGV) -- after ebwt2clust wrote its file
+    std::vector<int> status;                  // per rank: 0 = in, else its error (agreement before every collective)
+    std::vector<int> form;                    // per rank: e2s_resident_job applies
+    std::vector<uint64_t> closed, cands, events, cl_records, snp_bytes; int mcl = 0;
     // where only the host tail reproduces the reference (a read rank past the last read, -L outside 1..64, an irregular FASTA): every
-    // rank appends its packed candidates in rank order and ONE e2s_snp_from_packed runs at the end
-    bool host_tail = false; std::vector<uint8_t> pk_stream; std::vector<uint32_t> pk_off8; uint32_t pk_pw = 4;
+    // rank hands over its packed candidates and ONE e2s_snp_from_packed runs at the end
+    bool host_tail = false; std::vector<std::vector<uint8_t>> pk_stream; std::vector<std::vector<uint32_t>> pk_off8; uint32_t pk_pw = 4;
+    int fail_rank = -1; std::string fail_at;
     std::mutex log_m;
 };
 
 constexpr size_t BLOB = sizeof(e2s_boundary) + sizeof(e2s_scan_stats);
 
-int fd_sink(void* user, const void* data, size_t bytes) {
-    const int fd = *(int*)user;
+struct PSink { int fd; uint64_t at; };
+int pwrite_sink(void* user, const void* data, size_t bytes) {
+    PSink* s = (PSink*)user;
     const char* p = (const char*)data;
-    while (bytes) { const ssize_t w = ::write(fd, p, bytes); if (w <= 0) return 1; p += w; bytes -= (size_t)w; }
+    while (bytes) { const ssize_t w = ::pwrite(s->fd, p, bytes, (off_t)s->at); if (w <= 0) return 1; p += w; bytes -= (size_t)w; s->at += (uint64_t)w; }
     return 0;
 }
-int file_sink(void* user, const void* data, size_t bytes) { return fwrite(data, 1, bytes, (FILE*)user) == bytes ? 0 : 1; }
 
 #define STEP(call, what)                                                                                                        \
-    do { const int rc_ = (call); if (rc_) { std::lock_guard<std::mutex> lk(S.log_m);                                               \
+    do { const int rc_ = (call); if (rc_ && !mine_rc) { std::lock_guard<std::mutex> lk(S.log_m);                                   \
          std::cerr << "rank " << r << ": " << what << " failed (" << rc_ << "): " << (h ? e2s_last_error(h) : "") << std::endl;     \
-         S.rc.store(rc_); } } while (0)
+         mine_rc = rc_; } } while (0)
 
-// ONE all-gather of `bytes` per rank: RCCL on the rank's stream, or host memory + a barrier in the rehearsal mode
+// Do all ranks still stand?  Every rank publishes its status, all wait, all read the same answer: nobody enters a collective that
+// somebody else will not enter.  The first failure becomes the job's exit code.
+bool agree(Shared& S, int r, int my_rc) {
+    S.status[(size_t)r] = my_rc;
+    S.bar->wait();
+    bool all = true;
+    for (int q = 0; q < S.nranks; ++q) if (S.status[(size_t)q]) { all = false; int z = 0; S.rc.compare_exchange_strong(z, S.status[(size_t)q]); }
+    S.bar->wait();
+    return all;
+}
+
+// ONE all-gather of `bytes` per rank between host buffers (the stepwise path): RCCL on the rank's exchange stream, or host memory + a
+// barrier in the rehearsal mode
 int all_gather(Shared& S, int r, const void* mine, size_t bytes, std::vector<uint8_t>& all, void* d_send, void* d_recv, hipStream_t st) {
     all.resize(bytes * (size_t)S.nranks);
     if (S.shared_device) {
@@ -104,25 +118,42 @@ int all_gather(Shared& S, int r, const void* mine, size_t bytes, std::vector<uin
     return hipStreamSynchronize(st) == hipSuccess ? 0 : 4;
 }
 
+// the exchange of e2s_resident_job: device buffers, enqueued on the handle's stream
+struct AgCtx { Shared* S; int r; };
+int job_allgather(void* user, const void* d_send, void* d_recv, size_t bytes, void* stream) {
+    AgCtx* c = (AgCtx*)user;
+    Shared& S = *c->S;
+    if (!S.shared_device) return ncclAllGather(d_send, d_recv, bytes, ncclChar, S.comms[(size_t)c->r], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+    // rehearsal (all ranks on one device): through host memory, which means waiting for the stream here
+    std::vector<uint8_t> mine(bytes), all(bytes * (size_t)S.nranks);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(mine.data(), d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    { std::lock_guard<std::mutex> lk(S.log_m); if (S.host_blob.size() < all.size()) S.host_blob.resize(all.size()); }
+    S.bar->wait();
+    memcpy(S.host_blob.data() + bytes * (size_t)c->r, mine.data(), bytes);
+    S.bar->wait();
+    memcpy(all.data(), S.host_blob.data(), all.size());
+    S.bar->wait();
+    return hipMemcpy(d_recv, all.data(), all.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+}
+
 void rank_main(Shared& S, int r) {
     const Opts& o = S.o;
     const int dev = S.shared_device ? 0 : r;
     e2s_handle h = nullptr;
     hipStream_t xs = nullptr; void *d_send = nullptr, *d_recv = nullptr;
+    int mine_rc = 0;
     const uint64_t n = S.F->n;
     // contiguous SA ranges of (almost) equal size; the cuts may fall anywhere, the stitch takes care of clusters that cross them
     const uint64_t lo = n * (uint64_t)r / (uint64_t)S.nranks, hi = n * (uint64_t)(r + 1) / (uint64_t)S.nranks;
     const uint32_t hl = (uint32_t)std::min<uint64_t>(lo, E2S_MAX_CLUST_LEN + 2), hr = (uint32_t)std::min<uint64_t>(n - hi, 1);
+    // ---- setup: everything that can fail before the first exchange (handle, exchange buffers, reads, shard) ----
     STEP(e2s_create(dev, &h), "e2s_create");
-    if (!S.rc.load() && !S.shared_device) {
+    if (!mine_rc && !S.shared_device) {
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) != hipSuccess ||
-            hipMalloc(&d_send, BLOB) != hipSuccess || hipMalloc(&d_recv, BLOB * (size_t)S.nranks) != hipSuccess) S.rc.store(E2S_ERR_HIP);
+            hipMalloc(&d_send, BLOB) != hipSuccess || hipMalloc(&d_recv, BLOB * (size_t)S.nranks) != hipSuccess) mine_rc = E2S_ERR_HIP;
     }
-    if (!S.rc.load()) {
-        const int rc = e2s_upload_reads_fasta(h, o.input.c_str(), nullptr);     // every rank holds all reads (candidates name any of them)
-        if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) STEP(rc, "upload reads");
-    }
-    if (!S.rc.load()) {
+    if (!mine_rc && S.reads_ok) STEP(e2s_upload_reads(h, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads");   // every rank holds all reads
+    if (!mine_rc) {
         e2s_shard_desc d{};
         d.global_offset = lo; d.n_entries = hi - lo; d.n_total = n; d.halo_left = hl; d.halo_right = hr;
         d.lcp_bytes = o.lcp; d.da_bytes = o.da; d.pos_bytes = o.pos;
@@ -130,86 +161,130 @@ void rank_main(Shared& S, int r) {
         if (S.F->gesa) STEP(e2s_upload_gesa(h, &d, S.F->aos.p + p0 * (uint64_t)(o.lcp + o.da + o.pos + 1)), "upload (.gesa)");
         else STEP(e2s_upload_bcr(h, &d, S.F->bwt.p + p0, S.F->lcp.p + p0 * (uint64_t)o.lcp, S.F->pairsa.p + p0 * (uint64_t)(o.da + o.pos)), "upload (BCR)");
     }
-    // ---- ebwt2clust: scan, ONE all-gather, stitch ----
-    std::vector<uint8_t> mine(BLOB, 0), all;
-    if (!S.rc.load()) {
+    if (S.fail_rank == r && S.fail_at == "setup") { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (setup)" << std::endl; mine_rc = E2S_ERR_HIP; }
+    e2s_resident_params rp{};
+    rp.k = o.k; rp.min_len = o.min_len; rp.rank = r; rp.world = S.nranks; rp.want_image = 1;
+    rp.o.nr_reads1 = o.nr_reads1; rp.o.k_left = o.k_left; rp.o.k_right = o.k_right; rp.o.mcov_out = o.mcov_out; rp.o.consensus_reads = o.consensus_reads;
+    rp.o.max_gap = o.max_gap; rp.o.max_err = o.max_err; rp.o.pval = o.pval;
+    if (!mine_rc) { rp.probe_only = 1; S.form[(size_t)r] = e2s_resident_job(h, &rp, job_allgather, nullptr, nullptr) == E2S_OK ? 1 : 0; rp.probe_only = 0; }
+    auto leave = [&]() {
+        if (d_send) (void)hipFree(d_send);
+        if (d_recv) (void)hipFree(d_recv);
+        if (xs) (void)hipStreamDestroy(xs);
+        if (h) e2s_destroy(h);
+    };
+    if (!agree(S, r, mine_rc)) { leave(); return; }
+    bool native = true;
+    for (int q = 0; q < S.nranks; ++q) native = native && S.form[(size_t)q] != 0;
+
+    int mcl = 0; uint64_t n_cand = 0, nv = 0, ne = 0, nb = 0, need_host = 0;
+    bool done = false, host_tail = false;
+    // ---- the step as ONE enqueue: e2s_resident_job, its two exchanges on the handle's stream ----
+    if (native) {
+        AgCtx ctx{&S, r};
+        e2s_job_report rep{};
+        int jrc = e2s_resident_job(h, &rp, job_allgather, &ctx, &rep);
+        if (S.fail_rank == r && S.fail_at == "job") { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (job)" << std::endl; jrc = E2S_ERR_HIP; }
+        if (jrc == E2S_OK) {
+            done = true; mcl = rep.max_clust_length; n_cand = rep.n_candidates; nv = rep.n_variants; ne = rep.n_events; nb = rep.snp_bytes;
+            S.closed[(size_t)r] = rep.n_closed;
+            if (r == 0) S.mcl = mcl;
+        } else if (jrc == E2S_ERR_REF_CRASH) {                     // where clust2snp dies in the reference: ebwt2clust's file is written all the same
+            const char* why = e2s_last_error(h);
+            int z = 0; S.crash.compare_exchange_strong(z, (strstr(why, "divides by zero") || strstr(why, "histogram")) ? 136 : 139);
+            uint64_t nc = 0;
+            if (e2s_cluster_counts(h, &nc, nullptr) == E2S_OK) S.closed[(size_t)r] = nc;
+            done = true; n_cand = 0; ne = 0; nb = 0;
+        } else if (jrc != E2S_ERR_CAPACITY) STEP(jrc, "resident job");   // (E2S_ERR_CAPACITY: on every rank alike -- the stepwise calls below)
+        if (!agree(S, r, mine_rc)) { leave(); return; }
+        // (a rank whose job succeeded while another one's asked for the stepwise path cannot be: that verdict travels in the second exchange)
+    }
+    // ---- the stepwise calls with the same two exchanges ----
+    if (!done) {
+        std::vector<uint8_t> mine(BLOB, 0), all;
         STEP(e2s_prefilter_arm(h, o.mcov_out), "arm");
         STEP(e2s_cluster_scan(h, o.k, o.min_len, 0), "cluster scan");
-        if (!S.rc.load()) {
+        if (!mine_rc) {
             STEP(e2s_boundary_desc(h, (e2s_boundary*)mine.data()), "boundary");
             STEP(e2s_scan_stats_desc(h, (e2s_scan_stats*)(mine.data() + sizeof(e2s_boundary))), "scan statistics");
         }
-    }
-    if (all_gather(S, r, mine.data(), BLOB, all, d_send, d_recv, xs)) S.rc.store(E2S_ERR_HIP);      // (every rank takes part, failed or not)
-    std::vector<e2s_boundary> allb((size_t)S.nranks); std::vector<e2s_scan_stats> alls((size_t)S.nranks);
-    for (int q = 0; q < S.nranks; ++q) {
-        memcpy(&allb[(size_t)q], all.data() + BLOB * (size_t)q, sizeof(e2s_boundary));
-        memcpy(&alls[(size_t)q], all.data() + BLOB * (size_t)q + sizeof(e2s_boundary), sizeof(e2s_scan_stats));
-    }
-    int mcl = 0; uint64_t n_cand = 0, nv = 0, ne = 0, nb = 0, need_host = 0;
-    if (!S.rc.load()) {
-        STEP(e2s_stitch(h, allb.data(), S.nranks, r), "stitch");
-        uint64_t nc = 0, nrec = 0;
-        STEP(e2s_cluster_counts(h, &nc, &nrec), "counts");
-        S.closed[(size_t)r] = nc;
-        STEP(e2s_pack_clusters(h, 1), "pack .clusters");           // on the second stream, beside the per-cluster pass
-        // ---- clust2snp: statistics (pure function of the gathered array), per-cluster pass, tail ----
-        uint64_t n_clust = 0, n_bases = 0;
-        const int rc = e2s_auto_max_clust_length_ranks(allb.data(), alls.data(), S.nranks, n, o.k, o.lcp, o.mcov_out, o.pval, &mcl, &n_clust, &n_bases);
-        if (rc) S.rc.store(rc == E2S_ERR_REF_CRASH ? 136 : rc);
-        if (r == 0) S.mcl = mcl;
-    }
-    if (!S.rc.load()) {
-        e2s_c2s_params prm{};
-        prm.nr_reads1 = o.nr_reads1; prm.k_left = o.k_left; prm.k_right = o.k_right; prm.mcov_out = o.mcov_out;
-        prm.consensus_reads = o.consensus_reads; prm.max_clust_length = mcl; prm.min_len = o.min_len;
-        STEP(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand), "find candidates");
-        S.cands[(size_t)r] = n_cand;
-        if (!S.rc.load() && n_cand) {
-            e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
-            const int trc = e2s_call_variants(h, &tp, 0, &nv, &ne, &nb);   // (first_id 0: the text is written once, after the exchange below)
-            if (trc == E2S_ERR_STATE) { need_host = 1; ne = 0; } else STEP(trc, "tail (consensus, distance, text)");
+        if (!agree(S, r, mine_rc)) { leave(); return; }
+        if (all_gather(S, r, mine.data(), BLOB, all, d_send, d_recv, xs)) mine_rc = E2S_ERR_HIP;
+        std::vector<e2s_boundary> allb((size_t)S.nranks); std::vector<e2s_scan_stats> alls((size_t)S.nranks);
+        for (int q = 0; q < S.nranks; ++q) {
+            memcpy(&allb[(size_t)q], all.data() + BLOB * (size_t)q, sizeof(e2s_boundary));
+            memcpy(&alls[(size_t)q], all.data() + BLOB * (size_t)q + sizeof(e2s_boundary), sizeof(e2s_scan_stats));
         }
-    }
-    // the second exchange: events per rank, for sequential ids
-    std::vector<uint8_t> alle;
-    const uint64_t mine2[2] = {ne, need_host};
-    if (all_gather(S, r, mine2, 16, alle, d_send, d_recv, xs)) S.rc.store(E2S_ERR_HIP);
-    uint64_t before = 0; bool host_tail = false;
-    for (int q = 0; q < S.nranks; ++q) {
-        uint64_t v[2]; memcpy(v, alle.data() + 16 * (size_t)q, 16);
-        if (q < r) before += v[0];
-        host_tail |= v[1] != 0;
-    }
-    S.events[(size_t)r] = host_tail ? 0 : ne;
-    if (!S.rc.load() && !host_tail && n_cand) STEP(e2s_renumber_snp(h, 1 + before, &nb), "ids and text");
-    // ---- the files, rank by rank ----
-    S.cl_turn.wait_for(r);
-    if (!S.rc.load()) { uint64_t w = 0; STEP(e2s_stream_clusters(h, fd_sink, &S.cl_fd, &w), "write .clusters"); }
-    S.cl_turn.next();
-    S.snp_turn.wait_for(r);
-    if (!S.rc.load() && host_tail) {
-        S.host_tail = true;
-        const void* st = nullptr; const uint32_t* of = nullptr; uint64_t nc2 = 0, bytes = 0; uint32_t pw = 4;
-        if (n_cand) STEP(e2s_candidates_packed(h, &st, &of, &nc2, &bytes, &pw), "packed candidates");
-        if (!S.rc.load() && n_cand) {
-            const uint64_t base8 = S.pk_stream.size() / 8;
-            if (base8 + bytes / 8 >= (1ull << 32)) S.rc.store(E2S_ERR_CAPACITY);
-            else {
-                S.pk_stream.insert(S.pk_stream.end(), (const uint8_t*)st, (const uint8_t*)st + bytes);
-                for (uint64_t i = 0; i < nc2; ++i) S.pk_off8.push_back((uint32_t)(base8 + of[i]));
-                S.pk_pw = pw;
+        if (!mine_rc) {
+            STEP(e2s_stitch(h, allb.data(), S.nranks, r), "stitch");
+            uint64_t nc = 0, nrec = 0;
+            STEP(e2s_cluster_counts(h, &nc, &nrec), "counts");
+            S.closed[(size_t)r] = nc;
+            STEP(e2s_pack_clusters(h, 1), "pack .clusters");           // on the second stream, beside the per-cluster pass
+            // ---- clust2snp: statistics (pure function of the gathered array), per-cluster pass, tail ----
+            uint64_t n_clust = 0, n_bases = 0;
+            const int rc = e2s_auto_max_clust_length_ranks(allb.data(), alls.data(), S.nranks, n, o.k, o.lcp, o.mcov_out, o.pval, &mcl, &n_clust, &n_bases);
+            if (rc == E2S_ERR_REF_CRASH) { int z = 0; S.crash.compare_exchange_strong(z, 136); }      // (the same on every rank: the statistics are the merged ones)
+            else if (rc && !mine_rc) mine_rc = rc;
+            if (r == 0) S.mcl = mcl;
+        }
+        if (!mine_rc && !S.crash.load()) {
+            e2s_c2s_params prm{};
+            prm.nr_reads1 = o.nr_reads1; prm.k_left = o.k_left; prm.k_right = o.k_right; prm.mcov_out = o.mcov_out;
+            prm.consensus_reads = o.consensus_reads; prm.max_clust_length = mcl; prm.min_len = o.min_len;
+            STEP(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand), "find candidates");
+            if (!mine_rc && n_cand) {
+                e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
+                const int trc = e2s_call_variants(h, &tp, 0, &nv, &ne, &nb);   // (first_id 0: the text is written once, after the exchange below)
+                if (trc == E2S_ERR_STATE) { need_host = 1; ne = 0; }
+                else if (trc == E2S_ERR_REF_CRASH) { int z = 0; S.crash.compare_exchange_strong(z, 139); ne = 0; }    // the reference's SIGSEGV / throw
+                else STEP(trc, "tail (consensus, distance, text)");
             }
         }
-    } else if (!S.rc.load() && ne) {
-        if (!S.snp_f) S.snp_f = fopen(S.snp_path.c_str(), "w");   // (comes into being with the first event: nothing where the reference crashes)
-        if (!S.snp_f) S.rc.store(E2S_ERR_IO); else STEP(e2s_stream_snp(h, file_sink, S.snp_f), "write .snp");
+        // the second exchange: events per rank, for sequential ids
+        if (!agree(S, r, mine_rc)) { leave(); return; }
+        std::vector<uint8_t> alle;
+        const uint64_t mine2[2] = {ne, need_host};
+        if (all_gather(S, r, mine2, 16, alle, d_send, d_recv, xs)) mine_rc = E2S_ERR_HIP;
+        uint64_t before = 0;
+        for (int q = 0; q < S.nranks && !mine_rc; ++q) {
+            uint64_t v[2]; memcpy(v, alle.data() + 16 * (size_t)q, 16);
+            if (q < r) before += v[0];
+            host_tail |= v[1] != 0;
+        }
+        if (!mine_rc && !host_tail && n_cand) STEP(e2s_renumber_snp(h, 1 + before, &nb), "ids and text");
     }
-    S.snp_turn.next();
-    if (d_send) (void)hipFree(d_send);
-    if (d_recv) (void)hipFree(d_recv);
-    if (xs) (void)hipStreamDestroy(xs);
-    if (h) e2s_destroy(h);
+    S.cands[(size_t)r] = n_cand;
+    S.events[(size_t)r] = host_tail ? 0 : ne;
+    // ---- the files: every rank learns every rank's sizes through this process's memory, then all write at once ----
+    uint64_t my_records = 0;
+    if (!mine_rc) { const void* img = nullptr; STEP(e2s_clusters_image(h, &img, &my_records), ".clusters image"); }
+    S.cl_records[(size_t)r] = my_records;
+    S.snp_bytes[(size_t)r] = (host_tail || !ne) ? 0 : nb;
+    if (host_tail && !mine_rc && n_cand) {                          // the packed candidates, for ONE host tail over all ranks (main thread)
+        const void* st = nullptr; const uint32_t* of = nullptr; uint64_t nc2 = 0, bytes = 0; uint32_t pw = 4;
+        STEP(e2s_candidates_packed(h, &st, &of, &nc2, &bytes, &pw), "packed candidates");
+        if (!mine_rc) {
+            S.pk_stream[(size_t)r].assign((const uint8_t*)st, (const uint8_t*)st + bytes);
+            S.pk_off8[(size_t)r].assign(of, of + nc2);
+            S.pk_pw = pw;
+        }
+    }
+    if (host_tail) S.host_tail = true;
+    if (!agree(S, r, mine_rc)) { leave(); return; }
+    if (S.crash.load()) S.snp_bytes[(size_t)r] = 0;                 // (no `.snp` where the reference's clust2snp dies)
+    S.bar->wait();
+    uint64_t cl_at = 0, snp_at = 0, snp_total = 0;
+    for (int q = 0; q < S.nranks; ++q) { if (q < r) { cl_at += S.cl_records[(size_t)q] * 10; snp_at += S.snp_bytes[(size_t)q]; } snp_total += S.snp_bytes[(size_t)q]; }
+    if (r == 0 && snp_total) {                                      // (the `.snp` comes into being with the first event: nothing where the reference crashes)
+        S.snp_fd = ::open(S.snp_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (S.snp_fd < 0) mine_rc = E2S_ERR_IO;
+    }
+    if (!agree(S, r, mine_rc)) { leave(); return; }
+    if (my_records) { PSink ps{S.cl_fd, cl_at}; uint64_t w = 0; STEP(e2s_stream_clusters(h, pwrite_sink, &ps, &w), "write .clusters"); }
+    if (S.snp_bytes[(size_t)r]) { PSink ps{S.snp_fd, snp_at}; STEP(e2s_stream_snp(h, pwrite_sink, &ps), "write .snp"); }
+    (void)agree(S, r, mine_rc);
+    leave();
 }
 
 void help() {
@@ -272,6 +347,13 @@ int main(int argc, char** argv) {
     Barrier bar(S.nranks);
     S.bar = &bar;
     S.closed.assign((size_t)S.nranks, 0); S.cands.assign((size_t)S.nranks, 0); S.events.assign((size_t)S.nranks, 0);
+    S.cl_records.assign((size_t)S.nranks, 0); S.snp_bytes.assign((size_t)S.nranks, 0); S.status.assign((size_t)S.nranks, 0); S.form.assign((size_t)S.nranks, 0);
+    S.pk_stream.resize((size_t)S.nranks); S.pk_off8.resize((size_t)S.nranks);
+    if (const char* e = getenv("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
+    S.fail_at = getenv("E2S_MGPU_FAIL_AT") ? getenv("E2S_MGPU_FAIL_AT") : "setup";
+    // the reads: ONE index of the FASTA for all ranks (an irregular or unreadable file: no GPU tail, the host tail decides)
+    e2s_fasta_index* fix = nullptr;
+    S.reads_ok = e2s_fasta_index_open(o.input.c_str(), &fix, &S.rd_text, &S.rd_bytes, &S.rd_start, &S.rd_len, &S.rd_n, &S.rd_max) == E2S_OK && S.rd_n > 0;
     const std::string cl_path = o.input + ".clusters";
     S.cl_fd = ::open(cl_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
     S.snp_path = o.input.substr(0, o.input.rfind(".fast")) + ".snp";
@@ -281,17 +363,30 @@ int main(int argc, char** argv) {
     for (int r = 1; r < S.nranks; ++r) th.emplace_back(rank_main, std::ref(S), r);
     rank_main(S, 0);
     for (auto& t : th) t.join();
+    if (fix) e2s_fasta_index_close(fix);
     if (S.cl_fd >= 0) ::close(S.cl_fd);
-    if (S.snp_f) fclose(S.snp_f);
+    if (S.snp_fd >= 0) ::close(S.snp_fd);
     for (auto& c : S.comms) ncclCommDestroy(c);
+    if (S.rc.load()) ::unlink(cl_path.c_str());                  // (a job that failed leaves no half-written `.clusters` behind)
+    if (!S.rc.load() && S.crash.load()) S.rc.store(S.crash.load());   // (ebwt2clust's file stays, as after the reference's two runs)
     uint64_t closed = 0, cands = 0, events = 0;
     for (int r = 0; r < S.nranks; ++r) { closed += S.closed[(size_t)r]; cands += S.cands[(size_t)r]; events += S.events[(size_t)r]; }
-    if (!S.rc.load() && S.host_tail && !S.pk_off8.empty()) {
-        S.pk_off8.push_back((uint32_t)(S.pk_stream.size() / 8));
-        e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
-        uint64_t nv = 0;
-        const int trc = e2s_snp_from_packed(S.pk_stream.data(), S.pk_off8.data(), S.pk_off8.size() - 1, S.pk_pw, &tp, o.input.c_str(), S.snp_path.c_str(), &nv, &events);
-        if (trc) { std::cerr << "host tail failed (" << trc << ")" << std::endl; S.rc.store(trc == E2S_ERR_REF_CRASH ? 139 : trc); }
+    if (!S.rc.load() && S.host_tail && !S.crash.load()) {
+        // every rank's packed candidates, in rank order = SA order, through ONE host tail
+        std::vector<uint8_t> st; std::vector<uint32_t> of;
+        for (int r = 0; r < S.nranks && !S.rc.load(); ++r) {
+            const uint64_t base8 = st.size() / 8;
+            if (base8 + S.pk_stream[(size_t)r].size() / 8 >= (1ull << 32)) { S.rc.store(E2S_ERR_CAPACITY); break; }
+            st.insert(st.end(), S.pk_stream[(size_t)r].begin(), S.pk_stream[(size_t)r].end());
+            for (uint32_t v : S.pk_off8[(size_t)r]) of.push_back((uint32_t)(base8 + v));
+        }
+        if (!S.rc.load() && !of.empty()) {
+            of.push_back((uint32_t)(st.size() / 8));
+            e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
+            uint64_t nv = 0;
+            const int trc = e2s_snp_from_packed(st.data(), of.data(), of.size() - 1, S.pk_pw, &tp, o.input.c_str(), S.snp_path.c_str(), &nv, &events);
+            if (trc) { std::cerr << "host tail failed (" << trc << ")" << std::endl; S.rc.store(trc == E2S_ERR_REF_CRASH ? 139 : trc); }
+        }
     }
     const int rc = S.rc.load();
     if (rc == 139) { std::cerr << "the reference crashes on this input in its tail; no .snp written" << std::endl; return 139; }

@@ -14,26 +14,50 @@
 #include "../../include/e2s_hip.h"
 #include "fasta_index.hpp"
 
+struct e2s_fasta_index {                                          // the mapped file and its index (e2s_fasta_index_open)
+    int fd = -1; void* map = nullptr; size_t n = 0;
+    FastaIndex ix;
+    ~e2s_fasta_index() { if (map) munmap(map, n); if (fd >= 0) ::close(fd); }
+};
+extern "C" void e2s_internal_set_error(e2s_handle h, const char* msg);
+
+extern "C" int e2s_fasta_index_open(const char* fasta_path, e2s_fasta_index** out, const void** text, uint64_t* text_bytes, const uint64_t** start,
+                                    const uint32_t** len, uint64_t* n_reads, uint32_t* max_len) {
+    if (!fasta_path || !out) return E2S_ERR_ARG;
+    *out = nullptr;
+    e2s_fasta_index* f = new e2s_fasta_index();
+    f->fd = ::open(fasta_path, O_RDONLY);
+    if (f->fd < 0) { delete f; return E2S_ERR_IO; }
+    struct stat st;
+    if (fstat(f->fd, &st) != 0 || st.st_size == 0) { const int rc = st.st_size == 0 ? E2S_ERR_INPUT : E2S_ERR_IO; delete f; return rc; }
+    f->n = (size_t)st.st_size;
+    f->map = mmap(nullptr, f->n, PROT_READ, MAP_PRIVATE, f->fd, 0);
+    if (f->map == MAP_FAILED) { f->map = nullptr; delete f; return E2S_ERR_IO; }
+    madvise(f->map, f->n, MADV_SEQUENTIAL);
+    const int env = getenv("E2S_TAIL_THREADS") ? atoi(getenv("E2S_TAIL_THREADS")) : 0;
+    const unsigned T = env > 0 ? (unsigned)env : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (!e2s_index_fasta((const uint8_t*)f->map, f->n, T, f->ix)) { delete f; return E2S_ERR_INPUT; }      // irregular line structure: the host tail decides
+    if (text) *text = f->ix.text;
+    if (text_bytes) *text_bytes = f->ix.text_bytes;
+    if (start) *start = f->ix.start.data();
+    if (len) *len = f->ix.len.data();
+    if (n_reads) *n_reads = f->ix.start.size();
+    if (max_len) *max_len = f->ix.max_len;
+    *out = f;
+    return E2S_OK;
+}
+extern "C" void e2s_fasta_index_close(e2s_fasta_index* ix) { delete ix; }
+
 extern "C" int e2s_upload_reads_fasta(e2s_handle h, const char* fasta_path, uint64_t* n_reads) {
     if (!h || !fasta_path) return E2S_ERR_ARG;
     if (n_reads) *n_reads = 0;
-    const int fd = ::open(fasta_path, O_RDONLY);
-    if (fd < 0) return E2S_ERR_IO;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size == 0) { ::close(fd); return st.st_size == 0 ? E2S_ERR_INPUT : E2S_ERR_IO; }
-    const size_t n = (size_t)st.st_size;
-    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (m == MAP_FAILED) { ::close(fd); return E2S_ERR_IO; }
-    madvise(m, n, MADV_SEQUENTIAL);
-    const int env = getenv("E2S_TAIL_THREADS") ? atoi(getenv("E2S_TAIL_THREADS")) : 0;
-    const unsigned T = env > 0 ? (unsigned)env : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    FastaIndex ix;
-    int rc = E2S_ERR_INPUT;                                      // irregular line structure: the host tail decides
-    if (e2s_index_fasta((const uint8_t*)m, n, T, ix))
-        rc = e2s_upload_reads(h, ix.text, ix.text_bytes, ix.start.data(), ix.len.data(), ix.start.size(), ix.max_len);
-    if (rc == E2S_OK && n_reads) *n_reads = ix.start.size();
-    munmap(m, n);
-    ::close(fd);
+    e2s_fasta_index* f = nullptr;
+    const void* text = nullptr; uint64_t tb = 0, nr = 0; const uint64_t* st = nullptr; const uint32_t* ln = nullptr; uint32_t ml = 0;
+    int rc = e2s_fasta_index_open(fasta_path, &f, &text, &tb, &st, &ln, &nr, &ml);
+    if (rc) return rc;
+    rc = e2s_upload_reads(h, text, tb, st, ln, nr, ml);
+    if (rc == E2S_OK && n_reads) *n_reads = nr;
+    e2s_fasta_index_close(f);
     return rc;
 }
 
@@ -57,5 +81,10 @@ extern "C" int e2s_write_snp(e2s_handle h, const e2s_tail_params* p, const char*
     const void* stream = nullptr; const uint32_t* off8 = nullptr; uint64_t n_cand = 0, bytes = 0; uint32_t pw = 4;
     rc = e2s_candidates_packed(h, &stream, &off8, &n_cand, &bytes, &pw);
     if (rc) return rc;
-    return e2s_snp_from_packed(stream, off8, n_cand, pw, p, fasta_path, out_path, n_variants, n_events);
+    rc = e2s_snp_from_packed(stream, off8, n_cand, pw, p, fasta_path, out_path, n_variants, n_events);
+    // (the host tail has no handle and no text: the handle's message says what ITS code means, not what some earlier call left there)
+    if (rc == E2S_ERR_REF_CRASH) e2s_internal_set_error(h, "host tail: the reference crashes on this input (no candidate, one read rank in all, a negative -L or a right context beyond its read); nothing written");
+    else if (rc == E2S_ERR_IO) e2s_internal_set_error(h, "host tail: the FASTA cannot be read or the output cannot be written");
+    else if (rc) e2s_internal_set_error(h, "host tail failed");
+    return rc;
 }

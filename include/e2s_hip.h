@@ -266,6 +266,12 @@ int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const 
                      uint32_t max_len);
 int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len);
 int e2s_upload_reads_fasta(e2s_handle h, const char* fasta_path, uint64_t* n_reads);
+/* Host only: the same index built ONCE for several handles to upload from (e2s_upload_reads with the arrays handed out here) -- what a
+ * driver of several GPUs does instead of parsing the file once per GPU.  E2S_ERR_INPUT for an irregular file (see above), E2S_ERR_IO. */
+typedef struct e2s_fasta_index e2s_fasta_index;
+int e2s_fasta_index_open(const char* fasta_path, e2s_fasta_index** out, const void** text, uint64_t* text_bytes, const uint64_t** start,
+                         const uint32_t** len, uint64_t* n_reads, uint32_t* max_len);
+void e2s_fasta_index_close(e2s_fasta_index* ix);
 /* extract_variants + distance + to_file (clust2snp.cpp:505-780) over the candidates of the last e2s_find_candidates, on the
  * GPU: one wave per candidate gathers the left contexts, builds the two consensus strings (cons' tie-break, include.hpp:334-371),
  * counts the supports, runs distance() and the KisSNP2 text of every event is written into an image in HBM, ids counting
@@ -365,7 +371,8 @@ typedef struct {
     int32_t rank, world;                 /* this shard's place in SA order; world <= 64 */
     e2s_c2s_options o;                   /* clust2snp's options */
     int32_t want_image;                  /* != 0: the `.clusters` image is laid out on the second stream beside the rest (e2s_clusters_image waits for it) */
-    int32_t reserved;
+    int32_t probe_only;                  /* != 0: only answer whether this form applies (E2S_OK / E2S_ERR_STATE), enqueue nothing -- for drivers whose
+                                            ranks agree on the form before any of them enters an exchange */
 } e2s_resident_params;
 int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_allgather_fn allgather, void* user, e2s_job_report* rep);
 

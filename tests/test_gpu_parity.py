@@ -927,6 +927,37 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
 
 
 @pytest.mark.gpu
+def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
+    """a rank that fails -- before the first exchange (setup) or right after its step (job) -- takes the whole job down with an error
+    instead of leaving the other ranks inside an all-gather: the ranks agree on their status before every exchange.  3 rehearsal
+    ranks on GPU 0 and the RCCL path with one rank; the process must END (timeout = hang) with a non-zero code and no `.snp`.
+    And where the reference's clust2snp dies (an -L longer than the context the reads share: exit 139) the driver exits 139 too,
+    leaving ebwt2clust's `.clusters` behind as the reference's two runs would"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "ebwt2snp_mgpu")
+    meta = [m for m in goldens.e2e_cases() if m["name"] == "c1_bcr"][0]
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    for ranks, shared in ((3, True), (1, False)):
+        for at in ("setup", "job"):
+            for f in (p + ".clusters", IO.snp_out_path(p)):
+                if os.path.exists(f):
+                    os.remove(f)
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FAIL_RANK=str(ranks - 1), E2S_MGPU_FAIL_AT=at)
+            r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
+            assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
+            assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
+    for ranks, shared in ((1, False), (3, True)):
+        env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0")
+        r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks), "-L", "90", "-R", "20"], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 139, (ranks, r.returncode, r.stdout[-300:], r.stderr[-300:])
+        assert not os.path.exists(IO.snp_out_path(p))
+        assert hashlib.sha256(open(p + ".clusters", "rb").read()).hexdigest() == meta["clusters_sha256"], ranks
+        os.remove(p + ".clusters")
+
+
+@pytest.mark.gpu
 def test_bench_two_rank_rehearsal_equals_one_rank():
     """bench.py's N-rank path with the HIP kernels in separate processes (E2S_BENCH_REHEARSAL=1: both ranks on GPU 0, gloo instead of
     RCCL): the SAME EGSA cut into two SA ranges (--scaling strong) gives exactly the one-rank totals -- records, records of the
