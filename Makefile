@@ -35,8 +35,23 @@ oracle:
 asm: $(CSRC)/e2s_kernels.hip
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build_kernels.s $(CSRC)/e2s_kernels.hip -Rpass-analysis=kernel-resource-usage
 
+# Sanitizer builds of the host code that walks pointers, maps files and runs worker threads (host tail, FASTA index) and of the oracle's C
+# restatement; tests/test_host_logic.py::test_sanitizer_builds_over_goldens runs the goldens through both (E2S_TAIL_THREADS=8).
+SAN_SRC = tests/san_driver.cpp $(HOST)/snp_tail.cpp $(HOST)/fasta_index.cpp
+sanitize: build/san_asan build/san_tsan
+build/san_oracle_asan.o: oracle/e2s_oracle.c oracle/e2s_oracle.h
+	@mkdir -p build
+	gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -c -o $@ oracle/e2s_oracle.c
+build/san_oracle_tsan.o: oracle/e2s_oracle.c oracle/e2s_oracle.h
+	@mkdir -p build
+	gcc -O1 -g -fsanitize=thread -c -o $@ oracle/e2s_oracle.c
+build/san_asan: $(SAN_SRC) build/san_oracle_asan.o include/e2s_hip.h
+	$(CXX) -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -o $@ $(SAN_SRC) build/san_oracle_asan.o -lpthread
+build/san_tsan: $(SAN_SRC) build/san_oracle_tsan.o include/e2s_hip.h
+	$(CXX) -O1 -g -std=c++17 -fsanitize=thread -Iinclude -o $@ $(SAN_SRC) build/san_oracle_tsan.o -lpthread
+
 clean:
-	rm -rf $(LIB) bin build_kernels.s
+	rm -rf $(LIB) bin build_kernels.s build/san_*
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib bins oracle asm clean
+.PHONY: all lib bins oracle asm clean sanitize

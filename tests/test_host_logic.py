@@ -308,3 +308,30 @@ def test_integration_snippets_compile():
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src_path],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_sanitizer_builds_over_goldens(tmp_path):
+    """`make sanitize`: the host tail (worker threads, mmap, pointer walks), the FASTA index and the oracle's C restatement built with
+    -fsanitize=address,undefined and with -fsanitize=thread, every end-to-end golden through both with 8 tail threads and the parallel
+    FASTA cut forced on (E2S_TAIL_PAR_MIN_BYTES=1): no report, and the host tail's bytes equal the oracle's, which equal the golden's"""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["make", "-C", ROOT, "-s", "sanitize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for meta in goldens.e2e_cases():
+        reads, n1, en = goldens.e2e_inputs(meta)
+        d = tmp_path / meta["name"]
+        d.mkdir()
+        p = goldens.write_case_files(meta, reads, en, str(d))
+        x, y, z = meta["xyz"]
+        e, a = meta["e2c"], meta["c2s"]
+        args = [p, str(n1), str(e.get("k", 0)), str(e.get("m", 0)), str(x), str(y), str(z), str(a.get("L", 0)), str(a.get("R", 0)), str(a.get("g", 0)),
+                str(a.get("c", 0)), str(a.get("e", 0)), str(a.get("m", 0)), str(a.get("p", 0.0))]
+        for exe, env in (("san_asan", {"ASAN_OPTIONS": "halt_on_error=1:detect_leaks=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"}),
+                         ("san_tsan", {"TSAN_OPTIONS": "halt_on_error=1:exitcode=66"})):
+            env = dict(os.environ, E2S_TAIL_THREADS="8", E2S_TAIL_PAR_MIN_BYTES="1", **env)
+            r = subprocess.run([os.path.join(ROOT, "build", exe)] + args, capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0 and r.stdout.startswith("ok:"), (meta["name"], exe, r.returncode, r.stdout[-500:], r.stderr[-3000:])
+            assert "runtime error" not in r.stderr and "Sanitizer" not in r.stderr, (meta["name"], exe, r.stderr[-3000:])
+            assert open(p + ".oracle.snp", "rb").read() == goldens.golden_snp(meta), meta["name"]
