@@ -44,11 +44,21 @@ WORKLOADS = {
     # 3.02e9 entries: ten copies of an exactly sorted 2x1M x150bp block laid end to end, read ids remapped per copy
     # ("C2-style block tiled with read-id remap") -- BASELINE.json configs[2], 21 GB of EGSA + 3 GB of reads in HBM
     "c3": (1000000, 150, 10),
+    "c3b": (1000000, 150),        # ONE block of c3 (3.02e8 entries): what the full-size tests compare with the reference
     "c3x": (1000000, 150, 15),    # 4.53e9 entries: SA positions beyond 2^32 on one GPU (stress check, 32 GB of EGSA)
     # BASELINE.json configs[4] on ONE GPU: 3.02e10 entries (211 GB of EGSA, more than HBM) streamed from host memory through the GPU in
     # 100 chunks by the library's chunked job (ebwt2snp_amd/host/chunked.cpp); PCIe-inclusive by construction, run with --workload c5s
     "c5s": (1000000, 150, 100),
+    # BASELINE.json configs[4] as it is meant: the same 3.02e10 entries cut into N SA ranges, every rank RESIDENT (--gpus N --scaling strong;
+    # 12.5 copies = 26 GB of EGSA + 30 GB of reads per rank at N = 8).  E2S_BENCH_C5_COPIES scales it down for a rehearsal on one GPU.
+    "c5": (1000000, 150, 100),
 }
+if os.environ.get("E2S_BENCH_C5_COPIES"):
+    WORKLOADS["c5"] = WORKLOADS["c5"][:2] + (int(os.environ["E2S_BENCH_C5_COPIES"]),)
+    WORKLOADS["c5s"] = WORKLOADS["c5s"][:2] + (int(os.environ["E2S_BENCH_C5_COPIES"]),)
+if os.environ.get("E2S_BENCH_C5_READS"):                            # (tests: a smaller block)
+    for _w in ("c5", "c5s"):
+        WORKLOADS[_w] = (int(os.environ["E2S_BENCH_C5_READS"]),) + WORKLOADS[_w][1:]
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -134,6 +144,40 @@ def shard_strong(blk, m, rank, world):
     return out, lo, hi - lo, hl, hr
 
 
+def shard_strong_tiled(blk0, n1_block, copies, rank, world):
+    """rank's SA range of `copies` blocks laid end to end (c3: 10, c5: 100 -- BASELINE.json configs[3] / [4]) WITHOUT building the whole
+    EGSA: the cuts near r * M / N (inside clusters: pick_cut on the block, the copies are alike), then only the range itself --
+    the end of one copy, whole copies, the beginning of another, with the halos -- with the read ids of every copy remapped as
+    tile_block does.  3x10^10 entries over 8 ranks: 12.5 copies = 26 GB per rank."""
+    m = blk0["lcp"].numel()
+    M = m * copies
+
+    def cut(r):
+        if r == 0:
+            return 0
+        if r == world:
+            return M
+        approx = (M * r) // world
+        b, off = divmod(approx, m)
+        c = pick_cut(blk0["lcp"], min(off, m - 200000))
+        return b * m + c
+    lo, hi = cut(rank), cut(rank + 1)
+    hl = min(152, lo)
+    hr = 1 if rank < world - 1 else 0
+    a, z = lo - hl, hi + hr                                       # provided range [a, z)
+    out = {k: [] for k in ("bwt", "lcp", "pos", "da")}
+    p = a
+    while p < z:
+        b, off = divmod(p, m)
+        ln = min(m - off, z - p)
+        for k in ("bwt", "lcp", "pos"):
+            out[k].append(blk0[k][off:off + ln])
+        da = blk0["da"][off:off + ln]
+        out["da"].append(torch.where(da < n1_block, da + b * n1_block, da - n1_block + copies * n1_block + b * n1_block))
+        p += ln
+    return {k: torch.cat(v).contiguous() for k, v in out.items()}, lo, hi - lo, hl, hr, M
+
+
 PHASES = {}
 _T = [0.0]
 
@@ -181,13 +225,13 @@ def _exchange(blob, world, dist, dev):
     return [raw[i * n:(i + 1) * n] for i in range(world)]
 
 
-def emulate_peers(blk, m, n1, rd, L, er, en_, local):
+def emulate_peers(shard_of, m, n1, rd, L, er, en_, local):
     """what the other ranks of an en_-way strong cut would publish: every rank's descriptor + statistics blob (one scan of its
     range each) and the events of the ranks before `er` (their whole step, with the gathered blobs)"""
     import ctypes
     blobs, events = [], []
     for q in range(en_):
-        arrs, g0, n_own, hl, hr = shard_strong(blk, m, q, en_)
+        arrs, g0, n_own, hl, hr = shard_of(q)
         torch.cuda.synchronize()
         h = capi.Handle(local)
         h.attach_soa(capi.Handle.desc(m, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr), arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(),
@@ -197,7 +241,7 @@ def emulate_peers(blk, m, n1, rd, L, er, en_, local):
         h.close()
         del arrs
     for q in range(er):
-        arrs, g0, n_own, hl, hr = shard_strong(blk, m, q, en_)
+        arrs, g0, n_own, hl, hr = shard_of(q)
         torch.cuda.synchronize()
         h = capi.Handle(local)
         h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
@@ -523,8 +567,13 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             dist.barrier()
     else:
         reads, n1_block, blk0 = build_block(R, L, dev)
-    blk, n1 = tile_block(blk0, n1_block, copies)
-    m = blk["lcp"].numel()
+    tiled_strong = copies > 1 and ((world > 1 and scaling == "strong") or bool(a.emulate_rank))
+    if tiled_strong:
+        blk, n1 = None, n1_block * copies                          # (the whole EGSA is never built: every rank materialises its own range)
+        m = blk0["lcp"].numel() * copies
+    else:
+        blk, n1 = tile_block(blk0, n1_block, copies)
+        m = blk["lcp"].numel()
     emul = None
     if a.emulate_rank:
         # ONE rank of the N-way strong cut (BASELINE.json configs[3]) on this GPU, with the N-rank bookkeeping: the other ranks'
@@ -532,14 +581,21 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         # of the timed step is a real one-rank RCCL all-gather whose result is completed with those cached blobs
         er, en_ = (int(v) for v in a.emulate_rank.split("/"))
         assert 0 <= er < en_ and world == 1
+
+        def shard_of(q):
+            if tiled_strong:
+                return shard_strong_tiled(blk0, n1_block, copies, q, en_)[:5]
+            return shard_strong(blk, m, q, en_)
         emul = dict(rank=er, world=en_)
-        emul.update(emulate_peers(blk, m, n1, tile_reads(reads.to(dev), n1_block, copies), L, er, en_, local))
-        arrs, g0, n_own, hl, hr = shard_strong(blk, m, er, en_)
+        emul.update(emulate_peers(shard_of, m, n1, tile_reads(reads.to(dev), n1_block, copies), L, er, en_, local))
+        arrs, g0, n_own, hl, hr = shard_of(er)
         n_total = m
-        del blk
+        blk = None
         torch.cuda.empty_cache()
     elif world == 1:
         arrs, g0, n_own, hl, hr, n_total = blk, 0, m, 0, 0, m      # (no copy)
+    elif tiled_strong:
+        arrs, g0, n_own, hl, hr, n_total = shard_strong_tiled(blk0, n1_block, copies, rank, world)
     elif scaling == "strong":
         arrs, g0, n_own, hl, hr = shard_strong(blk, m, rank, world)
         n_total = m
@@ -711,6 +767,10 @@ def main():
         if world == 1:
             run_c5s(a, dev)
         return
+    if a.workload == "c5":
+        a.scaling = "strong"                                       # (the job is ONE EGSA: its ranks share it out)
+        if world == 1 and not a.emulate_rank and WORKLOADS["c5"][2] * WORKLOADS["c5"][0] > 12 * 1000000:
+            sys.exit("c5 (3x10^10 entries) does not fit one GPU resident: --gpus N (strong cut), --emulate-rank r/N, or --workload c5s (chunked through one GPU)")
 
     res = measure_workload(a, a.workload, world, rank, local, dist, dev, a.steps, a.warmup, a.scaling, with_cpu=not a.emulate_rank)
     if a.emulate_rank:

@@ -1164,3 +1164,124 @@ def test_gpu_tail_fuzz_ragged_reads(H, tmp_path, seed, L):
             assert O.clust2snp(p, O.c2s_opts(1000, L=L, R=Rc, m=mcov))[0] == 0
         out[tag] = open(IO.snp_out_path(p), "rb").read()
     assert out["hip"] == out["orc"] and out["orc"].count(b">SNP_higher") > 50
+
+
+@pytest.mark.gpu
+def test_shard_beyond_2_pow_32_is_a_shifted_copy(tmp_path):
+    """BASELINE.json configs[4] (3x10^10 entries over 8 GPUs): a rank whose SA range lies beyond 2^32 -- global_offset, record starts,
+    the boundary descriptor's positions, (first end + 1) mod 2^16, the provisional record 0 and its stitched form.  Nothing in the
+    hot path depends on WHERE a shard lies except those positions, so the same columns are run twice as rank 1 of 3 -- at offset 152
+    of a small EGSA and at offset 2^32 + 987 654 of a 3.02x10^10-entry one, with the same (shifted) descriptor from the rank before
+    it -- and everything must come out shifted by the difference: uint64_t start / uint16_t length exactly as ebwt2clust.cpp:70-76,104
+    compute them.  Both forms of the step: the stepwise calls and e2s_resident_job (plans and statistics on the device)."""
+    import ctypes
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from ebwt2snp_amd import pipeline
+    dev = torch.device("cuda", 0)
+    reads, n1, e = synth.synth_case(2500, 100, seed=31, tail_lcp0=False)
+    en = synth.egsa_to_numpy(e)
+    n = en["lcp"].size
+    # the shard: everything but the last entry, 152 entries of left halo; make sure it BEGINS INSIDE a cluster (LCPs >= 16 around 152)
+    lcp = en["lcp"].copy()
+    lcp[140:170] = 25                                           # (flat: no end inside, the cluster runs through entry 152)
+    cols = {k2: torch.from_numpy(v).to(dev) for k2, v in (("bwt", en["bwt"]), ("lcp", lcp), ("pos", en["suff"].astype(np.uint8)), ("da", en["text"].astype(np.int32)))}
+    rd = reads.to(dev).contiguous()
+    torch.cuda.synchronize()
+    hl, hr = 152, 1
+    n_own = n - hl - hr
+    runs = {}
+    for tag, n_total, g0 in (("small", n, hl), ("far", 30_200_000_016, (1 << 32) + 987_654)):
+        shift = g0 - hl
+        prev = capi.Boundary()                                   # the rank before: a cluster open since 37 entries before its end
+        prev.n_ends = 11; prev.open_after = 1; prev.open_start = g0 - 37; prev.last_end_start = g0 - 900; prev.first_end_low16 = 77
+        prev.tail_lcp = 20; prev.tail_prev_lcp = 20
+        last = capi.Boundary()                                   # the rank after (the last one): nothing open, LCP 0 at the end
+        last.n_ends = 3; last.last_end_start = n_total - 500; last.first_end_low16 = 9; last.tail_bwt = 36
+        zero_stats = capi.ScanStats(); zero_stats.min_len = 2; zero_stats.last_none = 1
+        for form in ("stepwise", "native"):
+            h = capi.Handle(0)
+            h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], rd.shape[1], keep=(rd,))
+            h.attach_soa(capi.Handle.desc(n_total, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr), cols["bwt"].data_ptr(), cols["lcp"].data_ptr(),
+                         cols["pos"].data_ptr(), cols["da"].data_ptr(), keep=tuple(cols.values()))
+            blob0, blob2 = bytes(prev) + bytes(zero_stats), bytes(last) + bytes(zero_stats)
+            if form == "stepwise":
+                r = pipeline.resident_job(h, n1, n_total, 1, 3, lambda blob: [blob0, blob, blob2], ids_exchange=lambda ne: 5, native=False)
+            else:
+                b1 = np.zeros((3, capi.JOB_BLOB_BYTES), dtype=np.uint8)
+                b1[0, :len(blob0)] = np.frombuffer(blob0, dtype=np.uint8); b1[2, :len(blob2)] = np.frombuffer(blob2, dtype=np.uint8)
+                b2 = np.zeros((3, 2), dtype=np.uint64); b2[:, 1] = 1; b2[0, 0] = 5
+                emul = dict(rank=1, world=3, dev_blobs={capi.JOB_BLOB_BYTES: torch.from_numpy(b1.reshape(-1)).to(dev), 16: torch.from_numpy(b2.view(np.uint8).reshape(-1)).to(dev)})
+                bench._VIEWS.clear()
+                r = pipeline.resident_job(h, n1, n_total, 1, 3, allgather=bench.make_allgather(3, 1, None, dev, emul), native=True)
+                assert r.get("native")
+            b = h.boundary()
+            rec = h.fetch_clusters().view(IO.CLUSTER_DTYPE).copy()
+            runs[(tag, form)] = dict(r=r, b=b, rec=rec, snp=h.fetch_snp().tobytes(), shift=shift)
+            h.close()
+    A = runs[("small", "stepwise")]
+    assert A["b"].begins_inside == 1 and A["b"].n_ends > 3000 and A["r"]["n_cand"] > 5 and A["r"]["n_events"] > 3
+    for key in (("small", "native"), ("far", "stepwise"), ("far", "native")):
+        B = runs[key]
+        d = np.uint64(B["shift"] - A["shift"])
+        for f in ("n_ends", "begins_inside", "open_after", "pass_through", "end_before_last", "tail_lcp", "tail_prev_lcp"):
+            assert getattr(B["b"], f) == getattr(A["b"], f), (key, f)
+        for f in ("open_start", "last_end_start"):
+            va, vb = getattr(A["b"], f), getattr(B["b"], f)
+            assert (va == capi.E2S_NONE and vb == capi.E2S_NONE) or vb == va + int(d), (key, f)
+        assert B["b"].first_end_low16 == (A["b"].first_end_low16 + int(d)) & 0xFFFF, key
+        assert len(B["rec"]) == len(A["rec"]) == A["r"]["n_records"] == B["r"]["n_records"], key
+        assert np.array_equal(B["rec"]["start"], A["rec"]["start"] + d) and np.array_equal(B["rec"]["length"], A["rec"]["length"]), key
+        # record 0 is the stitched one: it starts 37 entries before the shard (beyond 2^32 in the far run)
+        assert int(B["rec"]["start"][0]) == B["shift"] + hl - 37 and (key[0] == "small" or int(B["rec"]["start"][0]) > (1 << 32)), key
+        for f in ("n_cand", "mcl", "n_events", "n_variants", "snp_bytes"):
+            assert B["r"][f] == A["r"][f], (key, f)
+        assert B["snp"] == A["snp"] and b">SNP_higher_path_6|" in A["snp"], key      # ids continue after the 5 events of the rank before
+
+
+def _bench_line(args, env=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_full_c3_and_chunked_c5s_are_multiples_of_the_block():
+    """BASELINE.json configs[2] at FULL size (3.02x10^9 entries resident) and the chunked job of configs[4] over 12 copies (3.6x10^9 entries
+    streamed through the GPU): the block -- compared with the reference's own output in test_full_size_outputs_equal_reference -- ends with
+    LCP 0, no cluster crosses a seam and the read ids are remapped per copy, so every total is the block's times the copies (the records
+    of the file up to the one record the EOF rule adds at the very end)"""
+    base = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--second-workload", ""]
+    one = _bench_line(base + ["--workload", "c3b"])["config"]
+    ten = _bench_line(base + ["--workload", "c3"])["config"]
+    assert ten["entries_total"] == 10 * one["entries_total"] == 3020000000
+    for key in ("cluster_records", "candidates", "snp_events"):
+        assert ten[key] == 10 * one[key] and one[key] > 1000, key
+    assert abs(ten["clusters_file_records"] - 10 * one["clusters_file_records"]) <= 12 and ten["max_clust_length"] == one["max_clust_length"]
+    c5s = _bench_line(["--workload", "c5s"], env={"E2S_BENCH_C5_COPIES": "12"})["config"]
+    assert c5s["entries_total"] == 12 * one["entries_total"] and c5s["chunks"] == 12
+    assert c5s["candidates"] == 12 * one["candidates"] and c5s["snp_events"] == 12 * one["snp_events"] and c5s["max_clust_length"] == one["max_clust_length"]
+    assert abs(c5s["clusters_file_records"] - 12 * one["clusters_file_records"]) <= 14 and c5s["clusters_bytes"] == 10 * c5s["clusters_file_records"]
+
+
+@pytest.mark.gpu
+def test_c5_strong_cut_rehearsal_equals_the_chunked_job():
+    """BASELINE.json configs[4] as a multi-rank workload (bench.py --workload c5 --gpus N: ONE EGSA of `copies` blocks cut into N SA ranges,
+    every rank materialising only its own range and keeping it resident), rehearsed with 2 ranks on GPU 0 (gloo) at 6 copies of a
+    quarter-size block: the totals of the two ranks equal those of the chunked one-GPU job (c5s) over the same EGSA -- records, file
+    records, candidates, events and the bytes of the `.snp` (ids sequential over the ranks)"""
+    env = {"E2S_BENCH_C5_COPIES": "6", "E2S_BENCH_C5_READS": "250000"}
+    one = _bench_line(["--workload", "c5s"], env=env)["config"]
+    two = _bench_line(["--workload", "c5", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--second-workload", ""],
+                      env=dict(env, E2S_BENCH_REHEARSAL="1"))
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["entries_total"] == one["entries_total"]
+    for a, b in (("clusters_file_records", "clusters_file_records"), ("candidates", "candidates"), ("snp_events", "snp_events"), ("snp_bytes", "snp_bytes"),
+                 ("max_clust_length", "max_clust_length")):
+        assert two["config"][a] == one[b], (a, two["config"][a], one[b])
+    assert one["snp_events"] > 1000
