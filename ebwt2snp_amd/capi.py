@@ -77,7 +77,7 @@ class Timing(C.Structure):
 # every symbol include/e2s_hip.h declares (checked by tests/test_capi_symbols.py)
 BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)     # e2s_byte_sink
 SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
-           "e2s_attach_soa", "e2s_upload_lcp", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
+           "e2s_attach_soa", "e2s_upload_lcp", "e2s_upload_lcp_bwt", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_stream_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",

@@ -84,6 +84,8 @@ struct e2s_ctx {
     uint32_t seg_blocks_cap = 0;
     SegArgs seg_args{}; uint32_t seg_row_entries = 4096; uint64_t* d_kept_off = nullptr;     // the last segmented scan's arguments (compaction, image layout)
     uint64_t* d_scan_stats = nullptr;                            // [151 freq | n_records | n_bases] tallied by the scan kernel (in front of d_words)
+    std::vector<uint64_t> host_fl_starts; std::vector<uint16_t> host_fl_lens;   // e2s_internal_flagged_list
+    uint8_t* d_compact = nullptr; size_t compact_bytes = 0; uint64_t* d_compact_keys = nullptr; uint64_t compact_keys_cap = 0;   // e2s_internal_find_candidates_compact
     bool ko_clean = false;                                       // the ordering pass's bucket counts are zero (its last kernel leaves them so)
     uint8_t* d_xchg = nullptr; size_t xchg_bytes = 0;            // e2s_resident_job: the two exchanges' send / receive buffers
     // the scan that writes the image itself (k_scan_seg<1, FUSED, true>): records live in d_img only, statistics come with the mail
@@ -250,7 +252,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);      // (a failed stream is torn down all the same)
     release_shard(h);
     dev_free(h->d_starts); dev_free(h->d_lens);
-    dev_free(h->d_scalars); dev_free(h->d_scan_stats); dev_free(h->d_kept_off); dev_free(h->d_xchg);
+    dev_free(h->d_scalars); dev_free(h->d_scan_stats); dev_free(h->d_kept_off); dev_free(h->d_xchg); dev_free(h->d_compact); dev_free(h->d_compact_keys);
     dev_free(h->d_wrap); dev_free(h->d_fl_starts); dev_free(h->d_fl_lens);
     if (h->pin_cand) pin_free(h->pin_cand);
     if (h->pin_mail) pin_free(h->pin_mail);
@@ -457,6 +459,35 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
     }
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
+    CK(hipGetLastError());
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    return narrow_lcp(h);
+}
+
+extern "C" int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const void* lcp, const void* bwt) {
+    dbg_entry("e2s_upload_lcp_bwt");
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if (!lcp || !bwt) return fail(h, E2S_ERR_ARG, "null source pointer");
+    CK(hipSetDevice(h->device));
+    release_shard(h);
+    set_shard_common(h, d);
+    h->layout = 0;
+    const uint64_t n = h->n_prov;
+    CK(hipEventRecord(h->ev[0], h->stream));
+    if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
+    if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
+    CK(hipMemcpyAsync(h->bwt, bwt, n, hipMemcpyHostToDevice, h->stream));
+    DevScratch stage;
+    if (d->lcp_bytes == 8) {
+        CK(stage.alloc(n * 8));
+        CK(hipMemcpyAsync(stage.p, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        e2s_launch_narrow8((const uint8_t*)stage.p, n, (uint32_t*)h->lcp, h->stream);
+        LCHK("e2s_launch_narrow8");
+    } else CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
+    CK(hipEventRecord(h->ev[1], h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    stage.release();
     CK(hipGetLastError());
     ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
     return narrow_lcp(h);
@@ -1508,9 +1539,11 @@ static int cand_record_pass(e2s_ctx* h, const CandArgs& a, const e2s_c2s_params*
 
 // SA order and offsets follow without a host round trip (the kernels read the candidate count on the device); the last kernel
 // writes counts and error words into the pinned mailbox
-static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nullptr, unsigned long long* zero = nullptr, uint64_t n_zero = 0) {
+static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nullptr, unsigned long long* zero = nullptr, uint64_t n_zero = 0,
+                               uint64_t key_lo = ~0ull, uint64_t key_span = 0) {
     const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
-    e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, h->prov_lo << 2, (h->n_prov + 1) << 2, h->d_rank,
+    if (key_lo == ~0ull) { key_lo = h->prov_lo << 2; key_span = (h->n_prov + 1) << 2; }       // keys = (SA position << 2) | pair, spread over the shard's range
+    e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, key_lo, key_span, h->d_rank,
                           h->d_order, h->stream, true);
     LCHK("e2s_launch_cand_order");
     void* dev_mail = nullptr;
@@ -1936,6 +1969,122 @@ extern "C" int e2s_fetch_snp(e2s_handle h, void* out, uint64_t cap_bytes, uint64
     if (cap_bytes < h->snp_bytes) return fail(h, E2S_ERR_CAPACITY, "`.snp` output too small");
     CK(hipSetDevice(h->device));
     return copy_image_out(h, h->d_snp, h->snp_bytes, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (private, ebwt2snp_amd/host/chunked.cpp) the chunked jobs upload 2 bytes per entry: the clusters the pre-filter lets through come
+// back to the host as a list, their entries are gathered there from all four columns and go through the per-cluster pass in a
+// compact buffer
+// ---------------------------------------------------------------------------------------------
+// the list the pre-filter inside the last scan left (behind the seed slots), copied to the host; *needs_full: this shard has clusters
+// only the full path handles (lengths that wrapped the u16, a window too dense for the pre-filter's queue, a list that overflowed)
+extern "C" int e2s_internal_flagged_list(e2s_handle h, const uint64_t** starts, const uint16_t** lens, uint64_t* n, int* needs_full) {
+    if (!h || !starts || !lens || !n || !needs_full) return E2S_ERR_ARG;
+    *n = 0; *needs_full = 0;
+    if (!h->scanned || !h->pf_inflight || !h->pf_fused || h->pf_gen != h->scan_gen) return fail(h, E2S_ERR_STATE, "no pre-filter result of this scan (e2s_prefilter_arm + e2s_cluster_scan)");
+    CK(hipSetDevice(h->device));
+    uint64_t* mb = (uint64_t*)(h->pin_mail + 3400);
+    CK(hipMemcpyAsync(mb, h->d_scalars + 2, 8, hipMemcpyDeviceToHost, h->stream));
+    CK(hipMemcpyAsync(mb + 1, h->d_words + 20, 4, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    const uint64_t cnt = mb[0]; const uint32_t perr = *(const uint32_t*)(mb + 1);
+    if (cnt > h->fl_cap || (perr & E2S_DEVERR_DENSE) || !h->wrap_ranks.empty() || h->wrap_overflow || h->first_wrapped) { *needs_full = 1; return E2S_OK; }
+    const uint64_t m = cnt > E2S_SEED_SLOTS ? cnt - E2S_SEED_SLOTS : 0;
+    h->host_fl_starts.resize(m); h->host_fl_lens.resize(m);
+    if (m) {
+        CK(hipMemcpyAsync(h->host_fl_starts.data(), h->d_fl_starts + E2S_SEED_SLOTS, m * 8, hipMemcpyDeviceToHost, h->stream));
+        CK(hipMemcpyAsync(h->host_fl_lens.data(), h->d_fl_lens + E2S_SEED_SLOTS, m * 2, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+    }
+    *starts = h->host_fl_starts.data(); *lens = h->host_fl_lens.data(); *n = m;
+    return E2S_OK;
+}
+// the entry read_el hands out past EOF inside clust2snp, from the last real entry (slot model, see phantom_entry)
+extern "C" void e2s_internal_phantom(int lcp_bytes, int da_bytes, int pos_bytes, int gesa_layout, uint32_t text, uint32_t suff, uint32_t lcp, uint32_t bwt, uint32_t out[4]) {
+    e2s_ctx tmp;
+    tmp.d.lcp_bytes = lcp_bytes; tmp.d.da_bytes = da_bytes; tmp.d.pos_bytes = pos_bytes; tmp.layout = gesa_layout;
+    phantom_entry(&tmp, text, suff, lcp, bwt, &out[0], &out[1], &out[2], &out[3]);
+}
+// find_variants (clust2snp.cpp:367-500) over n_cl clusters whose entries lie GATHERED in compact host columns of default widths
+// (bwt 1, lcp 1, pos 1, da 4 bytes per entry): cluster i = entries [off[i], off[i] + len[i]) of them, its place in SA order =
+// gstart[i] (ascending).  The candidates are left as e2s_find_candidates leaves them (e2s_call_variants / e2s_candidates_packed follow).
+extern "C" int e2s_internal_find_candidates_compact(e2s_handle h, const e2s_c2s_params* p, uint64_t n_cl, const uint64_t* gstart, const uint64_t* off,
+                                                    const uint16_t* len, const uint8_t* bwt, const uint8_t* lcp, const uint8_t* pos, const uint32_t* da,
+                                                    uint64_t n_entries, uint64_t key_lo, uint64_t key_span, uint64_t* n_cand) {
+    if (!h || !p || (n_cl && (!gstart || !off || !len || !bwt || !lcp || !pos || !da))) return E2S_ERR_ARG;
+    CK(hipSetDevice(h->device));
+    release_shard(h);                                           // (this handle holds compact clusters, no SA range)
+    h->xb = 1; h->yb = 4; h->zb = 1; h->d = e2s_shard_desc{}; h->d.lcp_bytes = 1; h->d.da_bytes = 4; h->d.pos_bytes = 1; h->prov_lo = 0; h->n_prov = n_entries;
+    h->n_rec = n_cl; h->n_ends = n_cl; h->n_closed = n_cl; h->segmented = false; h->img_mode = false; h->plan = e2s_stitch_plan_t{};
+    h->scanned = true; h->stitched = true; h->records_from_file = true; h->min_len = 0;
+    h->variants_valid = false; h->cand_host_valid = false; h->n_cand = 0;
+    if (n_cand) *n_cand = 0;
+    if (!n_cl) { h->cand_downloaded = false; return E2S_OK; }
+    int rc;
+    // device buffers: the compact columns (one allocation), the list (starts = offsets, lengths) and the keys
+    const size_t o_bwt = 0, o_lcp = (n_entries + 255) & ~(size_t)255, o_pos = 2 * o_lcp, o_da = 3 * o_lcp, need = o_da + n_entries * 4 + 256;
+    if (need > h->compact_bytes) {
+        dev_free(h->d_compact); h->d_compact = nullptr; h->compact_bytes = 0;
+        CK(hipMalloc((void**)&h->d_compact, need + need / 4));
+        h->compact_bytes = need + need / 4;
+    }
+    if (n_cl + 8 > h->compact_keys_cap) {
+        dev_free(h->d_compact_keys); h->d_compact_keys = nullptr; h->compact_keys_cap = 0;
+        CK(hipMalloc((void**)&h->d_compact_keys, (n_cl + n_cl / 4 + 64) * 8));
+        h->compact_keys_cap = n_cl + n_cl / 4 + 56;
+    }
+    if ((rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, n_cl + 64)))) return rc;
+    CK(hipMemcpyAsync(h->d_compact + o_bwt, bwt, n_entries, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_compact + o_lcp, lcp, n_entries, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_compact + o_pos, pos, n_entries, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_compact + o_da, da, n_entries * 4, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_fl_starts, off, n_cl * 8, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_fl_lens, len, n_cl * 2, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_compact_keys, gstart, n_cl * 8, hipMemcpyHostToDevice, h->stream));
+    CandArgs a{};
+    a.bwt = h->d_compact + o_bwt; a.lcp = h->d_compact + o_lcp; a.pos = h->d_compact + o_pos; a.da = h->d_compact + o_da; a.xb = 1; a.yb = 4; a.zb = 1;
+    a.prov_lo = 0; a.prov_hi = n_entries; a.n_total = ~0ull >> 2;                       // (an EOF phantom entry, if a cluster holds one, was gathered like any other)
+    a.nr_reads1 = p->nr_reads1;
+    a.k_left_u = (uint64_t)(int64_t)p->k_left; a.k_right_u = (uint64_t)(int64_t)p->k_right;
+    a.k_left_lo = (uint32_t)p->k_left; a.mcov_u = (uint32_t)p->mcov_out;
+    a.len_lo = c2s_len_lo(p->mcov_out, p->min_len);
+    a.len_hi = std::min(p->max_clust_length, (int)E2S_MAX_CLUST_LEN);
+    a.list_cap = list_cap_of(p);
+    a.stride = (uint32_t)(sizeof(e2s_cand_header) + (size_t)4 * a.list_cap * sizeof(uint32_t));
+    a.cand_count = (unsigned long long*)(h->d_scalars + 1);
+    a.err = h->d_words + 1;
+    a.pos_pack = 1u;
+    a.blocks_hint = n_cl > 200000 ? 4096u : 1024u;
+    a.keys = h->d_compact_keys;
+    h->list_cap = a.list_cap; h->cand_stride = a.stride; h->pos_pack = a.pos_pack;
+    uint64_t want = std::max<uint64_t>(std::max<uint64_t>(4096, n_cl), h->cand_cap);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if ((rc = cand_buffers(h, a, want))) return rc;
+        a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap;
+        CK(hipMemcpyAsync(h->d_scalars + 2, &n_cl, 8, hipMemcpyHostToDevice, h->stream));        // the list's length
+        CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));
+        CK(hipEventRecord(h->ev[6], h->stream));
+        e2s_launch_cand_init((unsigned long long*)(h->d_scalars + 1), a.stream8_count, h->d_words + 1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, false,
+                             (uint32_t*)h->d_rank, e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);
+        CK(hipEventRecord(h->ev[4], h->stream));
+        e2s_launch_flagged_lists(a, nullptr, (const unsigned long long*)(h->d_scalars + 2), true, h->stream);
+        LCHK("e2s_launch_flagged_lists");
+        CK(hipEventRecord(h->ev[7], h->stream));
+        if ((rc = cand_order_and_mail(h, a, nullptr, nullptr, 0, key_lo << 2, (key_span + 1) << 2))) return rc;
+        CK(wait_stream(h));
+        CK(hipGetLastError());
+        const uint64_t* mb = (const uint64_t*)(h->pin_mail + 3328);
+        const uint64_t count = mb[0];
+        const uint32_t err = ((const uint32_t*)(mb + 2))[0];
+        if (err & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a gathered cluster reaches outside the compact buffer");
+        if (mb[3] * 8 > h->stream_cap_bytes) { h->stream_per_cand = a.stride; continue; }
+        if (count > h->cand_cap) { want = count + 1024; continue; }
+        h->n_flagged = n_cl; h->stream8_used = mb[3];
+        cand_accept(h, a, count, 4);
+        if (n_cand) *n_cand = count;
+        return E2S_OK;
+    }
+    return fail(h, E2S_ERR_CAPACITY, "candidate buffer overflow (compact pass)");
 }
 
 // ---------------------------------------------------------------------------------------------

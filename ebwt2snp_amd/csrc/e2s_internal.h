@@ -152,6 +152,7 @@ struct CandArgs {
     uint32_t blocks_hint;                           // k_flagged_lists: blocks to launch (0: 1024)
     uint64_t record_index_base;
     uint32_t* err;
+    const uint64_t* keys;                           // k_flagged_lists: SA-order key of list entry r (nullptr: its start) -- clusters gathered into a compact buffer
     const int* len_hi_dev;                          // k_flagged_lists: the upper length bound lives on the device (the resident job: max_clust_length is worked out there)
 };
 

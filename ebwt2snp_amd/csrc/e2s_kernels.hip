@@ -2020,14 +2020,14 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
     const u64 per_round = (u64)gridDim.x * 4;
     // a wave's list entry for the NEXT round is fetched while it works on the current one (a round is a chain of dependent
     // memory latencies: entry -> EGSA columns -> ...; the block's four waves meet at the barrier below every round)
-    u64 s_nx = 0; int len_nx = 0;
-    { const u64 r0 = first + (u64)blockIdx.x * 4 + wave; if (r0 < n) { s_nx = a.starts[r0]; len_nx = (int)a.lens[r0]; } }
+    u64 s_nx = 0, k_nx = 0; int len_nx = 0;
+    { const u64 r0 = first + (u64)blockIdx.x * 4 + wave; if (r0 < n) { s_nx = a.starts[r0]; len_nx = (int)a.lens[r0]; k_nx = a.keys ? a.keys[r0] : s_nx; } }
     for (u64 base = first + (u64)blockIdx.x * 4; base < n; base += per_round) {
         // (flushing earlier to start the PCIe stream sooner was tried: chunks of ~8 records ran 25 % slower)
         if (s_nstage > (u32)FW_STAGE - 16u || s_used8 + 16u * max8 > cap8) stage_flush();
         const u64 r = base + wave;
-        const u64 s = s_nx; const int len = len_nx;
-        { const u64 rn = r + per_round; if (rn < n) { s_nx = a.starts[rn]; len_nx = (int)a.lens[rn]; } }
+        const u64 s = s_nx, key = k_nx; const int len = len_nx;
+        { const u64 rn = r + per_round; if (rn < n) { s_nx = a.starts[rn]; len_nx = (int)a.lens[rn]; k_nx = a.keys ? a.keys[rn] : s_nx; } }
         if (r < n) {
             // length 0 = an unused reserved slot; the exact length bounds (the pre-filter may have run with the absolute maximum,
             // before max_clust_length was known)
@@ -2036,7 +2036,7 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
             // entries must be resident (index n_total being the EOF phantom): a record from a broken list must not fault
             if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull) || len < 1 || len > 3 * 64) {
                 if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
-            } else cluster_record<DEF>(a, s, len, s, lane, StageAlloc{s_stage, cap8, &s_used8, &s_nstage, s_keys, s_offs});
+            } else cluster_record<DEF>(a, s, len, key, lane, StageAlloc{s_stage, cap8, &s_used8, &s_nstage, s_keys, s_offs});
         }
         __syncthreads();
     }

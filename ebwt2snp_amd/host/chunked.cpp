@@ -21,6 +21,11 @@
 #include "../../include/e2s_hip.h"
 
 extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src);    // e2s_capi.hip (not part of the public ABI)
+extern "C" int e2s_internal_flagged_list(e2s_handle h, const uint64_t** starts, const uint16_t** lens, uint64_t* n, int* needs_full);
+extern "C" void e2s_internal_phantom(int lcp_bytes, int da_bytes, int pos_bytes, int gesa_layout, uint32_t text, uint32_t suff, uint32_t lcp, uint32_t bwt, uint32_t out[4]);
+extern "C" int e2s_internal_find_candidates_compact(e2s_handle h, const e2s_c2s_params* p, uint64_t n_cl, const uint64_t* gstart, const uint64_t* off,
+                                                    const uint16_t* len, const uint8_t* bwt, const uint8_t* lcp, const uint8_t* pos, const uint32_t* da,
+                                                    uint64_t n_entries, uint64_t key_lo, uint64_t key_span, uint64_t* n_cand);
 
 namespace {
 
@@ -49,11 +54,19 @@ std::vector<Chunk> plan_chunks(uint64_t n, uint64_t ce, uint32_t right_halo) {
 // two handles on one device and an uploader thread: chunk r goes into handle r & 1 while chunk r - 1 is processed on the other
 class ChunkPipe {
   public:
-    ChunkPipe(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::vector<Chunk>& chunks, bool want_all)
-        : p_(p), src_(src), chunks_(chunks), want_all_(want_all) {}
+    // mode 0: the LCP column (ebwt2clust), 1: all four columns, 2: LCP + BWT (the scan with clust2snp's pre-filter inside)
+    ChunkPipe(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::vector<Chunk>& chunks, int mode)
+        : p_(p), src_(src), chunks_(chunks), mode_(mode) {}
     ~ChunkPipe() { stop(); for (auto& h : h_) if (h) e2s_destroy(h); }
+    // the two handles first -- the caller makes the reads resident on them from ITS thread -- and only then the uploader thread, which
+    // works on the handles from then on (a handle is one thread's at a time)
+    int create() {
+        for (auto& h : h_) if (!h) { int rc = e2s_create(p_.device, &h); if (rc) { err_ = e2s_last_error(nullptr); return rc; } }
+        return E2S_OK;
+    }
     int start() {
-        for (auto& h : h_) { int rc = e2s_create(p_.device, &h); if (rc) { err_ = e2s_last_error(nullptr); return rc; } }
+        int rc = create();
+        if (rc) return rc;
         th_ = std::thread([this]() { run(); });
         return E2S_OK;
     }
@@ -95,13 +108,14 @@ class ChunkPipe {
             const uint64_t lo = c.lo - c.hl, n = (c.hi - c.lo) + c.hl + c.hr;
             const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
             const double t0 = now_s();
-            if (src_.get(src_.user, slot, lo, n, want_all_ ? 1 : 0, &bwt, &lcp, &psa, &aos) != 0) { fail(E2S_ERR_IO, "EGSA source", nullptr); return; }
+            if (src_.get(src_.user, slot, lo, n, mode_ == 1 ? 1 : 0, &bwt, &lcp, &psa, &aos) != 0) { fail(E2S_ERR_IO, "EGSA source", nullptr); return; }
             e2s_shard_desc d{};
             d.global_offset = c.lo; d.n_entries = c.hi - c.lo; d.n_total = p_.n_total; d.halo_left = c.hl; d.halo_right = c.hr;
             d.lcp_bytes = p_.lcp_bytes; d.da_bytes = p_.da_bytes; d.pos_bytes = p_.pos_bytes;
             int rc;
             if (src_.gesa) rc = e2s_upload_gesa(h_[slot], &d, aos);
-            else if (want_all_) rc = e2s_upload_bcr(h_[slot], &d, bwt, lcp, psa);
+            else if (mode_ == 1) rc = e2s_upload_bcr(h_[slot], &d, bwt, lcp, psa);
+            else if (mode_ == 2) rc = e2s_upload_lcp_bwt(h_[slot], &d, lcp, bwt);
             else rc = e2s_upload_lcp(h_[slot], &d, lcp, ((const uint8_t*)bwt)[c.hl + (c.hi - c.lo) - 1]);   // the BWT byte of the last owned entry (EOF rule)
             if (src_.release) src_.release(src_.user, slot);
             up_s_ += now_s() - t0;
@@ -110,7 +124,7 @@ class ChunkPipe {
             cv_.notify_all();
         }
     }
-    e2s_chunk_params p_; e2s_egsa_source src_; const std::vector<Chunk>& chunks_; bool want_all_;
+    e2s_chunk_params p_; e2s_egsa_source src_; const std::vector<Chunk>& chunks_; int mode_;
     e2s_handle h_[2] = {nullptr, nullptr};
     std::thread th_; std::mutex m_; std::condition_variable cv_;
     long ready_[2] = {-1, -1}; bool quit_ = false; int rc_ = 0; std::string err_; double up_s_ = 0;
@@ -119,18 +133,24 @@ class ChunkPipe {
 #define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
 
 // pass A: the scan of every chunk, stitched in order; descriptors and statistics of all chunks are kept for a second pass
+// (flagged: with the pre-filter inside the scan -- LCP + BWT uploaded -- the clusters it lets through, per chunk, for the per-cluster pass
+// that follows once max_clust_length is known; full: a chunk only the four-column path handles)
+struct Flagged { std::vector<uint64_t> st; std::vector<uint16_t> ln; bool full = false; };
 struct ScanPass {
     std::vector<e2s_boundary> all; std::vector<e2s_scan_stats> stats; std::vector<e2s_hist> hists;
     uint64_t n_closed = 0, n_records = 0; double up_s = 0;
 };
-int scan_pass(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::vector<Chunk>& chunks, e2s_byte_sink sink, void* user, ScanPass& out) {
+int scan_pass(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::vector<Chunk>& chunks, e2s_byte_sink sink, void* user, ScanPass& out,
+              int arm_mcov = -1, std::vector<Flagged>* flagged = nullptr) {
     const int nr = (int)chunks.size();
     out.all.assign(nr, e2s_boundary{}); out.stats.assign(nr, e2s_scan_stats{}); out.hists.assign(nr, e2s_hist{});
-    ChunkPipe pipe(p, src, chunks, false);
+    if (flagged) flagged->assign((size_t)nr, Flagged{});
+    ChunkPipe pipe(p, src, chunks, flagged ? 2 : 0);
     RC(pipe.start());
     for (int r = 0; r < nr; ++r) {
         e2s_handle h = nullptr;
         RC(pipe.acquire((size_t)r, &h));
+        if (flagged) RC(e2s_prefilter_arm(h, arm_mcov));
         RC(e2s_cluster_scan(h, p.k, p.min_len, 0));
         RC(e2s_boundary_desc(h, &out.all[r]));
         RC(e2s_scan_stats_desc(h, &out.stats[r]));
@@ -139,6 +159,13 @@ int scan_pass(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::
         RC(e2s_cluster_counts(h, &nc, &nrec));
         RC(e2s_cluster_hist(h, &out.hists[r]));
         out.n_closed += nc;
+        if (flagged) {
+            const uint64_t* fs = nullptr; const uint16_t* fl = nullptr; uint64_t fn = 0; int full = 0;
+            RC(e2s_internal_flagged_list(h, &fs, &fl, &fn, &full));
+            Flagged& F = (*flagged)[(size_t)r];
+            F.full = full != 0;
+            if (!F.full) { F.st.assign(fs, fs + fn); F.ln.assign(fl, fl + fn); }
+        }
         if (sink) { uint64_t w = 0; RC(e2s_stream_clusters(h, sink, user, &w)); out.n_records += w; } else out.n_records += nrec;
         pipe.done((size_t)r);
     }
@@ -186,7 +213,7 @@ int finish_tail(TailState& ts, const char* fasta_path, e2s_byte_sink snp_sink, v
     if (!out_path) { const int fd = mkstemp(&tmp[0]); if (fd < 0) return E2S_ERR_IO; close(fd); }
     uint64_t nv = 0, ne = 0;
     int rc = e2s_snp_from_packed(ts.stream.data(), ts.off8.data(), ts.off8.size() - 1, ts.pw, &ts.tp, fasta_path, tmp.c_str(), &nv, &ne);
-    ts.variants = nv; ts.events = ne;
+    ts.variants += nv; ts.events += ne;                          // (chunks before the switch to the host tail had no events, but may have kept variants)
     if (rc == E2S_OK && !out_path) {                             // the text goes to the sink
         FILE* f = fopen(tmp.c_str(), "rb");
         if (!f) rc = E2S_ERR_IO;
@@ -243,6 +270,53 @@ extern "C" int e2s_ebwt2clust_chunked(const e2s_chunk_params* p, const e2s_egsa_
     return E2S_OK;
 }
 
+// The per-cluster pass of one chunk over clusters GATHERED on the host (the 2-bytes-per-entry job): the chunk's flagged clusters with a
+// length the statistics allow, plus the records the EOF rule adds on the last chunk; their entries copied from all four columns of the
+// source into compact columns, the EOF phantom entry (index n_total) worked out as read_el leaves it.
+int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_options& o, const e2s_egsa_source& src, const Flagged& F,
+                       const e2s_stitch_plan_t& plan, int mcl, uint64_t* n_cand) {
+    *n_cand = 0;
+    const int len_lo = std::max(std::max(2 * o.mcov_out, p.min_len), -1), len_hi = std::min(mcl, (int)E2S_MAX_CLUST_LEN);
+    std::vector<uint64_t> st; std::vector<uint16_t> ln;
+    for (size_t i = 0; i < F.st.size(); ++i) if ((int)F.ln[i] >= len_lo && (int)F.ln[i] <= len_hi) { st.push_back(F.st[i]); ln.push_back(F.ln[i]); }
+    for (uint32_t t = 0; t < plan.n_tail; ++t)
+        if ((int)plan.tail_len[t] >= len_lo && (int)plan.tail_len[t] <= len_hi) { st.push_back(plan.tail_start[t]); ln.push_back(plan.tail_len[t]); }
+    e2s_c2s_params prm{};
+    prm.nr_reads1 = o.nr_reads1; prm.k_left = o.k_left; prm.k_right = o.k_right; prm.mcov_out = o.mcov_out;
+    prm.consensus_reads = o.consensus_reads; prm.max_clust_length = mcl; prm.min_len = p.min_len;
+    if (st.empty()) return e2s_internal_find_candidates_compact(hc, &prm, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, n_cand);
+    uint64_t gmin = ~0ull, gmax = 0, total = 0;
+    for (size_t i = 0; i < st.size(); ++i) { gmin = std::min(gmin, st[i]); gmax = std::max(gmax, st[i] + ln[i]); total += ln[i]; }
+    const uint64_t real_hi = std::min<uint64_t>(gmax, p.n_total);                // (index n_total is the EOF phantom)
+    const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
+    if (real_hi > gmin && src.get(src.user, 0, gmin, real_hi - gmin, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;
+    std::vector<uint8_t> cb(total), cl(total), cp(total); std::vector<uint32_t> cd(total); std::vector<uint64_t> off(st.size());
+    const uint8_t* B = (const uint8_t*)bwt; const uint8_t* L = (const uint8_t*)lcp; const uint8_t* P = (const uint8_t*)psa;
+    uint32_t ph[4] = {0, 0, 0, 0}; bool have_ph = false;
+    uint64_t at = 0;
+    for (size_t i = 0; i < st.size(); ++i) {
+        off[i] = at;
+        for (uint64_t e = st[i]; e < st[i] + ln[i]; ++e, ++at) {
+            if (e < p.n_total) {
+                const uint64_t j = e - gmin;
+                cb[at] = B[j]; cl[at] = L[j]; cp[at] = P[5 * j];
+                uint32_t d; memcpy(&d, P + 5 * j + 1, 4); cd[at] = d;
+            } else {
+                if (!have_ph) {                                      // from the last real entry (which the range holds: the cluster reaches it)
+                    const uint64_t j = p.n_total - 1 - gmin;
+                    uint32_t d; memcpy(&d, P + 5 * j + 1, 4);
+                    e2s_internal_phantom(p.lcp_bytes, p.da_bytes, p.pos_bytes, 0, d, P[5 * j], L[j], B[j], ph);
+                    have_ph = true;
+                }
+                cd[at] = ph[0]; cp[at] = (uint8_t)ph[1]; cl[at] = (uint8_t)ph[2]; cb[at] = (uint8_t)ph[3];
+            }
+        }
+    }
+    if (src.release && real_hi > gmin) src.release(src.user, 0);
+    return e2s_internal_find_candidates_compact(hc, &prm, st.size(), st.data(), off.data(), ln.data(), cb.data(), cl.data(), cp.data(), cd.data(), total, gmin,
+                                                gmax - gmin, n_cand);
+}
+
 extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src, const char* fasta_path,
                                     const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len,
                                     e2s_byte_sink clusters_sink, void* clusters_user, e2s_byte_sink snp_sink, void* snp_user, e2s_job_report* rep) {
@@ -251,44 +325,100 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     if (rep) memset(rep, 0, sizeof(*rep));
     const std::vector<Chunk> chunks = plan_chunks(p->n_total, p->chunk_entries, 1);
     const int nr = (int)chunks.size();
-    // pass A: ebwt2clust (LCP column only): records out, descriptors and statistics of every chunk kept
+    // BCR files of the default widths: ONE streaming pass over 2 of the 7 bytes per entry -- LCP + BWT, the scan with clust2snp's
+    // pre-filter inside; DA and positions are read only for the clusters it lets through (~0.5 % of the entries), gathered on the host
+    // once statistics() has said how long a cluster may be.  (E2S_CHUNK_TWO_PASS=1, other widths, `.gesa`: pass A = the LCP column,
+    // pass B = all four columns again.)
+    static const int two_pass_env = getenv("E2S_CHUNK_TWO_PASS") ? atoi(getenv("E2S_CHUNK_TWO_PASS")) : 0;
+    const bool slim = !two_pass_env && !src->gesa && p->lcp_bytes == 1 && p->da_bytes == 4 && p->pos_bytes == 1;
+    // pass A: ebwt2clust: records out, descriptors and statistics of every chunk kept (slim: and the clusters the pre-filter lets through)
     ScanPass sp;
-    RC(scan_pass(*p, *src, chunks, clusters_sink, clusters_user, sp));
+    std::vector<Flagged> flagged;
+    RC(scan_pass(*p, *src, chunks, clusters_sink, clusters_user, sp, slim ? o->mcov_out : -1, slim ? &flagged : nullptr));
     int mcl = 0; uint64_t n_clust = 0, n_bases = 0;
     int rc = e2s_auto_max_clust_length(sp.hists.data(), nr, o->mcov_out, o->pval, &mcl, &n_clust, &n_bases);
     if (rc) { fill_report(rep, &sp, nullptr, 0, 0, 0, chunks.size(), sp.up_s, t0); return rc; }
-    // pass B: clust2snp: all four columns, the scan again with the pre-filter inside, the per-cluster pass and the tail
-    ChunkPipe pipe(*p, *src, chunks, true);
-    RC(pipe.start());
-    if (fasta_path) {
-        rc = e2s_upload_reads_fasta(pipe.handle(0), fasta_path, nullptr);
-        if (rc != E2S_OK && rc != E2S_ERR_INPUT) return rc;      // (an irregular FASTA: the host tail decides)
-        if (rc == E2S_OK) RC(e2s_share_reads(pipe.handle(1), pipe.handle(0)));
-    } else {
-        RC(e2s_attach_reads(pipe.handle(0), d_text, d_start, d_len, n_reads, max_len));
-        RC(e2s_attach_reads(pipe.handle(1), d_text, d_start, d_len, n_reads, max_len));
-    }
     TailState ts;
     ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
-    for (int r = 0; r < nr; ++r) {
-        e2s_handle h = nullptr;
-        RC(pipe.acquire((size_t)r, &h));
-        RC(e2s_prefilter_arm(h, o->mcov_out));
-        RC(e2s_cluster_scan(h, p->k, p->min_len, 0));
-        RC(e2s_stitch(h, sp.all.data(), nr, r));                 // the descriptors of pass A: the same array, the same cuts
-        e2s_c2s_params prm{};
-        prm.nr_reads1 = o->nr_reads1; prm.k_left = o->k_left; prm.k_right = o->k_right; prm.mcov_out = o->mcov_out;
-        prm.consensus_reads = o->consensus_reads; prm.max_clust_length = mcl; prm.min_len = p->min_len;
-        uint64_t n_cand = 0;
-        RC(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand));
-        rc = chunk_tail(h, n_cand, snp_sink, snp_user, ts);
-        if (rc == E2S_SWITCH_TAILS) return E2S_ERR_STATE;         // (the sink has the earlier chunks' events already: see include/e2s_hip.h)
-        if (rc) return rc;
-        pipe.done((size_t)r);
+    double up_b = 0;
+    auto reads_on = [&](e2s_handle h0, e2s_handle h1) -> int {
+        if (fasta_path) {
+            int r2 = e2s_upload_reads_fasta(h0, fasta_path, nullptr);
+            if (r2 != E2S_OK && r2 != E2S_ERR_INPUT && r2 != E2S_ERR_IO) return r2;      // (an irregular / unreadable FASTA: the host tail decides)
+            if (r2 == E2S_OK && h1) RC(e2s_share_reads(h1, h0));
+        } else {
+            RC(e2s_attach_reads(h0, d_text, d_start, d_len, n_reads, max_len));
+            if (h1) RC(e2s_attach_reads(h1, d_text, d_start, d_len, n_reads, max_len));
+        }
+        return E2S_OK;
+    };
+    if (slim) {
+        // the per-cluster pass and the tail, chunk by chunk, over gathered clusters (a chunk the pre-filter could not handle: all four columns)
+        e2s_handle hc = nullptr, hf = nullptr;
+        RC(e2s_create(p->device, &hc));
+        struct Guard { e2s_handle& a; e2s_handle& b; ~Guard() { if (a) e2s_destroy(a); if (b) e2s_destroy(b); } } guard{hc, hf};
+        RC(reads_on(hc, nullptr));
+        for (int r = 0; r < nr; ++r) {
+            uint64_t n_cand = 0;
+            e2s_handle ht = hc;
+            if (flagged[(size_t)r].full) {
+                if (!hf) { RC(e2s_create(p->device, &hf)); RC(e2s_share_reads(hf, hc)); }
+                const Chunk& c = chunks[(size_t)r];
+                const uint64_t lo = c.lo - c.hl, n = (c.hi - c.lo) + c.hl + c.hr;
+                const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
+                const double u0 = now_s();
+                if (src->get(src->user, 0, lo, n, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;
+                e2s_shard_desc d{};
+                d.global_offset = c.lo; d.n_entries = c.hi - c.lo; d.n_total = p->n_total; d.halo_left = c.hl; d.halo_right = c.hr;
+                d.lcp_bytes = p->lcp_bytes; d.da_bytes = p->da_bytes; d.pos_bytes = p->pos_bytes;
+                rc = e2s_upload_bcr(hf, &d, bwt, lcp, psa);
+                if (src->release) src->release(src->user, 0);
+                up_b += now_s() - u0;
+                if (rc) return rc;
+                RC(e2s_prefilter_arm(hf, o->mcov_out));
+                RC(e2s_cluster_scan(hf, p->k, p->min_len, 0));
+                RC(e2s_stitch(hf, sp.all.data(), nr, r));
+                e2s_c2s_params prm{};
+                prm.nr_reads1 = o->nr_reads1; prm.k_left = o->k_left; prm.k_right = o->k_right; prm.mcov_out = o->mcov_out;
+                prm.consensus_reads = o->consensus_reads; prm.max_clust_length = mcl; prm.min_len = p->min_len;
+                RC(e2s_find_candidates(hf, &prm, (uint64_t)r << 40, &n_cand));
+                ht = hf;
+            } else {
+                e2s_stitch_plan_t plan;
+                if (e2s_stitch_plan(sp.all.data(), nr, r, p->n_total, p->k, p->lcp_bytes, &plan) != E2S_OK) return E2S_ERR_INPUT;
+                RC(compact_chunk_pass(hc, *p, *o, *src, flagged[(size_t)r], plan, mcl, &n_cand));
+            }
+            rc = chunk_tail(ht, n_cand, snp_sink, snp_user, ts);
+            if (rc == E2S_SWITCH_TAILS) return E2S_ERR_STATE;         // (the sink has the earlier chunks' events already: see include/e2s_hip.h)
+            if (rc) return rc;
+        }
+    } else {
+        // pass B: clust2snp: all four columns, the scan again with the pre-filter inside, the per-cluster pass and the tail
+        ChunkPipe pipe(*p, *src, chunks, 1);
+        RC(pipe.create());
+        RC(reads_on(pipe.handle(0), pipe.handle(1)));
+        RC(pipe.start());
+        for (int r = 0; r < nr; ++r) {
+            e2s_handle h = nullptr;
+            RC(pipe.acquire((size_t)r, &h));
+            RC(e2s_prefilter_arm(h, o->mcov_out));
+            RC(e2s_cluster_scan(h, p->k, p->min_len, 0));
+            RC(e2s_stitch(h, sp.all.data(), nr, r));                 // the descriptors of pass A: the same array, the same cuts
+            e2s_c2s_params prm{};
+            prm.nr_reads1 = o->nr_reads1; prm.k_left = o->k_left; prm.k_right = o->k_right; prm.mcov_out = o->mcov_out;
+            prm.consensus_reads = o->consensus_reads; prm.max_clust_length = mcl; prm.min_len = p->min_len;
+            uint64_t n_cand = 0;
+            RC(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand));
+            rc = chunk_tail(h, n_cand, snp_sink, snp_user, ts);
+            if (rc == E2S_SWITCH_TAILS) return E2S_ERR_STATE;         // (the sink has the earlier chunks' events already: see include/e2s_hip.h)
+            if (rc) return rc;
+            pipe.done((size_t)r);
+        }
+        pipe.stop();
+        up_b = pipe.upload_seconds();
     }
-    pipe.stop();
     rc = finish_tail(ts, fasta_path, snp_sink, snp_user, nullptr);
-    fill_report(rep, &sp, &ts, mcl, n_clust, n_bases, chunks.size(), sp.up_s + pipe.upload_seconds(), t0);
+    fill_report(rep, &sp, &ts, mcl, n_clust, n_bases, chunks.size(), sp.up_s + up_b, t0);
     return rc;
 }
 
@@ -313,13 +443,14 @@ extern "C" int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_op
         ts = TailState{};
         ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
         ts.host_mode = host_only;
-        ChunkPipe pipe(*p, *src, chunks, true);
-        RC(pipe.start());
+        ChunkPipe pipe(*p, *src, chunks, 1);
+        RC(pipe.create());
         if (!host_only) {
             int rc = e2s_upload_reads_fasta(pipe.handle(0), fasta_path, nullptr);
             if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) return rc;
             if (rc == E2S_OK) RC(e2s_share_reads(pipe.handle(1), pipe.handle(0)));
         }
+        RC(pipe.start());
         LazyFile out{nullptr, out_path};
         for (int r = 0; r < nr; ++r) {
             e2s_handle h = nullptr;

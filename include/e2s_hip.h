@@ -90,6 +90,10 @@ int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, con
  * discards the other fields.  tail_bwt = BWT byte of the shard's last owned entry (it feeds the
  * reference's EOF phantom on the last rank; ignored elsewhere). */
 int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void* lcp, uint8_t tail_bwt);
+/* The LCP and the BWT columns (host pointers, x bytes and 1 byte per entry): what the scan WITH clust2snp's pre-filter inside reads
+ * (e2s_prefilter_arm + e2s_cluster_scan) -- 2 of the 7 bytes per entry.  The document array and the positions are needed only for the
+ * clusters the pre-filter lets through (~0.5 % of the entries): the chunked jobs gather those from the host afterwards. */
+int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const void* lcp, const void* bwt);
 
 /* ---- ebwt2clust: cluster boundaries ------------------------------------------------------- */
 /* scan_mode: must be 0 (the segmented single-pass scan: every wave a worker over a contiguous range of 4-KiB tiles; the
