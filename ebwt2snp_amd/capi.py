@@ -459,18 +459,22 @@ def resident_job(h, n1, rank=0, world=1, allgather=None, k=16, min_len=2, mcov=5
     return rep
 
 
-def ebwt2snp_chunked(get, n_total, chunk_entries, n1, d_text, n_reads, read_len, clusters_sink=None, snp_sink=None, device=0, k=16, min_len=2,
-                     mcov=5, k_left=31, k_right=30, max_gap=10, max_err=2, cons_reads=20, pval=0.99, widths=(1, 4, 1)):
-    """both tools over an EGSA handed out chunk by chunk by get(slot, lo, n, want_all) -> (bwt_ptr, lcp_ptr, pairsa_ptr) (host
-    addresses, BCR layout); the reads as a dense matrix in HBM (d_text).  Sinks: callables (address, nbytes) -> None.  Returns JobReport."""
+def ebwt2snp_chunked(get, n_total, chunk_entries, n1, d_text=None, n_reads=0, read_len=0, clusters_sink=None, snp_sink=None, device=0, k=16, min_len=2,
+                     mcov=5, k_left=31, k_right=30, max_gap=10, max_err=2, cons_reads=20, pval=0.99, widths=(1, 4, 1), fasta_path=None, gesa=False):
+    """both tools over an EGSA handed out chunk by chunk by get(slot, lo, n, want_all) -> (bwt_ptr, lcp_ptr, pairsa_ptr) (host addresses,
+    BCR layout) or -> aos_ptr (gesa=True); the reads as a dense matrix in HBM (d_text) or a FASTA file (fasta_path).
+    Sinks: callables (address, nbytes) -> None.  Returns JobReport."""
     L = lib()
     L.e2s_ebwt2snp_chunked.argtypes = [C.POINTER(ChunkParams), C.POINTER(C2SOptions), C.POINTER(EgsaSource), C.c_char_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint64, C.c_uint32, BYTE_SINK, C.c_void_p, BYTE_SINK, C.c_void_p, C.POINTER(JobReport)]
 
     def _get(_user, slot, lo, n, want_all, pb, pl, pp, pa):
         try:
-            b, l, p = get(slot, lo, n, want_all)
-            pb[0], pl[0], pp[0] = b, l, p
+            if gesa:
+                pa[0] = get(slot, lo, n, want_all)
+            else:
+                b, l, p = get(slot, lo, n, want_all)
+                pb[0], pl[0], pp[0] = b, l, p
             return 0
         except Exception:                                          # pragma: no cover
             import traceback
@@ -484,13 +488,13 @@ def ebwt2snp_chunked(get, n_total, chunk_entries, n1, d_text, n_reads, read_len,
             return 0
         return BYTE_SINK(cb)
 
-    src = EgsaSource(EGSA_GET(_get), EGSA_RELEASE(0), None, 0, 0)
+    src = EgsaSource(EGSA_GET(_get), EGSA_RELEASE(0), None, 1 if gesa else 0, 0)
     p = ChunkParams(device, k, min_len, widths[0], widths[1], widths[2], n_total, chunk_entries)
     o = C2SOptions(n1, k_left, k_right, mcov, cons_reads, max_gap, max_err, pval)
     rep = JobReport()
     cs, ss = _sink(clusters_sink), _sink(snp_sink)
-    rc = L.e2s_ebwt2snp_chunked(C.byref(p), C.byref(o), C.byref(src), None, C.c_void_p(int(d_text)), None, None, n_reads, read_len, cs, None, ss, None,
-                                C.byref(rep))
+    rc = L.e2s_ebwt2snp_chunked(C.byref(p), C.byref(o), C.byref(src), fasta_path.encode() if fasta_path else None,
+                                C.c_void_p(int(d_text)) if d_text else None, None, None, n_reads, read_len, cs, None, ss, None, C.byref(rep))
     if rc:
         raise E2SError(rc, "e2s_ebwt2snp_chunked")
     return rep

@@ -1285,3 +1285,38 @@ def test_c5_strong_cut_rehearsal_equals_the_chunked_job():
                  ("max_clust_length", "max_clust_length")):
         assert two["config"][a] == one[b], (a, two["config"][a], one[b])
     assert one["snp_events"] > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [9973, 61000])
+def test_chunked_job_on_goldens(chunk, tmp_path):
+    """e2s_ebwt2snp_chunked -- both tools in one process over an EGSA that comes from the host in chunks -- on every end-to-end golden, the
+    chunks small enough for 4 to 60 of them: `.clusters` and `.snp` bytes equal the reference's.  BCR inputs of the default widths take
+    the 2-bytes-per-entry form (LCP + BWT streamed, the clusters the pre-filter lets through gathered on the host, the EOF phantom entry
+    worked out there); other widths and `.gesa` the two-pass form; E2S_CHUNK_TWO_PASS=1 forces it (both must agree)"""
+    import ctypes
+    for meta in goldens.e2e_cases():
+        reads, n1, en = goldens.e2e_inputs(meta)
+        d = tmp_path / ("c%d_%s" % (chunk, meta["name"]))
+        d.mkdir()
+        p = goldens.write_case_files(meta, reads, en, str(d))
+        x, y, z = meta["xyz"]
+        n = meta["n_entries"]
+        if meta["gesa"]:
+            aos = np.fromfile(p + ".gesa", dtype=np.uint8)
+            rec = x + y + z + 1
+            get = lambda slot, lo, cnt, want_all: aos.ctypes.data + lo * rec
+        else:
+            bwt, lcp, psa = (np.fromfile(p + e, dtype=np.uint8) for e in (".out", ".out.lcp", ".out.pairSA"))
+            get = lambda slot, lo, cnt, want_all: (bwt.ctypes.data + lo, lcp.ctypes.data + lo * x, psa.ctypes.data + lo * (y + z))
+        got = {"cl": bytearray(), "snp": bytearray()}
+        e, a = meta["e2c"], meta["c2s"]
+        rep = capi.ebwt2snp_chunked(get, n, chunk, n1, clusters_sink=lambda ad, nb: got["cl"].extend(ctypes.string_at(ad, nb)),
+                                    snp_sink=lambda ad, nb: got["snp"].extend(ctypes.string_at(ad, nb)), k=e.get("k", 0) or 16, min_len=e.get("m", 0) or 2,
+                                    mcov=a.get("m", 0) or 5, k_left=a.get("L", 0) or 31, k_right=a.get("R", 0) or 30, max_gap=a.get("g", 0) or 10,
+                                    max_err=a.get("e", 0) or 2, cons_reads=a.get("c", 0) or 20, pval=a.get("p", 0.0) or 0.99, widths=(x, y, z), fasta_path=p,
+                                    gesa=meta["gesa"])
+        assert rep.n_chunks >= min(3, n // chunk + 1) and rep.n_closed == meta["n_printed"] and rep.max_clust_length == meta["max_clust_length"], meta["name"]
+        assert rep.n_candidates == meta["n_candidates"] and rep.n_events == meta["n_events"], meta["name"]
+        assert hashlib.sha256(bytes(got["cl"])).hexdigest() == meta["clusters_sha256"], meta["name"]
+        assert bytes(got["snp"]) == goldens.golden_snp(meta), meta["name"]
