@@ -1999,6 +1999,42 @@ extern "C" int e2s_internal_flagged_list(e2s_handle h, const uint64_t** starts, 
     *starts = h->host_fl_starts.data(); *lens = h->host_fl_lens.data(); *n = m;
     return E2S_OK;
 }
+// the same for records loaded from a `.clusters` file (e2s_load_clusters; the shard needs its BWT column only): the records of a
+// length statistics() allows that hold two different bases often enough (k_record_prefilter), as a list on the host
+extern "C" int e2s_internal_record_prefilter(e2s_handle h, int mcov_out, int max_clust_length, const uint64_t** starts, const uint16_t** lens, uint64_t* n) {
+    if (!h || !starts || !lens || !n) return E2S_ERR_ARG;
+    *n = 0;
+    if (!h->stitched || !h->records_from_file || !h->bwt) return fail(h, E2S_ERR_STATE, "record pre-filter: records from a file and the BWT column");
+    CK(hipSetDevice(h->device));
+    h->host_fl_starts.clear(); h->host_fl_lens.clear();
+    *starts = nullptr; *lens = nullptr;
+    if (!h->n_rec) return E2S_OK;
+    const int len_lo = c2s_len_lo(mcov_out, 0), len_hi = std::min(max_clust_length, (int)E2S_MAX_CLUST_LEN);
+    int rc;
+    uint64_t want = std::max<uint64_t>(h->fl_cap, h->n_rec / 8 + 4096);
+    uint64_t* mb = (uint64_t*)(h->pin_mail + 3400);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = ensure_flagged(h, want))) return rc;
+        CK(hipMemsetAsync(h->d_scalars + 2, 0, 8, h->stream));
+        e2s_launch_record_prefilter((const unsigned long long*)h->d_starts, h->d_lens, h->n_rec, h->bwt, h->prov_lo, h->prov_lo + h->n_prov, (uint32_t)mcov_out, len_lo, len_hi,
+                                    (unsigned long long*)h->d_fl_starts, h->d_fl_lens, h->fl_cap, (unsigned long long*)(h->d_scalars + 2), h->stream);
+        LCHK("e2s_launch_record_prefilter");
+        CK(hipMemcpyAsync(mb, h->d_scalars + 2, 8, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+        if (mb[0] <= h->fl_cap) break;
+        if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "flagged list overflow");
+        want = mb[0] + 4096;
+    }
+    const uint64_t m = mb[0];
+    h->host_fl_starts.resize(m); h->host_fl_lens.resize(m);
+    if (m) {
+        CK(hipMemcpyAsync(h->host_fl_starts.data(), h->d_fl_starts, m * 8, hipMemcpyDeviceToHost, h->stream));
+        CK(hipMemcpyAsync(h->host_fl_lens.data(), h->d_fl_lens, m * 2, hipMemcpyDeviceToHost, h->stream));
+        CK(hipStreamSynchronize(h->stream));
+    }
+    *starts = h->host_fl_starts.data(); *lens = h->host_fl_lens.data(); *n = m;
+    return E2S_OK;
+}
 // the entry read_el hands out past EOF inside clust2snp, from the last real entry (slot model, see phantom_entry)
 extern "C" void e2s_internal_phantom(int lcp_bytes, int da_bytes, int pos_bytes, int gesa_layout, uint32_t text, uint32_t suff, uint32_t lcp, uint32_t bwt, uint32_t out[4]) {
     e2s_ctx tmp;

@@ -22,6 +22,7 @@
 
 extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src);    // e2s_capi.hip (not part of the public ABI)
 extern "C" int e2s_internal_flagged_list(e2s_handle h, const uint64_t** starts, const uint16_t** lens, uint64_t* n, int* needs_full);
+extern "C" int e2s_internal_record_prefilter(e2s_handle h, int mcov_out, int max_clust_length, const uint64_t** starts, const uint16_t** lens, uint64_t* n);
 extern "C" void e2s_internal_phantom(int lcp_bytes, int da_bytes, int pos_bytes, int gesa_layout, uint32_t text, uint32_t suff, uint32_t lcp, uint32_t bwt, uint32_t out[4]);
 extern "C" int e2s_internal_find_candidates_compact(e2s_handle h, const e2s_c2s_params* p, uint64_t n_cl, const uint64_t* gstart, const uint64_t* off,
                                                     const uint16_t* len, const uint8_t* bwt, const uint8_t* lcp, const uint8_t* pos, const uint32_t* da,
@@ -287,9 +288,10 @@ int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_o
     if (st.empty()) return e2s_internal_find_candidates_compact(hc, &prm, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, n_cand);
     uint64_t gmin = ~0ull, gmax = 0, total = 0;
     for (size_t i = 0; i < st.size(); ++i) { gmin = std::min(gmin, st[i]); gmax = std::max(gmax, st[i] + ln[i]); total += ln[i]; }
+    if (gmax > p.n_total + 1) return E2S_ERR_INPUT;               // a record past EOF (only index n_total, the phantom, exists beyond the array)
     const uint64_t real_hi = std::min<uint64_t>(gmax, p.n_total);                // (index n_total is the EOF phantom)
     const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
-    if (real_hi > gmin && src.get(src.user, 0, gmin, real_hi - gmin, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;
+    if (real_hi > gmin && src.get(src.user, 2, gmin, real_hi - gmin, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;      // (slot 2: see e2s_egsa_source)
     std::vector<uint8_t> cb(total), cl(total), cp(total); std::vector<uint32_t> cd(total); std::vector<uint64_t> off(st.size());
     const uint8_t* B = (const uint8_t*)bwt; const uint8_t* L = (const uint8_t*)lcp; const uint8_t* P = (const uint8_t*)psa;
     uint32_t ph[4] = {0, 0, 0, 0}; bool have_ph = false;
@@ -312,7 +314,7 @@ int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_o
             }
         }
     }
-    if (src.release && real_hi > gmin) src.release(src.user, 0);
+    if (src.release && real_hi > gmin) src.release(src.user, 2);
     return e2s_internal_find_candidates_compact(hc, &prm, st.size(), st.data(), off.data(), ln.data(), cb.data(), cl.data(), cp.data(), cd.data(), total, gmin,
                                                 gmax - gmin, n_cand);
 }
@@ -367,12 +369,12 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
                 const uint64_t lo = c.lo - c.hl, n = (c.hi - c.lo) + c.hl + c.hr;
                 const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
                 const double u0 = now_s();
-                if (src->get(src->user, 0, lo, n, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;
+                if (src->get(src->user, 2, lo, n, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;
                 e2s_shard_desc d{};
                 d.global_offset = c.lo; d.n_entries = c.hi - c.lo; d.n_total = p->n_total; d.halo_left = c.hl; d.halo_right = c.hr;
                 d.lcp_bytes = p->lcp_bytes; d.da_bytes = p->da_bytes; d.pos_bytes = p->pos_bytes;
                 rc = e2s_upload_bcr(hf, &d, bwt, lcp, psa);
-                if (src->release) src->release(src->user, 0);
+                if (src->release) src->release(src->user, 2);
                 up_b += now_s() - u0;
                 if (rc) return rc;
                 RC(e2s_prefilter_arm(hf, o->mcov_out));
@@ -438,13 +440,47 @@ extern "C" int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_op
     };
     TailState ts;
     double up_s = 0;
+    // BCR files of the default widths: 2 of the 7 bytes per entry go up (the record pre-filter reads the BWT only), the clusters it lets
+    // through are gathered on the host from all four columns (as in e2s_ebwt2snp_chunked)
+    static const int two_pass_env = getenv("E2S_CHUNK_TWO_PASS") ? atoi(getenv("E2S_CHUNK_TWO_PASS")) : 0;
+    const bool slim = !two_pass_env && !src->gesa && p->lcp_bytes == 1 && p->da_bytes == 4 && p->pos_bytes == 1;
     // one pass over the chunks; host_only: the host tail from the first chunk on (the second attempt, below)
     auto pass = [&](bool host_only) -> int {
         ts = TailState{};
         ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
         ts.host_mode = host_only;
-        ChunkPipe pipe(*p, *src, chunks, 1);
+        ChunkPipe pipe(*p, *src, chunks, slim ? 2 : 1);
+        e2s_handle hc = nullptr;
+        struct Guard { e2s_handle& a; ~Guard() { if (a) e2s_destroy(a); } } guard{hc};
         RC(pipe.create());
+        if (slim) {                                               // the compact per-cluster pass and the tail run on a handle of their own
+            RC(e2s_create(p->device, &hc));
+            if (!host_only) {
+                int rc = e2s_upload_reads_fasta(hc, fasta_path, nullptr);
+                if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) return rc;
+            }
+            RC(pipe.start());
+            LazyFile out{nullptr, out_path};
+            for (int r = 0; r < nr; ++r) {
+                e2s_handle h = nullptr;
+                RC(pipe.acquire((size_t)r, &h));
+                const uint64_t i0 = first_at_or_after(chunks[r].lo), i1 = r == nr - 1 ? n_records : first_at_or_after(chunks[r].hi);
+                RC(e2s_load_clusters(h, (const uint8_t*)recs + i0 * 10, i1 - i0));
+                Flagged F;
+                const uint64_t* fs = nullptr; const uint16_t* fl = nullptr; uint64_t fn = 0;
+                RC(e2s_internal_record_prefilter(h, o->mcov_out, max_clust_length, &fs, &fl, &fn));
+                F.st.assign(fs, fs + fn); F.ln.assign(fl, fl + fn);
+                pipe.done((size_t)r);                             // (the next chunk uploads while this one's clusters are gathered and passed)
+                uint64_t n_cand = 0;
+                e2s_chunk_params p0 = *p; p0.min_len = 0;
+                RC(compact_chunk_pass(hc, p0, *o, *src, F, e2s_stitch_plan_t{}, max_clust_length, &n_cand));
+                RC(chunk_tail(hc, n_cand, lazy_file_sink, &out, ts));
+            }
+            pipe.stop();
+            up_s += pipe.upload_seconds();
+            out.close();
+            return finish_tail(ts, fasta_path, nullptr, nullptr, out_path);
+        }
         if (!host_only) {
             int rc = e2s_upload_reads_fasta(pipe.handle(0), fasta_path, nullptr);
             if (rc != E2S_OK && rc != E2S_ERR_INPUT && rc != E2S_ERR_IO) return rc;

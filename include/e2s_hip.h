@@ -298,14 +298,18 @@ int e2s_write_snp(e2s_handle h, const e2s_tail_params* p, const char* fasta_path
 
 /* ---- whole jobs over an EGSA that comes from the host in chunks (EGSAs larger than HBM) --------------------------
  * The array goes through ONE GPU in chunks of chunk_entries SA positions (left halo 152, right halo 1 -- or max cluster length + 1
- * where records come from a file), chunk i + 1 uploading on a second handle while chunk i is processed.  Every chunk is a rank of
+ * where records come from a file), chunk i + 1 uploading on a second handle while chunk i is processed.  BCR files of the default
+ * widths stream only LCP + BWT (2 of the 7 bytes per entry: what the scan with clust2snp's pre-filter inside reads); the document
+ * array and the positions are read for the ~0.5 % of the entries that lie in clusters the pre-filter lets through.  Every chunk is a rank of
  * the boundary stitch (e2s_stitch_plan / e2s_hist_after_stitch), so the outputs are byte for byte those of one pass over the whole
  * array: no new semantics.  The reference streams the same files with O(cluster) memory (include.hpp:120-199, ebwt2clust.cpp:90-122). */
 typedef struct {
     /* Hands out host memory holding the entries [lo, lo + n) of the EGSA (global SA positions).  BCR layout (gesa == 0): *bwt (1 byte per
      * entry), *lcp (x bytes), *pairsa (z + y bytes: [pos][da]); .gesa layout: *aos (y + z + x + 1 bytes per entry: [da][pos][lcp][bwt]).
      * want_all == 0: only the LCP column and *bwt are needed (ebwt2clust reads and discards the rest).  The pointers stay valid until
-     * release(user, slot); slots 0 and 1 are in use alternately, never the same one twice at a time.  Returns 0, or non-zero to abort. */
+     * release(user, slot); slots 0 and 1 are in use alternately by the streaming uploads, never the same one twice at a time; slot 2
+     * (want_all = 1) is random access to the few entries the per-cluster pass needs from all columns -- the clusters the pre-filter
+     * let through, gathered on the host -- possibly while a streaming slot is in use.  Returns 0, or non-zero to abort. */
     int (*get)(void* user, int slot, uint64_t lo, uint64_t n, int want_all, const void** bwt, const void** lcp, const void** pairsa, const void** aos);
     void (*release)(void* user, int slot);                     /* may be NULL */
     void* user;
