@@ -274,9 +274,11 @@ extern "C" int e2s_ebwt2clust_chunked(const e2s_chunk_params* p, const e2s_egsa_
 // The per-cluster pass of one chunk over clusters GATHERED on the host (the 2-bytes-per-entry job): the chunk's flagged clusters with a
 // length the statistics allow, plus the records the EOF rule adds on the last chunk; their entries copied from all four columns of the
 // source into compact columns, the EOF phantom entry (index n_total) worked out as read_el leaves it.
+double g_gather_s = 0, g_compact_s = 0;                          // (E2S_CLI_TIMING: where the second phase goes)
 int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_options& o, const e2s_egsa_source& src, const Flagged& F,
                        const e2s_stitch_plan_t& plan, int mcl, uint64_t* n_cand) {
     *n_cand = 0;
+    const double t_in = now_s();
     const int len_lo = std::max(std::max(2 * o.mcov_out, p.min_len), -1), len_hi = std::min(mcl, (int)E2S_MAX_CLUST_LEN);
     std::vector<uint64_t> st; std::vector<uint16_t> ln;
     for (size_t i = 0; i < F.st.size(); ++i) if ((int)F.ln[i] >= len_lo && (int)F.ln[i] <= len_hi) { st.push_back(F.st[i]); ln.push_back(F.ln[i]); }
@@ -292,31 +294,44 @@ int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_o
     const uint64_t real_hi = std::min<uint64_t>(gmax, p.n_total);                // (index n_total is the EOF phantom)
     const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
     if (real_hi > gmin && src.get(src.user, 2, gmin, real_hi - gmin, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;      // (slot 2: see e2s_egsa_source)
-    std::vector<uint8_t> cb(total), cl(total), cp(total); std::vector<uint32_t> cd(total); std::vector<uint64_t> off(st.size());
+    static thread_local std::vector<uint8_t> cb, cl, cp; static thread_local std::vector<uint32_t> cd; static thread_local std::vector<uint64_t> off;
+    cb.resize(total); cl.resize(total); cp.resize(total); cd.resize(total); off.resize(st.size());
     const uint8_t* B = (const uint8_t*)bwt; const uint8_t* L = (const uint8_t*)lcp; const uint8_t* P = (const uint8_t*)psa;
-    uint32_t ph[4] = {0, 0, 0, 0}; bool have_ph = false;
+    uint32_t ph[4] = {0, 0, 0, 0};
+    if (gmax > p.n_total) {                                       // the EOF phantom, from the last real entry (which the range holds: the cluster reaches it)
+        const uint64_t j = p.n_total - 1 - gmin;
+        uint32_t d; memcpy(&d, P + 5 * j + 1, 4);
+        e2s_internal_phantom(p.lcp_bytes, p.da_bytes, p.pos_bytes, 0, d, P[5 * j], L[j], B[j], ph);
+    }
     uint64_t at = 0;
-    for (size_t i = 0; i < st.size(); ++i) {
-        off[i] = at;
-        for (uint64_t e = st[i]; e < st[i] + ln[i]; ++e, ++at) {
-            if (e < p.n_total) {
-                const uint64_t j = e - gmin;
-                cb[at] = B[j]; cl[at] = L[j]; cp[at] = P[5 * j];
-                uint32_t d; memcpy(&d, P + 5 * j + 1, 4); cd[at] = d;
-            } else {
-                if (!have_ph) {                                      // from the last real entry (which the range holds: the cluster reaches it)
-                    const uint64_t j = p.n_total - 1 - gmin;
-                    uint32_t d; memcpy(&d, P + 5 * j + 1, 4);
-                    e2s_internal_phantom(p.lcp_bytes, p.da_bytes, p.pos_bytes, 0, d, P[5 * j], L[j], B[j], ph);
-                    have_ph = true;
-                }
-                cd[at] = ph[0]; cp[at] = (uint8_t)ph[1]; cl[at] = (uint8_t)ph[2]; cb[at] = (uint8_t)ph[3];
-            }
+    for (size_t i = 0; i < st.size(); ++i) { off[i] = at; at += ln[i]; }
+    // the gather itself: worker threads over the clusters (~10^6 entries per 3x10^8-entry chunk).  (Plain pointers: the buffers are
+    // this thread's thread_local ones, a worker naming them would get its own, empty ones.)
+    uint8_t* const pb = cb.data(); uint8_t* const pl = cl.data(); uint8_t* const pp = cp.data(); uint32_t* const pd = cd.data(); const uint64_t* const po = off.data();
+    auto work = [&, pb, pl, pp, pd, po](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            const uint64_t a2 = po[i];
+            const uint64_t real = st[i] + ln[i] <= p.n_total ? ln[i] : (st[i] < p.n_total ? p.n_total - st[i] : 0);
+            const uint64_t j0 = st[i] - gmin;
+            memcpy(pb + a2, B + j0, real); memcpy(pl + a2, L + j0, real);
+            for (uint64_t q = 0; q < real; ++q) { pp[a2 + q] = P[5 * (j0 + q)]; uint32_t d; memcpy(&d, P + 5 * (j0 + q) + 1, 4); pd[a2 + q] = d; }
+            for (uint64_t q = real; q < ln[i]; ++q) { pd[a2 + q] = ph[0]; pp[a2 + q] = (uint8_t)ph[1]; pl[a2 + q] = (uint8_t)ph[2]; pb[a2 + q] = (uint8_t)ph[3]; }
         }
+    };
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), st.size() / 4096));
+    if (T == 1) work(0, st.size());
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, st.size() * t / T, st.size() * (t + 1) / T);
+        work(0, st.size() / T);
+        for (auto& x : th) x.join();
     }
     if (src.release && real_hi > gmin) src.release(src.user, 2);
-    return e2s_internal_find_candidates_compact(hc, &prm, st.size(), st.data(), off.data(), ln.data(), cb.data(), cl.data(), cp.data(), cd.data(), total, gmin,
-                                                gmax - gmin, n_cand);
+    const double t_g = now_s();
+    const int rc = e2s_internal_find_candidates_compact(hc, &prm, st.size(), st.data(), off.data(), ln.data(), cb.data(), cl.data(), cp.data(), cd.data(), total, gmin,
+                                                        gmax - gmin, n_cand);
+    g_gather_s += t_g - t_in; g_compact_s += now_s() - t_g;
+    return rc;
 }
 
 extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src, const char* fasta_path,
@@ -343,6 +358,8 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     TailState ts;
     ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
     double up_b = 0;
+    const double t_phase2 = now_s();
+    g_gather_s = g_compact_s = 0;
     auto reads_on = [&](e2s_handle h0, e2s_handle h1) -> int {
         if (fasta_path) {
             int r2 = e2s_upload_reads_fasta(h0, fasta_path, nullptr);
@@ -421,6 +438,9 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     }
     rc = finish_tail(ts, fasta_path, snp_sink, snp_user, nullptr);
     fill_report(rep, &sp, &ts, mcl, n_clust, n_bases, chunks.size(), sp.up_s + up_b, t0);
+    if (getenv("E2S_CLI_TIMING"))
+        fprintf(stderr, "[timing]   chunked job: %.1f ms in all; streaming pass %.1f ms (uploads %.1f ms); second phase: gather %.1f ms, per-cluster pass %.1f ms, the rest (tail, sinks) %.1f ms\n",
+                (now_s() - t0) * 1e3, (t_phase2 - t0) * 1e3, sp.up_s * 1e3, g_gather_s * 1e3, g_compact_s * 1e3, (now_s() - t_phase2 - g_gather_s - g_compact_s) * 1e3);
     return rc;
 }
 
