@@ -86,6 +86,7 @@ struct e2s_ctx {
     uint64_t* d_scan_stats = nullptr;                            // [151 freq | n_records | n_bases] tallied by the scan kernel (in front of d_words)
     std::vector<uint64_t> host_fl_starts; std::vector<uint16_t> host_fl_lens;   // e2s_internal_flagged_list
     uint8_t* d_compact = nullptr; size_t compact_bytes = 0; uint64_t* d_compact_keys = nullptr; uint64_t compact_keys_cap = 0;   // e2s_internal_find_candidates_compact
+    std::vector<hipStream_t> up_streams;                         // upload_sliced
     bool ko_clean = false;                                       // the ordering pass's bucket counts are zero (its last kernel leaves them so)
     uint8_t* d_xchg = nullptr; size_t xchg_bytes = 0;            // e2s_resident_job: the two exchanges' send / receive buffers
     // the scan that writes the image itself (k_scan_seg<1, FUSED, true>): records live in d_img only, statistics come with the mail
@@ -268,6 +269,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->ev_pf) ev_destroy(h->ev_pf);
     if (h->ev_img) ev_destroy(h->ev_img);
     for (auto& e : h->ev_chunk) if (e) ev_destroy(e);
+    for (auto st : h->up_streams) stream_destroy(st);
     if (h->stream2) stream_destroy(h->stream2);
     if (h->stream) stream_destroy(h->stream);
     delete h;
@@ -348,6 +350,35 @@ static int narrow_lcp(e2s_ctx* h) {
     return E2S_OK;
 }
 
+// A large host-to-device copy from ordinary (pageable) memory is staged by the runtime through pinned buffers on the CALLING thread:
+// one thread's memcpy (15-25 GB/s on these hosts) bounds it, below what the link gives.  Cut into slices copied by a few threads, each
+// on a stream of its own, the staging runs on several cores and the DMA engines side by side.  E2S_UPLOAD_THREADS (default 4; 1 = one copy).
+#include <thread>
+static int upload_sliced(e2s_ctx* h, void* dst, const void* src, size_t bytes) {
+    static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 4;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(T_env, 1), bytes >> 24));     // (slices of at least 16 MB)
+    if (T == 1) { CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return E2S_OK; }
+    if (h->up_streams.size() < (size_t)T) {
+        const size_t have = h->up_streams.size();
+        h->up_streams.resize((size_t)T, nullptr);
+        for (size_t i = have; i < (size_t)T; ++i) CK(hipStreamCreateWithFlags(&h->up_streams[i], hipStreamNonBlocking));
+    }
+    CK(hipStreamSynchronize(h->stream));                        // (whatever was enqueued before must not be overtaken)
+    std::vector<int> rcs((size_t)T, 0);
+    std::vector<std::thread> th;
+    const int dev = h->device;
+    auto work = [&, dev](int t) {
+        const size_t a = (bytes / 256 * (size_t)t / (size_t)T) * 256, b = t == T - 1 ? bytes : (bytes / 256 * (size_t)(t + 1) / (size_t)T) * 256;
+        if (hipSetDevice(dev) != hipSuccess || hipMemcpyAsync((uint8_t*)dst + a, (const uint8_t*)src + a, b - a, hipMemcpyHostToDevice, h->up_streams[(size_t)t]) != hipSuccess ||
+            hipStreamSynchronize(h->up_streams[(size_t)t]) != hipSuccess) rcs[(size_t)t] = 1;
+    };
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int v : rcs) if (v) return fail(h, E2S_ERR_HIP, "sliced host-to-device copy failed");
+    return E2S_OK;
+}
+
 extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa) {
     dbg_entry("e2s_upload_bcr");
     int rc = check_desc(h, d);
@@ -363,19 +394,17 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
     if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
     if ((rc = dev_alloc(h, &h->da, n * h->yb))) return rc;
-    CK(hipMemcpyAsync(h->bwt, bwt, n, hipMemcpyHostToDevice, h->stream));
+    if ((rc = upload_sliced(h, h->bwt, bwt, n))) return rc;
     DevScratch stage8, stage;
     if (d->lcp_bytes == 8) {
         CK(stage8.alloc(n * 8));
-        CK(hipMemcpyAsync(stage8.p, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        if ((rc = upload_sliced(h, stage8.p, lcp, n * 8))) return rc;
         e2s_launch_narrow8((const uint8_t*)stage8.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
-    } else {
-        CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
-    }
+    } else if ((rc = upload_sliced(h, h->lcp, lcp, n * h->xb))) return rc;
     const size_t rec = (size_t)d->pos_bytes + d->da_bytes;
     CK(stage.alloc(n * rec + 16));
-    CK(hipMemcpyAsync(stage.p, pairsa, n * rec, hipMemcpyHostToDevice, h->stream));
+    if ((rc = upload_sliced(h, stage.p, pairsa, n * rec))) return rc;
     e2s_launch_unpack_pairsa((const uint8_t*)stage.p, n, d->pos_bytes, d->da_bytes, h->pos, h->zb, h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_pairsa");
     CK(hipEventRecord(h->ev[1], h->stream));
@@ -404,7 +433,7 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     const size_t rec = (size_t)d->da_bytes + d->pos_bytes + d->lcp_bytes + 1;
     DevScratch stage;
     CK(stage.alloc(n * rec + 16));
-    CK(hipMemcpyAsync(stage.p, aos, n * rec, hipMemcpyHostToDevice, h->stream));
+    if ((rc = upload_sliced(h, stage.p, aos, n * rec))) return rc;
     e2s_launch_unpack_gesa((const uint8_t*)stage.p, n, d->da_bytes, d->pos_bytes, d->lcp_bytes, h->bwt, h->lcp, h->xb, h->pos, h->zb,
                            h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_gesa");
@@ -449,14 +478,12 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
     DevScratch stage;
     if (d->lcp_bytes == 8) {
         CK(stage.alloc(n * 8));
-        CK(hipMemcpyAsync(stage.p, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        if ((rc = upload_sliced(h, stage.p, lcp, n * 8))) return rc;
         e2s_launch_narrow8((const uint8_t*)stage.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
         CK(hipStreamSynchronize(h->stream));
         stage.release();
-    } else {
-        CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
-    }
+    } else if ((rc = upload_sliced(h, h->lcp, lcp, n * h->xb))) return rc;
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
     CK(hipGetLastError());
@@ -477,14 +504,14 @@ extern "C" int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const v
     CK(hipEventRecord(h->ev[0], h->stream));
     if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
-    CK(hipMemcpyAsync(h->bwt, bwt, n, hipMemcpyHostToDevice, h->stream));
+    if ((rc = upload_sliced(h, h->bwt, bwt, n))) return rc;
     DevScratch stage;
     if (d->lcp_bytes == 8) {
         CK(stage.alloc(n * 8));
-        CK(hipMemcpyAsync(stage.p, lcp, n * 8, hipMemcpyHostToDevice, h->stream));
+        if ((rc = upload_sliced(h, stage.p, lcp, n * 8))) return rc;
         e2s_launch_narrow8((const uint8_t*)stage.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
-    } else CK(hipMemcpyAsync(h->lcp, lcp, n * h->xb, hipMemcpyHostToDevice, h->stream));
+    } else if ((rc = upload_sliced(h, h->lcp, lcp, n * h->xb))) return rc;
     CK(hipEventRecord(h->ev[1], h->stream));
     CK(hipStreamSynchronize(h->stream));
     stage.release();
