@@ -2222,9 +2222,12 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     h->ko_clean = false;
     e2s_launch_job_plan(pa, h->stream);
     LCHK("e2s_launch_job_plan");
-    // ---- the `.clusters` image on the second stream, beside the per-cluster pass: laid out from the segments (offsets: k_seg_fix), then
-    // finished in place from the plan.  (Started right behind k_seg_fix it saturated HBM under the plan's one block: 45-65 us for it.)
-    if (p->want_image) {
+    // ---- the `.clusters` image on the second stream: laid out from the segments (offsets: k_seg_fix), then finished in place from the
+    // plan.  WHERE it starts decides what it runs beside -- it is bandwidth bound, the per-cluster pass and the tail latency bound, and
+    // whatever runs beside it waits longer for every gather (E2S_JOB_IMAGE_AT: 0 behind the plan, 1 behind the ordering pass, 2 behind
+    // the tail's text).  (Right behind k_seg_fix it saturated HBM under the plan's one block: 45-65 us for that.)
+    static const int image_at = getenv("E2S_JOB_IMAGE_AT") ? atoi(getenv("E2S_JOB_IMAGE_AT")) : 0;
+    auto image_now = [&]() -> int {
         if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
         CK(hipEventRecord(h->ev_img, h->stream));
         CK(hipStreamWaitEvent(h->stream2, h->ev_img, 0));
@@ -2233,7 +2236,9 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
         LCHK("e2s_launch_pack_segments");
         e2s_launch_img_patch_dev(h->d_img, h->img_cap, d_jd, d_scan_mail, p->min_len, h->stream2);
         CK(hipEventRecord(h->ev_img, h->stream2));
-    }
+        return E2S_OK;
+    };
+    if (p->want_image && image_at == 0 && (rc = image_now())) return rc;
     // ---- the per-cluster pass over the clusters the pre-filter let through (the list is on the stream already), SA order, offsets
     const bool defw = h->xb == 1 && h->yb == 4 && h->zb == 1;
     h->pf_inflight = false; h->pf_fused = false;
@@ -2245,6 +2250,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
     if ((rc = cand_order_and_mail(h, ca, d_cand_bad, h->d_part, 8 + ng * 3))) return rc;      // (the last kernel of the pass also clears the tail's sums)
+    if (p->want_image && image_at == 1 && (rc = image_now())) return rc;
     CK(hipEventRecord(h->ev[2], h->stream));
     e2s_launch_consensus(ta, h->list_cap, h->stream);
     LCHK("e2s_launch_consensus");
@@ -2257,6 +2263,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream);
     LCHK("e2s_launch_tail_write");
     CK(hipEventRecord(h->ev[5], h->stream));
+    if (p->want_image && image_at >= 2 && (rc = image_now())) return rc;
     static_assert(256 + (E2S_MAX_CLUST_LEN + 5) * 8 <= 1536, "the scan's mail and statistics end before the job record");
     JobDev* const jdh = (JobDev*)(h->pin_mail + 1536);
     CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 1536 + sizeof(JobDev), hipMemcpyDeviceToHost, h->stream));    // the scan's mail + statistics + the job record: one copy
