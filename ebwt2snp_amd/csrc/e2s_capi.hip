@@ -150,7 +150,7 @@ extern "C" const char* e2s_version(void) { return "ebwt2snp_amd 0.1 (gfx950)"; }
 
 extern "C" const char* e2s_last_error(e2s_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 // (private, ebwt2snp_amd/host/reads_upload.cpp) the outcome of a handle-less host call becomes the handle's message
-extern "C" void e2s_internal_set_error(e2s_handle h, const char* msg) { if (h) h->err = msg ? msg : ""; }
+extern "C" void e2s_internal_set_error(e2s_handle h, const char* msg) { (h ? h->err : g_create_error) = msg ? msg : ""; }
 
 extern "C" int e2s_create(int device_id, e2s_handle* out) {
     dbg_entry("e2s_create");
@@ -251,6 +251,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (!h) return E2S_OK;
     if (hipSetDevice(h->device) != hipSuccess) return fail(h, E2S_ERR_HIP, "e2s_destroy: the handle's device cannot be selected");
     if (h->stream) (void)hipStreamSynchronize(h->stream);      // (a failed stream is torn down all the same)
+    if (!h->err.empty()) g_create_error = h->err;               // a job that owned its handles failed: its message outlives them (e2s_last_error(NULL))
     release_shard(h);
     dev_free(h->d_starts); dev_free(h->d_lens);
     dev_free(h->d_scalars); dev_free(h->d_scan_stats); dev_free(h->d_kept_off); dev_free(h->d_xchg); dev_free(h->d_compact); dev_free(h->d_compact_keys);
@@ -728,7 +729,10 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;
     sa.k_u32 = a.k_u32; sa.kb = a.kb; sa.hge = a.hge;
     sa.n_tiles = (h->n_prov + row_entries - 1) / row_entries;
-    static int resident[5] = {0, 0, 0, 0, 0};
+    // (occupancy answers are the device's: the cache is per device -- one process may hold handles on several GPUs)
+    static int resident_dev[E2S_MAX_DEVICES][5] = {};
+    static int fused_resident_dev[E2S_MAX_DEVICES] = {};
+    int* const resident = resident_dev[h->device % E2S_MAX_DEVICES];
     if (!resident[h->xb]) {
         resident[h->xb] = e2s_scan_seg_resident_blocks(h->xb);
         if (const char* ev = getenv("E2S_SCAN_WORKERS")) {        // tuning aid: cap the number of scan workers
@@ -743,8 +747,9 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     const bool armed = first && h->pf_armed;
     const bool fused = armed && fused_env && prefilter_eligible(h);
     if (fused) {
-        static const int fused_resident = e2s_scan_seg_fused_resident_blocks();
-        nb = std::min<uint64_t>(nb, (uint64_t)std::max(fused_resident, 4));
+        int& fused_resident = fused_resident_dev[h->device % E2S_MAX_DEVICES];
+        if (!fused_resident) fused_resident = std::max(e2s_scan_seg_fused_resident_blocks(), 4);
+        nb = std::min<uint64_t>(nb, (uint64_t)fused_resident);
     } else if (armed) nb = std::min<uint64_t>(nb, 4096);         // leave registers for the pre-filter's waves beside it
     if (nb == 0) nb = 1;
     sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
@@ -763,6 +768,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
     if (!seg_cap) seg_cap = (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
     else if (seg_cap == ~0ull) seg_cap = range_entries + 16;          // worst case: room for everything
+    seg_cap = (seg_cap + 7) & ~7ull;                                   // (the layout kernel loads four records at once: 16-byte aligned segments)
     if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
     if ((rc = ensure_records(h, nb * seg_cap))) return rc;
     sa.seg_cap = (uint32_t)seg_cap; sa.starts32 = (uint32_t*)h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;

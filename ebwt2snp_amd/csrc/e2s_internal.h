@@ -203,6 +203,7 @@ struct TailArgs {
 
 // ---- the resident job without host round trips (e2s_resident_job): what one rank publishes, what the plan kernel derives ----
 #define E2S_JOB_BLOB 1344u                  // e2s_boundary (72 B) + e2s_scan_stats (1248 B), padded: one rank's share of the first all-gather
+#define E2S_MAX_DEVICES 64                    /* per-device caches of launch parameters (device id modulo this) */
 #define E2S_JOB_MAX_RANKS 64
 #define E2S_JOBERR_PLAN 16u                 // stat_rc: the gathered descriptors do not fit together
 #define E2S_JOBERR_SEEDS 32u                //          more wrapped clusters than seed slots

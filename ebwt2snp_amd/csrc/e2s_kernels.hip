@@ -1460,32 +1460,40 @@ __global__ __launch_bounds__(256) void k_pack_seg_write(SegArgs a, u32 row_entri
     const u64 rb = seg_range_base(a, b, row_entries);
     u64 done = off[b];                                          // records of the image before the trip at hand
     for (u32 c0 = 0; c0 < n; c0 += PKS_REC) {
-        // wave w looks at records c0 + 256 w + 64 q + lane, q = 0..3
-        u64 st[4]; u32 ln[4]; u32 keep[4]; u32 cnt = 0;
+        // thread t looks at the four records c0 + 4 t .. + 3: ONE 16-byte and ONE 8-byte load (the segment arrays are 16-byte aligned, c0 a
+        // multiple of 1024; the arrays are seg_cap long, a multiple of 8, so a whole load never leaves the segment)
+        const u32 i0 = c0 + 4u * tid;
+        uint4 s4 = make_uint4(0, 0, 0, 0); uint2 l2 = make_uint2(0, 0);
+        if (i0 < n) { s4 = *(const uint4*)(ps + i0); l2 = *(const uint2*)(pl + i0); }
+        const u32 sv[4] = {s4.x, s4.y, s4.z, s4.w};
+        const u32 lv[4] = {l2.x & 0xFFFFu, l2.x >> 16, l2.y & 0xFFFFu, l2.y >> 16};
+        u64 st[4]; u32 ln[4]; u32 keep[4]; u32 mine = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const u32 i = c0 + 256u * wave + 64u * q + lane;
-            ln[q] = i < n ? (u32)pl[i] : 0u;
-            st[q] = i < n ? ((i == 0u && d.first_unknown) ? d.first_start : rb + (u64)ps[i]) : 0ull;
+            const u32 i = i0 + (u32)q;
+            ln[q] = i < n ? lv[q] : 0u;
+            st[q] = (i == 0u && d.first_unknown) ? d.first_start : rb + (u64)sv[q];
             keep[q] = (i < n && ((int)ln[q] >= min_len || (i == 0u && b == slot0_b))) ? 1u : 0u;
-            cnt += (u32)__popcll(__ballot(keep[q] != 0u));
+            mine += keep[q];
         }
-        if (lane == 0) s_w[wave] = cnt;
+        // rank of the thread's first kept record: a wave scan (DPP) of the per-thread counts + the waves before
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= (u32)o) incl += v; }
+        if (lane == 63) s_w[wave] = incl;
         __syncthreads();
-        u32 r = 0;
+        u32 r = incl - mine;
         for (u32 w = 0; w < wave; ++w) r += s_w[w];
         const u32 m = s_w[0] + s_w[1] + s_w[2] + s_w[3];
         const u64 D = done * 10ull;                              // byte offset of the trip's first record in the image
         const u32 sh = (u32)(D & 15ull);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const u64 bm = __ballot(keep[q] != 0u);
             if (keep[q]) {
-                const u32 rr = r + (u32)__popcll(bm & ((1ull << lane) - 1ull));
-                uint16_t* o = (uint16_t*)(s_img + sh + (size_t)rr * 10);
+                uint16_t* o = (uint16_t*)(s_img + sh + (size_t)r * 10);
                 o[0] = (uint16_t)st[q]; o[1] = (uint16_t)(st[q] >> 16); o[2] = (uint16_t)(st[q] >> 32); o[3] = (uint16_t)(st[q] >> 48); o[4] = (uint16_t)ln[q];
+                ++r;
             }
-            r += (u32)__popcll(bm);
         }
         __syncthreads();
         // the 16-byte units [D & ~15, ...) that the trip's bytes [D, D + 10 m) touch: whole units as one store, the two partial ones by 2 bytes

@@ -555,7 +555,11 @@ void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint3
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) {
     if (!a.n_cand) return;
     if (list_cap < 1) list_cap = 1;
-    static size_t lds_set[2] = {0, 0};
+    // (a kernel's dynamic-LDS limit is set per device: the cache of what has been set is per device, too)
+    static size_t lds_set_dev[E2S_MAX_DEVICES][2] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t* const lds_set = lds_set_dev[dev % E2S_MAX_DEVICES];
     if (a.kl <= 32) {                                               // two candidates per wave
         const size_t per_wave = (size_t)2 * 2 * list_cap * (64 + 8 + 4);
         const unsigned wpb = 4 * per_wave <= 60 * 1024 ? 4u : 2 * per_wave <= 120 * 1024 ? 2u : 1u;

@@ -20,6 +20,7 @@
 
 #include "../../include/e2s_hip.h"
 
+extern "C" void e2s_internal_set_error(e2s_handle h, const char* msg);   // e2s_capi.hip: h == nullptr: this thread's handle-less message
 extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src);    // e2s_capi.hip (not part of the public ABI)
 extern "C" int e2s_internal_flagged_list(e2s_handle h, const uint64_t** starts, const uint16_t** lens, uint64_t* n, int* needs_full);
 extern "C" int e2s_internal_record_prefilter(e2s_handle h, int mcov_out, int max_clust_length, const uint64_t** starts, const uint16_t** lens, uint64_t* n);
@@ -58,7 +59,11 @@ class ChunkPipe {
     // mode 0: the LCP column (ebwt2clust), 1: all four columns, 2: LCP + BWT (the scan with clust2snp's pre-filter inside)
     ChunkPipe(const e2s_chunk_params& p, const e2s_egsa_source& src, const std::vector<Chunk>& chunks, int mode)
         : p_(p), src_(src), chunks_(chunks), mode_(mode) {}
-    ~ChunkPipe() { stop(); for (auto& h : h_) if (h) e2s_destroy(h); }
+    ~ChunkPipe() {
+        stop();
+        for (auto& h : h_) if (h) e2s_destroy(h);
+        if (rc_) e2s_internal_set_error(nullptr, err_.c_str());      // the uploader's failure is the job's message (e2s_last_error(NULL))
+    }
     // the two handles first -- the caller makes the reads resident on them from ITS thread -- and only then the uploader thread, which
     // works on the handles from then on (a handle is one thread's at a time)
     int create() {

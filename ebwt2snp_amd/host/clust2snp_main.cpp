@@ -101,13 +101,6 @@ int main(int argc, char** argv) {
     std::cout << "Output events will be stored in " << filename_out << std::endl;
 
     pc.mark("open files");
-    {
-        e2s_handle probe = nullptr;
-        const int rc0 = e2s_create(0, &probe);
-        if (rc0) { std::cerr << "GPU unavailable: " << e2s_last_error(nullptr) << std::endl; return 2; }
-        e2s_destroy(probe);
-    }
-    pc.mark("e2s_create (HIP start-up)");
     int rc;
 
     // statistics(), clust2snp.cpp:877-966: one pass over the records of the file (host threads)
@@ -159,7 +152,7 @@ int main(int argc, char** argv) {
     e2s_job_report rep{};
     rc = e2s_clust2snp_chunked(&cp, &co, max_clust_length, &src, CL.p, CL.n / 10, input.c_str(), filename_out.c_str(), &rep);
     if (pc.on) std::cerr << "[timing]   " << rep.n_chunks << " chunk(s), upload " << rep.seconds_upload * 1e3 << " ms of " << rep.seconds_total * 1e3 << " ms" << std::endl;
-    pc.mark("upload + candidates + tail + .snp");
+    pc.mark("HIP start-up + upload + candidates + tail + .snp");
     std::cout << " 100% done." << std::endl;
     std::cout << "Done. " << rep.n_candidates << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
     std::cout << "(2/4) Extracting reads from fasta file ..." << std::endl;
@@ -169,7 +162,7 @@ int main(int argc, char** argv) {
         std::cerr << "no candidate variant: the reference crashes here (SIGSEGV, clust2snp.cpp:531); no .snp written" << std::endl;
         return 139;
     }
-    if (rc) { std::cerr << "writing the .snp failed (" << rc << ")" << std::endl; return 2; }
+    if (rc) { std::cerr << "clust2snp failed (" << rc << "): " << e2s_last_error(nullptr) << std::endl; return 2; }
     std::cout << "Done. " << std::endl;
     return 0;
 }

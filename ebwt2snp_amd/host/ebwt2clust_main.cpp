@@ -61,13 +61,6 @@ int main(int argc, char** argv) {
     // The EGSA goes through the GPU in chunks of SA positions (one chunk if it fits): the next chunk uploads while the current one is
     // scanned, the chunks are stitched like the ranks of a multi-GPU job, and the records stream out of pinned staging buffers
     // into <input>.clusters -- any size of input, O(chunk) memory on the device (e2s_ebwt2clust_chunked).
-    {
-        e2s_handle probe = nullptr;
-        int rc0 = e2s_create(gpu, &probe);
-        if (rc0) { std::cerr << "GPU unavailable: " << e2s_last_error(nullptr) << std::endl; return 2; }
-        e2s_destroy(probe);
-    }
-    pc.mark("e2s_create (HIP start-up)");
     std::string filename_out = input;
     filename_out.append(".clusters");
     const int ofd = ::open(filename_out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
@@ -90,10 +83,15 @@ int main(int argc, char** argv) {
     cp.n_total = F.n; cp.chunk_entries = chunk_entries_env();
     e2s_job_report rep{};
     int rc = e2s_ebwt2clust_chunked(&cp, &src, sink, &sinkst, &rep);
-    if (rc) { std::cerr << "cluster scan failed (" << rc << ")" << std::endl; return 2; }
     if (ofd >= 0) ::close(ofd);
+    if (rc) {
+        // (the job owns its handles: its message is this thread's handle-less one; no GPU shows up here, too)
+        std::cerr << "cluster scan failed (" << rc << "): " << e2s_last_error(nullptr) << std::endl;
+        if (ofd >= 0) ::unlink(filename_out.c_str());             // no partial .clusters left behind
+        return 2;
+    }
     if (pc.on) std::cerr << "[timing]   " << rep.n_chunks << " chunk(s), upload " << rep.seconds_upload * 1e3 << " ms of " << rep.seconds_total * 1e3 << " ms" << std::endl;
-    pc.mark("upload + scan + records -> .clusters");
+    pc.mark("HIP start-up + upload + scan + records -> .clusters");
     const uint64_t n_closed = rep.n_closed;
     // the reference prints the count as unsigned int (ebwt2clust.cpp:88,137)
     std::cout << "Done. " << (unsigned int)n_closed << " clusters saved to output file." << std::endl;

@@ -73,3 +73,25 @@ cout << "Done. " << (unsigned)rep.n_closed << " clusters saved to output file." 
 // [end]
     return 0;
 }
+
+int snippet_resident_job(e2s_handle h, int k, int min_len, int rank, int world, uint64_t nr_reads1, int k_left, int k_right, int mcov_out, int consensus_reads,
+                         int max_gap, int max_err, double pval) {
+// [snippet 5: the whole step as one call per rank]
+struct Comm { /* ncclComm_t comm; */ };
+auto allgather = [](void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream) -> int {
+    (void)user; (void)d_send; (void)d_recv; (void)bytes_per_rank; (void)hip_stream;
+    // return ncclAllGather(d_send, d_recv, bytes_per_rank, ncclChar, ((Comm*)user)->comm, (hipStream_t)hip_stream) != ncclSuccess;
+    return 0;                                                   // ENQUEUED on the handle's stream: the library never waits for it on the host
+};
+Comm comm;
+e2s_resident_params rp = {k, min_len, rank, world, {nr_reads1, k_left, k_right, mcov_out, consensus_reads, max_gap, max_err, pval}, 1, 0};
+e2s_job_report jr;
+int rc = e2s_resident_job(h, &rp, allgather, &comm, &jr);        // shard + reads resident (e2s_upload_bcr, e2s_upload_reads_fasta): ONE enqueue, ONE wait
+if (rc == E2S_ERR_STATE || rc == E2S_ERR_CAPACITY) {
+    // this form does not apply to the input / a buffer was too small -- on every rank alike: the stepwise calls of section 3 run the step
+}
+// jr.n_ends, jr.n_records, jr.max_clust_length, jr.n_candidates, jr.n_events, jr.snp_bytes; both images in HBM:
+const void* d_clusters; uint64_t n_rec; e2s_clusters_image(h, &d_clusters, &n_rec);      // or e2s_stream_clusters / e2s_stream_snp in rank order
+// [end]
+    return rc + (int)n_rec;
+}

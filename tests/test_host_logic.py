@@ -335,3 +335,23 @@ def test_sanitizer_builds_over_goldens(tmp_path):
             assert r.returncode == 0 and r.stdout.startswith("ok:"), (meta["name"], exe, r.returncode, r.stdout[-500:], r.stderr[-3000:])
             assert "runtime error" not in r.stderr and "Sanitizer" not in r.stderr, (meta["name"], exe, r.stderr[-3000:])
             assert open(p + ".oracle.snp", "rb").read() == goldens.golden_snp(meta), meta["name"]
+
+
+def test_executables_without_a_gpu_say_why_and_leave_no_partial_output(tmp_path):
+    """The jobs own their handles: their failure text is the thread's handle-less message, and a failed ebwt2clust removes the
+    `.clusters` it had opened (a partial file used to stay behind, and only a number was printed)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    meta = [m for m in goldens.e2e_cases() if m["name"] == "tiny_bcr"][0]
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "bin", "ebwt2clust"), "-i", p], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "no HIP device available" in r.stderr and "no CPU path" in r.stderr, (r.returncode, r.stderr)
+    assert not os.path.exists(p + ".clusters")
+    with open(p + ".clusters", "wb") as f:
+        f.write(open(os.path.join(goldens.GOLD, "tiny_bcr.clusters"), "rb").read())
+    r = subprocess.run([os.path.join(root, "bin", "clust2snp"), "-i", p, "-n", str(n1)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "no HIP device available" in r.stderr, (r.returncode, r.stderr)
+    assert not os.path.exists(p[:p.rfind(".fast")] + ".snp")

@@ -7,7 +7,7 @@ usage: tools/profile_summary.py gpurun_out/<tag> profiles/<round> [workload]"""
 import csv, glob, json, os, sys
 
 OURS = ("k_scan", "k_seg", "k_hist", "k_cluster_filter", "k_flagged", "k_cand", "k_apply", "k_tile", "k_unpack", "k_ko",
-        "k_pack", "k_consensus", "k_tail", "k_reads", "k_record", "k_phase", "k_lcp", "k_snapshot")
+        "k_pack", "k_consensus", "k_tail", "k_reads", "k_record", "k_phase", "k_lcp", "k_snapshot", "k_job", "k_img")
 
 
 def ours(name):
