@@ -77,6 +77,8 @@ struct e2s_ctx {
     hipEvent_t ev_wait = nullptr;
     hipEvent_t ev_chunk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
+    hipStream_t stream3 = nullptr; hipEvent_t ev_k2b = nullptr, ev_cons = nullptr;   // e2s_resident_job: the consensus beside the ordering pass
+    bool tail_by_slot = false;                      // the tail's records / consensus strings are indexed by candidate slot (d_order maps the order to them)
     uint64_t* d_keys = nullptr;
     bool cand_downloaded = false;
     // segmented record storage (scan_mode 0): segment b = d_starts/d_lens[b*seg_cap ...), SegDesc per block
@@ -272,6 +274,9 @@ extern "C" int e2s_destroy(e2s_handle h) {
     for (auto& e : h->ev_chunk) if (e) ev_destroy(e);
     for (auto st : h->up_streams) stream_destroy(st);
     if (h->stream2) stream_destroy(h->stream2);
+    if (h->stream3) stream_destroy(h->stream3);
+    if (h->ev_k2b) ev_destroy(h->ev_k2b);
+    if (h->ev_cons) ev_destroy(h->ev_cons);
     if (h->stream) stream_destroy(h->stream);
     delete h;
     return E2S_OK;
@@ -1898,6 +1903,7 @@ static int tail_prepare(e2s_ctx* h, const e2s_tail_params* p, uint64_t n, TailAr
     a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
     a.kl = p->k_left; a.kr = p->k_right; a.max_gap = p->max_gap; a.max_err = p->max_err;
     a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = (uint32_t*)(h->d_part + 6);
+    a.stream8_cap = h->stream_cap_bytes / 8;
     return E2S_OK;
 }
 // the handle's state from the totals of a tail that has run: events, bytes of the text with ids from first_id, candidates kept, error bits
@@ -1929,6 +1935,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     const uint64_t n = h->n_cand, ng = (n + 63) / 64;
     TailArgs a;
     if ((rc = tail_prepare(h, p, n, a))) return rc;
+    h->tail_by_slot = false;
     unsigned long long* totals = h->d_part;
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
@@ -1974,6 +1981,7 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
         a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
         a.kl = h->tail_p.k_left; a.kr = h->tail_p.k_right; a.max_gap = h->tail_p.max_gap; a.max_err = h->tail_p.max_err;
         a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = h->d_part + 4; a.err = (uint32_t*)(h->d_part + 6);
+        a.slot_of = h->tail_by_slot ? h->d_order : nullptr;
         e2s_launch_tail_write(a, part_excl, first_id, nullptr, h->d_snp, h->snp_cap, h->stream);
         LCHK("e2s_launch_tail_write");
         CK(hipGetLastError());
@@ -2255,11 +2263,41 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     unsigned long long* totals = h->d_part;
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
-    if ((rc = cand_order_and_mail(h, ca, d_cand_bad, h->d_part, 8 + ng * 3))) return rc;      // (the last kernel of the pass also clears the tail's sums)
-    if (p->want_image && image_at == 1 && (rc = image_now())) return rc;
-    CK(hipEventRecord(h->ev[2], h->stream));
-    e2s_launch_consensus(ta, h->list_cap, h->stream);
-    LCHK("e2s_launch_consensus");
+    // The consensus needs the candidates, not their order: it runs BY SLOT on a third stream beside the ordering pass (four small kernels,
+    // 45 us alone on c3 and 190 us beside the image's layout); what follows the order -- the groups' sums, ids, text -- goes through d_order.
+    static const int cons_beside = getenv("E2S_JOB_CONS_BESIDE") ? atoi(getenv("E2S_JOB_CONS_BESIDE")) : 1;
+    if (cons_beside) {
+        if (!h->stream3) {
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            CK(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
+            CK(hipEventCreateWithFlags(&h->ev_k2b, hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&h->ev_cons, hipEventDisableTiming));
+        }
+        CK(hipMemsetAsync(h->d_part, 0, 64, h->stream));         // the tail's totals, n_keep and error word (the groups' sums are WRITTEN, not added to)
+        CK(hipEventRecord(h->ev_k2b, h->stream));
+        CK(hipStreamWaitEvent(h->stream3, h->ev_k2b, 0));
+        TailArgs tb = ta;
+        tb.by_slot = 1u; tb.off8 = h->d_slot_off8;
+        e2s_launch_consensus(tb, h->list_cap, h->stream3);
+        LCHK("e2s_launch_consensus");
+        CK(hipEventRecord(h->ev_cons, h->stream3));
+        CK(hipEventRecord(h->ev[2], h->stream));
+        if ((rc = cand_order_and_mail(h, ca, d_cand_bad))) return rc;
+        if (p->want_image && image_at == 1 && (rc = image_now())) return rc;
+        CK(hipStreamWaitEvent(h->stream, h->ev_cons, 0));
+        ta.slot_of = h->d_order;
+        e2s_launch_tail_group_sums(ta, (uint32_t)ng, h->stream);
+        LCHK("e2s_launch_tail_group_sums");
+        h->tail_by_slot = true;
+    } else {
+        if ((rc = cand_order_and_mail(h, ca, d_cand_bad, h->d_part, 8 + ng * 3))) return rc;      // (the last kernel of the pass also clears the tail's sums)
+        if (p->want_image && image_at == 1 && (rc = image_now())) return rc;
+        CK(hipEventRecord(h->ev[2], h->stream));
+        e2s_launch_consensus(ta, h->list_cap, h->stream);
+        LCHK("e2s_launch_consensus");
+        h->tail_by_slot = false;
+    }
     e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, 1, totals, totals + 4, tail_err, d_jd, blob2, &d_scan_mail->err, &d_jd->stat_rc, d_cand_bad, h->stream);
     LCHK("e2s_launch_tail_partials");
     if (W > 1) {                                                // exchange 2: (events, ok) -> this rank's first id

@@ -180,7 +180,7 @@ struct FilterArgs {
 #define E2S_TAILERR_RANK  1u   // a candidate names a read past the last one (the reference repeats stale text: host tail instead)
 #define E2S_TAILERR_CRASH 2u   // right_pos beyond the read's end: substr throws in the reference
 struct TailRec {               // one per candidate, written by k_consensus
-    uint32_t emit;             // both supports > 0 and distance <= 3: an event of the `.snp`
+    uint32_t emit;             // bit 0: both supports > 0 and distance <= 3: an event of the `.snp`; bit 1: both supports > 0 (a candidate "kept")
     int32_t  L;                // indel length of distance() (0: SNP)
     uint32_t s0, s1;           // supports
     uint32_t right_len;        // length of the right context
@@ -199,6 +199,13 @@ struct TailArgs {
     unsigned long long* n_keep;
     uint32_t* err;
     const unsigned long long* n_cand_dev;                        // != nullptr: the number of candidates lives on the device (n_cand = the launch's capacity)
+    // the consensus BESIDE the ordering pass (e2s_resident_job): k_consensus* take candidate SLOTS as the per-cluster pass filled them
+    // (by_slot: off8 = the slot table, rec / cons indexed by slot, no group sums), and what follows the order goes through
+    // slot_of (SA-ordered index -> slot): k_tail_group_sums, k_tail_write
+    const uint32_t* slot_of; uint32_t by_slot;
+    // 8-byte units of `stream` that exist: where the per-cluster pass ran out of room (the resident job finds out at its one wait, after the
+    // tail has run) a slot's offset points past what was written -- such a candidate is skipped, nothing outside the buffer is read
+    uint64_t stream8_cap;
 };
 
 // ---- the resident job without host round trips (e2s_resident_job): what one rank publishes, what the plan kernel derives ----
@@ -219,6 +226,7 @@ struct JobDev {                             // device copy at d_mail + 1536; rea
     uint32_t my_ok, reserved;               // this rank's verdict on its own step (what it sends in the second all-gather)
 };
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st);
+void e2s_launch_tail_group_sums(const TailArgs& a, uint32_t ng, hipStream_t st);
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, JobDev* jd, unsigned long long* blob2,
                               const uint32_t* bad_a, const uint32_t* bad_b, const uint32_t* bad_c, hipStream_t st);

@@ -125,9 +125,13 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     uint16_t* const ctx = (uint16_t*)(s_tail + wave * per_wave);    // [2 * list_cap][64] of (character | 8 * base_to_int << 8): allele 0's rows, then allele 1's
     u64* const rbase = (u64*)(s_tail + wave * per_wave + (size_t)2 * list_cap * 128);   // text offset of row j's first character
     u32* const rhave = (u32*)(rbase + 2 * list_cap);                // characters of row j that exist (the rest read as 0)
-    const uint8_t* r = a.stream + (size_t)a.off8[c] * 8;
+    const u32 o8 = a.off8[c];
+    bool rec_ok = (u64)o8 + 2ull <= a.stream8_cap;
+    const uint8_t* r = a.stream + (size_t)(rec_ok ? o8 : 0u) * 8;
     const u32* w = (const u32*)r;
-    const u32 n0 = w[0], n1 = w[1], right_idx = w[2], right_pos = w[3];
+    u32 n0 = rec_ok ? w[0] : 0u, n1 = rec_ok ? w[1] : 0u;
+    const u32 right_idx = w[2], right_pos = w[3];
+    if (!rec_ok || (u64)o8 + ((16ull + (4ull + a.pos_pack) * ((u64)n0 + n1) + 7ull) >> 3) > a.stream8_cap) n0 = n1 = 0u;   // (a record that was never written: no event)
     const u32 kl = (u32)a.kl;
     uint8_t* const sa = s_ab[wave][0];
     uint8_t* const sb = s_ab[wave][1];
@@ -228,11 +232,13 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
         const u32 l3 = 1u + kind + 12u + 5u + drl + 1u + tlen + 1u + tl_digits32(supp[1]) + 10u;
         const u32 l2 = kl - (L < 0 ? (u32)(-L) : 0u) + right_len + 1u, l4 = kl - (L > 0 ? (u32)L : 0u) + right_len + 1u;
         TailRec t;
-        t.emit = emit ? 1u : 0u; t.L = L; t.s0 = supp[0]; t.s1 = supp[1]; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
+        t.emit = (emit ? 1u : 0u) | (keep ? 2u : 0u); t.L = L; t.s0 = supp[0]; t.s1 = supp[1]; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
         a.rec[c] = t;
         // (per group of 64 candidates: one counter for the whole job saturates at ~90 atomics per microsecond -- 3 ms for 2.6x10^5 waves)
-        if (keep) atomicAdd(&a.part[3 * (c >> 6) + 2], 1ull);
-        if (emit) { atomicAdd(&a.part[3 * (c >> 6)], 1ull); atomicAdd(&a.part[3 * (c >> 6) + 1], (u64)t.base_len); }
+        if (!a.by_slot) {                                           // (by slot: the groups are those of the ORDER, summed by k_tail_group_sums)
+            if (keep) atomicAdd(&a.part[3 * (c >> 6) + 2], 1ull);
+            if (emit) { atomicAdd(&a.part[3 * (c >> 6)], 1ull); atomicAdd(&a.part[3 * (c >> 6) + 1], (u64)t.base_len); }
+        }
         if (bad) atomicOr(a.err, bad);
     }
 }
@@ -257,9 +263,13 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     uint16_t* const ctx = (uint16_t*)mine;                          // [2 * list_cap][32] of (character | 8 * base_to_int << 8)
     u64* const rbase = (u64*)(mine + (size_t)2 * list_cap * 64);
     u32* const rhave = (u32*)(rbase + 2 * list_cap);
-    const uint8_t* r = a.stream + (size_t)a.off8[valid ? c : c0] * 8;
+    const u32 o8 = a.off8[valid ? c : c0];
+    const bool rec_ok = (u64)o8 + 2ull <= a.stream8_cap;
+    const uint8_t* r = a.stream + (size_t)(rec_ok ? o8 : 0u) * 8;
     const u32* w = (const u32*)r;
-    const u32 n0 = valid ? w[0] : 0u, n1 = valid ? w[1] : 0u, right_idx = w[2], right_pos = w[3];
+    u32 n0 = valid && rec_ok ? w[0] : 0u, n1 = valid && rec_ok ? w[1] : 0u;
+    const u32 right_idx = w[2], right_pos = w[3];
+    if ((u64)o8 + ((16ull + (4ull + a.pos_pack) * ((u64)n0 + n1) + 7ull) >> 3) > a.stream8_cap) n0 = n1 = 0u;      // (a record that was never written: no event)
     const u32 kl = (u32)a.kl;
     uint8_t* const sa = s_ab[wave][half][0];
     uint8_t* const sb = s_ab[wave][half][1];
@@ -365,12 +375,32 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
         const u32 l3 = 1u + kind + 12u + 5u + drl + 1u + tlen + 1u + tl_digits32(supp1) + 10u;
         const u32 l2 = kl - (L < 0 ? (u32)(-L) : 0u) + right_len + 1u, l4 = kl - (L > 0 ? (u32)L : 0u) + right_len + 1u;
         TailRec t;
-        t.emit = emit ? 1u : 0u; t.L = L; t.s0 = supp0; t.s1 = supp1; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
+        t.emit = (emit ? 1u : 0u) | (keep ? 2u : 0u); t.L = L; t.s0 = supp0; t.s1 = supp1; t.right_len = right_len; t.base_len = l1 + l2 + l3 + l4; t.right_at = right_at;
         a.rec[c] = t;
-        if (keep) atomicAdd(&a.part[3 * (c >> 6) + 2], 1ull);
-        if (emit) { atomicAdd(&a.part[3 * (c >> 6)], 1ull); atomicAdd(&a.part[3 * (c >> 6) + 1], (u64)t.base_len); }
+        if (!a.by_slot) {
+            if (keep) atomicAdd(&a.part[3 * (c >> 6) + 2], 1ull);
+            if (emit) { atomicAdd(&a.part[3 * (c >> 6)], 1ull); atomicAdd(&a.part[3 * (c >> 6) + 1], (u64)t.base_len); }
+        }
         if (bad) atomicOr(a.err, bad);
     }
+}
+
+// ---- the group sums where the consensus ran by slot (beside the ordering pass): group g = the SA-ordered candidates 64 g .. 64 g + 63
+__global__ __launch_bounds__(256) void k_tail_group_sums(TailArgs a, u32 ng) {
+    const u32 lane = tl_lane();
+    const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ng) return;
+    if (a.n_cand_dev) a.n_cand = min((u64)a.n_cand, (u64)*a.n_cand_dev);
+    const u64 c = g * 64 + lane;
+    u32 em = 0, bl = 0;
+    if (c < a.n_cand) { const TailRec* t = a.rec + a.slot_of[c]; em = t->emit; bl = (em & 1u) ? t->base_len : 0u; }
+    const u64 ev = __ballot((em & 1u) != 0u), kp = __ballot((em & 2u) != 0u);
+    for (int o = 32; o > 0; o >>= 1) bl += __shfl_xor(bl, o);
+    if (lane == 0) { a.part[3 * g] = (u64)__popcll(ev); a.part[3 * g + 1] = (u64)bl; a.part[3 * g + 2] = (u64)__popcll(kp); }
+}
+void e2s_launch_tail_group_sums(const TailArgs& a, uint32_t ng, hipStream_t st) {
+    if (!ng) return;
+    hipLaunchKernelGGL(k_tail_group_sums, dim3((ng + 3) / 4), dim3(256), 0, st, a, ng);
 }
 
 // ---- K3b: exclusive scan of the per-group (events, text bytes) pairs; totals behind the last group -------------------------
@@ -464,9 +494,11 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
     const u64 g = blockIdx.x;
     TailRec t; t.emit = 0; t.base_len = 0; t.L = 0; t.s0 = t.s1 = t.right_len = 0; t.right_at = 0;
+    u64 slot = g * 64 + lane;                                       // where this lane's candidate has its record and consensus strings
     {
         const u64 c = g * 64 + lane;
-        if (c < a.n_cand) t = a.rec[c];
+        if (c < a.n_cand) { if (a.slot_of) slot = a.slot_of[c]; t = a.rec[slot]; }
+        t.emit &= 1u;
     }
     // exclusive scan of (emit, base_len) inside the group
     const u64 em = __ballot(t.emit != 0u);
@@ -479,7 +511,7 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
     const u32 kl = (u32)a.kl;
     if (wave < 2 && t.emit) {
         const u32 line = wave;
-        const uint8_t* ca = a.cons + (g * 64 + lane) * 128;         // consensus of allele 0, of allele 1 at + 64
+        const uint8_t* ca = a.cons + slot * 128;                    // consensus of allele 0, of allele 1 at + 64
         uint8_t* b = s_hdr[line][lane];
         const int L = t.L;
         u32 at = 0;
@@ -502,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
     for (u32 k = 0; k < 4; ++k) {
         const int src = (int)(wave * 4 + k);
         if (!((em >> src) & 1ull)) continue;                        // (wave-uniform)
-        const u64 c2 = g * 64 + (u64)src;
+        const u64 c2 = __shfl((unsigned long long)slot, src);
         const int L = __shfl(t.L, src);
         const u32 rl = __shfl(t.right_len, src);
         const u64 rat = __shfl(t.right_at, src), o = __shfl(my_off, src);
