@@ -78,6 +78,7 @@ struct e2s_ctx {
     hipEvent_t ev_chunk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream2 = nullptr;                  // candidate records travel to the host while the order is computed
     hipStream_t stream3 = nullptr; hipEvent_t ev_k2b = nullptr, ev_cons = nullptr;   // e2s_resident_job: the consensus beside the ordering pass
+    unsigned long long* d_pieces = nullptr;          // e2s_resident_job: piece bounds [9] | candidate-slot snapshots [9] | done counters (u32 [8])
     bool tail_by_slot = false;                      // the tail's records / consensus strings are indexed by candidate slot (d_order maps the order to them)
     uint64_t* d_keys = nullptr;
     bool cand_downloaded = false;
@@ -275,6 +276,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     for (auto st : h->up_streams) stream_destroy(st);
     if (h->stream2) stream_destroy(h->stream2);
     if (h->stream3) stream_destroy(h->stream3);
+    dev_free(h->d_pieces);
     if (h->ev_k2b) ev_destroy(h->ev_k2b);
     if (h->ev_cons) ev_destroy(h->ev_cons);
     if (h->stream) stream_destroy(h->stream);
@@ -1943,7 +1945,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     CK(hipEventRecord(h->ev[2], h->stream));
     e2s_launch_consensus(a, h->list_cap, h->stream);
     LCHK("e2s_launch_consensus");
-    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, nullptr, nullptr, nullptr, nullptr, nullptr, h->stream);
+    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->stream);
     LCHK("e2s_launch_tail_partials");
     if (first_id) {                                              // first_id 0: the ids come later (e2s_renumber_snp writes the text, once)
         e2s_launch_tail_write(a, part_excl, first_id, nullptr, h->d_snp, h->snp_cap, h->stream);
@@ -2223,6 +2225,25 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     TailArgs ta;
     if ((rc = tail_prepare(h, &tp, ncap, ta))) return rc;
     ta.n_cand_dev = (const unsigned long long*)(h->d_scalars + 1);
+    // The consensus needs the candidates, not their order: it runs BY SLOT on a third stream beside the ordering pass (four small kernels,
+    // 45 us alone on c3 and 190 us beside the image's layout); what follows the order -- the groups' sums, ids, text -- goes through d_order.
+    // E2S_JOB_PIECES > 1 also cuts the per-cluster pass into pieces, piece c's consensus beside piece c + 1's lists: measured SLOWER (c3:
+    // 2.77 / 2.97 / 3.32 / 3.95 ms per step with 1 / 2 / 4 / 8 pieces) -- both kernels are chains of dependent gathers whose rate is set by
+    // the waves resident on the chip, and side by side they share the same wave slots and LDS (a quarter of the list takes K2b 290 us
+    // beside the consensus where the whole list takes 250 us alone).  Kept as a switch, with its tests; default one piece.
+    static const int cons_beside = getenv("E2S_JOB_CONS_BESIDE") ? atoi(getenv("E2S_JOB_CONS_BESIDE")) : 1;
+    static const int pieces_env = getenv("E2S_JOB_PIECES") ? atoi(getenv("E2S_JOB_PIECES")) : 1;
+    const uint32_t n_pieces = !cons_beside || pieces_env < 1 ? 1u : (uint32_t)std::min(pieces_env, E2S_JOB_MAX_PIECES);
+    if (cons_beside && !h->stream3) {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        CK(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
+        CK(hipEventCreateWithFlags(&h->ev_k2b, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&h->ev_cons, hipEventDisableTiming));
+    }
+    if (!h->d_pieces) CK(hipMalloc((void**)&h->d_pieces, 256));
+    if (!h->ev_chunk[0]) for (auto& e : h->ev_chunk) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    unsigned long long* const piece_bounds = h->d_pieces; unsigned long long* const piece_snap = h->d_pieces + 9; uint32_t* const piece_done = (uint32_t*)(h->d_pieces + 18);
     // ---- exchange 1, then everything the host used to do between the scan and the per-cluster pass, on the device
     if (W > 1 && allgather(user, blob, recv, E2S_JOB_BLOB, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
     JobPlanArgs pa{};
@@ -2232,6 +2253,8 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     pa.fl_starts = (unsigned long long*)h->d_fl_starts; pa.fl_lens = h->d_fl_lens;
     pa.cand_count = (unsigned long long*)(h->d_scalars + 1); pa.stream8_count = ca.stream8_count; pa.cand_err = h->d_words + 1;
     pa.ko_cnt = (uint32_t*)h->d_rank; pa.n_ko = e2s_cand_order_buckets(h->cand_cap) + 1u;
+    pa.zero8 = h->d_part;                                        // (tail_prepare above put it in place)
+    pa.fl_count = (const unsigned long long*)(h->d_scalars + 2); pa.n_pieces = n_pieces > 1 ? n_pieces : 0u; pa.piece_bounds = piece_bounds; pa.piece_snap = piece_snap; pa.piece_done = piece_done;
     if (!h->ko_clean) CK(hipMemsetAsync(h->d_rank, 0, (size_t)pa.n_ko * 4, h->stream));      // (a fresh buffer / an aborted pass: otherwise the last pass left them clean)
     h->ko_clean = false;
     e2s_launch_job_plan(pa, h->stream);
@@ -2253,34 +2276,31 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
         return E2S_OK;
     };
     if (p->want_image && image_at == 0 && (rc = image_now())) return rc;
-    // ---- the per-cluster pass over the clusters the pre-filter let through (the list is on the stream already), SA order, offsets
+    // ---- the per-cluster pass over the clusters the pre-filter let through (the list is on the stream already), in pieces; SA order, offsets
     const bool defw = h->xb == 1 && h->yb == 4 && h->zb == 1;
     h->pf_inflight = false; h->pf_fused = false;
-    e2s_launch_flagged_lists(ca, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
-    LCHK("e2s_launch_flagged_lists");
-    CK(hipEventRecord(h->ev[7], h->stream));
-    // ---- the tail, sized for the candidate slots there are; the kernels read the count on the device
+    // ---- the tail, sized for the candidate slots there are; the kernels read the counts on the device
     unsigned long long* totals = h->d_part;
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
-    // The consensus needs the candidates, not their order: it runs BY SLOT on a third stream beside the ordering pass (four small kernels,
-    // 45 us alone on c3 and 190 us beside the image's layout); what follows the order -- the groups' sums, ids, text -- goes through d_order.
-    static const int cons_beside = getenv("E2S_JOB_CONS_BESIDE") ? atoi(getenv("E2S_JOB_CONS_BESIDE")) : 1;
     if (cons_beside) {
-        if (!h->stream3) {
-            int prio_lo = 0, prio_hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            CK(hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi));
-            CK(hipEventCreateWithFlags(&h->ev_k2b, hipEventDisableTiming));
-            CK(hipEventCreateWithFlags(&h->ev_cons, hipEventDisableTiming));
-        }
-        CK(hipMemsetAsync(h->d_part, 0, 64, h->stream));         // the tail's totals, n_keep and error word (the groups' sums are WRITTEN, not added to)
-        CK(hipEventRecord(h->ev_k2b, h->stream));
-        CK(hipStreamWaitEvent(h->stream3, h->ev_k2b, 0));
+        // (the tail's totals, kept count and error word were cleared by k_job_plan; the groups' sums are WRITTEN by k_tail_group_sums, not added to)
         TailArgs tb = ta;
         tb.by_slot = 1u; tb.off8 = h->d_slot_off8;
-        e2s_launch_consensus(tb, h->list_cap, h->stream3);
-        LCHK("e2s_launch_consensus");
+        for (uint32_t c = 0; c < n_pieces; ++c) {
+            CandArgs cc = ca;
+            if (n_pieces > 1) {
+                cc.snap_out = piece_snap + c + 1; cc.done_ctr = piece_done + c;
+                e2s_launch_flagged_lists(cc, piece_bounds + c, piece_bounds + c + 1, defw, h->stream);
+                tb.slot_lo_dev = piece_snap + c; tb.n_cand_dev = piece_snap + c + 1;     // the slots this piece took
+            } else e2s_launch_flagged_lists(cc, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
+            LCHK("e2s_launch_flagged_lists");
+            CK(hipEventRecord(h->ev_chunk[c], h->stream));
+            CK(hipStreamWaitEvent(h->stream3, h->ev_chunk[c], 0));
+            e2s_launch_consensus(tb, h->list_cap, h->stream3);
+            LCHK("e2s_launch_consensus");
+        }
+        CK(hipEventRecord(h->ev[7], h->stream));
         CK(hipEventRecord(h->ev_cons, h->stream3));
         CK(hipEventRecord(h->ev[2], h->stream));
         if ((rc = cand_order_and_mail(h, ca, d_cand_bad))) return rc;
@@ -2291,6 +2311,9 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
         LCHK("e2s_launch_tail_group_sums");
         h->tail_by_slot = true;
     } else {
+        e2s_launch_flagged_lists(ca, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
+        LCHK("e2s_launch_flagged_lists");
+        CK(hipEventRecord(h->ev[7], h->stream));
         if ((rc = cand_order_and_mail(h, ca, d_cand_bad, h->d_part, 8 + ng * 3))) return rc;      // (the last kernel of the pass also clears the tail's sums)
         if (p->want_image && image_at == 1 && (rc = image_now())) return rc;
         CK(hipEventRecord(h->ev[2], h->stream));
@@ -2298,13 +2321,13 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
         LCHK("e2s_launch_consensus");
         h->tail_by_slot = false;
     }
-    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, 1, totals, totals + 4, tail_err, d_jd, blob2, &d_scan_mail->err, &d_jd->stat_rc, d_cand_bad, h->stream);
+    e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, 1, totals, totals + 4, tail_err, d_jd, blob2, &d_scan_mail->err, &d_jd->stat_rc, d_cand_bad,
+                             (const unsigned long long*)(h->d_scalars + 1), h->stream);
     LCHK("e2s_launch_tail_partials");
-    if (W > 1) {                                                // exchange 2: (events, ok) -> this rank's first id
+    if (W > 1) {                                                // exchange 2: (events, ok) -> this rank's first id (worked out by the text kernel itself)
         if (allgather(user, blob2, recv2, 16, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
-        e2s_launch_job_ids(recv2, W, p->rank, d_jd, h->stream);
-    }
-    e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream);
+        e2s_launch_tail_write(ta, part_excl, 1, nullptr, h->d_snp, h->snp_cap, h->stream, recv2, W, p->rank, d_jd);
+    } else e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream);
     LCHK("e2s_launch_tail_write");
     CK(hipEventRecord(h->ev[5], h->stream));
     if (p->want_image && image_at >= 2 && (rc = image_now())) return rc;

@@ -154,6 +154,9 @@ struct CandArgs {
     uint32_t* err;
     const uint64_t* keys;                           // k_flagged_lists: SA-order key of list entry r (nullptr: its start) -- clusters gathered into a compact buffer
     const int* len_hi_dev;                          // k_flagged_lists: the upper length bound lives on the device (the resident job: max_clust_length is worked out there)
+    // k_flagged_lists run over the list in pieces (the resident job: the consensus of a piece's candidates runs beside the next piece): the
+    // LAST block to finish leaves the number of candidate slots taken so far in *snap_out (done_ctr: cleared by the plan kernel)
+    unsigned long long* snap_out; uint32_t* done_ctr;
 };
 
 
@@ -203,6 +206,7 @@ struct TailArgs {
     // (by_slot: off8 = the slot table, rec / cons indexed by slot, no group sums), and what follows the order goes through
     // slot_of (SA-ordered index -> slot): k_tail_group_sums, k_tail_write
     const uint32_t* slot_of; uint32_t by_slot;
+    const unsigned long long* slot_lo_dev;                       // by_slot: this launch handles the slots [*slot_lo_dev, *n_cand_dev) (nullptr: from 0)
     // 8-byte units of `stream` that exist: where the per-cluster pass ran out of room (the resident job finds out at its one wait, after the
     // tail has run) a slot's offset points past what was written -- such a candidate is skipped, nothing outside the buffer is read
     uint64_t stream8_cap;
@@ -212,6 +216,7 @@ struct TailArgs {
 #define E2S_JOB_BLOB 1344u                  // e2s_boundary (72 B) + e2s_scan_stats (1248 B), padded: one rank's share of the first all-gather
 #define E2S_MAX_DEVICES 64                    /* per-device caches of launch parameters (device id modulo this) */
 #define E2S_JOB_MAX_RANKS 64
+#define E2S_JOB_MAX_PIECES 8
 #define E2S_JOBERR_PLAN 16u                 // stat_rc: the gathered descriptors do not fit together
 #define E2S_JOBERR_SEEDS 32u                //          more wrapped clusters than seed slots
 struct JobDev {                             // device copy at d_mail + 1536; reaches the host with the mail
@@ -229,12 +234,12 @@ void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st);
 void e2s_launch_tail_group_sums(const TailArgs& a, uint32_t ng, hipStream_t st);
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, JobDev* jd, unsigned long long* blob2,
-                              const uint32_t* bad_a, const uint32_t* bad_b, const uint32_t* bad_c, hipStream_t st);
-void e2s_launch_job_ids(const unsigned long long* blobs2, int world, int rank, JobDev* jd, hipStream_t st);
+                              const uint32_t* bad_a, const uint32_t* bad_b, const uint32_t* bad_c, const unsigned long long* n_cand_dev, hipStream_t st);
 void e2s_launch_reads_extent(const uint64_t* rstart, const uint32_t* rlen, uint64_t n_reads, unsigned long long* out, hipStream_t st);   // *out = max(start + len), *out zeroed by the caller
 void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st);
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, const unsigned long long* first_id_dev,
-                           uint8_t* out, unsigned long long out_cap, hipStream_t st);
+                           uint8_t* out, unsigned long long out_cap, hipStream_t st, const unsigned long long* ids2 = nullptr, int world = 1, int rank = 0,
+                           JobDev* jd = nullptr);
 
 void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st);
 void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,
@@ -275,6 +280,9 @@ struct JobPlanArgs {
     JobDev* out;
     unsigned long long* fl_starts; uint16_t* fl_lens;            // seed slots: the head of the flagged list
     unsigned long long* cand_count; unsigned long long* stream8_count; uint32_t* cand_err; uint32_t* ko_cnt; uint32_t n_ko;
+    unsigned long long* zero8;                                   // 8 words cleared here (nullptr: none)
+    // the per-cluster pass in pieces: bounds[c] = fl_count * c / n_pieces (list entries), snap[0] = 0 (candidate slots), done[c] = 0
+    const unsigned long long* fl_count; uint32_t n_pieces; unsigned long long* piece_bounds; unsigned long long* piece_snap; uint32_t* piece_done;
 };
 void e2s_launch_job_plan(const JobPlanArgs& a, hipStream_t st);
 void e2s_launch_img_patch_dev(uint8_t* img, unsigned long long cap, const JobDev* jd, const ScanMail* mail, int min_len, hipStream_t st);

@@ -1131,6 +1131,14 @@ __global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
     if (tid < sizeof(ScanMail) / 8) ((u64*)&s_mail)[tid] = ((const u64*)a.mail)[tid];
     // the per-cluster pass's counters (k_cand_init's part; the ordering pass's bucket counts were left clean by k_cand_offsets)
     if (tid == 255) { *a.cand_count = 0; *a.stream8_count = 0; *a.cand_err = 0; }
+    if (a.zero8 && tid >= 240 && tid < 248) a.zero8[tid - 240] = 0ull;
+    if (a.n_pieces && tid >= 200 && tid <= 200 + a.n_pieces) {  // (the flagged list is complete: the scan kernel wrote it)
+        const u32 c = tid - 200;
+        const u64 nfl = *a.fl_count;
+        a.piece_bounds[c] = c == a.n_pieces ? nfl : nfl / a.n_pieces * c;
+        a.piece_snap[c] = 0ull;                                  // ([0] stays 0; [c + 1] is written by piece c's last block)
+        if (c < a.n_pieces) a.piece_done[c] = 0u;
+    }      // the tail's totals, kept count and error word (a memset of its own cost a launch gap before the consensus)
     __syncthreads();
     for (u32 i = tid; i < (u32)W * (sizeof(e2s_boundary) / 8); i += 256u) {
         const u32 r = i / (sizeof(e2s_boundary) / 8), w = i % (sizeof(e2s_boundary) / 8);
@@ -2049,6 +2057,10 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
         __syncthreads();
     }
     stage_flush();
+    if (a.snap_out && tid == 0) {                                // (stage_flush ended in a barrier: the block's reservations are all made)
+        __threadfence();
+        if (atomicAdd(a.done_ctr, 1u) == gridDim.x - 1u) *a.snap_out = atomicAdd(a.cand_count, 0ull);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------

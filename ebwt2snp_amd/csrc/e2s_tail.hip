@@ -118,7 +118,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_tail[];
 __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     __shared__ uint8_t s_ab[4][2][128];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6;
-    const u64 c = (u64)blockIdx.x * (blockDim.x >> 6) + wave;      // (1, 2 or 4 waves per block: long lists need the LDS)
+    const u64 c = (a.slot_lo_dev ? (u64)*a.slot_lo_dev : 0ull) + (u64)blockIdx.x * (blockDim.x >> 6) + wave;      // (1, 2 or 4 waves per block: long lists need the LDS)
     if (a.n_cand_dev) a.n_cand = min((u64)a.n_cand, (u64)*a.n_cand_dev);
     if (c >= a.n_cand) return;
     const size_t per_wave = (size_t)2 * list_cap * (128 + 8 + 4);
@@ -253,7 +253,7 @@ __device__ __forceinline__ u32 tl_half_pop(u64 m, u32 half) { return (u32)__popc
 __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap) {
     __shared__ uint8_t s_ab[4][2][2][64];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
-    const u64 c0 = ((u64)blockIdx.x * (blockDim.x >> 6) + wave) * 2ull;
+    const u64 c0 = (a.slot_lo_dev ? (u64)*a.slot_lo_dev : 0ull) + ((u64)blockIdx.x * (blockDim.x >> 6) + wave) * 2ull;
     if (a.n_cand_dev) a.n_cand = min((u64)a.n_cand, (u64)*a.n_cand_dev);
     if (c0 >= a.n_cand) return;
     const u64 c = c0 + half;
@@ -414,9 +414,11 @@ __device__ __forceinline__ u64 tl_wave_incl_scan64(u64 x, u32 lane) {
 // second all-gather -- ok = no error bit of the tail and none in the words the per-cluster pass leaves (ok_words: its own and the pre-filter's)
 __global__ __launch_bounds__(1024) void k_tail_partials(const unsigned long long* part, unsigned long long* part_excl, u32 ng, u64 first_id,
                                                         unsigned long long* totals /* events, bytes, kept, error bits */, const unsigned long long* n_keep,
-                                                        const u32* err, JobDev* jd, unsigned long long* blob2, const u32* bad_a, const u32* bad_b, const u32* bad_c) {
+                                                        const u32* err, JobDev* jd, unsigned long long* blob2, const u32* bad_a, const u32* bad_b, const u32* bad_c,
+                                                        const unsigned long long* n_cand_dev) {
     __shared__ u64 s_e[1024], s_b[1024], s_k[16];
     const u32 tid = threadIdx.x, lane = tl_lane();
+    if (n_cand_dev) ng = (u32)min((u64)ng, (*n_cand_dev + 63ull) / 64ull);     // (the job sizes the launch for the slots there are: only the groups in use)
     const u32 per = (ng + 1023u) / 1024u, lo = min(ng, tid * per), hi = min(ng, lo + per);
     u64 se = 0, sb = 0, sk = 0;
     for (u32 g = lo; g < hi; ++g) { se += part[3 * g]; sb += part[3 * g + 1]; sk += part[3 * g + 2]; }
@@ -472,21 +474,22 @@ __device__ __forceinline__ u32 tl_put_num(uint8_t* b, u32 at, u64 v) {
 constexpr u32 TL_HDR_STRIDE = 148;                                  // >= the longest header (141), 37 words: lanes hit different banks
 // ids of the events of a rank: first_id = 1 + the events of the ranks before it (second all-gather: (events, ok) per rank); the size of
 // its text follows in closed form (only the id digits depend on first_id)
-__global__ void k_job_ids(const unsigned long long* blobs2, int world, int rank, JobDev* jd) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 before = 0; u32 bad = 0;
-    for (int r = 0; r < world; ++r) { if (r < rank) before += blobs2[2 * r]; if (blobs2[2 * r + 1] == 0ull) bad = 1u; }
-    const u64 ne = jd->events, old_id = jd->first_id, new_id = 1ull + before;
-    const u64 text = jd->snp_bytes - 2ull * (tl_digit_sum_below(old_id + ne) - tl_digit_sum_below(old_id));
-    jd->snp_bytes = text + 2ull * (tl_digit_sum_below(new_id + ne) - tl_digit_sum_below(new_id));
-    jd->first_id = new_id; jd->events_before = before; jd->peers_not_ok = bad;
-}
-void e2s_launch_job_ids(const unsigned long long* blobs2, int world, int rank, JobDev* jd, hipStream_t st) {
-    hipLaunchKernelGGL(k_job_ids, dim3(1), dim3(64), 0, st, blobs2, world, rank, jd);
-}
+// ids2 (the resident job on several ranks): the gathered (events, ok) pairs -- every block derives the rank's first id from them (a
+// launch of its own for that was 4 us + a launch gap on the critical path), block 0 completes the job's record
 __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, const unsigned long long* first_id_dev, uint8_t* out,
-                                                     u64 out_cap) {
+                                                     u64 out_cap, const unsigned long long* ids2, int world, int rank, JobDev* jd) {
     if (first_id_dev) first_id = *first_id_dev;
+    if (ids2) {
+        u64 before = 0; u32 bad = 0;
+        for (int r = 0; r < world; ++r) { if (r < rank) before += ids2[2 * r]; if (ids2[2 * r + 1] == 0ull) bad = 1u; }
+        first_id = 1ull + before;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const u64 ne = jd->events, old_id = jd->first_id;
+            const u64 text = jd->snp_bytes - 2ull * (tl_digit_sum_below(old_id + ne) - tl_digit_sum_below(old_id));
+            jd->snp_bytes = text + 2ull * (tl_digit_sum_below(first_id + ne) - tl_digit_sum_below(first_id));
+            jd->first_id = first_id; jd->events_before = before; jd->peers_not_ok = bad;
+        }
+    }
     if (a.n_cand_dev) a.n_cand = min((u64)a.n_cand, (u64)*a.n_cand_dev);
     if ((u64)blockIdx.x * 64ull >= a.n_cand) return;
     __shared__ __attribute__((aligned(4))) uint8_t s_hdr[2][64][TL_HDR_STRIDE];
@@ -609,11 +612,11 @@ void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) 
 }
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, JobDev* jd, unsigned long long* blob2,
-                              const uint32_t* bad_a, const uint32_t* bad_b, const uint32_t* bad_c, hipStream_t st) {
-    hipLaunchKernelGGL(k_tail_partials, dim3(1), dim3(1024), 0, st, part, part_excl, ng, first_id, totals, n_keep, err, jd, blob2, bad_a, bad_b, bad_c);
+                              const uint32_t* bad_a, const uint32_t* bad_b, const uint32_t* bad_c, const unsigned long long* n_cand_dev, hipStream_t st) {
+    hipLaunchKernelGGL(k_tail_partials, dim3(1), dim3(1024), 0, st, part, part_excl, ng, first_id, totals, n_keep, err, jd, blob2, bad_a, bad_b, bad_c, n_cand_dev);
 }
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, const unsigned long long* first_id_dev,
-                           uint8_t* out, unsigned long long out_cap, hipStream_t st) {
+                           uint8_t* out, unsigned long long out_cap, hipStream_t st, const unsigned long long* ids2, int world, int rank, JobDev* jd) {
     if (!a.n_cand) return;
-    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)((a.n_cand + 63) / 64)), dim3(1024), 0, st, a, part_excl, first_id, first_id_dev, out, out_cap);
+    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)((a.n_cand + 63) / 64)), dim3(1024), 0, st, a, part_excl, first_id, first_id_dev, out, out_cap, ids2, world, rank, jd);
 }

@@ -808,6 +808,29 @@ def test_resident_job_images_equal_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_resident_job_in_pieces(tmp_path):
+    """e2s_resident_job with its per-cluster pass cut into 3 and 8 pieces (E2S_JOB_PIECES; the consensus of piece c runs by candidate SLOT on
+    a third stream beside the lists of piece c + 1 and beside the ordering pass): both images are the oracle's files.  The library reads
+    the switch when it is loaded: one child process per setting (tests/job_pieces_driver.py), one after the other"""
+    import subprocess
+    import sys
+    reads, n1, e = synth.synth_case(5000, 100, seed=71)
+    en = synth.egsa_to_numpy(e)
+    p = str(tmp_path / "j.fasta")
+    IO.write_fasta(p, reads.numpy())
+    IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+    assert O.ebwt2clust(p)[0] == 0 and O.clust2snp(p, O.c2s_opts(n1))[0] == 0
+    want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
+    drv = os.path.join(os.path.dirname(os.path.abspath(__file__)), "job_pieces_driver.py")
+    for pieces, beside in ((3, 1), (8, 1), (0, 0)):
+        out = str(tmp_path / ("img%d_%d" % (pieces, beside)))
+        env = dict(os.environ, E2S_JOB_PIECES=str(pieces), E2S_JOB_CONS_BESIDE=str(beside))
+        r = subprocess.run([sys.executable, drv, out], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (pieces, r.stdout[-800:], r.stderr[-1500:])
+        assert open(out + ".clusters", "rb").read() == want_cl and open(out + ".snp", "rb").read() == want_snp, (pieces, beside)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["c2_first_1e8", "c3_block"])
 def test_full_size_outputs_equal_reference(case, tmp_path):
     """BASELINE.json's single-GPU configurations at full scale against the reference's own executables (oracle/_ref): the first 10^8
@@ -913,11 +936,15 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
             a += ["-" + kk, str(vv)]
         for kk, vv in meta["c2s"].items():
             a += ["-" + ("M" if kk == "m" else kk), str(vv)]
-        for ranks, shared in ((1, False), (2, True), (3, True), (5, True)):
+        # (pieces: the native job's per-cluster pass cut into that many launches, the consensus of one piece beside the next -- inputs this
+        #  small take one piece by default)
+        for ranks, shared, pieces in ((1, False, 0), (2, True, 0), (3, True, 3), (5, True, 0), (1, False, 8)):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
             env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0")
+            if pieces:
+                env["E2S_JOB_PIECES"] = str(pieces)
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)] + a, capture_output=True, text=True, env=env, timeout=300)
             assert r.returncode == 0, (meta["name"], ranks, r.stdout[-800:], r.stderr[-800:])
             assert ("RCCL all-gather" in r.stdout) == (not shared)
