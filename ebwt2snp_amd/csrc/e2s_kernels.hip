@@ -2429,7 +2429,8 @@ void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst,
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
     // room for two rounds' worst case and, at usual list lengths, ~200 packed candidates between two global reservations
     const uint32_t max8 = (16u + (4u + a.pos_pack) * 2u * a.list_cap + 7u) >> 3;
-    const uint32_t cap8 = std::max<uint32_t>(3072u, 2u * 16u * max8);
+    static const int env_cap8 = getenv("E2S_K2B_CAP8") ? atoi(getenv("E2S_K2B_CAP8")) : 0;
+    const uint32_t cap8 = std::max<uint32_t>(env_cap8 > 0 ? (uint32_t)env_cap8 : 3072u, 2u * 16u * max8);
     const size_t dyn = (size_t)cap8 * 8;
     static const int env_blocks = getenv("E2S_K2B_BLOCKS") ? atoi(getenv("E2S_K2B_BLOCKS")) : 0;
     // c2 (2x10^4 flagged clusters): 512 / 1024 / 2048 / 4096 blocks -> 0.124 / 0.117 / 0.131 / 0.177 ms for the phase; c3 (3x10^5): 1024 / 4096 ->

@@ -534,6 +534,8 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
         s_hlen[line][lane] = (uint8_t)at;
     }
     __syncthreads();
+    // (fetching the four events' consensus strings and right contexts before the first is written -- ahead of the header work or behind it --
+    //  and 32-bit digit arithmetic were measured: 156-159 us against 135-146 on c3; the plain loop stays)
     for (u32 k = 0; k < 4; ++k) {
         const int src = (int)(wave * 4 + k);
         if (!((em >> src) & 1ull)) continue;                        // (wave-uniform)
