@@ -249,6 +249,9 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
 // lanes 0-31 serve candidate 2w, lanes 32-63 candidate 2w + 1: the same instruction stream, loops running to the longer of the two
 // lists, ballots read per half.  Results are those of k_consensus (same order of rows, same tie-breaks).
 // Dynamic LDS per wave: 2 candidates x 2 x list_cap rows of 32 x 2 B + (8 + 4) B of row base / length each.
+// (Round 3: the record's first 256 bytes fetched as ONE window, two dwords per lane, header / list entries / positions picked out of the
+// registers by ds_bpermute -- a chain of five dependent round trips cut to three -- changed nothing: 470 us against 469 on c3.  The kernel
+// is bound by the issue of its ~950 vector instructions per wave as much as by its gathers; see profiles/round3_k2b_variants.txt.)
 __device__ __forceinline__ u32 tl_half_pop(u64 m, u32 half) { return (u32)__popc(half ? (u32)(m >> 32) : (u32)m); }
 __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap) {
     __shared__ uint8_t s_ab[4][2][2][64];
@@ -534,8 +537,8 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
         s_hlen[line][lane] = (uint8_t)at;
     }
     __syncthreads();
-    // (fetching the four events' consensus strings and right contexts before the first is written -- ahead of the header work or behind it --
-    //  and 32-bit digit arithmetic were measured: 156-159 us against 135-146 on c3; the plain loop stays)
+    // (fetching the four events' consensus strings and right contexts ahead of the header work, together with 32-bit digit arithmetic,
+    //  was measured: 156-159 us against 135-146 on c3 -- twelve more registers live across the barrier; the plain loop stays)
     for (u32 k = 0; k < 4; ++k) {
         const int src = (int)(wave * 4 + k);
         if (!((em >> src) & 1ull)) continue;                        // (wave-uniform)
