@@ -649,6 +649,18 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
     other = measure(False, min(warmup, 2) + 1, max(3, steps // 2)) if SECOND_LEG and emul is None else None
     host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True) if emul is None else None
     info = prim["info"]
+    # the `.clusters` layout kernel alone (in the step it runs on the second stream beside the per-cluster pass, where its time says
+    # little about the kernel): scan, wait, then ONE synchronous e2s_pack_clusters under the wall clock (~15 us of call overhead included)
+    layout_ms = None
+    if emul is None and world == 1:
+        ts = []
+        for _ in range(6):
+            h.cluster_scan(16, 2, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h.pack_clusters(async_=False)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        layout_ms = float(np.median(ts[1:]))
     keys = ("n_ends", "n_cand", "mcl", "n_events", "snp_bytes", "n_records")
     if other is not None:
         assert tuple(other["info"][k2] for k2 in keys) == tuple(info[k2] for k2 in keys), "the two modes differ"
@@ -707,6 +719,10 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
                                 "frac_uses": "algorithmic_bytes (2 B/entry read + 6 B/record written: the segment record of round 3)",
                                 "frac_with_10_byte_records": (n_own * 2 + info["n_ends"] * 10) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,   # (rounds 1-2 accounting)
                                 "hist_ms": float(np.mean(prim["hist_ms"]))})
+        if layout_ms:
+            res["roofline_image_layout"] = roof("k_pack_seg_write", info["n_ends"] * 6 + info["n_records"] * 10, layout_ms,
+                                                "the `.clusters` layout kernel alone (6 B read per segment record + 10 B written per file record), wall clock "
+                                                "around one synchronous call; in the step it runs on the second stream beside the per-cluster pass")
         if host:
             res["config"]["outputs_on_host_phase_ms"] = {k2: round(v / host["steps"] * 1e3, 4) for k2, v in host["phases"].items()}
         if other is not None:

@@ -1873,6 +1873,8 @@ static int tail_applicable(e2s_ctx* h, const e2s_tail_params* p) {
     if (p->k_left < 0) return fail(h, E2S_ERR_REF_CRASH, "negative -L: the reference throws here");                // cons(size_t(-n)) throws in the reference
     if (p->k_left < 1 || p->k_left > 64) return fail(h, E2S_ERR_STATE, "GPU tail: -L outside 1..64 (use the host tail, e2s_snp_from_packed)");
     if (h->text_bytes < 4) return fail(h, E2S_ERR_STATE, "GPU tail: fewer than 4 bytes of reads (use the host tail, e2s_snp_from_packed)");
+    if (hipSetDevice(h->device) == hipSuccess && h->list_cap && !e2s_consensus_fits(p->k_left, h->list_cap))
+        return fail(h, E2S_ERR_STATE, "GPU tail: lists of this length (-c) do not fit the device's LDS (use the host tail, e2s_snp_from_packed)");
     return E2S_OK;
 }
 // buffers for up to n candidates and the kernels' arguments (a.n_cand = n: the launches' extent)
@@ -2186,6 +2188,11 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     const e2s_tail_params tp{p->o.k_left, p->o.k_right, p->o.max_gap, p->o.max_err};
     int rc = tail_applicable(h, &tp);
     if (rc) return rc;
+    {
+        const e2s_c2s_params cp0{p->o.nr_reads1, p->o.k_left, p->o.k_right, p->o.mcov_out, p->o.consensus_reads, (int)E2S_MAX_CLUST_LEN, p->min_len};
+        if (hipSetDevice(h->device) != hipSuccess || !e2s_consensus_fits(p->o.k_left, list_cap_of(&cp0)))
+            return fail(h, E2S_ERR_STATE, "resident job: lists of this length (-c) do not fit the device's LDS: use the stepwise calls (host tail)");
+    }
     const e2s_shard_desc& d = h->d;
     const bool last_rank = d.global_offset + d.n_entries == d.n_total;
     if (last_rank != (p->rank == p->world - 1)) return fail(h, E2S_ERR_ARG, "rank order must be SA order: only the last rank may hold the EGSA's end");

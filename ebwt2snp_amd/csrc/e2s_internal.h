@@ -231,6 +231,7 @@ struct JobDev {                             // device copy at d_mail + 1536; rea
     uint32_t my_ok, reserved;               // this rank's verdict on its own step (what it sends in the second all-gather)
 };
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st);
+bool e2s_consensus_fits(int kl, uint32_t list_cap);           // the lists of a candidate fit the current device's LDS
 void e2s_launch_tail_group_sums(const TailArgs& a, uint32_t ng, hipStream_t st);
 void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long* part_excl, uint32_t ng, unsigned long long first_id,
                               unsigned long long* totals, const unsigned long long* n_keep, const uint32_t* err, JobDev* jd, unsigned long long* blob2,

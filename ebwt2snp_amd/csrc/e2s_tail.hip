@@ -592,6 +592,31 @@ void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint3
     if (!n_reads) return;
     hipLaunchKernelGGL(k_reads_compact, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, text, (const u64*)rstart, len, n_reads, out);
 }
+// LDS of a CU on the current device (gfx950: 160 KB); the consensus kernels' waves per block follow from it, not from constants
+static size_t tl_device_lds_bytes(int dev) {
+    static size_t cache[E2S_MAX_DEVICES] = {};
+    size_t& c = cache[dev % E2S_MAX_DEVICES];
+    if (!c) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+        c = (size_t)v;
+    }
+    return c;
+}
+static void tl_consensus_shape(int kl, uint32_t list_cap, size_t lds_cu, size_t* per_wave, unsigned* wpb) {
+    if (list_cap < 1) list_cap = 1;
+    *per_wave = kl <= 32 ? (size_t)2 * 2 * list_cap * (64 + 8 + 4) : (size_t)2 * list_cap * (128 + 8 + 4);
+    // (four waves per block while six such blocks fit a CU, two while three do: 60 / 120 KB of gfx950's 160)
+    *wpb = 4 * *per_wave <= lds_cu * 3 / 8 ? 4u : 2 * *per_wave <= lds_cu * 3 / 4 ? 2u : 1u;
+}
+// can the consensus kernels hold -c lists of this length in the device's LDS?  (no: the host tail takes over)
+bool e2s_consensus_fits(int kl, uint32_t list_cap) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t per_wave; unsigned wpb;
+    tl_consensus_shape(kl, list_cap, tl_device_lds_bytes(dev), &per_wave, &wpb);
+    return wpb * per_wave + 2048 <= tl_device_lds_bytes(dev);       // (+ the kernels' static LDS)
+}
 void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) {
     if (!a.n_cand) return;
     if (list_cap < 1) list_cap = 1;
@@ -600,18 +625,15 @@ void e2s_launch_consensus(const TailArgs& a, uint32_t list_cap, hipStream_t st) 
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t* const lds_set = lds_set_dev[dev % E2S_MAX_DEVICES];
+    size_t per_wave; unsigned wpb;
+    tl_consensus_shape(a.kl, list_cap, tl_device_lds_bytes(dev), &per_wave, &wpb);
+    const size_t lds = wpb * per_wave;
     if (a.kl <= 32) {                                               // two candidates per wave
-        const size_t per_wave = (size_t)2 * 2 * list_cap * (64 + 8 + 4);
-        const unsigned wpb = 4 * per_wave <= 60 * 1024 ? 4u : 2 * per_wave <= 120 * 1024 ? 2u : 1u;
-        const size_t lds = wpb * per_wave;
         if (lds > 48 * 1024 && lds > lds_set[1]) { (void)hipFuncSetAttribute((const void*)k_consensus_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[1] = lds; }
         const unsigned long long waves = (a.n_cand + 1) / 2;
         hipLaunchKernelGGL(k_consensus_pair, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, a, list_cap);
         return;
     }
-    const size_t per_wave = (size_t)2 * list_cap * (128 + 8 + 4);
-    const unsigned wpb = 4 * per_wave <= 60 * 1024 ? 4u : 2 * per_wave <= 120 * 1024 ? 2u : 1u;
-    const size_t lds = wpb * per_wave;
     if (lds > 48 * 1024 && lds > lds_set[0]) { (void)hipFuncSetAttribute((const void*)k_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set[0] = lds; }
     hipLaunchKernelGGL(k_consensus, dim3((unsigned)((a.n_cand + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, a, list_cap);
 }
