@@ -11,17 +11,24 @@ import oracle_lib as O
 from ebwt2snp_amd import synth, egsa_io as IO
 
 E2C, C2S = os.path.join(ROOT, "bin", "ebwt2clust"), os.path.join(ROOT, "bin", "clust2snp")
+RAGGED = os.environ.get("E2S_STRESS_RAGGED", "0") == "1"       # (off: the seeds of rounds 1-2 produce the cases they produced then)
 
 
 def case(seed, d):
     rnd = random.Random(seed)
     R, L = rnd.choice([300, 800, 1500, 3000]), rnd.choice([60, 100, 150])
     xyz = rnd.choice([(1, 4, 1), (1, 4, 1), (2, 4, 1), (4, 4, 4), (1, 8, 2), (2, 8, 2), (8, 8, 8), (1, 4, 4)])
-    reads, n1, e = synth.synth_case(R, L, seed=seed, coverage=rnd.choice([10, 20, 35]), tail_lcp0=rnd.random() < 0.7)
+    cov, t0 = rnd.choice([10, 20, 35]), rnd.random() < 0.7
+    ragged = RAGGED and rnd.random() < 0.5                      # reads of different lengths: the (start, length) index path of the GPU tail
+    if ragged:
+        reads, n1, e, _ = synth.synth_case_ragged(R, L, seed=seed, coverage=cov, tail_lcp0=t0)
+    else:
+        reads, n1, e = synth.synth_case(R, L, seed=seed, coverage=cov, tail_lcp0=t0)
+        reads = reads.numpy()
     en = synth.egsa_to_numpy(e, *xyz)
     ext = rnd.choice(["fasta", "fa", "fastq.txt"])              # H14: output name derived from the last ".fast"
     p = os.path.join(d, "reads." + ext)
-    IO.write_fasta(p, reads.numpy(), width=rnd.choice([None, None, 60]))
+    IO.write_fasta(p, reads, width=rnd.choice([None, None, 60]))
     (IO.write_gesa if rnd.random() < 0.4 else IO.write_bcr)(p, en["text"], en["suff"], en["lcp"], en["bwt"], *xyz)
     wopt = ["-x", xyz[0], "-y", xyz[1], "-z", xyz[2]] if xyz != (1, 4, 1) or rnd.random() < 0.3 else []
     a1 = list(wopt)
