@@ -776,10 +776,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        import faulthandler
+        faulthandler.dump_traceback_later(900, exit=True)         # a rank that waits for a failed peer says where, and ends
         if REHEARSAL:
             local = 0
-            import faulthandler
-            faulthandler.dump_traceback_later(900, exit=True)     # a rehearsal that stalls says where
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # the box's hostname may not resolve
             dist.init_process_group("gloo")
         else:
