@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -159,6 +160,17 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     dbg_entry("e2s_create");
     if (!out) return E2S_ERR_ARG;
     *out = nullptr;
+    // E2S_CLI_TIMING=1: the process's FIRST handle pays for the start of the HIP runtime (device discovery, code objects): say how much
+    struct CreateClock {
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~CreateClock() {
+            static bool first = true;
+            if (first && getenv("E2S_CLI_TIMING"))
+                fprintf(stderr, "[timing]   e2s_create, first handle of the process (HIP start-up): %.1f ms\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            first = false;
+        }
+    } create_clock;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
