@@ -537,17 +537,29 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
         s_hlen[line][lane] = (uint8_t)at;
     }
     __syncthreads();
-    // (fetching the four events' consensus strings and right contexts ahead of the header work, together with 32-bit digit arithmetic,
-    //  was measured: 156-159 us against 135-146 on c3 -- twelve more registers live across the barrier; the plain loop stays)
+    // a wave copies four events: what they read from global memory (consensus strings, right context) is fetched for all four behind the
+    // barrier, BEFORE the first is written (the loop used to pay one round trip per event, four in a row)
+    u32 ach4[4], bch4[4], rch4[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const int src = (int)(wave * 4 + k);
+        const bool on = (em >> src) & 1ull;                         // (wave-uniform)
+        const u64 c2 = __shfl((unsigned long long)slot, src);
+        const u32 rl = __shfl(t.right_len, src);
+        const u64 rat = __shfl((unsigned long long)t.right_at, src);
+        const uint8_t* ca = a.cons + c2 * 128;
+        ach4[k] = on && lane < kl ? (u32)ca[lane] : 0u;
+        bch4[k] = on && lane < kl ? (u32)ca[64 + lane] : 0u;
+        rch4[k] = on && lane < rl ? (u32)a.text[rat + lane] : 0u;
+    }
+#pragma unroll
     for (u32 k = 0; k < 4; ++k) {
         const int src = (int)(wave * 4 + k);
         if (!((em >> src) & 1ull)) continue;                        // (wave-uniform)
-        const u64 c2 = __shfl((unsigned long long)slot, src);
         const int L = __shfl(t.L, src);
         const u32 rl = __shfl(t.right_len, src);
-        const u64 rat = __shfl(t.right_at, src), o = __shfl(my_off, src);
-        const uint8_t* ca = a.cons + c2 * 128;
-        const u32 ach = lane < kl ? (u32)ca[lane] : 0u, bch = lane < kl ? (u32)ca[64 + lane] : 0u;   // the two consensus strings, one letter per lane
+        const u64 rat = __shfl((unsigned long long)t.right_at, src), o = __shfl((unsigned long long)my_off, src);
+        const u32 ach = ach4[k], bch = bch4[k], rch = rch4[k];
         const u32 n1 = s_hlen[0][src], n3 = s_hlen[1][src];
         const u32 skip0 = L < 0 ? (u32)(-L) : 0u, skip1 = L > 0 ? (u32)L : 0u;
         const u32 l2 = kl - skip0 + rl + 1u, l4 = kl - skip1 + rl + 1u;
@@ -556,13 +568,15 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
             for (u32 i = lane; i < n1; i += 64) p[i] = s_hdr[0][src][i];
             p += n1;
             if (lane >= skip0 && lane < kl) p[lane - skip0] = (uint8_t)ach;
-            for (u32 i = lane; i < rl; i += 64) p[kl - skip0 + i] = a.text[rat + i];
+            if (lane < rl) p[kl - skip0 + lane] = (uint8_t)rch;
+            for (u32 i = lane + 64u; i < rl; i += 64) p[kl - skip0 + i] = a.text[rat + i];
             if (lane == 0) p[kl - skip0 + rl] = '\n';
             p += l2;
             for (u32 i = lane; i < n3; i += 64) p[i] = s_hdr[1][src][i];
             p += n3;
             if (lane >= skip1 && lane < kl) p[lane - skip1] = (uint8_t)bch;
-            for (u32 i = lane; i < rl; i += 64) p[kl - skip1 + i] = a.text[rat + i];
+            if (lane < rl) p[kl - skip1 + lane] = (uint8_t)rch;
+            for (u32 i = lane + 64u; i < rl; i += 64) p[kl - skip1 + i] = a.text[rat + i];
             if (lane == 0) p[kl - skip1 + rl] = '\n';
         }
     }
