@@ -1636,29 +1636,37 @@ constexpr int MAXCH = 3;                           // ceil(150/64)
 
 // One cluster record [s, s+len) handled by one wave: lane i <-> entry s+i (three 64-entry chunks cover
 // the 150-entry maximum).  `alloc(lane)` hands out the memory of the next candidate (wave-uniform).
-template <bool DEF, typename Alloc>                // DEF: widths (x,y,z) = (1,4,1)
-__device__ __forceinline__ void cluster_record(const CandArgs& a, const u64 s, const int len, const u64 key, const u32 lane, Alloc alloc) {
+// the four columns of a cluster's entries, lane i <-> entry s + i per 64-entry chunk: LOADS ONLY, so that the caller can issue them for the
+// cluster of its next round before it works on the current one (len 0: nothing is loaded)
+struct ClusterCols { u32 text[MAXCH], suff[MAXCH], lcp[MAXCH], bwt[MAXCH]; };
+template <bool DEF>
+__device__ __forceinline__ void cluster_load(const CandArgs& a, const u64 s, const int len, const u32 lane, ClusterCols& k) {
     const int nch = (len + 63) >> 6;
-    u32 text[MAXCH], suff[MAXCH], lcp[MAXCH], bwt[MAXCH];
-    bool valid[MAXCH];
 #pragma unroll
     for (int c = 0; c < MAXCH; ++c) {
-        valid[c] = false; text[c] = suff[c] = lcp[c] = bwt[c] = 0;
+        k.text[c] = k.suff[c] = k.lcp[c] = k.bwt[c] = 0;
         if (c < nch) {
             const int o = c * 64 + (int)lane;
-            valid[c] = o < len;
-            if (valid[c]) {
+            if (o < len) {
                 const u64 g = s + (u64)o;
-                if (g == a.n_total) { text[c] = a.ph_text; suff[c] = a.ph_suff; lcp[c] = a.ph_lcp; bwt[c] = a.ph_bwt; }
+                if (g == a.n_total) { k.text[c] = a.ph_text; k.suff[c] = a.ph_suff; k.lcp[c] = a.ph_lcp; k.bwt[c] = a.ph_bwt; }
                 else {
                     const int64_t i = (int64_t)(g - a.prov_lo);
-                    bwt[c] = a.bwt[i];
-                    if (DEF) { lcp[c] = ((const uint8_t*)a.lcp)[i]; suff[c] = ((const uint8_t*)a.pos)[i]; text[c] = ((const u32*)a.da)[i]; }
-                    else { lcp[c] = load_w(a.lcp, a.xb, i); suff[c] = load_w(a.pos, a.zb, i); text[c] = load_w(a.da, a.yb, i); }
+                    k.bwt[c] = a.bwt[i];
+                    if (DEF) { k.lcp[c] = ((const uint8_t*)a.lcp)[i]; k.suff[c] = ((const uint8_t*)a.pos)[i]; k.text[c] = ((const u32*)a.da)[i]; }
+                    else { k.lcp[c] = load_w(a.lcp, a.xb, i); k.suff[c] = load_w(a.pos, a.zb, i); k.text[c] = load_w(a.da, a.yb, i); }
                 }
             }
         }
     }
+}
+template <bool DEF, typename Alloc>                // DEF: widths (x,y,z) = (1,4,1)
+__device__ __forceinline__ void cluster_record(const CandArgs& a, const ClusterCols& k, const int len, const u64 key, const u32 lane, Alloc alloc) {
+    const int nch = (len + 63) >> 6;
+    const u32 (&text)[MAXCH] = k.text; const u32 (&suff)[MAXCH] = k.suff; const u32 (&lcp)[MAXCH] = k.lcp; const u32 (&bwt)[MAXCH] = k.bwt;
+    bool valid[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) valid[c] = c < nch && c * 64 + (int)lane < len;
     // counts[sample][base] and the first entry with the strictly largest LCP (clust2snp.cpp:377-393)
     u32 cnt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     u32 best_lcp = 0, best_text = 0, best_suff = 0;
@@ -2034,25 +2042,42 @@ __global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigne
     const u64 n = min((u64)*n_dev, a.n_rec);                     // this launch handles list entries [*lo_dev, *n_dev)
     const u64 first = lo_dev ? (u64)*lo_dev : 0ull;
     const u64 per_round = (u64)gridDim.x * 4;
-    // a wave's list entry for the NEXT round is fetched while it works on the current one (a round is a chain of dependent
-    // memory latencies: entry -> EGSA columns -> ...; the block's four waves meet at the barrier below every round)
-    u64 s_nx = 0, k_nx = 0; int len_nx = 0;
-    { const u64 r0 = first + (u64)blockIdx.x * 4 + wave; if (r0 < n) { s_nx = a.starts[r0]; len_nx = (int)a.lens[r0]; k_nx = a.keys ? a.keys[r0] : s_nx; } }
+    // A round is a chain of dependent memory latencies (entry -> its EGSA columns -> the test), and the block's four waves meet at the
+    // barrier below every round: a wave keeps TWO rounds ahead in flight -- the list entry of round r + 2 and the four columns of round
+    // r + 1's cluster are fetched before it works on round r's (registers only).
+    // which entries are worked on at all: length 0 = an unused reserved slot; the exact length bounds (the pre-filter may have run with
+    // the absolute maximum, before max_clust_length was known); entries must be resident (index n_total being the EOF phantom): a
+    // record from a broken list must not fault
+    auto entry_kind = [&](u64 s, int len) -> int {                  // 0: skip, 1: work on it, 2: outside the shard (error)
+        if (len == 0 || len < a.len_lo || len > a.len_hi) return 0;
+        if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull) || len < 1 || len > 3 * 64) return 2;
+        return 1;
+    };
+    u64 s_n2 = 0, k_n2 = 0; int len_n2 = 0;                        // round r + 2's entry
+    u64 s_n1 = 0, k_n1 = 0; int len_n1 = 0, kind_n1 = 0;          // round r + 1's entry, its columns on their way
+    ClusterCols c_n1;
+    {
+        const u64 r0 = first + (u64)blockIdx.x * 4 + wave;
+        if (r0 < n) { s_n1 = a.starts[r0]; len_n1 = (int)a.lens[r0]; k_n1 = a.keys ? a.keys[r0] : s_n1; }
+        const u64 r1 = r0 + per_round;
+        if (r1 < n) { s_n2 = a.starts[r1]; len_n2 = (int)a.lens[r1]; k_n2 = a.keys ? a.keys[r1] : s_n2; }
+        kind_n1 = r0 < n ? entry_kind(s_n1, len_n1) : 0;
+        cluster_load<DEF>(a, s_n1, kind_n1 == 1 ? len_n1 : 0, lane, c_n1);
+    }
     for (u64 base = first + (u64)blockIdx.x * 4; base < n; base += per_round) {
         // (flushing earlier to start the PCIe stream sooner was tried: chunks of ~8 records ran 25 % slower)
         if (s_nstage > (u32)FW_STAGE - 16u || s_used8 + 16u * max8 > cap8) stage_flush();
         const u64 r = base + wave;
-        const u64 s = s_nx, key = k_nx; const int len = len_nx;
-        { const u64 rn = r + per_round; if (rn < n) { s_nx = a.starts[rn]; len_nx = (int)a.lens[rn]; k_nx = a.keys ? a.keys[rn] : s_nx; } }
+        const u64 key = k_n1; const int len = len_n1, kind = kind_n1;
+        const ClusterCols cur = c_n1;
+        // round r + 1: its entry arrived a round ago -- its columns leave now; round r + 2: its entry leaves now
+        s_n1 = s_n2; len_n1 = len_n2; k_n1 = k_n2;
+        kind_n1 = r + per_round < n ? entry_kind(s_n1, len_n1) : 0;
+        cluster_load<DEF>(a, s_n1, kind_n1 == 1 ? len_n1 : 0, lane, c_n1);
+        { const u64 rn = r + 2 * per_round; if (rn < n) { s_n2 = a.starts[rn]; len_n2 = (int)a.lens[rn]; k_n2 = a.keys ? a.keys[rn] : s_n2; } }
         if (r < n) {
-            // length 0 = an unused reserved slot; the exact length bounds (the pre-filter may have run with the absolute maximum,
-            // before max_clust_length was known)
-            if (len == 0 || len < a.len_lo || len > a.len_hi) {
-            } else
-            // entries must be resident (index n_total being the EOF phantom): a record from a broken list must not fault
-            if (s < a.prov_lo || s + (u64)len > a.prov_hi + (a.prov_hi == a.n_total ? 1ull : 0ull) || len < 1 || len > 3 * 64) {
-                if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE);
-            } else cluster_record<DEF>(a, s, len, key, lane, StageAlloc{s_stage, cap8, &s_used8, &s_nstage, s_keys, s_offs});
+            if (kind == 2) { if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE); }
+            else if (kind == 1) cluster_record<DEF>(a, cur, len, key, lane, StageAlloc{s_stage, cap8, &s_used8, &s_nstage, s_keys, s_offs});
         }
         __syncthreads();
     }
