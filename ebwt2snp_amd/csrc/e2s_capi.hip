@@ -2238,7 +2238,11 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     if ((rc = cand_args(h, &cp, (uint64_t)p->rank << 40, ca))) return rc;
     h->variants_valid = false; h->cand_host_valid = false;
     ca.len_hi_dev = &d_jd->len_hi;
-    if ((rc = cand_buffers(h, ca, std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap)))) return rc;
+    // (E2S_JOB_TEST_CAND_CAP: a testing aid -- a fresh handle starts with that few candidate slots, so that the step overflows them, says so
+    //  in its mail and is redone through the stepwise calls)
+    static const int test_cand_cap = getenv("E2S_JOB_TEST_CAND_CAP") ? atoi(getenv("E2S_JOB_TEST_CAND_CAP")) : 0;
+    const uint64_t cand_want = test_cand_cap > 0 && h->cand_cap == 0 ? (uint64_t)test_cand_cap : std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap);
+    if ((rc = cand_buffers(h, ca, cand_want))) return rc;
     ca.starts = h->d_fl_starts; ca.lens = h->d_fl_lens; ca.n_rec = h->fl_cap;
     const uint64_t ncap = h->cand_cap, ng = (ncap + 63) / 64;
     TailArgs ta;

@@ -811,7 +811,8 @@ def test_resident_job_images_equal_oracle(tmp_path):
 def test_resident_job_in_pieces(tmp_path):
     """e2s_resident_job with its per-cluster pass cut into 3 and 8 pieces (E2S_JOB_PIECES; the consensus of piece c runs by candidate SLOT on
     a third stream beside the lists of piece c + 1 and beside the ordering pass): both images are the oracle's files.  The library reads
-    the switch when it is loaded: one child process per setting (tests/job_pieces_driver.py), one after the other"""
+    the switch when it is loaded: one child process per setting (tests/job_pieces_driver.py), one after the other.  And the job whose
+    candidate slots overflow (E2S_JOB_TEST_CAND_CAP=16 on a fresh handle): redone stepwise, same bytes, the next job native again"""
     import subprocess
     import sys
     reads, n1, e = synth.synth_case(5000, 100, seed=71)
@@ -822,12 +823,16 @@ def test_resident_job_in_pieces(tmp_path):
     assert O.ebwt2clust(p)[0] == 0 and O.clust2snp(p, O.c2s_opts(n1))[0] == 0
     want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
     drv = os.path.join(os.path.dirname(os.path.abspath(__file__)), "job_pieces_driver.py")
-    for pieces, beside in ((3, 1), (8, 1), (0, 0)):
-        out = str(tmp_path / ("img%d_%d" % (pieces, beside)))
+    for pieces, beside, tiny_cap in ((3, 1, 0), (8, 1, 0), (0, 0, 0), (1, 1, 16), (3, 1, 16), (0, 0, 16)):
+        out = str(tmp_path / ("img%d_%d_%d" % (pieces, beside, tiny_cap)))
         env = dict(os.environ, E2S_JOB_PIECES=str(pieces), E2S_JOB_CONS_BESIDE=str(beside))
+        if tiny_cap:
+            # a fresh handle with room for 16 candidates: the job overflows its slots (the tail still runs over what there is), says so in
+            # its mail (E2S_ERR_CAPACITY) and the step is redone through the stepwise calls; the next job on the handle fits
+            env.update(E2S_JOB_TEST_CAND_CAP=str(tiny_cap), E2S_TEST_EXPECT_FALLBACK="1")
         r = subprocess.run([sys.executable, drv, out], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, (pieces, r.stdout[-800:], r.stderr[-1500:])
-        assert open(out + ".clusters", "rb").read() == want_cl and open(out + ".snp", "rb").read() == want_snp, (pieces, beside)
+        assert open(out + ".clusters", "rb").read() == want_cl and open(out + ".snp", "rb").read() == want_snp, (pieces, beside, tiny_cap)
 
 
 @pytest.mark.gpu
@@ -938,13 +943,17 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
             a += ["-" + ("M" if kk == "m" else kk), str(vv)]
         # (pieces: the native job's per-cluster pass cut into that many launches, the consensus of one piece beside the next -- inputs this
         #  small take one piece by default)
-        for ranks, shared, pieces in ((1, False, 0), (2, True, 0), (3, True, 3), (5, True, 0), (1, False, 8)):
+        # (tiny: the ranks' fresh handles start with room for 4 candidates -- ranks that overflow say so in the second all-gather and
+        #  EVERY rank redoes its step through the stepwise calls)
+        for ranks, shared, pieces, tiny in ((1, False, 0, 0), (2, True, 0, 0), (3, True, 3, 0), (5, True, 0, 0), (1, False, 8, 0), (3, True, 0, 4), (1, False, 0, 4)):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
             env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0")
             if pieces:
                 env["E2S_JOB_PIECES"] = str(pieces)
+            if tiny:
+                env["E2S_JOB_TEST_CAND_CAP"] = str(tiny)
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)] + a, capture_output=True, text=True, env=env, timeout=300)
             assert r.returncode == 0, (meta["name"], ranks, r.stdout[-800:], r.stderr[-800:])
             assert ("RCCL all-gather" in r.stdout) == (not shared)
