@@ -785,7 +785,9 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     }
     sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
     const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
-    if (!seg_cap) seg_cap = (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
+    // (E2S_TEST_SEG_CAP: a testing aid -- the first attempt's segments hold that few records, so that a worker overflows its segment)
+    static const int test_seg_cap = getenv("E2S_TEST_SEG_CAP") ? atoi(getenv("E2S_TEST_SEG_CAP")) : 0;
+    if (!seg_cap) seg_cap = test_seg_cap > 0 ? (uint64_t)test_seg_cap : (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
     else if (seg_cap == ~0ull) seg_cap = range_entries + 16;          // worst case: room for everything
     seg_cap = (seg_cap + 7) & ~7ull;                                   // (the layout kernel loads four records at once: 16-byte aligned segments)
     if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
@@ -1367,7 +1369,9 @@ static bool prefilter_eligible(const e2s_ctx* h) {
 }
 // the flagged-cluster list (empty, behind the reserved seed slots), the pre-filter's error word and its arguments
 static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words = false) {
-    int rc = ensure_flagged(h, std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
+    // (E2S_TEST_FL_CAP: a testing aid -- a fresh handle's list of flagged clusters starts that short, so that the pre-filter overflows it)
+    static const int test_fl_cap = getenv("E2S_TEST_FL_CAP") ? atoi(getenv("E2S_TEST_FL_CAP")) : 0;
+    int rc = ensure_flagged(h, test_fl_cap > 0 && h->fl_cap == 0 ? (uint64_t)test_fl_cap + E2S_SEED_SLOTS : std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
     if (rc) return rc;
     // one launch: the list starts behind the reserved seed slots (length 0 = empty slot), the pre-filter's error word is
     // cleared -- and, for the scan that carries the pre-filter, the scan's words as well

@@ -19,11 +19,12 @@ def main(prefix):
     n = en["lcp"].size
     h = capi.Handle(0)
     _attach_job_inputs(h, reads.numpy(), en, n, 0, n, 0, 0, dev)
-    expect_fallback = os.environ.get("E2S_TEST_EXPECT_FALLBACK") == "1"
+    expect_fallback = int(os.environ.get("E2S_TEST_EXPECT_FALLBACK", "0"))        # the first N steps are redone stepwise
     for it in range(2):                                          # (twice: the second step finds the buffers and counters of the first)
         r = pipeline.resident_job(h, n1, n, native=True)
-        # (E2S_JOB_TEST_CAND_CAP: the first step overflows its candidate slots, reports it, and is redone stepwise; the second fits)
-        assert bool(r.get("native")) == (not (expect_fallback and it == 0)), (it, r)
+        # (the testing aids make the first step overflow a buffer: it reports it and is redone stepwise; the second fits -- the segments'
+        #  estimate apart, which is made anew for every scan)
+        assert bool(r.get("native")) == (it >= expect_fallback), (it, r)
     cl, snp = h.fetch_clusters().tobytes(), h.fetch_snp().tobytes()
     h.close()
     open(prefix + ".clusters", "wb").write(cl)

@@ -823,13 +823,16 @@ def test_resident_job_in_pieces(tmp_path):
     assert O.ebwt2clust(p)[0] == 0 and O.clust2snp(p, O.c2s_opts(n1))[0] == 0
     want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
     drv = os.path.join(os.path.dirname(os.path.abspath(__file__)), "job_pieces_driver.py")
-    for pieces, beside, tiny_cap in ((3, 1, 0), (8, 1, 0), (0, 0, 0), (1, 1, 16), (3, 1, 16), (0, 0, 16)):
-        out = str(tmp_path / ("img%d_%d_%d" % (pieces, beside, tiny_cap)))
+    for pieces, beside, tiny_cap, extra in ((3, 1, 0, {}), (8, 1, 0, {}), (0, 0, 0, {}), (1, 1, 16, {}), (3, 1, 16, {}), (0, 0, 16, {}),
+                                            (1, 1, 0, {"E2S_TEST_FL_CAP": "8", "E2S_TEST_EXPECT_FALLBACK": "1"}),
+                                            (1, 1, 0, {"E2S_TEST_SEG_CAP": "8", "E2S_TEST_EXPECT_FALLBACK": "2"})):
+        out = str(tmp_path / ("img%d_%d_%d_%d" % (pieces, beside, tiny_cap, len(extra))))
         env = dict(os.environ, E2S_JOB_PIECES=str(pieces), E2S_JOB_CONS_BESIDE=str(beside))
         if tiny_cap:
             # a fresh handle with room for 16 candidates: the job overflows its slots (the tail still runs over what there is), says so in
             # its mail (E2S_ERR_CAPACITY) and the step is redone through the stepwise calls; the next job on the handle fits
             env.update(E2S_JOB_TEST_CAND_CAP=str(tiny_cap), E2S_TEST_EXPECT_FALLBACK="1")
+        env.update(extra)                                           # ... a list of flagged clusters / record segments that overflow
         r = subprocess.run([sys.executable, drv, out], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, (pieces, r.stdout[-800:], r.stderr[-1500:])
         assert open(out + ".clusters", "rb").read() == want_cl and open(out + ".snp", "rb").read() == want_snp, (pieces, beside, tiny_cap)
