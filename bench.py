@@ -392,8 +392,9 @@ def cpu_baseline(blk, reads, n1, sample_entries, dev, truth=None):
             t2 = time.time()
             assert rc == 0
         res = dict(value=n / (t2 - t0), unit="EGSA entries/s", cores=1, node_cores=os.cpu_count(), kind=kind,
-                   sample="first %d entries of the same EGSA (BCR triple + FASTA on local disk): ebwt2clust %.2f s + clust2snp %.2f s; the reference is "
-                          "single-threaded: 1 of the node's %d cores" % (n, t1 - t0, t2 - t1, os.cpu_count()))
+                   sample="%s of the timed workload's EGSA (BCR triple + FASTA on local disk): ebwt2clust %.2f s + clust2snp %.2f s; the reference is "
+                          "single-threaded: 1 of the node's %d cores" % ("one whole block (%d entries)" % n if n == blk["lcp"].numel() else "the first %d entries" % n,
+                                                                          t1 - t0, t2 - t1, os.cpu_count()))
         snp = IO.snp_out_path(p)
         want_cl, want_snp = open(p + ".clusters", "rb").read(), open(snp, "rb").read()
         # the drop-in executables of this repo on the very same files, end to end (process start, file reads, upload, kernels,
@@ -753,7 +754,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--cpu-sample", type=int, default=100000000, help="entries of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=302000000, help="entries of the CPU baseline sample (0 = skip; the default covers one whole block "
+                    "of c3: ~20 s of the reference on one core)")
     ap.add_argument("--second-workload", default="c2", help="a second, shorter leg on this workload ('' = none; N = 1 only)")
     ap.add_argument("--emulate-rank", default="", help="R/N: time rank R of the N-way STRONG cut of the workload on this one GPU (N-rank bookkeeping, "
                     "one-rank RCCL exchanges; the peers' descriptors are computed before the timed region).  Not the driver's metric: a readiness check")
