@@ -82,6 +82,7 @@ int main(int argc, char** argv) {
     if (input.compare("") == 0 || nr_reads1 == 0) help();
 
     PhaseClock pc;
+    CliReport report;
     EgsaFiles F;
     F.open_or_die(input, lcp, da, pos);
     std::cout << "This is clust2snp." << std::endl
@@ -163,6 +164,11 @@ int main(int argc, char** argv) {
         return 139;
     }
     if (rc) { std::cerr << "clust2snp failed (" << rc << "): " << e2s_last_error(nullptr) << std::endl; return 2; }
+    {
+        e2s_job_report r2 = rep;                                  // (the statistics ran here, on the host, before the job)
+        r2.max_clust_length = max_clust_length; r2.n_records = CL.n / 10;
+        report.write("clust2snp", input, r2, F.n, F.n * (uint64_t)(lcp + 1), rep.snp_bytes);
+    }
     std::cout << "Done. " << std::endl;
     return 0;
 }

@@ -53,6 +53,7 @@ int main(int argc, char** argv) {
     if (input.compare("") == 0) help();
 
     PhaseClock pc;
+    CliReport report;
     EgsaFiles F;
     F.open_or_die(input, lcp, da, pos);
     pc.mark("open files");
@@ -92,6 +93,7 @@ int main(int argc, char** argv) {
     }
     if (pc.on) std::cerr << "[timing]   " << rep.n_chunks << " chunk(s), upload " << rep.seconds_upload * 1e3 << " ms of " << rep.seconds_total * 1e3 << " ms" << std::endl;
     pc.mark("HIP start-up + upload + scan + records -> .clusters");
+    report.write("ebwt2clust", input, rep, F.n, F.n * (uint64_t)lcp, rep.n_records * 10ull);   // (E2S_CLI_JSON; the LCP column is what this tool uploads)
     const uint64_t n_closed = rep.n_closed;
     // the reference prints the count as unsigned int (ebwt2clust.cpp:88,137)
     std::cout << "Done. " << (unsigned int)n_closed << " clusters saved to output file." << std::endl;

@@ -94,6 +94,29 @@ struct PhaseClock {
     }
 };
 
+// E2S_CLI_JSON=<path>: a perf report of the run as one JSON object in a side file (stdout stays the reference's, byte for byte):
+// entries, wall seconds since process start-up code ran, the job's own seconds and the part spent uploading, rates, counts
+struct CliReport {
+    double t_start = PhaseClock::now();
+    void write(const char* tool, const std::string& input, const e2s_job_report& rep, uint64_t entries, uint64_t bytes_uploaded, uint64_t bytes_out) const {
+        const char* path = getenv("E2S_CLI_JSON");
+        if (!path || !*path) return;
+        FILE* f = fopen(path, "w");
+        if (!f) return;
+        const double wall = (PhaseClock::now() - t_start) * 1e-3;
+        fprintf(f, "{\"tool\": \"%s\", \"library\": \"%s\", \"entries\": %llu, \"seconds_wall\": %.6f, \"seconds_job\": %.6f, \"seconds_upload\": %.6f, "
+                   "\"entries_per_s\": %.6g, \"bytes_uploaded\": %llu, \"upload_GBps\": %.4g, \"bytes_out\": %llu, \"chunks\": %d, "
+                   "\"clusters_printed\": %llu, \"clusters_file_records\": %llu, \"max_clust_length\": %d, \"candidates\": %llu, \"variants\": %llu, \"events\": %llu, \"input\": \"",
+                tool, e2s_version(), (unsigned long long)entries, wall, rep.seconds_total, rep.seconds_upload, wall > 0 ? (double)entries / wall : 0.0,
+                (unsigned long long)bytes_uploaded, rep.seconds_upload > 0 ? (double)bytes_uploaded / rep.seconds_upload / 1e9 : 0.0, (unsigned long long)bytes_out, (int)rep.n_chunks,
+                (unsigned long long)rep.n_closed, (unsigned long long)rep.n_records, (int)rep.max_clust_length, (unsigned long long)rep.n_candidates,
+                (unsigned long long)rep.n_variants, (unsigned long long)rep.n_events);
+        for (char c : input) { if (c == '"' || c == '\\') fputc('\\', f); if ((unsigned char)c >= 0x20) fputc(c, f); }
+        fprintf(f, "\"}\n");
+        fclose(f);
+    }
+};
+
 inline void die_on(int rc, e2s_handle h, const char* what) {
     if (rc == E2S_OK) return;
     std::cerr << what << " failed (" << rc << "): " << e2s_last_error(h) << std::endl;

@@ -808,6 +808,29 @@ def test_resident_job_images_equal_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_json_report(tmp_path):
+    """E2S_CLI_JSON=<path>: the executables leave a perf report beside their outputs (a `--json` report; an environment
+    switch, so that the option strings stay the reference's): one JSON object, counts equal to what the tools print / write"""
+    import json
+    import subprocess
+    meta = [m for m in goldens.e2e_cases() if m["name"] == "c1_bcr"][0]
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j1, j2 = str(tmp_path / "e2c.json"), str(tmp_path / "c2s.json")
+    r = subprocess.run([os.path.join(root, "bin", "ebwt2clust"), "-i", p], capture_output=True, text=True, env=dict(os.environ, E2S_CLI_JSON=j1), timeout=300)
+    assert r.returncode == 0, r.stderr
+    a = json.load(open(j1))
+    assert a["tool"] == "ebwt2clust" and a["entries"] == en["lcp"].size and a["clusters_printed"] == meta["n_printed"]
+    assert a["clusters_file_records"] * 10 == os.path.getsize(p + ".clusters") == a["bytes_out"] and a["entries_per_s"] > 0 and a["chunks"] >= 1
+    r = subprocess.run([os.path.join(root, "bin", "clust2snp"), "-i", p, "-n", str(n1)], capture_output=True, text=True, env=dict(os.environ, E2S_CLI_JSON=j2), timeout=300)
+    assert r.returncode == 0, r.stderr
+    b = json.load(open(j2))
+    assert b["tool"] == "clust2snp" and b["entries"] == en["lcp"].size and b["candidates"] > 0 and b["events"] > 0 and b["seconds_wall"] >= b["seconds_job"] > 0
+    assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta)
+
+
+@pytest.mark.gpu
 def test_resident_job_in_pieces(tmp_path):
     """e2s_resident_job with its per-cluster pass cut into 3 and 8 pieces (E2S_JOB_PIECES; the consensus of piece c runs by candidate SLOT on
     a third stream beside the lists of piece c + 1 and beside the ordering pass): both images are the oracle's files.  The library reads
