@@ -1667,8 +1667,11 @@ __device__ __forceinline__ void cluster_record(const CandArgs& a, const ClusterC
     bool valid[MAXCH];
 #pragma unroll
     for (int c = 0; c < MAXCH; ++c) valid[c] = c < nch && c * 64 + (int)lane < len;
-    // counts[sample][base] and the first entry with the strictly largest LCP (clust2snp.cpp:377-393)
-    u32 cnt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // counts[sample][base] and the first entry with the strictly largest LCP (clust2snp.cpp:377-393).  The eight counts: every lane adds
+    // 1 << (8 x base) into the packed word of its sample (a cluster has <= 192 entries: four 8-bit fields hold the sums), two DPP scans
+    // sum them over the wave -- eight ballots per chunk, each with its AND / count / add on the scalar unit, were a third of the kernel's
+    // scalar instructions.  The largest LCP by a DPP scan, too (six ds_bpermute round trips before).
+    u32 pk0 = 0u, pk1 = 0u;
     u32 best_lcp = 0, best_text = 0, best_suff = 0;
     u32 smp[MAXCH], bas[MAXCH];
 #pragma unroll
@@ -1676,12 +1679,9 @@ __device__ __forceinline__ void cluster_record(const CandArgs& a, const ClusterC
         if (c < nch) {
             smp[c] = ((u64)text[c] < a.nr_reads1) ? 0u : 1u;            // uint32 text vs uint64 nr_reads1
             bas[c] = base_to_int(bwt[c]);
-#pragma unroll
-            for (int sb = 0; sb < 8; ++sb)
-                cnt[sb >> 2][sb & 3] += (u32)__popcll(__ballot(valid[c] && smp[c] == (u32)(sb >> 2) && bas[c] == (u32)(sb & 3)));
-            u32 m = valid[c] ? lcp[c] : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
+            const u32 inc = valid[c] ? 1u << (8u * bas[c]) : 0u;
+            pk0 += smp[c] ? 0u : inc; pk1 += smp[c] ? inc : 0u;
+            const u32 m = wave_bcast_last(wave_incl_max(valid[c] ? lcp[c] : 0u));
             if (m > best_lcp) {                                          // strictly greater: earlier chunk wins ties
                 const u64 who = __ballot(valid[c] && lcp[c] == m);
                 const int src = __ffsll((long long)who) - 1;
@@ -1692,15 +1692,17 @@ __device__ __forceinline__ void cluster_record(const CandArgs& a, const ClusterC
         }
     }
     if ((u64)best_lcp < a.k_right_u) return;                            // clust2snp.cpp:396
+    const u32 t0 = wave_bcast_last(wave_incl_scan(pk0)), t1 = wave_bcast_last(wave_incl_scan(pk1));
     u32 f0 = 0, f1 = 0;                                                  // frequent characters, :402-407
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { if (cnt[0][b] >= a.mcov_u) f0 |= 1u << b; if (cnt[1][b] >= a.mcov_u) f1 |= 1u << b; }
+    for (int b = 0; b < 4; ++b) { if (((t0 >> (8 * b)) & 0xFFu) >= a.mcov_u) f0 |= 1u << b; if (((t1 >> (8 * b)) & 0xFFu) >= a.mcov_u) f1 |= 1u << b; }
     if (f0 == 0 || f1 == 0 || __popc(f0) > 2 || __popc(f1) > 2 || f0 == f1 || __popc(f0 | f1) > 3) return;   // :419-429
     u32 pair = 0;
-    for (int b0 = 0; b0 < 4; ++b0) {
-        if (!((f0 >> b0) & 1u)) continue;
-        for (int b1 = 0; b1 < 4; ++b1) {
-            if (!((f1 >> b1) & 1u) || b0 == b1) continue;
+    // (the pairs (b0, b1) of frequent characters, b0 != b1, in the reference's order: only the set bits are walked)
+    for (u32 q0 = f0; q0; q0 &= q0 - 1u) {
+        const int b0 = __ffs((int)q0) - 1;
+        for (u32 q1 = f1 & ~(1u << b0); q1; q1 &= q1 - 1u) {
+            const int b1 = __ffs((int)q1) - 1;
             const u32 c0 = "ACGT"[b0], c1 = "ACGT"[b1];                  // int_to_base, raw compare ch == c (:455,466)
             // membership and rank in SA order (:446-476)
             u32 n0 = 0, n1 = 0, rk0[MAXCH], rk1[MAXCH];
