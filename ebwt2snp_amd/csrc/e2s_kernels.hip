@@ -1703,7 +1703,9 @@ __device__ __forceinline__ void cluster_record(const CandArgs& a, const ClusterC
         const int b0 = __ffs((int)q0) - 1;
         for (u32 q1 = f1 & ~(1u << b0); q1; q1 &= q1 - 1u) {
             const int b1 = __ffs((int)q1) - 1;
-            const u32 c0 = "ACGT"[b0], c1 = "ACGT"[b1];                  // int_to_base, raw compare ch == c (:455,466)
+            // int_to_base, raw compare ch == c (:455,466) -- from a packed constant: indexing the string literal with a run-time index is a
+            // load from constant memory on every pair's critical path
+            const u32 c0 = (0x54474341u >> (8 * b0)) & 0xFFu, c1 = (0x54474341u >> (8 * b1)) & 0xFFu;
             // membership and rank in SA order (:446-476)
             u32 n0 = 0, n1 = 0, rk0[MAXCH], rk1[MAXCH];
             bool m0[MAXCH], m1[MAXCH];
