@@ -522,8 +522,10 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
         const int L = t.L;
         u32 at = 0;
         b[at++] = '>';
-        at = tl_put(b, at, L != 0 ? "INDEL" : "SNP");
-        at = tl_put(b, at, line ? "_lower_path_" : "_higher_path_");
+        // (every literal in a call of its own: a literal CHOSEN at run time is a pointer into constant memory, and tl_put then loads it
+        //  one character at a time -- seventeen dependent loads per header line)
+        if (L != 0) at = tl_put(b, at, "INDEL"); else at = tl_put(b, at, "SNP");
+        if (line) at = tl_put(b, at, "_lower_path_"); else at = tl_put(b, at, "_higher_path_");
         at = tl_put_num(b, at, first_id + my_rank);
         at = tl_put(b, at, "|P_1:");
         at = tl_put_num(b, at, t.right_len);
