@@ -315,17 +315,24 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
         u32 C = 'A', bc8 = 0u, cnt = 0u;                            // cons (include.hpp:334-371): as in k_consensus
         for (u32 j = 0; j < n_max; ++j) {
             const bool on = colok & (j < n);
-            const u32 v = on ? (u32)rows[(size_t)j * 32 + hl] : 0u;
+            u32 r16 = (u32)rows[(size_t)j * 32 + hl];                   // (read whether the lane has the row or not, masked in registers)
+            asm volatile("" : "+v"(r16));
+            const u32 v = on ? r16 : 0u;
             const u32 ch = v & 0xFFu, b8 = v >> 8;
             cnt += on ? 1u << b8 : 0u;
             // (no `on` here: C's count is the largest at all times, so a lane without a row -- v = 0, class 0 -- never takes over)
             if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
         }
         u32 supp = 0u;
+        // (the rows are read whether the lane has one or not -- row j < list_cap lies inside the candidate's LDS area -- and masked in
+        //  registers: a read under a condition is a branch and an EXEC save / restore per row)
         for (u32 j = 0; j < n_max; ++j) {
             const bool on = colok & (j < n);
-            const u32 ch = on ? ((u32)rows[(size_t)j * 32 + hl] & 0xFFu) : 0u;
-            const u32 d = tl_half_pop(__ballot(on && C != ch), half);
+            u32 r8 = (u32)rows[(size_t)j * 32 + hl] & 0xFFu;
+            asm volatile("" : "+v"(r8));                                // (keeps the read where it is: the compiler would sink it under `on` again)
+            u32 ch = on ? r8 : C;                                       // a lane without a row agrees with the consensus: ONE compare is the ballot
+            asm volatile("" : "+v"(ch));                                // (... and stays one: `on & (r8 != C)` costs a 0 / 1 round trip through a register)
+            const u32 d = tl_half_pop(__ballot(C != ch), half);
             if (j < n && (int)d <= a.max_err) ++supp;
         }
         if (s) supp1 = supp; else supp0 = supp;
