@@ -197,6 +197,7 @@ REHEARSAL = os.environ.get("E2S_BENCH_REHEARSAL", "0") == "1"
 # with a single rank, to exercise it on a one-GPU box
 FORCE_DIST = os.environ.get("E2S_BENCH_FORCE_DIST", "0") == "1"
 SECOND_LEG = os.environ.get("E2S_BENCH_SECOND_LEG", "1") == "1"      # also time the two kernels apart (reported as other_mode)
+BENCH_TIMING = int(os.environ.get("E2S_BENCH_TIMING", "1"))          # the library's timing level inside the timed region (0 none, 1 scan kernel, 2 every phase)
 NATIVE = os.environ.get("E2S_BENCH_NATIVE", "1") == "1"              # e2s_resident_job (one enqueue, one wait); 0: the stepwise calls
 
 
@@ -541,7 +542,7 @@ def pmc_traffic(workload, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE; collected by
     tools/profile.sh in separate --pmc runs of this same command, summarised by tools/profile_summary.py).  None when no
     committed profile covers the workload -- counters cannot be read from inside the timed run."""
-    for rnd in ("round3", "round2", "round1"):
+    for rnd in ("round4", "round3", "round2", "round1"):
         for name in ("%s_%s_pmc_traffic.json" % (rnd, workload), "%s_fused_%s_pmc_traffic.json" % (rnd, workload),
                      "%s_fused_pmc_traffic.json" % rnd):
             try:
@@ -622,9 +623,12 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(fused, n_warm, n_steps, on_host=False):
-        """W untimed + K timed steps of the whole job, bracketed by barrier + synchronize; max over ranks"""
+    def measure(fused, n_warm, n_steps, on_host=False, timing=1):
+        """W untimed + K timed steps of the whole job, bracketed by barrier + synchronize; max over ranks.
+        timing: the library's kernel-timing level (e2s_set_timing) -- 0: no events at all (what a production caller gets), 1: two events
+        around the dominant scan kernel (the roofline's launch duration, measured live in the timed region), 2: every phase"""
         info = None
+        h.set_timing(timing)
         for _ in range(n_warm):
             info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host, emul=emul)
         r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[], tail_ms=[])
@@ -646,9 +650,11 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         r.update(elapsed=elapsed, info=info, phases=dict(PHASES), steps=n_steps)
         return r
 
-    prim = measure(True, warmup, steps)
-    other = measure(False, min(warmup, 2) + 1, max(3, steps // 2)) if SECOND_LEG and emul is None else None
-    host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True) if emul is None else None
+    prim = measure(True, warmup, steps, timing=BENCH_TIMING)
+    bare = measure(True, 1, steps, timing=0) if BENCH_TIMING else prim      # the same steps without a single timing event
+    phases = measure(True, 1, max(3, steps // 2), timing=2) if emul is not None else None     # (per-phase kernel times for the rank report)
+    other = measure(False, min(warmup, 2) + 1, max(3, steps // 2), timing=2) if SECOND_LEG and emul is None else None
+    host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True, timing=0) if emul is None else None
     info = prim["info"]
     # the `.clusters` layout kernel alone (in the step it runs on the second stream beside the per-cluster pass, where its time says
     # little about the kernel): scan, wait, then ONE synchronous e2s_pack_clusters under the wall clock (~15 us of call overhead included)
@@ -709,17 +715,20 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             # the 99.7 % of clusters its pre-filter rejects, so against THAT figure the kernel would read 'frac_vs_survey_bytes' > 1
             "roofline": roof(("k_scan_seg<1,true>", "k_scan_seg<1,true,false>"), fused_bytes, fused_ms),
             "value_outputs_on_host": n_total * host["steps"] / host["elapsed"] if host else None,
-            "tail_ms": float(np.mean(prim["tail_ms"])),
+            "ms_per_step_without_timing_events": bare["elapsed"] / bare["steps"] * 1e3,
+            "timing_events_in_timed_region": {0: "none", 1: "two, around the scan kernel (roofline.launch_ms)", 2: "every phase"}[BENCH_TIMING],
         }
         if emul is not None:
-            res["kernel_ms"] = {"scan+prefilter+fix+stats": float(np.mean(prim["scan_all_ms"])), "scan_kernel": fused_ms,
-                                "per_cluster_pass_to_K2b_end": float(np.mean(prim["cand_ms"])), "tail": float(np.mean(prim["tail_ms"]))}
+            res["kernel_ms"] = {"scan+prefilter+fix+stats": float(np.mean(phases["scan_all_ms"])), "scan_kernel": float(np.mean(phases["scan_ms"])),
+                                "per_cluster_pass_to_K2b_end": float(np.mean(phases["cand_ms"])), "tail": float(np.mean(phases["tail_ms"])),
+                                "note": "from a separate leg with every phase's events recorded (each costs stream time: ms_per_step there %.4f)"
+                                        % (phases["elapsed"] / phases["steps"] * 1e3)}
             res["rank_entries"] = n_own
             res["target_ms_for_6x_at_8"] = None
         res["roofline"].update({"survey_8d_bytes": ref_pattern_bytes + n_own, "frac_vs_survey_bytes": (ref_pattern_bytes + n_own) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "frac_uses": "algorithmic_bytes (2 B/entry read + 6 B/record written: the segment record of round 3)",
                                 "frac_with_10_byte_records": (n_own * 2 + info["n_ends"] * 10) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,   # (rounds 1-2 accounting)
-                                "hist_ms": float(np.mean(prim["hist_ms"]))})
+                                })
         if layout_ms:
             res["roofline_image_layout"] = roof("k_pack_seg_write", info["n_ends"] * 6 + info["n_records"] * 10, layout_ms,
                                                 "the `.clusters` layout kernel alone (6 B read per segment record + 10 B written per file record), wall clock "

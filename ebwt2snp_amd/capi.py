@@ -81,7 +81,7 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_stream_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
-           "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_stream", "e2s_synchronize",
+           "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_set_timing", "e2s_stream", "e2s_synchronize",
            "e2s_pack_clusters", "e2s_clusters_image", "e2s_upload_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_renumber_snp", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp",
            "e2s_ebwt2clust_chunked", "e2s_clust2snp_chunked", "e2s_ebwt2snp_chunked", "e2s_hist_of_records", "e2s_resident_job", "e2s_fasta_index_open", "e2s_fasta_index_close"]
 
@@ -144,6 +144,7 @@ def lib():
     L.e2s_stream_snp.argtypes = [H, BYTE_SINK, C.c_void_p]
     L.e2s_write_snp.argtypes = [H, C.POINTER(TailParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_last_timing.argtypes = [H, C.POINTER(Timing)]
+    L.e2s_set_timing.argtypes = [H, C.c_int]
     L.e2s_stream.argtypes = [H, C.POINTER(C.c_void_p)]
     L.e2s_synchronize.argtypes = [H]
     _lib = L
@@ -381,6 +382,10 @@ class Handle:
         nv, ne = C.c_uint64(0), C.c_uint64(0)
         self._ck(self.L.e2s_write_snp(self.h, C.byref(p), fasta_path.encode(), out_path.encode(), C.byref(nv), C.byref(ne)))
         return nv.value, ne.value
+
+    def set_timing(self, level):
+        """0: no timing events (default), 1: around the scan kernel only, 2: every phase (each event costs stream time)"""
+        self._ck(self.L.e2s_set_timing(self.h, int(level)))
 
     def timing(self):
         t = Timing()

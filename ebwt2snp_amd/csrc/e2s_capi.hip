@@ -103,7 +103,8 @@ struct e2s_ctx {
     ScanMail* d_mail = nullptr;
     uint32_t last_text = 0, last_suff = 0, last_lcp = 0, last_bwt = 0; bool last_known = false;
     e2s_stitch_plan_t plan{};
-    // timing
+    // timing (opt-in: e2s_set_timing / E2S_TIMING; 0 none, 1 the scan kernel, 2 every phase)
+    int timing = 0;
     hipEvent_t ev[8] = {};
     e2s_timing tm{};
 };
@@ -116,6 +117,9 @@ struct e2s_ctx {
             return E2S_ERR_HIP;                                                                          \
         }                                                                                                \
     } while (0)
+
+// a timing event on a stream, recorded only at the handle's timing level (an event between two dependent kernels costs stream time)
+#define TREC(level, idx, st) do { if (h->timing >= (level)) CK(hipEventRecord(h->ev[idx], st)); } while (0)
 
 // sum of digits(v) over v in [0, x) (as tl_digit_sum_below in e2s_tail.hip: the ids' share of the `.snp` text in closed form)
 static uint64_t digit_sum_below(uint64_t x) {
@@ -130,7 +134,7 @@ static inline void dev_free(void* p) { if (p) (void)hipFree(p); }
 static inline void pin_free(void* p) { if (p) (void)hipHostFree(p); }
 static inline void ev_destroy(hipEvent_t e) { if (e) (void)hipEventDestroy(e); }
 static inline void stream_destroy(hipStream_t s) { if (s) (void)hipStreamDestroy(s); }
-static inline void ev_ms(float* ms, hipEvent_t a, hipEvent_t b) { if (hipEventElapsedTime(ms, a, b) != hipSuccess) *ms = 0.f; }
+static inline void ev_ms(float* ms, hipEvent_t a, hipEvent_t b, bool recorded = true) { if (!recorded || hipEventElapsedTime(ms, a, b) != hipSuccess) *ms = 0.f; }
 
 // E2S_DEBUG_SYNC=1: synchronise and check after every launch, naming the one that failed (development aid)
 static bool debug_sync() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_DEBUG_SYNC"); v = (e && *e == '1') ? 1 : 0; } return v == 1; }
@@ -181,6 +185,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     if (device_id < 0 || device_id >= ndev) { g_create_error = "device id out of range"; return E2S_ERR_ARG; }
     e2s_ctx* h = new e2s_ctx();
     h->device = device_id;
+    if (const char* ev = getenv("E2S_TIMING")) h->timing = std::max(0, std::min(2, atoi(ev)));
     if (const char* ev = getenv("E2S_STREAM_PER_CAND")) h->stream_per_cand = (uint32_t)std::max(8, atoi(ev));   // (tests: force the overflow path)
     // the handle's stream at the highest priority, the second stream (image layout beside the per-cluster pass, a pre-filter beside the
     // scan) at the lowest: where both have work ready, the critical path's blocks are dispatched first
@@ -409,7 +414,7 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     set_shard_common(h, d);
     h->layout = 0;
     const uint64_t n = h->n_prov;
-    CK(hipEventRecord(h->ev[0], h->stream));
+    TREC(2, 0, h->stream);
     if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
     if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
@@ -427,11 +432,11 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     if ((rc = upload_sliced(h, stage.p, pairsa, n * rec))) return rc;
     e2s_launch_unpack_pairsa((const uint8_t*)stage.p, n, d->pos_bytes, d->da_bytes, h->pos, h->zb, h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_pairsa");
-    CK(hipEventRecord(h->ev[1], h->stream));
+    TREC(2, 1, h->stream);
     CK(hipStreamSynchronize(h->stream));
     stage.release(); stage8.release();
     CK(hipGetLastError());
-    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
     return narrow_lcp(h);
 }
 
@@ -445,7 +450,7 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     set_shard_common(h, d);
     h->layout = 1;
     const uint64_t n = h->n_prov;
-    CK(hipEventRecord(h->ev[0], h->stream));
+    TREC(2, 0, h->stream);
     if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
     if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
@@ -457,11 +462,11 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     e2s_launch_unpack_gesa((const uint8_t*)stage.p, n, d->da_bytes, d->pos_bytes, d->lcp_bytes, h->bwt, h->lcp, h->xb, h->pos, h->zb,
                            h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_gesa");
-    CK(hipEventRecord(h->ev[1], h->stream));
+    TREC(2, 1, h->stream);
     CK(hipStreamSynchronize(h->stream));
     stage.release();
     CK(hipGetLastError());
-    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
     return narrow_lcp(h);
 }
 
@@ -493,7 +498,7 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
     h->layout = 0;
     h->tail_bwt_given = true; h->tail_bwt_arg = tail_bwt;
     const uint64_t n = h->n_prov;
-    CK(hipEventRecord(h->ev[0], h->stream));
+    TREC(2, 0, h->stream);
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
     DevScratch stage;
     if (d->lcp_bytes == 8) {
@@ -504,10 +509,10 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
         CK(hipStreamSynchronize(h->stream));
         stage.release();
     } else if ((rc = upload_sliced(h, h->lcp, lcp, n * h->xb))) return rc;
-    CK(hipEventRecord(h->ev[1], h->stream));
+    TREC(2, 1, h->stream);
     CK(hipStreamSynchronize(h->stream));
     CK(hipGetLastError());
-    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
     return narrow_lcp(h);
 }
 
@@ -521,7 +526,7 @@ extern "C" int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const v
     set_shard_common(h, d);
     h->layout = 0;
     const uint64_t n = h->n_prov;
-    CK(hipEventRecord(h->ev[0], h->stream));
+    TREC(2, 0, h->stream);
     if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
     if ((rc = upload_sliced(h, h->bwt, bwt, n))) return rc;
@@ -532,11 +537,11 @@ extern "C" int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const v
         e2s_launch_narrow8((const uint8_t*)stage.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
     } else if ((rc = upload_sliced(h, h->lcp, lcp, n * h->xb))) return rc;
-    CK(hipEventRecord(h->ev[1], h->stream));
+    TREC(2, 1, h->stream);
     CK(hipStreamSynchronize(h->stream));
     stage.release();
     CK(hipGetLastError());
-    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1]);
+    ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
     return narrow_lcp(h);
 }
 
@@ -617,7 +622,7 @@ static void take_scan_stats(e2s_ctx* h, const ScanMail& mail, int min_len) {
     rs.hist.last_len = rs.last_none ? 0 : buf[E2S_MAX_CLUST_LEN + 3];
     rs.min_len = min_len;
     h->raw_stats_valid = true;
-    ev_ms(&h->tm.hist_ms, h->ev[3], h->ev[1]);                  // the scan's follow-up kernel(s)
+    ev_ms(&h->tm.hist_ms, h->ev[3], h->ev[1], h->timing >= 2);                  // the scan's follow-up kernel(s)
 }
 
 static int ensure_image(e2s_ctx* h, uint64_t records) {
@@ -682,15 +687,15 @@ static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail
     if (!fused) CK(hipMemsetAsync(h->d_scan_stats, 0, 160 * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
     CK(hipMemsetAsync(h->d_imgst, 0, off_slots, h->stream));
     h->scan_start_ev = fused ? 6 : 0;
-    CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
+    TREC(1, h->scan_start_ev, h->stream);
     e2s_launch_scan_img(sa, fused ? &fa : nullptr, g, h->stream);
     if (fused) { h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true; h->pf_gen = h->scan_gen; }
     LCHK("e2s_launch_scan_img");
-    CK(hipEventRecord(h->ev[3], h->stream));
+    TREC(1, 3, h->stream);
     static_assert(sizeof(ScanMail) <= 256, "mail layout");
     uint64_t* dh = (uint64_t*)((uint8_t*)h->d_mail + 256);
     e2s_launch_scan_img_fin(sa, g, a.flags, a.tailv, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, (unsigned long long*)dh, h->stream);
-    CK(hipEventRecord(h->ev[1], h->stream));
+    TREC(2, 1, h->stream);
     LCHK("e2s_launch_scan_img_fin");
     CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
     CK(wait_stream(h));
@@ -808,14 +813,14 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     // three timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix.
     // With the pre-filter inside the scan kernel the start event is the per-cluster pass's (ev[6]).
     h->scan_start_ev = fuse_now ? 6 : 0;
-    CK(hipEventRecord(h->ev[h->scan_start_ev], h->stream));
+    TREC(1, h->scan_start_ev, h->stream);
     if (fuse_now) {
         // (a rerun after a segment overflow scans alone: the pre-filter's list does not depend on the segments)
         e2s_launch_scan_seg_fused(sa, fa, h->stream);
         h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true; h->pf_gen = h->scan_gen;
     } else e2s_launch_scan_seg(sa, h->xb, h->stream);
     LCHK("e2s_launch_scan_seg");
-    CK(hipEventRecord(h->ev[3], h->stream));
+    TREC(1, 3, h->stream);
     // k_seg_fix: the shard's boundary flags, the records that began in an earlier block, the offsets of the kept records in the
     // image, and the statistics the scan kernel tallied (e2s_scan_stats_desc / e2s_cluster_hist: no kernel of their own)
     static_assert(sizeof(ScanMail) <= 256, "mail layout");
@@ -823,7 +828,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     const bool last_rank = d.global_offset + d.n_entries == d.n_total;
     e2s_launch_seg_fix(sa, a.flags, a.tailv, (unsigned long long*)h->d_seg_off, (unsigned long long*)h->d_kept_off, a.err, h->bwt, h->pos, h->da, h->xb, h->yb,
                        h->zb, h->d_mail, (unsigned long long*)dh, blob, last_rank ? 1 : 0, h->tail_bwt_given ? (int)h->tail_bwt_arg : -1, h->stream);
-    CK(hipEventRecord(h->ev[1], h->stream));
+    TREC(2, 1, h->stream);
     LCHK("e2s_launch_seg_fix");
     if (copy_mail) CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
     h->segmented = true; h->seg_cap = sa.seg_cap; h->seg_blocks = sa.n_blocks;
@@ -843,8 +848,8 @@ static int scan_finish(e2s_ctx* h, const ScanMail& mail, int min_len) {
     h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
     h->tail_lcp = mail.tail_lcp; h->tail_prev_lcp = mail.tail_prev_lcp;
     const uint32_t wrap_n = mail.wrap_count;
-    ev_ms(&h->tm.scan_ms, h->ev[h->scan_start_ev], h->ev[1]);
-    ev_ms(&h->tm.scan_main_ms, h->ev[h->scan_start_ev], h->ev[3]);
+    ev_ms(&h->tm.scan_ms, h->ev[h->scan_start_ev], h->ev[1], h->timing >= 2);
+    ev_ms(&h->tm.scan_main_ms, h->ev[h->scan_start_ev], h->ev[3], h->timing >= 1);
     h->tm.scan_bytes_read = d.n_entries * (uint64_t)d.lcp_bytes;
     h->tm.scan_bytes_written = h->n_ends * 10;
 
@@ -1241,15 +1246,15 @@ extern "C" int e2s_cluster_hist(e2s_handle h, e2s_hist* out) {
     memset(out, 0, sizeof(*out));
     uint64_t* dh = h->d_scalars + 8;
     CK(hipMemsetAsync(dh, 0, (E2S_MAX_CLUST_LEN + 5) * 8, h->stream));
-    CK(hipEventRecord(h->ev[4], h->stream));
+    TREC(2, 4, h->stream);
     if (h->n_rec) e2s_launch_hist(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)dh, h->stream);
-    CK(hipEventRecord(h->ev[5], h->stream));
+    TREC(2, 5, h->stream);
     if (h->n_rec) e2s_launch_hist_tail(h->d_lens, h->n_rec, h->min_len, (unsigned long long*)(dh + E2S_MAX_CLUST_LEN + 3), h->stream);
     uint64_t* buf = (uint64_t*)(h->pin_mail + 256);
     CK(hipMemcpyAsync(buf, dh, (E2S_MAX_CLUST_LEN + 4) * 8, hipMemcpyDeviceToHost, h->stream));
     CK(hipStreamSynchronize(h->stream));
     CK(hipGetLastError());
-    ev_ms(&h->tm.hist_ms, h->ev[4], h->ev[5]);
+    ev_ms(&h->tm.hist_ms, h->ev[4], h->ev[5], h->timing >= 2);
     memcpy(out->freq, buf, (E2S_MAX_CLUST_LEN + 1) * 8);
     out->n_records = buf[E2S_MAX_CLUST_LEN + 1];
     out->n_bases = buf[E2S_MAX_CLUST_LEN + 2];
@@ -1389,10 +1394,10 @@ static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_r
     FilterArgs f;
     int rc = prefilter_setup(h, mcov_out, min_len, est_records, st, f, false);
     if (rc) return rc;
-    CK(hipEventRecord(h->ev[6], st));
+    TREC(2, 6, st);
     e2s_launch_cluster_filter2(f, 0, (h->n_prov + 4095) / 4096, max_workers, st);
     LCHK("e2s_launch_cluster_filter");
-    CK(hipEventRecord(h->ev[4], st));
+    TREC(2, 4, st);
     h->pf_inflight = true; h->pf_mcov = mcov_out; h->pf_len_lo = f.len_lo; h->pf_fused = false; h->pf_gen = h->scan_gen;
     h->pf_on_stream2 = st != h->stream;
     if (h->pf_on_stream2) {
@@ -1555,7 +1560,7 @@ static int cand_streaming_pass(e2s_ctx* h, const CandArgs& a, const FilterArgs& 
     if (chunks == 1) {
         e2s_launch_cluster_filter2(f, 0, w_tiles, 0, h->stream);
         LCHK("e2s_launch_cluster_filter2");
-        CK(hipEventRecord(h->ev[4], h->stream));
+        TREC(2, 4, h->stream);
         e2s_launch_flagged_lists(a, nullptr, fl_count, defw, h->stream);
         LCHK("e2s_launch_flagged_lists");
         return E2S_OK;
@@ -1571,7 +1576,7 @@ static int cand_streaming_pass(e2s_ctx* h, const CandArgs& a, const FilterArgs& 
         e2s_launch_flagged_lists(a, snap + c, snap + c + 1, defw, h->stream2);
     }
     LCHK("e2s_launch_cluster_filter2 (chunks)");
-    CK(hipEventRecord(h->ev[4], h->stream));
+    TREC(2, 4, h->stream);
     CK(hipEventRecord(h->ev_chunk[8], h->stream2));
     CK(hipStreamWaitEvent(h->stream, h->ev_chunk[8], 0));          // the ordering pass needs every candidate
     return E2S_OK;
@@ -1587,7 +1592,7 @@ static int cand_record_pass(e2s_ctx* h, const CandArgs& a, const e2s_c2s_params*
                                 a.len_lo, a.len_hi, (unsigned long long*)h->d_fl_starts, h->d_fl_lens, h->fl_cap,
                                 (unsigned long long*)(h->d_scalars + 2), h->stream);
     LCHK("e2s_launch_record_prefilter");
-    CK(hipEventRecord(h->ev[4], h->stream));
+    TREC(2, 4, h->stream);
     e2s_launch_flagged_lists(a, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
     LCHK("e2s_launch_flagged_lists");
     return E2S_OK;
@@ -1621,8 +1626,8 @@ static void cand_accept(e2s_ctx* h, const CandArgs& a, uint64_t count, int pf_en
     h->cand_downloaded = count != 0;
     h->pin_order = h->pin_cand ? (uint32_t*)(h->pin_cand + h->stream_ord_off) : nullptr;
     h->cand_host_valid = !h->cand_dev;
-    ev_ms(&h->tm.cand_ms, h->ev[6], h->ev[7]);
-    ev_ms(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev]);   // the pre-filter (inside the scan kernel: that kernel)
+    ev_ms(&h->tm.cand_ms, h->ev[6], h->ev[7], h->timing >= 2);
+    ev_ms(&h->tm.cand_main_ms, h->ev[6], h->ev[pf_end_ev], h->timing >= 2 || (h->timing >= 1 && pf_end_ev == 3));   // the pre-filter (inside the scan kernel: that kernel)
     h->tm.cand_bytes_read = d.n_entries * (uint64_t)(d.lcp_bytes + d.da_bytes + d.pos_bytes + 1) + h->n_rec * 10;
     h->tm.cand_bytes_written = count * a.stride;
 }
@@ -1646,7 +1651,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
     uint64_t want = std::max<uint64_t>(std::max<uint64_t>(4096, h->n_rec / 256), h->cand_cap);
     uint64_t count = 0;
     bool done = false;
-    if (h->n_rec == 0) { done = true; CK(hipEventRecord(h->ev[6], h->stream)); CK(hipEventRecord(h->ev[4], h->stream)); CK(hipEventRecord(h->ev[7], h->stream)); }
+    if (h->n_rec == 0) { done = true; TREC(2, 6, h->stream); TREC(2, 4, h->stream); TREC(2, 7, h->stream); }
     for (int attempt = 0; attempt < 5 && !done; ++attempt) {
         if ((rc = cand_buffers(h, a, want))) return rc;
         // a pre-filter launched ahead (e2s_prefilter_arm / e2s_prefilter_begin) for this very scan and the same -m stands in for
@@ -1664,7 +1669,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap;
         FilterArgs f;
         filter_args(h, p->mcov_out, a.len_lo, a.len_hi, f);
-        if (!use_pf) CK(hipEventRecord(h->ev[6], h->stream));
+        if (!use_pf) TREC(2, 6, h->stream);
         {   // one launch: the pass's counters, the seeds into the reserved head of the list, the ordering pass's bucket counts
             void* dev_mail = nullptr;
             CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
@@ -1681,7 +1686,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         } else if (streaming) rc = cand_streaming_pass(h, a, f, defw);
         else rc = cand_record_pass(h, a, p, defw);
         if (rc) return rc;
-        CK(hipEventRecord(h->ev[7], h->stream));
+        TREC(2, 7, h->stream);
         if ((rc = cand_order_and_mail(h, a))) return rc;
         CK(wait_stream(h));
         CK(hipGetLastError());
@@ -1928,7 +1933,7 @@ static int tail_prepare(e2s_ctx* h, const e2s_tail_params* p, uint64_t n, TailAr
 }
 // the handle's state from the totals of a tail that has run: events, bytes of the text with ids from first_id, candidates kept, error bits
 static int tail_accept(e2s_ctx* h, const e2s_tail_params* p, uint64_t first_id, uint64_t events, uint64_t bytes, uint64_t kept, uint32_t err) {
-    ev_ms(&h->tm.tail_ms, h->ev[2], h->ev[5]);
+    ev_ms(&h->tm.tail_ms, h->ev[2], h->ev[5], h->timing >= 2);
     if (err & E2S_TAILERR_RANK) return fail(h, E2S_ERR_STATE, "GPU tail: a candidate names a read past the last one (the reference repeats stale text: use the host tail)");
     if (err & E2S_TAILERR_CRASH) return fail(h, E2S_ERR_REF_CRASH, "a right context starts beyond its read (-L longer than the shared context): the reference throws here");     // substr throws in the reference
     if (first_id && bytes > h->snp_cap) return fail(h, E2S_ERR_CAPACITY, "`.snp` image bound exceeded");
@@ -1960,7 +1965,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
     CK(hipMemsetAsync(h->d_part, 0, 64 + ng * 24, h->stream));   // (one clear for the totals, the error word and the groups' sums)
-    CK(hipEventRecord(h->ev[2], h->stream));
+    TREC(2, 2, h->stream);
     e2s_launch_consensus(a, h->list_cap, h->stream);
     LCHK("e2s_launch_consensus");
     e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, first_id, totals, totals + 4, tail_err, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->stream);
@@ -1969,7 +1974,7 @@ extern "C" int e2s_call_variants(e2s_handle h, const e2s_tail_params* p, uint64_
         e2s_launch_tail_write(a, part_excl, first_id, nullptr, h->d_snp, h->snp_cap, h->stream);
         LCHK("e2s_launch_tail_write");
     }
-    CK(hipEventRecord(h->ev[5], h->stream));
+    TREC(2, 5, h->stream);
     uint64_t* mb = (uint64_t*)(h->pin_mail + 3200);
     CK(hipMemcpyAsync(mb, totals, 32, hipMemcpyDeviceToHost, h->stream));
     CK(wait_stream(h));
@@ -2160,13 +2165,13 @@ extern "C" int e2s_internal_find_candidates_compact(e2s_handle h, const e2s_c2s_
         a.starts = h->d_fl_starts; a.lens = h->d_fl_lens; a.n_rec = h->fl_cap;
         CK(hipMemcpyAsync(h->d_scalars + 2, &n_cl, 8, hipMemcpyHostToDevice, h->stream));        // the list's length
         CK(hipMemsetAsync(h->d_words + 20, 0, 4, h->stream));
-        CK(hipEventRecord(h->ev[6], h->stream));
+        TREC(2, 6, h->stream);
         e2s_launch_cand_init((unsigned long long*)(h->d_scalars + 1), a.stream8_count, h->d_words + 1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, false,
                              (uint32_t*)h->d_rank, e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);
-        CK(hipEventRecord(h->ev[4], h->stream));
+        TREC(2, 4, h->stream);
         e2s_launch_flagged_lists(a, nullptr, (const unsigned long long*)(h->d_scalars + 2), true, h->stream);
         LCHK("e2s_launch_flagged_lists");
-        CK(hipEventRecord(h->ev[7], h->stream));
+        TREC(2, 7, h->stream);
         if ((rc = cand_order_and_mail(h, a, nullptr, nullptr, 0, key_lo << 2, (key_span + 1) << 2))) return rc;
         CK(wait_stream(h));
         CK(hipGetLastError());
@@ -2327,9 +2332,9 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
             e2s_launch_consensus(tb, h->list_cap, h->stream3);
             LCHK("e2s_launch_consensus");
         }
-        CK(hipEventRecord(h->ev[7], h->stream));
+        TREC(2, 7, h->stream);
         CK(hipEventRecord(h->ev_cons, h->stream3));
-        CK(hipEventRecord(h->ev[2], h->stream));
+        TREC(2, 2, h->stream);
         if ((rc = cand_order_and_mail(h, ca, d_cand_bad))) return rc;
         if (p->want_image && image_at == 1 && (rc = image_now())) return rc;
         CK(hipStreamWaitEvent(h->stream, h->ev_cons, 0));
@@ -2340,10 +2345,10 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     } else {
         e2s_launch_flagged_lists(ca, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
         LCHK("e2s_launch_flagged_lists");
-        CK(hipEventRecord(h->ev[7], h->stream));
+        TREC(2, 7, h->stream);
         if ((rc = cand_order_and_mail(h, ca, d_cand_bad, h->d_part, 8 + ng * 3))) return rc;      // (the last kernel of the pass also clears the tail's sums)
         if (p->want_image && image_at == 1 && (rc = image_now())) return rc;
-        CK(hipEventRecord(h->ev[2], h->stream));
+        TREC(2, 2, h->stream);
         e2s_launch_consensus(ta, h->list_cap, h->stream);
         LCHK("e2s_launch_consensus");
         h->tail_by_slot = false;
@@ -2351,16 +2356,21 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, 1, totals, totals + 4, tail_err, d_jd, blob2, &d_scan_mail->err, &d_jd->stat_rc, d_cand_bad,
                              (const unsigned long long*)(h->d_scalars + 1), h->stream);
     LCHK("e2s_launch_tail_partials");
+    // the text kernel's first block also delivers the step's mail (the scan's descriptor + statistics + the job record) into the pinned mailbox
+    static_assert(256 + (E2S_MAX_CLUST_LEN + 5) * 8 <= 1536 && sizeof(JobDev) % 8 == 0, "the scan's mail and statistics end before the job record");
+    void* dev_mail = nullptr;
+    CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
+    const uint32_t mail_words = (uint32_t)((1536 + sizeof(JobDev)) / 8);
     if (W > 1) {                                                // exchange 2: (events, ok) -> this rank's first id (worked out by the text kernel itself)
         if (allgather(user, blob2, recv2, 16, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
-        e2s_launch_tail_write(ta, part_excl, 1, nullptr, h->d_snp, h->snp_cap, h->stream, recv2, W, p->rank, d_jd);
-    } else e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream);
+        e2s_launch_tail_write(ta, part_excl, 1, nullptr, h->d_snp, h->snp_cap, h->stream, recv2, W, p->rank, d_jd, (const unsigned long long*)h->d_mail,
+                              (unsigned long long*)dev_mail, mail_words);
+    } else e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream, nullptr, 1, 0, nullptr,
+                                 (const unsigned long long*)h->d_mail, (unsigned long long*)dev_mail, mail_words);
     LCHK("e2s_launch_tail_write");
-    CK(hipEventRecord(h->ev[5], h->stream));
+    TREC(2, 5, h->stream);
     if (p->want_image && image_at >= 2 && (rc = image_now())) return rc;
-    static_assert(256 + (E2S_MAX_CLUST_LEN + 5) * 8 <= 1536, "the scan's mail and statistics end before the job record");
     JobDev* const jdh = (JobDev*)(h->pin_mail + 1536);
-    CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 1536 + sizeof(JobDev), hipMemcpyDeviceToHost, h->stream));    // the scan's mail + statistics + the job record: one copy
     CK(wait_stream(h));                                         // ---- the ONE wait of the step
     CK(hipGetLastError());
 
@@ -2412,6 +2422,14 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
         rep->n_clust = jd.n_clust; rep->n_bases = jd.n_bases; rep->n_candidates = count; rep->n_variants = h->n_variants; rep->n_events = h->n_events;
         rep->snp_bytes = h->snp_bytes; rep->n_ends = h->n_ends;
     }
+    return E2S_OK;
+}
+
+extern "C" int e2s_set_timing(e2s_handle h, int level) {
+    dbg_entry("e2s_set_timing");
+    if (!h || level < 0 || level > 2) return E2S_ERR_ARG;
+    h->timing = level;
+    memset(&h->tm, 0, sizeof(h->tm));
     return E2S_OK;
 }
 

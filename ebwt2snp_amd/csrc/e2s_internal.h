@@ -240,7 +240,7 @@ void e2s_launch_reads_extent(const uint64_t* rstart, const uint32_t* rlen, uint6
 void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st);
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, const unsigned long long* first_id_dev,
                            uint8_t* out, unsigned long long out_cap, hipStream_t st, const unsigned long long* ids2 = nullptr, int world = 1, int rank = 0,
-                           JobDev* jd = nullptr);
+                           JobDev* jd = nullptr, const unsigned long long* mail_src = nullptr, unsigned long long* mail_dst = nullptr, uint32_t mail_words = 0);
 
 void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsigned long long tile_hi, int max_workers, hipStream_t st);
 void e2s_launch_phase_init(unsigned long long* count, unsigned long long count_value, uint16_t* lens, uint32_t n_lens, uint32_t* w0, uint32_t n0,

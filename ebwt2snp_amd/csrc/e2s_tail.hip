@@ -486,8 +486,12 @@ constexpr u32 TL_HDR_STRIDE = 148;                                  // >= the lo
 // its text follows in closed form (only the id digits depend on first_id)
 // ids2 (the resident job on several ranks): the gathered (events, ok) pairs -- every block derives the rank's first id from them (a
 // launch of its own for that was 4 us + a launch gap on the critical path), block 0 completes the job's record
+// mail_src / mail_dst / mail_words (the resident job): block 0 also delivers the step's mail -- the scan's descriptor and statistics and the
+// job's record, all written by EARLIER kernels of the stream (and, just above, by this block's first thread) -- into the host's pinned
+// mailbox: the copy engine's turn behind the last kernel (a launch gap + ~4 us) is gone, and the host's one wait is for this kernel
 __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, const unsigned long long* first_id_dev, uint8_t* out,
-                                                     u64 out_cap, const unsigned long long* ids2, int world, int rank, JobDev* jd) {
+                                                     u64 out_cap, const unsigned long long* ids2, int world, int rank, JobDev* jd,
+                                                     const unsigned long long* mail_src, unsigned long long* mail_dst, u32 mail_words) {
     if (first_id_dev) first_id = *first_id_dev;
     if (ids2) {
         u64 before = 0; u32 bad = 0;
@@ -499,6 +503,10 @@ __global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned 
             jd->snp_bytes = text + 2ull * (tl_digit_sum_below(first_id + ne) - tl_digit_sum_below(first_id));
             jd->first_id = first_id; jd->events_before = before; jd->peers_not_ok = bad;
         }
+    }
+    if (mail_dst && blockIdx.x == 0) {
+        __syncthreads();                                            // (thread 0's completion of the record, above)
+        for (u32 w = threadIdx.x; w < mail_words; w += 1024u) mail_dst[w] = __hip_atomic_load(mail_src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (a.n_cand_dev) a.n_cand = min((u64)a.n_cand, (u64)*a.n_cand_dev);
     if ((u64)blockIdx.x * 64ull >= a.n_cand) return;
@@ -666,7 +674,10 @@ void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long
     hipLaunchKernelGGL(k_tail_partials, dim3(1), dim3(1024), 0, st, part, part_excl, ng, first_id, totals, n_keep, err, jd, blob2, bad_a, bad_b, bad_c, n_cand_dev);
 }
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, const unsigned long long* first_id_dev,
-                           uint8_t* out, unsigned long long out_cap, hipStream_t st, const unsigned long long* ids2, int world, int rank, JobDev* jd) {
-    if (!a.n_cand) return;
-    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)((a.n_cand + 63) / 64)), dim3(1024), 0, st, a, part_excl, first_id, first_id_dev, out, out_cap, ids2, world, rank, jd);
+                           uint8_t* out, unsigned long long out_cap, hipStream_t st, const unsigned long long* ids2, int world, int rank, JobDev* jd,
+                           const unsigned long long* mail_src, unsigned long long* mail_dst, uint32_t mail_words) {
+    if (!a.n_cand && !mail_dst) return;
+    const unsigned long long groups = (a.n_cand + 63) / 64;
+    hipLaunchKernelGGL(k_tail_write, dim3((unsigned)(groups ? groups : 1)), dim3(1024), 0, st, a, part_excl, first_id, first_id_dev, out, out_cap, ids2, world, rank, jd,
+                       mail_src, mail_dst, mail_words);
 }

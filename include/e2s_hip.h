@@ -397,6 +397,11 @@ typedef struct {
     uint64_t cand_bytes_read, cand_bytes_written;
 } e2s_timing;
 int e2s_last_timing(e2s_handle h, e2s_timing* out);
+/* Kernel timing is OPT-IN: an event recorded between two dependent kernels costs stream time (5-10 us per boundary on gfx950
+ * against ~2 us for a bare boundary), so by default the library records none.  level 0: none (e2s_last_timing reports zeros
+ * for the kernel times); 1: two events around the dominant scan kernel only (scan_main_ms); 2: every phase (all fields).
+ * A handle starts at the level of the environment variable E2S_TIMING (default 0). */
+int e2s_set_timing(e2s_handle h, int level);
 /* The HIP stream the handle launches on (hipStream_t as void*), for callers that bracket calls
  * with their own events. */
 int e2s_stream(e2s_handle h, void** stream);

@@ -18,6 +18,7 @@ blk, n1 = bench.tile_block(blk0, n1b, copies)
 m = blk["lcp"].numel()
 rd = bench.tile_reads(reads.to(dev), n1b, copies)
 h = capi.Handle(0)
+h.set_timing(2)
 h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
 h.attach_soa(capi.Handle.desc(m), blk["bwt"].data_ptr(), blk["lcp"].data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr(), keep=tuple(blk.values()))
 acc = {}

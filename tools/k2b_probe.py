@@ -13,6 +13,7 @@ blk, n1 = bench.tile_block(blk, n1, copies)
 m = blk["lcp"].numel()
 torch.cuda.synchronize()   # the arrays are built on torch's stream; the library runs on its own
 h = capi.Handle(0)
+h.set_timing(2)
 h.attach_soa(capi.Handle.desc(m), blk["bwt"].data_ptr(), blk["lcp"].data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr())
 for c in (20, 10, 4, 1):
     ts = []

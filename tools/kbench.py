@@ -17,6 +17,7 @@ blk, n1 = bench.tile_block(blk0, n1, copies)
 torch.cuda.synchronize()
 n = blk["lcp"].numel()
 h = capi.Handle(0)
+h.set_timing(2)
 h.attach_soa(capi.Handle.desc(n), blk["bwt"].data_ptr(), blk["lcp"].data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr())
 flush = torch.zeros(1 << 30, dtype=torch.uint8, device=dev)       # > Infinity Cache: evicts the columns between scans, as a full step does
 for fused in (False, True):

@@ -15,7 +15,7 @@ for rn in ${RANKS:-0/8 3/8 7/8 1/2 2/4}; do
 import json, sys
 j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 print("rank %d/%d: %.4f ms/step, %d entries; kernels %s; host phases %s" % (j["emulated_rank"], j["emulated_world"], j["ms_per_step"], j["rank_entries"],
-      {k: round(v, 4) for k, v in j["kernel_ms"].items()}, j["config"]["host_phase_ms"]))
+      {k: round(v, 4) for k, v in j["kernel_ms"].items() if not isinstance(v, str)}, j["config"]["host_phase_ms"]))
 PY
 done
 if [ "${TRACE:-1}" = "1" ]; then

@@ -12,6 +12,7 @@ torch.cuda.synchronize()   # the arrays are built on torch's stream; the library
 for x in (1, 4):
     lcp = blk["lcp"] if x == 1 else blk["lcp"].to(torch.int32).contiguous()
     h = capi.Handle(0)
+    h.set_timing(2)
     d = capi.Handle.desc(m, x=x, y=4, z=1)
     h.attach_soa(d, blk["bwt"].data_ptr(), lcp.data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr(), keep=(lcp,))
     for it in range(3):
