@@ -22,7 +22,7 @@ if [ "${TRACE:-1}" = "1" ]; then
   cd /tmp && export TMPDIR=/tmp
   timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- python3 "$root/bench.py" --workload c3 --emulate-rank 3/8 --steps 10 --warmup 2 > "$out/trace.log" 2>&1
   cd "$root"
-  python3 tools/timeline.py "$out/trace" 12 > "$out/timeline_rank3of8.txt" || true
+  python3 tools/timeline.py "$out/trace" ${WHICH:-16} > "$out/timeline_rank3of8.txt" || true
   cat "$out/timeline_rank3of8.txt"
   find "$out/trace" -name "*.db" -delete; find "$out/trace" -name "*kernel_trace.csv" -size +20M -delete
 fi
