@@ -93,10 +93,7 @@ struct e2s_ctx {
     std::vector<hipStream_t> up_streams;                         // upload_sliced
     bool ko_clean = false;                                       // the ordering pass's bucket counts are zero (its last kernel leaves them so)
     uint8_t* d_xchg = nullptr; size_t xchg_bytes = 0;            // e2s_resident_job: the two exchanges' send / receive buffers
-    // the scan that writes the image itself (k_scan_seg<1, FUSED, true>): records live in d_img only, statistics come with the mail
-    bool img_mode = false; uint64_t img_scan_records = 0; uint32_t img_skip = 0;     // img_skip: the shard's record 0 turned out shorter than min_len
-    uint8_t* d_imgst = nullptr; size_t imgst_bytes = 0; int img_waves[2] = {0, 0};      // ticket | statistics | status words A, B | per-wave reports
-    std::vector<uint64_t> wrap_pairs;                             // img_mode: (start, u16 length) of records whose true length wrapped
+    uint64_t img_scan_records = 0; uint32_t img_skip = 0;       // records the scan counted for the image; img_skip: the shard's record 0 turned out shorter than min_len
     uint64_t first_rec_addr = E2S_NONE;
     uint64_t* d_cstarts = nullptr; uint16_t* d_clens = nullptr; uint64_t ccap = 0; bool compact_valid = false;   // contiguous copy, on demand
     uint8_t* pin_mail = nullptr;                 // 4 KB pinned mailbox for small downloads / uploads
@@ -219,6 +216,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
 static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st);
 static bool prefilter_eligible(const e2s_ctx* h);
 static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words);
+static int prefilter_room(e2s_ctx* h, uint64_t est_records);
 
 // Wait for the handle's stream with a short spin on an event before falling back to the blocking wait: the two
 // waits of a job (after the scan, after the per-cluster pass) sit on its critical path, and the blocking wait's
@@ -283,7 +281,7 @@ extern "C" int e2s_destroy(e2s_handle h) {
     release_reads(h);
     dev_free(h->d_cons); dev_free(h->d_trec); dev_free(h->d_part); dev_free(h->d_snp);
     for (auto& ev : h->ev) if (ev) ev_destroy(ev);
-    dev_free(h->d_img); dev_free(h->d_img_scratch); dev_free(h->d_imgst);
+    dev_free(h->d_img); dev_free(h->d_img_scratch);
     for (auto& p : h->pin_io) if (p) pin_free(p);
     for (auto& e : h->ev_io) if (e) ev_destroy(e);
     if (h->ev_wait) ev_destroy(h->ev_wait);
@@ -565,27 +563,6 @@ static const uint8_t* image_ptr(const e2s_ctx* h) { return h->d_img ? h->d_img +
 static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_t** lens, uint64_t* n) {
     *n = h->n_rec;
     if (!h->segmented) { *starts = h->d_starts; *lens = h->d_lens; return E2S_OK; }
-    if (h->img_mode) {
-        // the records live in the packed image only (those append_entry keeps: the others matter to nobody downstream)
-        uint64_t nr = 0;
-        int rc = pack_image(h, &nr);
-        if (rc) return rc;
-        *n = nr;
-        if (!h->compact_valid) {
-            if (nr + 8 > h->ccap) {
-                dev_free(h->d_cstarts); dev_free(h->d_clens); h->d_cstarts = nullptr; h->d_clens = nullptr; h->ccap = 0;
-                CK(hipMalloc((void**)&h->d_cstarts, (nr + 8) * 8));
-                CK(hipMalloc((void**)&h->d_clens, (nr + 8) * 2 + 64));
-                h->ccap = nr + 8;
-            }
-            e2s_launch_unpack_clusters(image_ptr(h), nr, (unsigned long long*)h->d_cstarts, h->d_clens, h->d_words + 28, h->stream);   // (ordering word: unused here)
-            CK(hipStreamSynchronize(h->stream));
-            CK(hipGetLastError());
-            h->compact_valid = true;
-        }
-        *starts = h->d_cstarts; *lens = h->d_clens;
-        return E2S_OK;
-    }
     if (!h->compact_valid) {
         if (h->n_rec + 8 > h->ccap) {
             dev_free(h->d_cstarts); dev_free(h->d_clens); h->d_cstarts = nullptr; h->d_clens = nullptr; h->ccap = 0;
@@ -635,82 +612,6 @@ static int ensure_image(e2s_ctx* h, uint64_t records) {
     return E2S_OK;
 }
 
-// The scan that writes the `.clusters` image and the statistics itself (k_scan_seg<1, FUSED, true>: byte LCPs, 16-byte aligned
-// columns): one kernel + one block that gathers the mail.  *done stays false where the input is denser than the chunks' staging
-// buffers or the image's estimate (E2S_DEVERR_SEGFULL): the caller then takes the segment path, which handles everything.
-static int scan_image(e2s_ctx* h, const ScanArgs& a, int min_len, ScanMail& mail, bool* done) {
-    *done = false;
-    const uint64_t n_tiles = (h->n_prov + 4095) / 4096;
-    const uint64_t n_chunks = (n_tiles + E2S_IMG_TILES - 1) / E2S_IMG_TILES;
-    if (n_chunks + E2S_IMG_COUNTERS >= (1ull << 31)) return E2S_OK;                       // (2^46 entries: not on one GPU)
-    static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
-    const bool fused = h->pf_armed && fused_env && prefilter_eligible(h);
-    int& resident = h->img_waves[fused ? 1 : 0];
-    if (!resident) {
-        resident = e2s_scan_img_resident_waves(fused);
-        if (const char* ev = getenv("E2S_SCAN_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < resident) resident = cap; }
-        if (resident < 4) resident = 4;
-    }
-    const uint32_t n_waves = (uint32_t)(((std::max<uint64_t>(std::min<uint64_t>(n_chunks, (uint64_t)resident), E2S_IMG_COUNTERS) + 3) / 4) * 4);   // (every counter has a wave)
-    int rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096));
-    if (rc) return rc;
-    // ticket counters (64 B each) | statistics (153 x 8, padded) | status words A | B | the waves' reports
-    static_assert(E2S_IMG_COUNTERS >= 1 && E2S_IMG_COUNTERS <= 16, "ticket counters");
-    const size_t off_stats = 64 * E2S_IMG_COUNTERS, off_a = off_stats + 160 * 8, off_b = off_a + n_chunks * 8, off_slots = (off_b + n_chunks * 8 + 63) & ~(size_t)63;
-    const size_t need = off_slots + (size_t)n_waves * sizeof(ImgSlot);
-    if (need > h->imgst_bytes) {
-        dev_free(h->d_imgst); h->d_imgst = nullptr; h->imgst_bytes = 0;
-        CK(hipMalloc((void**)&h->d_imgst, need + need / 4));
-        h->imgst_bytes = need + need / 4;
-    }
-    SegArgs sa{};
-    sa.lcp = h->lcp; sa.n_prov = h->n_prov; sa.prov_lo = h->prov_lo; sa.prov_is_global0 = a.prov_is_global0;
-    sa.own_lo = a.own_lo; sa.end_hi = a.end_hi; sa.start_hi = a.start_hi;
-    sa.k_u32 = a.k_u32; sa.kb = a.kb; sa.hge = a.hge;
-    sa.n_tiles = n_tiles;
-    sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
-    ImgArgs g{};
-    g.img = h->d_img; g.img_cap = h->img_cap - 2;               // (room for the records the EOF rule adds)
-    g.ticket = (unsigned long long*)h->d_imgst;
-    g.st_a = (unsigned long long*)(h->d_imgst + off_a); g.st_b = (unsigned long long*)(h->d_imgst + off_b);
-    g.slots = (ImgSlot*)(h->d_imgst + off_slots);
-    g.n_chunks = (uint32_t)n_chunks; g.n_waves = n_waves; g.err = a.err;
-    FilterArgs fa{};
-    if (h->pf_armed) {                                          // e2s_prefilter_arm
-        h->pf_armed = false;
-        if (fused) {
-            h->pf_inflight = false;
-            if ((rc = prefilter_setup(h, h->pf_arm_mcov, min_len, h->n_prov / 32, h->stream, fa, true))) return rc;
-        } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
-    }
-    sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
-    if (!fused) CK(hipMemsetAsync(h->d_scan_stats, 0, 160 * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
-    CK(hipMemsetAsync(h->d_imgst, 0, off_slots, h->stream));
-    h->scan_start_ev = fused ? 6 : 0;
-    TREC(1, h->scan_start_ev, h->stream);
-    e2s_launch_scan_img(sa, fused ? &fa : nullptr, g, h->stream);
-    if (fused) { h->pf_inflight = true; h->pf_mcov = h->pf_arm_mcov; h->pf_len_lo = fa.len_lo; h->pf_on_stream2 = false; h->pf_fused = true; h->pf_gen = h->scan_gen; }
-    LCHK("e2s_launch_scan_img");
-    TREC(1, 3, h->stream);
-    static_assert(sizeof(ScanMail) <= 256, "mail layout");
-    uint64_t* dh = (uint64_t*)((uint8_t*)h->d_mail + 256);
-    e2s_launch_scan_img_fin(sa, g, a.flags, a.tailv, a.err, h->bwt, h->pos, h->da, h->xb, h->yb, h->zb, h->d_mail, (unsigned long long*)dh, h->stream);
-    TREC(2, 1, h->stream);
-    LCHK("e2s_launch_scan_img_fin");
-    CK(hipMemcpyAsync(h->pin_mail, h->d_mail, 256 + (E2S_MAX_CLUST_LEN + 5) * 8, hipMemcpyDeviceToHost, h->stream));   // mail + statistics
-    CK(wait_stream(h));
-    CK(hipGetLastError());
-    mail = *(const ScanMail*)h->pin_mail;
-    if (mail.err & E2S_DEVERR_STALL) return fail(h, E2S_ERR_HIP, "scan: a chunk's status word never arrived");
-    if (mail.err & E2S_DEVERR_SEGFULL) return E2S_OK;           // too dense for this path
-    h->segmented = true; h->img_mode = true; h->img_scan_records = mail.img_records; h->img_skip = 0;
-    h->first_rec_addr = mail.first_rec_addr;
-    h->n_ends = mail.total_ends;
-    take_scan_stats(h, mail, min_len);
-    *done = true;
-    return E2S_OK;
-}
-
 // ---- e2s_cluster_scan in pieces: arguments, launch (everything up to the copy of the mail, no wait), finish (the handle's state from
 // the mail).  e2s_cluster_scan = launch, wait, finish, with a rerun where the segments overflowed; the resident job (e2s_resident_job)
 // launches, goes on enqueueing the per-cluster pass and the tail behind it, and finishes when the whole step has run.
@@ -739,12 +640,13 @@ static void scan_begin(e2s_ctx* h, int k, int min_len) {
     drop_image(h);
     drop_prefilter(h);                                          // (a result of an earlier scan: other k, other data)
     ++h->scan_gen;
-    h->img_mode = false;
 }
 
 // the segmented scan: wave workers over contiguous tile ranges.  seg_cap 0 = the usual estimate; first: the armed pre-filter is taken along.
 // blob != nullptr: k_seg_fix also leaves this rank's share of the job's first all-gather there.
-static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t seg_cap, bool first, uint8_t* blob, bool copy_mail = true) {
+// prepare_only: every buffer the launch needs is put in place and nothing is enqueued (nor is the handle's state touched) -- the
+// launch proper then cannot fail for want of memory (e2s_resident_job: a rank must not drop out between its enqueue and the exchanges)
+static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t seg_cap, bool first, uint8_t* blob, bool copy_mail = true, bool prepare_only = false) {
     int rc;
     const e2s_shard_desc& d = h->d;
     const uint64_t row_entries = (uint64_t)64 * (E2S_SPAN_BYTES / h->xb);   // entries per wave-tile (64 lanes x 64 B)
@@ -801,6 +703,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
     FilterArgs fa{};
     bool fuse_now = false;
+    if (prepare_only) return (armed && prefilter_eligible(h)) ? prefilter_room(h, h->n_prov / 32) : E2S_OK;
     if (armed) {                                                 // e2s_prefilter_arm
         h->pf_armed = false;
         if (fused) {
@@ -839,12 +742,10 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
 // the handle's state from the mail of a scan that has run (either form)
 static int scan_finish(e2s_ctx* h, const ScanMail& mail, int min_len) {
     const e2s_shard_desc& d = h->d;
-    if (!h->img_mode) {
-        h->img_scan_records = mail.img_records; h->img_skip = 0;
-        h->first_rec_addr = mail.first_rec_addr;
-        h->n_ends = mail.total_ends;
-        take_scan_stats(h, mail, min_len);
-    }
+    h->img_scan_records = mail.img_records; h->img_skip = 0;
+    h->first_rec_addr = mail.first_rec_addr;
+    h->n_ends = mail.total_ends;
+    take_scan_stats(h, mail, min_len);
     h->begins_inside = mail.begins_inside; h->open_after = mail.open_after; h->end_before_last = mail.end_before_last;
     h->tail_lcp = mail.tail_lcp; h->tail_prev_lcp = mail.tail_prev_lcp;
     const uint32_t wrap_n = mail.wrap_count;
@@ -855,15 +756,10 @@ static int scan_finish(e2s_ctx* h, const ScanMail& mail, int min_len) {
 
     // records whose uint16_t length wrapped: the per-cluster pass must take them from the record list
     // (addresses into d_starts/d_lens: ranks for the contiguous layout, segment slots for the segmented one)
-    h->wrap_ranks.clear(); h->wrap_pairs.clear(); h->wrap_overflow = wrap_n > E2S_WRAP_CAP; h->first_wrapped = false;
+    h->wrap_ranks.clear(); h->wrap_overflow = wrap_n > E2S_WRAP_CAP; h->first_wrapped = false;
     if (wrap_n && !h->wrap_overflow) {
-        if (h->img_mode) {                                      // (start, u16 length) pairs
-            h->wrap_pairs.resize(2 * (size_t)wrap_n);
-            CK(hipMemcpy(h->wrap_pairs.data(), h->d_wrap, (size_t)wrap_n * 16, hipMemcpyDeviceToHost));
-        } else {
-            h->wrap_ranks.resize(wrap_n);
-            CK(hipMemcpy(h->wrap_ranks.data(), h->d_wrap, wrap_n * 8, hipMemcpyDeviceToHost));
-        }
+        h->wrap_ranks.resize(wrap_n);
+        CK(hipMemcpy(h->wrap_ranks.data(), h->d_wrap, wrap_n * 8, hipMemcpyDeviceToHost));
     }
     h->first_end_pos = h->n_ends ? mail.first_end_pos : E2S_NONE;
     h->open_start = mail.open_start; h->last_end_start = mail.last_end_start; h->first_len_prov = (uint16_t)mail.first_len_prov;
@@ -893,20 +789,13 @@ extern "C" int e2s_cluster_scan(e2s_handle h, int k, int min_len, int scan_mode)
     scan_args(h, k, a);
     int rc;
     ScanMail mail{};
-    bool img_done = false;
-    // E2S_SCAN_IMG=1: the scan that writes the image itself (tickets + decoupled look-back).  Measured slower than segments + one
-    // layout kernel on this chip (its waves wait for the chunks before them), so it is the opt-in
-    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 0;
-    if (img_env && h->xb == 1 && ((uintptr_t)h->lcp & 15u) == 0 && (rc = scan_image(h, a, min_len, mail, &img_done))) return rc;
-    if (!img_done) {
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if ((rc = seg_scan_launch(h, a, min_len, attempt ? ~0ull : 0ull, attempt == 0, nullptr))) return rc;
-            CK(wait_stream(h));
-            CK(hipGetLastError());
-            mail = *(const ScanMail*)h->pin_mail;
-            if (!(mail.err & E2S_DEVERR_SEGFULL)) break;
-            if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record segment overflow");
-        }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = seg_scan_launch(h, a, min_len, attempt ? ~0ull : 0ull, attempt == 0, nullptr))) return rc;
+        CK(wait_stream(h));
+        CK(hipGetLastError());
+        mail = *(const ScanMail*)h->pin_mail;
+        if (!(mail.err & E2S_DEVERR_SEGFULL)) break;
+        if (attempt == 1) return fail(h, E2S_ERR_CAPACITY, "record segment overflow");
     }
     return scan_finish(h, mail, min_len);
 }
@@ -951,27 +840,6 @@ extern "C" int e2s_stitch(e2s_handle h, const e2s_boundary* all, int nranks, int
     if (pl.patch_first) h->first_wrapped = h->first_end_pos != E2S_NONE && h->first_end_pos - pl.first_start + 1 >= 65536;
     h->n_rec = h->n_ends;
     h->n_closed = h->n_ends;
-    if (h->img_mode) {
-        // the image is the scan's: record 0 of a shard that began inside a cluster is finished in its reserved slot -- or skipped, if
-        // append_entry drops it (the image then begins one record later) -- and the records the EOF rule adds follow the last one
-        const bool keep_first = !pl.patch_first || (int)pl.first_len >= h->min_len;
-        h->img_skip = (pl.patch_first && !keep_first) ? 1u : 0u;
-        uint64_t ts[2] = {0, 0}; uint16_t tl[2] = {0, 0}; uint32_t nt = 0;
-        for (uint32_t t = 0; t < pl.n_tail; ++t) if ((int)pl.tail_len[t] >= h->min_len) { ts[nt] = pl.tail_start[t]; tl[nt] = pl.tail_len[t]; ++nt; }
-        if (h->img_scan_records + nt > h->img_cap) return fail(h, E2S_ERR_CAPACITY, "image overflow at the tail");
-        if ((pl.patch_first && keep_first) || nt) {
-            e2s_launch_img_patch(h->d_img, (pl.patch_first && keep_first) ? 1u : 0u, pl.first_start, pl.first_len, h->img_scan_records, nt, ts[0], tl[0], ts[1], tl[1],
-                                 h->stream);
-            LCHK("e2s_launch_img_patch");
-        }
-        h->compact_valid = false;
-        h->n_rec += pl.n_tail; h->n_closed += pl.n_tail;
-        h->plan = pl;
-        h->stitched = true;
-        drop_image(h);
-        h->img_records = h->img_scan_records - h->img_skip + nt; h->img_valid = true;      // nothing to pack
-        return E2S_OK;
-    }
     if (h->segmented) {
         // record 0 lives at the head of the first non-empty segment; the tail records stay on the host
         // (hist and the per-cluster pass take them from the plan, records_contiguous() appends them)
@@ -1040,7 +908,6 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 // unthrottled -- what the per-cluster pass gains, the tail loses when the pack reaches into it; inside the box's run-to-run noise.
 static uint32_t pack_blocks_beside() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_PACK_BLOCKS"); v = e ? atoi(e) : 0; } return (uint32_t)v; }
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
-    if (h->img_mode && h->stitched) { h->img_valid = true; h->img_pending = false; return E2S_OK; }   // the scan wrote it, e2s_stitch finished it
     h->img_valid = false; h->img_pending = false; h->img_records = 0; h->img_total_known = false; h->img_prestitch = false; h->img_stream = st;
     const uint64_t n_raw = h->stitched ? h->n_rec : h->n_ends;
     if (!n_raw) { h->img_valid = true; h->img_prestitch = !h->stitched; return E2S_OK; }
@@ -1103,7 +970,6 @@ extern "C" int e2s_pack_clusters(e2s_handle h, int async) {
     if (!h->stitched && !(h->scanned && h->segmented && !h->records_from_file)) return fail(h, E2S_ERR_STATE, "neither e2s_cluster_scan nor e2s_stitch has run");
     CK(hipSetDevice(h->device));
     if (h->img_valid || h->img_pending) return async ? E2S_OK : pack_image_finish(h, nullptr);     // already there / on its way
-    if (!h->stitched && h->img_mode) return E2S_OK;             // (the scan wrote it)
     int rc = pack_image_launch(h, async ? h->stream2 : h->stream);
     if (rc || async) return rc;
     return pack_image_finish(h, nullptr);
@@ -1224,7 +1090,7 @@ extern "C" int e2s_load_clusters(e2s_handle h, const void* recs, uint64_t n_reco
         CK(e1);
     }
     h->n_rec = n_records; h->n_ends = n_records; h->n_closed = n_records;
-    h->min_len = 0; h->segmented = false; h->img_mode = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};
+    h->min_len = 0; h->segmented = false; h->compact_valid = false; h->plan = e2s_stitch_plan_t{};
     drop_image(h);
     h->wrap_ranks.clear(); h->wrap_overflow = false; h->first_wrapped = false;
     h->scanned = true; h->stitched = true; h->records_from_file = true;
@@ -1373,10 +1239,14 @@ static bool prefilter_eligible(const e2s_ctx* h) {
     return !(h->records_from_file || h->xb != 1 || !aligned || !h->bwt);
 }
 // the flagged-cluster list (empty, behind the reserved seed slots), the pre-filter's error word and its arguments
-static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words = false) {
+// room for the list of flagged clusters (allocation only: what e2s_resident_job's probe call does ahead of the enqueue)
+static int prefilter_room(e2s_ctx* h, uint64_t est_records) {
     // (E2S_TEST_FL_CAP: a testing aid -- a fresh handle's list of flagged clusters starts that short, so that the pre-filter overflows it)
     static const int test_fl_cap = getenv("E2S_TEST_FL_CAP") ? atoi(getenv("E2S_TEST_FL_CAP")) : 0;
-    int rc = ensure_flagged(h, test_fl_cap > 0 && h->fl_cap == 0 ? (uint64_t)test_fl_cap + E2S_SEED_SLOTS : std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
+    return ensure_flagged(h, test_fl_cap > 0 && h->fl_cap == 0 ? (uint64_t)test_fl_cap + E2S_SEED_SLOTS : std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
+}
+static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words = false) {
+    int rc = prefilter_room(h, est_records);
     if (rc) return rc;
     // one launch: the list starts behind the reserved seed slots (length 0 = empty slot), the pre-filter's error word is
     // cleared -- and, for the scan that carries the pre-filter, the scan's words as well
@@ -1523,7 +1393,6 @@ static int cand_seeds(e2s_ctx* h, const CandArgs& a, bool streaming, uint64_t* n
     if (streaming) {
         for (uint32_t t = 0; t < h->plan.n_tail; ++t) seed(h->plan.tail_start[t], h->plan.tail_len[t]);
         if (h->first_wrapped) seed(h->plan.first_start, h->plan.first_len);
-        for (size_t i = 0; i + 1 < h->wrap_pairs.size(); i += 2) seed(h->wrap_pairs[i], (uint16_t)h->wrap_pairs[i + 1]);   // (the image scan lists them as they are)
         for (uint64_t r : h->wrap_ranks) {                          // rare: a cluster of 65536+ entries
             uint64_t st = 0; uint16_t ln = 0;
             CK(hipMemcpy(&ln, h->d_lens + r, 2, hipMemcpyDeviceToHost));
@@ -2117,7 +1986,7 @@ extern "C" int e2s_internal_find_candidates_compact(e2s_handle h, const e2s_c2s_
     CK(hipSetDevice(h->device));
     release_shard(h);                                           // (this handle holds compact clusters, no SA range)
     h->xb = 1; h->yb = 4; h->zb = 1; h->d = e2s_shard_desc{}; h->d.lcp_bytes = 1; h->d.da_bytes = 4; h->d.pos_bytes = 1; h->prov_lo = 0; h->n_prov = n_entries;
-    h->n_rec = n_cl; h->n_ends = n_cl; h->n_closed = n_cl; h->segmented = false; h->img_mode = false; h->plan = e2s_stitch_plan_t{};
+    h->n_rec = n_cl; h->n_ends = n_cl; h->n_closed = n_cl; h->segmented = false; h->plan = e2s_stitch_plan_t{};
     h->scanned = true; h->stitched = true; h->records_from_file = true; h->min_len = 0;
     h->variants_valid = false; h->cand_host_valid = false; h->n_cand = 0;
     if (n_cand) *n_cand = 0;
@@ -2201,10 +2070,9 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
     // ---- does this form apply?  (decided before anything is enqueued; otherwise: the stepwise calls)
     static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
-    static const int img_env = getenv("E2S_SCAN_IMG") ? atoi(getenv("E2S_SCAN_IMG")) : 0;
     static const int job_env = getenv("E2S_RESIDENT_JOB") ? atoi(getenv("E2S_RESIDENT_JOB")) : 1;
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt | (uintptr_t)h->da) & 15u) == 0;
-    if (!job_env || !fused_env || img_env || p->world > E2S_JOB_MAX_RANKS || h->xb != 1 || h->yb != 4 || !aligned || !h->bwt || !h->pos || !h->da)
+    if (!job_env || !fused_env || p->world > E2S_JOB_MAX_RANKS || h->xb != 1 || h->yb != 4 || !aligned || !h->bwt || !h->pos || !h->da)
         return fail(h, E2S_ERR_STATE, "resident job: not applicable to this shard (wide or unaligned columns, a missing column, or switched off): use the stepwise calls");
     const e2s_tail_params tp{p->o.k_left, p->o.k_right, p->o.max_gap, p->o.max_err};
     int rc = tail_applicable(h, &tp);
@@ -2217,9 +2085,11 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     const e2s_shard_desc& d = h->d;
     const bool last_rank = d.global_offset + d.n_entries == d.n_total;
     if (last_rank != (p->rank == p->world - 1)) return fail(h, E2S_ERR_ARG, "rank order must be SA order: only the last rank may hold the EGSA's end");
-    if (p->probe_only) return E2S_OK;
     CK(hipSetDevice(h->device));
     const int W = p->world;
+    // ---- PREPARE: every buffer, stream and event of the step is put in place here, before anything is enqueued.  The probe call
+    // (probe_only) ends behind this block: a driver whose ranks agree on their probes' results before any of them enqueues knows that
+    // no rank will drop out for want of memory between its enqueue and the two exchanges (where its peers would wait for it for ever).
     // exchange buffers: [my blob][W blobs][my (events, ok)][W pairs]
     const size_t off_recv = E2S_JOB_BLOB, off_send2 = off_recv + (size_t)W * E2S_JOB_BLOB, off_recv2 = off_send2 + 64, xneed = off_recv2 + (size_t)W * 16 + 64;
     if (xneed > h->xchg_bytes) {
@@ -2232,27 +2102,25 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     ScanMail* const d_scan_mail = h->d_mail;
     JobDev* const d_jd = (JobDev*)((uint8_t*)h->d_mail + 1536);
     uint32_t* const d_cand_bad = h->d_words + 30;
-
-    // ---- scan + pre-filter in one kernel, k_seg_fix (which also leaves this rank's blob)
-    scan_begin(h, p->k, p->min_len);
     ScanArgs a;
     scan_args(h, p->k, a);
-    h->pf_armed = true; h->pf_arm_mcov = p->o.mcov_out;
-    if ((rc = seg_scan_launch(h, a, p->min_len, 0, true, blob, false))) return rc;      // (the mail travels once, at the end, with everything else)
-    if (!h->pf_fused) return fail(h, E2S_ERR_STATE, "resident job: the pre-filter did not go into the scan kernel");       // (cannot happen: checked above)
-    // (every buffer of the step is in place BEFORE the first exchange: a rank that cannot allocate leaves here, where no other rank waits for it)
+    {
+        const bool armed0 = h->pf_armed; const int mcov0 = h->pf_arm_mcov;
+        h->pf_armed = true; h->pf_arm_mcov = p->o.mcov_out;
+        rc = seg_scan_launch(h, a, p->min_len, 0, true, blob, false, true);      // (segments, descriptors, the flagged list)
+        h->pf_armed = armed0; h->pf_arm_mcov = mcov0;
+        if (rc) return rc;
+    }
     if (p->want_image && (rc = ensure_image(h, std::max<uint64_t>(h->img_cap, h->n_prov / 8 + 4096)))) return rc;
     e2s_c2s_params cp{p->o.nr_reads1, p->o.k_left, p->o.k_right, p->o.mcov_out, p->o.consensus_reads, (int)E2S_MAX_CLUST_LEN, p->min_len};
     CandArgs ca;
     if ((rc = cand_args(h, &cp, (uint64_t)p->rank << 40, ca))) return rc;
-    h->variants_valid = false; h->cand_host_valid = false;
     ca.len_hi_dev = &d_jd->len_hi;
     // (E2S_JOB_TEST_CAND_CAP: a testing aid -- a fresh handle starts with that few candidate slots, so that the step overflows them, says so
     //  in its mail and is redone through the stepwise calls)
     static const int test_cand_cap = getenv("E2S_JOB_TEST_CAND_CAP") ? atoi(getenv("E2S_JOB_TEST_CAND_CAP")) : 0;
     const uint64_t cand_want = test_cand_cap > 0 && h->cand_cap == 0 ? (uint64_t)test_cand_cap : std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap);
     if ((rc = cand_buffers(h, ca, cand_want))) return rc;
-    ca.starts = h->d_fl_starts; ca.lens = h->d_fl_lens; ca.n_rec = h->fl_cap;
     const uint64_t ncap = h->cand_cap, ng = (ncap + 63) / 64;
     TailArgs ta;
     if ((rc = tail_prepare(h, &tp, ncap, ta))) return rc;
@@ -2275,9 +2143,32 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     }
     if (!h->d_pieces) CK(hipMalloc((void**)&h->d_pieces, 256));
     if (!h->ev_chunk[0]) for (auto& e : h->ev_chunk) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
+    if (!h->ev_wait) CK(hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming));
+    void* dev_mail = nullptr;
+    CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
+    if (p->probe_only) return E2S_OK;
+
+    // ---- ENQUEUE: from here to the second exchange nothing allocates.  Should a HIP call fail all the same, this rank still enqueues the
+    // exchanges its peers are going to wait in (`bail` below) -- with a zeroed share, which they read as "a rank of the job is not ok".
+    // (E2S_JOB_FAIL_AT = 1 | 2 with E2S_JOB_FAIL_RANK: a testing aid -- this rank's enqueue "fails" before the first exchange / between the two)
+    static const int fail_at = getenv("E2S_JOB_FAIL_AT") ? atoi(getenv("E2S_JOB_FAIL_AT")) : 0;
+    static const int fail_rank = getenv("E2S_JOB_FAIL_RANK") ? atoi(getenv("E2S_JOB_FAIL_RANK")) : -1;
     unsigned long long* const piece_bounds = h->d_pieces; unsigned long long* const piece_snap = h->d_pieces + 9; uint32_t* const piece_done = (uint32_t*)(h->d_pieces + 18);
+    int stage = 0;                                              // exchanges enqueued so far
+    auto enqueue = [&]() -> int {
+    int rc = E2S_OK;
+    // ---- scan + pre-filter in one kernel, k_seg_fix (which also leaves this rank's blob)
+    scan_begin(h, p->k, p->min_len);
+    h->pf_armed = true; h->pf_arm_mcov = p->o.mcov_out;
+    if ((rc = seg_scan_launch(h, a, p->min_len, 0, true, blob, false))) return rc;      // (the mail travels once, at the end, with everything else)
+    if (!h->pf_fused) return fail(h, E2S_ERR_STATE, "resident job: the pre-filter did not go into the scan kernel");       // (cannot happen: checked above)
+    h->variants_valid = false; h->cand_host_valid = false;
+    ca.starts = h->d_fl_starts; ca.lens = h->d_fl_lens; ca.n_rec = h->fl_cap;
+    if (fail_at == 1 && fail_rank == p->rank) return fail(h, E2S_ERR_HIP, "resident job: injected failure before the first exchange");
     // ---- exchange 1, then everything the host used to do between the scan and the per-cluster pass, on the device
     if (W > 1 && allgather(user, blob, recv, E2S_JOB_BLOB, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
+    stage = 1;
     JobPlanArgs pa{};
     pa.blobs = recv; pa.world = W; pa.rank = p->rank; pa.n_total = d.n_total; pa.k = p->k; pa.lcp_bytes = d.lcp_bytes; pa.mcov = p->o.mcov_out; pa.pval = p->o.pval;
     pa.min_len = p->min_len; pa.len_lo = ca.len_lo;
@@ -2287,6 +2178,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     pa.ko_cnt = (uint32_t*)h->d_rank; pa.n_ko = e2s_cand_order_buckets(h->cand_cap) + 1u;
     pa.zero8 = h->d_part;                                        // (tail_prepare above put it in place)
     pa.fl_count = (const unsigned long long*)(h->d_scalars + 2); pa.n_pieces = n_pieces > 1 ? n_pieces : 0u; pa.piece_bounds = piece_bounds; pa.piece_snap = piece_snap; pa.piece_done = piece_done;
+    pa.img_cap = p->want_image ? h->img_cap - 2 : ~0ull;
     if (!h->ko_clean) CK(hipMemsetAsync(h->d_rank, 0, (size_t)pa.n_ko * 4, h->stream));      // (a fresh buffer / an aborted pass: otherwise the last pass left them clean)
     h->ko_clean = false;
     e2s_launch_job_plan(pa, h->stream);
@@ -2297,7 +2189,6 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     // the tail's text).  (Right behind k_seg_fix it saturated HBM under the plan's one block: 45-65 us for that.)
     static const int image_at = getenv("E2S_JOB_IMAGE_AT") ? atoi(getenv("E2S_JOB_IMAGE_AT")) : 0;
     auto image_now = [&]() -> int {
-        if (!h->ev_img) CK(hipEventCreateWithFlags(&h->ev_img, hipEventDisableTiming));
         CK(hipEventRecord(h->ev_img, h->stream));
         CK(hipStreamWaitEvent(h->stream2, h->ev_img, 0));
         e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, 0xFFFFFFFFu, (const unsigned long long*)h->d_kept_off, h->d_img, h->img_cap - 2, d_scan_mail, 0, 0, 0, 0, 0,
@@ -2356,20 +2247,39 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     e2s_launch_tail_partials(part_raw, part_excl, (uint32_t)ng, 1, totals, totals + 4, tail_err, d_jd, blob2, &d_scan_mail->err, &d_jd->stat_rc, d_cand_bad,
                              (const unsigned long long*)(h->d_scalars + 1), h->stream);
     LCHK("e2s_launch_tail_partials");
+    if (fail_at == 2 && fail_rank == p->rank) return fail(h, E2S_ERR_HIP, "resident job: injected failure between the exchanges");
     // the text kernel's first block also delivers the step's mail (the scan's descriptor + statistics + the job record) into the pinned mailbox
     static_assert(256 + (E2S_MAX_CLUST_LEN + 5) * 8 <= 1536 && sizeof(JobDev) % 8 == 0, "the scan's mail and statistics end before the job record");
-    void* dev_mail = nullptr;
-    CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
     const uint32_t mail_words = (uint32_t)((1536 + sizeof(JobDev)) / 8);
     if (W > 1) {                                                // exchange 2: (events, ok) -> this rank's first id (worked out by the text kernel itself)
         if (allgather(user, blob2, recv2, 16, (void*)h->stream) != 0) return fail(h, E2S_ERR_IO, "the exchange callback failed");
+        stage = 2;
         e2s_launch_tail_write(ta, part_excl, 1, nullptr, h->d_snp, h->snp_cap, h->stream, recv2, W, p->rank, d_jd, (const unsigned long long*)h->d_mail,
                               (unsigned long long*)dev_mail, mail_words);
     } else e2s_launch_tail_write(ta, part_excl, 1, (const unsigned long long*)&d_jd->first_id, h->d_snp, h->snp_cap, h->stream, nullptr, 1, 0, nullptr,
                                  (const unsigned long long*)h->d_mail, (unsigned long long*)dev_mail, mail_words);
+    stage = 2;
     LCHK("e2s_launch_tail_write");
     TREC(2, 5, h->stream);
     if (p->want_image && image_at >= 2 && (rc = image_now())) return rc;
+    return E2S_OK;
+    };
+    if ((rc = enqueue()) != E2S_OK) {
+        // bail: the peers have enqueued (or will enqueue) both exchanges -- enter them with a zeroed share and let the stream drain; the
+        // zeroed (events, ok) pair tells every peer that a rank of the job is not ok, and they come back with E2S_ERR_CAPACITY
+        const std::string why = h->err;
+        if (W > 1 && !h->err.empty() && h->err.find("exchange callback") == std::string::npos) {
+            if (stage == 0 && hipMemsetAsync(blob, 0, E2S_JOB_BLOB, h->stream) == hipSuccess && allgather(user, blob, recv, E2S_JOB_BLOB, (void*)h->stream) == 0) stage = 1;
+            if (stage == 1 && hipMemsetAsync(blob2, 0, 16, h->stream) == hipSuccess) (void)allgather(user, blob2, recv2, 16, (void*)h->stream);
+        }
+        (void)hipStreamSynchronize(h->stream);
+        if (h->stream3) (void)hipStreamSynchronize(h->stream3);
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipGetLastError();
+        h->scanned = false; h->pf_inflight = false; h->pf_fused = false; h->ko_clean = false; h->img_pending = false; h->img_valid = false;
+        h->err = why;
+        return rc;
+    }
     JobDev* const jdh = (JobDev*)(h->pin_mail + 1536);
     CK(wait_stream(h));                                         // ---- the ONE wait of the step
     CK(hipGetLastError());
@@ -2377,11 +2287,18 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     // ---- the handle's state, as the stepwise calls leave it
     const ScanMail mail = *(const ScanMail*)h->pin_mail;
     const JobDev jd = *jdh;
+    // The verdict "redo through the stepwise calls" is the SAME on every rank: every reason for it is in the rank's device-side ok that
+    // travelled in the second exchange (segment, list, slot, stream or image overflow, plan or seed trouble, a tail error), and a rank
+    // whose own step was fine learns of a peer's trouble from peers_not_ok.  It is evaluated BEFORE the reference's crash cases (which
+    // every rank derives alike from the merged statistics): no rank may return E2S_ERR_REF_CRASH while another one asks for the redo.
     const bool my_ok = jd.my_ok != 0u;
-    bool redo = !my_ok || jd.peers_not_ok || (mail.err & E2S_DEVERR_SEGFULL) || (jd.stat_rc & (E2S_JOBERR_PLAN | E2S_JOBERR_SEEDS));
+    const uint64_t* cm = (const uint64_t*)(h->pin_mail + 3328);
+    const uint64_t count = cm[0], flagged = cm[1];
+    const uint32_t cerr = ((const uint32_t*)(cm + 2))[0] | ((const uint32_t*)(cm + 2))[1];
+    const bool redo = !my_ok || jd.peers_not_ok;
+    if (cm[3] * 8 > h->stream_cap_bytes) h->stream_per_cand = ca.stride;      // (the stepwise calls start with room for the full stride)
     if (mail.err & E2S_DEVERR_SEGFULL) { h->scanned = false; return fail(h, E2S_ERR_CAPACITY, "resident job: a record segment overflowed: run the step through the stepwise calls"); }
     if ((rc = scan_finish(h, mail, p->min_len))) return rc;
-    if (h->wrap_overflow) redo = true;
     // e2s_stitch
     h->plan = jd.plan;
     h->first_wrapped = jd.first_wrapped != 0;
@@ -2390,27 +2307,24 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     if (p->want_image) {
         h->img_records = jd.img_records; h->img_total_known = true; h->img_prestitch = false; h->img_stream = h->stream2;
         h->img_pending = true; h->img_valid = false;
-        if (mail.img_records + jd.n_tail_kept > h->img_cap - 2) { drop_image(h); redo = true; }
+        if (jd.stat_rc & E2S_JOBERR_IMAGE) drop_image(h);
     }
-    // statistics(): the reference's crashes first (every rank sees the same merged statistics)
-    switch (jd.stat_rc & 3u) {
+    if (redo) {
+        // (the stepwise calls size every buffer for what they find; the job fits the next time)
+        h->n_cand = 0; h->variants_valid = false;
+        return fail(h, E2S_ERR_CAPACITY, "resident job: a buffer was too small or the input needs the stepwise path (on some rank of the job): run the step through the stepwise calls");
+    }
+    // statistics(): the reference's crashes (every rank sees the same merged statistics)
+    switch (jd.stat_rc & E2S_JOBERR_CRASH_MASK) {
         case 1: return fail(h, E2S_ERR_REF_CRASH, "no cluster record: the reference divides by zero here");
         case 2: return fail(h, E2S_ERR_REF_CRASH, "no cluster of length <= 150: the reference divides by zero here");
         case 3: return fail(h, E2S_ERR_REF_CRASH, "the automatic -c falls outside the histogram: the reference reads past it here");
         default: break;
     }
     // e2s_find_candidates
-    const uint64_t* cm = (const uint64_t*)(h->pin_mail + 3328);
-    const uint64_t count = cm[0], flagged = cm[1];
-    const uint32_t cerr = ((const uint32_t*)(cm + 2))[0] | ((const uint32_t*)(cm + 2))[1];
     if (cerr & E2S_DEVERR_REMOTE) return fail(h, E2S_ERR_INPUT, "a cluster record reaches outside the resident shard (halo too small or record past EOF)");
-    if ((cerr & E2S_DEVERR_DENSE) || cm[3] * 8 > h->stream_cap_bytes || flagged > h->fl_cap || count > h->cand_cap) redo = true;
-    if (cm[3] * 8 > h->stream_cap_bytes) h->stream_per_cand = ca.stride;
-    if (redo) {
-        // (the stepwise calls size every buffer for what they find; the job fits the next time)
-        h->n_cand = 0; h->variants_valid = false;
-        return fail(h, E2S_ERR_CAPACITY, "resident job: a buffer was too small or the input needs the stepwise path (on some rank of the job): run the step through the stepwise calls");
-    }
+    if (h->wrap_overflow || (cerr & E2S_DEVERR_DENSE) || cm[3] * 8 > h->stream_cap_bytes || flagged > h->fl_cap || count > h->cand_cap)
+        return fail(h, E2S_ERR_HIP, "resident job: the device reported a step as good that overflowed a buffer (internal error)");     // (all of these are in the device-side ok)
     h->n_flagged = flagged; h->stream8_used = cm[3];
     cand_accept(h, ca, count, 3);
     // e2s_call_variants (a shard without candidates has no events; only a JOB without candidates is where the reference crashes)

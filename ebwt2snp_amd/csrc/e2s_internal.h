@@ -77,41 +77,6 @@ struct SegArgs {
     unsigned long long* wrap_list; uint32_t* wrap_count;        // addresses (b*seg_cap + i) of records with true length >= 65536
 };
 
-// ---- the scan that writes the `.clusters` image itself (k_scan_seg<1, FUSED, true>): the work is cut into CHUNKS of a few
-// wave-tiles handed out by a ticket counter; a wave stages the records that END in its chunk in LDS (4 bytes each), learns the
-// start of a cluster that reaches into the chunk from the chunk before (status word A), counts the records append_entry keeps,
-// chains that count with a decoupled look-back (status word B) and writes its piece of the packed 10-byte image -- and its share
-// of the statistics -- itself.  No segments, no pack, no histogram kernel.
-#ifndef E2S_IMG_TILES
-#define E2S_IMG_TILES 8u             // wave-tiles per chunk: offsets inside a chunk (+ the tile before it) fit 16 bits
-#endif
-#ifndef E2S_IMG_COUNTERS
-#define E2S_IMG_COUNTERS 4u          // interleaved ticket counters
-#endif
-#ifndef E2S_IMG_CAP
-#define E2S_IMG_CAP 3072u
-#endif
-//                                      records a chunk may stage (12 KB of LDS per wave): ~0.09 per entry, 2.5 x the usual density
-#define E2S_DEVERR_STALL 16u         // a status word never arrived (should not happen: every wait has an exit)
-struct ImgSlot {                     // per wave, written once when the wave runs out of tickets; reduced by k_scan_img_fin
-    unsigned long long raw_ends;     // clusters that END in the wave's chunks (before the min_len filter)
-    unsigned long long first_end_pos;            // smallest SA position of such an end (~0: none)
-    unsigned long long last_c1;      // 1 + index of the wave's last chunk with an end, and that end's cluster start (~0: began before the shard)
-    unsigned long long last_start;
-    unsigned long long kept_c1;      // 1 + index of its last chunk with a record the statistics count, that record's length, and whether it is the
-    unsigned long long kept_len;     //   shard's provisional record 0
-    unsigned long long kept_is_rec0;
-    unsigned long long reserved;
-};
-struct ImgArgs {
-    uint8_t* img; unsigned long long img_cap;                    // packed 10-byte records; capacity in records
-    unsigned long long* st_a; unsigned long long* st_b;          // per chunk: [valid:1][state:2][start:48] / [flag:2][count:62]; zero before the launch
-    unsigned long long* ticket;                                  // E2S_IMG_COUNTERS counters, 64 bytes apart; zero before the launch
-    uint32_t n_chunks; uint32_t n_waves;
-    ImgSlot* slots;                                              // [n_waves]
-    uint32_t* err;
-};
-
 // everything the host needs after a scan, gathered by k_scan_mail so that ONE small download suffices
 struct ScanMail {
     uint64_t total_ends, first_end_pos, open_start, last_end_start;
@@ -119,7 +84,7 @@ struct ScanMail {
     uint32_t begins_inside, open_after, end_before_last, err;
     uint32_t wrap_count, first_len_prov, tail_lcp, tail_prev_lcp;
     uint32_t last_text, last_suff, last_lcp, last_bwt;      // the last provided entry (EOF phantom model)
-    uint64_t img_records;                                    // records in the image the scan wrote itself (ImgArgs), the provisional record 0 included
+    uint64_t img_records;                                    // records the `.clusters` image will hold (what append_entry keeps), the provisional record 0 included
 };
 
 struct CandHeader {           // == e2s_cand_header
@@ -219,6 +184,8 @@ struct TailArgs {
 #define E2S_JOB_MAX_PIECES 8
 #define E2S_JOBERR_PLAN 16u                 // stat_rc: the gathered descriptors do not fit together
 #define E2S_JOBERR_SEEDS 32u                //          more wrapped clusters than seed slots
+#define E2S_JOBERR_IMAGE 64u                //          the `.clusters` image is too small for this rank's records
+#define E2S_JOBERR_CRASH_MASK 3u            // stat_rc's low bits: where the reference's statistics() crashes (the same on every rank: not a reason to redo)
 struct JobDev {                             // device copy at d_mail + 1536; reaches the host with the mail
     e2s_stitch_plan_t plan;                 // this rank's
     int32_t mcl; uint32_t stat_rc;          // max_clust_length; e2s_auto_len_core's code | E2S_JOBERR_*
@@ -271,10 +238,6 @@ void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_
 void e2s_launch_seg_fix(const SegArgs& a, uint32_t* flags, uint32_t* tailv, unsigned long long* seg_off, unsigned long long* kept_off, uint32_t* err,
                         const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out,
                         uint8_t* blob, int is_last_rank, int tail_bwt_arg, hipStream_t st);
-int  e2s_scan_img_resident_waves(bool fused);
-void e2s_launch_scan_img(const SegArgs& a, const FilterArgs* f, const ImgArgs& g, hipStream_t st);
-void e2s_launch_scan_img_fin(const SegArgs& a, const ImgArgs& g, uint32_t* flags, uint32_t* tailv, uint32_t* err, const uint8_t* bwt, const void* pos,
-                             const void* da, int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out, hipStream_t st);
 struct JobPlanArgs {
     const uint8_t* blobs; int world, rank; uint64_t n_total; int k, lcp_bytes, mcov; double pval; int min_len, len_lo;
     const ScanMail* mail; SegArgs seg; uint32_t row_entries;
@@ -284,6 +247,7 @@ struct JobPlanArgs {
     unsigned long long* zero8;                                   // 8 words cleared here (nullptr: none)
     // the per-cluster pass in pieces: bounds[c] = fl_count * c / n_pieces (list entries), snap[0] = 0 (candidate slots), done[c] = 0
     const unsigned long long* fl_count; uint32_t n_pieces; unsigned long long* piece_bounds; unsigned long long* piece_snap; uint32_t* piece_done;
+    unsigned long long img_cap;                                  // records the `.clusters` image has room for (~0: no image wanted)
 };
 void e2s_launch_job_plan(const JobPlanArgs& a, hipStream_t st);
 void e2s_launch_img_patch_dev(uint8_t* img, unsigned long long cap, const JobDev* jd, const ScanMail* mail, int min_len, hipStream_t st);

@@ -1,10 +1,10 @@
 // e2s_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ebwt2snp hot path.
 //
-//   K1  k_scan_seg<X,FUSED,IMG>  cluster-boundary scan over the LCP array (cluster_lm + append_entry, ebwt2clust.cpp:54-139); FUSED: with
-//                                clust2snp's pre-filter in the same pass; IMG: chunks handed out by tickets, the packed `.clusters` image and the
-//                                statistics written by the scan itself (decoupled look-back over per-chunk status words)
-//       k_scan_img_fin / k_seg_fix   one block after the scan: the shard's descriptor (ScanMail) and statistics for the host
-//       k_pack_seg_* / k_hist_seg    image and statistics from per-worker segments (the scan without IMG: wide LCP columns, dense inputs)
+//   K1  k_scan_seg<X,FUSED>      cluster-boundary scan over the LCP array (cluster_lm + append_entry, ebwt2clust.cpp:54-139); FUSED: with
+//                                clust2snp's pre-filter in the same pass.  Every wave a worker over a contiguous range of 4-KiB tiles, records
+//                                into per-worker segments
+//       k_seg_fix                  one block after the scan: the shard's descriptor (ScanMail), the segments' offsets and the statistics
+//       k_pack_seg_write           the `.clusters` image from the segments
 //   K2a k_cluster_filter2 / k_record_prefilter   the pre-filter as a kernel of its own     (find_events, clust2snp.cpp:788-857)
 //   K2b k_flagged_lists<DEF>     exact per-cluster test, lists, packed candidates          (find_variants, clust2snp.cpp:367-500)
 //   KO  k_ko_*                   SA order of the candidates
@@ -131,45 +131,15 @@ __device__ __forceinline__ u32 pf_merge(u32 x, u32 y) { return (((x & 0xFFFFFFu)
 // documents the method) runs inside the scan on the same GE / NLE / start / end planes -- the LCP is read once, the
 // stencil evaluated once; the worker additionally reads the BWT, and before its range it looks at the 192 entries in front of
 // it (start_carry below) for the pre-filter's view of a cluster that reaches into the range.  f is unused otherwise.
-// IMG (X == 1): the ranges are CHUNKS of E2S_IMG_TILES tiles handed out by a ticket counter (a wave that holds ticket c knows that
-// the chunks before c are held by waves that run: every wait below ends), and a chunk's records never reach a segment -- they are
-// staged in LDS (4 bytes each: 1 + offset of the start | offset of the end << 16, counted from the chunk's origin) and leave as the
-// chunk's piece of the packed 10-byte `.clusters` image, append_entry's length filter (ebwt2clust.cpp:54-63) applied:
-//   status word A[c] = [valid][closed | open with start | inside one cluster throughout][start]   -- published after the chunk's tiles;
-//                      the chunk after it finishes its record 0 (a cluster that began earlier) from it, walking back over "throughout"s
-//   status word B[c] = [aggregate | inclusive][records kept]   -- decoupled look-back: the chunk's offset in the image
-// The statistics of the kept records (statistics(), clust2snp.cpp:889-909) are counted on the way: per-block LDS histogram
-// replicas, flushed once.  A shard that begins inside a cluster keeps slot 0 of the image for that record whatever its
-// provisional length says (e2s_stitch knows the true one).
-#ifndef E2S_IMG_ABL
-#define E2S_IMG_ABL 0
-#endif
-constexpr u64 IMG_A_VALID = 1ull << 63, IMG_A_OPEN = 1ull << 61, IMG_A_PASS = 2ull << 61, IMG_POS_MASK = (1ull << 48) - 1ull;
-constexpr u64 IMG_B_AGG = 1ull << 62, IMG_B_INCL = 2ull << 62, IMG_CNT_MASK = (1ull << 62) - 1ull;
-constexpr u32 IMG_SPIN_LIMIT = 1u << 24;                   // (a status word arrives within microseconds; ~10 s of polling means a bug, not a wait)
 typedef u64 __attribute__((aligned(2))) u64_a2;           // a record's start field: 2-byte aligned in the packed image (one global_store_dwordx2)
-__device__ __forceinline__ u64 img_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void img_store(unsigned long long* p, u64 v) { __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 wave_first64(u64 v) {
     return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
 }
-// one status word, polled by lane 0 until `ready(v)`; the same value in every lane.  Gives up (error bit) after IMG_SPIN_LIMIT polls.
-template <typename Ready>
-__device__ __forceinline__ u64 img_wait(const unsigned long long* p, u32 lane, u32* err, Ready ready) {
-    u64 v = 0;
-    for (u32 spin = 0;; ++spin) {
-        if (lane == 0) v = img_load(p);
-        v = wave_first64(v);
-        if (ready(v)) return v;
-        if (spin >= IMG_SPIN_LIMIT) { if (lane == 0) atomicOr(err, E2S_DEVERR_STALL); return v; }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-template <int X, bool FUSED, bool IMG = false>
-__global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f, ImgArgs g) {
+// (The scan that wrote the packed image itself -- tickets, per-chunk status words, a decoupled look-back -- was built and measured in round 3 and
+//  lost by 2x to segments + one layout kernel (profiles/round3_scan_image_variant.txt); it lives in the history: commit b90733f.)
+template <int X, bool FUSED>
+__global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f) {
     static_assert(!FUSED || (X == 1 && SPAN_WORDS == 16), "the fused pre-filter works on 1-byte LCPs, 64 entries per lane");
-    static_assert(!IMG || (X == 1 && SPAN_WORDS == 16 && (E2S_IMG_TILES + 1u) * 4096u <= 65535u), "IMG: offsets inside a chunk are 16 bits");
     constexpr int NR = SPAN_WORDS;
     constexpr int ES = 4 * NR / X;                           // entries per thread span
     constexpr int TILE = 64 * ES;                            // entries per wave-tile
@@ -178,40 +148,21 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
     const u32 lane = threadIdx.x & 63u;
     const u32 wslot = threadIdx.x >> 6;
-    // IMG: a chunk's records, the block's histogram replicas (4 per wave: lengths concentrate on a few values), two 64-bit sums
-    __shared__ u32 s_cbuf[IMG ? 4 : 1][IMG ? E2S_IMG_CAP + 2u : 1u];
+    // the block's histogram replicas (4 per wave: lengths concentrate on a few values), two 64-bit sums
     __shared__ u32 s_hist[16][E2S_MAX_CLUST_LEN_K + 2];
     __shared__ u64 s_acc[2];
-    u32* const cbuf = s_cbuf[IMG ? wslot : 0];
     for (u32 i = threadIdx.x; i < 16u * (E2S_MAX_CLUST_LEN_K + 2); i += 256u) (&s_hist[0][0])[i] = 0u;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0ull;
     __syncthreads();
-    // IMG: what the wave reports once (ImgSlot) and its lanes' share of the statistics
-    u64 w_raw = 0, w_first_end = ~0ull, w_last_c1 = 0, w_last_start = ~0ull, w_kept_c1 = 0, w_kept_len = 0, w_kept_rec0 = 0;
-    u64 l_nrec = 0, l_nb = 0;
+    u64 l_nrec = 0, l_nb = 0;                                   // the lanes' share of the statistics
     u32 qn = 0;                                                 // (FUSED) flagged clusters queued in LDS: wave state, kept from range to range
     __shared__ u64 s_q[FUSED ? 4 : 1][FUSED ? F2_Q : 1];
     u64* const q = s_q[FUSED ? wslot : 0];
-    // IMG: ONE chunk per ticket.  (Two consecutive chunks per ticket -- half the atomics -- chain the waves into a line: the first chunk
-    // of ticket t waits for the second chunk of ticket t - 1, which its wave only starts after the first: 49 ms instead of 0.06 on c2.)
-    // The counters are E2S_IMG_COUNTERS interleaved ones (chunk = counter + COUNTERS * value; a wave draws from counter wave % COUNTERS),
-    // so that no single word takes one atomic per chunk of the whole chip.  Every wait still ends: the smallest chunk nobody holds yet
-    // belongs to a counter whose waves hold only smaller chunks, and those never wait for anything that is not held.
-    const u32 my_counter = (blockIdx.x * 4u + wslot) % E2S_IMG_COUNTERS;
-    for (;;) {
-    u32 b; u64 t0, t1;                                          // (one trip without IMG)
-    if constexpr (IMG) {
-        u32 tk = 0;
-        if (lane == 0) tk = (u32)atomicAdd(g.ticket + 8u * my_counter, 1ull);    // (the counters lie 64 bytes apart)
-        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)tk) * E2S_IMG_COUNTERS + my_counter;
-        if (c >= g.n_chunks) break;
-        b = c; t0 = (u64)c * E2S_IMG_TILES; t1 = min(t0 + (u64)E2S_IMG_TILES, a.n_tiles);
-    } else {
-        b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // worker (= segment) index
-        if (b >= a.n_blocks) break;                             // (every wave of the block meets at the barrier below)
-        t0 = (u64)b * a.tiles_per_block + min(b, a.tiles_rem);
-        t1 = min(t0 + (u64)a.tiles_per_block + (b < a.tiles_rem ? 1u : 0u), a.n_tiles);
-    }
+    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // worker (= segment) index
+    const bool working = b < a.n_blocks;                        // (every wave of the block meets at the barrier below)
+    if (working) {
+    const u64 t0 = (u64)b * a.tiles_per_block + min(b, a.tiles_rem);
+    const u64 t1 = min(t0 + (u64)a.tiles_per_block + (b < a.tiles_rem ? 1u : 0u), a.n_tiles);
     const uint8_t* base = (const uint8_t*)a.lcp;
     const int64_t n_prov = (int64_t)a.n_prov;
     const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
@@ -292,8 +243,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // records of a tile are staged in LDS by the lanes that own their ENDs and written out in rank order, 64 per
     // store: a sparse store per record costs ~55 SIMD cycles on this chip whatever the number of active lanes (the
     // per-record stores were 16 of the kernel's 68 us)
-    __shared__ uint64_t s_stage[IMG ? 1 : 4][IMG ? 1 : SEG_STAGE + 1];   // (+1: the start of a cluster still open at the tile's end)
-    uint64_t* const st_rec = s_stage[IMG ? 0 : (threadIdx.x >> 6)];
+    __shared__ uint64_t s_stage[4][SEG_STAGE + 1];              // (+1: the start of a cluster still open at the tile's end)
+    uint64_t* const st_rec = s_stage[threadIdx.x >> 6];
     // pre-filter state (FUSED): see k_cluster_filter2
     u32 pf_open1 = 0, cin0 = 0, ccarry = 0;
     auto queue_flush = [&]() {
@@ -463,33 +414,12 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         {
             const u32 rk0 = run + inc - cnt;
             const u32 tile_end1 = (u32)((tile - torg + 1) * TILE);
-            const bool plain = IMG ? (run + tile_total <= E2S_IMG_CAP && !masked)
-                                   : (run + tile_total <= a.seg_cap && tile_end1 + 2u - open1 < 65536u && tile_total <= (u32)SEG_STAGE && !masked);
+            const bool plain = run + tile_total <= a.seg_cap && tile_end1 + 2u - open1 < 65536u && tile_total <= (u32)SEG_STAGE && !masked;
 #ifdef E2S_ABL_NOEMIT                                           // diagnostic build: time the kernel without the emit loops
             asm volatile("" :: "v"(rk0));
             if (rk0 == 0xFFFFFFFFu)
 #endif
-            if (IMG && plain) {
-                // the same walk into the CHUNK's buffer: 16-bit halves of slot run + rank (offsets inside a chunk fit 16 bits); nothing
-                // leaves before the chunk's offset in the image is known
-                uint16_t* const st16 = (uint16_t*)(cbuf + run);
-                if (lane == 0) st16[0] = (uint16_t)open1;
-                {
-                    uint16_t* pe = st16 + 2u * (inc - cnt) + 1u;
-                    u32 h = (u32)E;
-                    while (h) { *pe = (uint16_t)(base_off + (u32)__builtin_ctz(h)); h &= h - 1u; pe += 2; }
-                    h = (u32)(E >> 32);
-                    while (h) { *pe = (uint16_t)(base_off + 32u + (u32)__builtin_ctz(h)); h &= h - 1u; pe += 2; }
-                }
-                {
-                    const u64 below = (S & (0ull - S)) - 1ull;
-                    uint16_t* ps = st16 + 2u * (inc - cnt + ((E & below) != 0ull ? 1u : 0u));
-                    u32 h = (u32)S;
-                    while (h) { *ps = (uint16_t)(base_off + 1u + (u32)__builtin_ctz(h)); h &= h - 1u; ps += 2; }
-                    h = (u32)(S >> 32);
-                    while (h) { *ps = (uint16_t)(base_off + 33u + (u32)__builtin_ctz(h)); h &= h - 1u; ps += 2; }
-                }
-            } else if (plain) {
+            if (plain) {
                 u32* const st32 = (u32*)st_rec;
                 if (lane == 0) st32[0] = open1;
                 {
@@ -549,9 +479,6 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                         Eh &= ~upto;
                         const u32 off = hbase + e;
                         const u32 st1 = sc ? hbase + (32u - (u32)__builtin_clz(sc)) : cur1;      // 1 + offset of the start
-                        if constexpr (IMG) {
-                            if (rk < E2S_IMG_CAP) cbuf[rk] = st1 | (off << 16);                  // (st1 == 0: began before the chunk)
-                        } else
                         if (rk < a.seg_cap) {
                             if (st1 != 0u) {
                                 const u32 len = off + 2u - st1;
@@ -643,9 +570,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         }
         if (!have_cb) start_carry();
         slow_run(t1);
-        if constexpr (FUSED && !IMG) queue_flush();
+        if constexpr (FUSED) queue_flush();
     }
-    if constexpr (!IMG) {
     // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
     const u64 unk_m = __ballot(unknown != 0);
     const u64 fe_m = __ballot(first_end != ~0ull);
@@ -667,158 +593,6 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         d.kept = kept_w; d.last_kept1 = lk1_w; d.last_kept_len = lk_len_w; d.first_start = ~0ull;
         a.desc[b] = d;
     }
-    break;
-    } else {
-    // ---- IMG: the chunk's records leave as its piece of the image --------------------------------------------------------------
-    const u32 c = b;
-    {   // status word A: what the chunk after this one inherits
-        u64 wa = IMG_A_VALID;
-        if (state == 2u) wa |= IMG_A_OPEN | ((g_range + (u64)(open1 - 1u)) & IMG_POS_MASK);
-        else if (state == 0u && t0 < t1 && in0) wa |= IMG_A_PASS;
-        if (lane == 0) img_store(&g.st_a[c], wa);
-    }
-    if (run > E2S_IMG_CAP && lane == 0) atomicOr(g.err, E2S_DEVERR_SEGFULL);      // denser than the staging buffer: the host takes the segment path
-    const u32 m = min(run, E2S_IMG_CAP);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // record 0 of a chunk that begins inside a cluster: the start comes from the nearest chunk before it that is not inside one
-    // cluster throughout; none in this shard = the shard's provisional record 0 (e2s_stitch finishes it)
-    const u32 v0 = m ? cbuf[0] : 0u;
-    const bool unk0 = m != 0u && (v0 & 0xFFFFu) == 0u;
-    u64 r0_start = 0; u32 r0_len = 0; bool r0_shard = false;
-    if (unk0) {
-        const u64 e0 = g_range + (u64)(v0 >> 16);
-        u64 st = ~0ull;
-#if (E2S_IMG_ABL & 4)
-        st = g_range;
-        for (int64_t q = -1; q >= 0; --q) {
-#else
-        for (int64_t q = (int64_t)c - 1; q >= 0; --q) {
-#endif
-            const u64 v = img_wait(&g.st_a[q], lane, g.err, [](u64 x) { return (x & IMG_A_VALID) != 0ull; });
-            if ((v & (3ull << 61)) == IMG_A_PASS) continue;
-            if ((v & (3ull << 61)) == IMG_A_OPEN) st = v & IMG_POS_MASK;
-            break;
-        }
-        if (st == ~0ull) { r0_shard = true; r0_len = (u32)((e0 + 1ull) & 0xFFFFull); }
-        else {
-            const u64 true_len = e0 - st + 1ull;
-            r0_start = st; r0_len = (u32)(true_len & 0xFFFFull);
-            if (true_len >= 65536ull && lane == 0) {            // the reference's uint16_t length wraps (ebwt2clust.cpp:104): listed for the per-cluster pass
-                const u32 i = atomicAdd(a.wrap_count, 1u);
-                if (i < E2S_WRAP_CAP) { a.wrap_list[2u * i] = st; a.wrap_list[2u * i + 1u] = r0_len; }
-            }
-        }
-    }
-    // what append_entry keeps (and statistics() counts); the last such record of the chunk
-    u32 kept = 0, lk_at = ~0u, lk_len = 0;
-    auto rec_len = [&](u32 r, u32 v) -> u32 { return (r == 0u && unk0) ? r0_len : (((v >> 16) + 2u - (v & 0xFFFFu)) & 0xFFFFu); };
-    for (u32 q0 = 0; q0 < m; q0 += 64u) {
-        const u32 r = q0 + lane;
-        const bool valid = r < m;
-        const u32 v = valid ? cbuf[r] : 0u;
-        const u32 len = rec_len(r, v);
-        const bool sk = valid && (int)len >= a.min_len;
-        const bool ik = sk || (valid && r == 0u && r0_shard);
-#if (E2S_IMG_ABL & 8)
-        if (sk) { ++l_nrec; l_nb += (u64)len; }
-#else
-        if (sk) { ++l_nrec; l_nb += (u64)len; if (len <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&hrow[len], 1u); }
-#endif
-        kept += (u32)__popcll(__ballot(ik));
-        const u64 skm = __ballot(sk);
-        if (skm) { const int top = 63 - __clzll(skm); lk_at = q0 + (u32)top; lk_len = (u32)__builtin_amdgcn_readlane((int)len, top); }
-    }
-    // the chunk's offset in the image: decoupled look-back over the status words B
-    if (lane == 0) img_store(&g.st_b[c], IMG_B_AGG | (u64)kept);
-    u64 P = 0;
-#if (E2S_IMG_ABL & 2)
-    P = (u64)c * 100ull;
-    for (int64_t q = -1; q >= 0;) {
-#else
-    for (int64_t q = (int64_t)c - 1; q >= 0;) {
-#endif
-        const int64_t qi = q - (int64_t)lane;                       // lane 0 looks at the nearest chunk
-        u64 v = IMG_B_INCL;                                         // (before the first chunk: nothing)
-        bool done = false;
-        for (u32 spin = 0;; ++spin) {
-            if (qi >= 0) v = img_load(&g.st_b[qi]);
-            const u64 ready = __ballot((v >> 62) != 0ull), incl = __ballot((v >> 62) == 2ull);
-            const int unready1 = ~ready ? __ffsll((long long)~ready) - 1 : 64, incl1 = incl ? __ffsll((long long)incl) - 1 : 64;
-            if (incl1 < unready1 || unready1 == 64) {               // every word up to the nearest inclusive one (or all 64) has arrived
-                const u32 upto = incl1 < 64 ? (u32)incl1 : 63u;
-                u64 x = lane <= upto ? (v & IMG_CNT_MASK) : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor((unsigned long long)x, o);
-                P += x;
-                done = incl1 < 64;
-                break;
-            }
-            if (spin >= IMG_SPIN_LIMIT) { if (lane == 0) atomicOr(g.err, E2S_DEVERR_STALL); done = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (done) break;
-        q -= 64;
-    }
-    if (lane == 0) img_store(&g.st_b[c], IMG_B_INCL | ((P + (u64)kept) & IMG_CNT_MASK));
-    // the piece itself: kept records in order, 10 bytes each (one 8-byte and one 2-byte store per record)
-    {
-        u64 at = P;
-        for (u32 q0 = 0; q0 < m; q0 += 64u) {
-            const u32 r = q0 + lane;
-            const bool valid = r < m;
-            const u32 v = valid ? cbuf[r] : 0u;
-            const u32 len = rec_len(r, v);
-            const bool ik = valid && ((int)len >= a.min_len || (r == 0u && r0_shard));
-            const u64 km = __ballot(ik);
-            if (ik) {
-                const u64 idx = at + (u64)__popcll(km & ((1ull << lane) - 1ull));
-                const u64 stv = (r == 0u && unk0) ? r0_start : g_range + (u64)((v & 0xFFFFu) - 1u);
-#if !(E2S_IMG_ABL & 1)                                        // (diagnostic builds, bits: 1 no image stores, 2 no look-back, 4 no wait for A, 8 no histogram)
-                if (idx < g.img_cap) {
-                    uint8_t* o = g.img + idx * 10ull;
-                    *(u64_a2*)o = stv;
-                    *(uint16_t*)(o + 8) = (uint16_t)len;
-                } else atomicOr(g.err, E2S_DEVERR_SEGFULL);
-#else
-                if (idx == 0x123456789ull) g.img[0] = (uint8_t)stv;
-#endif
-            }
-            at += (u64)__popcll(km);
-        }
-    }
-    // the wave's report
-    w_raw += (u64)run;
-    if (m) {
-        w_first_end = min(w_first_end, g_range + (u64)(v0 >> 16));
-        const u32 vl = cbuf[m - 1u];
-        w_last_c1 = (u64)c + 1ull;
-        w_last_start = (m == 1u && unk0) ? (r0_shard ? ~0ull : r0_start) : g_range + (u64)((vl & 0xFFFFu) - 1u);
-    }
-    if (lk_at != ~0u) { w_kept_c1 = (u64)c + 1ull; w_kept_len = lk_len; w_kept_rec0 = (lk_at == 0u && r0_shard) ? 1ull : 0ull; }
-    __builtin_amdgcn_wave_barrier();                                // (the buffer is reused by the next chunk)
-    }
-    }
-    if constexpr (IMG) {
-        if constexpr (FUSED) {
-            if (qn) {                                               // (the queue outlives the chunks: the last flush)
-                u64 gbase = 0;
-                if (lane == 0) gbase = atomicAdd(f.fl_count, (unsigned long long)qn);
-                gbase = __shfl(gbase, 0);
-                if (lane < qn) {
-                    const u64 v = q[lane];
-                    if (gbase + lane < f.fl_cap) { f.fl_starts[gbase + lane] = v & 0xFFFFFFFFFFFFull; f.fl_lens[gbase + lane] = (uint16_t)(v >> 48); }
-                }
-            }
-        }
-        // the wave's report
-        const u32 w = blockIdx.x * 4u + wslot;
-        if (lane == 0 && w < g.n_waves) {
-            ImgSlot sl;
-            sl.raw_ends = w_raw; sl.first_end_pos = w_first_end; sl.last_c1 = w_last_c1; sl.last_start = w_last_start;
-            sl.kept_c1 = w_kept_c1; sl.kept_len = w_kept_len; sl.kept_is_rec0 = w_kept_rec0; sl.reserved = 0;
-            g.slots[w] = sl;
-        }
     }
     // the block's share of the statistics: one flush of the histogram replicas and the two sums
 #pragma unroll
@@ -1259,6 +1033,7 @@ __global__ __launch_bounds__(256) void k_job_plan(JobPlanArgs a) {
         seed(st, a.seg.lens[r]);
     }
     if (ns > 64u || m.wrap_count > (u32)E2S_WRAP_CAP) rc |= E2S_JOBERR_SEEDS;
+    if (m.img_records + (u64)nt > a.img_cap) rc |= E2S_JOBERR_IMAGE;    // (the layout kernel clips silently: the verdict must travel with the rank's ok)
     jd.stat_rc = rc;
     *a.out = jd;
 }
@@ -1280,80 +1055,6 @@ void e2s_launch_img_patch_dev(uint8_t* img, unsigned long long cap, const JobDev
     hipLaunchKernelGGL(k_img_patch_dev, dim3(1), dim3(64), 0, st, img, (u64)cap, jd, mail, min_len);
 }
 
-// The same for the scan that wrote the image itself (ImgArgs): the waves' reports are reduced, the status words give the image's
-// size and the cluster still open at the shard's end; the statistics leave in k_hist_seg's layout.
-__global__ __launch_bounds__(1024) void k_scan_img_fin(SegArgs a, ImgArgs g, u32* flags, u32* tailv, u32* err, const uint8_t* bwt, const void* pos, const void* da,
-                                                       int xb, int yb, int zb, ScanMail* out, u64* stats_out) {
-    __shared__ u64 s_raw, s_first, s_last_c1, s_kept_c1, s_last_start, s_kept_len, s_kept_rec0;
-    __shared__ u32 s_flags[4], s_tailv[2];
-    const u64 NONE = ~0ull;
-    const u32 tid = threadIdx.x;
-    if (tid == 0) { s_raw = 0; s_first = NONE; s_last_c1 = 0; s_kept_c1 = 0; s_last_start = NONE; s_kept_len = 0; s_kept_rec0 = 0; }
-    if (tid == 1023) shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, (u32)xb, s_flags, s_tailv);
-    __syncthreads();
-    u64 raw = 0, first = NONE, last_c1 = 0, kept_c1 = 0;
-    for (u32 w = tid; w < g.n_waves; w += 1024u) {
-        const ImgSlot sl = g.slots[w];
-        raw += sl.raw_ends; first = min(first, (u64)sl.first_end_pos); last_c1 = max(last_c1, (u64)sl.last_c1); kept_c1 = max(kept_c1, (u64)sl.kept_c1);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        raw += __shfl_xor((unsigned long long)raw, o); first = min(first, (u64)__shfl_xor((unsigned long long)first, o));
-        last_c1 = max(last_c1, (u64)__shfl_xor((unsigned long long)last_c1, o)); kept_c1 = max(kept_c1, (u64)__shfl_xor((unsigned long long)kept_c1, o));
-    }
-    if ((tid & 63u) == 0) {
-        if (raw) atomicAdd((unsigned long long*)&s_raw, (unsigned long long)raw);
-        atomicMin((unsigned long long*)&s_first, (unsigned long long)first);
-        atomicMax((unsigned long long*)&s_last_c1, (unsigned long long)last_c1); atomicMax((unsigned long long*)&s_kept_c1, (unsigned long long)kept_c1);
-    }
-    __syncthreads();
-    // a chunk belongs to one wave: the slot that names the last chunk carries its values
-    for (u32 w = tid; w < g.n_waves; w += 1024u) {
-        const ImgSlot sl = g.slots[w];
-        if (s_last_c1 && sl.last_c1 == s_last_c1) s_last_start = sl.last_start;
-        if (s_kept_c1 && sl.kept_c1 == s_kept_c1) { s_kept_len = sl.kept_len; s_kept_rec0 = sl.kept_is_rec0; }
-    }
-    for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 3); i += 1024u) stats_out[i] = a.stats[i];
-    __syncthreads();
-    if (tid == 0) {
-        ScanMail m;
-        const u64 li = a.n_prov - 1;
-        const u64 total = s_raw;
-        const u64 wb = g.n_chunks ? img_load(&g.st_b[g.n_chunks - 1u]) : IMG_B_INCL;
-        const u32 v_text = da ? (yb == 1 ? (u32)((const uint8_t*)da)[li] : yb == 2 ? (u32)((const uint16_t*)da)[li] : ((const u32*)da)[li]) : 0u;
-        const u32 v_suff = pos ? (zb == 1 ? (u32)((const uint8_t*)pos)[li] : zb == 2 ? (u32)((const uint16_t*)pos)[li] : ((const u32*)pos)[li]) : 0u;
-        const u32 v_lcp = xb == 1 ? (u32)((const uint8_t*)a.lcp)[li] : xb == 2 ? (u32)((const uint16_t*)a.lcp)[li] : ((const u32*)a.lcp)[li];
-        const u32 v_bwt = bwt ? (u32)bwt[li] : 0u;
-        const u32 v_wrap = *a.wrap_count, v_err = *err;
-        const u32 f0 = s_flags[E2S_FLAG_BEGINS_INSIDE], f1 = s_flags[E2S_FLAG_OPEN_AFTER], f2 = s_flags[E2S_FLAG_END_BEFORE_LAST];
-        flags[E2S_FLAG_BEGINS_INSIDE] = f0; flags[E2S_FLAG_OPEN_AFTER] = f1; flags[E2S_FLAG_END_BEFORE_LAST] = f2;
-        tailv[0] = s_tailv[0]; tailv[1] = s_tailv[1];
-        // the cluster open after the last chunk: the nearest status word A that is not "inside one cluster throughout"
-        u64 carry = NONE;
-        for (int64_t q = (int64_t)g.n_chunks - 1; q >= 0; --q) {
-            const u64 v = img_load(&g.st_a[q]);
-            if ((v & (3ull << 61)) == IMG_A_PASS) continue;
-            if ((v & (3ull << 61)) == IMG_A_OPEN) carry = v & IMG_POS_MASK;
-            break;
-        }
-        m.total_ends = total;
-        m.first_end_pos = total ? s_first : NONE;
-        m.first_rec_addr = total ? 0ull : NONE; m.last_rec_addr = NONE;
-        m.begins_inside = f0; m.open_after = f1; m.end_before_last = f2;
-        m.err = v_err | ((wb >> 62) == 2ull ? 0u : E2S_DEVERR_STALL);
-        m.wrap_count = v_wrap;
-        m.tail_lcp = s_tailv[0]; m.tail_prev_lcp = s_tailv[1];
-        m.open_start = (f1 && carry != NONE) ? carry : NONE;
-        m.last_end_start = total ? s_last_start : NONE;
-        m.first_len_prov = total ? (u32)((s_first + 1ull) & 0xFFFFull) : 0u;
-        m.last_text = v_text; m.last_suff = v_suff; m.last_lcp = v_lcp; m.last_bwt = v_bwt;
-        m.img_records = wb & IMG_CNT_MASK;
-        *out = m;
-        // the last record the statistics count (the reference counts it twice, H4), and whether it is the provisional record 0
-        stats_out[E2S_MAX_CLUST_LEN_K + 3] = s_kept_c1 ? s_kept_len : 0ull;
-        stats_out[E2S_MAX_CLUST_LEN_K + 4] = s_kept_c1 ? (s_kept_rec0 ? 0ull : 1ull) : NONE;
-    }
-}
 // e2s_stitch on the image: record 0 of a shard that began inside a cluster, the records the EOF rule adds behind the last one
 __global__ void k_img_patch(uint8_t* img, u32 patch_first, u64 first_start, uint16_t first_len, u64 n_at, u32 n_tail, u64 t0, uint16_t l0, u64 t1, uint16_t l1) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -2280,28 +1981,15 @@ int e2s_scan_seg_fused_resident_blocks() { return 4 * resident_blocks((const voi
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
     const dim3 grid((a.n_blocks + 3) / 4), blk(256);           // four independent workers (waves) per block
     const FilterArgs f{};
-    const ImgArgs g{};
-    if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1, false>), grid, blk, 0, st, a, f, g);
-    else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2, false>), grid, blk, 0, st, a, f, g);
-    else hipLaunchKernelGGL((k_scan_seg<4, false>), grid, blk, 0, st, a, f, g);
+    if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1, false>), grid, blk, 0, st, a, f);
+    else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2, false>), grid, blk, 0, st, a, f);
+    else hipLaunchKernelGGL((k_scan_seg<4, false>), grid, blk, 0, st, a, f);
 }
 // the scan with the per-cluster pass's pre-filter inside (1-byte LCPs, 16-byte aligned LCP and BWT)
 void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_t st) {
-    hipLaunchKernelGGL((k_scan_seg<1, true>), dim3((a.n_blocks + 3) / 4), dim3(256), 0, st, a, f, ImgArgs{});
+    hipLaunchKernelGGL((k_scan_seg<1, true>), dim3((a.n_blocks + 3) / 4), dim3(256), 0, st, a, f);
 }
 // the scan that writes the image itself: g.n_waves waves (a whole number of blocks) taking tickets
-int e2s_scan_img_resident_waves(bool fused) {
-    return 4 * resident_blocks(fused ? (const void*)k_scan_seg<1, true, true> : (const void*)k_scan_seg<1, false, true>, 256, 0);
-}
-void e2s_launch_scan_img(const SegArgs& a, const FilterArgs* f, const ImgArgs& g, hipStream_t st) {
-    const dim3 grid((g.n_waves + 3) / 4), blk(256);
-    if (f) hipLaunchKernelGGL((k_scan_seg<1, true, true>), grid, blk, 0, st, a, *f, g);
-    else hipLaunchKernelGGL((k_scan_seg<1, false, true>), grid, blk, 0, st, a, FilterArgs{}, g);
-}
-void e2s_launch_scan_img_fin(const SegArgs& a, const ImgArgs& g, u32* flags, u32* tailv, u32* err, const uint8_t* bwt, const void* pos, const void* da,
-                             int xb, int yb, int zb, ScanMail* out, unsigned long long* stats_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_img_fin, dim3(1), dim3(1024), 0, st, a, g, flags, tailv, err, bwt, pos, da, xb, yb, zb, out, (u64*)stats_out);
-}
 void e2s_launch_seg_fix(const SegArgs& a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err, const uint8_t* bwt, const void* pos,
                         const void* da, int xb, int yb, int zb, ScanMail* out, u64* stats_out, uint8_t* blob, int is_last_rank, int tail_bwt_arg, hipStream_t st) {
     hipLaunchKernelGGL(k_seg_fix, dim3(1), dim3(1024), 0, st, a, flags, tailv, seg_off, kept_off, err, bwt, pos, da, xb, yb, zb, out, stats_out, blob, is_last_rank,

@@ -454,7 +454,9 @@ __global__ __launch_bounds__(1024) void k_tail_partials(const unsigned long long
             totals[3] = (u64)*err;
             if (jd) {
                 jd->events = re; jd->snp_bytes = totals[1]; jd->n_keep = k; jd->tail_err = *err; jd->first_id = first_id; jd->events_before = 0; jd->peers_not_ok = 0;
-                const u32 ok = (*err == 0u && *bad_a == 0u && *bad_b == 0u && *bad_c == 0u) ? 1u : 0u;
+                // (bad_b is the plan's stat_rc: its low bits say where the reference's statistics() crashes -- every rank sees the same
+                //  merged statistics, so that is a result, not a reason for the ranks to redo the step)
+                const u32 ok = (*err == 0u && *bad_a == 0u && (*bad_b & ~E2S_JOBERR_CRASH_MASK) == 0u && *bad_c == 0u) ? 1u : 0u;
                 jd->my_ok = ok;
                 if (blob2) { blob2[0] = re; blob2[1] = (u64)ok; }
             }

@@ -279,8 +279,11 @@ extern "C" int e2s_ebwt2clust_chunked(const e2s_chunk_params* p, const e2s_egsa_
 // The per-cluster pass of one chunk over clusters GATHERED on the host (the 2-bytes-per-entry job): the chunk's flagged clusters with a
 // length the statistics allow, plus the records the EOF rule adds on the last chunk; their entries copied from all four columns of the
 // source into compact columns, the EOF phantom entry (index n_total) worked out as read_el leaves it.
-double g_gather_s = 0, g_compact_s = 0;                          // (E2S_CLI_TIMING: where the second phase goes)
-int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_options& o, const e2s_egsa_source& src, const Flagged& F,
+struct CompactJob {                                               // per job (two jobs may run on two threads): the gather buffers, reused from chunk to chunk, and
+    std::vector<uint8_t> cb, cl, cp; std::vector<uint32_t> cd; std::vector<uint64_t> off;    // where the second phase's time goes (E2S_CLI_TIMING)
+    double gather_s = 0, compact_s = 0;
+};
+int compact_chunk_pass(CompactJob& J, e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_options& o, const e2s_egsa_source& src, const Flagged& F,
                        const e2s_stitch_plan_t& plan, int mcl, uint64_t* n_cand) {
     *n_cand = 0;
     const double t_in = now_s();
@@ -299,7 +302,7 @@ int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_o
     const uint64_t real_hi = std::min<uint64_t>(gmax, p.n_total);                // (index n_total is the EOF phantom)
     const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;
     if (real_hi > gmin && src.get(src.user, 2, gmin, real_hi - gmin, 1, &bwt, &lcp, &psa, &aos) != 0) return E2S_ERR_IO;      // (slot 2: see e2s_egsa_source)
-    static thread_local std::vector<uint8_t> cb, cl, cp; static thread_local std::vector<uint32_t> cd; static thread_local std::vector<uint64_t> off;
+    std::vector<uint8_t>&cb = J.cb, &cl = J.cl, &cp = J.cp; std::vector<uint32_t>& cd = J.cd; std::vector<uint64_t>& off = J.off;
     cb.resize(total); cl.resize(total); cp.resize(total); cd.resize(total); off.resize(st.size());
     const uint8_t* B = (const uint8_t*)bwt; const uint8_t* L = (const uint8_t*)lcp; const uint8_t* P = (const uint8_t*)psa;
     uint32_t ph[4] = {0, 0, 0, 0};
@@ -310,8 +313,7 @@ int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_o
     }
     uint64_t at = 0;
     for (size_t i = 0; i < st.size(); ++i) { off[i] = at; at += ln[i]; }
-    // the gather itself: worker threads over the clusters (~10^6 entries per 3x10^8-entry chunk).  (Plain pointers: the buffers are
-    // this thread's thread_local ones, a worker naming them would get its own, empty ones.)
+    // the gather itself: worker threads over the clusters (~10^6 entries per 3x10^8-entry chunk)
     uint8_t* const pb = cb.data(); uint8_t* const pl = cl.data(); uint8_t* const pp = cp.data(); uint32_t* const pd = cd.data(); const uint64_t* const po = off.data();
     auto work = [&, pb, pl, pp, pd, po](size_t i0, size_t i1) {
         for (size_t i = i0; i < i1; ++i) {
@@ -335,7 +337,7 @@ int compact_chunk_pass(e2s_handle hc, const e2s_chunk_params& p, const e2s_c2s_o
     const double t_g = now_s();
     const int rc = e2s_internal_find_candidates_compact(hc, &prm, st.size(), st.data(), off.data(), ln.data(), cb.data(), cl.data(), cp.data(), cd.data(), total, gmin,
                                                         gmax - gmin, n_cand);
-    g_gather_s += t_g - t_in; g_compact_s += now_s() - t_g;
+    J.gather_s += t_g - t_in; J.compact_s += now_s() - t_g;
     return rc;
 }
 
@@ -364,7 +366,7 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     ts.tp = e2s_tail_params{o->k_left, o->k_right, o->max_gap, o->max_err};
     double up_b = 0;
     const double t_phase2 = now_s();
-    g_gather_s = g_compact_s = 0;
+    CompactJob cj;
     auto reads_on = [&](e2s_handle h0, e2s_handle h1) -> int {
         if (fasta_path) {
             int r2 = e2s_upload_reads_fasta(h0, fasta_path, nullptr);
@@ -410,7 +412,7 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
             } else {
                 e2s_stitch_plan_t plan;
                 if (e2s_stitch_plan(sp.all.data(), nr, r, p->n_total, p->k, p->lcp_bytes, &plan) != E2S_OK) return E2S_ERR_INPUT;
-                RC(compact_chunk_pass(hc, *p, *o, *src, flagged[(size_t)r], plan, mcl, &n_cand));
+                RC(compact_chunk_pass(cj, hc, *p, *o, *src, flagged[(size_t)r], plan, mcl, &n_cand));
             }
             rc = chunk_tail(ht, n_cand, snp_sink, snp_user, ts);
             if (rc == E2S_SWITCH_TAILS) return E2S_ERR_STATE;         // (the sink has the earlier chunks' events already: see include/e2s_hip.h)
@@ -445,7 +447,7 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     fill_report(rep, &sp, &ts, mcl, n_clust, n_bases, chunks.size(), sp.up_s + up_b, t0);
     if (getenv("E2S_CLI_TIMING"))
         fprintf(stderr, "[timing]   chunked job: %.1f ms in all; streaming pass %.1f ms (uploads %.1f ms); second phase: gather %.1f ms, per-cluster pass %.1f ms, the rest (tail, sinks) %.1f ms\n",
-                (now_s() - t0) * 1e3, (t_phase2 - t0) * 1e3, sp.up_s * 1e3, g_gather_s * 1e3, g_compact_s * 1e3, (now_s() - t_phase2 - g_gather_s - g_compact_s) * 1e3);
+                (now_s() - t0) * 1e3, (t_phase2 - t0) * 1e3, sp.up_s * 1e3, cj.gather_s * 1e3, cj.compact_s * 1e3, (now_s() - t_phase2 - cj.gather_s - cj.compact_s) * 1e3);
     return rc;
 }
 
@@ -486,6 +488,7 @@ extern "C" int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_op
             }
             RC(pipe.start());
             LazyFile out{nullptr, out_path};
+            CompactJob cj;
             for (int r = 0; r < nr; ++r) {
                 e2s_handle h = nullptr;
                 RC(pipe.acquire((size_t)r, &h));
@@ -498,7 +501,7 @@ extern "C" int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_op
                 pipe.done((size_t)r);                             // (the next chunk uploads while this one's clusters are gathered and passed)
                 uint64_t n_cand = 0;
                 e2s_chunk_params p0 = *p; p0.min_len = 0;
-                RC(compact_chunk_pass(hc, p0, *o, *src, F, e2s_stitch_plan_t{}, max_clust_length, &n_cand));
+                RC(compact_chunk_pass(cj, hc, p0, *o, *src, F, e2s_stitch_plan_t{}, max_clust_length, &n_cand));
                 RC(chunk_tail(hc, n_cand, lazy_file_sink, &out, ts));
             }
             pipe.stop();

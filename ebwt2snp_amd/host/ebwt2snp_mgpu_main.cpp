@@ -12,11 +12,13 @@
 // exchange) the ranks run the stepwise calls with the same two exchanges.  Both files are written by all ranks AT ONCE, each at
 // its own offset (pwrite): the sizes are exchanged through the process's memory.
 // No rank ever waits for one that failed: before every exchange the ranks agree -- a barrier over their status in this process --
-// whether all of them are still in; if not, all leave.  (E2S_MGPU_FAIL_RANK=r, E2S_MGPU_FAIL_AT=setup|job: inject a failure: tests.)
+// whether all of them are still in; if not, all leave.  (E2S_MGPU_FAIL_RANK=r, E2S_MGPU_FAIL_AT=setup|job: inject a failure: tests;
+// E2S_JOB_FAIL_RANK=r, E2S_JOB_FAIL_AT=1|2: inside e2s_resident_job, before the first exchange / between the two.)
 // -G 1 runs the same code with a one-rank communicator.
 // E2S_MGPU_SHARED_DEVICE=1 puts every rank on GPU 0 and exchanges through host memory (RCCL refuses two ranks on one device):
 // a rehearsal of the N-rank logic on a one-GPU box, not a way to run jobs.
 #include <fcntl.h>
+#include <cerrno>
 #include <rccl/rccl.h>
 #include <hip/hip_runtime.h>
 #include <unistd.h>
@@ -65,6 +67,7 @@ struct Shared {
     std::atomic<int> crash{0};                // 136 / 139: the reference's clust2snp dies on this input (SIGFPE / SIGSEGV) -- after ebwt2clust wrote its file
     std::vector<int> status;                  // per rank: 0 = in, else its error (agreement before every collective)
     std::vector<int> form;                    // per rank: e2s_resident_job applies
+    std::vector<int> verdict;                 // per rank, after the job: 1 done, 2 done (the reference crashes here), 0 redo through the stepwise calls
     std::vector<uint64_t> closed, cands, events, cl_records, snp_bytes; int mcl = 0;
     // where only the host tail reproduces the reference (a read rank past the last read, -L outside 1..64, an irregular FASTA): every
     // rank hands over its packed candidates and ONE e2s_snp_from_packed runs at the end
@@ -183,21 +186,43 @@ void rank_main(Shared& S, int r) {
     if (native) {
         AgCtx ctx{&S, r};
         e2s_job_report rep{};
+        // (the job's buffers were all put in place by the probe call above, before the ranks agreed to enter: between its enqueue and the
+        //  two exchanges a rank can only fail on a HIP error, and then it still enters both exchanges with a zeroed share -- e2s_resident_job's
+        //  `bail`; E2S_JOB_FAIL_AT / E2S_JOB_FAIL_RANK inject such a failure INSIDE the job, E2S_MGPU_FAIL_AT=job one behind it)
         int jrc = e2s_resident_job(h, &rp, job_allgather, &ctx, &rep);
         if (S.fail_rank == r && S.fail_at == "job") { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (job)" << std::endl; jrc = E2S_ERR_HIP; }
-        if (jrc == E2S_OK) {
+        int crash_code = 0;
+        if (jrc == E2S_OK) S.verdict[(size_t)r] = 1;
+        else if (jrc == E2S_ERR_REF_CRASH) {                       // where clust2snp dies in the reference: ebwt2clust's file is written all the same
+            const char* why = e2s_last_error(h);
+            crash_code = (strstr(why, "divides by zero") || strstr(why, "histogram")) ? 136 : 139;
+            S.verdict[(size_t)r] = 2;
+        } else if (jrc == E2S_ERR_CAPACITY) S.verdict[(size_t)r] = 0;    // (on every rank alike -- the stepwise calls below)
+        else {
+            STEP(jrc, "resident job");
+            if (jrc == E2S_ERR_IO && !S.shared_device) {
+                // the exchange itself failed on this rank: its peers may sit in a collective that will never complete -- abort every communicator
+                // (their pending collectives end with an error) and let the job end
+                std::lock_guard<std::mutex> lk(S.log_m);
+                for (auto& c : S.comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+            }
+        }
+        if (!agree(S, r, mine_rc)) { leave(); return; }
+        // the verdict travels in the second exchange, so the ranks agree on it; should they ever not (a bug), everybody takes the stepwise
+        // path rather than some rank waiting in an exchange the others never enter
+        bool all_done = true;
+        for (int q = 0; q < S.nranks; ++q) all_done = all_done && S.verdict[(size_t)q] != 0;
+        if (all_done && S.verdict[(size_t)r] == 1) {
             done = true; mcl = rep.max_clust_length; n_cand = rep.n_candidates; nv = rep.n_variants; ne = rep.n_events; nb = rep.snp_bytes;
             S.closed[(size_t)r] = rep.n_closed;
             if (r == 0) S.mcl = mcl;
-        } else if (jrc == E2S_ERR_REF_CRASH) {                     // where clust2snp dies in the reference: ebwt2clust's file is written all the same
-            const char* why = e2s_last_error(h);
-            int z = 0; S.crash.compare_exchange_strong(z, (strstr(why, "divides by zero") || strstr(why, "histogram")) ? 136 : 139);
+        } else if (all_done) {
+            int z = 0; S.crash.compare_exchange_strong(z, crash_code);
             uint64_t nc = 0;
             if (e2s_cluster_counts(h, &nc, nullptr) == E2S_OK) S.closed[(size_t)r] = nc;
             done = true; n_cand = 0; ne = 0; nb = 0;
-        } else if (jrc != E2S_ERR_CAPACITY) STEP(jrc, "resident job");   // (E2S_ERR_CAPACITY: on every rank alike -- the stepwise calls below)
-        if (!agree(S, r, mine_rc)) { leave(); return; }
-        // (a rank whose job succeeded while another one's asked for the stepwise path cannot be: that verdict travels in the second exchange)
+        }
+        S.bar->wait();                                              // (every rank has read the verdicts)
     }
     // ---- the stepwise calls with the same two exchanges ----
     if (!done) {
@@ -347,7 +372,7 @@ int main(int argc, char** argv) {
     Barrier bar(S.nranks);
     S.bar = &bar;
     S.closed.assign((size_t)S.nranks, 0); S.cands.assign((size_t)S.nranks, 0); S.events.assign((size_t)S.nranks, 0);
-    S.cl_records.assign((size_t)S.nranks, 0); S.snp_bytes.assign((size_t)S.nranks, 0); S.status.assign((size_t)S.nranks, 0); S.form.assign((size_t)S.nranks, 0);
+    S.cl_records.assign((size_t)S.nranks, 0); S.snp_bytes.assign((size_t)S.nranks, 0); S.status.assign((size_t)S.nranks, 0); S.form.assign((size_t)S.nranks, 0); S.verdict.assign((size_t)S.nranks, 0);
     S.pk_stream.resize((size_t)S.nranks); S.pk_off8.resize((size_t)S.nranks);
     if (const char* e = getenv("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
     S.fail_at = getenv("E2S_MGPU_FAIL_AT") ? getenv("E2S_MGPU_FAIL_AT") : "setup";
@@ -356,6 +381,7 @@ int main(int argc, char** argv) {
     S.reads_ok = e2s_fasta_index_open(o.input.c_str(), &fix, &S.rd_text, &S.rd_bytes, &S.rd_start, &S.rd_len, &S.rd_n, &S.rd_max) == E2S_OK && S.rd_n > 0;
     const std::string cl_path = o.input + ".clusters";
     S.cl_fd = ::open(cl_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (S.cl_fd < 0) { std::cerr << "cannot create " << cl_path << ": " << strerror(errno) << std::endl; if (fix) e2s_fasta_index_close(fix); return 2; }
     S.snp_path = o.input.substr(0, o.input.rfind(".fast")) + ".snp";
     std::cout << "This is ebwt2snp_mgpu. Input file: " << o.input << ", " << F.n << " EGSA entries over " << S.nranks << " GPU(s)"
               << (S.shared_device ? " [rehearsal: all ranks on GPU 0, exchange through host memory]" : " [RCCL all-gather]") << std::endl;
@@ -366,7 +392,7 @@ int main(int argc, char** argv) {
     if (fix) e2s_fasta_index_close(fix);
     if (S.cl_fd >= 0) ::close(S.cl_fd);
     if (S.snp_fd >= 0) ::close(S.snp_fd);
-    for (auto& c : S.comms) ncclCommDestroy(c);
+    for (auto& c : S.comms) if (c) ncclCommDestroy(c);
     if (S.rc.load()) ::unlink(cl_path.c_str());                  // (a job that failed leaves no half-written `.clusters` behind)
     if (!S.rc.load() && S.crash.load()) S.rc.store(S.crash.load());   // (ebwt2clust's file stays, as after the reference's two runs)
     uint64_t closed = 0, cands = 0, events = 0;

@@ -28,8 +28,9 @@ extern "C" int e2s_fasta_index_open(const char* fasta_path, e2s_fasta_index** ou
     e2s_fasta_index* f = new e2s_fasta_index();
     f->fd = ::open(fasta_path, O_RDONLY);
     if (f->fd < 0) { delete f; return E2S_ERR_IO; }
-    struct stat st;
-    if (fstat(f->fd, &st) != 0 || st.st_size == 0) { const int rc = st.st_size == 0 ? E2S_ERR_INPUT : E2S_ERR_IO; delete f; return rc; }
+    struct stat st{};
+    if (fstat(f->fd, &st) != 0) { delete f; return E2S_ERR_IO; }
+    if (st.st_size == 0) { delete f; return E2S_ERR_INPUT; }      // (an empty file is an input error, not an I/O one)
     f->n = (size_t)st.st_size;
     f->map = mmap(nullptr, f->n, PROT_READ, MAP_PRIVATE, f->fd, 0);
     if (f->map == MAP_FAILED) { f->map = nullptr; delete f; return E2S_ERR_IO; }

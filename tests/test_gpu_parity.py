@@ -1010,6 +1010,17 @@ def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
             assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
             assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
+    # ... and INSIDE e2s_resident_job, after the scan has been enqueued: before the first exchange (1) and between the two (2).  The failing
+    # rank still enters the exchanges its peers wait in (with a zeroed share), everybody comes back, the job ends with an error
+    for ranks, shared, fail_rank in ((3, True, 1), (3, True, 2), (1, False, 0)):
+        for at in ("1", "2"):
+            for f in (p + ".clusters", IO.snp_out_path(p)):
+                if os.path.exists(f):
+                    os.remove(f)
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_JOB_FAIL_RANK=str(fail_rank), E2S_JOB_FAIL_AT=at)
+            r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
+            assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
+            assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
     for ranks, shared in ((1, False), (3, True)):
         env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0")
         r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks), "-L", "90", "-R", "20"], capture_output=True, text=True, env=env, timeout=120)

@@ -32,8 +32,7 @@ for fused in (False, True):
             h.cluster_scan(16, 2, 0)
             ts.append(h.timing().scan_main_ms)
         b = h.boundary()
-        # (the default scan leaves 6-byte records in its segments; E2S_SCAN_IMG=1: the 10-byte file records)
-        nbytes = n * (2 if fused else 1) + b.n_ends * (10 if os.environ.get("E2S_SCAN_IMG") == "1" else 6)
+        nbytes = n * (2 if fused else 1) + b.n_ends * 6
         med = float(np.median(ts[3:]))
         print("%-5s %-32s median %.4f ms  min %.4f  -> %.0f GB/s algorithmic = %.3f of 8 TB/s  (%d entries, %d records)"
               % ("fused" if fused else "K1", mode, med, min(ts[3:]), nbytes / med / 1e6, nbytes / med / 1e6 / 8000.0, n, b.n_ends), flush=True)
