@@ -11,10 +11,11 @@ PCIe included on the way out) and `value_end_to_end` (this repo's executables th
 
   python bench.py --gpus 1 --steps 20 --warmup 3                      (default workload: c3, BASELINE.json configs[2])
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-      bench.py --gpus N --steps K --warmup W [--scaling strong]
+      bench.py --gpus N --steps K --warmup W [--scaling weak]
 
-N > 1, --scaling weak (default): the global EGSA is N copies of the workload; rank r owns a contiguous SA range whose cuts fall
-INSIDE clusters, so the stitch is real.  --scaling strong (BASELINE.json configs[3]): the SAME workload cut into N SA ranges.
+N > 1, --scaling strong (the default: BASELINE.json configs[3]): the SAME workload cut into N contiguous SA ranges whose cuts fall
+INSIDE clusters, so the stitch is real; at N = 8 a second leg runs configs[4] (c5: 3x10^10 entries, every rank building only its
+range) the same way.  --scaling weak: the global EGSA is N copies of the workload.
 Either way: ONE all-gather of the 88-byte boundary descriptors + 1.2-KB statistics (RCCL over xGMI), and an 8-byte one for the
 `.snp` ids, which are sequential over the ranks.
 """
@@ -640,19 +641,25 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             tm = h.timing()
             r["scan_ms"].append(tm.scan_main_ms); r["cand_ms"].append(tm.cand_main_ms); r["scan_all_ms"].append(tm.scan_ms)
             r["hist_ms"].append(tm.hist_ms); r["tail_ms"].append(tm.tail_ms)
+        own = time.perf_counter() - t0                              # this rank's own steps, before it waits for the others
         barrier()
         elapsed = time.perf_counter() - t0
+        rank_ms = None
         if dist is not None:
             rdev = torch.device("cpu") if REHEARSAL else dev
             t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        r.update(elapsed=elapsed, info=info, phases=dict(PHASES), steps=n_steps)
+            lo, hi = torch.tensor([own], dtype=torch.float64, device=rdev), torch.tensor([own], dtype=torch.float64, device=rdev)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            rank_ms = {"min": float(lo.item()) / n_steps * 1e3, "max": float(hi.item()) / n_steps * 1e3}
+        r.update(elapsed=elapsed, info=info, phases=dict(PHASES), steps=n_steps, rank_ms=rank_ms)
         return r
 
     prim = measure(True, warmup, steps, timing=BENCH_TIMING)
     bare = measure(True, 1, steps, timing=0) if BENCH_TIMING else prim      # the same steps without a single timing event
-    phases = measure(True, 1, max(3, steps // 2), timing=2) if emul is not None else None     # (per-phase kernel times for the rank report)
+    phases = measure(True, 1, max(3, steps // 2), timing=2) if (emul is not None or world > 1) else None     # (per-phase kernel times for the rank report)
     other = measure(False, min(warmup, 2) + 1, max(3, steps // 2), timing=2) if SECOND_LEG and emul is None else None
     host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True, timing=0) if emul is None else None
     info = prim["info"]
@@ -718,13 +725,17 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             "ms_per_step_without_timing_events": bare["elapsed"] / bare["steps"] * 1e3,
             "timing_events_in_timed_region": {0: "none", 1: "two, around the scan kernel (roofline.launch_ms)", 2: "every phase"}[BENCH_TIMING],
         }
-        if emul is not None:
+        if prim["rank_ms"]:
+            res["per_rank_ms_per_step"] = dict(prim["rank_ms"], what="each rank's own K steps (before the closing barrier), min and max over the ranks")
+        if phases is not None:
             res["kernel_ms"] = {"scan+prefilter+fix+stats": float(np.mean(phases["scan_all_ms"])), "scan_kernel": float(np.mean(phases["scan_ms"])),
                                 "per_cluster_pass_to_K2b_end": float(np.mean(phases["cand_ms"])), "tail": float(np.mean(phases["tail_ms"])),
                                 "note": "from a separate leg with every phase's events recorded (each costs stream time: ms_per_step there %.4f)"
                                         % (phases["elapsed"] / phases["steps"] * 1e3)}
+            res["kernel_ms"]["what"] = ("rank 0's phases; 'scan+prefilter+fix+stats' ends before the first exchange, 'per_cluster_pass_to_K2b_end' starts behind it "
+                                        "(exchange 1 + plan lie between), 'tail' brackets exchange 2")
+        if emul is not None:
             res["rank_entries"] = n_own
-            res["target_ms_for_6x_at_8"] = None
         res["roofline"].update({"survey_8d_bytes": ref_pattern_bytes + n_own, "frac_vs_survey_bytes": (ref_pattern_bytes + n_own) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "frac_uses": "algorithmic_bytes (2 B/entry read + 6 B/record written: the segment record of round 3)",
                                 "frac_with_10_byte_records": (n_own * 2 + info["n_ends"] * 10) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,   # (rounds 1-2 accounting)
@@ -762,13 +773,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: 'strong' (the default: the SAME EGSA cut into N SA ranges = BASELINE.json configs[3]) or 'weak' (N copies)")
     ap.add_argument("--cpu-sample", type=int, default=302000000, help="entries of the CPU baseline sample (0 = skip; the default covers one whole block "
                     "of c3: ~20 s of the reference on one core)")
     ap.add_argument("--second-workload", default="c2", help="a second, shorter leg on this workload ('' = none; N = 1 only)")
     ap.add_argument("--emulate-rank", default="", help="R/N: time rank R of the N-way STRONG cut of the workload on this one GPU (N-rank bookkeeping, "
                     "one-rank RCCL exchanges; the peers' descriptors are computed before the timed region).  Not the driver's metric: a readiness check")
     a = ap.parse_args()
+    if a.scaling is None:
+        a.scaling = "strong" if a.gpus > 1 else "weak"             # (one GPU: the two are the same job)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -823,6 +837,13 @@ def main():
     second = None
     if world == 1 and a.second_workload and a.second_workload != a.workload and a.second_workload in WORKLOADS:
         second = measure_workload(a, a.second_workload, world, rank, local, dist, dev, a.steps, a.warmup, "weak", with_cpu=False)
+    c5_leg = None
+    if world > 1 and a.workload == "c3" and a.scaling == "strong" and (world >= 8 or os.environ.get("E2S_BENCH_C5_LEG", "0") == "1"):
+        # BASELINE.json configs[4]: the 3x10^10-entry EGSA (more than one GPU's HBM), the mandatory 8-GPU shard -- every rank builds only its range
+        try:
+            c5_leg = measure_workload(a, "c5", world, rank, local, dist, dev, max(3, a.steps // 4), 2, "strong", with_cpu=False)
+        except Exception as ex:                                     # (never takes the configs[3] line down with it)
+            c5_leg = {"error": repr(ex)}
     if rank == 0:
         out = {"metric": "EGSA entries/sec through ebwt2clust+clust2snp", "value": res["value"], "unit": "EGSA entries/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
@@ -830,6 +851,8 @@ def main():
         out.update({k2: v for k2, v in res.items() if k2 not in ("value", "ms_per_step")})
         if second is not None:
             out["second_workload"] = second
+        if c5_leg is not None:
+            out["c5_strong"] = c5_leg
         # the CPU baseline and the end-to-end executables run on a 10^8-entry sample of the MAIN workload's block (c3: 150-bp reads)
         cb = out.get("cpu_baseline") or {}
         out["value_end_to_end"] = (cb.get("drop_in") or {}).get("value")
