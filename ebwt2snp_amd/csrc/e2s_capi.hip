@@ -36,6 +36,7 @@ struct e2s_ctx {
     std::vector<uint64_t> wrap_ranks; bool wrap_overflow = false;
     uint64_t first_end_pos = E2S_NONE; bool first_wrapped = false;
     uint64_t* d_fl_starts = nullptr; uint16_t* d_fl_lens = nullptr; uint64_t fl_cap = 0; uint64_t n_flagged = 0;
+    bool fl_test_done = false, cand_test_done = false;   // E2S_TEST_FL_CAP / E2S_JOB_TEST_CAND_CAP have been applied to this handle's first pre-filter / job
     uint64_t* d_scalars = nullptr;               // [0] total_ends  [1] cand_count  [2..] hist (153)
     uint32_t* d_words = nullptr;                 // [1] err [2..4] flags [8,9] tailv [12] wrap count [20] pre-filter err
     bool scanned = false, stitched = false, records_from_file = false;
@@ -216,7 +217,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
 static int start_prefilter(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, int max_workers, hipStream_t st);
 static bool prefilter_eligible(const e2s_ctx* h);
 static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words);
-static int prefilter_room(e2s_ctx* h, uint64_t est_records);
+static int prefilter_room(e2s_ctx* h, uint64_t est_records, bool for_launch);
 
 // Wait for the handle's stream with a short spin on an event before falling back to the blocking wait: the two
 // waits of a job (after the scan, after the per-cluster pass) sit on its critical path, and the blocking wait's
@@ -703,7 +704,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
     FilterArgs fa{};
     bool fuse_now = false;
-    if (prepare_only) return (armed && prefilter_eligible(h)) ? prefilter_room(h, h->n_prov / 32) : E2S_OK;
+    if (prepare_only) return (armed && prefilter_eligible(h)) ? prefilter_room(h, h->n_prov / 32, false) : E2S_OK;
     if (armed) {                                                 // e2s_prefilter_arm
         h->pf_armed = false;
         if (fused) {
@@ -1240,13 +1241,16 @@ static bool prefilter_eligible(const e2s_ctx* h) {
 }
 // the flagged-cluster list (empty, behind the reserved seed slots), the pre-filter's error word and its arguments
 // room for the list of flagged clusters (allocation only: what e2s_resident_job's probe call does ahead of the enqueue)
-static int prefilter_room(e2s_ctx* h, uint64_t est_records) {
-    // (E2S_TEST_FL_CAP: a testing aid -- a fresh handle's list of flagged clusters starts that short, so that the pre-filter overflows it)
+static int prefilter_room(e2s_ctx* h, uint64_t est_records, bool for_launch) {
+    // (E2S_TEST_FL_CAP: a testing aid -- the list of flagged clusters of a handle's FIRST pre-filter is that short, so that it overflows;
+    //  a prepare call ahead of that launch sizes it the same way)
     static const int test_fl_cap = getenv("E2S_TEST_FL_CAP") ? atoi(getenv("E2S_TEST_FL_CAP")) : 0;
-    return ensure_flagged(h, test_fl_cap > 0 && h->fl_cap == 0 ? (uint64_t)test_fl_cap + E2S_SEED_SLOTS : std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
+    const bool tiny = test_fl_cap > 0 && !h->fl_test_done;
+    if (for_launch) h->fl_test_done = true;
+    return ensure_flagged(h, tiny ? (uint64_t)test_fl_cap + E2S_SEED_SLOTS : std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
 }
 static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_records, hipStream_t st, FilterArgs& f, bool scan_words = false) {
-    int rc = prefilter_room(h, est_records);
+    int rc = prefilter_room(h, est_records, true);
     if (rc) return rc;
     // one launch: the list starts behind the reserved seed slots (length 0 = empty slot), the pre-filter's error word is
     // cleared -- and, for the scan that carries the pre-filter, the scan's words as well
@@ -2119,7 +2123,8 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     // (E2S_JOB_TEST_CAND_CAP: a testing aid -- a fresh handle starts with that few candidate slots, so that the step overflows them, says so
     //  in its mail and is redone through the stepwise calls)
     static const int test_cand_cap = getenv("E2S_JOB_TEST_CAND_CAP") ? atoi(getenv("E2S_JOB_TEST_CAND_CAP")) : 0;
-    const uint64_t cand_want = test_cand_cap > 0 && h->cand_cap == 0 ? (uint64_t)test_cand_cap : std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap);
+    const bool cand_tiny = test_cand_cap > 0 && !h->cand_test_done && h->cand_cap <= (uint64_t)test_cand_cap;       // (a probe call sizes them the same way)
+    const uint64_t cand_want = cand_tiny ? (uint64_t)test_cand_cap : std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap);
     if ((rc = cand_buffers(h, ca, cand_want))) return rc;
     const uint64_t ncap = h->cand_cap, ng = (ncap + 63) / 64;
     TailArgs ta;
@@ -2148,6 +2153,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     void* dev_mail = nullptr;
     CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
     if (p->probe_only) return E2S_OK;
+    h->cand_test_done = true;
 
     // ---- ENQUEUE: from here to the second exchange nothing allocates.  Should a HIP call fail all the same, this rank still enqueues the
     // exchanges its peers are going to wait in (`bail` below) -- with a zeroed share, which they read as "a rank of the job is not ok".

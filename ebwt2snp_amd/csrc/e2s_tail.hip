@@ -193,9 +193,14 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
     const u32 ca = sa[lane], cb = sb[lane];
     const int none = __popcll(__ballot(lane < kl && ca != cb));
     int D = none, L = 0;
-    if (a.max_gap > 0) {
+    // A gap of i costs at least i, so gaps longer than the plain distance `none` can neither be the first minimum that is used nor change
+    // the test below (it only asks whether a minimum is <= none): the loop ends at min(max_gap, none) -- and is skipped for equal strings,
+    // where the reference finds no indel.  (It used to run max_gap = 10 times for every candidate: a quarter of this kernel's instructions;
+    // a SNP's two consensus strings differ in their last letter only: none = 1.)
+    const int gap_hi = min(a.max_gap, none);
+    if (gap_hi > 0) {
         int best_ab = 0, best_ba = 0, ia = 0, ib = 0;
-        for (int i = 1; i <= a.max_gap; ++i) {
+        for (int i = 1; i <= gap_hi; ++i) {
             int mab, mba;
             if ((u32)i <= kl) {
                 const u32 la = kl - (u32)i;                         // a.substr(0, len - i) against b, right-aligned: a[x] ~ b[x + i]
@@ -347,9 +352,13 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     const u32 ca = sa[hl], cb = sb[hl];
     const int none = (int)tl_half_pop(__ballot(colok && ca != cb), half);
     int D = none, L = 0;
-    if (a.max_gap > 0) {
+    // (gaps longer than `none` cannot matter -- see k_consensus; the bound is the larger of the two halves': for the other half the extra
+    //  rounds only see costs above its own `none`, which never become a minimum that is used)
+    const int none_other = __shfl_xor(none, 32);
+    const int gap_hi = min(a.max_gap, max(none, none_other));
+    if (gap_hi > 0) {
         int best_ab = 0, best_ba = 0, ia = 0, ib = 0;
-        for (int i = 1; i <= a.max_gap; ++i) {
+        for (int i = 1; i <= gap_hi; ++i) {
             int mab, mba;
             if ((u32)i <= kl) {
                 const u32 la = kl - (u32)i;
