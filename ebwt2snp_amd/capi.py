@@ -82,8 +82,8 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_set_timing", "e2s_stream", "e2s_synchronize",
-           "e2s_pack_clusters", "e2s_clusters_image", "e2s_upload_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_renumber_snp", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp",
-           "e2s_ebwt2clust_chunked", "e2s_clust2snp_chunked", "e2s_ebwt2snp_chunked", "e2s_hist_of_records", "e2s_resident_job", "e2s_fasta_index_open", "e2s_fasta_index_close"]
+           "e2s_pack_clusters", "e2s_clusters_image", "e2s_upload_reads", "e2s_share_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_renumber_snp", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp",
+           "e2s_ebwt2clust_chunked", "e2s_clust2snp_chunked", "e2s_ebwt2snp_chunked", "e2s_find_candidates_gathered", "e2s_hist_of_records", "e2s_resident_job", "e2s_fasta_index_open", "e2s_fasta_index_close"]
 
 _lib = None
 

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
 // issue of those instructions as much as by its chain of gathers (c3: ~950 vector + ~920 scalar instructions per candidate).  Here
 // lanes 0-31 serve candidate 2w, lanes 32-63 candidate 2w + 1: the same instruction stream, loops running to the longer of the two
 // lists, ballots read per half.  Results are those of k_consensus (same order of rows, same tie-breaks).
-// Dynamic LDS per wave: 2 candidates x 2 x list_cap rows of 32 x 2 B + (8 + 4) B of row base / length each.
+// Dynamic LDS per wave: 2 candidates x (2 x list_cap rows of 32 x 2 B + (8 + 4) B of row base / length each + one spare row).
 // (Round 3: the record's first 256 bytes fetched as ONE window, two dwords per lane, header / list entries / positions picked out of the
 // registers by ds_bpermute -- a chain of five dependent round trips cut to three -- changed nothing: 470 us against 469 on c3.  The kernel
 // is bound by the issue of its ~950 vector instructions per wave as much as by its gathers; see profiles/round3_k2b_variants.txt.)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     if (c0 >= a.n_cand) return;
     const u64 c = c0 + half;
     const bool valid = c < a.n_cand;
-    const size_t per_cand = (size_t)2 * list_cap * (64 + 8 + 4);
+    const size_t per_cand = (size_t)2 * list_cap * (64 + 8 + 4) + 64;       // (+ one row: the per-row loops read two rows per trip)
     uint8_t* const mine = s_tail + ((size_t)wave * 2 + half) * per_cand;
     uint16_t* const ctx = (uint16_t*)mine;                          // [2 * list_cap][32] of (character | 8 * base_to_int << 8)
     u64* const rbase = (u64*)(mine + (size_t)2 * list_cap * 64);
@@ -318,27 +318,35 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
         const u32 n_max = max((u32)__builtin_amdgcn_readlane((int)n, 0), (u32)__builtin_amdgcn_readlane((int)n, 32));
         const uint16_t* rows = ctx + (size_t)(s ? m0 : 0u) * 32;
         u32 C = 'A', bc8 = 0u, cnt = 0u;                            // cons (include.hpp:334-371): as in k_consensus
-        for (u32 j = 0; j < n_max; ++j) {
-            const bool on = colok & (j < n);
-            u32 r16 = (u32)rows[(size_t)j * 32 + hl];                   // (read whether the lane has the row or not, masked in registers)
-            asm volatile("" : "+v"(r16));
-            const u32 v = on ? r16 : 0u;
-            const u32 ch = v & 0xFFu, b8 = v >> 8;
-            cnt += on ? 1u << b8 : 0u;
-            // (no `on` here: C's count is the largest at all times, so a lane without a row -- v = 0, class 0 -- never takes over)
-            if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
+        const u32 n_col = colok ? n : 0u;                           // rows this lane takes part in: ONE compare per row says whether it counts
+        // (two rows per trip, both LDS reads in flight together: half the loop control, one wait for two rows.  The row behind the last one
+        //  of an odd list lies inside the candidate's LDS area -- 2 * list_cap rows, their bases / lengths, one spare row -- and is masked.)
+        for (u32 j = 0; j < n_max; j += 2u) {
+            u32 ra = (u32)rows[(size_t)j * 32 + hl], rb = (u32)rows[(size_t)(j + 1u) * 32 + hl];   // (read whether the lane has the row or not, masked in registers)
+            asm volatile("" : "+v"(ra), "+v"(rb));
+#pragma unroll
+            for (u32 q = 0; q < 2u; ++q) {
+                const bool on = j + q < n_col;
+                const u32 v = on ? (q ? rb : ra) : 0u;
+                const u32 ch = v & 0xFFu, b8 = v >> 8;
+                cnt += on ? 1u << b8 : 0u;
+                // (no `on` here: C's count is the largest at all times, so a lane without a row -- v = 0, class 0 -- never takes over)
+                if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
+            }
         }
         u32 supp = 0u;
-        // (the rows are read whether the lane has one or not -- row j < list_cap lies inside the candidate's LDS area -- and masked in
-        //  registers: a read under a condition is a branch and an EXEC save / restore per row)
-        for (u32 j = 0; j < n_max; ++j) {
-            const bool on = colok & (j < n);
-            u32 r8 = (u32)rows[(size_t)j * 32 + hl] & 0xFFu;
-            asm volatile("" : "+v"(r8));                                // (keeps the read where it is: the compiler would sink it under `on` again)
-            u32 ch = on ? r8 : C;                                       // a lane without a row agrees with the consensus: ONE compare is the ballot
-            asm volatile("" : "+v"(ch));                                // (... and stays one: `on & (r8 != C)` costs a 0 / 1 round trip through a register)
-            const u32 d = tl_half_pop(__ballot(C != ch), half);
-            if (j < n && (int)d <= a.max_err) ++supp;
+        // (the rows are read whether the lane has one or not and masked in registers: a read under a condition is a branch and an EXEC
+        //  save / restore per row)
+        for (u32 j = 0; j < n_max; j += 2u) {
+            u32 ra = (u32)rows[(size_t)j * 32 + hl] & 0xFFu, rb = (u32)rows[(size_t)(j + 1u) * 32 + hl] & 0xFFu;
+            asm volatile("" : "+v"(ra), "+v"(rb));                      // (keeps the reads where they are: the compiler would sink them under `on` again)
+#pragma unroll
+            for (u32 q = 0; q < 2u; ++q) {
+                u32 ch = j + q < n_col ? (q ? rb : ra) : C;             // a lane without a row agrees with the consensus: ONE compare is the ballot
+                asm volatile("" : "+v"(ch));                            // (... and stays one: `on & (r8 != C)` costs a 0 / 1 round trip through a register)
+                const u32 d = tl_half_pop(__ballot(C != ch), half);
+                if (j + q < n && (int)d <= a.max_err) ++supp;
+            }
         }
         if (s) supp1 = supp; else supp0 = supp;
         (s ? sb : sa)[hl] = (uint8_t)C;
@@ -647,7 +655,7 @@ static size_t tl_device_lds_bytes(int dev) {
 }
 static void tl_consensus_shape(int kl, uint32_t list_cap, size_t lds_cu, size_t* per_wave, unsigned* wpb) {
     if (list_cap < 1) list_cap = 1;
-    *per_wave = kl <= 32 ? (size_t)2 * 2 * list_cap * (64 + 8 + 4) : (size_t)2 * list_cap * (128 + 8 + 4);
+    *per_wave = kl <= 32 ? (size_t)2 * (2 * list_cap * (64 + 8 + 4) + 64) : (size_t)2 * list_cap * (128 + 8 + 4);
     // (four waves per block while six such blocks fit a CU, two while three do: 60 / 120 KB of gfx950's 160)
     *wpb = 4 * *per_wave <= lds_cu * 3 / 8 ? 4u : 2 * *per_wave <= lds_cu * 3 / 4 ? 2u : 1u;
 }

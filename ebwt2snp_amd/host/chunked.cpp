@@ -341,6 +341,24 @@ int compact_chunk_pass(CompactJob& J, e2s_handle hc, const e2s_chunk_params& p, 
     return rc;
 }
 
+// One shard's per-cluster pass over GATHERED clusters (include/e2s_hip.h): what the chunked job does per chunk, for callers that drive
+// their shards themselves (bin/ebwt2snp_mgpu: a rank uploads LCP + BWT only).
+extern "C" int e2s_find_candidates_gathered(e2s_handle h_scan, e2s_handle h_pass, const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src,
+                                            const e2s_stitch_plan_t* plan, int max_clust_length, uint64_t* n_cand, uint64_t* n_gathered) {
+    if (!h_scan || !h_pass || !p || !o || !src || !src->get || !plan || !n_cand) return E2S_ERR_ARG;
+    if (src->gesa || p->lcp_bytes != 1 || p->da_bytes != 4 || p->pos_bytes != 1) return E2S_ERR_STATE;      // (the compact pass reads BCR files of the default widths)
+    const uint64_t* fs = nullptr; const uint16_t* fl = nullptr; uint64_t fn = 0; int full = 0;
+    int rc = e2s_internal_flagged_list(h_scan, &fs, &fl, &fn, &full);
+    if (rc) return rc;
+    if (full) { e2s_internal_set_error(h_scan, "the pre-filter's list is not usable for this shard (a window too dense, a wrapped length): upload all four columns"); return E2S_ERR_STATE; }
+    Flagged F;
+    F.st.assign(fs, fs + fn); F.ln.assign(fl, fl + fn);
+    CompactJob cj;
+    rc = compact_chunk_pass(cj, h_pass, *p, *o, *src, F, *plan, max_clust_length, n_cand);
+    if (n_gathered) { uint64_t t = 0; for (uint16_t l : F.ln) t += l; *n_gathered = t; }
+    return rc;
+}
+
 extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src, const char* fasta_path,
                                     const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len,
                                     e2s_byte_sink clusters_sink, void* clusters_user, e2s_byte_sink snp_sink, void* snp_user, e2s_job_report* rep) {

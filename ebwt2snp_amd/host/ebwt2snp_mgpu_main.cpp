@@ -4,8 +4,11 @@
 //
 // What it replaces: running `ebwt2clust -i F` and then `clust2snp -i F -n N` (ebwt2clust.cpp:141-198, clust2snp.cpp:969-1085;
 // pipeline.sh:115,122); it writes the same two files, <F>.clusters and <F minus .fast*>.snp, byte for byte.
-// One thread per GPU.  Rank r owns the r-th contiguous SA range (left halo 152, right halo 1) and keeps it -- and all reads, uploaded
-// from ONE index of the FASTA built by the main thread -- resident in HBM.  The step itself is e2s_resident_job: scan, exchange,
+// One thread per GPU.  Rank r owns the r-th contiguous SA range (left halo 152, right halo 1).  BCR files of the default widths: a rank
+// uploads LCP + BWT only (2 of the 7 bytes per entry: what the scan with the pre-filter inside reads) and gathers the document array and the
+// positions of the few clusters that filter lets through from the mapped files (e2s_find_candidates_gathered: what the one-GPU chunked job does
+// per chunk); the stepwise calls with the same two exchanges.  Other inputs (.gesa, other widths, E2S_MGPU_FULL_COLUMNS=1): all four columns
+// -- and all reads, uploaded from ONE index of the FASTA built by the main thread -- resident in HBM, and the step is e2s_resident_job: scan, exchange,
 // stitch + statistics, per-cluster pass, tail, all enqueued at once, the two exchanges being ncclAllGather calls on the rank's stream
 // (RCCL; xGMI between the GPUs): 1.3 KB of descriptor + statistics per rank, then 16 bytes (events, ok) for the `.snp` ids, which are
 // sequential over the ranks.  Where that form does not apply (or a buffer was too small: every rank learns it in the second
@@ -68,7 +71,8 @@ struct Shared {
     std::vector<int> status;                  // per rank: 0 = in, else its error (agreement before every collective)
     std::vector<int> form;                    // per rank: e2s_resident_job applies
     std::vector<int> verdict;                 // per rank, after the job: 1 done, 2 done (the reference crashes here), 0 redo through the stepwise calls
-    std::vector<uint64_t> closed, cands, events, cl_records, snp_bytes; int mcl = 0;
+    std::vector<uint64_t> closed, cands, events, cl_records, snp_bytes, uploaded, gathered; int mcl = 0;
+    bool slim = false;                        // ranks upload LCP + BWT only, the flagged clusters' other columns are gathered from the files
     // where only the host tail reproduces the reference (a read rank past the last read, -L outside 1..64, an irregular FASTA): every
     // rank hands over its packed candidates and ONE e2s_snp_from_packed runs at the end
     bool host_tail = false; std::vector<std::vector<uint8_t>> pk_stream; std::vector<std::vector<uint32_t>> pk_off8; uint32_t pk_pw = 4;
@@ -142,7 +146,7 @@ int job_allgather(void* user, const void* d_send, void* d_recv, size_t bytes, vo
 void rank_main(Shared& S, int r) {
     const Opts& o = S.o;
     const int dev = S.shared_device ? 0 : r;
-    e2s_handle h = nullptr;
+    e2s_handle h = nullptr, hc = nullptr, hf = nullptr;        // hc (slim): the reads, the gathered per-cluster pass and the tail; hf: a shard that needs all four columns after all
     hipStream_t xs = nullptr; void *d_send = nullptr, *d_recv = nullptr;
     int mine_rc = 0;
     const uint64_t n = S.F->n;
@@ -155,30 +159,39 @@ void rank_main(Shared& S, int r) {
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc(&d_send, BLOB) != hipSuccess || hipMalloc(&d_recv, BLOB * (size_t)S.nranks) != hipSuccess) mine_rc = E2S_ERR_HIP;
     }
-    if (!mine_rc && S.reads_ok) STEP(e2s_upload_reads(h, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads");   // every rank holds all reads
+    if (!mine_rc && S.slim) STEP(e2s_create(dev, &hc), "e2s_create (per-cluster pass)");
+    e2s_handle const hr_ = S.slim ? hc : h;                     // where the reads live
+    if (!mine_rc && S.reads_ok) STEP(e2s_upload_reads(hr_, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads");   // every rank holds all reads
+    e2s_shard_desc d{};
+    d.global_offset = lo; d.n_entries = hi - lo; d.n_total = n; d.halo_left = hl; d.halo_right = hr;
+    d.lcp_bytes = o.lcp; d.da_bytes = o.da; d.pos_bytes = o.pos;
+    const uint64_t p0 = lo - hl, n_prov = (hi - lo) + hl + hr;
     if (!mine_rc) {
-        e2s_shard_desc d{};
-        d.global_offset = lo; d.n_entries = hi - lo; d.n_total = n; d.halo_left = hl; d.halo_right = hr;
-        d.lcp_bytes = o.lcp; d.da_bytes = o.da; d.pos_bytes = o.pos;
-        const uint64_t p0 = lo - hl;
-        if (S.F->gesa) STEP(e2s_upload_gesa(h, &d, S.F->aos.p + p0 * (uint64_t)(o.lcp + o.da + o.pos + 1)), "upload (.gesa)");
-        else STEP(e2s_upload_bcr(h, &d, S.F->bwt.p + p0, S.F->lcp.p + p0 * (uint64_t)o.lcp, S.F->pairsa.p + p0 * (uint64_t)(o.da + o.pos)), "upload (BCR)");
+        if (S.slim) { STEP(e2s_upload_lcp_bwt(h, &d, S.F->lcp.p + p0, S.F->bwt.p + p0), "upload (LCP + BWT)"); S.uploaded[(size_t)r] = 2 * n_prov; }
+        else {
+            if (S.F->gesa) STEP(e2s_upload_gesa(h, &d, S.F->aos.p + p0 * (uint64_t)(o.lcp + o.da + o.pos + 1)), "upload (.gesa)");
+            else STEP(e2s_upload_bcr(h, &d, S.F->bwt.p + p0, S.F->lcp.p + p0 * (uint64_t)o.lcp, S.F->pairsa.p + p0 * (uint64_t)(o.da + o.pos)), "upload (BCR)");
+            S.uploaded[(size_t)r] = (uint64_t)(o.lcp + o.da + o.pos + 1) * n_prov;
+        }
     }
     if (S.fail_rank == r && S.fail_at == "setup") { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (setup)" << std::endl; mine_rc = E2S_ERR_HIP; }
     e2s_resident_params rp{};
     rp.k = o.k; rp.min_len = o.min_len; rp.rank = r; rp.world = S.nranks; rp.want_image = 1;
     rp.o.nr_reads1 = o.nr_reads1; rp.o.k_left = o.k_left; rp.o.k_right = o.k_right; rp.o.mcov_out = o.mcov_out; rp.o.consensus_reads = o.consensus_reads;
     rp.o.max_gap = o.max_gap; rp.o.max_err = o.max_err; rp.o.pval = o.pval;
-    if (!mine_rc) { rp.probe_only = 1; S.form[(size_t)r] = e2s_resident_job(h, &rp, job_allgather, nullptr, nullptr) == E2S_OK ? 1 : 0; rp.probe_only = 0; }
+    if (!mine_rc && !S.slim) { rp.probe_only = 1; S.form[(size_t)r] = e2s_resident_job(h, &rp, job_allgather, nullptr, nullptr) == E2S_OK ? 1 : 0; rp.probe_only = 0; }
     auto leave = [&]() {
         if (d_send) (void)hipFree(d_send);
         if (d_recv) (void)hipFree(d_recv);
         if (xs) (void)hipStreamDestroy(xs);
+        if (hf) e2s_destroy(hf);
+        if (hc) e2s_destroy(hc);
         if (h) e2s_destroy(h);
     };
     if (!agree(S, r, mine_rc)) { leave(); return; }
-    bool native = true;
+    bool native = !S.slim;
     for (int q = 0; q < S.nranks; ++q) native = native && S.form[(size_t)q] != 0;
+    e2s_handle ht = h;                                          // where the candidates and the tail end up
 
     int mcl = 0; uint64_t n_cand = 0, nv = 0, ne = 0, nb = 0, need_host = 0;
     bool done = false, host_tail = false;
@@ -257,10 +270,33 @@ void rank_main(Shared& S, int r) {
             e2s_c2s_params prm{};
             prm.nr_reads1 = o.nr_reads1; prm.k_left = o.k_left; prm.k_right = o.k_right; prm.mcov_out = o.mcov_out;
             prm.consensus_reads = o.consensus_reads; prm.max_clust_length = mcl; prm.min_len = o.min_len;
-            STEP(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand), "find candidates");
+            if (S.slim) {
+                // the clusters the pre-filter let through, gathered from all four columns of the mapped files, through find_variants on hc
+                e2s_stitch_plan_t plan{};
+                e2s_chunk_params cp{}; cp.device = dev; cp.k = o.k; cp.min_len = o.min_len; cp.lcp_bytes = o.lcp; cp.da_bytes = o.da; cp.pos_bytes = o.pos; cp.n_total = n;
+                e2s_c2s_options co{}; co.nr_reads1 = o.nr_reads1; co.k_left = o.k_left; co.k_right = o.k_right; co.mcov_out = o.mcov_out;
+                co.consensus_reads = o.consensus_reads; co.max_gap = o.max_gap; co.max_err = o.max_err; co.pval = o.pval;
+                FileSource fsrc{S.F, o.lcp, o.da, o.pos};
+                const e2s_egsa_source src = fsrc.source();
+                int grc = e2s_stitch_plan(allb.data(), S.nranks, r, n, o.k, o.lcp, &plan);
+                uint64_t ng = 0;
+                if (grc == E2S_OK) grc = e2s_find_candidates_gathered(h, hc, &cp, &co, &src, &plan, mcl, &n_cand, &ng);
+                if (grc == E2S_OK) { ht = hc; S.gathered[(size_t)r] = ng; S.uploaded[(size_t)r] += 7 * ng; }
+                else if (grc == E2S_ERR_STATE) {
+                    // (a window too dense for the pre-filter's queue, a cluster of 65536+ entries: this shard needs all four columns after all)
+                    STEP(e2s_create(dev, &hf), "e2s_create (full columns)");
+                    if (!mine_rc && S.reads_ok) STEP(e2s_share_reads(hf, hc), "share reads");
+                    if (!mine_rc) STEP(e2s_upload_bcr(hf, &d, S.F->bwt.p + p0, S.F->lcp.p + p0, S.F->pairsa.p + p0 * 5), "upload (BCR, all columns)");
+                    if (!mine_rc) STEP(e2s_prefilter_arm(hf, o.mcov_out), "arm");
+                    if (!mine_rc) STEP(e2s_cluster_scan(hf, o.k, o.min_len, 0), "cluster scan (all columns)");
+                    if (!mine_rc) STEP(e2s_stitch(hf, allb.data(), S.nranks, r), "stitch (all columns)");
+                    if (!mine_rc) STEP(e2s_find_candidates(hf, &prm, (uint64_t)r << 40, &n_cand), "find candidates");
+                    ht = hf; S.uploaded[(size_t)r] += 7 * n_prov;
+                } else STEP(grc, "find candidates (gathered)");
+            } else STEP(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand), "find candidates");
             if (!mine_rc && n_cand) {
                 e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
-                const int trc = e2s_call_variants(h, &tp, 0, &nv, &ne, &nb);   // (first_id 0: the text is written once, after the exchange below)
+                const int trc = e2s_call_variants(ht, &tp, 0, &nv, &ne, &nb);   // (first_id 0: the text is written once, after the exchange below)
                 if (trc == E2S_ERR_STATE) { need_host = 1; ne = 0; }
                 else if (trc == E2S_ERR_REF_CRASH) { int z = 0; S.crash.compare_exchange_strong(z, 139); ne = 0; }    // the reference's SIGSEGV / throw
                 else STEP(trc, "tail (consensus, distance, text)");
@@ -277,7 +313,7 @@ void rank_main(Shared& S, int r) {
             if (q < r) before += v[0];
             host_tail |= v[1] != 0;
         }
-        if (!mine_rc && !host_tail && n_cand) STEP(e2s_renumber_snp(h, 1 + before, &nb), "ids and text");
+        if (!mine_rc && !host_tail && n_cand) STEP(e2s_renumber_snp(ht, 1 + before, &nb), "ids and text");
     }
     S.cands[(size_t)r] = n_cand;
     S.events[(size_t)r] = host_tail ? 0 : ne;
@@ -288,7 +324,7 @@ void rank_main(Shared& S, int r) {
     S.snp_bytes[(size_t)r] = (host_tail || !ne) ? 0 : nb;
     if (host_tail && !mine_rc && n_cand) {                          // the packed candidates, for ONE host tail over all ranks (main thread)
         const void* st = nullptr; const uint32_t* of = nullptr; uint64_t nc2 = 0, bytes = 0; uint32_t pw = 4;
-        STEP(e2s_candidates_packed(h, &st, &of, &nc2, &bytes, &pw), "packed candidates");
+        STEP(e2s_candidates_packed(ht, &st, &of, &nc2, &bytes, &pw), "packed candidates");
         if (!mine_rc) {
             S.pk_stream[(size_t)r].assign((const uint8_t*)st, (const uint8_t*)st + bytes);
             S.pk_off8[(size_t)r].assign(of, of + nc2);
@@ -307,7 +343,7 @@ void rank_main(Shared& S, int r) {
     }
     if (!agree(S, r, mine_rc)) { leave(); return; }
     if (my_records) { PSink ps{S.cl_fd, cl_at}; uint64_t w = 0; STEP(e2s_stream_clusters(h, pwrite_sink, &ps, &w), "write .clusters"); }
-    if (S.snp_bytes[(size_t)r]) { PSink ps{S.snp_fd, snp_at}; STEP(e2s_stream_snp(h, pwrite_sink, &ps), "write .snp"); }
+    if (S.snp_bytes[(size_t)r]) { PSink ps{S.snp_fd, snp_at}; STEP(e2s_stream_snp(ht, pwrite_sink, &ps), "write .snp"); }
     (void)agree(S, r, mine_rc);
     leave();
 }
@@ -327,6 +363,7 @@ void help() {
 }  // namespace
 
 int main(int argc, char** argv) {
+    const double t_main = PhaseClock::now();
     if (argc < 3) help();
     Opts o;
     int opt;
@@ -372,7 +409,8 @@ int main(int argc, char** argv) {
     Barrier bar(S.nranks);
     S.bar = &bar;
     S.closed.assign((size_t)S.nranks, 0); S.cands.assign((size_t)S.nranks, 0); S.events.assign((size_t)S.nranks, 0);
-    S.cl_records.assign((size_t)S.nranks, 0); S.snp_bytes.assign((size_t)S.nranks, 0); S.status.assign((size_t)S.nranks, 0); S.form.assign((size_t)S.nranks, 0); S.verdict.assign((size_t)S.nranks, 0);
+    S.cl_records.assign((size_t)S.nranks, 0); S.snp_bytes.assign((size_t)S.nranks, 0); S.uploaded.assign((size_t)S.nranks, 0); S.gathered.assign((size_t)S.nranks, 0);
+    S.slim = !F.gesa && o.lcp == 1 && o.da == 4 && o.pos == 1 && !(getenv("E2S_MGPU_FULL_COLUMNS") && atoi(getenv("E2S_MGPU_FULL_COLUMNS")) != 0); S.status.assign((size_t)S.nranks, 0); S.form.assign((size_t)S.nranks, 0); S.verdict.assign((size_t)S.nranks, 0);
     S.pk_stream.resize((size_t)S.nranks); S.pk_off8.resize((size_t)S.nranks);
     if (const char* e = getenv("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
     S.fail_at = getenv("E2S_MGPU_FAIL_AT") ? getenv("E2S_MGPU_FAIL_AT") : "setup";
@@ -423,5 +461,18 @@ int main(int argc, char** argv) {
     std::cout << "Done. " << cands << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
     if (cands == 0) { std::cerr << "no candidate variant: the reference crashes here (SIGSEGV, clust2snp.cpp:531); no .snp written" << std::endl; return 139; }
     std::cout << events << " events saved to " << S.snp_path << std::endl;
+    if (const char* jp = getenv("E2S_CLI_JSON")) {                  // a perf report in a side file (stdout stays as it is)
+        if (FILE* f = *jp ? fopen(jp, "w") : nullptr) {
+            fprintf(f, "{\"tool\": \"ebwt2snp_mgpu\", \"library\": \"%s\", \"entries\": %llu, \"ranks\": %d, \"form\": \"%s\", \"seconds_wall\": %.6f, \"bytes_uploaded_per_rank\": [",
+                    e2s_version(), (unsigned long long)F.n, S.nranks, S.slim ? "LCP + BWT uploaded, flagged clusters gathered from the files" : "all four columns resident (e2s_resident_job)",
+                    (PhaseClock::now() - t_main) * 1e-3);
+            for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.uploaded[(size_t)r]);
+            fprintf(f, "], \"entries_gathered_per_rank\": [");
+            for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.gathered[(size_t)r]);
+            fprintf(f, "], \"clusters_printed\": %llu, \"candidates\": %llu, \"events\": %llu, \"max_clust_length\": %d}\n", (unsigned long long)closed, (unsigned long long)cands,
+                    (unsigned long long)events, S.mcl);
+            fclose(f);
+        }
+    }
     return 0;
 }

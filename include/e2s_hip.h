@@ -266,6 +266,8 @@ int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n
  * line structure is irregular (a header after a header, no header first, ...), where the reference's line juggling yields
  * text this index cannot express: keep to e2s_snp_from_packed then.
  * Make the reads resident BEFORE e2s_find_candidates: the candidates then stay in HBM instead of crossing PCIe. */
+/* dst uses the reads resident on src (same device) without a copy; src keeps ownership and must outlive dst's use of them */
+int e2s_share_reads(e2s_handle dst, e2s_handle src);
 int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
                      uint32_t max_len);
 int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len);
@@ -352,6 +354,16 @@ int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, i
 int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src, const char* fasta_path,
                          const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len,
                          e2s_byte_sink clusters_sink, void* clusters_user, e2s_byte_sink snp_sink, void* snp_user, e2s_job_report* rep);
+/* The per-cluster pass of ONE shard that holds only LCP + BWT (e2s_upload_lcp_bwt -> e2s_prefilter_arm -> e2s_cluster_scan -> e2s_stitch on
+ * h_scan): the clusters its pre-filter let through -- and the records the EOF rule adds (plan = this rank's e2s_stitch_plan) -- are gathered
+ * from all four columns of `src` (slot 2: random access) on host threads and passed through find_variants (clust2snp.cpp:367-500) on
+ * h_pass, where the candidates then live (e2s_call_variants / e2s_candidates_packed on h_pass; make the reads resident there first).
+ * What the chunked jobs do per chunk, for drivers that hold their shards themselves (bin/ebwt2snp_mgpu: 2 of the 7 bytes per entry
+ * uploaded per rank).  p: n_total, widths, min_len.  *n_gathered (may be NULL): entries gathered.  E2S_ERR_STATE: not applicable to this
+ * shard (.gesa source, other widths, a window too dense for the pre-filter, a cluster of 65536+ entries): upload all four columns and
+ * use e2s_find_candidates. */
+int e2s_find_candidates_gathered(e2s_handle h_scan, e2s_handle h_pass, const e2s_chunk_params* p, const e2s_c2s_options* o, const e2s_egsa_source* src,
+                                 const e2s_stitch_plan_t* plan, int max_clust_length, uint64_t* n_cand, uint64_t* n_gathered);
 /* host-only: the partial statistics of packed 10-byte records (clust2snp.cpp:889-909 without the H4 double count), worker threads */
 int e2s_hist_of_records(const void* recs, uint64_t n_records, e2s_hist* out);
 

@@ -971,11 +971,17 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
         #  small take one piece by default)
         # (tiny: the ranks' fresh handles start with room for 4 candidates -- ranks that overflow say so in the second all-gather and
         #  EVERY rank redoes its step through the stepwise calls)
-        for ranks, shared, pieces, tiny in ((1, False, 0, 0), (2, True, 0, 0), (3, True, 3, 0), (5, True, 0, 0), (1, False, 8, 0), (3, True, 0, 4), (1, False, 0, 4)):
+        # (full = 1: every rank keeps all four columns resident and the step is e2s_resident_job; 0 -- the default for BCR files of the
+        #  default widths -- a rank uploads LCP + BWT only and gathers the flagged clusters' other columns from the mapped files; the
+        #  E2S_CLI_JSON side file says which form ran and how many bytes each rank uploaded)
+        slim_ok = (not meta.get("gesa")) and tuple(meta["xyz"]) == (1, 4, 1)
+        for ranks, shared, pieces, tiny, full in ((1, False, 0, 0, 1), (2, True, 0, 0, 1), (3, True, 3, 0, 1), (5, True, 0, 0, 1), (1, False, 8, 0, 1), (3, True, 0, 4, 1),
+                                                  (1, False, 0, 4, 1), (1, False, 0, 0, 0), (2, True, 0, 0, 0), (3, True, 0, 0, 0), (5, True, 0, 0, 0)):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
-            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0")
+            jpath = str(d / "perf.json")
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FULL_COLUMNS=str(full), E2S_CLI_JSON=jpath)
             if pieces:
                 env["E2S_JOB_PIECES"] = str(pieces)
             if tiny:
@@ -986,6 +992,16 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
             assert "Done. %d clusters saved to output file." % meta["n_printed"] in r.stdout, (meta["name"], ranks, r.stdout)
             assert hashlib.sha256(open(p + ".clusters", "rb").read()).hexdigest() == meta["clusters_sha256"], (meta["name"], ranks)
             assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta), (meta["name"], ranks)
+            import json
+            jr = json.load(open(jpath))
+            os.remove(jpath)
+            slim = slim_ok and not full
+            assert jr["form"].startswith("LCP + BWT") == slim and len(jr["bytes_uploaded_per_rank"]) == ranks, (meta["name"], ranks, jr)
+            n_tot = jr["entries"]
+            if slim:                                                # 2 bytes per provided entry + 7 per gathered one: far below the 7 per entry of the resident form
+                assert sum(jr["bytes_uploaded_per_rank"]) <= 2 * (n_tot + 153 * ranks) + 7 * sum(jr["entries_gathered_per_rank"]), jr
+            else:
+                assert sum(jr["bytes_uploaded_per_rank"]) >= sum(meta["xyz"]) * n_tot + n_tot, jr
 
 
 @pytest.mark.gpu
@@ -1006,7 +1022,7 @@ def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
-            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FAIL_RANK=str(ranks - 1), E2S_MGPU_FAIL_AT=at)
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FAIL_RANK=str(ranks - 1), E2S_MGPU_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="1")
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
             assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
             assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
@@ -1017,12 +1033,12 @@ def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
-            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_JOB_FAIL_RANK=str(fail_rank), E2S_JOB_FAIL_AT=at)
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_JOB_FAIL_RANK=str(fail_rank), E2S_JOB_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="1")
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
             assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
             assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
-    for ranks, shared in ((1, False), (3, True)):
-        env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0")
+    for ranks, shared, full in ((1, False, "1"), (3, True, "1"), (3, True, "0")):
+        env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FULL_COLUMNS=full)
         r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks), "-L", "90", "-R", "20"], capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 139, (ranks, r.returncode, r.stdout[-300:], r.stderr[-300:])
         assert not os.path.exists(IO.snp_out_path(p))
@@ -1086,12 +1102,13 @@ def test_chunked_clust2snp_switches_to_host_tail_midway(tmp_path):
         os.remove(IO.snp_out_path(p))
     # the multi-GPU driver: the rank that meets the bad read rank makes ALL ranks hand their packed candidates to one host tail
     mg = os.path.join(os.path.dirname(exe), "ebwt2snp_mgpu")
-    for ranks, opts in ((1, []), (3, []), (4, ["-L", "65"])):
+    for ranks, opts, full in ((1, [], "1"), (3, [], "1"), (3, [], "0"), (4, ["-L", "65"], "1"), (4, ["-L", "65"], "0")):
         if opts:
             assert O.clust2snp(p, O.c2s_opts(n1, L=65))[0] == 0
             want = open(IO.snp_out_path(p), "rb").read()
             os.remove(IO.snp_out_path(p))
-        r = subprocess.run([mg, "-i", p, "-n", str(n1), "-G", str(ranks)] + opts, env=dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if ranks > 1 else "0"),
+        r = subprocess.run([mg, "-i", p, "-n", str(n1), "-G", str(ranks)] + opts,
+                           env=dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if ranks > 1 else "0", E2S_MGPU_FULL_COLUMNS=full),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (ranks, r.stdout[-500:], r.stderr[-500:])
         assert open(IO.snp_out_path(p), "rb").read() == want and len(want) > 2000, (ranks, opts)
