@@ -46,6 +46,7 @@ WORKLOADS = {
     # ("C2-style block tiled with read-id remap") -- BASELINE.json configs[2], 21 GB of EGSA + 3 GB of reads in HBM
     "c3": (1000000, 150, 10),
     "c3b": (1000000, 150),        # ONE block of c3 (3.02e8 entries): what the full-size tests compare with the reference
+    "c3e": (1000000, 150, 10),    # c3 with 1 % substitution errors in the reads (WORKLOAD_OPTS): sequencing errors split clusters and add single-read alleles
     "c3x": (1000000, 150, 15),    # 4.53e9 entries: SA positions beyond 2^32 on one GPU (stress check, 32 GB of EGSA)
     # BASELINE.json configs[4] on ONE GPU: 3.02e10 entries (211 GB of EGSA, more than HBM) streamed from host memory through the GPU in
     # 100 chunks by the library's chunked job (ebwt2snp_amd/host/chunked.cpp); PCIe-inclusive by construction, run with --workload c5s
@@ -60,15 +61,16 @@ if os.environ.get("E2S_BENCH_C5_COPIES"):
 if os.environ.get("E2S_BENCH_C5_READS"):                            # (tests: a smaller block)
     for _w in ("c5", "c5s"):
         WORKLOADS[_w] = (int(os.environ["E2S_BENCH_C5_READS"]),) + WORKLOADS[_w][1:]
+WORKLOAD_OPTS = {"c3e": dict(error_rate=0.01)}
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
 _TRUTH = {}
 
 
-def build_block(R, L, device):
+def build_block(R, L, device, **opts):
     tr = {}
-    reads, n1 = synth.make_reads(R, L, seed=1, device=device, truth=tr)       # (= synth.synth_case(R, L, seed=1), keeping the planted truth)
+    reads, n1 = synth.make_reads(R, L, seed=1, device=device, truth=tr, **opts)       # (= synth.synth_case(R, L, seed=1), keeping the planted truth)
     e = synth.build_egsa(reads, device=device)
     e["lcp"][-1] = 0
     _TRUTH[(R, L)] = tr
@@ -568,11 +570,11 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         # every rank lives on ONE GPU here: build in turns (four concurrent 2x10^8-entry sorts on one device stalled for minutes)
         for turn in range(world):
             if turn == rank:
-                reads, n1_block, blk0 = build_block(R, L, dev)
+                reads, n1_block, blk0 = build_block(R, L, dev, **WORKLOAD_OPTS.get(name, {}))
                 torch.cuda.synchronize()
             dist.barrier()
     else:
-        reads, n1_block, blk0 = build_block(R, L, dev)
+        reads, n1_block, blk0 = build_block(R, L, dev, **WORKLOAD_OPTS.get(name, {}))
     tiled_strong = copies > 1 and ((world > 1 and scaling == "strong") or bool(a.emulate_rank))
     if tiled_strong:
         blk, n1 = None, n1_block * copies                          # (the whole EGSA is never built: every rank materialises its own range)
@@ -715,6 +717,8 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
                        "snp_events": tot["n_events"], "snp_bytes": tot["snp_bytes"], "max_clust_length": info["mcl"],
                        "input_build_s": round(t_build, 2),
                        "one_enqueue_one_wait": bool(info.get("native", False)),      # e2s_resident_job ran the timed steps (else: the stepwise calls)
+                       "clusters_to_exact_test": info.get("n_flagged"),               # what the pre-filter let through (this rank), and as a share of its records
+                       "flagged_fraction_of_records": (info.get("n_flagged") or 0) / max(1, info["n_ends"]),
                        "step": "arm -> scan+pre-filter -> stitch -> statistics -> .clusters image (2nd stream) || candidates -> GPU tail -> .snp image; inputs and outputs in HBM",
                        "host_phase_ms": {k2: round(v / steps * 1e3, 4) for k2, v in prim["phases"].items()}},
             # the dominant kernel of the timed step.  Algorithmic bytes: LCP 1 + BWT 1 per entry read once, 6 B per record

@@ -429,7 +429,7 @@ class JobReport(C.Structure):
     _fields_ = [("n_closed", C.c_uint64), ("n_records", C.c_uint64), ("max_clust_length", C.c_int32), ("n_chunks", C.c_int32),
                 ("n_clust", C.c_uint64), ("n_bases", C.c_uint64), ("n_candidates", C.c_uint64), ("n_variants", C.c_uint64),
                 ("n_events", C.c_uint64), ("hist", Hist), ("seconds_upload", C.c_double), ("seconds_total", C.c_double), ("snp_bytes", C.c_uint64),
-                ("n_ends", C.c_uint64)]
+                ("n_ends", C.c_uint64), ("n_flagged", C.c_uint64)]
 
 
 class ResidentParams(C.Structure):

@@ -2340,7 +2340,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
         memset(rep, 0, sizeof(*rep));
         rep->n_closed = h->n_closed; rep->n_records = p->want_image ? h->img_records : 0; rep->max_clust_length = jd.mcl; rep->n_chunks = 1;
         rep->n_clust = jd.n_clust; rep->n_bases = jd.n_bases; rep->n_candidates = count; rep->n_variants = h->n_variants; rep->n_events = h->n_events;
-        rep->snp_bytes = h->snp_bytes; rep->n_ends = h->n_ends;
+        rep->snp_bytes = h->snp_bytes; rep->n_ends = h->n_ends; rep->n_flagged = flagged > E2S_SEED_SLOTS ? flagged - E2S_SEED_SLOTS : 0;
     }
     return E2S_OK;
 }

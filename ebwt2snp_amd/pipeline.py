@@ -36,7 +36,7 @@ def resident_job(h, n1, n_total, rank=0, world=1, exchange=exchange_none, k=16, 
             rep = capi.resident_job(h, n1, rank, world, allgather, k, min_len, mcov, pval, k_left, k_right, max_gap, max_err, cons_reads, want_image=pack)
             t("native job")
             out = dict(n_ends=rep.n_ends, n_cand=rep.n_candidates, mcl=rep.max_clust_length, n_clust=rep.n_clust, n_variants=rep.n_variants,
-                       n_events=rep.n_events, snp_bytes=rep.snp_bytes, native=True)
+                       n_events=rep.n_events, snp_bytes=rep.snp_bytes, native=True, n_flagged=rep.n_flagged)
             if pack:
                 out["n_records"] = rep.n_records                   # (known without waiting; h.clusters_image() waits for the layout on the second stream)
             return out

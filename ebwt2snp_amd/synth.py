@@ -20,13 +20,15 @@ _ASCII = torch.tensor([65, 67, 71, 84], dtype=torch.uint8)  # A C G T
 
 
 def make_reads(n_reads_per_indiv, read_len, coverage=20, snp_every=300, indel_every=5000,
-               seed=1, device="cpu", truth=None):
+               seed=1, device="cpu", truth=None, error_rate=0.0):
     """Two individuals from one random genome; individual 2 carries SNPs and 3-bp deletions.
 
     Returns (reads uint8 [2R, L] of ASCII codes, nr_reads1 = R).  Reads 0..R-1 come from
     individual 1, R..2R-1 from individual 2; no reverse complements, no 'N'.
     truth: an optional dict that receives the planted ground truth (genome of individual 1 as ASCII,
     0-based SNP positions on it, REF / ALT letters) -- what snp_vs_vcf (snp_vs_vcf.cpp:108-573) is fed with.
+    error_rate: every base of every read is replaced by one of the three other letters with this probability (sequencing
+    errors: they split clusters and add single-read alleles -- many more clusters reach the per-cluster pass's pre-filter).
     """
     R, L = int(n_reads_per_indiv), int(read_len)
     g = torch.Generator(device="cpu")
@@ -53,6 +55,13 @@ def make_reads(n_reads_per_indiv, read_len, coverage=20, snp_every=300, indel_ev
         idx = pos.to(device)[:, None] + torch.arange(L, device=device)[None, :]
         outs.append(indiv_d[idx])
     codes = torch.cat(outs, 0)                       # [2R, L] in 0..3
+    if error_rate > 0:
+        g3 = torch.Generator(device=codes.device)
+        g3.manual_seed(seed + 2)
+        hit = torch.rand(codes.shape, generator=g3, device=codes.device) < float(error_rate)
+        shift = torch.randint(1, 4, codes.shape, generator=g3, device=codes.device)
+        codes = torch.where(hit, (codes + shift) % 4, codes)
+        del hit, shift
     reads = _ASCII.to(device)[codes]
     return reads, R
 
@@ -164,10 +173,10 @@ def egsa_bruteforce(reads_list):
     return dict(text=text, suff=suff, lcp=lcp, bwt=bwt)
 
 
-def synth_case(n_reads_per_indiv, read_len, seed=1, device="cpu", coverage=20, tail_lcp0=True):
+def synth_case(n_reads_per_indiv, read_len, seed=1, device="cpu", coverage=20, tail_lcp0=True, error_rate=0.0):
     """reads + EGSA for one synthetic configuration.  tail_lcp0 forces the last LCP to 0 so the
     reference's EOF phantom (hazard H1) cannot extend a cluster past the end."""
-    reads, n1 = make_reads(n_reads_per_indiv, read_len, coverage=coverage, seed=seed, device=device)
+    reads, n1 = make_reads(n_reads_per_indiv, read_len, coverage=coverage, seed=seed, device=device, error_rate=error_rate)
     e = build_egsa(reads, device=device)
     if tail_lcp0:
         e["lcp"][-1] = 0

@@ -338,6 +338,7 @@ typedef struct {
     e2s_hist hist;                       /* the merged histogram (before the H4 double count) */
     double seconds_upload, seconds_total;
     uint64_t snp_bytes, n_ends;          /* e2s_resident_job: bytes of this rank's `.snp` text; clusters that END in this shard */
+    uint64_t n_flagged;                  /* e2s_resident_job: clusters the pre-filter let through to the exact per-cluster test */
 } e2s_job_report;
 /* ebwt2clust, chunked: the `.clusters` bytes go to clusters_sink chunk by chunk (file order). */
 int e2s_ebwt2clust_chunked(const e2s_chunk_params* p, const e2s_egsa_source* src, e2s_byte_sink clusters_sink, void* sink_user, e2s_job_report* rep);

@@ -808,6 +808,44 @@ def test_resident_job_images_equal_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_reads_with_sequencing_errors_equal_oracle(tmp_path):
+    """2 x 5000 reads x 100 bp with 1 % substitution errors (synth.make_reads(error_rate=0.01): what bench.py's c3e workload is made of):
+    errors split clusters (half again as many records) and plant single-read alleles, which the pre-filter's per-letter counts reject
+    like any allele below -m -- the resident job (one enqueue), the stepwise calls and the executables in chunks all give the oracle's files"""
+    import subprocess
+    import torch
+    from ebwt2snp_amd import pipeline
+    dev = torch.device("cuda", 0)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for err in (0.0, 0.01):
+        reads, n1, e = synth.synth_case(5000, 100, seed=91, error_rate=err)
+        en = synth.egsa_to_numpy(e)
+        d = tmp_path / ("e%g" % err)
+        d.mkdir()
+        p = str(d / "r.fasta")
+        IO.write_fasta(p, reads.numpy())
+        IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+        assert O.ebwt2clust(p)[0] == 0 and O.clust2snp(p, O.c2s_opts(n1))[0] == 0
+        want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
+        n = en["lcp"].size
+        h = capi.Handle(0)
+        _attach_job_inputs(h, reads.numpy(), en, n, 0, n, 0, 0, dev)
+        for native in (True, False):
+            r = pipeline.resident_job(h, n1, n, native=native)
+            assert bool(r.get("native")) == native, r
+            assert h.fetch_clusters().tobytes() == want_cl and h.fetch_snp().tobytes() == want_snp, (err, native)
+            if native:
+                frac = r["n_flagged"] / max(1, r["n_ends"])
+        h.close()
+        print("error rate %g: %d records, %.4f of them reach the exact per-cluster test" % (err, r["n_ends"], frac))
+        os.remove(p + ".clusters"); os.remove(IO.snp_out_path(p))
+        for exe, args in (("ebwt2clust", []), ("clust2snp", ["-n", str(n1)])):
+            r2 = subprocess.run([os.path.join(root, "bin", exe), "-i", p] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, E2S_CHUNK_ENTRIES="300000"))
+            assert r2.returncode == 0, r2.stderr[-400:]
+        assert open(p + ".clusters", "rb").read() == want_cl and open(IO.snp_out_path(p), "rb").read() == want_snp, err
+
+
+@pytest.mark.gpu
 def test_cli_json_report(tmp_path):
     """E2S_CLI_JSON=<path>: the executables leave a perf report beside their outputs (a `--json` report; an environment
     switch, so that the option strings stay the reference's): one JSON object, counts equal to what the tools print / write"""
