@@ -12,6 +12,7 @@
 #include "../../include/e2s_hip.h"
 #include "e2s_internal.h"
 #include "e2s_plan.h"
+#include "e2s_env.h"
 
 static_assert(sizeof(CandHeader) == sizeof(e2s_cand_header), "candidate header layout");
 static_assert(E2S_MAX_CLUST_LEN == E2S_MAX_CLUST_LEN_K, "max cluster length");
@@ -184,7 +185,7 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
     e2s_ctx* h = new e2s_ctx();
     h->device = device_id;
     if (const char* ev = getenv("E2S_TIMING")) h->timing = std::max(0, std::min(2, atoi(ev)));
-    if (const char* ev = getenv("E2S_STREAM_PER_CAND")) h->stream_per_cand = (uint32_t)std::max(8, atoi(ev));   // (tests: force the overflow path)
+    if (const char* ev = e2s_env_dev("E2S_STREAM_PER_CAND")) h->stream_per_cand = (uint32_t)std::max(8, atoi(ev));   // (tests: force the overflow path)
     // the handle's stream at the highest priority, the second stream (image layout beside the per-cluster pass, a pre-filter beside the
     // scan) at the lowest: where both have work ready, the critical path's blocks are dispatched first
     int prio_lo = 0, prio_hi = 0;
@@ -351,7 +352,7 @@ static int dev_alloc(e2s_ctx* h, void** p, size_t bytes) {
 // kernels -- plane stencil, fused pre-filter, streaming per-cluster pass -- are written for byte columns; egsa's default
 // output has 4-byte LCPs although short reads never exceed 255.  E2S_NARROW_LCP=0 keeps the column as it is.
 static int narrow_lcp(e2s_ctx* h) {
-    static const int enabled = getenv("E2S_NARROW_LCP") ? atoi(getenv("E2S_NARROW_LCP")) : 1;
+    static const int enabled = e2s_env_dev("E2S_NARROW_LCP") ? atoi(e2s_env_dev("E2S_NARROW_LCP")) : 1;
     if (!enabled || h->xb == 1 || !h->n_prov) return E2S_OK;
     uint32_t* mb = (uint32_t*)(h->pin_mail + 3088);
     CK(hipMemsetAsync(h->d_words + 24, 0, 4, h->stream));
@@ -662,7 +663,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     int* const resident = resident_dev[h->device % E2S_MAX_DEVICES];
     if (!resident[h->xb]) {
         resident[h->xb] = e2s_scan_seg_resident_blocks(h->xb);
-        if (const char* ev = getenv("E2S_SCAN_WORKERS")) {        // tuning aid: cap the number of scan workers
+        if (const char* ev = e2s_env_dev("E2S_SCAN_WORKERS")) {        // tuning aid: cap the number of scan workers
             const int cap = atoi(ev);
             if (cap > 0 && cap < resident[h->xb]) resident[h->xb] = cap;
         }
@@ -670,7 +671,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     // as many workers as waves fit on the chip (a whole number per SIMD), tiles dealt out evenly
     uint64_t nb = std::min<uint64_t>(sa.n_tiles, (uint64_t)resident[h->xb]);
     // e2s_prefilter_arm: the pre-filter runs inside the scan kernel (E2S_FUSED=0: beside it, on the second stream)
-    static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
+    static const int fused_env = e2s_env_dev("E2S_FUSED") ? atoi(e2s_env_dev("E2S_FUSED")) : 1;
     const bool armed = first && h->pf_armed;
     const bool fused = armed && fused_env && prefilter_eligible(h);
     if (fused) {
@@ -694,7 +695,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
     const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
     // (E2S_TEST_SEG_CAP: a testing aid -- the first attempt's segments hold that few records, so that a worker overflows its segment)
-    static const int test_seg_cap = getenv("E2S_TEST_SEG_CAP") ? atoi(getenv("E2S_TEST_SEG_CAP")) : 0;
+    static const int test_seg_cap = e2s_env_dev("E2S_TEST_SEG_CAP") ? atoi(e2s_env_dev("E2S_TEST_SEG_CAP")) : 0;
     if (!seg_cap) seg_cap = test_seg_cap > 0 ? (uint64_t)test_seg_cap : (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
     else if (seg_cap == ~0ull) seg_cap = range_entries + 16;          // worst case: room for everything
     seg_cap = (seg_cap + 7) & ~7ull;                                   // (the layout kernel loads four records at once: 16-byte aligned segments)
@@ -904,10 +905,9 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 // segments (k_pack_seg_*), or from contiguous records loaded from a file -- and leaves through two pinned staging buffers: the
 // copy of one chunk runs while the sink consumes the previous one.  The pack can run on the handle's second stream beside the
 // per-cluster pass (e2s_pack_clusters with async != 0): it is bandwidth bound, that pass latency bound.
-// blocks of the records' pack when it runs on the second stream beside other kernels (E2S_PACK_BLOCKS; 0 = one per segment, the default).
-// Measured on c3: throttled to 256 / 512 / 768 / 1024 / 2048 blocks the step takes 3.18 / 2.83 / 2.75 / 2.83 / 2.83 ms against 2.82-2.93
-// unthrottled -- what the per-cluster pass gains, the tail loses when the pack reaches into it; inside the box's run-to-run noise.
-static uint32_t pack_blocks_beside() { static int v = -1; if (v < 0) { const char* e = getenv("E2S_PACK_BLOCKS"); v = e ? atoi(e) : 0; } return (uint32_t)v; }
+// (Throttling the pack's blocks where it runs beside other kernels was measured in round 3 -- 256 ... 2048 blocks: 3.18 / 2.83 / 2.75 / 2.83 /
+// 2.83 ms per c3 step against 2.82-2.93 unthrottled: what the per-cluster pass gains, the tail loses -- and the switch is gone: one block per segment.)
+static uint32_t pack_blocks_beside() { return 0u; }
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
     h->img_valid = false; h->img_pending = false; h->img_records = 0; h->img_total_known = false; h->img_prestitch = false; h->img_stream = st;
     const uint64_t n_raw = h->stitched ? h->n_rec : h->n_ends;
@@ -1244,7 +1244,7 @@ static bool prefilter_eligible(const e2s_ctx* h) {
 static int prefilter_room(e2s_ctx* h, uint64_t est_records, bool for_launch) {
     // (E2S_TEST_FL_CAP: a testing aid -- the list of flagged clusters of a handle's FIRST pre-filter is that short, so that it overflows;
     //  a prepare call ahead of that launch sizes it the same way)
-    static const int test_fl_cap = getenv("E2S_TEST_FL_CAP") ? atoi(getenv("E2S_TEST_FL_CAP")) : 0;
+    static const int test_fl_cap = e2s_env_dev("E2S_TEST_FL_CAP") ? atoi(e2s_env_dev("E2S_TEST_FL_CAP")) : 0;
     const bool tiny = test_fl_cap > 0 && !h->fl_test_done;
     if (for_launch) h->fl_test_done = true;
     return ensure_flagged(h, tiny ? (uint64_t)test_fl_cap + E2S_SEED_SLOTS : std::max<uint64_t>(h->fl_cap, est_records / 8 + 4096 + E2S_SEED_SLOTS));
@@ -1424,8 +1424,8 @@ static int cand_seeds(e2s_ctx* h, const CandArgs& a, bool streaming, uint64_t* n
 // K2b for the clusters a chunk let through on the second stream beside the next chunk (opt-in: E2S_FILTER_CHUNKS; on 2x10^8
 // entries 2 / 4 chunks took 0.34 / 0.44 ms for this phase against 0.26 ms in one piece)
 static int cand_streaming_pass(e2s_ctx* h, const CandArgs& a, const FilterArgs& f, bool defw) {
-    static const int env_chunks = getenv("E2S_FILTER_CHUNKS") ? atoi(getenv("E2S_FILTER_CHUNKS")) : 1;
-    static const long min_tiles = getenv("E2S_FILTER_CHUNK_MIN_TILES") ? atol(getenv("E2S_FILTER_CHUNK_MIN_TILES")) : 4096;
+    static const int env_chunks = e2s_env_dev("E2S_FILTER_CHUNKS") ? atoi(e2s_env_dev("E2S_FILTER_CHUNKS")) : 1;
+    static const long min_tiles = e2s_env_dev("E2S_FILTER_CHUNK_MIN_TILES") ? atol(e2s_env_dev("E2S_FILTER_CHUNK_MIN_TILES")) : 4096;
     const uint64_t w_tiles = (h->n_prov + 4095) / 4096;
     int chunks = std::max(1, std::min(env_chunks, 8));
     if ((long)w_tiles < min_tiles || w_tiles < (uint64_t)chunks) chunks = 1;   // too little work per chunk to hide a launch
@@ -1567,7 +1567,7 @@ extern "C" int e2s_find_candidates(e2s_handle h, const e2s_c2s_params* p, uint64
         count = mb[0];
         const uint64_t flagged = mb[1];
         const uint32_t err = ((const uint32_t*)(mb + 2))[0] | ((const uint32_t*)(mb + 2))[1];     // K2b's word | the pre-filter's
-        if (getenv("E2S_DEBUG_CAND"))
+        if (e2s_env_dev("E2S_DEBUG_CAND"))
             fprintf(stderr, "[cand] attempt %d: streaming %d use_pf %d cand_cap %llu stream_cap %zu | count %llu flagged %llu (fl_cap %llu) stream8 %llu err %x\n", attempt,
                     (int)streaming, (int)use_pf, (unsigned long long)h->cand_cap, h->stream_cap_bytes, (unsigned long long)count, (unsigned long long)flagged,
                     (unsigned long long)h->fl_cap, (unsigned long long)mb[3], err);
@@ -2073,10 +2073,9 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     if (p->world < 1 || p->rank < 0 || p->rank >= p->world || (p->world > 1 && !allgather)) return fail(h, E2S_ERR_ARG, "rank / world / exchange");
     if (!h->have_shard) return fail(h, E2S_ERR_STATE, "no EGSA shard resident");
     // ---- does this form apply?  (decided before anything is enqueued; otherwise: the stepwise calls)
-    static const int fused_env = getenv("E2S_FUSED") ? atoi(getenv("E2S_FUSED")) : 1;
-    static const int job_env = getenv("E2S_RESIDENT_JOB") ? atoi(getenv("E2S_RESIDENT_JOB")) : 1;
+    static const int fused_env = e2s_env_dev("E2S_FUSED") ? atoi(e2s_env_dev("E2S_FUSED")) : 1;
     const bool aligned = (((uintptr_t)h->lcp | (uintptr_t)h->bwt | (uintptr_t)h->da) & 15u) == 0;
-    if (!job_env || !fused_env || p->world > E2S_JOB_MAX_RANKS || h->xb != 1 || h->yb != 4 || !aligned || !h->bwt || !h->pos || !h->da)
+    if (!fused_env || p->world > E2S_JOB_MAX_RANKS || h->xb != 1 || h->yb != 4 || !aligned || !h->bwt || !h->pos || !h->da)
         return fail(h, E2S_ERR_STATE, "resident job: not applicable to this shard (wide or unaligned columns, a missing column, or switched off): use the stepwise calls");
     const e2s_tail_params tp{p->o.k_left, p->o.k_right, p->o.max_gap, p->o.max_err};
     int rc = tail_applicable(h, &tp);
@@ -2122,7 +2121,7 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     ca.len_hi_dev = &d_jd->len_hi;
     // (E2S_JOB_TEST_CAND_CAP: a testing aid -- a fresh handle starts with that few candidate slots, so that the step overflows them, says so
     //  in its mail and is redone through the stepwise calls)
-    static const int test_cand_cap = getenv("E2S_JOB_TEST_CAND_CAP") ? atoi(getenv("E2S_JOB_TEST_CAND_CAP")) : 0;
+    static const int test_cand_cap = e2s_env_dev("E2S_JOB_TEST_CAND_CAP") ? atoi(e2s_env_dev("E2S_JOB_TEST_CAND_CAP")) : 0;
     const bool cand_tiny = test_cand_cap > 0 && !h->cand_test_done && h->cand_cap <= (uint64_t)test_cand_cap;       // (a probe call sizes them the same way)
     const uint64_t cand_want = cand_tiny ? (uint64_t)test_cand_cap : std::max<uint64_t>(std::max<uint64_t>(4096, h->n_prov / 6000), h->cand_cap);
     if ((rc = cand_buffers(h, ca, cand_want))) return rc;
@@ -2136,8 +2135,8 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     // 2.77 / 2.97 / 3.32 / 3.95 ms per step with 1 / 2 / 4 / 8 pieces) -- both kernels are chains of dependent gathers whose rate is set by
     // the waves resident on the chip, and side by side they share the same wave slots and LDS (a quarter of the list takes K2b 290 us
     // beside the consensus where the whole list takes 250 us alone).  Kept as a switch, with its tests; default one piece.
-    static const int cons_beside = getenv("E2S_JOB_CONS_BESIDE") ? atoi(getenv("E2S_JOB_CONS_BESIDE")) : 1;
-    static const int pieces_env = getenv("E2S_JOB_PIECES") ? atoi(getenv("E2S_JOB_PIECES")) : 1;
+    static const int cons_beside = e2s_env_dev("E2S_JOB_CONS_BESIDE") ? atoi(e2s_env_dev("E2S_JOB_CONS_BESIDE")) : 1;
+    static const int pieces_env = e2s_env_dev("E2S_JOB_PIECES") ? atoi(e2s_env_dev("E2S_JOB_PIECES")) : 1;
     const uint32_t n_pieces = !cons_beside || pieces_env < 1 ? 1u : (uint32_t)std::min(pieces_env, E2S_JOB_MAX_PIECES);
     if (cons_beside && !h->stream3) {
         int prio_lo = 0, prio_hi = 0;
@@ -2158,8 +2157,8 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     // ---- ENQUEUE: from here to the second exchange nothing allocates.  Should a HIP call fail all the same, this rank still enqueues the
     // exchanges its peers are going to wait in (`bail` below) -- with a zeroed share, which they read as "a rank of the job is not ok".
     // (E2S_JOB_FAIL_AT = 1 | 2 with E2S_JOB_FAIL_RANK: a testing aid -- this rank's enqueue "fails" before the first exchange / between the two)
-    static const int fail_at = getenv("E2S_JOB_FAIL_AT") ? atoi(getenv("E2S_JOB_FAIL_AT")) : 0;
-    static const int fail_rank = getenv("E2S_JOB_FAIL_RANK") ? atoi(getenv("E2S_JOB_FAIL_RANK")) : -1;
+    static const int fail_at = e2s_env_dev("E2S_JOB_FAIL_AT") ? atoi(e2s_env_dev("E2S_JOB_FAIL_AT")) : 0;
+    static const int fail_rank = e2s_env_dev("E2S_JOB_FAIL_RANK") ? atoi(e2s_env_dev("E2S_JOB_FAIL_RANK")) : -1;
     unsigned long long* const piece_bounds = h->d_pieces; unsigned long long* const piece_snap = h->d_pieces + 9; uint32_t* const piece_done = (uint32_t*)(h->d_pieces + 18);
     int stage = 0;                                              // exchanges enqueued so far
     auto enqueue = [&]() -> int {
@@ -2191,9 +2190,9 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     LCHK("e2s_launch_job_plan");
     // ---- the `.clusters` image on the second stream: laid out from the segments (offsets: k_seg_fix), then finished in place from the
     // plan.  WHERE it starts decides what it runs beside -- it is bandwidth bound, the per-cluster pass and the tail latency bound, and
-    // whatever runs beside it waits longer for every gather (E2S_JOB_IMAGE_AT: 0 behind the plan, 1 behind the ordering pass, 2 behind
-    // the tail's text).  (Right behind k_seg_fix it saturated HBM under the plan's one block: 45-65 us for that.)
-    static const int image_at = getenv("E2S_JOB_IMAGE_AT") ? atoi(getenv("E2S_JOB_IMAGE_AT")) : 0;
+    // whatever runs beside it waits longer for every gather.  Started behind the plan (round 3 measured the alternatives -- behind the ordering
+    // pass, behind the tail's text: the loss moves, it does not shrink; right behind k_seg_fix it saturated HBM under the plan's one block).
+    constexpr int image_at = 0;
     auto image_now = [&]() -> int {
         CK(hipEventRecord(h->ev_img, h->stream));
         CK(hipStreamWaitEvent(h->stream2, h->ev_img, 0));

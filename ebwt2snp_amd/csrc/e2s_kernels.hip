@@ -19,6 +19,7 @@
 #include "e2s_plan.h"
 #include <type_traits>
 #include "e2s_swar.h"
+#include "e2s_env.h"
 
 
 // ----------------------------------------------------------------------------------------------
@@ -2040,7 +2041,7 @@ void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsign
         resident = 3 * 1024;
         const int fit = 4 * resident_blocks((const void*)k_cluster_filter2, 256, 0);
         if (fit < resident) resident = fit;
-        if (const char* ev = getenv("E2S_FILTER_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < fit) resident = cap; }
+        if (const char* ev = e2s_env_dev("E2S_FILTER_WORKERS")) { const int cap = atoi(ev); if (cap > 0 && cap < fit) resident = cap; }
     }
     if (tile_hi <= tile_lo) return;
     a.w_tile0 = tile_lo; a.w_tiles = tile_hi - tile_lo;
@@ -2146,13 +2147,11 @@ void e2s_launch_snapshot(const unsigned long long* src, unsigned long long* dst,
 void e2s_launch_flagged_lists(const CandArgs& a, const unsigned long long* lo_dev, const unsigned long long* n_dev, bool def_widths, hipStream_t st) {
     // room for two rounds' worst case and, at usual list lengths, ~200 packed candidates between two global reservations
     const uint32_t max8 = (16u + (4u + a.pos_pack) * 2u * a.list_cap + 7u) >> 3;
-    static const int env_cap8 = getenv("E2S_K2B_CAP8") ? atoi(getenv("E2S_K2B_CAP8")) : 0;
-    const uint32_t cap8 = std::max<uint32_t>(env_cap8 > 0 ? (uint32_t)env_cap8 : 3072u, 2u * 16u * max8);
+    const uint32_t cap8 = std::max<uint32_t>(3072u, 2u * 16u * max8);
     const size_t dyn = (size_t)cap8 * 8;
-    static const int env_blocks = getenv("E2S_K2B_BLOCKS") ? atoi(getenv("E2S_K2B_BLOCKS")) : 0;
     // c2 (2x10^4 flagged clusters): 512 / 1024 / 2048 / 4096 blocks -> 0.124 / 0.117 / 0.131 / 0.177 ms for the phase; c3 (3x10^5): 1024 / 4096 ->
     // 0.889 / 0.845 ms: the caller asks for more blocks when it expects many clusters
-    const unsigned blocks = env_blocks > 0 ? (unsigned)env_blocks : (a.blocks_hint ? a.blocks_hint : 1024u);
+    const unsigned blocks = a.blocks_hint ? a.blocks_hint : 1024u;
     if (dyn > 48 * 1024) {
         (void)hipFuncSetAttribute((const void*)k_flagged_lists<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         (void)hipFuncSetAttribute((const void*)k_flagged_lists<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/e2s_hip.h"
+#include "../csrc/e2s_env.h"
 
 extern "C" void e2s_internal_set_error(e2s_handle h, const char* msg);   // e2s_capi.hip: h == nullptr: this thread's handle-less message
 extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src);    // e2s_capi.hip (not part of the public ABI)
@@ -371,7 +372,7 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     // pre-filter inside; DA and positions are read only for the clusters it lets through (~0.5 % of the entries), gathered on the host
     // once statistics() has said how long a cluster may be.  (E2S_CHUNK_TWO_PASS=1, other widths, `.gesa`: pass A = the LCP column,
     // pass B = all four columns again.)
-    static const int two_pass_env = getenv("E2S_CHUNK_TWO_PASS") ? atoi(getenv("E2S_CHUNK_TWO_PASS")) : 0;
+    static const int two_pass_env = e2s_env_dev("E2S_CHUNK_TWO_PASS") ? atoi(e2s_env_dev("E2S_CHUNK_TWO_PASS")) : 0;
     const bool slim = !two_pass_env && !src->gesa && p->lcp_bytes == 1 && p->da_bytes == 4 && p->pos_bytes == 1;
     // pass A: ebwt2clust: records out, descriptors and statistics of every chunk kept (slim: and the clusters the pre-filter lets through)
     ScanPass sp;
@@ -487,7 +488,7 @@ extern "C" int e2s_clust2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_op
     double up_s = 0;
     // BCR files of the default widths: 2 of the 7 bytes per entry go up (the record pre-filter reads the BWT only), the clusters it lets
     // through are gathered on the host from all four columns (as in e2s_ebwt2snp_chunked)
-    static const int two_pass_env = getenv("E2S_CHUNK_TWO_PASS") ? atoi(getenv("E2S_CHUNK_TWO_PASS")) : 0;
+    static const int two_pass_env = e2s_env_dev("E2S_CHUNK_TWO_PASS") ? atoi(e2s_env_dev("E2S_CHUNK_TWO_PASS")) : 0;
     const bool slim = !two_pass_env && !src->gesa && p->lcp_bytes == 1 && p->da_bytes == 4 && p->pos_bytes == 1;
     // one pass over the chunks; host_only: the host tail from the first chunk on (the second attempt, below)
     auto pass = [&](bool host_only) -> int {

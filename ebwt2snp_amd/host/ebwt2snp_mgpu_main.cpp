@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "egsa_files.hpp"
+#include "../csrc/e2s_env.h"
 
 namespace {
 
@@ -412,8 +413,8 @@ int main(int argc, char** argv) {
     S.cl_records.assign((size_t)S.nranks, 0); S.snp_bytes.assign((size_t)S.nranks, 0); S.uploaded.assign((size_t)S.nranks, 0); S.gathered.assign((size_t)S.nranks, 0);
     S.slim = !F.gesa && o.lcp == 1 && o.da == 4 && o.pos == 1 && !(getenv("E2S_MGPU_FULL_COLUMNS") && atoi(getenv("E2S_MGPU_FULL_COLUMNS")) != 0); S.status.assign((size_t)S.nranks, 0); S.form.assign((size_t)S.nranks, 0); S.verdict.assign((size_t)S.nranks, 0);
     S.pk_stream.resize((size_t)S.nranks); S.pk_off8.resize((size_t)S.nranks);
-    if (const char* e = getenv("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
-    S.fail_at = getenv("E2S_MGPU_FAIL_AT") ? getenv("E2S_MGPU_FAIL_AT") : "setup";
+    if (const char* e = e2s_env_dev("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
+    S.fail_at = e2s_env_dev("E2S_MGPU_FAIL_AT") ? e2s_env_dev("E2S_MGPU_FAIL_AT") : "setup";
     // the reads: ONE index of the FASTA for all ranks (an irregular or unreadable file: no GPU tail, the host tail decides)
     e2s_fasta_index* fix = nullptr;
     S.reads_ok = e2s_fasta_index_open(o.input.c_str(), &fix, &S.rd_text, &S.rd_bytes, &S.rd_start, &S.rd_len, &S.rd_n, &S.rd_max) == E2S_OK && S.rd_n > 0;

@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "../../include/e2s_hip.h"
+#include "../csrc/e2s_env.h"
 
 namespace {
 
@@ -202,7 +203,7 @@ bool fetch_reads(const char* path, const std::vector<uint64_t>& ranks, ReadStore
     LineReader R(nullptr, 0);
     const bool ok = f.open(path);
     if (ok) {
-        const long par_min = getenv("E2S_TAIL_PAR_MIN_BYTES") ? atol(getenv("E2S_TAIL_PAR_MIN_BYTES")) : (8L << 20);
+        const long par_min = e2s_env_dev("E2S_TAIL_PAR_MIN_BYTES") ? atol(e2s_env_dev("E2S_TAIL_PAR_MIN_BYTES")) : (8L << 20);
         const unsigned T = tail_threads(f.n, (uint64_t)std::max(par_min, 1L));
         if (T > 1 && f.n >= (size_t)par_min && fetch_reads_parallel(S, ranks, T)) { if (pieces) *pieces = T; return true; }
     }
