@@ -1474,18 +1474,19 @@ static int cand_record_pass(e2s_ctx* h, const CandArgs& a, const e2s_c2s_params*
 // SA order and offsets follow without a host round trip (the kernels read the candidate count on the device); the last kernel
 // writes counts and error words into the pinned mailbox
 static int cand_order_and_mail(e2s_ctx* h, const CandArgs& a, uint32_t* bad = nullptr, unsigned long long* zero = nullptr, uint64_t n_zero = 0,
-                               uint64_t key_lo = ~0ull, uint64_t key_span = 0) {
+                               uint64_t key_lo = ~0ull, uint64_t key_span = 0, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     const unsigned long long* n_dev = (const unsigned long long*)(h->d_scalars + 1);
     if (key_lo == ~0ull) { key_lo = h->prov_lo << 2; key_span = (h->n_prov + 1) << 2; }       // keys = (SA position << 2) | pair, spread over the shard's range
     e2s_launch_cand_order((const unsigned long long*)h->d_keys, h->cand_cap, n_dev, key_lo, key_span, h->d_rank,
-                          h->d_order, h->stream, true);
+                          h->d_order, st, true);
     LCHK("e2s_launch_cand_order");
     void* dev_mail = nullptr;
     CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
     e2s_launch_cand_offsets(h->d_order, h->d_slot_off8, h->cand_cap, n_dev, (const unsigned long long*)(h->d_scalars + 6),
                             (uint32_t*)(a.host_stream + h->stream_ord_off), (const unsigned long long*)(h->d_scalars + 2), h->d_words + 1,
                             h->d_words + 20, (unsigned long long*)((uint8_t*)dev_mail + 3328), bad, h->fl_cap, a.stream8_cap, zero, n_zero, (uint32_t*)h->d_rank,
-                            e2s_cand_order_buckets(h->cand_cap) + 1u, h->stream);
+                            e2s_cand_order_buckets(h->cand_cap) + 1u, st);
     h->ko_clean = true;                                         // (k_cand_offsets leaves the bucket counts at zero)
     LCHK("e2s_launch_cand_offsets");
     return E2S_OK;
@@ -2211,7 +2212,30 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     unsigned long long* totals = h->d_part;
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
-    if (cons_beside) {
+    if (cons_beside && n_pieces == 1) {
+        // The consensus needs the candidates, not their order: it runs BY SLOT beside the ordering pass.  The CRITICAL chain -- lists ->
+        // consensus -> sums -> text -- stays on the handle's stream with nothing but the fork's event between its kernels; the ordering pass
+        // (five small kernels, long done when the consensus ends) goes to the third stream.  (Round 3 had it the other way round: the
+        // consensus behind a cross-stream wait, 15 us after the lists ended, and the sums behind another, 10-13 us after the consensus.)
+        // (the tail's totals, kept count and error word were cleared by k_job_plan; the groups' sums are WRITTEN by k_tail_group_sums, not added to)
+        TailArgs tb = ta;
+        tb.by_slot = 1u; tb.off8 = h->d_slot_off8;
+        e2s_launch_flagged_lists(ca, nullptr, (const unsigned long long*)(h->d_scalars + 2), defw, h->stream);
+        LCHK("e2s_launch_flagged_lists");
+        CK(hipEventRecord(h->ev_chunk[0], h->stream));
+        CK(hipStreamWaitEvent(h->stream3, h->ev_chunk[0], 0));
+        TREC(2, 7, h->stream);
+        TREC(2, 2, h->stream);
+        e2s_launch_consensus(tb, h->list_cap, h->stream);
+        LCHK("e2s_launch_consensus");
+        if ((rc = cand_order_and_mail(h, ca, d_cand_bad, nullptr, 0, ~0ull, 0, h->stream3))) return rc;
+        CK(hipEventRecord(h->ev_cons, h->stream3));
+        CK(hipStreamWaitEvent(h->stream, h->ev_cons, 0));
+        ta.slot_of = h->d_order;
+        e2s_launch_tail_group_sums(ta, (uint32_t)ng, h->stream);
+        LCHK("e2s_launch_tail_group_sums");
+        h->tail_by_slot = true;
+    } else if (cons_beside) {
         // (the tail's totals, kept count and error word were cleared by k_job_plan; the groups' sums are WRITTEN by k_tail_group_sums, not added to)
         TailArgs tb = ta;
         tb.by_slot = 1u; tb.off8 = h->d_slot_off8;

@@ -508,7 +508,8 @@ constexpr u32 TL_HDR_STRIDE = 148;                                  // >= the lo
 // mail_src / mail_dst / mail_words (the resident job): block 0 also delivers the step's mail -- the scan's descriptor and statistics and the
 // job's record, all written by EARLIER kernels of the stream (and, just above, by this block's first thread) -- into the host's pinned
 // mailbox: the copy engine's turn behind the last kernel (a launch gap + ~4 us) is gone, and the host's one wait is for this kernel
-__global__ __launch_bounds__(1024) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, const unsigned long long* first_id_dev, uint8_t* out,
+// (launch bounds: 8 waves per SIMD = 64 VGPRs -- at 66 the compiler's answer was 7 waves per SIMD, i.e. ONE 16-wave block per CU instead of two: 97 -> 144 us on c3)
+__global__ __launch_bounds__(1024, 8) void k_tail_write(TailArgs a, const unsigned long long* part_excl, u64 first_id, const unsigned long long* first_id_dev, uint8_t* out,
                                                      u64 out_cap, const unsigned long long* ids2, int world, int rank, JobDev* jd,
                                                      const unsigned long long* mail_src, unsigned long long* mail_dst, u32 mail_words) {
     if (first_id_dev) first_id = *first_id_dev;
