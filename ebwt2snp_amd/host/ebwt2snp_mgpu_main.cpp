@@ -150,6 +150,8 @@ void rank_main(Shared& S, int r) {
     e2s_handle h = nullptr, hc = nullptr, hf = nullptr;        // hc (slim): the reads, the gathered per-cluster pass and the tail; hf: a shard that needs all four columns after all
     hipStream_t xs = nullptr; void *d_send = nullptr, *d_recv = nullptr;
     int mine_rc = 0;
+    PhaseClock pc;                                               // E2S_CLI_TIMING=1: rank 0's phases on stderr
+    pc.on = pc.on && r == 0;
     const uint64_t n = S.F->n;
     // contiguous SA ranges of (almost) equal size; the cuts may fall anywhere, the stitch takes care of clusters that cross them
     const uint64_t lo = n * (uint64_t)r / (uint64_t)S.nranks, hi = n * (uint64_t)(r + 1) / (uint64_t)S.nranks;
@@ -175,6 +177,7 @@ void rank_main(Shared& S, int r) {
             S.uploaded[(size_t)r] = (uint64_t)(o.lcp + o.da + o.pos + 1) * n_prov;
         }
     }
+    pc.mark("rank 0: handles, reads and shard uploaded");
     if (S.fail_rank == r && S.fail_at == "setup") { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (setup)" << std::endl; mine_rc = E2S_ERR_HIP; }
     e2s_resident_params rp{};
     rp.k = o.k; rp.min_len = o.min_len; rp.rank = r; rp.world = S.nranks; rp.want_image = 1;
@@ -237,6 +240,7 @@ void rank_main(Shared& S, int r) {
             done = true; n_cand = 0; ne = 0; nb = 0;
         }
         S.bar->wait();                                              // (every rank has read the verdicts)
+        pc.mark("rank 0: e2s_resident_job (one enqueue, one wait)");
     }
     // ---- the stepwise calls with the same two exchanges ----
     if (!done) {
@@ -247,6 +251,7 @@ void rank_main(Shared& S, int r) {
             STEP(e2s_boundary_desc(h, (e2s_boundary*)mine.data()), "boundary");
             STEP(e2s_scan_stats_desc(h, (e2s_scan_stats*)(mine.data() + sizeof(e2s_boundary))), "scan statistics");
         }
+        pc.mark("rank 0: scan (+ pre-filter), descriptor");
         if (!agree(S, r, mine_rc)) { leave(); return; }
         if (all_gather(S, r, mine.data(), BLOB, all, d_send, d_recv, xs)) mine_rc = E2S_ERR_HIP;
         std::vector<e2s_boundary> allb((size_t)S.nranks); std::vector<e2s_scan_stats> alls((size_t)S.nranks);
@@ -267,6 +272,7 @@ void rank_main(Shared& S, int r) {
             else if (rc && !mine_rc) mine_rc = rc;
             if (r == 0) S.mcl = mcl;
         }
+        pc.mark("rank 0: exchange 1, stitch, statistics, image layout started");
         if (!mine_rc && !S.crash.load()) {
             e2s_c2s_params prm{};
             prm.nr_reads1 = o.nr_reads1; prm.k_left = o.k_left; prm.k_right = o.k_right; prm.mcov_out = o.mcov_out;
@@ -295,6 +301,7 @@ void rank_main(Shared& S, int r) {
                     ht = hf; S.uploaded[(size_t)r] += 7 * n_prov;
                 } else STEP(grc, "find candidates (gathered)");
             } else STEP(e2s_find_candidates(h, &prm, (uint64_t)r << 40, &n_cand), "find candidates");
+            pc.mark(S.slim ? "rank 0: flagged clusters gathered from the files + per-cluster pass" : "rank 0: per-cluster pass");
             if (!mine_rc && n_cand) {
                 e2s_tail_params tp{o.k_left, o.k_right, o.max_gap, o.max_err};
                 const int trc = e2s_call_variants(ht, &tp, 0, &nv, &ne, &nb);   // (first_id 0: the text is written once, after the exchange below)
@@ -303,6 +310,7 @@ void rank_main(Shared& S, int r) {
                 else STEP(trc, "tail (consensus, distance, text)");
             }
         }
+        pc.mark("rank 0: tail (consensus, distance)");
         // the second exchange: events per rank, for sequential ids
         if (!agree(S, r, mine_rc)) { leave(); return; }
         std::vector<uint8_t> alle;
@@ -316,6 +324,7 @@ void rank_main(Shared& S, int r) {
         }
         if (!mine_rc && !host_tail && n_cand) STEP(e2s_renumber_snp(ht, 1 + before, &nb), "ids and text");
     }
+    pc.mark("rank 0: step done (exchange 2, ids and text)");
     S.cands[(size_t)r] = n_cand;
     S.events[(size_t)r] = host_tail ? 0 : ne;
     // ---- the files: every rank learns every rank's sizes through this process's memory, then all write at once ----
@@ -346,6 +355,7 @@ void rank_main(Shared& S, int r) {
     if (my_records) { PSink ps{S.cl_fd, cl_at}; uint64_t w = 0; STEP(e2s_stream_clusters(h, pwrite_sink, &ps, &w), "write .clusters"); }
     if (S.snp_bytes[(size_t)r]) { PSink ps{S.snp_fd, snp_at}; STEP(e2s_stream_snp(ht, pwrite_sink, &ps), "write .snp"); }
     (void)agree(S, r, mine_rc);
+    pc.mark("rank 0: both files written");
     leave();
 }
 
@@ -417,7 +427,9 @@ int main(int argc, char** argv) {
     S.fail_at = e2s_env_dev("E2S_MGPU_FAIL_AT") ? e2s_env_dev("E2S_MGPU_FAIL_AT") : "setup";
     // the reads: ONE index of the FASTA for all ranks (an irregular or unreadable file: no GPU tail, the host tail decides)
     e2s_fasta_index* fix = nullptr;
+    PhaseClock pcm;
     S.reads_ok = e2s_fasta_index_open(o.input.c_str(), &fix, &S.rd_text, &S.rd_bytes, &S.rd_start, &S.rd_len, &S.rd_n, &S.rd_max) == E2S_OK && S.rd_n > 0;
+    pcm.mark("FASTA indexed (one index for all ranks)");
     const std::string cl_path = o.input + ".clusters";
     S.cl_fd = ::open(cl_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (S.cl_fd < 0) { std::cerr << "cannot create " << cl_path << ": " << strerror(errno) << std::endl; if (fix) e2s_fasta_index_close(fix); return 2; }
