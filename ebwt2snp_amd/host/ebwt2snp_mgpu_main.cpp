@@ -17,7 +17,10 @@
 // No rank ever waits for one that failed: before every exchange the ranks agree -- a barrier over their status in this process --
 // whether all of them are still in; if not, all leave.  (E2S_MGPU_FAIL_RANK=r, E2S_MGPU_FAIL_AT=setup|job: inject a failure: tests;
 // E2S_JOB_FAIL_RANK=r, E2S_JOB_FAIL_AT=1|2: inside e2s_resident_job, before the first exchange / between the two.)
-// -G 1 runs the same code with a one-rank communicator.
+// -G 1 runs the same code without a communicator (one rank has nothing to exchange; E2S_MGPU_FORCE_RCCL=1 under E2S_DEV=1 creates a
+// one-rank communicator all the same: how the RCCL calls are exercised on a one-GPU box).  ncclCommInitAll (1.7 s) runs in a thread of
+// its own beside the uploads, the FASTA is indexed beside them too, and a job that went through ends with _exit: E2S_CLI_TIMING=1 shows
+// where the time of a run goes.
 // E2S_MGPU_SHARED_DEVICE=1 puts every rank on GPU 0 and exchanges through host memory (RCCL refuses two ranks on one device):
 // a rehearsal of the N-rank logic on a one-GPU box, not a way to run jobs.
 #include <fcntl.h>
@@ -58,9 +61,18 @@ class Barrier {
     int n_, cnt_ = 0, gen_ = 0; std::mutex m_; std::condition_variable cv_;
 };
 
+struct Shared;
+void latch_set(Shared& S, int& what, int v);
+int latch_wait(Shared& S, const int& what);
+
 struct Shared {
     Opts o; EgsaFiles* F; int nranks; bool shared_device;
     std::vector<ncclComm_t> comms;
+    bool teardown = false;                    // free every handle and communicator before the process ends (development: leak checks)
+    bool use_rccl = false;                    // more than one rank on separate GPUs (or E2S_MGPU_FORCE_RCCL=1: the RCCL path with ONE rank, tests)
+    // two things the ranks' threads wait for while they already create handles and upload their shards: the communicators
+    // (ncclCommInitAll: 1.7 s on an MI355X box, started in a thread of its own) and the one index of the FASTA (main thread)
+    std::mutex latch_m; std::condition_variable latch_cv; int comms_state = 0, reads_state = 0;     // 0 pending, 1 ready, -1 failed
     std::vector<uint8_t> host_blob;           // rehearsal: the exchange through host memory
     Barrier* bar;
     // the reads, indexed once
@@ -80,6 +92,9 @@ struct Shared {
     int fail_rank = -1; std::string fail_at;
     std::mutex log_m;
 };
+
+void latch_set(Shared& S, int& what, int v) { { std::lock_guard<std::mutex> lk(S.latch_m); what = v; } S.latch_cv.notify_all(); }
+int latch_wait(Shared& S, const int& what) { std::unique_lock<std::mutex> lk(S.latch_m); S.latch_cv.wait(lk, [&]() { return what != 0; }); return what; }
 
 constexpr size_t BLOB = sizeof(e2s_boundary) + sizeof(e2s_scan_stats);
 
@@ -120,6 +135,7 @@ int all_gather(Shared& S, int r, const void* mine, size_t bytes, std::vector<uin
         S.bar->wait();
         return 0;
     }
+    if (!S.use_rccl) { memcpy(all.data(), mine, bytes); return 0; }          // (one rank: nothing to exchange)
     if (hipMemcpyAsync(d_send, mine, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
     if (ncclAllGather(d_send, d_recv, bytes, ncclChar, S.comms[(size_t)r], st) != ncclSuccess) return 2;
     if (hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, st) != hipSuccess) return 3;
@@ -131,7 +147,8 @@ struct AgCtx { Shared* S; int r; };
 int job_allgather(void* user, const void* d_send, void* d_recv, size_t bytes, void* stream) {
     AgCtx* c = (AgCtx*)user;
     Shared& S = *c->S;
-    if (!S.shared_device) return ncclAllGather(d_send, d_recv, bytes, ncclChar, S.comms[(size_t)c->r], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+    if (S.use_rccl) return ncclAllGather(d_send, d_recv, bytes, ncclChar, S.comms[(size_t)c->r], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+    if (!S.shared_device) return hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : 1;   // (never called: one rank)
     // rehearsal (all ranks on one device): through host memory, which means waiting for the stream here
     std::vector<uint8_t> mine(bytes), all(bytes * (size_t)S.nranks);
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(mine.data(), d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
@@ -158,13 +175,12 @@ void rank_main(Shared& S, int r) {
     const uint32_t hl = (uint32_t)std::min<uint64_t>(lo, E2S_MAX_CLUST_LEN + 2), hr = (uint32_t)std::min<uint64_t>(n - hi, 1);
     // ---- setup: everything that can fail before the first exchange (handle, exchange buffers, reads, shard) ----
     STEP(e2s_create(dev, &h), "e2s_create");
-    if (!mine_rc && !S.shared_device) {
+    if (!mine_rc && S.use_rccl) {
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc(&d_send, BLOB) != hipSuccess || hipMalloc(&d_recv, BLOB * (size_t)S.nranks) != hipSuccess) mine_rc = E2S_ERR_HIP;
     }
     if (!mine_rc && S.slim) STEP(e2s_create(dev, &hc), "e2s_create (per-cluster pass)");
     e2s_handle const hr_ = S.slim ? hc : h;                     // where the reads live
-    if (!mine_rc && S.reads_ok) STEP(e2s_upload_reads(hr_, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads");   // every rank holds all reads
     e2s_shard_desc d{};
     d.global_offset = lo; d.n_entries = hi - lo; d.n_total = n; d.halo_left = hl; d.halo_right = hr;
     d.lcp_bytes = o.lcp; d.da_bytes = o.da; d.pos_bytes = o.pos;
@@ -177,7 +193,12 @@ void rank_main(Shared& S, int r) {
             S.uploaded[(size_t)r] = (uint64_t)(o.lcp + o.da + o.pos + 1) * n_prov;
         }
     }
-    pc.mark("rank 0: handles, reads and shard uploaded");
+    pc.mark("rank 0: handle(s), shard uploaded");
+    // the reads: every rank holds all of them, uploaded from the ONE index the main thread has been building meanwhile
+    (void)latch_wait(S, S.reads_state);
+    if (!mine_rc && S.reads_ok) STEP(e2s_upload_reads(hr_, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads");
+    if (S.use_rccl && latch_wait(S, S.comms_state) < 0 && !mine_rc) mine_rc = E2S_ERR_HIP;       // (ncclCommInitAll failed: said so on stderr)
+    pc.mark("rank 0: reads uploaded (waited for the FASTA index and the communicators)");
     if (S.fail_rank == r && S.fail_at == "setup") { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (setup)" << std::endl; mine_rc = E2S_ERR_HIP; }
     e2s_resident_params rp{};
     rp.k = o.k; rp.min_len = o.min_len; rp.rank = r; rp.world = S.nranks; rp.want_image = 1;
@@ -217,7 +238,7 @@ void rank_main(Shared& S, int r) {
         } else if (jrc == E2S_ERR_CAPACITY) S.verdict[(size_t)r] = 0;    // (on every rank alike -- the stepwise calls below)
         else {
             STEP(jrc, "resident job");
-            if (jrc == E2S_ERR_IO && !S.shared_device) {
+            if (jrc == E2S_ERR_IO && S.use_rccl) {
                 // the exchange itself failed on this rank: its peers may sit in a collective that will never complete -- abort every communicator
                 // (their pending collectives end with an error) and let the job end
                 std::lock_guard<std::mutex> lk(S.log_m);
@@ -354,9 +375,11 @@ void rank_main(Shared& S, int r) {
     if (!agree(S, r, mine_rc)) { leave(); return; }
     if (my_records) { PSink ps{S.cl_fd, cl_at}; uint64_t w = 0; STEP(e2s_stream_clusters(h, pwrite_sink, &ps, &w), "write .clusters"); }
     if (S.snp_bytes[(size_t)r]) { PSink ps{S.snp_fd, snp_at}; STEP(e2s_stream_snp(ht, pwrite_sink, &ps), "write .snp"); }
-    (void)agree(S, r, mine_rc);
+    const bool all_fine = agree(S, r, mine_rc);
     pc.mark("rank 0: both files written");
-    leave();
+    // (a job that went through leaves its handles to the end of the process: freeing tens of GB of HBM buffer by buffer took 0.7-1.2 s of a
+    //  0.8-s job on the full c3 files; E2S_MGPU_TEARDOWN=1 under E2S_DEV=1 frees everything the slow way)
+    if (!all_fine || S.teardown) leave();
 }
 
 void help() {
@@ -400,8 +423,10 @@ int main(int argc, char** argv) {
         }
     }
     if (o.input.empty() || o.nr_reads1 == 0 || o.gpus < 1) help();
+    PhaseClock pcs;
     EgsaFiles F;
     F.open_or_die(o.input, o.lcp, o.da, o.pos);
+    pcs.mark("index files mapped");
     Shared S;
     S.o = o; S.F = &F; S.nranks = o.gpus;
     S.shared_device = getenv("E2S_MGPU_SHARED_DEVICE") != nullptr && atoi(getenv("E2S_MGPU_SHARED_DEVICE")) != 0;
@@ -409,13 +434,23 @@ int main(int argc, char** argv) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::cerr << "GPU unavailable (this build has no CPU path)" << std::endl; return 2; }
     if (!S.shared_device && S.nranks > ndev) { std::cerr << "-G " << S.nranks << " but only " << ndev << " GPU(s) visible" << std::endl; return 2; }
-    if (!S.shared_device) {
-        // one communicator per GPU, all in this process (ncclCommInitAll), each driven by its own thread
-        std::vector<int> devs((size_t)S.nranks);
-        for (int r = 0; r < S.nranks; ++r) devs[(size_t)r] = r;
-        S.comms.resize((size_t)S.nranks);
-        const ncclResult_t nr = ncclCommInitAll(S.comms.data(), S.nranks, devs.data());
-        if (nr != ncclSuccess) { std::cerr << "ncclCommInitAll failed: " << ncclGetErrorString(nr) << std::endl; return 2; }
+    // RCCL: one communicator per GPU, all in this process (ncclCommInitAll), each driven by its rank's thread -- only where there is
+    // something to exchange (one rank has nothing: ncclCommInitAll alone costs 1.7 s of a 0.8-s job), and created in a thread of its own
+    // while the ranks upload their shards and the FASTA is indexed; a rank waits for it right before its first exchange
+    S.use_rccl = !S.shared_device && (S.nranks > 1 || (e2s_env_dev("E2S_MGPU_FORCE_RCCL") && atoi(e2s_env_dev("E2S_MGPU_FORCE_RCCL")) != 0));
+    S.teardown = e2s_env_dev("E2S_MGPU_TEARDOWN") && atoi(e2s_env_dev("E2S_MGPU_TEARDOWN")) != 0;
+    std::thread comm_thread;
+    if (S.use_rccl) {
+        S.comms.assign((size_t)S.nranks, nullptr);
+        comm_thread = std::thread([&S]() {
+            PhaseClock pcc;
+            std::vector<int> devs((size_t)S.nranks);
+            for (int r = 0; r < S.nranks; ++r) devs[(size_t)r] = r;
+            const ncclResult_t nr = ncclCommInitAll(S.comms.data(), S.nranks, devs.data());
+            if (nr != ncclSuccess) { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "ncclCommInitAll failed: " << ncclGetErrorString(nr) << std::endl; }
+            pcc.mark("RCCL communicators (ncclCommInitAll, beside the uploads)");
+            latch_set(S, S.comms_state, nr == ncclSuccess ? 1 : -1);
+        });
     }
     Barrier bar(S.nranks);
     S.bar = &bar;
@@ -425,25 +460,30 @@ int main(int argc, char** argv) {
     S.pk_stream.resize((size_t)S.nranks); S.pk_off8.resize((size_t)S.nranks);
     if (const char* e = e2s_env_dev("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
     S.fail_at = e2s_env_dev("E2S_MGPU_FAIL_AT") ? e2s_env_dev("E2S_MGPU_FAIL_AT") : "setup";
-    // the reads: ONE index of the FASTA for all ranks (an irregular or unreadable file: no GPU tail, the host tail decides)
     e2s_fasta_index* fix = nullptr;
-    PhaseClock pcm;
-    S.reads_ok = e2s_fasta_index_open(o.input.c_str(), &fix, &S.rd_text, &S.rd_bytes, &S.rd_start, &S.rd_len, &S.rd_n, &S.rd_max) == E2S_OK && S.rd_n > 0;
-    pcm.mark("FASTA indexed (one index for all ranks)");
     const std::string cl_path = o.input + ".clusters";
     S.cl_fd = ::open(cl_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    if (S.cl_fd < 0) { std::cerr << "cannot create " << cl_path << ": " << strerror(errno) << std::endl; if (fix) e2s_fasta_index_close(fix); return 2; }
+    if (S.cl_fd < 0) { std::cerr << "cannot create " << cl_path << ": " << strerror(errno) << std::endl; if (comm_thread.joinable()) comm_thread.join(); return 2; }
     S.snp_path = o.input.substr(0, o.input.rfind(".fast")) + ".snp";
     std::cout << "This is ebwt2snp_mgpu. Input file: " << o.input << ", " << F.n << " EGSA entries over " << S.nranks << " GPU(s)"
-              << (S.shared_device ? " [rehearsal: all ranks on GPU 0, exchange through host memory]" : " [RCCL all-gather]") << std::endl;
+              << (S.shared_device ? " [rehearsal: all ranks on GPU 0, exchange through host memory]" : (S.use_rccl ? " [RCCL all-gather]" : " [one rank: nothing to exchange]")) << std::endl;
     std::vector<std::thread> th;
-    for (int r = 1; r < S.nranks; ++r) th.emplace_back(rank_main, std::ref(S), r);
-    rank_main(S, 0);
+    for (int r = 0; r < S.nranks; ++r) th.emplace_back(rank_main, std::ref(S), r);
+    {
+        // the reads: ONE index of the FASTA for all ranks, built here while the ranks upload their shards (an irregular or unreadable file:
+        // no GPU tail, the host tail decides)
+        PhaseClock pcm;
+        S.reads_ok = e2s_fasta_index_open(o.input.c_str(), &fix, &S.rd_text, &S.rd_bytes, &S.rd_start, &S.rd_len, &S.rd_n, &S.rd_max) == E2S_OK && S.rd_n > 0;
+        pcm.mark("FASTA indexed (one index for all ranks, beside the shards' uploads)");
+        latch_set(S, S.reads_state, 1);
+    }
     for (auto& t : th) t.join();
-    if (fix) e2s_fasta_index_close(fix);
+    if (comm_thread.joinable()) comm_thread.join();
+    pcs.mark("ranks done");
+    if (fix && (S.teardown || S.rc.load())) e2s_fasta_index_close(fix);
     if (S.cl_fd >= 0) ::close(S.cl_fd);
     if (S.snp_fd >= 0) ::close(S.snp_fd);
-    for (auto& c : S.comms) if (c) ncclCommDestroy(c);
+    if (S.teardown || S.rc.load()) for (auto& c : S.comms) if (c) ncclCommDestroy(c);
     if (S.rc.load()) ::unlink(cl_path.c_str());                  // (a job that failed leaves no half-written `.clusters` behind)
     if (!S.rc.load() && S.crash.load()) S.rc.store(S.crash.load());   // (ebwt2clust's file stays, as after the reference's two runs)
     uint64_t closed = 0, cands = 0, events = 0;
@@ -465,6 +505,7 @@ int main(int argc, char** argv) {
             if (trc) { std::cerr << "host tail failed (" << trc << ")" << std::endl; S.rc.store(trc == E2S_ERR_REF_CRASH ? 139 : trc); }
         }
     }
+    pcs.mark("output files closed");
     const int rc = S.rc.load();
     if (rc == 139) { std::cerr << "the reference crashes on this input in its tail; no .snp written" << std::endl; return 139; }
     if (rc == 136) { std::cerr << "no usable cluster record: the reference divides by zero here (SIGFPE)" << std::endl; return 136; }
@@ -486,6 +527,10 @@ int main(int argc, char** argv) {
                     (unsigned long long)events, S.mcl);
             fclose(f);
         }
+    }
+    if (!S.teardown) {                                              // both files are closed; nothing else of this process is worth an orderly teardown
+        std::cout.flush(); std::cerr.flush(); fflush(nullptr);
+        _exit(0);
     }
     return 0;
 }

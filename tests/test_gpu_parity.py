@@ -1019,14 +1019,18 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
                 if os.path.exists(f):
                     os.remove(f)
             jpath = str(d / "perf.json")
-            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FULL_COLUMNS=str(full), E2S_CLI_JSON=jpath)
+            # (-G 1 has nothing to exchange and creates no communicator unless told to: the RCCL calls -- ncclCommInitAll in its own thread,
+            #  ncclAllGather on the rank's stream -- run on this one-GPU box with a one-rank communicator)
+            force_rccl = ranks == 1 and (full == 1 or meta["name"].endswith("bcr"))
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FULL_COLUMNS=str(full), E2S_CLI_JSON=jpath,
+                       E2S_MGPU_FORCE_RCCL="1" if force_rccl else "0")
             if pieces:
                 env["E2S_JOB_PIECES"] = str(pieces)
             if tiny:
                 env["E2S_JOB_TEST_CAND_CAP"] = str(tiny)
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)] + a, capture_output=True, text=True, env=env, timeout=300)
             assert r.returncode == 0, (meta["name"], ranks, r.stdout[-800:], r.stderr[-800:])
-            assert ("RCCL all-gather" in r.stdout) == (not shared)
+            assert ("RCCL all-gather" in r.stdout) == (not shared and (ranks > 1 or force_rccl)), r.stdout[:300]
             assert "Done. %d clusters saved to output file." % meta["n_printed"] in r.stdout, (meta["name"], ranks, r.stdout)
             assert hashlib.sha256(open(p + ".clusters", "rb").read()).hexdigest() == meta["clusters_sha256"], (meta["name"], ranks)
             assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta), (meta["name"], ranks)
@@ -1060,7 +1064,8 @@ def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
-            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FAIL_RANK=str(ranks - 1), E2S_MGPU_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="1")
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FAIL_RANK=str(ranks - 1), E2S_MGPU_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="1",
+                       E2S_MGPU_FORCE_RCCL="1")
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
             assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
             assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
@@ -1071,7 +1076,8 @@ def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
-            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_JOB_FAIL_RANK=str(fail_rank), E2S_JOB_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="1")
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_JOB_FAIL_RANK=str(fail_rank), E2S_JOB_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="1",
+                       E2S_MGPU_FORCE_RCCL="1", E2S_MGPU_TEARDOWN="1")
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
             assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
             assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
