@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     for (u32 i = threadIdx.x; i < 16u * (E2S_MAX_CLUST_LEN_K + 2); i += 256u) (&s_hist[0][0])[i] = 0u;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0ull;
     __syncthreads();
-    u64 l_nrec = 0, l_nb = 0;                                   // the lanes' share of the statistics
+    // the lane's share of the statistics: records kept and their base count (lengths of disjoint clusters inside a range of < 2^32 entries)
+    u32 l_kept = 0, l_nb32 = 0;
     u32 qn = 0;                                                 // (FUSED) flagged clusters queued in LDS: wave state, kept from range to range
     __shared__ u64 s_q[FUSED ? 4 : 1][FUSED ? F2_Q : 1];
     u64* const q = s_q[FUSED ? wslot : 0];
@@ -176,13 +177,14 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     uint16_t* const seg_lens = a.lens + seg;
     const u32 shift1 = (u32)((t0 - torg) * TILE) + 1u;          // 1 + offset of the range's first entry from the origin of the offsets
     // what append_entry keeps (ebwt2clust.cpp:54-63) and statistics() counts (clust2snp.cpp:889-909), tallied as the records leave
-    u32 l_kept = 0, lk1 = 0, lk_len = 0;                        // per lane: kept records, 1 + rank of the last one, its length
+    u32 lk1 = 0, lk_len = 0;                                    // per lane: 1 + rank of the last kept record, its length
     u32* const hrow = s_hist[wslot * 4u + (lane & 3u)];
+    // (a lane meets its records in rising rank order -- every 64th of a tile, tile after tile --, so "the last kept one" is an assignment)
     auto tally = [&](const u32 rank, const u32 len16) {
         if ((int)len16 >= a.min_len) {
-            ++l_kept; ++l_nrec; l_nb += (u64)len16;
+            ++l_kept; l_nb32 += len16;
             if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&hrow[len16], 1u);
-            if (rank + 1u > lk1) { lk1 = rank + 1u; lk_len = len16; }
+            lk1 = rank + 1u; lk_len = len16;
         }
     };
 
@@ -596,6 +598,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     }
     }
     // the block's share of the statistics: one flush of the histogram replicas and the two sums
+    u64 l_nrec = (u64)l_kept, l_nb = (u64)l_nb32;              // (a wave is one worker: the records it kept are the records the statistics count)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { l_nrec += __shfl_xor((unsigned long long)l_nrec, o); l_nb += __shfl_xor((unsigned long long)l_nb, o); }
     if (lane == 0 && l_nrec) { atomicAdd((unsigned long long*)&s_acc[0], (unsigned long long)l_nrec); atomicAdd((unsigned long long*)&s_acc[1], (unsigned long long)l_nb); }
