@@ -86,12 +86,18 @@ auto allgather = [](void* user, const void* d_send, void* d_recv, size_t bytes_p
 Comm comm;
 e2s_resident_params rp = {k, min_len, rank, world, {nr_reads1, k_left, k_right, mcov_out, consensus_reads, max_gap, max_err, pval}, 1, 0};
 e2s_job_report jr;
+rp.probe_only = 1;                                                 // PREPARE: does the form apply? + every buffer, stream and event of the step put in place
+int can = e2s_resident_job(h, &rp, allgather, &comm, NULL);        // ... the ranks agree on `can` (and on their set-up) BEFORE any of them enqueues:
+rp.probe_only = 0;                                                 // from here to the second exchange a rank allocates nothing and cannot drop out for want of memory
 int rc = e2s_resident_job(h, &rp, allgather, &comm, &jr);        // shard + reads resident (e2s_upload_bcr, e2s_upload_reads_fasta): ONE enqueue, ONE wait
 if (rc == E2S_ERR_STATE || rc == E2S_ERR_CAPACITY) {
-    // this form does not apply to the input / a buffer was too small -- on every rank alike: the stepwise calls of section 3 run the step
+    // this form does not apply to the input / a buffer was too small -- on every rank alike (the verdict travels in the second exchange
+    // and is evaluated before the reference's crash cases): the stepwise calls of section 3 run the step
 }
+// (a rank whose enqueue fails on a HIP error after its scan is on the stream still enters both exchanges, with a zeroed share: its peers
+//  come back with E2S_ERR_CAPACITY instead of waiting for it; a failing exchange itself -- E2S_ERR_IO -- is for the driver: ncclCommAbort)
 // jr.n_ends, jr.n_records, jr.max_clust_length, jr.n_candidates, jr.n_events, jr.snp_bytes; both images in HBM:
 const void* d_clusters; uint64_t n_rec; e2s_clusters_image(h, &d_clusters, &n_rec);      // or e2s_stream_clusters / e2s_stream_snp in rank order
 // [end]
-    return rc + (int)n_rec;
+    return rc + can + (int)n_rec;
 }
