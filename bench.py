@@ -561,65 +561,93 @@ def pmc_traffic(workload, kernel):
     return None, None
 
 
-def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scaling, with_cpu):
-    """build the workload, attach it, time W + K steps (+ the other mode, + outputs to host); returns the result dict on rank 0"""
-    R, L = WORKLOADS[name][:2]
-    copies = WORKLOADS[name][2] if len(WORKLOADS[name]) > 2 else 1
-    t0 = time.time()
-    if REHEARSAL and dist is not None:
-        # every rank lives on ONE GPU here: build in turns (four concurrent 2x10^8-entry sorts on one device stalled for minutes)
-        for turn in range(world):
-            if turn == rank:
-                reads, n1_block, blk0 = build_block(R, L, dev, **WORKLOAD_OPTS.get(name, {}))
-                torch.cuda.synchronize()
-            dist.barrier()
-    else:
-        reads, n1_block, blk0 = build_block(R, L, dev, **WORKLOAD_OPTS.get(name, {}))
-    tiled_strong = copies > 1 and ((world > 1 and scaling == "strong") or bool(a.emulate_rank))
-    if tiled_strong:
-        blk, n1 = None, n1_block * copies                          # (the whole EGSA is never built: every rank materialises its own range)
-        m = blk0["lcp"].numel() * copies
-    else:
-        blk, n1 = tile_block(blk0, n1_block, copies)
-        m = blk["lcp"].numel()
-    emul = None
-    if a.emulate_rank:
-        # ONE rank of the N-way strong cut (BASELINE.json configs[3]) on this GPU, with the N-rank bookkeeping: the other ranks'
-        # descriptors, statistics and event counts are worked out once, before the timed region (emulate_peers), and every exchange
-        # of the timed step is a real one-rank RCCL all-gather whose result is completed with those cached blobs
-        er, en_ = (int(v) for v in a.emulate_rank.split("/"))
-        assert 0 <= er < en_ and world == 1
+def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scaling, with_cpu, agree=False):
+    """build the workload, attach it, time W + K steps (+ the other mode, + outputs to host); returns the result dict on rank 0.
+    agree: the ranks tell each other whether their build went through BEFORE the first step (a rank that ran out of memory must not
+    leave the others inside the step's exchanges): if any did not, every rank skips the workload and rank 0 returns {"skipped": why}"""
+    def _build():
+        R, L = WORKLOADS[name][:2]
+        copies = WORKLOADS[name][2] if len(WORKLOADS[name]) > 2 else 1
+        t0 = time.time()
+        if REHEARSAL and dist is not None:
+            # every rank lives on ONE GPU here: build in turns (four concurrent 2x10^8-entry sorts on one device stalled for minutes)
+            for turn in range(world):
+                if turn == rank:
+                    reads, n1_block, blk0 = build_block(R, L, dev, **WORKLOAD_OPTS.get(name, {}))
+                    torch.cuda.synchronize()
+                dist.barrier()
+        else:
+            reads, n1_block, blk0 = build_block(R, L, dev, **WORKLOAD_OPTS.get(name, {}))
+        tiled_strong = copies > 1 and ((world > 1 and scaling == "strong") or bool(a.emulate_rank))
+        if tiled_strong:
+            blk, n1 = None, n1_block * copies                          # (the whole EGSA is never built: every rank materialises its own range)
+            m = blk0["lcp"].numel() * copies
+        else:
+            blk, n1 = tile_block(blk0, n1_block, copies)
+            m = blk["lcp"].numel()
+        emul = None
+        if a.emulate_rank:
+            # ONE rank of the N-way strong cut (BASELINE.json configs[3]) on this GPU, with the N-rank bookkeeping: the other ranks'
+            # descriptors, statistics and event counts are worked out once, before the timed region (emulate_peers), and every exchange
+            # of the timed step is a real one-rank RCCL all-gather whose result is completed with those cached blobs
+            er, en_ = (int(v) for v in a.emulate_rank.split("/"))
+            assert 0 <= er < en_ and world == 1
 
-        def shard_of(q):
-            if tiled_strong:
-                return shard_strong_tiled(blk0, n1_block, copies, q, en_)[:5]
-            return shard_strong(blk, m, q, en_)
-        emul = dict(rank=er, world=en_)
-        emul.update(emulate_peers(shard_of, m, n1, tile_reads(reads.to(dev), n1_block, copies), L, er, en_, local))
-        arrs, g0, n_own, hl, hr = shard_of(er)
-        n_total = m
-        blk = None
-        torch.cuda.empty_cache()
-    elif world == 1:
-        arrs, g0, n_own, hl, hr, n_total = blk, 0, m, 0, 0, m      # (no copy)
-    elif tiled_strong:
-        arrs, g0, n_own, hl, hr, n_total = shard_strong_tiled(blk0, n1_block, copies, rank, world)
-    elif scaling == "strong":
-        arrs, g0, n_own, hl, hr = shard_strong(blk, m, rank, world)
-        n_total = m
-    else:
-        arrs, g0, n_own, hl, hr = shard_weak(blk, m, rank, world)
-        n_total = m * world
-    rd = tile_reads(reads.to(dev), n1_block, copies)               # dense [reads][L] matrix: read r at r * L
-    if world > 1:
-        del blk
-    torch.cuda.synchronize()
-    t_build = time.time() - t0
+            def shard_of(q):
+                if tiled_strong:
+                    return shard_strong_tiled(blk0, n1_block, copies, q, en_)[:5]
+                return shard_strong(blk, m, q, en_)
+            emul = dict(rank=er, world=en_)
+            emul.update(emulate_peers(shard_of, m, n1, tile_reads(reads.to(dev), n1_block, copies), L, er, en_, local))
+            arrs, g0, n_own, hl, hr = shard_of(er)
+            n_total = m
+            blk = None
+            torch.cuda.empty_cache()
+        elif world == 1:
+            arrs, g0, n_own, hl, hr, n_total = blk, 0, m, 0, 0, m      # (no copy)
+        elif tiled_strong:
+            arrs, g0, n_own, hl, hr, n_total = shard_strong_tiled(blk0, n1_block, copies, rank, world)
+        elif scaling == "strong":
+            arrs, g0, n_own, hl, hr = shard_strong(blk, m, rank, world)
+            n_total = m
+        else:
+            arrs, g0, n_own, hl, hr = shard_weak(blk, m, rank, world)
+            n_total = m * world
+        rd = tile_reads(reads.to(dev), n1_block, copies)               # dense [reads][L] matrix: read r at r * L
+        if world > 1:
+            del blk
+        torch.cuda.synchronize()
+        t_build = time.time() - t0
 
-    h = capi.Handle(local)
-    h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
-    d = capi.Handle.desc(n_total, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr)
-    h.attach_soa(d, arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(), arrs["pos"].data_ptr(), arrs["da"].data_ptr(), keep=tuple(arrs.values()))
+        h = capi.Handle(local)
+        h.attach_reads(rd.data_ptr(), None, None, rd.shape[0], L, keep=(rd,))
+        d = capi.Handle.desc(n_total, offset=g0, n_entries=n_own, halo_left=hl, halo_right=hr)
+        h.attach_soa(d, arrs["bwt"].data_ptr(), arrs["lcp"].data_ptr(), arrs["pos"].data_ptr(), arrs["da"].data_ptr(), keep=tuple(arrs.values()))
+
+
+        return locals()
+    loc, why = None, ""
+    try:
+        loc = _build()
+    except Exception as ex:                                       # (out of memory while materialising a rank's range, ...)
+        if not agree or dist is None:
+            raise
+        why = repr(ex)
+    if agree and dist is not None:
+        rdev0 = torch.device("cpu") if REHEARSAL else dev
+        okt = torch.tensor([1 if loc is not None else 0], dtype=torch.int64, device=rdev0)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            if loc is not None:
+                loc["h"].close()
+            loc = None
+            torch.cuda.empty_cache()
+            return {"skipped": why or "another rank could not build its range"} if rank == 0 else None
+    R, L, copies = loc["R"], loc["L"], loc["copies"]
+    reads, n1_block, blk0, n1, m, emul = loc["reads"], loc["n1_block"], loc["blk0"], loc["n1"], loc["m"], loc["emul"]
+    arrs, g0, n_own, hl, hr, n_total, rd, t_build, h = (loc[k2] for k2 in ("arrs", "g0", "n_own", "hl", "hr", "n_total", "rd", "t_build", "h"))
+    blk = loc.get("blk")                                           # (kept alive where it is the attached EGSA itself: one GPU, no copy)
+    del loc
 
     def barrier():
         if dist is not None:
@@ -845,7 +873,7 @@ def main():
     if world > 1 and a.workload == "c3" and a.scaling == "strong" and (world >= 8 or os.environ.get("E2S_BENCH_C5_LEG", "0") == "1"):
         # BASELINE.json configs[4]: the 3x10^10-entry EGSA (more than one GPU's HBM), the mandatory 8-GPU shard -- every rank builds only its range
         try:
-            c5_leg = measure_workload(a, "c5", world, rank, local, dist, dev, max(3, a.steps // 4), 2, "strong", with_cpu=False)
+            c5_leg = measure_workload(a, "c5", world, rank, local, dist, dev, max(3, a.steps // 4), 2, "strong", with_cpu=False, agree=True)
         except Exception as ex:                                     # (never takes the configs[3] line down with it)
             c5_leg = {"error": repr(ex)}
     if rank == 0:
