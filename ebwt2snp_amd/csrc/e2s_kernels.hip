@@ -1711,8 +1711,11 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
 __device__ __forceinline__ u32 packed_size8(u32 n0, u32 n1, u32 pw) { return (16u + (4u + pw) * (n0 + n1) + 7u) >> 3; }
 // K2b: lists and candidate records (clust2snp.cpp:431-496) for the few clusters K2a let through.  Persistent
 // blocks, one wave per cluster, candidates staged in LDS so that a block reserves output slots ~once per 32.
+#ifndef K2B_WAVES
+#define K2B_WAVES 1
+#endif
 template <bool DEF>
-__global__ __launch_bounds__(256) void k_flagged_lists(CandArgs a, const unsigned long long* lo_dev, const unsigned long long* n_dev, u32 cap8) {
+__global__ __launch_bounds__(256, K2B_WAVES) void k_flagged_lists(CandArgs a, const unsigned long long* lo_dev, const unsigned long long* n_dev, u32 cap8) {
     __shared__ u32 s_nstage, s_used8;
     __shared__ u64 s_gbase, s_sbase;
     __shared__ u64 s_keys[FW_STAGE];
