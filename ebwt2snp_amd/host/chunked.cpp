@@ -374,6 +374,16 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     // pass B = all four columns again.)
     static const int two_pass_env = e2s_env_dev("E2S_CHUNK_TWO_PASS") ? atoi(e2s_env_dev("E2S_CHUNK_TWO_PASS")) : 0;
     const bool slim = !two_pass_env && !src->gesa && p->lcp_bytes == 1 && p->da_bytes == 4 && p->pos_bytes == 1;
+    // the handle of the second phase (slim), created up front: a FASTA is indexed and made resident on it by a thread of its own WHILE the
+    // streaming pass runs (the reads are not needed before the tail; the handle is that thread's alone until it is joined)
+    e2s_handle hc = nullptr, hf = nullptr;
+    struct Guard { e2s_handle& a; e2s_handle& b; ~Guard() { if (a) e2s_destroy(a); if (b) e2s_destroy(b); } } guard{hc, hf};
+    std::thread reads_thread; int reads_rc = E2S_OK;
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reads_thread};      // (joined before the handles go)
+    if (slim && fasta_path) {
+        RC(e2s_create(p->device, &hc));
+        reads_thread = std::thread([&reads_rc, hc, fasta_path]() { reads_rc = e2s_upload_reads_fasta(hc, fasta_path, nullptr); });
+    }
     // pass A: ebwt2clust: records out, descriptors and statistics of every chunk kept (slim: and the clusters the pre-filter lets through)
     ScanPass sp;
     std::vector<Flagged> flagged;
@@ -399,10 +409,13 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
     };
     if (slim) {
         // the per-cluster pass and the tail, chunk by chunk, over gathered clusters (a chunk the pre-filter could not handle: all four columns)
-        e2s_handle hc = nullptr, hf = nullptr;
-        RC(e2s_create(p->device, &hc));
-        struct Guard { e2s_handle& a; e2s_handle& b; ~Guard() { if (a) e2s_destroy(a); if (b) e2s_destroy(b); } } guard{hc, hf};
-        RC(reads_on(hc, nullptr));
+        if (reads_thread.joinable()) {
+            reads_thread.join();
+            if (reads_rc != E2S_OK && reads_rc != E2S_ERR_INPUT && reads_rc != E2S_ERR_IO) return reads_rc;      // (an irregular / unreadable FASTA: the host tail decides)
+        } else {
+            RC(e2s_create(p->device, &hc));
+            RC(reads_on(hc, nullptr));
+        }
         for (int r = 0; r < nr; ++r) {
             uint64_t n_cand = 0;
             e2s_handle ht = hc;
