@@ -662,7 +662,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         h.set_timing(timing)
         for _ in range(n_warm):
             info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host, emul=emul)
-        r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[], tail_ms=[])
+        r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[], tail_ms=[], k2b_end_ms=[])
         barrier()
         PHASES.clear()
         t0 = time.perf_counter()
@@ -670,7 +670,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host, emul=emul)
             tm = h.timing()
             r["scan_ms"].append(tm.scan_main_ms); r["cand_ms"].append(tm.cand_main_ms); r["scan_all_ms"].append(tm.scan_ms)
-            r["hist_ms"].append(tm.hist_ms); r["tail_ms"].append(tm.tail_ms)
+            r["hist_ms"].append(tm.hist_ms); r["tail_ms"].append(tm.tail_ms); r["k2b_end_ms"].append(tm.cand_ms)
         own = time.perf_counter() - t0                              # this rank's own steps, before it waits for the others
         barrier()
         elapsed = time.perf_counter() - t0
@@ -761,11 +761,11 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             res["per_rank_ms_per_step"] = dict(prim["rank_ms"], what="each rank's own K steps (before the closing barrier), min and max over the ranks")
         if phases is not None:
             res["kernel_ms"] = {"scan+prefilter+fix+stats": float(np.mean(phases["scan_all_ms"])), "scan_kernel": float(np.mean(phases["scan_ms"])),
-                                "per_cluster_pass_to_K2b_end": float(np.mean(phases["cand_ms"])), "tail": float(np.mean(phases["tail_ms"])),
+                                "scan_start_to_K2b_end": float(np.mean(phases["k2b_end_ms"])), "tail": float(np.mean(phases["tail_ms"])),
                                 "note": "from a separate leg with every phase's events recorded (each costs stream time: ms_per_step there %.4f)"
                                         % (phases["elapsed"] / phases["steps"] * 1e3)}
-            res["kernel_ms"]["what"] = ("rank 0's phases; 'scan+prefilter+fix+stats' ends before the first exchange, 'per_cluster_pass_to_K2b_end' starts behind it "
-                                        "(exchange 1 + plan lie between), 'tail' brackets exchange 2")
+            res["kernel_ms"]["what"] = ("rank 0's phases; 'scan+prefilter+fix+stats' ends before the first exchange; 'scan_start_to_K2b_end' minus it = exchange 1 + plan + "
+                                        "the lists; 'tail' (consensus ... text) brackets exchange 2")
         if emul is not None:
             res["rank_entries"] = n_own
         res["roofline"].update({"survey_8d_bytes": ref_pattern_bytes + n_own, "frac_vs_survey_bytes": (ref_pattern_bytes + n_own) / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
