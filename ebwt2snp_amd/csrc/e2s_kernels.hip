@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // being processed, Wn = the next one, in flight meanwhile.
     u32 WA[NW], WB[NW], BA[FUSED ? NR : 1], BB[FUSED ? NR : 1];
     ClassConsts kc = class_consts();                            // (FUSED) held in VGPRs: see e2s_swar.h
+#ifndef E2S_KC_UNPINNED
     if constexpr (FUSED) asm volatile("" : "+v"(kc.m07), "+v"(kc.ehi), "+v"(kc.elo), "+v"(kc.c20), "+v"(kc.one), "+v"(kc.h));
+#endif
     auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
         constexpr bool PF = decltype(prefetch)::value;
         if (PF) load_fast(tile + 1, Wn, Bn);                    // in flight while this tile is processed
@@ -402,8 +404,17 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         if constexpr (FUSED && PF)
         asm volatile("" : "+v"(Bn[0]), "+v"(Bn[1]), "+v"(Bn[2]), "+v"(Bn[3]), "+v"(Bn[4]), "+v"(Bn[5]), "+v"(Bn[6]), "+v"(Bn[7]),
                           "+v"(Bn[8]), "+v"(Bn[9]), "+v"(Bn[10]), "+v"(Bn[11]), "+v"(Bn[12]), "+v"(Bn[13]), "+v"(Bn[14]), "+v"(Bn[15]));
-        if (run == 0 && tile_total != 0) {                      // the range's first end (once per worker)
-            if (cnt != 0 && inc == cnt) first_end = g_range + base_off + (u32)(__ffsll((long long)E) - 1);
+        if (run == 0 && tile_total != 0) {
+            // the range's first end (once per worker), and whether its cluster STARTED in the range: both wave-uniform (scalar registers) --
+            // as per-lane variables set by "whichever lane wrote record 0" they cost three VGPRs for the whole kernel
+            const int fl = __ffsll((long long)__ballot(cnt != 0)) - 1;                          // the lane that holds the first end
+            const u32 epos = (u32)__builtin_amdgcn_readlane((int)(u32)(__ffsll((long long)E) - 1), fl);
+            first_end = g_range + (u32)__builtin_amdgcn_readlane((int)base_off, fl) + epos;
+            // a start at or before that end, in this tile (a lane before fl, or lane fl up to the end's position) or earlier in the range
+            const u64 sb = __ballot(S != 0ull) & ((1ull << fl) - 1ull);
+            const u32 slo = (u32)__builtin_amdgcn_readlane((int)(u32)S, fl), shi = (u32)__builtin_amdgcn_readlane((int)(u32)(S >> 32), fl);
+            const u64 sfl = (((u64)shi << 32) | slo) & ((2ull << epos) - 1ull);
+            if (open1 == 0u && sb == 0ull && sfl == 0ull) unknown = 1u;
         }
         // emit.  Starts and ends alternate along the array (S0 <= E0 < S1 <= E1 ...), so the cluster that starts at p is the
         // tile's record number "ends strictly before p", and the one that ends at q is record number "ends strictly before q":
@@ -459,10 +470,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                             seg_starts[run + r] = s1 - shift1;
                             seg_lens[run + r] = (uint16_t)(e + 2u - s1);
                             tally(run + r, e + 2u - s1);
-                        } else {
-                            seg_lens[run + r] = (uint16_t)((g_range + e + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch
-                            unknown = 1;
-                        }
+                        } else seg_lens[run + r] = (uint16_t)((g_range + e + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch (`unknown`, above)
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -489,10 +497,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                                 seg_lens[rk] = (uint16_t)len;
                                 tally(rk, len & 0xFFFFu);
                                 if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
-                            } else {
-                                seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);       // finished by k_seg_fix / e2s_stitch
-                                unknown = 1;
-                            }
+                            } else seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);       // finished by k_seg_fix / e2s_stitch (`unknown`, above)
                         }
                         ++rk;
                     }
@@ -575,10 +580,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         slow_run(t1);
         if constexpr (FUSED) queue_flush();
     }
-    // worker descriptor: `unknown` / `first_end` were set by whichever lane wrote record 0
-    const u64 unk_m = __ballot(unknown != 0);
-    const u64 fe_m = __ballot(first_end != ~0ull);
-    const u64 fe = __shfl(first_end, fe_m ? __ffsll((long long)fe_m) - 1 : 0);
+    // worker descriptor (`unknown` / `first_end`: wave-uniform, set with the range's first end)
     u32 kept_w = l_kept, lk1_w = lk1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { kept_w += (u32)__shfl_xor((int)kept_w, o); lk1_w = max(lk1_w, (u32)__shfl_xor((int)lk1_w, o)); }
@@ -588,8 +590,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         SegDesc d;
         d.count = min(run, a.seg_cap);
         d.overflow = run > a.seg_cap ? 1u : 0u;
-        d.first_unknown = unk_m ? 1u : 0u;
-        d.first_end_pos = fe_m ? fe : ~0ull;
+        d.first_unknown = unknown;
+        d.first_end_pos = first_end;
         if (state == 0u) { d.open_after = (t0 < t1) ? in0 : 0u; d.open_start = ~0ull; }         // no event at all
         else if (state == 1u) { d.open_after = 0; d.open_start = ~0ull; }
         else { d.open_after = 1; d.open_start = g_range + (open1 - 1u); }
