@@ -283,7 +283,10 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // being processed, Wn = the next one, in flight meanwhile.
     u32 WA[NW], WB[NW], BA[FUSED ? NR : 1], BB[FUSED ? NR : 1];
     ClassConsts kc = class_consts();                            // (FUSED) held in VGPRs: see e2s_swar.h
-#ifndef E2S_KC_UNPINNED
+    // (Round 2 pinned the six class constants into VGPRs: v_bitop3 / v_perm issue faster with register operands.  Round 4: left to the
+    //  compiler -- scalar operands and literals -- they free the registers that were missing for a FOURTH wave per SIMD: 124 VGPRs, no
+    //  vector spill, 1.567 -> 1.468-1.518 ms on c3 (A/B/A/B on one box); with them pinned the kernel needs 129.  -DE2S_KC_PINNED: the old form.)
+#ifdef E2S_KC_PINNED
     if constexpr (FUSED) asm volatile("" : "+v"(kc.m07), "+v"(kc.ehi), "+v"(kc.elo), "+v"(kc.c20), "+v"(kc.one), "+v"(kc.h));
 #endif
     auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
