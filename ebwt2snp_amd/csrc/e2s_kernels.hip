@@ -177,14 +177,13 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     uint16_t* const seg_lens = a.lens + seg;
     const u32 shift1 = (u32)((t0 - torg) * TILE) + 1u;          // 1 + offset of the range's first entry from the origin of the offsets
     // what append_entry keeps (ebwt2clust.cpp:54-63) and statistics() counts (clust2snp.cpp:889-909), tallied as the records leave
-    u32 lk1 = 0, lk_len = 0;                                    // per lane: 1 + rank of the last kept record, its length
     u32* const hrow = s_hist[wslot * 4u + (lane & 3u)];
-    // (a lane meets its records in rising rank order -- every 64th of a tile, tile after tile --, so "the last kept one" is an assignment)
-    auto tally = [&](const u32 rank, const u32 len16) {
+    // (which record is the LAST one kept -- the statistics count it twice, H4 -- is found by k_seg_fix in the segment itself: tracked here
+    //  it cost two VGPRs for the whole kernel, the two that stood between the pinned class constants and a fourth wave per SIMD)
+    auto tally = [&](const u32 len16) {
         if ((int)len16 >= a.min_len) {
             ++l_kept; l_nb32 += len16;
             if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&hrow[len16], 1u);
-            lk1 = rank + 1u; lk_len = len16;
         }
     };
 
@@ -283,10 +282,10 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // being processed, Wn = the next one, in flight meanwhile.
     u32 WA[NW], WB[NW], BA[FUSED ? NR : 1], BB[FUSED ? NR : 1];
     ClassConsts kc = class_consts();                            // (FUSED) held in VGPRs: see e2s_swar.h
-    // (Round 2 pinned the six class constants into VGPRs: v_bitop3 / v_perm issue faster with register operands.  Round 4: left to the
-    //  compiler -- scalar operands and literals -- they free the registers that were missing for a FOURTH wave per SIMD: 124 VGPRs, no
-    //  vector spill, 1.567 -> 1.468-1.518 ms on c3 (A/B/A/B on one box); with them pinned the kernel needs 129.  -DE2S_KC_PINNED: the old form.)
-#ifdef E2S_KC_PINNED
+    // (The six class constants pinned into VGPRs: v_bitop3 / v_perm issue faster with register operands -- round 2.  Round 4 made room
+    //  for them AND a fourth wave per SIMD: 138 -> 123 VGPRs (the statistics' tally on two 32-bit counters, the range's first end and its
+    //  flag wave-uniform, the last kept record found by k_seg_fix).  -DE2S_KC_UNPINNED leaves them to the compiler: 4 waves as well.)
+#ifndef E2S_KC_UNPINNED
     if constexpr (FUSED) asm volatile("" : "+v"(kc.m07), "+v"(kc.ehi), "+v"(kc.elo), "+v"(kc.c20), "+v"(kc.one), "+v"(kc.h));
 #endif
     auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                         const u32 s1 = (u32)v, e = (u32)(v >> 32);
                         seg_starts[run + r] = s1 - shift1;
                         seg_lens[run + r] = (uint16_t)(e + 2u - s1);
-                        tally(run + r, e + 2u - s1);
+                        tally(e + 2u - s1);
                     }
                 } else {                                                    // no start seen in the range before this tile
                     for (u32 r = lane; r < tile_total; r += 64u) {
@@ -472,7 +471,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                         if (s1 != 0u) {
                             seg_starts[run + r] = s1 - shift1;
                             seg_lens[run + r] = (uint16_t)(e + 2u - s1);
-                            tally(run + r, e + 2u - s1);
+                            tally(e + 2u - s1);
                         } else seg_lens[run + r] = (uint16_t)((g_range + e + 1) & 0xFFFFull);   // finished by k_seg_fix / e2s_stitch (`unknown`, above)
                     }
                 }
@@ -498,7 +497,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
                                 const u32 len = off + 2u - st1;
                                 seg_starts[rk] = st1 - shift1;
                                 seg_lens[rk] = (uint16_t)len;
-                                tally(rk, len & 0xFFFFu);
+                                tally(len & 0xFFFFu);
                                 if (len >= 65536u) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg + rk; }
                             } else seg_lens[rk] = (uint16_t)((g_range + off + 1) & 0xFFFFull);       // finished by k_seg_fix / e2s_stitch (`unknown`, above)
                         }
@@ -584,11 +583,9 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         if constexpr (FUSED) queue_flush();
     }
     // worker descriptor (`unknown` / `first_end`: wave-uniform, set with the range's first end)
-    u32 kept_w = l_kept, lk1_w = lk1;
+    u32 kept_w = l_kept;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { kept_w += (u32)__shfl_xor((int)kept_w, o); lk1_w = max(lk1_w, (u32)__shfl_xor((int)lk1_w, o)); }
-    const u64 lk_m = __ballot(lk1 == lk1_w && lk1 != 0u);
-    const u32 lk_len_w = lk_m ? (u32)__shfl((int)lk_len, __ffsll((long long)lk_m) - 1) : 0u;
+    for (int o = 32; o > 0; o >>= 1) kept_w += (u32)__shfl_xor((int)kept_w, o);
     if (lane == 0) {
         SegDesc d;
         d.count = min(run, a.seg_cap);
@@ -598,7 +595,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         if (state == 0u) { d.open_after = (t0 < t1) ? in0 : 0u; d.open_start = ~0ull; }         // no event at all
         else if (state == 1u) { d.open_after = 0; d.open_start = ~0ull; }
         else { d.open_after = 1; d.open_start = g_range + (open1 - 1u); }
-        d.kept = kept_w; d.last_kept1 = lk1_w; d.last_kept_len = lk_len_w; d.first_start = ~0ull;
+        d.kept = kept_w; d.last_kept1 = 0u; d.last_kept_len = 0u; d.first_start = ~0ull;      // (last_kept*: no longer filled in -- seg_last_kept)
         a.desc[b] = d;
     }
     }
@@ -680,6 +677,23 @@ __device__ void shard_flags_eval(const void* lcp, u64 n_prov, u64 prov_lo, u64 o
 constexpr int SEGFIX_MAX = 8192;             // scan workers (= resident waves: 256 CUs x <= 32)
 __device__ __forceinline__ u64 seg_range_base(const SegArgs& a, u32 b, u32 row_entries) {      // SA position of the first entry of worker b's range
     return a.prov_lo + ((u64)b * a.tiles_per_block + min(b, a.tiles_rem)) * (u64)row_entries;
+}
+// 1 + index of the LAST record of worker b's segment that append_entry keeps (length >= min_len), among the records whose length the scan
+// knew -- record 0 is left out where its start lay before the range (the caller looks at that one itself); 0: none.  Eight lengths per
+// round trip, from the segment's end: nearly every record is kept, so the first round answers.
+__device__ __forceinline__ u32 seg_last_kept(const SegArgs& a, u32 b, u32 count, u32 first_unknown) {
+    const volatile uint16_t* lens = a.lens + (u64)b * a.seg_cap;
+    const u32 lo = first_unknown ? 1u : 0u;
+    for (u32 hi = count; hi > lo;) {
+        const u32 n = min(8u, hi - lo);
+        u32 v[8];
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) v[q] = q < n ? (u32)lens[hi - 1u - q] : 0u;
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) if (q < n && (int)v[q] >= a.min_len) return hi - q;
+        hi -= n;
+    }
+    return 0u;
 }
 // blob (the resident job): this rank's share of the first all-gather -- e2s_boundary + e2s_scan_stats exactly as e2s_boundary_desc /
 // e2s_scan_stats_desc hand them out (tail_bwt_arg >= 0: the BWT byte of the shard's last entry given by the caller, e2s_upload_lcp).
@@ -858,14 +872,16 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         u64 last_len = 0, at = NONE;
         if (s_lastk) {
             const u32 bk = s_lastk - 1u;
-            if (dk.last_kept1) { last_len = dk.last_kept_len; at = (u64)bk * a.seg_cap + dk.last_kept1 - 1u; }
+            const u32 lk = seg_last_kept(a, bk, dk.count, dk.first_unknown);
+            if (lk) { at = (u64)bk * a.seg_cap + lk - 1u; last_len = vlens[at]; }
             else { last_len = vlens[(u64)bk * a.seg_cap]; at = (u64)bk * a.seg_cap; }       // only its record 0, finished above
             // (a provisional record 0 that holds a slot without reaching min_len is not what the statistics end with)
             if ((int)last_len < a.min_len) {
                 last_len = 0; at = NONE;
                 for (u32 b2 = bk; b2-- > 0;) {
                     const SegDesc d2 = a.desc[b2];
-                    if (d2.last_kept1) { last_len = d2.last_kept_len; at = (u64)b2 * a.seg_cap + d2.last_kept1 - 1u; break; }
+                    const u32 lk2 = seg_last_kept(a, b2, d2.count, d2.first_unknown);
+                    if (lk2) { at = (u64)b2 * a.seg_cap + lk2 - 1u; last_len = vlens[at]; break; }
                     if (s_kept[b2] && (int)vlens[(u64)b2 * a.seg_cap] >= a.min_len) { last_len = vlens[(u64)b2 * a.seg_cap]; at = (u64)b2 * a.seg_cap; break; }
                 }
             }
