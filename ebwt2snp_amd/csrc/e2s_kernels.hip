@@ -2003,7 +2003,14 @@ __global__ void k_unpack_gesa(const uint8_t* src, u64 n, int yb_file, int zb_fil
 static int resident_blocks(const void* fn, int threads, size_t dyn_lds);
 int e2s_scan_seg_resident_blocks(int xb) {                   // resident WORKERS (waves)
     const void* fn = xb == 1 ? (const void*)k_scan_seg<1, false> : xb == 2 ? (const void*)k_scan_seg<2, false> : (const void*)k_scan_seg<4, false>;
-    return 4 * resident_blocks(fn, 256, 0);
+    // (the kernels are bound by their vector instructions: 3, 4 or 5 workers per SIMD run at the same speed -- profiles/round4_scan_workers.txt:
+    //  0.766-0.769 ms for K1 on c3 -- 2 cost 8 %, and the 7 that K1's 66 VGPRs would allow cost 5 %: more workers, each with its start-up,
+    //  its descriptor and its share of the histogram's flush.  At most five per SIMD.)
+    int per_cu = 0, dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    per_cu = resident_blocks(fn, 256, 0) / (cus > 0 ? cus : 1);
+    return 4 * (per_cu < 5 ? per_cu : 5) * cus;
 }
 int e2s_scan_seg_fused_resident_blocks() { return 4 * resident_blocks((const void*)k_scan_seg<1, true>, 256, 0); }
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
