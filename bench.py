@@ -662,7 +662,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         h.set_timing(timing)
         for _ in range(n_warm):
             info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host, emul=emul)
-        r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[], tail_ms=[], k2b_end_ms=[])
+        r = dict(scan_ms=[], cand_ms=[], scan_all_ms=[], hist_ms=[], tail_ms=[], k2b_end_ms=[], enqueue_ms=[])
         barrier()
         PHASES.clear()
         t0 = time.perf_counter()
@@ -670,7 +670,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             info = run_step(h, n1, n_total, world, rank, dist, dev, fused=fused, on_host=on_host, emul=emul)
             tm = h.timing()
             r["scan_ms"].append(tm.scan_main_ms); r["cand_ms"].append(tm.cand_main_ms); r["scan_all_ms"].append(tm.scan_ms)
-            r["hist_ms"].append(tm.hist_ms); r["tail_ms"].append(tm.tail_ms); r["k2b_end_ms"].append(tm.cand_ms)
+            r["hist_ms"].append(tm.hist_ms); r["tail_ms"].append(tm.tail_ms); r["k2b_end_ms"].append(tm.cand_ms); r["enqueue_ms"].append(tm.enqueue_ms)
         own = time.perf_counter() - t0                              # this rank's own steps, before it waits for the others
         barrier()
         elapsed = time.perf_counter() - t0
@@ -755,6 +755,8 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             "roofline": roof(("k_scan_seg<1,true>", "k_scan_seg<1,true,false>"), fused_bytes, fused_ms),
             "value_outputs_on_host": n_total * host["steps"] / host["elapsed"] if host else None,
             "ms_per_step_without_timing_events": bare["elapsed"] / bare["steps"] * 1e3,
+            # host wall time of one step's whole enqueue (all launches of both tools): it runs ahead of the GPU -- why no hipGraph replay
+            "host_enqueue_ms_per_step": float(np.mean(bare["enqueue_ms"])),
             "timing_events_in_timed_region": {0: "none", 1: "two, around the scan kernel (roofline.launch_ms)", 2: "every phase"}[BENCH_TIMING],
         }
         if prim["rank_ms"]:

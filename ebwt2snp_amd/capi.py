@@ -71,7 +71,7 @@ class Timing(C.Structure):
     _fields_ = [("scan_ms", C.c_float), ("scan_main_ms", C.c_float), ("hist_ms", C.c_float), ("cand_ms", C.c_float),
                 ("cand_main_ms", C.c_float), ("upload_ms", C.c_float), ("tail_ms", C.c_float),
                 ("scan_bytes_read", C.c_uint64), ("scan_bytes_written", C.c_uint64),
-                ("cand_bytes_read", C.c_uint64), ("cand_bytes_written", C.c_uint64)]
+                ("cand_bytes_read", C.c_uint64), ("cand_bytes_written", C.c_uint64), ("enqueue_ms", C.c_float), ("reserved", C.c_float)]
 
 
 # every symbol include/e2s_hip.h declares (checked by tests/test_capi_symbols.py)

@@ -2293,7 +2293,10 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     if (p->want_image && image_at >= 2 && (rc = image_now())) return rc;
     return E2S_OK;
     };
-    if ((rc = enqueue()) != E2S_OK) {
+    const auto t_enq = std::chrono::steady_clock::now();
+    rc = enqueue();
+    h->tm.enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_enq).count();
+    if (rc != E2S_OK) {
         // bail: the peers have enqueued (or will enqueue) both exchanges -- enter them with a zeroed share and let the stream drain; the
         // zeroed (events, ok) pair tells every peer that a rank of the job is not ok, and they come back with E2S_ERR_CAPACITY
         const std::string why = h->err;

@@ -408,6 +408,9 @@ typedef struct {
     float tail_ms;        /* e2s_call_variants kernels */
     uint64_t scan_bytes_read, scan_bytes_written;   /* algorithmic bytes of the last call */
     uint64_t cand_bytes_read, cand_bytes_written;
+    float enqueue_ms;     /* e2s_resident_job: host time of the step's whole enqueue (every launch of both tools, the exchanges' callbacks), wall clock --
+                             it runs ahead of the GPU: the step's length is the kernels', not the launches' (always measured, no event involved) */
+    float reserved;
 } e2s_timing;
 int e2s_last_timing(e2s_handle h, e2s_timing* out);
 /* Kernel timing is OPT-IN: an event recorded between two dependent kernels costs stream time (5-10 us per boundary on gfx950
