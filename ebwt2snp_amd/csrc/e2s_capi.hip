@@ -587,7 +587,7 @@ static int records_contiguous(e2s_ctx* h, const uint64_t** starts, const uint16_
     return E2S_OK;
 }
 
-// the statistics the scan phase leaves behind the mail (k_hist_seg / k_scan_img_fin layout) -> e2s_scan_stats
+// the statistics the scan phase leaves behind the mail (k_seg_fix: 151 bins, records, bases, last length, its address) -> e2s_scan_stats
 static void take_scan_stats(e2s_ctx* h, const ScanMail& mail, int min_len) {
     const uint64_t* buf = (const uint64_t*)(h->pin_mail + 256);
     e2s_scan_stats& rs = h->raw_stats;
