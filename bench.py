@@ -752,7 +752,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
             # the dominant kernel of the timed step.  Algorithmic bytes: LCP 1 + BWT 1 per entry read once, 6 B per record
             # written.  SURVEY 8d prices the reference's access pattern (7 B/entry + 10 B/record); this design never reads DA / pos for
             # the 99.7 % of clusters its pre-filter rejects, so against THAT figure the kernel would read 'frac_vs_survey_bytes' > 1
-            "roofline": roof(("k_scan_seg<1,true>", "k_scan_seg<1,true,false>"), fused_bytes, fused_ms),
+            "roofline": roof(("k_scan_seg<1,true,false>", "k_scan_seg<1,true>"), fused_bytes, fused_ms),
             "value_outputs_on_host": n_total * host["steps"] / host["elapsed"] if host else None,
             "ms_per_step_without_timing_events": bare["elapsed"] / bare["steps"] * 1e3,
             # host wall time of one step's whole enqueue (all launches of both tools): it runs ahead of the GPU -- why no hipGraph replay
@@ -783,7 +783,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
         if other is not None:
             scan_ms, pf_ms = float(np.mean(other["scan_ms"])), float(np.mean(other["cand_ms"]))
             # the north-star kernel -- ebwt2clust's scan alone -- and the pre-filter as a kernel of its own
-            res["roofline_scan"] = roof(("k_scan_seg<1>", "k_scan_seg<1,false>", "k_scan_seg<1,false,false>"), n_own * 1 + info["n_ends"] * 6, scan_ms,
+            res["roofline_scan"] = roof(("k_scan_seg<1>", "k_scan_seg<1,false,false>", "k_scan_seg<1,false>"), n_own * 1 + info["n_ends"] * 6, scan_ms,
                                         "ebwt2clust's scan alone (1 B/entry + 6 B/record as it leaves the kernel; SURVEY 8d K1 figure with 10-byte records: "
                                         "frac %.3f), measured in the separate-kernels leg" % ((n_own + info["n_ends"] * 10) / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
             res["roofline_prefilter"] = roof("k_cluster_filter2", n_own * 2, pf_ms)
