@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 4: random cases beside the reference on the round's final kernels (CLI seeds, half of the second batch with ragged reads; random columns)
+# round 4: random cases beside the reference on the round's final kernels: tools/stress_round4.sh <first CLI seed> <CLI seeds> <first column seed> <column seeds>
+# (half of the CLI seeds with ragged reads); output under gpurun_out/r4_stress/
 root=$(pwd); out=$root/gpurun_out/r4_stress; mkdir -p $out
-timeout -k 10 420 python3 tools/stress_cli.py 7000 7200 > $out/cli.txt 2>&1; echo "cli rc $?" >> $out/cli.txt; tail -2 $out/cli.txt
-E2S_STRESS_RAGGED=1 timeout -k 10 330 python3 tools/stress_cli.py 7200 7350 > $out/cli_ragged.txt 2>&1; echo "cli ragged rc $?" >> $out/cli_ragged.txt; tail -2 $out/cli_ragged.txt
-E2S_DEV=1 timeout -k 10 330 python3 tools/stress_columns.py 8000 8300 > $out/columns.txt 2>&1; echo "columns rc $?" >> $out/columns.txt; tail -2 $out/columns.txt
+c0=${1:-7000}; cn=${2:-200}; k0=${3:-8000}; kn=${4:-300}
+timeout -k 10 500 python3 tools/stress_cli.py $c0 $((c0 + cn / 2)) > $out/cli_$c0.txt 2>&1; echo "cli rc $?" >> $out/cli_$c0.txt; tail -2 $out/cli_$c0.txt
+E2S_STRESS_RAGGED=1 timeout -k 10 500 python3 tools/stress_cli.py $((c0 + cn / 2)) $((c0 + cn)) > $out/cli_ragged_$c0.txt 2>&1; echo "cli ragged rc $?" >> $out/cli_ragged_$c0.txt; tail -2 $out/cli_ragged_$c0.txt
+E2S_DEV=1 timeout -k 10 500 python3 tools/stress_columns.py $k0 $((k0 + kn)) > $out/columns_$k0.txt 2>&1; echo "columns rc $?" >> $out/columns_$k0.txt; tail -2 $out/columns_$k0.txt
