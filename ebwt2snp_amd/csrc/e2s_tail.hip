@@ -250,26 +250,85 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
 
 // ---- K3a for k_left <= 32: TWO candidates per wave, one per half-wave ------------------------------------------------------------
 // A left context fills at most 32 lanes, so in k_consensus half of every vector instruction is idle, and the kernel is bound by the
-// issue of those instructions as much as by its chain of gathers (c3: ~950 vector + ~920 scalar instructions per candidate).  Here
-// lanes 0-31 serve candidate 2w, lanes 32-63 candidate 2w + 1: the same instruction stream, loops running to the longer of the two
-// lists, ballots read per half.  Results are those of k_consensus (same order of rows, same tie-breaks).
-// Dynamic LDS per wave: 2 candidates x (2 x list_cap rows of 32 x 2 B + (8 + 4) B of row base / length each + one spare row).
-// (Round 3: the record's first 256 bytes fetched as ONE window, two dwords per lane, header / list entries / positions picked out of the
-// registers by ds_bpermute -- a chain of five dependent round trips cut to three -- changed nothing: 470 us against 469 on c3.  The kernel
-// is bound by the issue of its ~950 vector instructions per wave as much as by its gathers; see profiles/round3_k2b_variants.txt.)
+// issue of those instructions as much as by its chain of gathers.  Here lanes 0-31 serve candidate 2w, lanes 32-63 candidate 2w + 1: the
+// same instruction stream, loops running to the longer of the two lists, ballots read per half.  Results are those of k_consensus.
+//
+// Round 4, second form -- the two per-row loops were ~31 vector instructions per row (two thirds of the kernel's):
+//   * rows are BYTES (32 B per row: 8 waves per SIMD fit where the (character, class) pairs allowed 6);
+//   * cons (include.hpp:334-371) is sequential by definition -- the letter changes when a count becomes STRICTLY larger than the leader's,
+//     so among equal counts the class that reached the count first wins and class 0's letter ('A', but also 'N', lower case, the 0 behind a
+//     read's end) is that of the row where class 0 last TOOK the lead.  But the outcome is decided by the four totals alone unless
+//     (a) two classes share the largest total, or (b) class 0 wins, another class occurs, and the column holds a 0 -- so: one pass that only
+//     counts (5 instructions per row: the class slot is (ch >> 1) & 3 for the characters {0, A, C, G, T}, which the gather checks), the
+//     winner from the totals, and the sequential loop only for a wave that holds such a column (or any other character).  (b) is narrowed
+//     by what is cheap to know: the other classes' totals are all <= 1 and row 0 is class 0 => class 0 never lost the lead => 'A';
+//   * the supports (clust2snp.cpp:544-593) one ROW per lane: 32 B of the row against the consensus as 8 dwords, mismatching bytes counted
+//     by SWAR + v_bcnt -- ~55 instructions for up to 32 rows instead of ~14 per row.
+// Dynamic LDS per wave: 2 candidates x (2 x list_cap rows of 32 B + (8 + 4) B of row base / length each + one spare row), to 32 B.
+// (Round 3: the record's first 256 bytes fetched as ONE window -- a chain of five dependent round trips cut to three -- changed nothing.)
 __device__ __forceinline__ u32 tl_half_pop(u64 m, u32 half) { return (u32)__popc(half ? (u32)(m >> 32) : (u32)m); }
+__device__ __forceinline__ u32 tl_nzb(u32 x, u32 acc) {            // acc + the number of nonzero bytes of x
+    const u32 t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    return (u32)__popc(t) + acc;
+}
+// the left contexts as rows of 32 bytes: 8 lanes per row, an unaligned dword each (see tl_gather_rows); returns nonzero in a lane that saw
+// a character outside {0, 'A', 'C', 'G', 'T'} (its low three bits pick the one it could be from an 8-entry v_perm table)
+__device__ __forceinline__ u32 tl_gather_rows_b(const TailArgs& a, uint8_t* rows, const u64* rbase, const u32* rhave, u32 nrows, u32 nr_max, u32 gl) {
+    constexpr u32 BATCH = 8;
+    const u32 q4 = (gl & 7u) * 4u, rsub = gl >> 3;
+    const u32 last = nrows ? nrows - 1u : 0u;
+    u32 odd = 0u;
+    for (u32 j0 = 0; j0 < nr_max; j0 += 4u * BATCH) {
+        u32 w4[BATCH];
+#pragma unroll
+        for (u32 u = 0; u < BATCH; ++u) {
+            w4[u] = 0u;
+            if (j0 + 4u * u >= nr_max) break;                       // (wave-uniform)
+            const u32 j = j0 + 4u * u + rsub, jj = min(j, last);
+            const u32 have = rhave[jj];
+            const u64 base = rbase[jj];
+            const bool ok = (j < nrows) & ((int)q4 < (int)have);    // (a near-end row's length word is negative)
+            const u32 v = *(const u32*)(a.text + (ok ? base + q4 : 0ull));
+            const u32 keep = have - q4;
+            const u32 mask = keep >= 4u ? ~0u : (1u << (8u * keep)) - 1u;
+            w4[u] = ok ? v & mask : 0u;
+            // (a character that exists must be a letter of ACGT -- a 0 byte IN the text is not one; the 0s behind a row's end are ours)
+            odd |= ok ? (v ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, v & 0x07070707u)) & mask : 0u;   // [FF 'A' FF 'C' 'T' FF FF 'G']
+        }
+#pragma unroll
+        for (u32 u = 0; u < BATCH; ++u) {
+            if (j0 + 4u * u >= nr_max) break;
+            const u32 j = j0 + 4u * u + rsub;
+            if (j < nrows) {
+                *(u32*)(rows + (size_t)j * 32u + q4) = w4[u];
+            }
+        }
+    }
+    return odd;
+}
+__device__ __forceinline__ void tl_gather_rows_b_bytes(const TailArgs& a, uint8_t* rows, const u64* rbase, const u32* rhave, u32 nrows, u32 nr_max, u32 gl) {
+    const u32 last = nrows ? nrows - 1u : 0u;
+    for (u32 j = 0; j < nr_max; ++j) {
+        const u32 hv = rhave[min(j, last)];
+        if (j < nrows && (hv & TL_ROW_NEAR_END)) {
+            const u32 have = hv & ~TL_ROW_NEAR_END;
+            rows[(size_t)j * 32u + gl] = gl < have ? a.text[rbase[j] + gl] : (uint8_t)0;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap) {
-    __shared__ uint8_t s_ab[4][2][2][64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ab[4][2][2][64];
+    __shared__ u32 s_minh[4][2][2];
     const u32 lane = tl_lane(), wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31u;
     const u64 c0 = (a.slot_lo_dev ? (u64)*a.slot_lo_dev : 0ull) + ((u64)blockIdx.x * (blockDim.x >> 6) + wave) * 2ull;
     if (a.n_cand_dev) a.n_cand = min((u64)a.n_cand, (u64)*a.n_cand_dev);
     if (c0 >= a.n_cand) return;
     const u64 c = c0 + half;
     const bool valid = c < a.n_cand;
-    const size_t per_cand = (size_t)2 * list_cap * (64 + 8 + 4) + 64;       // (+ one row: the per-row loops read two rows per trip)
+    const size_t per_cand = ((size_t)2 * list_cap * (32 + 8 + 4) + 32 + 31) & ~(size_t)31;   // (+ one row: the counting loop reads two rows per trip)
     uint8_t* const mine = s_tail + ((size_t)wave * 2 + half) * per_cand;
-    uint16_t* const ctx = (uint16_t*)mine;                          // [2 * list_cap][32] of (character | 8 * base_to_int << 8)
-    u64* const rbase = (u64*)(mine + (size_t)2 * list_cap * 64);
+    uint8_t* const ctx = mine;                                      // [2 * list_cap + 1][32] characters: allele 0's rows, then allele 1's
+    u64* const rbase = (u64*)(mine + ((size_t)2 * list_cap + 1) * 32);
     u32* const rhave = (u32*)(rbase + 2 * list_cap);
     const u32 o8 = a.off8[valid ? c : c0];
     const bool rec_ok = (u64)o8 + 2ull <= a.stream8_cap;
@@ -287,6 +346,9 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     const u32 nr_max = max((u32)__builtin_amdgcn_readlane((int)nrows, 0), (u32)__builtin_amdgcn_readlane((int)nrows, 32));
     const u32* idx = w + 4;
     const uint8_t* pp = r + 16 + 4 * (size_t)(n0 + n1);
+    if (hl < 2u) s_minh[wave][half][hl] = 32u;                      // the shortest row of either allele: columns at or behind it hold a 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (u32 j0 = 0; j0 < nr_max; j0 += 32u) {
         const u32 j = j0 + hl;
         if (j < nrows) {
@@ -302,13 +364,15 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
             const bool near = have != 0u && base + 32ull > a.text_bytes;
             any_near |= near;
             rbase[j] = base; rhave[j] = have | (near ? TL_ROW_NEAR_END : 0u);
+            atomicMin(&s_minh[wave][half][j < m0 ? 0 : 1], have);
         }
     }
     any_near = __ballot(any_near) != 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    tl_gather_rows<8>(a, ctx, rbase, rhave, nrows, nr_max, hl);     // rows of 32 entries, 8 lanes per row
-    if (any_near) tl_gather_rows_bytes<8>(a, ctx, rbase, rhave, nrows, nr_max, hl);
+    u32 odd = tl_gather_rows_b(a, ctx, rbase, rhave, nrows, nr_max, hl);   // rows of 32 characters, 8 lanes per row
+    if (any_near) { tl_gather_rows_b_bytes(a, ctx, rbase, rhave, nrows, nr_max, hl); odd = 1u; }   // (the text's last bytes: not checked, the sequential loop)
+    const bool plain = __ballot(odd != 0u) == 0ull;                 // every character of the wave's rows is one of {0, A, C, G, T}
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     u32 supp0 = 0u, supp1 = 0u;
@@ -316,42 +380,74 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     for (int s = 0; s < 2; ++s) {
         const u32 n = s ? m1 : m0;
         const u32 n_max = max((u32)__builtin_amdgcn_readlane((int)n, 0), (u32)__builtin_amdgcn_readlane((int)n, 32));
-        const uint16_t* rows = ctx + (size_t)(s ? m0 : 0u) * 32;
-        u32 C = 'A', bc8 = 0u, cnt = 0u;                            // cons (include.hpp:334-371): as in k_consensus
+        const uint8_t* rows = ctx + (size_t)(s ? m0 : 0u) * 32;
         const u32 n_col = colok ? n : 0u;                           // rows this lane takes part in: ONE compare per row says whether it counts
-        // (two rows per trip, both LDS reads in flight together: half the loop control, one wait for two rows.  The row behind the last one
-        //  of an odd list lies inside the candidate's LDS area -- 2 * list_cap rows, their bases / lengths, one spare row -- and is masked.)
-        for (u32 j = 0; j < n_max; j += 2u) {
-            u32 ra = (u32)rows[(size_t)j * 32 + hl], rb = (u32)rows[(size_t)(j + 1u) * 32 + hl];   // (read whether the lane has the row or not, masked in registers)
-            asm volatile("" : "+v"(ra), "+v"(rb));
+        u32 C = 'A';
+        bool seq = !plain;
+        if (plain) {
+            // the four totals of the column, 8 bits each (a list holds at most 150 contexts).  Two rows per trip, both LDS reads in flight
+            // together; the row behind the last one of an odd list lies inside the candidate's LDS area (the spare row) and is masked.
+            u32 cnt = 0u;
+            for (u32 j = 0; j < n_max; j += 2u) {
+                u32 ra = (u32)rows[(size_t)j * 32 + hl], rb = (u32)rows[(size_t)(j + 1u) * 32 + hl];   // (read whether the lane has the row or not)
+                asm volatile("" : "+v"(ra), "+v"(rb));
 #pragma unroll
-            for (u32 q = 0; q < 2u; ++q) {
-                const bool on = j + q < n_col;
-                const u32 v = on ? (q ? rb : ra) : 0u;
-                const u32 ch = v & 0xFFu, b8 = v >> 8;
-                cnt += on ? 1u << b8 : 0u;
-                // (no `on` here: C's count is the largest at all times, so a lane without a row -- v = 0, class 0 -- never takes over)
-                if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
+                for (u32 q = 0; q < 2u; ++q) {
+                    const u32 one = j + q < n_col ? 1u : 0u;
+                    cnt += one << (((q ? rb : ra) << 2) & 0x18u);   // slot (ch >> 1) & 3: {0, A} 0, C 1, T 2, G 3
+                }
+            }
+            const u32 t0 = cnt & 0xFFu, t1 = (cnt >> 8) & 0xFFu, t2 = (cnt >> 16) & 0xFFu, t3 = cnt >> 24;
+            const u32 M = max(max(t0, t1), max(t2, t3));
+            const u32 x = cnt ^ (M * 0x01010101u);
+            const u32 z = ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x)) & 0x80808080u;   // 0x80 in the bytes that hold M (at least one)
+            const u32 slot8 = (u32)__builtin_ctz(z) - 7u;           // the lowest such slot, times 8 (all totals 0: slot 0, 'A', as cons starts)
+            C = (0x47544341u >> slot8) & 0xFFu;                     // "ACTG" by slot
+            const bool tie = __popc(z) > 1 && M != 0u;
+            const u32 r0 = (u32)rows[hl];
+            const bool never_lost = (((r0 << 2) & 0x18u) == 0u) & ((cnt & 0xFEFEFE00u) == 0u);   // row 0 is class 0 and no other class occurs twice
+            const bool zero_col = hl >= s_minh[wave][half][s];
+            const bool redo = n_col != 0u && (tie || (slot8 == 0u && zero_col && (cnt & 0xFFFFFF00u) != 0u && !never_lost));
+            seq = __ballot(redo) != 0ull;
+        }
+        if (seq) {                                                  // cons as the reference runs it (wave-uniform branch)
+            u32 bc8 = 0u, cnt = 0u;                                 // bc8 = 8 * base_to_int(C)
+            C = 'A';
+            for (u32 j = 0; j < n_max; j += 2u) {
+                u32 ra = (u32)rows[(size_t)j * 32 + hl], rb = (u32)rows[(size_t)(j + 1u) * 32 + hl];
+                asm volatile("" : "+v"(ra), "+v"(rb));
+#pragma unroll
+                for (u32 q = 0; q < 2u; ++q) {
+                    const bool on = j + q < n_col;
+                    const u32 ch = on ? (q ? rb : ra) : 0u;
+                    const u32 f = ch & 0xDFu, code = (f >> 1) & 3u;  // base_to_int without a branch: the letter f could be, by its low three bits
+                    const u32 e = __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, f & 7u) & 0xFFu;
+                    const u32 b8 = e == f ? (code ^ (code >> 1)) << 3 : 0u;
+                    cnt += on ? 1u << b8 : 0u;
+                    // (no `on` here: C's count is the largest at all times, so a lane without a row -- class 0 -- never takes over)
+                    if (((cnt >> b8) & 0xFFu) > ((cnt >> bc8) & 0xFFu)) { C = ch; bc8 = b8; }
+                }
             }
         }
+        uint8_t* const sx = s ? sb : sa;
+        sx[hl] = (uint8_t)(colok ? C : 0u);                         // (0 behind k_left: the rows hold 0 there, too)
+        sx[32 + hl] = 0;
+        if (valid && colok) a.cons[c * 128 + (u64)s * 64 + hl] = (uint8_t)C;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // supports: lane hl takes row j0 + hl -- its 32 characters against the consensus, 8 dwords
+        const uint4 k0 = *(const uint4*)sx, k1 = *(const uint4*)(sx + 16);
         u32 supp = 0u;
-        // (the rows are read whether the lane has one or not and masked in registers: a read under a condition is a branch and an EXEC
-        //  save / restore per row)
-        for (u32 j = 0; j < n_max; j += 2u) {
-            u32 ra = (u32)rows[(size_t)j * 32 + hl] & 0xFFu, rb = (u32)rows[(size_t)(j + 1u) * 32 + hl] & 0xFFu;
-            asm volatile("" : "+v"(ra), "+v"(rb));                      // (keeps the reads where they are: the compiler would sink them under `on` again)
-#pragma unroll
-            for (u32 q = 0; q < 2u; ++q) {
-                u32 ch = j + q < n_col ? (q ? rb : ra) : C;             // a lane without a row agrees with the consensus: ONE compare is the ballot
-                asm volatile("" : "+v"(ch));                            // (... and stays one: `on & (r8 != C)` costs a 0 / 1 round trip through a register)
-                const u32 d = tl_half_pop(__ballot(C != ch), half);
-                if (j + q < n && (int)d <= a.max_err) ++supp;
-            }
+        for (u32 j0 = 0; j0 < n_max; j0 += 32u) {
+            const u32 j = j0 + hl;
+            const uint8_t* row = rows + (size_t)(j < n ? j : 0u) * 32;
+            const uint4 x0 = *(const uint4*)row, x1 = *(const uint4*)(row + 16);
+            u32 d = tl_nzb(x0.x ^ k0.x, 0u);
+            d = tl_nzb(x0.y ^ k0.y, d); d = tl_nzb(x0.z ^ k0.z, d); d = tl_nzb(x0.w ^ k0.w, d);
+            d = tl_nzb(x1.x ^ k1.x, d); d = tl_nzb(x1.y ^ k1.y, d); d = tl_nzb(x1.z ^ k1.z, d); d = tl_nzb(x1.w ^ k1.w, d);
+            supp += tl_half_pop(__ballot(j < n && (int)d <= a.max_err), half);
         }
         if (s) supp1 = supp; else supp0 = supp;
-        (s ? sb : sa)[hl] = (uint8_t)C;
-        (s ? sb : sa)[32 + hl] = 0;
-        if (valid && colok) a.cons[c * 128 + (u64)s * 64 + hl] = (uint8_t)C;
     }
     bad = tl_half_pop(__ballot(bad & E2S_TAILERR_RANK), half) ? E2S_TAILERR_RANK : 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -656,7 +752,7 @@ static size_t tl_device_lds_bytes(int dev) {
 }
 static void tl_consensus_shape(int kl, uint32_t list_cap, size_t lds_cu, size_t* per_wave, unsigned* wpb) {
     if (list_cap < 1) list_cap = 1;
-    *per_wave = kl <= 32 ? (size_t)2 * (2 * list_cap * (64 + 8 + 4) + 64) : (size_t)2 * list_cap * (128 + 8 + 4);
+    *per_wave = kl <= 32 ? (size_t)2 * (((size_t)2 * list_cap * (32 + 8 + 4) + 32 + 31) & ~(size_t)31) : (size_t)2 * list_cap * (128 + 8 + 4);
     // (four waves per block while six such blocks fit a CU, two while three do: 60 / 120 KB of gfx950's 160)
     *wpb = 4 * *per_wave <= lds_cu * 3 / 8 ? 4u : 2 * *per_wave <= lds_cu * 3 / 4 ? 2u : 1u;
 }
