@@ -38,6 +38,14 @@ __device__ __forceinline__ u32 tl_pos(const uint8_t* p, u32 pw, u32 j) {
     return pw == 1u ? (u32)p[j] : pw == 2u ? (u32)p[2 * j] | ((u32)p[2 * j + 1] << 8) : ((const u32*)p)[j];
 }
 
+// entry j of a packed record's position list (1, 2 or 4 bytes each, the list 4-byte aligned inside an 8-byte aligned, 8-byte padded record):
+// the aligned dword that holds it, shifted -- one load whatever the width, no branch for the compiler to wait at
+__device__ __forceinline__ u32 tl_pos_rec(const uint8_t* p, u32 pw, u32 j) {
+    const u32 at = pw * j;
+    const u32 v = *(const u32*)(p + (at & ~3u)) >> (8u * (at & 3u));
+    return pw >= 4u ? v : v & ((1u << (8u * pw)) - 1u);
+}
+
 // base_to_int (include.hpp:265-279) of four characters at once: the class from bits 1-2 of the case-folded byte (A 0, C 1, G 3, T 2 ->
 // 0 1 2 3), kept only where the byte IS that letter -- its low three bits pick the one letter it could be from an 8-entry v_perm table
 __device__ __forceinline__ u32 tl_b2i4(u32 v) {
@@ -262,8 +270,8 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
 //     counts (5 instructions per row: the class slot is (ch >> 1) & 3 for the characters {0, A, C, G, T}, which the gather checks), the
 //     winner from the totals, and the sequential loop only for a wave that holds such a column (or any other character).  (b) is narrowed
 //     by what is cheap to know: the other classes' totals are all <= 1 and row 0 is class 0 => class 0 never lost the lead => 'A';
-//   * the supports (clust2snp.cpp:544-593) one ROW per lane: 32 B of the row against the consensus as 8 dwords, mismatching bytes counted
-//     by SWAR + v_bcnt -- ~55 instructions for up to 32 rows instead of ~14 per row.
+//   * the supports (clust2snp.cpp:544-593) one ROW per lane, both alleles' rows in one sweep: 32 B of the row against the consensus of
+//     its allele as 8 dwords, mismatching bytes counted by SWAR + v_bcnt -- ~70 instructions for up to 32 rows instead of ~14 per row.
 // Dynamic LDS per wave: 2 candidates x (2 x list_cap rows of 32 B + (8 + 4) B of row base / length each + one spare row), to 32 B.
 // (Round 3: the record's first 256 bytes fetched as ONE window -- a chain of five dependent round trips cut to three -- changed nothing.)
 __device__ __forceinline__ u32 tl_half_pop(u64 m, u32 half) { return (u32)__popc(half ? (u32)(m >> 32) : (u32)m); }
@@ -279,29 +287,26 @@ __device__ __forceinline__ u32 tl_gather_rows_b(const TailArgs& a, uint8_t* rows
     const u32 last = nrows ? nrows - 1u : 0u;
     u32 odd = 0u;
     for (u32 j0 = 0; j0 < nr_max; j0 += 4u * BATCH) {
-        u32 w4[BATCH];
+        u32 w4[BATCH], mk[BATCH];                                   // the dword as loaded, and which of its characters exist
 #pragma unroll
-        for (u32 u = 0; u < BATCH; ++u) {
-            w4[u] = 0u;
+        for (u32 u = 0; u < BATCH; ++u) {                           // (loads only: nothing here may wait for one of them)
+            w4[u] = 0u; mk[u] = 0u;
             if (j0 + 4u * u >= nr_max) break;                       // (wave-uniform)
             const u32 j = j0 + 4u * u + rsub, jj = min(j, last);
             const u32 have = rhave[jj];
             const u64 base = rbase[jj];
             const bool ok = (j < nrows) & ((int)q4 < (int)have);    // (a near-end row's length word is negative)
-            const u32 v = *(const u32*)(a.text + (ok ? base + q4 : 0ull));
+            w4[u] = *(const u32*)(a.text + (ok ? base + q4 : 0ull));
             const u32 keep = have - q4;
-            const u32 mask = keep >= 4u ? ~0u : (1u << (8u * keep)) - 1u;
-            w4[u] = ok ? v & mask : 0u;
-            // (a character that exists must be a letter of ACGT -- a 0 byte IN the text is not one; the 0s behind a row's end are ours)
-            odd |= ok ? (v ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, v & 0x07070707u)) & mask : 0u;   // [FF 'A' FF 'C' 'T' FF FF 'G']
+            mk[u] = !ok ? 0u : keep >= 4u ? ~0u : (1u << (8u * keep)) - 1u;
         }
 #pragma unroll
         for (u32 u = 0; u < BATCH; ++u) {
             if (j0 + 4u * u >= nr_max) break;
             const u32 j = j0 + 4u * u + rsub;
-            if (j < nrows) {
-                *(u32*)(rows + (size_t)j * 32u + q4) = w4[u];
-            }
+            // (a character that exists must be a letter of ACGT -- a 0 byte IN the text is not one; the 0s behind a row's end are ours)
+            odd |= (w4[u] ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, w4[u] & 0x07070707u)) & mk[u];   // [FF 'A' FF 'C' 'T' FF FF 'G']
+            if (j < nrows) *(u32*)(rows + (size_t)j * 32u + q4) = w4[u] & mk[u];
         }
     }
     return odd;
@@ -353,14 +358,15 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
         const u32 j = j0 + hl;
         if (j < nrows) {
             const u32 e = j < m0 ? j : n0 + (j - m0);
-            const u32 rd = idx[e];
-            u64 base = 0; u32 have = 0;
-            if ((u64)rd >= a.n_reads) bad |= E2S_TAILERR_RANK;
-            else {
-                const u32 len = a.rstart ? a.rlen[rd] : a.stride, p0 = tl_pos(pp, a.pos_pack, e);
-                have = p0 < len ? min(len - p0, kl) : 0u;
-                base = (a.rstart ? a.rstart[rd] : (u64)rd * a.stride) + p0;
-            }
+            // (read and position are both of the record: one round trip, not one behind the other -- and no branch on the read's rank, which
+            //  the compiler would put the second load behind)
+            const u32 rd = idx[e], p0 = tl_pos_rec(pp, a.pos_pack, e);
+            const bool rok = (u64)rd < a.n_reads;
+            const u32 rdc = rok ? rd : 0u;
+            const u32 len = a.rstart ? a.rlen[rdc] : a.stride;
+            const u32 have = rok && p0 < len ? min(len - p0, kl) : 0u;
+            const u64 base = rok ? (a.rstart ? a.rstart[rdc] : (u64)rdc * a.stride) + p0 : 0ull;
+            if (!rok) bad |= E2S_TAILERR_RANK;
             const bool near = have != 0u && base + 32ull > a.text_bytes;
             any_near |= near;
             rbase[j] = base; rhave[j] = have | (near ? TL_ROW_NEAR_END : 0u);
@@ -433,21 +439,23 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
         sx[hl] = (uint8_t)(colok ? C : 0u);                         // (0 behind k_left: the rows hold 0 there, too)
         sx[32 + hl] = 0;
         if (valid && colok) a.cons[c * 128 + (u64)s * 64 + hl] = (uint8_t)C;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // supports: lane hl takes row j0 + hl -- its 32 characters against the consensus, 8 dwords
-        const uint4 k0 = *(const uint4*)sx, k1 = *(const uint4*)(sx + 16);
-        u32 supp = 0u;
-        for (u32 j0 = 0; j0 < n_max; j0 += 32u) {
-            const u32 j = j0 + hl;
-            const uint8_t* row = rows + (size_t)(j < n ? j : 0u) * 32;
-            const uint4 x0 = *(const uint4*)row, x1 = *(const uint4*)(row + 16);
-            u32 d = tl_nzb(x0.x ^ k0.x, 0u);
-            d = tl_nzb(x0.y ^ k0.y, d); d = tl_nzb(x0.z ^ k0.z, d); d = tl_nzb(x0.w ^ k0.w, d);
-            d = tl_nzb(x1.x ^ k1.x, d); d = tl_nzb(x1.y ^ k1.y, d); d = tl_nzb(x1.z ^ k1.z, d); d = tl_nzb(x1.w ^ k1.w, d);
-            supp += tl_half_pop(__ballot(j < n && (int)d <= a.max_err), half);
-        }
-        if (s) supp1 = supp; else supp0 = supp;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // supports of BOTH alleles in one sweep: lane hl takes row j0 + hl of the candidate's m0 + m1 rows -- its 32 characters against the
+    // consensus of its allele, 8 dwords
+    for (u32 j0 = 0; j0 < nr_max; j0 += 32u) {
+        const u32 j = j0 + hl;
+        const bool in = j < nrows, second = j >= m0;
+        const uint8_t* row = ctx + (size_t)(in ? j : 0u) * 32;
+        const uint8_t* kx = second ? sb : sa;
+        const uint4 x0 = *(const uint4*)row, x1 = *(const uint4*)(row + 16), k0 = *(const uint4*)kx, k1 = *(const uint4*)(kx + 16);
+        u32 d = tl_nzb(x0.x ^ k0.x, 0u);
+        d = tl_nzb(x0.y ^ k0.y, d); d = tl_nzb(x0.z ^ k0.z, d); d = tl_nzb(x0.w ^ k0.w, d);
+        d = tl_nzb(x1.x ^ k1.x, d); d = tl_nzb(x1.y ^ k1.y, d); d = tl_nzb(x1.z ^ k1.z, d); d = tl_nzb(x1.w ^ k1.w, d);
+        const bool ok = in && (int)d <= a.max_err;
+        supp0 += tl_half_pop(__ballot(ok && !second), half);
+        supp1 += tl_half_pop(__ballot(ok && second), half);
     }
     bad = tl_half_pop(__ballot(bad & E2S_TAILERR_RANK), half) ? E2S_TAILERR_RANK : 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
