@@ -62,6 +62,7 @@ struct e2s_ctx {
     bool have_reads = false, reads_owned = false; uint8_t* d_text = nullptr; uint64_t* d_rstart = nullptr; uint32_t* d_rlen = nullptr;
     uint64_t n_reads = 0; uint32_t reads_max_len = 0;
     uint64_t text_bytes = 0;                                     // extent of d_text that the reads cover (the tail never loads past it)
+    uint2* d_text2 = nullptr; uint32_t* d_impure = nullptr; bool text2_owned = false, reads_all_acgt = false;   // the text as bit planes + reads outside "ACGT" (TailArgs::text2): pack_reads
     uint8_t* d_cons = nullptr; TailRec* d_trec = nullptr; uint64_t tail_cap = 0; unsigned long long* d_part = nullptr; uint64_t part_cap = 0;
     uint8_t* d_snp = nullptr; uint64_t snp_cap = 0, snp_bytes = 0, n_events = 0, n_variants = 0; bool variants_valid = false, snp_valid = false;
     e2s_tail_params tail_p{}; uint64_t snp_first_id = 1, snp_first_id_scan = 1, snp_bytes_at_first = 0;
@@ -237,7 +238,9 @@ static hipError_t wait_stream(e2s_ctx* h) {
 
 static void release_reads(e2s_ctx* h) {
     if (h->reads_owned) { dev_free(h->d_text); dev_free(h->d_rstart); dev_free(h->d_rlen); }
+    if (h->text2_owned) { dev_free(h->d_text2); dev_free(h->d_impure); }
     h->d_text = nullptr; h->d_rstart = nullptr; h->d_rlen = nullptr; h->have_reads = h->reads_owned = false; h->n_reads = 0;
+    h->d_text2 = nullptr; h->d_impure = nullptr; h->text2_owned = false; h->reads_all_acgt = false;
 }
 
 // Forget a pre-filter result that was started ahead of e2s_find_candidates (arm / begin): whatever replaces the shard, the
@@ -1699,6 +1702,29 @@ extern "C" int e2s_candidates_packed(e2s_handle h, const void** stream, const ui
 // ---------------------------------------------------------------------------------------------
 // clust2snp's tail on the GPU: reads resident in HBM, consensus / distance / KisSNP2 text by e2s_tail.hip
 // ---------------------------------------------------------------------------------------------
+// The resident text a second time as two bit planes per 32 characters (+ one bit per read that holds a character outside "ACGT"): the
+// half-wave consensus kernel gathers a left context from it as ONE 16-byte load instead of eight dwords across 1.5 cache lines.  A quarter
+// of the text's bytes; built where the reads become resident (they must not change while they are: the kernels read them asynchronously
+// anyway).  Without the memory for it the tail gathers bytes as before.  E2S_TAIL_PACKED=0 (development): not built.
+static int pack_reads(e2s_ctx* h) {
+    if (!h->have_reads || h->text_bytes < 4) return E2S_OK;
+    const char* sw = e2s_env_dev("E2S_TAIL_PACKED");
+    if (sw && sw[0] == '0') return E2S_OK;
+    const size_t b2 = (size_t)(h->text_bytes / 32 + 3) * sizeof(uint2), bi = (size_t)((h->n_reads + 31) / 32 + 1) * 4;
+    if (hipMalloc((void**)&h->d_text2, b2) != hipSuccess) { (void)hipGetLastError(); h->d_text2 = nullptr; return E2S_OK; }
+    if (hipMalloc((void**)&h->d_impure, bi) != hipSuccess) { (void)hipGetLastError(); dev_free(h->d_text2); h->d_text2 = nullptr; h->d_impure = nullptr; return E2S_OK; }
+    h->text2_owned = true;
+    CK(hipMemsetAsync(h->d_text2, 0, b2, h->stream));
+    CK(hipMemsetAsync(h->d_impure, 0, bi, h->stream));
+    e2s_launch_reads_pack2(h->d_text, h->text_bytes, h->d_rstart, h->d_rlen, h->reads_max_len, h->n_reads, h->d_text2, h->d_impure, h->stream);
+    LCHK("e2s_launch_reads_pack2");
+    uint32_t any = 1;                                             // (the word behind the bits: is any read flagged at all?  No: the kernel looks nothing up)
+    CK(hipMemcpyAsync(&any, h->d_impure + (h->n_reads + 31) / 32, 4, hipMemcpyDeviceToHost, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->reads_all_acgt = any == 0;
+    return E2S_OK;
+}
+
 extern "C" int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len) {
     dbg_entry("e2s_attach_reads");
     if (!h || (n_reads && (!d_text || ((d_start == nullptr) != (d_len == nullptr)) || (!d_start && !max_len)))) return E2S_ERR_ARG;
@@ -1716,7 +1742,7 @@ extern "C" int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t
         CK(hipMemcpyAsync(&h->text_bytes, ext, 8, hipMemcpyDeviceToHost, h->stream));
         CK(hipStreamSynchronize(h->stream));
     }
-    return E2S_OK;
+    return pack_reads(h);
 }
 
 // (private, ebwt2snp_amd/host/chunked.cpp) a second handle on the same device reads the first one's resident reads
@@ -1726,6 +1752,7 @@ extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src) {
     dst->d_text = src->d_text; dst->d_rstart = src->d_rstart; dst->d_rlen = src->d_rlen; dst->n_reads = src->n_reads;
     dst->reads_max_len = src->reads_max_len; dst->have_reads = src->have_reads; dst->reads_owned = false; dst->variants_valid = false;
     dst->text_bytes = src->text_bytes;
+    dst->d_text2 = src->d_text2; dst->d_impure = src->d_impure; dst->text2_owned = false; dst->reads_all_acgt = src->reads_all_acgt;
     return E2S_OK;
 }
 
@@ -1759,7 +1786,7 @@ extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_by
         h->d_text = dense; h->d_rstart = nullptr; h->d_rlen = nullptr;
         h->text_bytes = n_reads * (uint64_t)max_len;
     }
-    return E2S_OK;
+    return pack_reads(h);
 }
 
 // what the GPU tail needs before it can run at all (both e2s_call_variants and the resident job)
@@ -1800,6 +1827,7 @@ static int tail_prepare(e2s_ctx* h, const e2s_tail_params* p, uint64_t n, TailAr
     a = TailArgs{};
     a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
     a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
+    a.text2 = h->d_text2; a.impure = h->reads_all_acgt ? nullptr : h->d_impure;
     a.kl = p->k_left; a.kr = p->k_right; a.max_gap = p->max_gap; a.max_err = p->max_err;
     a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = totals + 4; a.err = (uint32_t*)(h->d_part + 6);
     a.stream8_cap = h->stream_cap_bytes / 8;
@@ -1878,6 +1906,7 @@ extern "C" int e2s_renumber_snp(e2s_handle h, uint64_t first_id, uint64_t* snp_b
         TailArgs a{};
         a.stream = h->d_stream; a.off8 = (const uint32_t*)(h->d_stream + h->stream_ord_off); a.n_cand = n; a.pos_pack = h->pos_pack;
         a.text = h->d_text; a.rstart = h->d_rstart; a.rlen = h->d_rlen; a.n_reads = h->n_reads; a.stride = h->reads_max_len; a.text_bytes = h->text_bytes;
+        a.text2 = h->d_text2; a.impure = h->reads_all_acgt ? nullptr : h->d_impure;
         a.kl = h->tail_p.k_left; a.kr = h->tail_p.k_right; a.max_gap = h->tail_p.max_gap; a.max_err = h->tail_p.max_err;
         a.cons = h->d_cons; a.rec = h->d_trec; a.part = part_raw; a.n_keep = h->d_part + 4; a.err = (uint32_t*)(h->d_part + 6);
         a.slot_of = h->tail_by_slot ? h->d_order : nullptr;

@@ -160,6 +160,10 @@ struct TailArgs {
     const uint8_t* text; const uint64_t* rstart; const uint32_t* rlen; uint64_t n_reads;  // the reads: read r = text[rstart[r] .. +rlen[r])
     uint32_t stride;           // rstart == nullptr: every read is `stride` long and read r starts at r * stride (no index to look up)
     uint64_t text_bytes;       // extent of the text (>= 4): no load reaches past it
+    // the same text as two bit planes per 32 characters (e2s_launch_reads_pack2; nullptr: not built): text2[g] = (plane of bit 0, plane of bit 1)
+    // of the codes (ch >> 1) & 3 -- A 0, C 1, T 2, G 3 -- of characters 32 g .. 32 g + 31; a character outside "ACGT" has code 0 and its
+    // READ's bit set in `impure`: k_consensus_pair gathers a left context as ONE 16-byte load where none of a wave's reads is flagged
+    const uint2* text2; const uint32_t* impure;                  // (impure == nullptr with text2 set: no read is flagged)
     int kl, kr, max_gap, max_err;
     uint8_t* cons;             // [n_cand][2][64] consensus strings
     TailRec* rec;              // [n_cand]
@@ -205,6 +209,10 @@ void e2s_launch_tail_partials(const unsigned long long* part, unsigned long long
                               const uint32_t* bad_a, const uint32_t* bad_b, const uint32_t* bad_c, const unsigned long long* n_cand_dev, hipStream_t st);
 void e2s_launch_reads_extent(const uint64_t* rstart, const uint32_t* rlen, uint64_t n_reads, unsigned long long* out, hipStream_t st);   // *out = max(start + len), *out zeroed by the caller
 void e2s_launch_reads_compact(const uint8_t* text, const uint64_t* rstart, uint32_t len, uint64_t n_reads, uint8_t* out, hipStream_t st);
+// the reads as bit planes (TailArgs::text2 / impure): out holds text_bytes / 32 + 3 pairs, impure (n_reads + 31) / 32 words + one more that is
+// set when any read is flagged, both zeroed by the caller
+void e2s_launch_reads_pack2(const uint8_t* text, uint64_t text_bytes, const uint64_t* rstart, const uint32_t* rlen, uint32_t stride, uint64_t n_reads,
+                            uint2* out, uint32_t* impure, hipStream_t st);
 void e2s_launch_tail_write(const TailArgs& a, const unsigned long long* part_excl, unsigned long long first_id, const unsigned long long* first_id_dev,
                            uint8_t* out, unsigned long long out_cap, hipStream_t st, const unsigned long long* ids2 = nullptr, int world = 1, int rank = 0,
                            JobDev* jd = nullptr, const unsigned long long* mail_src = nullptr, unsigned long long* mail_dst = nullptr, uint32_t mail_words = 0);

@@ -351,6 +351,9 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     const u32 nr_max = max((u32)__builtin_amdgcn_readlane((int)nrows, 0), (u32)__builtin_amdgcn_readlane((int)nrows, 32));
     const u32* idx = w + 4;
     const uint8_t* pp = r + 16 + 4 * (size_t)(n0 + n1);
+    const bool try2 = a.text2 != nullptr;                           // the reads as bit planes are there
+    u32 imp = 0u;                                                   // a row of a read that holds a character outside "ACGT"
+    uint2* const prow = (uint2*)ctx;                                // [2 * list_cap] rows as (plane of bit 0, plane of bit 1): where the byte rows go if they are needed
     if (hl < 2u) s_minh[wave][half][hl] = 32u;                      // the shortest row of either allele: columns at or behind it hold a 0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -371,18 +374,87 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
             any_near |= near;
             rbase[j] = base; rhave[j] = have | (near ? TL_ROW_NEAR_END : 0u);
             atomicMin(&s_minh[wave][half][j < m0 ? 0 : 1], have);
+            if (try2) {
+                // the row from the bit planes: the two groups of 32 characters it lies in (16 bytes, 8-byte aligned: one line 7 times out of 8),
+                // shifted to its first character, cut to the characters that exist -- the lane that knows the row fetches it
+                const u32 iw = a.impure ? a.impure[rdc >> 5] : 0u;   // (nullptr: no read of the text is flagged -- nothing to look up)
+                const uint2 g0 = a.text2[base >> 5], g1 = a.text2[(base >> 5) + 1ull];
+                const u32 sh = (u32)base & 31u, vm = have >= 32u ? ~0u : (1u << have) - 1u;
+                prow[j] = make_uint2(__builtin_amdgcn_alignbit(g1.x, g0.x, sh) & vm, __builtin_amdgcn_alignbit(g1.y, g0.y, sh) & vm);
+                imp |= rok ? (iw >> (rdc & 31u)) & 1u : 0u;
+            }
         }
     }
-    any_near = __ballot(any_near) != 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    u32 supp0 = 0u, supp1 = 0u;
+    const bool colok = hl < kl;
+    // ---- the usual case on the bit planes: none of the wave's reads holds a character outside "ACGT", and the column totals decide both
+    // consensus strings.  Anything else -- a flagged read, a tie at the top, class 0 winning a column that holds a 0 -- takes the bytes below.
+    bool fast2 = try2 && __ballot(imp != 0u) == 0ull;
+    if (fast2) {
+        u32 C2[2] = {'A', 'A'};
+        for (int s = 0; s < 2 && fast2; ++s) {
+            const u32 n = s ? m1 : m0;
+            const u32 n_max = max((u32)__builtin_amdgcn_readlane((int)n, 0), (u32)__builtin_amdgcn_readlane((int)n, 32));
+            const uint2* pr = prow + (s ? m0 : 0u);
+            const u32 n_col = colok ? n : 0u;
+            u32 cnt = 0u;
+            for (u32 j = 0; j < n_max; j += 2u) {                   // (the row behind an odd list's last one lies inside the candidate's LDS area and is masked)
+                uint2 ra = pr[j], rb = pr[j + 1u];
+                asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(rb.x), "+v"(rb.y));
+#pragma unroll
+                for (u32 q = 0; q < 2u; ++q) {
+                    const uint2 w = q ? rb : ra;
+                    const u32 one = j + q < n_col ? 1u : 0u;
+                    cnt += one << ((((w.x >> hl) & 1u) << 3) | (((w.y >> hl) & 1u) << 4));   // slot = the code: A 0, C 1, T 2, G 3
+                }
+            }
+            const u32 t0 = cnt & 0xFFu, t1 = (cnt >> 8) & 0xFFu, t2 = (cnt >> 16) & 0xFFu, t3 = cnt >> 24;
+            const u32 M = max(max(t0, t1), max(t2, t3));
+            const u32 x = cnt ^ (M * 0x01010101u);
+            const u32 z = ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x)) & 0x80808080u;   // 0x80 in the bytes that hold M (at least one)
+            const u32 slot8 = (u32)__builtin_ctz(z) - 7u;
+            C2[s] = (0x47544341u >> slot8) & 0xFFu;                 // "ACTG" by slot
+            const bool tie = __popc(z) > 1 && M != 0u;
+            const uint2 r0 = pr[0];
+            const bool never_lost = ((((r0.x | r0.y) >> hl) & 1u) == 0u) & ((cnt & 0xFEFEFE00u) == 0u);   // row 0 is class 0 and no other class occurs twice
+            const bool zero_col = hl >= s_minh[wave][half][s];
+            const bool redo = n_col != 0u && (tie || (slot8 == 0u && zero_col && (cnt & 0xFFFFFF00u) != 0u && !never_lost));
+            if (__ballot(redo) != 0ull) fast2 = false;
+        }
+        if (fast2) {
+            sa[hl] = (uint8_t)(colok ? C2[0] : 0u); sa[32 + hl] = 0;
+            sb[hl] = (uint8_t)(colok ? C2[1] : 0u); sb[32 + hl] = 0;
+            if (valid && colok) { a.cons[c * 128 + hl] = (uint8_t)C2[0]; a.cons[c * 128 + 64 + hl] = (uint8_t)C2[1]; }
+            // the consensus strings as planes (every letter is one of ACGT here), per half; then the supports one row per lane: a column of the
+            // row mismatches where its code differs or where the row has ended (its character is 0, the consensus holds a letter)
+            const u32 k0 = (C2[0] >> 1) & 3u, k1 = (C2[1] >> 1) & 3u;
+            const u64 b0l = __ballot(colok && (k0 & 1u)), b0h = __ballot(colok && (k0 & 2u)), b1l = __ballot(colok && (k1 & 1u)), b1h = __ballot(colok && (k1 & 2u));
+            const u32 c0l = half ? (u32)(b0l >> 32) : (u32)b0l, c0h = half ? (u32)(b0h >> 32) : (u32)b0h;
+            const u32 c1l = half ? (u32)(b1l >> 32) : (u32)b1l, c1h = half ? (u32)(b1h >> 32) : (u32)b1h;
+            const u32 colmask = kl >= 32u ? ~0u : (1u << kl) - 1u;
+            for (u32 j0 = 0; j0 < nr_max; j0 += 32u) {
+                const u32 j = j0 + hl;
+                const bool in = j < nrows, second = j >= m0;
+                const uint2 row = prow[in ? j : 0u];
+                const u32 hv = rhave[in ? j : 0u] & ~TL_ROW_NEAR_END;
+                const u32 vm = hv >= 32u ? ~0u : (1u << hv) - 1u;
+                const u32 diff = (row.x ^ (second ? c1l : c0l)) | (row.y ^ (second ? c1h : c0h));
+                const u32 d = (u32)__popc(((diff & vm) | ~vm) & colmask);
+                const bool ok = in && (int)d <= a.max_err;
+                supp0 += tl_half_pop(__ballot(ok && !second), half);
+                supp1 += tl_half_pop(__ballot(ok && second), half);
+            }
+        }
+    }
+  if (!fast2) {
+    any_near = __ballot(any_near) != 0ull;
     u32 odd = tl_gather_rows_b(a, ctx, rbase, rhave, nrows, nr_max, hl);   // rows of 32 characters, 8 lanes per row
     if (any_near) { tl_gather_rows_b_bytes(a, ctx, rbase, rhave, nrows, nr_max, hl); odd = 1u; }   // (the text's last bytes: not checked, the sequential loop)
     const bool plain = __ballot(odd != 0u) == 0ull;                 // every character of the wave's rows is one of {0, A, C, G, T}
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    u32 supp0 = 0u, supp1 = 0u;
-    const bool colok = hl < kl;
     for (int s = 0; s < 2; ++s) {
         const u32 n = s ? m1 : m0;
         const u32 n_max = max((u32)__builtin_amdgcn_readlane((int)n, 0), (u32)__builtin_amdgcn_readlane((int)n, 32));
@@ -457,6 +529,7 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
         supp0 += tl_half_pop(__ballot(ok && !second), half);
         supp1 += tl_half_pop(__ballot(ok && second), half);
     }
+  }
     bad = tl_half_pop(__ballot(bad & E2S_TAILERR_RANK), half) ? E2S_TAILERR_RANK : 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -737,6 +810,49 @@ __global__ __launch_bounds__(256) void k_reads_extent(const u64* rstart, const u
     for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n_reads; r += (u64)gridDim.x * 256) m = max(m, rstart[r] + rlen[r]);
     for (int d = 32; d; d >>= 1) m = max(m, (u64)__shfl_xor((unsigned long long)m, d));
     if (tl_lane() == 0 && m) atomicMax(out, (unsigned long long)m);
+}
+// ---- the reads as two bit planes per 32 characters (TailArgs::text2): thread t takes characters 32 t .. 32 t + 31
+__global__ __launch_bounds__(256) void k_reads_pack2(const uint8_t* text, u64 text_bytes, u32 stride, u64 n_reads, uint2* out, u32* impure) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x, at = t * 32ull;
+    if (at >= text_bytes) return;
+    u32 lo = 0u, hi = 0u;
+#pragma unroll
+    for (u32 k = 0; k < 8u; ++k) {
+        const u64 p = at + 4ull * k;
+        u32 w = 0u, have = 0u;                                      // (the last group of the text: byte by byte)
+        if (p + 4ull <= text_bytes) { w = *(const u32*)(text + p); have = 4u; }
+        else for (; p + have < text_bytes; ++have) w |= (u32)text[p + have] << (8u * have);
+        const u32 x = w ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, w & 0x07070707u);   // zero byte <=> one of "ACGT" (see tl_gather_rows_b)
+        const u32 badm = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;               // 0x80 per byte that is not
+        const u32 okb = ((badm ^ 0x80808080u) >> 7) * 0xFFu;                                  // 0xFF per byte that is
+        const u32 c = (w >> 1) & 0x03030303u & okb;
+        lo |= (((c & 0x01010101u) * 0x10204080u) >> 28) << (4u * k);
+        hi |= ((((c >> 1) & 0x01010101u) * 0x10204080u) >> 28) << (4u * k);
+        if (impure && stride) {                                     // (reads of one length: the read follows from the position)
+            for (u32 i = 0; i < have; ++i) if ((badm >> (8u * i + 7u)) & 1u) {
+                const u64 rd = (p + i) / stride;
+                if (rd < n_reads) { atomicOr(&impure[rd >> 5], 1u << (rd & 31u)); impure[(n_reads + 31) / 32] = 1u; }   // (the word behind the bits: any at all)
+            }
+        }
+    }
+    out[t] = make_uint2(lo, hi);
+}
+// reads of their own lengths: which of them hold a character outside "ACGT" (a thread per read)
+__global__ __launch_bounds__(256) void k_reads_impure(const uint8_t* text, const u64* rstart, const u32* rlen, u64 n_reads, u32* impure) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint8_t* p = text + rstart[r];
+    const u32 n = rlen[r];
+    bool bad = false;
+    for (u32 i = 0; i < n; ++i) { const u32 ch = p[i]; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+    if (bad) { atomicOr(&impure[r >> 5], 1u << (r & 31u)); impure[(n_reads + 31) / 32] = 1u; }
+}
+void e2s_launch_reads_pack2(const uint8_t* text, uint64_t text_bytes, const uint64_t* rstart, const uint32_t* rlen, uint32_t stride, uint64_t n_reads,
+                            uint2* out, uint32_t* impure, hipStream_t st) {
+    if (!text_bytes) return;
+    const uint64_t groups = (text_bytes + 31) / 32;
+    hipLaunchKernelGGL(k_reads_pack2, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, text, (u64)text_bytes, rstart ? 0u : stride, (u64)n_reads, out, impure);
+    if (rstart && n_reads) hipLaunchKernelGGL(k_reads_impure, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, text, (const u64*)rstart, rlen, (u64)n_reads, impure);
 }
 void e2s_launch_reads_extent(const uint64_t* rstart, const uint32_t* rlen, uint64_t n_reads, unsigned long long* out, hipStream_t st) {
     if (!n_reads) return;

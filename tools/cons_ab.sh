@@ -1,10 +1,16 @@
 #!/bin/bash
-# the half-wave consensus kernel in its counting form against the build before it (build/ab/libe2s_hip_seq.so: the sequential per-row loops),
-# A/B/A/B on ONE box: per-kernel averages of the bench step under rocprofv3 + the step itself;  tools/cons_ab.sh [bench args, e.g. --workload c3e]
+# the half-wave consensus kernel, A/B/C twice on ONE box: per-kernel averages of the bench step under rocprofv3 + the step itself
+#   new    the library as built (left contexts gathered from the reads' bit planes)
+#   bytes  the same library with E2S_TAIL_PACKED=0 (development switch: the planes are not built, eight dwords per row from the text)
+#   seq    build/ab/libe2s_hip_seq.so, if present: the build before the counting form (sequential per-row loops)
+#   tools/cons_ab.sh [bench args, e.g. --workload c3e]
 root=$(pwd); out=$root/gpurun_out/r4_cons_ab; mkdir -p $out
+vs="new bytes"; [ -z "$NOSEQ" ] && [ -f $root/build/ab/libe2s_hip_seq.so ] && vs="new bytes seq"
 for i in 1 2; do
-  for v in new seq; do
-    if [ $v = seq ]; then export E2S_LIB_PATH=$root/build/ab/libe2s_hip_seq.so; else unset E2S_LIB_PATH; fi
+  for v in $vs; do
+    unset E2S_LIB_PATH E2S_DEV E2S_TAIL_PACKED
+    [ $v = seq ] && export E2S_LIB_PATH=$root/build/ab/libe2s_hip_seq.so
+    [ $v = bytes ] && export E2S_DEV=1 E2S_TAIL_PACKED=0
     tools/kstats.sh "$@" > $out/${v}_$i.txt 2>&1 || { tail -5 $out/${v}_$i.txt; exit 1; }
     echo "== $v $i: $(grep -E 'k_consensus' $out/${v}_$i.txt | tr -s ' ') | $(grep -E 'k_flagged' $out/${v}_$i.txt | tr -s ' ' | cut -c1-60) | $(grep 'bench under' $out/${v}_$i.txt)"
   done
