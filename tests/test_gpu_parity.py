@@ -1162,7 +1162,7 @@ def test_chunked_clust2snp_switches_to_host_tail_midway(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,L,letters,rate", [(201, 31, "CGTacgt", 0.05), (202, 31, "CGTacgt", 0.05), (203, 40, "CGTacgt", 0.05), (204, 17, "CGTacgt", 0.05),
                                                   (205, 64, "CGTacgt", 0.05), (206, 31, "CGT", 0.05), (207, 31, "CGT", 0.15), (208, 24, "CGT", 0.2), (209, 32, "CGT", 0.1),
-                                                  (210, 31, "CGTR", 0.04), (211, 9, "CGT", 0.2), (212, 31, "C", 0.12), (213, 31, "CGT|Rn", 0.08)])
+                                                  (210, 31, "CGTR", 0.04), (211, 9, "CGT", 0.2), (212, 31, "C", 0.12), (213, 31, "CGT|Ry", 0.08)])
 def test_gpu_tail_fuzz_columns(H, tmp_path, seed, L, letters, rate):
     """the GPU tail on columns that no real index produces: positions and read numbers unrelated to the reads (mostly A, some lower
     case), suffixes that start at the very end of a read -- of the LAST read, too, where a dword of the gather would reach past the
@@ -1170,7 +1170,7 @@ def test_gpu_tail_fuzz_columns(H, tmp_path, seed, L, letters, rate):
     alphabets reach the half-wave kernel's counting form of cons (totals first, the sequential loop only for a wave with a tie at the
     top or a class-0 winner in a column with a 0 behind a read's end): two-letter reads at 12 % make the ties, "CGTR" the mixed waves (another letter is class 0 with its own character; N draws rand() in the reference).
     The same alphabets decide where the left contexts come from: reads of "ACGT" only are gathered from their bit planes (TailArgs::text2),
-    "CGT|Rn" flags one read in 23, so that the kernel looks the reads up and takes the planes in some waves and the bytes in others"""
+    "CGT|Ry" flags one read in 23, so that the kernel looks the reads up and takes the planes in some waves and the bytes in others"""
     en, _, mcov, Rc = _fuzz_columns(seed)
     rnd = np.random.RandomState(seed)
     n = en["lcp"].size
