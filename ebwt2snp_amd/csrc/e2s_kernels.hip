@@ -1836,10 +1836,45 @@ __device__ __forceinline__ u32 ko_bucket(u64 key, u64 key_lo, u32 shift, u32 nb)
 }
 // n_dev (optional): the count lives on the device (the launch is sized for the capacity n)
 __device__ __forceinline__ u64 ko_n(u64 n, const unsigned long long* n_dev) { return n_dev ? min(n, (u64)*n_dev) : n; }
+// The scan for 1024 .. 16384 buckets (what e2s_cand_order_buckets gives up to 5x10^5 candidates) by ONE SMALL block: four waves, a
+// thread's <= 64 counts in its registers between the two halves of the scan (one round trip), the waves' totals through four words of LDS.
+// The 1024-thread form below took 30 us whatever the number of buckets -- not for its work: the ordering pass runs beside the consensus
+// kernel, which fills every wave slot of the chip, and a block of sixteen waves waits until one CU has FOUR free slots on each SIMD at
+// once, about a consensus wave's lifetime; one wave per SIMD finds room as soon as anything ends.  (With the consensus kernel at 42 us for
+// a rank of eight, the ordering pass beside it had become the longer of the two.)
+__device__ __forceinline__ void ko_scan256(u32* cnt, u32 nb, u32* s_w /* [4], shared */) {
+    const u32 tid = threadIdx.x, per = nb / 256u, lo = tid * per;  // per: 4, 8, 16, 32 or 64
+    uint4 v[16];
+#pragma unroll
+    for (u32 q = 0; q < 16u; ++q) v[q] = 4u * q < per ? *(const uint4*)(cnt + lo + 4u * q) : make_uint4(0, 0, 0, 0);
+    u32 sum = 0;
+#pragma unroll
+    for (u32 q = 0; q < 16u; ++q) sum += v[q].x + v[q].y + v[q].z + v[q].w;
+    const u32 inc = wave_incl_scan(sum);
+    if ((tid & 63u) == 63u) s_w[tid >> 6] = inc;
+    __syncthreads();
+    u32 run = inc - sum;
+    for (u32 w = 0; w < (tid >> 6); ++w) run += s_w[w];
+#pragma unroll
+    for (u32 q = 0; q < 16u; ++q) {
+        if (4u * q < per) {
+            uint4 o;
+            o.x = run; run += v[q].x; o.y = run; run += v[q].y; o.z = run; run += v[q].z; o.w = run; run += v[q].w;
+            *(uint4*)(cnt + lo + 4u * q) = o;
+        }
+    }
+    if (tid == 255u) cnt[nb] = run;
+}
 __global__ void k_ko_count(const u64* keys, u64 n, const unsigned long long* n_dev, u64 key_lo, u32 shift, u32 nb, u32* cnt, u32* slot) {
     n = ko_n(n, n_dev);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) slot[i] = atomicAdd(&cnt[ko_bucket(keys[i], key_lo, shift, nb)], 1u);
+}
+// (Tried: the count kernel's LAST block -- a ticket -- doing the scan, one launch less on the chain: 77 us instead of 9 + 15 -- two thousand
+//  blocks' tickets on one word, and a device-scope fence per block that empties the L1 under the consensus kernel beside it: 39 -> 92 us.)
+__global__ __launch_bounds__(256) void k_ko_scan256(u32* cnt, u32 nb) {
+    __shared__ u32 s_w[4];
+    ko_scan256(cnt, nb, s_w);
 }
 // exclusive scan of cnt[0..nb) in place, total at cnt[nb] (one block; nb a power of two >= 256, or a multiple of 4096).  A thread owns `per`
 // consecutive counts and moves them 16 at a time (four 16-byte loads in flight), not one global round trip each.
@@ -1954,7 +1989,8 @@ void e2s_launch_cand_order(const u64* keys, u64 n, const unsigned long long* n_d
     if (!counts_cleared) (void)hipMemsetAsync(cnt, 0, ((size_t)nb + 1) * 4, st);   // (a failure stays in hipGetLastError, which the caller reads after the launches)
     const dim3 g((unsigned)((n + 255) / 256)), blk(256);
     hipLaunchKernelGGL(k_ko_count, g, blk, 0, st, keys, n, n_dev, key_lo, shift, nb, cnt, slot);
-    hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, cnt, nb);
+    if (nb >= 1024u && nb <= 16384u) hipLaunchKernelGGL(k_ko_scan256, dim3(1), dim3(256), 0, st, cnt, nb);
+    else hipLaunchKernelGGL(k_ko_scan, dim3(1), dim3(1024), 0, st, cnt, nb);
     hipLaunchKernelGGL(k_ko_place, g, blk, 0, st, keys, n, n_dev, key_lo, shift, nb, (const u32*)cnt, (const u32*)slot, gkeys, gidx);
     hipLaunchKernelGGL(k_ko_rank, g, blk, 0, st, (const u64*)gkeys, (const u32*)gidx, n, n_dev, key_lo, shift, nb, (const u32*)cnt, order);
 }
