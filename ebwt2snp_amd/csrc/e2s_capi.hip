@@ -2241,7 +2241,15 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     unsigned long long* totals = h->d_part;
     unsigned long long* part_raw = h->d_part + 8; unsigned long long* part_excl = part_raw + 3 * (h->part_cap + 1);
     uint32_t* tail_err = (uint32_t*)(h->d_part + 6);
-    if (cons_beside && n_pieces == 1) {
+    // Which arm of the fork behind the lists stays on the handle's stream: the LONGER one, so that the join finds the other arm done and costs
+    // nothing (a cross-stream wait that is not yet satisfied adds 10-12 us behind the later arm, and the arm on the other stream starts 8-10 us
+    // late).  The ordering pass is ~46 us whatever the shard; the consensus takes ~1.3 ns per candidate: the longer arm for a shard of c3's
+    // size (0.33 ms against 0.15), the shorter one for an eighth of it (40 us) -- there the ordering pass keeps the stream (the arrangement
+    // below, with one piece).  The candidates are not known at enqueue time: 1 per ~12 000 entries as on c3 / c3e; a wrong guess costs the
+    // ~20 us it would have saved.  E2S_JOB_ORDER_FIRST=0 / 1 (development) forces it.
+    static const char* order_first_env = e2s_env_dev("E2S_JOB_ORDER_FIRST");
+    const bool order_first = order_first_env ? order_first_env[0] == '1' : h->n_prov / 12000 < 40000;
+    if (cons_beside && n_pieces == 1 && !order_first) {
         // The consensus needs the candidates, not their order: it runs BY SLOT beside the ordering pass.  The CRITICAL chain -- lists ->
         // consensus -> sums -> text -- stays on the handle's stream with nothing but the fork's event between its kernels; the ordering pass
         // (five small kernels, long done when the consensus ends) goes to the third stream.  (Round 3 had it the other way round: the

@@ -886,8 +886,10 @@ def test_resident_job_in_pieces(tmp_path):
     drv = os.path.join(os.path.dirname(os.path.abspath(__file__)), "job_pieces_driver.py")
     for pieces, beside, tiny_cap, extra in ((3, 1, 0, {}), (8, 1, 0, {}), (0, 0, 0, {}), (1, 1, 16, {}), (3, 1, 16, {}), (0, 0, 16, {}),
                                             (1, 1, 0, {"E2S_TEST_FL_CAP": "8", "E2S_TEST_EXPECT_FALLBACK": "1"}),
-                                            (1, 1, 0, {"E2S_TEST_SEG_CAP": "8", "E2S_TEST_EXPECT_FALLBACK": "2"})):
-        out = str(tmp_path / ("img%d_%d_%d_%d" % (pieces, beside, tiny_cap, len(extra))))
+                                            (1, 1, 0, {"E2S_TEST_SEG_CAP": "8", "E2S_TEST_EXPECT_FALLBACK": "2"}),
+                                            # which arm of the fork behind the lists keeps the handle's stream (the library picks by the shard's size)
+                                            (1, 1, 0, {"E2S_JOB_ORDER_FIRST": "0"}), (1, 1, 0, {"E2S_JOB_ORDER_FIRST": "1"})):
+        out = str(tmp_path / ("img%d_%d_%d_%s" % (pieces, beside, tiny_cap, "_".join(sorted(extra.values())))))
         env = dict(os.environ, E2S_JOB_PIECES=str(pieces), E2S_JOB_CONS_BESIDE=str(beside))
         if tiny_cap:
             # a fresh handle with room for 16 candidates: the job overflows its slots (the tail still runs over what there is), says so in
