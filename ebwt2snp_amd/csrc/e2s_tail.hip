@@ -3,6 +3,7 @@
 //   K3a k_consensus[_pair]  extract_variants: the <= c + c left contexts of a candidate gathered from the reads, the two
 //                           consensus strings with cons' order-dependent tie-break (include.hpp:334-371), the supports
 //                           (clust2snp.cpp:544-593), the right context, and distance() (clust2snp.cpp:254-302)
+//                           (k_left <= 32: the left contexts from the reads' bit planes -- k_reads_pack2 -- where every read of the wave is "ACGT" only)
 //   K3b k_tail_partials     exclusive scan of the per-group event counts / text lengths (one block)
 //   K3c k_tail_write        to_file (clust2snp.cpp:633-780): the KisSNP2 text of every event, ids sequential, written into
 //                           one image in HBM at offsets that follow from the scan
