@@ -12,6 +12,7 @@ from ebwt2snp_amd import synth, egsa_io as IO
 
 E2C, C2S = os.path.join(ROOT, "bin", "ebwt2clust"), os.path.join(ROOT, "bin", "clust2snp")
 RAGGED = os.environ.get("E2S_STRESS_RAGGED", "0") == "1"       # (off: the seeds of rounds 1-2 produce the cases they produced then)
+ERRORS = os.environ.get("E2S_STRESS_ERRORS", "0") == "1"       # sequencing errors in half of the cases (0.5 - 3 %): ties and near-ties in the consensus
 
 
 def case(seed, d):
@@ -23,7 +24,8 @@ def case(seed, d):
     if ragged:
         reads, n1, e, _ = synth.synth_case_ragged(R, L, seed=seed, coverage=cov, tail_lcp0=t0)
     else:
-        reads, n1, e = synth.synth_case(R, L, seed=seed, coverage=cov, tail_lcp0=t0)
+        err = rnd.choice([0.005, 0.01, 0.03]) if ERRORS and rnd.random() < 0.5 else 0.0
+        reads, n1, e = synth.synth_case(R, L, seed=seed, coverage=cov, tail_lcp0=t0, error_rate=err)
         reads = reads.numpy()
     en = synth.egsa_to_numpy(e, *xyz)
     ext = rnd.choice(["fasta", "fa", "fastq.txt"])              # H14: output name derived from the last ".fast"
