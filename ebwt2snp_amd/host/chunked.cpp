@@ -213,7 +213,12 @@ int chunk_tail(e2s_handle h, uint64_t n_cand, e2s_byte_sink snp_sink, void* snp_
 }
 int finish_tail(TailState& ts, const char* fasta_path, e2s_byte_sink snp_sink, void* snp_user, const char* out_path) {
     if (ts.cands == 0) return E2S_ERR_REF_CRASH;                 // zero candidates: the reference crashes before creating the file
-    if (!ts.host_mode) return E2S_OK;
+    if (!ts.host_mode) {
+        // candidates, but not one event (every candidate lost its supports or lies beyond -v): the reference has opened its output by then
+        // and leaves it EMPTY -- the lazily created file of the chunks' sink never came into being
+        if (out_path && ts.events == 0) { FILE* f = fopen(out_path, "w"); if (!f) return E2S_ERR_IO; fclose(f); }
+        return E2S_OK;
+    }
     if (!fasta_path) return E2S_ERR_STATE;
     ts.off8.push_back((uint32_t)(ts.stream.size() / 8));
     std::string tmp = out_path ? std::string(out_path) : std::string("/tmp/e2s_tail_XXXXXX");

@@ -514,6 +514,11 @@ int main(int argc, char** argv) {
     std::cout << "Cluster sizes allowed: [" << o.mcov_out * 2 << "," << S.mcl << "]" << std::endl;
     std::cout << "Done. " << cands << " potential variants detected (some might be detected twice: on fw and rev strands)" << std::endl;
     if (cands == 0) { std::cerr << "no candidate variant: the reference crashes here (SIGSEGV, clust2snp.cpp:531); no .snp written" << std::endl; return 139; }
+    if (events == 0) {       // candidates, but not one event: the reference has opened its output by then and leaves it EMPTY (the file above comes with the first event)
+        const int fd = ::open(S.snp_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) { std::cerr << "could not create " << S.snp_path << std::endl; return 2; }
+        ::close(fd);
+    }
     std::cout << events << " events saved to " << S.snp_path << std::endl;
     if (const char* jp = getenv("E2S_CLI_JSON")) {                  // a perf report in a side file (stdout stays as it is)
         if (FILE* f = *jp ? fopen(jp, "w") : nullptr) {

@@ -846,6 +846,33 @@ def test_reads_with_sequencing_errors_equal_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_candidates_without_events_leave_an_empty_snp(tmp_path):
+    """candidates, but not one event (reads with 3 % sequencing errors and -n cutting the samples in the wrong place: the one candidate's
+    supports vanish): the reference has opened its output by then and leaves it EMPTY, exit code 0 -- so do bin/clust2snp, whose `.snp`
+    otherwise comes into being with its first event (found by tools/stress_cli.py with E2S_STRESS_ERRORS=1, seed 16024), and
+    bin/ebwt2snp_mgpu in both of its forms"""
+    import subprocess
+    reads, n1, e = synth.synth_case(1500, 100, seed=16024, coverage=10, tail_lcp0=True, error_rate=0.03)
+    en = synth.egsa_to_numpy(e)
+    p = str(tmp_path / "r.fasta")
+    IO.write_fasta(p, reads.numpy())
+    IO.write_bcr(p, en["text"], en["suff"], en["lcp"], en["bwt"])
+    assert O.ebwt2clust(p)[0] == 0 and O.clust2snp(p, O.c2s_opts(750, L=40))[0] == 0
+    snp = IO.snp_out_path(p)
+    want_cl = open(p + ".clusters", "rb").read()
+    assert os.path.getsize(snp) == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cmds, env in (([["ebwt2clust", "-i", p], ["clust2snp", "-i", p, "-n", "750", "-L", "40"]], {}),
+                      ([["ebwt2snp_mgpu", "-i", p, "-n", "750", "-L", "40", "-G", "1"]], {}),
+                      ([["ebwt2snp_mgpu", "-i", p, "-n", "750", "-L", "40", "-G", "1"]], {"E2S_MGPU_FULL_COLUMNS": "1"})):
+        os.remove(snp); os.remove(p + ".clusters")
+        for c in cmds:
+            r = subprocess.run([os.path.join(root, "bin", c[0])] + c[1:], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+            assert r.returncode == 0, (c, r.stdout[-300:], r.stderr[-300:])
+        assert open(p + ".clusters", "rb").read() == want_cl and os.path.exists(snp) and os.path.getsize(snp) == 0, (cmds, env)
+
+
+@pytest.mark.gpu
 def test_cli_json_report(tmp_path):
     """E2S_CLI_JSON=<path>: the executables leave a perf report beside their outputs (a `--json` report; an environment
     switch, so that the option strings stay the reference's): one JSON object, counts equal to what the tools print / write"""
