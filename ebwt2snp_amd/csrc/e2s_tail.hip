@@ -275,6 +275,9 @@ __global__ __launch_bounds__(256) void k_consensus(TailArgs a, u32 list_cap) {
 //     its allele as 8 dwords, mismatching bytes counted by SWAR + v_bcnt -- ~70 instructions for up to 32 rows instead of ~14 per row.
 // Dynamic LDS per wave: 2 candidates x (2 x list_cap rows of 32 B + (8 + 4) B of row base / length each + one spare row), to 32 B.
 // (Round 3: the record's first 256 bytes fetched as ONE window -- a chain of five dependent round trips cut to three -- changed nothing.)
+// LDS of ONE candidate of the half-wave kernel (kernel and launcher take it from here): 2 x list_cap rows of 32 B, one spare row (the counting
+// loops read two rows per trip), (8 + 4) B of row base / length per row, to 32 B
+__host__ __device__ constexpr size_t tl_pair_cand_lds(u32 list_cap) { return ((size_t)2 * list_cap * (32 + 8 + 4) + 32 + 31) & ~(size_t)31; }
 __device__ __forceinline__ u32 tl_half_pop(u64 m, u32 half) { return (u32)__popc(half ? (u32)(m >> 32) : (u32)m); }
 __device__ __forceinline__ u32 tl_nzb(u32 x, u32 acc) {            // acc + the number of nonzero bytes of x
     const u32 t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
     if (c0 >= a.n_cand) return;
     const u64 c = c0 + half;
     const bool valid = c < a.n_cand;
-    const size_t per_cand = ((size_t)2 * list_cap * (32 + 8 + 4) + 32 + 31) & ~(size_t)31;   // (+ one row: the counting loop reads two rows per trip)
+    const size_t per_cand = tl_pair_cand_lds(list_cap);
     uint8_t* const mine = s_tail + ((size_t)wave * 2 + half) * per_cand;
     uint8_t* const ctx = mine;                                      // [2 * list_cap + 1][32] characters: allele 0's rows, then allele 1's
     u64* const rbase = (u64*)(mine + ((size_t)2 * list_cap + 1) * 32);
@@ -877,7 +880,7 @@ static size_t tl_device_lds_bytes(int dev) {
 }
 static void tl_consensus_shape(int kl, uint32_t list_cap, size_t lds_cu, size_t* per_wave, unsigned* wpb) {
     if (list_cap < 1) list_cap = 1;
-    *per_wave = kl <= 32 ? (size_t)2 * (((size_t)2 * list_cap * (32 + 8 + 4) + 32 + 31) & ~(size_t)31) : (size_t)2 * list_cap * (128 + 8 + 4);
+    *per_wave = kl <= 32 ? 2 * tl_pair_cand_lds(list_cap) : (size_t)2 * list_cap * (128 + 8 + 4);
     // (four waves per block while six such blocks fit a CU, two while three do: 60 / 120 KB of gfx950's 160)
     *wpb = 4 * *per_wave <= lds_cu * 3 / 8 ? 4u : 2 * *per_wave <= lds_cu * 3 / 4 ? 2u : 1u;
 }
