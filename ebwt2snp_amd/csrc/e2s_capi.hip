@@ -1714,7 +1714,7 @@ static int pack_reads(e2s_ctx* h) {
     if (hipMalloc((void**)&h->d_text2, b2) != hipSuccess) { (void)hipGetLastError(); h->d_text2 = nullptr; return E2S_OK; }
     if (hipMalloc((void**)&h->d_impure, bi) != hipSuccess) { (void)hipGetLastError(); dev_free(h->d_text2); h->d_text2 = nullptr; h->d_impure = nullptr; return E2S_OK; }
     h->text2_owned = true;
-    CK(hipMemsetAsync(h->d_text2, 0, b2, h->stream));
+    CK(hipMemsetAsync((uint8_t*)h->d_text2 + b2 - 3 * sizeof(uint2), 0, 3 * sizeof(uint2), h->stream));   // (the kernel writes every group of the text: only the slack behind them)
     CK(hipMemsetAsync(h->d_impure, 0, bi, h->stream));
     e2s_launch_reads_pack2(h->d_text, h->text_bytes, h->d_rstart, h->d_rlen, h->reads_max_len, h->n_reads, h->d_text2, h->d_impure, h->stream);
     LCHK("e2s_launch_reads_pack2");

@@ -820,11 +820,16 @@ __global__ __launch_bounds__(256) void k_reads_pack2(const uint8_t* text, u64 te
     const u64 t = (u64)blockIdx.x * 256 + threadIdx.x, at = t * 32ull;
     if (at >= text_bytes) return;
     u32 lo = 0u, hi = 0u;
+    // (a group inside the text of a 16-byte aligned buffer -- every group but the last, usually -- comes as two 16-byte loads)
+    const bool whole = at + 32ull <= text_bytes && (((uintptr_t)text) & 15u) == 0u;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    if (whole) { q0 = *(const uint4*)(text + at); q1 = *(const uint4*)(text + at + 16); }
 #pragma unroll
     for (u32 k = 0; k < 8u; ++k) {
         const u64 p = at + 4ull * k;
         u32 w = 0u, have = 0u;                                      // (the last group of the text: byte by byte)
-        if (p + 4ull <= text_bytes) { w = *(const u32*)(text + p); have = 4u; }
+        if (whole) { w = k == 0 ? q0.x : k == 1 ? q0.y : k == 2 ? q0.z : k == 3 ? q0.w : k == 4 ? q1.x : k == 5 ? q1.y : k == 6 ? q1.z : q1.w; have = 4u; }
+        else if (p + 4ull <= text_bytes) { w = *(const u32*)(text + p); have = 4u; }
         else for (; p + have < text_bytes; ++have) w |= (u32)text[p + have] << (8u * have);
         const u32 x = w ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, w & 0x07070707u);   // zero byte <=> one of "ACGT" (see tl_gather_rows_b)
         const u32 badm = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;               // 0x80 per byte that is not

@@ -266,7 +266,7 @@ int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n
  * line structure is irregular (a header after a header, no header first, ...), where the reference's line juggling yields
  * text this index cannot express: keep to e2s_snp_from_packed then.
  * Make the reads resident BEFORE e2s_find_candidates: the candidates then stay in HBM instead of crossing PCIe.
- * Both calls also keep the text a second time as 2-bit planes (a quarter of its bytes; one pass over it, ~2 ms for 3 GB) from which the
+ * Both calls also keep the text a second time as 2-bit planes (a quarter of its bytes; one pass over it, ~1.7 ms for 3 GB) from which the
  * consensus kernel gathers the left contexts of reads made of "ACGT" alone: attached reads must not change while they are attached. */
 /* dst uses the reads resident on src (same device) without a copy; src keeps ownership and must outlive dst's use of them */
 int e2s_share_reads(e2s_handle dst, e2s_handle src);
