@@ -14,8 +14,14 @@ all: lib bins oracle
 lib: $(LIB)
 
 LIBSRC   = $(CSRC)/e2s_kernels.hip $(CSRC)/e2s_tail.hip $(CSRC)/e2s_capi.hip $(HOST)/snp_tail.cpp $(HOST)/fasta_index.cpp $(HOST)/reads_upload.cpp $(HOST)/chunked.cpp
-$(LIB): $(LIBSRC) $(CSRC)/e2s_internal.h $(CSRC)/e2s_swar.h $(CSRC)/e2s_plan.h $(HOST)/fasta_index.hpp include/e2s_hip.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(LIBSRC) -lpthread
+# the library exports what include/e2s_hip.h declares and nothing else (the calls between its own translation units, the kernels' host
+# stubs and launchers stay local; e2s_diag_*: diagnostic builds only, e.g. EXTRA=-DE2S_DIAG_STAMPS)
+EXPORTS  = build/e2s_exports.map
+$(EXPORTS): include/e2s_hip.h
+	@mkdir -p build
+	@(echo "{ global:"; grep -oE '\be2s_[a-z0-9_]+[[:space:]]*\(' $< | tr -d ' (' | sort -u | sed 's/$$/;/'; echo "e2s_diag_*; local: *; };") > $@
+$(LIB): $(LIBSRC) $(CSRC)/e2s_internal.h $(CSRC)/e2s_swar.h $(CSRC)/e2s_plan.h $(CSRC)/e2s_env.h $(HOST)/fasta_index.hpp include/e2s_hip.h $(EXPORTS)
+	$(HIPCC) $(HIPFLAGS) -shared -Wl,--version-script=$(EXPORTS) -o $@ $(LIBSRC) -lpthread
 
 bins: bin/ebwt2clust bin/clust2snp bin/ebwt2snp_mgpu
 

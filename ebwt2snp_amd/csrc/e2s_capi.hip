@@ -612,7 +612,7 @@ static int ensure_image(e2s_ctx* h, uint64_t records) {
     dev_free(h->d_img); dev_free(h->d_img_scratch); h->d_img = nullptr; h->d_img_scratch = nullptr; h->img_cap = 0;
     const uint64_t cap = records + records / 8 + 4096;
     CK(hipMalloc((void**)&h->d_img, cap * 10 + 64));
-    CK(hipMalloc((void**)&h->d_img_scratch, std::max<uint64_t>(e2s_pack_clusters_blocks(cap) * 12 + 64, (uint64_t)(8192 + 2) * 12 + 64)));
+    CK(hipMalloc((void**)&h->d_img_scratch, std::max<uint64_t>(e2s_pack_clusters_blocks(cap) * 12 + 64, (uint64_t)(E2S_SEGFIX_MAX + 2) * 12 + 64)));
     h->img_cap = cap;
     return E2S_OK;
 }
@@ -683,9 +683,18 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
         nb = std::min<uint64_t>(nb, (uint64_t)fused_resident);
     } else if (armed) nb = std::min<uint64_t>(nb, 4096);         // leave registers for the pre-filter's waves beside it
     if (nb == 0) nb = 1;
+    // The scan runs over RANGES of tiles, one wave each and several times as many as waves are resident: the dispatcher hands the next block
+    // of four ranges to whatever CU has room (k_scan_seg).  A range is a segment of the output.  Ranges of E2S_SCAN_RANGE_TILES tiles (a
+    // range's start-up -- the carries from the entries before it, its descriptor, its block's share of the histogram -- costs about a third
+    // of a tile), as many as k_seg_fix handles at most, at least one per resident wave.
+    const uint64_t nw = nb;
+    static const int range_tiles_env = e2s_env_dev("E2S_SCAN_RANGE_TILES") ? atoi(e2s_env_dev("E2S_SCAN_RANGE_TILES")) : 0;
+    const uint64_t range_tiles = range_tiles_env > 0 ? (uint64_t)range_tiles_env : (uint64_t)E2S_SCAN_RANGE_TILES;
+    nb = std::max<uint64_t>(nw, std::min<uint64_t>((uint64_t)E2S_SEGFIX_MAX, (sa.n_tiles + range_tiles - 1) / range_tiles));
+    nb = std::min<uint64_t>(nb, std::max<uint64_t>(sa.n_tiles, 1));
     sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
     sa.tiles_rem = (uint32_t)(sa.n_tiles % nb);
-    if (nb > 8192) return fail(h, E2S_ERR_STATE, "more scan workers than k_seg_fix handles");
+    if (nb > (uint64_t)E2S_SEGFIX_MAX) return fail(h, E2S_ERR_STATE, "more scan ranges than k_seg_fix handles");
     sa.n_blocks = (uint32_t)nb;
     if (nb + 1 > h->seg_blocks_cap) {
         dev_free(h->d_seg_desc); dev_free(h->d_seg_off); dev_free(h->d_kept_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->d_kept_off = nullptr;

@@ -10,6 +10,10 @@
 #define E2S_SPAN_BYTES 64        // bytes of LCP per thread and tile in the segmented scan
 #endif
 #define E2S_MAX_CLUST_LEN_K 150
+#define E2S_SEGFIX_MAX 32768     // segments (= ranges of the scan) k_seg_fix ties together
+#ifndef E2S_SCAN_RANGE_TILES
+#define E2S_SCAN_RANGE_TILES 8   // tiles per range of the scan where the shard leaves the choice (large shards: n_tiles / E2S_SEGFIX_MAX)
+#endif
 
 // device-side error bits
 #define E2S_DEVERR_REMOTE 2u   // a cluster's entries are not resident in this shard
@@ -69,7 +73,7 @@ struct SegArgs {
     const void* lcp; uint64_t n_prov, prov_lo; uint32_t prov_is_global0;
     uint64_t own_lo, end_hi, start_hi;
     uint32_t k_u32, kb, hge;
-    uint64_t n_tiles; uint32_t tiles_per_block; uint32_t n_blocks;   // worker b owns tiles_per_block tiles, +1 for b < tiles_rem
+    uint64_t n_tiles; uint32_t tiles_per_block; uint32_t n_blocks;   // range (= segment) b holds tiles_per_block tiles, +1 for b < tiles_rem; n_blocks ranges
     uint32_t tiles_rem;
     uint32_t* starts32; uint16_t* lens; uint32_t seg_cap;      // segment b = [b*seg_cap, (b+1)*seg_cap): start - first entry of worker b's range, length
     SegDesc* desc;

@@ -138,6 +138,11 @@ __device__ __forceinline__ u64 wave_first64(u64 v) {
 }
 // (The scan that wrote the packed image itself -- tickets, per-chunk status words, a decoupled look-back -- was built and measured in round 3 and
 //  lost by 2x to segments + one layout kernel (profiles/round3_scan_image_variant.txt); it lives in the history: commit b90733f.)
+#ifdef E2S_DIAG_STAMPS
+// diagnostic build only (tools/scan_stamps.py): when every range of the scan started and ended (s_memrealtime, 100 MHz), and where it ran.
+// The stamps go to a buffer nothing else reads; no result depends on them.
+__device__ unsigned long long g_e2s_stamps[32768 * 4];
+#endif
 template <int X, bool FUSED>
 __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f) {
     static_assert(!FUSED || (X == 1 && SPAN_WORDS == 16), "the fused pre-filter works on 1-byte LCPs, 64 entries per lane");
@@ -152,16 +157,26 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // the block's histogram replicas (4 per wave: lengths concentrate on a few values), two 64-bit sums
     __shared__ u32 s_hist[16][E2S_MAX_CLUST_LEN_K + 2];
     __shared__ u64 s_acc[2];
+    __shared__ u32 s_arrived;                                   // waves of the block that are done
     for (u32 i = threadIdx.x; i < 16u * (E2S_MAX_CLUST_LEN_K + 2); i += 256u) (&s_hist[0][0])[i] = 0u;
     if (threadIdx.x < 2) s_acc[threadIdx.x] = 0ull;
+    if (threadIdx.x == 2) s_arrived = 0u;
     __syncthreads();
     // the lane's share of the statistics: records kept and their base count (lengths of disjoint clusters inside a range of < 2^32 entries)
     u32 l_kept = 0, l_nb32 = 0;
     u32 qn = 0;                                                 // (FUSED) flagged clusters queued in LDS: wave state, kept from range to range
     __shared__ u64 s_q[FUSED ? 4 : 1][FUSED ? F2_Q : 1];
     u64* const q = s_q[FUSED ? wslot : 0];
-    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // worker (= segment) index
+    // Every WAVE takes ONE range of tiles (= segment), and there are several times as many ranges as waves fit on the chip: the hardware's
+    // dispatcher is the work queue -- a block's four waves take four consecutive ranges, and the next block starts where wave slots come
+    // free.  Measured with as many ranges as resident waves, one each (profiles/round5_scan_worker_ends.txt): the four waves of a SIMD do
+    // not share its issue slots evenly -- the oldest ended at 0.55 of the kernel's length, the youngest at 0.92, the slowest few at 1.0 --
+    // and 27 % of the wave slots' time stood empty.
+    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // range (= segment) index
     const bool working = b < a.n_blocks;                        // (every wave of the block meets at the barrier below)
+#ifdef E2S_DIAG_STAMPS
+    const u64 diag_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (working) {
     const u64 t0 = (u64)b * a.tiles_per_block + min(b, a.tiles_rem);
     const u64 t1 = min(t0 + (u64)a.tiles_per_block + (b < a.tiles_rem ? 1u : 0u), a.n_tiles);
@@ -597,6 +612,14 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
         else { d.open_after = 1; d.open_start = g_range + (open1 - 1u); }
         d.kept = kept_w; d.last_kept1 = 0u; d.last_kept_len = 0u; d.first_start = ~0ull;      // (last_kept*: no longer filled in -- seg_last_kept)
         a.desc[b] = d;
+#ifdef E2S_DIAG_STAMPS
+        if (b < 32768u) {
+            g_e2s_stamps[4 * b + 0] = diag_t0;
+            g_e2s_stamps[4 * b + 1] = __builtin_amdgcn_s_memrealtime();
+            g_e2s_stamps[4 * b + 2] = ((u64)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
+            g_e2s_stamps[4 * b + 3] = ((u64)run << 32) | (u64)(t1 - t0);
+        }
+#endif
     }
     }
     // the block's share of the statistics: one flush of the histogram replicas and the two sums
@@ -604,14 +627,21 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { l_nrec += __shfl_xor((unsigned long long)l_nrec, o); l_nb += __shfl_xor((unsigned long long)l_nb, o); }
     if (lane == 0 && l_nrec) { atomicAdd((unsigned long long*)&s_acc[0], (unsigned long long)l_nrec); atomicAdd((unsigned long long*)&s_acc[1], (unsigned long long)l_nb); }
-    __syncthreads();
-    for (u32 i = threadIdx.x; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 256u) {
+    // No barrier at the end: the four waves' ranges take different times (each wave competes with the other waves of its own SIMD), and a wave
+    // that waited here kept its slot from the next block's waves -- measured, 7 % of the wave slots' time (profiles/round5_scan_worker_ends.txt).
+    // A wave leaves as soon as it has counted itself in; the LAST one of the block flushes the replicas.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    u32 arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&s_arrived, 1u);
+    if ((u32)__builtin_amdgcn_readfirstlane((int)arrived) != 3u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (u32 i = lane; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 64u) {
         u32 v = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) v += s_hist[r][i];
         if (v) atomicAdd(&a.stats[i], (unsigned long long)v);
     }
-    if (threadIdx.x == 0 && s_acc[0]) { atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 1], (unsigned long long)s_acc[0]); atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 2], (unsigned long long)s_acc[1]); }
+    if (lane == 0 && s_acc[0]) { atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 1], (unsigned long long)s_acc[0]); atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 2], (unsigned long long)s_acc[1]); }
 }
 
 // shard descriptors: begins_inside / open_after / end_before_last and the two last LCP values, evaluated scalar-ly on the
@@ -674,7 +704,7 @@ __device__ void shard_flags_eval(const void* lcp, u64 n_prov, u64 prov_lo, u64 o
 // the per-worker counts), the records whose start lies in an earlier block -- with their share of the kept counts and the
 // statistics, which the scan could not tally without their length --, the statistics themselves (the scan's block-wise sums plus
 // those shares), and the ScanMail the host downloads.
-constexpr int SEGFIX_MAX = 8192;             // scan workers (= resident waves: 256 CUs x <= 32)
+constexpr int SEGFIX_MAX = E2S_SEGFIX_MAX;   // segments (= ranges of the scan) one launch ties together: 32 per thread at most
 __device__ __forceinline__ u64 seg_range_base(const SegArgs& a, u32 b, u32 row_entries) {      // SA position of the first entry of worker b's range
     return a.prov_lo + ((u64)b * a.tiles_per_block + min(b, a.tiles_rem)) * (u64)row_entries;
 }
@@ -697,120 +727,127 @@ __device__ __forceinline__ u32 seg_last_kept(const SegArgs& a, u32 b, u32 count,
 }
 // blob (the resident job): this rank's share of the first all-gather -- e2s_boundary + e2s_scan_stats exactly as e2s_boundary_desc /
 // e2s_scan_stats_desc hand them out (tail_bwt_arg >= 0: the BWT byte of the shard's last entry given by the caller, e2s_upload_lcp).
+//
+// A thread owns a CONTIGUOUS run of segments (dpt = ceil(n / 1024) of them) and walks it three times -- the descriptors stay in the caches --,
+// with what the run inherits and where it begins taken from scans over the 1024 threads' summaries (wave scans + one LDS round per scan):
+//   1. sums of the counts, the last cluster left open in the run (or "every segment lies inside one cluster": PASS);
+//   2. with the open cluster the run inherits: record 0 of every segment whose cluster began in an earlier one gets its start and length,
+//      its place in the statistics and -- if append_entry keeps it -- in the kept counts;
+//   3. with the run's offsets: the exclusive sums of raw and kept counts per segment.
 __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err,
                                                   const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out,
                                                   u64* stats_out, uint8_t* blob, int is_last_rank, int tail_bwt_arg) {
-    __shared__ u32 s_cnt[SEGFIX_MAX];
-    __shared__ u32 s_kept[SEGFIX_MAX];
-    __shared__ u64 s_open[SEGFIX_MAX];       // open_start | PASS (inside one cluster throughout) | NONE (closed after the block)
-    __shared__ u32 s_part[1024], s_kpart[1024];
+    __shared__ u64 s_wopen[16];              // per wave: the last open start of its threads' runs | PASS | NONE
+    __shared__ u32 s_wcnt[16], s_wkept[16];
     __shared__ u32 s_first, s_last, s_err, s_lastk;
     __shared__ u32 s_hadj[E2S_MAX_CLUST_LEN_K + 2];
     __shared__ u64 s_nadj[2];
     const u64 NONE = ~0ull, PASS = ~0ull - 1;
-    const u32 tid = threadIdx.x, nb = a.n_blocks;
+    const u32 tid = threadIdx.x, nb = a.n_blocks, lane = tid & 63u, wave = tid >> 6;
     const u32 row_entries = 64u * (64u / (u32)xb);
     __shared__ u32 s_flags[4], s_tailv[2];
     if (tid == 0) { s_first = 0xFFFFFFFFu; s_last = 0; s_err = 0; s_lastk = 0; s_nadj[0] = 0; s_nadj[1] = 0; }
     for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 2); i += 1024u) s_hadj[i] = 0u;
     // the shard's boundary flags (an otherwise idle thread, while the others fetch descriptors)
     if (tid == 1023) shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, (u32)xb, s_flags, s_tailv);
-    __syncthreads();
-    // every descriptor this thread looks at is loaded up front (<= 8, all in flight together: the loop used to pay
-    // one global-memory latency per trip, twice)
-    constexpr int DPT = SEGFIX_MAX / 1024;
-    u32 d_cnt[DPT], d_unk[DPT]; u64 d_fend[DPT];
+    static_assert(SEGFIX_MAX <= 32 * 1024, "a thread's run of segments: one bit each in slotmask");
+    const u32 dpt = (nb + 1023u) / 1024u;                       // <= 32
+    const u32 lo = min(nb, tid * dpt), hi = min(nb, lo + dpt);
+    auto open_of = [&](const SegDesc& d) -> u64 { return !d.open_after ? NONE : (d.open_start != NONE ? d.open_start : PASS); };
+    // ---- walk 1
+    u32 sum = 0; u64 run_open = PASS;
     {
-        SegDesc d[DPT];
-#pragma unroll
-        for (int q = 0; q < DPT; ++q) {                         // unconditional (clamped) loads: one basic block, all in flight
-            const u32 b = tid + (u32)q * 1024u;
-            d[q] = a.desc[b < nb ? b : (nb ? nb - 1u : 0u)];
-        }
         u32 fmin = 0xFFFFFFFFu, fmax = 0u, ferr = 0u;
-#pragma unroll
-        for (int q = 0; q < DPT; ++q) {
-            const u32 b = tid + (u32)q * 1024u;
-            const bool in = b < nb;
-            d_cnt[q] = in ? d[q].count : 0u; d_unk[q] = d[q].first_unknown; d_fend[q] = d[q].first_end_pos;
-            if (in) {
-                s_cnt[b] = d[q].count;
-                s_kept[b] = d[q].kept;
-                s_open[b] = !d[q].open_after ? NONE : (d[q].open_start != NONE ? d[q].open_start : PASS);
-                if (d[q].overflow) ferr = E2S_DEVERR_SEGFULL;
-                if (d[q].count) { fmin = min(fmin, b); fmax = max(fmax, b); }
-            }
+#pragma unroll 4
+        for (u32 b = lo; b < hi; ++b) {
+            const SegDesc d = a.desc[b];
+            sum += d.count;
+            const u64 o = open_of(d);
+            if (o != PASS) run_open = o;
+            if (d.overflow) ferr = E2S_DEVERR_SEGFULL;
+            if (d.count) { fmin = min(fmin, b); fmax = max(fmax, b); }
         }
         // wave-level reduction first: one LDS atomic per wave instead of one per descriptor on a single address
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { fmin = min(fmin, (u32)__shfl_xor((int)fmin, o)); fmax = max(fmax, (u32)__shfl_xor((int)fmax, o)); ferr |= (u32)__shfl_xor((int)ferr, o); }
-        if ((tid & 63u) == 0) {
+        __syncthreads();                                        // (s_first / s_last / s_err are set)
+        if (lane == 0) {
             if (fmin != 0xFFFFFFFFu) { atomicMin(&s_first, fmin); atomicMax(&s_last, fmax); }
             if (ferr) atomicOr(&s_err, ferr);
         }
     }
-    __syncthreads();
-    // the open start a block inherits: nearest earlier block that is not inside one cluster throughout
-    auto carry_into = [&](u32 b) -> u64 {
-        for (u32 q = b; q-- > 0;) { const u64 v = s_open[q]; if (v != PASS) return v; }
-        return NONE;
-    };
-    // record 0 of a block whose cluster began in an earlier block: start and length -- and whether append_entry keeps it.  The one
-    // that began in an earlier SHARD stays provisional (e2s_stitch finishes it) and keeps a slot in the image whatever its length.
-    u64 t_nadj = 0, t_badj = 0;
+    // the open start a run inherits: the nearest earlier run that is not inside one cluster throughout (inclusive "last defined" scan
+    // over the wave, then the waves before)
+    u64 incl = run_open;
 #pragma unroll
-    for (int q = 0; q < DPT; ++q) {
-        const u32 b = tid + (u32)q * 1024u;
-        if (b >= nb || !d_cnt[q] || !d_unk[q]) continue;
-        const u64 carry = carry_into(b);
-        const u64 seg = (u64)b * a.seg_cap;
-        u32 len16; bool slot;
-        if (carry == NONE) { len16 = (u32)a.lens[seg]; slot = true; }          // begins in an earlier shard: e2s_stitch
-        else {
-            const u64 true_len = d_fend[q] - carry + 1;
-            len16 = (u32)(true_len & 0xFFFFull);
-            a.desc[b].first_start = carry;
-            a.lens[seg] = (uint16_t)len16;
-            if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
-            slot = (int)len16 >= a.min_len;
+    for (int o = 1; o < 64; o <<= 1) { const u64 v = __shfl_up((unsigned long long)incl, o); if (lane >= (u32)o && incl == PASS) incl = v; }
+    if (lane == 63) s_wopen[wave] = incl;
+    __syncthreads();
+    u64 carry = __shfl_up((unsigned long long)incl, 1);
+    if (lane == 0) carry = PASS;
+    for (u32 w = wave; carry == PASS && w-- > 0;) carry = s_wopen[w];
+    if (carry == PASS) carry = NONE;                            // nothing before the run leaves a cluster open
+    const u64 carry_end_of_all = [&]() -> u64 {                 // what a segment behind the last one would inherit (the shard's open cluster)
+        u64 c = PASS;
+        for (u32 w = 16; c == PASS && w-- > 0;) c = s_wopen[w];
+        return c == PASS ? NONE : c;
+    }();
+    // ---- walk 2: record 0 of a segment whose cluster began in an earlier one: start and length -- and whether append_entry keeps it.  The
+    // one that began in an earlier SHARD stays provisional (e2s_stitch finishes it) and keeps a slot in the image whatever its length.
+    u64 t_nadj = 0, t_badj = 0;
+    u32 ksum = 0, slotmask = 0, lastk = 0;
+    {
+        u64 c = carry;
+#pragma unroll 4
+        for (u32 b = lo; b < hi; ++b) {
+            const SegDesc d = a.desc[b];
+            u32 kept = d.kept;
+            if (d.count && d.first_unknown) {
+                const u64 seg = (u64)b * a.seg_cap;
+                u32 len16; bool slot;
+                if (c == NONE) { len16 = (u32)a.lens[seg]; slot = true; }          // begins in an earlier shard: e2s_stitch
+                else {
+                    const u64 true_len = d.first_end_pos - c + 1;
+                    len16 = (u32)(true_len & 0xFFFFull);
+                    a.desc[b].first_start = c;
+                    a.lens[seg] = (uint16_t)len16;
+                    if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
+                    slot = (int)len16 >= a.min_len;
+                }
+                if ((int)len16 >= a.min_len) {                  // what the statistics count: the length as stored
+                    ++t_nadj; t_badj += (u64)len16;
+                    if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&s_hadj[len16], 1u);
+                }
+                if (slot) { kept += 1u; slotmask |= 1u << (b - lo); }
+            }
+            ksum += kept;
+            if (kept) lastk = b + 1u;
+            const u64 o = open_of(d);
+            if (o != PASS) c = o;
         }
-        if ((int)len16 >= a.min_len) {                          // what the statistics count: the length as stored
-            ++t_nadj; t_badj += (u64)len16;
-            if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&s_hadj[len16], 1u);
-        }
-        if (slot) s_kept[b] += 1u;                              // (this thread owns block b)
     }
     // (one LDS atomic per wave: ~3000 of them on one address were a third of this kernel's time)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { t_nadj += __shfl_xor((unsigned long long)t_nadj, o); t_badj += __shfl_xor((unsigned long long)t_badj, o); }
-    if ((tid & 63u) == 0 && t_nadj) { atomicAdd((unsigned long long*)&s_nadj[0], (unsigned long long)t_nadj); atomicAdd((unsigned long long*)&s_nadj[1], (unsigned long long)t_badj); }
-    __syncthreads();
-    // exclusive scans of the raw and the kept counts: each thread owns a contiguous chunk
-    const u32 per = (nb + 1023) / 1024, lo = min(nb, tid * per), hi = min(nb, lo + per);
-    u32 sum = 0, ksum = 0, lastk = 0;
-    for (u32 b = lo; b < hi; ++b) { sum += s_cnt[b]; ksum += s_kept[b]; if (s_kept[b]) lastk = b + 1u; }
-    s_part[tid] = sum; s_kpart[tid] = ksum;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lastk = max(lastk, (u32)__shfl_xor((int)lastk, o));
-    if ((tid & 63u) == 0 && lastk) atomicMax(&s_lastk, lastk);
-    __syncthreads();
-    if (tid < 64) {                           // 1024 partials: 16 per lane, wave scan
-        u32 loc = 0, kloc = 0;
-        for (int i = 0; i < 16; ++i) { loc += s_part[tid * 16 + i]; kloc += s_kpart[tid * 16 + i]; }
-        const u32 inc = wave_incl_scan(loc), kinc = wave_incl_scan(kloc);
-        u32 run = inc - loc, krun = kinc - kloc;
-        for (int i = 0; i < 16; ++i) {
-            const u32 v = s_part[tid * 16 + i], kv = s_kpart[tid * 16 + i];
-            s_part[tid * 16 + i] = run; s_kpart[tid * 16 + i] = krun;
-            run += v; krun += kv;
-        }
+    for (int o = 32; o > 0; o >>= 1) {
+        t_nadj += __shfl_xor((unsigned long long)t_nadj, o); t_badj += __shfl_xor((unsigned long long)t_badj, o);
+        lastk = max(lastk, (u32)__shfl_xor((int)lastk, o));
     }
+    if (lane == 0) {
+        if (t_nadj) { atomicAdd((unsigned long long*)&s_nadj[0], (unsigned long long)t_nadj); atomicAdd((unsigned long long*)&s_nadj[1], (unsigned long long)t_badj); }
+        if (lastk) atomicMax(&s_lastk, lastk);
+    }
+    // ---- walk 3: exclusive sums of the raw and the kept counts
+    const u32 inc = wave_incl_scan(sum), kinc = wave_incl_scan(ksum);
+    if (lane == 63) { s_wcnt[wave] = inc; s_wkept[wave] = kinc; }
     __syncthreads();
     {
-        u64 run = s_part[tid], krun = s_kpart[tid];
+        u64 run = inc - sum, krun = kinc - ksum;
+        for (u32 w = 0; w < wave; ++w) { run += s_wcnt[w]; krun += s_wkept[w]; }
+#pragma unroll 4
         for (u32 b = lo; b < hi; ++b) {
+            const SegDesc d = a.desc[b];
             seg_off[b] = run; kept_off[b] = krun;
-            run += s_cnt[b]; krun += s_kept[b];
+            run += d.count; krun += d.kept + ((slotmask >> (b - lo)) & 1u);
         }
         if (hi == nb && lo < nb) { seg_off[nb] = run; kept_off[nb] = krun; }
         if (nb == 0 && tid == 0) { seg_off[0] = 0; kept_off[0] = 0; }
@@ -826,16 +863,16 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         ScanMail m;
         const bool any = s_first != 0xFFFFFFFFu;
         const u64 first_addr = any ? (u64)s_first * a.seg_cap : NONE;
-        const u64 last_addr = any ? (u64)s_last * a.seg_cap + s_cnt[s_last] - 1 : NONE;
         // every global value the mail needs is loaded unconditionally (clamped addresses) so that the loads are all
         // in flight together instead of queueing behind one another's branches
         const u64 li = a.n_prov - 1;
-        const u64 total = nb ? seg_off[nb] : 0;                      // written above by the thread that owns the last chunk
+        const u64 total = nb ? seg_off[nb] : 0;                      // written above by the thread that owns the last run
         const u64 ktotal = nb ? kept_off[nb] : 0;
         // (what other threads of this block wrote above is read back past the L1: volatile)
-        const volatile SegDesc* vdesc = a.desc; const volatile uint16_t* vlens = a.lens;
+        const volatile SegDesc* vdesc = a.desc; const volatile uint16_t* vlens = a.lens; const volatile u64* vkept = kept_off;
         SegDesc dl = a.desc[any ? s_last : 0];
         dl.first_start = vdesc[any ? s_last : 0].first_start;
+        const u64 last_addr = any ? (u64)s_last * a.seg_cap + dl.count - 1 : NONE;
         const SegDesc dk = a.desc[s_lastk ? s_lastk - 1u : 0u];
         const u64 v_first_end = a.desc[any ? s_first : 0].first_end_pos;
         const u32 v_last_st32 = a.starts32[any ? last_addr : 0];
@@ -856,10 +893,9 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         m.err = s_err | v_err;
         m.wrap_count = v_wrap;
         m.tail_lcp = tv0; m.tail_prev_lcp = tv1;
-        const u64 carry = carry_into(nb);
-        m.open_start = (f1 && carry != NONE) ? carry : NONE;
+        m.open_start = (f1 && carry_end_of_all != NONE) ? carry_end_of_all : NONE;
         // the start of the shard's last record: in its block's range, or -- record 0 of that block -- what was found above
-        const bool last_is_r0 = any && s_cnt[s_last] == 1u && dl.first_unknown;
+        const bool last_is_r0 = any && dl.count == 1u && dl.first_unknown;
         const u64 v_last_start = last_is_r0 ? dl.first_start : seg_range_base(a, s_last, row_entries) + v_last_st32;
         m.last_end_start = (total > 0 && !(total == 1 && f0)) ? v_last_start : NONE;
         m.first_len_prov = total > 0 ? v_first_len : 0u;
@@ -882,7 +918,7 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
                     const SegDesc d2 = a.desc[b2];
                     const u32 lk2 = seg_last_kept(a, b2, d2.count, d2.first_unknown);
                     if (lk2) { at = (u64)b2 * a.seg_cap + lk2 - 1u; last_len = vlens[at]; break; }
-                    if (s_kept[b2] && (int)vlens[(u64)b2 * a.seg_cap] >= a.min_len) { last_len = vlens[(u64)b2 * a.seg_cap]; at = (u64)b2 * a.seg_cap; break; }
+                    if (vkept[b2 + 1u] != vkept[b2] && (int)vlens[(u64)b2 * a.seg_cap] >= a.min_len) { last_len = vlens[(u64)b2 * a.seg_cap]; at = (u64)b2 * a.seg_cap; break; }
                 }
             }
         }
@@ -2048,9 +2084,14 @@ int e2s_scan_seg_resident_blocks(int xb) {                   // resident WORKERS
     per_cu = resident_blocks(fn, 256, 0) / (cus > 0 ? cus : 1);
     return 4 * (per_cu < 5 ? per_cu : 5) * cus;
 }
+#ifdef E2S_DIAG_STAMPS
+extern "C" int e2s_diag_scan_stamps(void* out, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_e2s_stamps), bytes < sizeof(g_e2s_stamps) ? bytes : sizeof(g_e2s_stamps));
+}
+#endif
 int e2s_scan_seg_fused_resident_blocks() { return 4 * resident_blocks((const void*)k_scan_seg<1, true>, 256, 0); }
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
-    const dim3 grid((a.n_blocks + 3) / 4), blk(256);           // four independent workers (waves) per block
+    const dim3 grid((a.n_blocks + 3) / 4), blk(256);           // four ranges (waves) per block
     const FilterArgs f{};
     if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1, false>), grid, blk, 0, st, a, f);
     else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2, false>), grid, blk, 0, st, a, f);

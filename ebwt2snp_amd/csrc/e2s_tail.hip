@@ -382,7 +382,10 @@ __global__ __launch_bounds__(256) void k_consensus_pair(TailArgs a, u32 list_cap
                 // the row from the bit planes: the two groups of 32 characters it lies in (16 bytes, 8-byte aligned: one line 7 times out of 8),
                 // shifted to its first character, cut to the characters that exist -- the lane that knows the row fetches it
                 const u32 iw = a.impure ? a.impure[rdc >> 5] : 0u;   // (nullptr: no read of the text is flagged -- nothing to look up)
-                const uint2 g0 = a.text2[base >> 5], g1 = a.text2[(base >> 5) + 1ull];
+                // (a position at or behind its read's end -- have == 0, e.g. a 4-byte position column that holds anything -- names no character:
+                //  nothing is fetched from there, as in the byte path; a row that exists lies inside the text, so its two groups inside the planes)
+                const u64 g = have ? base >> 5 : 0ull;
+                const uint2 g0 = a.text2[g], g1 = a.text2[g + 1ull];
                 const u32 sh = (u32)base & 31u, vm = have >= 32u ? ~0u : (1u << have) - 1u;
                 prow[j] = make_uint2(__builtin_amdgcn_alignbit(g1.x, g0.x, sh) & vm, __builtin_amdgcn_alignbit(g1.y, g0.y, sh) & vm);
                 imp |= rok ? (iw >> (rdc & 31u)) & 1u : 0u;

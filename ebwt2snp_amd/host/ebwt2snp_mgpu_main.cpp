@@ -15,7 +15,8 @@
 // exchange) the ranks run the stepwise calls with the same two exchanges.  Both files are written by all ranks AT ONCE, each at
 // its own offset (pwrite): the sizes are exchanged through the process's memory.
 // No rank ever waits for one that failed: before every exchange the ranks agree -- a barrier over their status in this process --
-// whether all of them are still in; if not, all leave.  (E2S_MGPU_FAIL_RANK=r, E2S_MGPU_FAIL_AT=setup|job: inject a failure: tests;
+// whether all of them are still in; if not, all leave; and a rank whose exchange breaks all the same -- before the collective, in it or behind
+// it -- aborts every communicator and releases every waiter (abort_exchange).  (E2S_MGPU_FAIL_RANK=r, E2S_MGPU_FAIL_AT=setup|job|xchg: inject a failure: tests;
 // E2S_JOB_FAIL_RANK=r, E2S_JOB_FAIL_AT=1|2: inside e2s_resident_job, before the first exchange / between the two.)
 // -G 1 runs the same code without a communicator (one rank has nothing to exchange; E2S_MGPU_FORCE_RCCL=1 under E2S_DEV=1 creates a
 // one-rank communicator all the same: how the RCCL calls are exercised on a one-GPU box).  ncclCommInitAll (1.7 s) runs in a thread of
@@ -49,16 +50,20 @@ struct Opts {
 };
 
 // a barrier over the ranks' threads: the rehearsal's exchanges, the agreement before every collective, the sizes of the outputs
+// (abort(): a rank that cannot enter an exchange releases everybody who waits or will wait -- wait() then answers false, at once and for good)
 class Barrier {
   public:
     explicit Barrier(int n) : n_(n) {}
-    void wait() {
+    bool wait() {
         std::unique_lock<std::mutex> lk(m_);
+        if (aborted_) return false;
         const int gen = gen_;
-        if (++cnt_ == n_) { cnt_ = 0; ++gen_; cv_.notify_all(); } else cv_.wait(lk, [&]() { return gen_ != gen; });
+        if (++cnt_ == n_) { cnt_ = 0; ++gen_; cv_.notify_all(); } else cv_.wait(lk, [&]() { return gen_ != gen || aborted_; });
+        return !aborted_;
     }
+    void abort() { { std::lock_guard<std::mutex> lk(m_); aborted_ = true; } cv_.notify_all(); }
   private:
-    int n_, cnt_ = 0, gen_ = 0; std::mutex m_; std::condition_variable cv_;
+    int n_, cnt_ = 0, gen_ = 0; bool aborted_ = false; std::mutex m_; std::condition_variable cv_;
 };
 
 struct Shared;
@@ -111,35 +116,56 @@ int pwrite_sink(void* user, const void* data, size_t bytes) {
          std::cerr << "rank " << r << ": " << what << " failed (" << rc_ << "): " << (h ? e2s_last_error(h) : "") << std::endl;     \
          mine_rc = rc_; } } while (0)
 
+// An exchange broke on this rank -- before the collective, in it or behind it: its peers may sit in a collective (or, in the rehearsal, at the
+// barrier of one) that will never complete.  Every communicator is aborted (pending collectives end with an error), everybody at the
+// barrier is released, and the job ends with an error on every rank.  Idempotent; any rank may call it.
+void abort_exchange(Shared& S) {
+    { std::lock_guard<std::mutex> lk(S.log_m); for (auto& c : S.comms) if (c) { (void)ncclCommAbort(c); c = nullptr; } }
+    int z = 0; S.rc.compare_exchange_strong(z, E2S_ERR_IO);
+    S.bar->abort();
+}
+// E2S_MGPU_FAIL_AT=xchg (E2S_DEV=1): the rank fails where an exchange begins, before it has entered the collective
+bool inject_xchg(Shared& S, int r) {
+    if (S.fail_rank != r || S.fail_at != "xchg") return false;
+    std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (exchange)" << std::endl;
+    return true;
+}
+
 // Do all ranks still stand?  Every rank publishes its status, all wait, all read the same answer: nobody enters a collective that
 // somebody else will not enter.  The first failure becomes the job's exit code.
 bool agree(Shared& S, int r, int my_rc) {
     S.status[(size_t)r] = my_rc;
-    S.bar->wait();
+    if (!S.bar->wait()) return false;                           // (an aborted exchange: S.rc says so)
     bool all = true;
     for (int q = 0; q < S.nranks; ++q) if (S.status[(size_t)q]) { all = false; int z = 0; S.rc.compare_exchange_strong(z, S.status[(size_t)q]); }
-    S.bar->wait();
+    if (!S.bar->wait()) return false;
     return all;
 }
 
 // ONE all-gather of `bytes` per rank between host buffers (the stepwise path): RCCL on the rank's exchange stream, or host memory + a
 // barrier in the rehearsal mode
+// A failure at ANY point -- the copy in front of the collective included -- ends in abort_exchange: no peer is left waiting.
 int all_gather(Shared& S, int r, const void* mine, size_t bytes, std::vector<uint8_t>& all, void* d_send, void* d_recv, hipStream_t st) {
-    all.resize(bytes * (size_t)S.nranks);
+    all.assign(bytes * (size_t)S.nranks, 0);
+    auto broken = [&](int code) { abort_exchange(S); return code; };
+    if (inject_xchg(S, r)) return broken(9);
     if (S.shared_device) {
         { std::lock_guard<std::mutex> lk(S.log_m); if (S.host_blob.size() < all.size()) S.host_blob.resize(all.size()); }
-        S.bar->wait();
+        if (!S.bar->wait()) return 5;
         memcpy(S.host_blob.data() + bytes * (size_t)r, mine, bytes);
-        S.bar->wait();
+        if (!S.bar->wait()) return 5;
         memcpy(all.data(), S.host_blob.data(), all.size());
-        S.bar->wait();
+        if (!S.bar->wait()) return 5;
         return 0;
     }
     if (!S.use_rccl) { memcpy(all.data(), mine, bytes); return 0; }          // (one rank: nothing to exchange)
-    if (hipMemcpyAsync(d_send, mine, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
-    if (ncclAllGather(d_send, d_recv, bytes, ncclChar, S.comms[(size_t)r], st) != ncclSuccess) return 2;
-    if (hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, st) != hipSuccess) return 3;
-    return hipStreamSynchronize(st) == hipSuccess ? 0 : 4;
+    ncclComm_t comm;
+    { std::lock_guard<std::mutex> lk(S.log_m); comm = S.comms[(size_t)r]; }
+    if (!comm) return 6;                                                     // (aborted by a peer)
+    if (hipMemcpyAsync(d_send, mine, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return broken(1);
+    if (ncclAllGather(d_send, d_recv, bytes, ncclChar, comm, st) != ncclSuccess) return broken(2);
+    if (hipMemcpyAsync(all.data(), d_recv, all.size(), hipMemcpyDeviceToHost, st) != hipSuccess) return broken(3);
+    return hipStreamSynchronize(st) == hipSuccess ? 0 : broken(4);
 }
 
 // the exchange of e2s_resident_job: device buffers, enqueued on the handle's stream
@@ -147,18 +173,23 @@ struct AgCtx { Shared* S; int r; };
 int job_allgather(void* user, const void* d_send, void* d_recv, size_t bytes, void* stream) {
     AgCtx* c = (AgCtx*)user;
     Shared& S = *c->S;
-    if (S.use_rccl) return ncclAllGather(d_send, d_recv, bytes, ncclChar, S.comms[(size_t)c->r], (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+    if (S.use_rccl) {
+        ncclComm_t comm;
+        { std::lock_guard<std::mutex> lk(S.log_m); comm = S.comms[(size_t)c->r]; }
+        return comm && ncclAllGather(d_send, d_recv, bytes, ncclChar, comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+    }
     if (!S.shared_device) return hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : 1;   // (never called: one rank)
     // rehearsal (all ranks on one device): through host memory, which means waiting for the stream here
     std::vector<uint8_t> mine(bytes), all(bytes * (size_t)S.nranks);
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(mine.data(), d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(mine.data(), d_send, bytes, hipMemcpyDeviceToHost) != hipSuccess) { abort_exchange(S); return 1; }
     { std::lock_guard<std::mutex> lk(S.log_m); if (S.host_blob.size() < all.size()) S.host_blob.resize(all.size()); }
-    S.bar->wait();
+    if (!S.bar->wait()) return 1;
     memcpy(S.host_blob.data() + bytes * (size_t)c->r, mine.data(), bytes);
-    S.bar->wait();
+    if (!S.bar->wait()) return 1;
     memcpy(all.data(), S.host_blob.data(), all.size());
-    S.bar->wait();
-    return hipMemcpy(d_recv, all.data(), all.size(), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+    if (!S.bar->wait()) return 1;
+    if (hipMemcpy(d_recv, all.data(), all.size(), hipMemcpyHostToDevice) != hipSuccess) { abort_exchange(S); return 1; }
+    return 0;
 }
 
 void rank_main(Shared& S, int r) {
@@ -238,12 +269,8 @@ void rank_main(Shared& S, int r) {
         } else if (jrc == E2S_ERR_CAPACITY) S.verdict[(size_t)r] = 0;    // (on every rank alike -- the stepwise calls below)
         else {
             STEP(jrc, "resident job");
-            if (jrc == E2S_ERR_IO && S.use_rccl) {
-                // the exchange itself failed on this rank: its peers may sit in a collective that will never complete -- abort every communicator
-                // (their pending collectives end with an error) and let the job end
-                std::lock_guard<std::mutex> lk(S.log_m);
-                for (auto& c : S.comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
-            }
+            // the exchange itself failed on this rank: its peers may sit in a collective that will never complete
+            if (jrc == E2S_ERR_IO) abort_exchange(S);
         }
         if (!agree(S, r, mine_rc)) { leave(); return; }
         // the verdict travels in the second exchange, so the ranks agree on it; should they ever not (a bug), everybody takes the stepwise

@@ -594,13 +594,14 @@ def test_executables_random_cases_vs_reference(seed):
 
 @pytest.mark.gpu
 def test_few_workers_many_tiles_each(tmp_path):
-    """on test-sized inputs every wave worker of the plane kernels owns a single tile; E2S_SCAN_WORKERS=7 / E2S_FILTER_WORKERS=5
-    (read once per process) give each worker a range of ~10 tiles, i.e. the two-tiles-per-trip hot loops with their register
-    roles and tile-to-tile carries that large shards run in: a child pytest repeats the column / candidate cases that way"""
+    """on test-sized inputs a wave of the scan takes a range of 8 tiles and a worker of the pre-filter kernel a single tile;
+    E2S_SCAN_WORKERS=7 + E2S_SCAN_RANGE_TILES=10 / E2S_FILTER_WORKERS=5 (read once per process) give each a range of ~10 tiles, i.e.
+    the two-tiles-per-trip hot loops with their register roles and tile-to-tile carries in both parities: a child pytest repeats
+    the column / candidate cases that way"""
     import subprocess
     import sys
     here = os.path.abspath(__file__)
-    env = dict(os.environ, E2S_SCAN_WORKERS="7", E2S_FILTER_WORKERS="5")
+    env = dict(os.environ, E2S_SCAN_WORKERS="7", E2S_SCAN_RANGE_TILES="10", E2S_FILTER_WORKERS="5")
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "fused_streaming_fuzz_columns or sharded_fuzz_columns or fused_streaming_candidates_equal_oracle or "
                               "fused_streaming_adversarial or scan_fuzz_vs_oracle"],
@@ -1077,8 +1078,9 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
 
 @pytest.mark.gpu
 def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
-    """a rank that fails -- before the first exchange (setup) or right after its step (job) -- takes the whole job down with an error
-    instead of leaving the other ranks inside an all-gather: the ranks agree on their status before every exchange.  3 rehearsal
+    """a rank that fails -- before the first exchange (setup), right after its step (job) or where an exchange begins (xchg) -- takes the
+    whole job down with an error instead of leaving the other ranks inside an all-gather: the ranks agree on their status before every
+    exchange, and an exchange that breaks aborts the communicators.  3 rehearsal
     ranks on GPU 0 and the RCCL path with one rank; the process must END (timeout = hang) with a non-zero code and no `.snp`.
     And where the reference's clust2snp dies (an -L longer than the context the reads share: exit 139) the driver exits 139 too,
     leaving ebwt2clust's `.clusters` behind as the reference's two runs would"""
@@ -1107,6 +1109,19 @@ def test_multi_gpu_driver_never_waits_for_a_failed_rank(tmp_path):
                     os.remove(f)
             env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_JOB_FAIL_RANK=str(fail_rank), E2S_JOB_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="1",
                        E2S_MGPU_FORCE_RCCL="1", E2S_MGPU_TEARDOWN="1")
+            r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
+            assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
+            assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
+    # ... and in the DEFAULT form of the driver (LCP + BWT uploaded, the stepwise calls with host-synchronous exchanges): a failure during
+    # the set-up, and one where an exchange BEGINS -- the rank never enters the collective its peers are in (the copy in front of
+    # ncclAllGather fails: VERDICT r4 item 8); abort_exchange aborts every communicator and releases every waiter
+    for ranks, shared, fail_rank in ((3, True, 2), (3, True, 0), (1, False, 0)):
+        for at in ("setup", "xchg"):
+            for f in (p + ".clusters", IO.snp_out_path(p)):
+                if os.path.exists(f):
+                    os.remove(f)
+            env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FAIL_RANK=str(fail_rank), E2S_MGPU_FAIL_AT=at, E2S_MGPU_FULL_COLUMNS="0",
+                       E2S_MGPU_FORCE_RCCL="1")
             r = subprocess.run([exe, "-i", p, "-n", str(n1), "-G", str(ranks)], capture_output=True, text=True, env=env, timeout=120)
             assert r.returncode not in (0, 136, 139) and "injected failure" in r.stderr, (ranks, at, r.returncode, r.stderr[-400:])
             assert not os.path.exists(IO.snp_out_path(p)) and not os.path.exists(p + ".clusters"), (ranks, at)
@@ -1233,6 +1248,54 @@ def test_gpu_tail_fuzz_columns(H, tmp_path, seed, L, letters, rate):
             assert O.clust2snp(p, O.c2s_opts(1000, L=L, R=Rc, m=mcov))[0] == 0
         out[tag] = open(IO.snp_out_path(p), "rb").read()
     assert out["hip"] == out["orc"] and out["orc"].count(b">SNP_higher") > 100 and out["orc"].count(b">INDEL_higher") > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [221, 222])
+def test_gpu_tail_positions_beyond_the_reads_end(H, tmp_path, seed):
+    """4-byte position columns that name characters far behind their read's end (up to 2^32 - 1) -- an inconsistent index.  The
+    reference's substr throws for them, so there is no reference output; what is pinned: such a row holds no character (the host tail's
+    rule, snp_tail.cpp), the consensus kernel fetches NOTHING from there -- neither bytes nor the reads' bit planes, which would lie up
+    to 128 MB behind their allocation (advisor, round 4) -- and its two forms and the host tail write the same `.snp`.  The positions
+    that become a candidate's RIGHT context stay real (there the reference's crash is reproduced as E2S_ERR_REF_CRASH): wild positions
+    go only to entries whose LCP is smaller than their predecessor's, which are never the first strict maximum of their cluster"""
+    en, _, mcov, Rc = _fuzz_columns(seed)
+    rnd = np.random.RandomState(seed)
+    n = en["lcp"].size
+    reads = np.full((2000, 100), 65, dtype=np.uint8)
+    mut = rnd.rand(2000, 100) < 0.05
+    reads[mut] = rnd.choice(np.frombuffer(b"CGT", dtype=np.uint8), int(mut.sum()))
+    lcp = en["lcp"].astype(np.int64)
+    falling = np.zeros(n, dtype=bool)
+    falling[1:] = (lcp[1:] < lcp[:-1]) & (lcp[1:] >= 16)
+    wild = falling & (rnd.rand(n) < 0.3)
+    suff = en["suff"].astype(np.uint32)
+    suff[wild] = rnd.choice(np.array([101, 131, 4096, 1 << 20, (1 << 31) + 5, (1 << 32) - 1], dtype=np.uint64), int(wild.sum())).astype(np.uint32)
+    text = en["text"].copy()
+    text[rnd.rand(n) < 0.1] = 1999                               # the last read, often: base + position runs off the text's end
+    p = str(tmp_path / "reads.fasta")
+    IO.write_fasta(p, reads)
+    IO.write_bcr(p, text, suff, en["lcp"], en["bwt"], z=4)
+    assert int(wild.sum()) > 2000
+    tools.ebwt2clust(p, handle=H, z=4)
+    out = {}
+    old = os.environ.get("E2S_TAIL_PACKED")
+    try:
+        for form in ("planes", "bytes", "host"):
+            if form == "bytes":
+                os.environ["E2S_TAIL_PACKED"] = "0"              # (read when the reads become resident; E2S_DEV=1: tests/conftest.py)
+            r = tools.clust2snp(p, 1000, handle=H, L=31, R=Rc, m=mcov, z=4, tail="host" if form == "host" else "auto")
+            assert r["n_candidates"] > 50
+            out[form] = open(IO.snp_out_path(p), "rb").read()
+            if form != "host":
+                H.call_variants(31, Rc, 10, 2)                   # the GPU tail applies (no fall-back) and gives the file's bytes
+                assert H.fetch_snp().tobytes() == out[form]
+    finally:
+        if old is None:
+            os.environ.pop("E2S_TAIL_PACKED", None)
+        else:
+            os.environ["E2S_TAIL_PACKED"] = old
+    assert out["planes"] == out["bytes"] == out["host"] and out["host"].count(b">SNP_higher") > 50
 
 
 @pytest.mark.gpu
