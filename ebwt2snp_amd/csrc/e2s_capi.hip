@@ -203,15 +203,15 @@ extern "C" int e2s_create(int device_id, e2s_handle* out) {
         e2s_destroy(h);
         return E2S_ERR_HIP;
     }
-    // the scan's statistics (160 x 8 B) sit in front of the control words: ONE clear before a scan covers both
-    if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&h->d_scan_stats, 160 * 8 + 64 * sizeof(uint32_t)) != hipSuccess ||
+    // the scan's statistics (E2S_STATS_REPL copies of 160 x 8 B) sit in front of the control words: ONE clear before a scan covers both
+    if (hipMalloc(&h->d_scalars, 256 * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&h->d_scan_stats, (size_t)E2S_STATS_REPL * E2S_STATS_STRIDE * 8 + 64 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&h->d_wrap, 2 * E2S_WRAP_CAP * sizeof(uint64_t)) != hipSuccess || hipMalloc(&h->d_mail, 4096) != hipSuccess ||   // ScanMail | statistics at +256
         hipHostMalloc((void**)&h->pin_mail, 4096, hipHostMallocDefault) != hipSuccess) {
         g_create_error = "hipMalloc failed";
         e2s_destroy(h);
         return E2S_ERR_HIP;
     }
-    h->d_words = (uint32_t*)(h->d_scan_stats + 160);
+    h->d_words = (uint32_t*)(h->d_scan_stats + (size_t)E2S_STATS_REPL * E2S_STATS_STRIDE);
     *out = h;
     return E2S_OK;
 }
@@ -726,7 +726,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
             fuse_now = true;
         } else if ((rc = start_prefilter(h, h->pf_arm_mcov, min_len, h->n_prov / 32, 2048, h->stream2))) return rc;
     }
-    if (!fuse_now) CK(hipMemsetAsync(h->d_scan_stats, 0, 160 * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
+    if (!fuse_now) CK(hipMemsetAsync(h->d_scan_stats, 0, (size_t)E2S_STATS_REPL * E2S_STATS_STRIDE * 8 + 16 * sizeof(uint32_t), h->stream));   // the statistics and the scan's words
     // three timing events per scan (each record costs stream time): start, after the scan kernel, after k_seg_fix.
     // With the pre-filter inside the scan kernel the start event is the per-cluster pass's (ev[6]).
     h->scan_start_ev = fuse_now ? 6 : 0;
@@ -1268,7 +1268,7 @@ static int prefilter_setup(e2s_ctx* h, int mcov_out, int min_len, uint64_t est_r
     // cleared -- and, for the scan that carries the pre-filter, the scan's words as well
     static_assert(E2S_SEED_SLOTS <= 256, "k_phase_init");
     e2s_launch_phase_init((unsigned long long*)(h->d_scalars + 2), E2S_SEED_SLOTS, h->d_fl_lens, (uint32_t)E2S_SEED_SLOTS, h->d_words + 20, 1,
-                          scan_words ? h->d_words : nullptr, 16, scan_words ? (unsigned long long*)h->d_scan_stats : nullptr, 160, st);
+                          scan_words ? h->d_words : nullptr, 16, scan_words ? (unsigned long long*)h->d_scan_stats : nullptr, E2S_STATS_REPL * E2S_STATS_STRIDE, st);
     LCHK("e2s_launch_phase_init");
     filter_args(h, mcov_out, c2s_len_lo(mcov_out, min_len), (int)E2S_MAX_CLUST_LEN, f);
     return E2S_OK;

@@ -10,6 +10,8 @@
 #define E2S_SPAN_BYTES 64        // bytes of LCP per thread and tile in the segmented scan
 #endif
 #define E2S_MAX_CLUST_LEN_K 150
+#define E2S_STATS_STRIDE 160     // the scan's statistics: [151 freq | n_records | n_bases | ...] in 64-bit words,
+#define E2S_STATS_REPL 8         // ... E2S_STATS_REPL copies of them that the scan's waves add to (range b: copy b mod 8), summed by k_seg_fix
 #define E2S_SEGFIX_MAX 32768     // segments (= ranges of the scan) k_seg_fix ties together
 #ifndef E2S_SCAN_RANGE_TILES
 #define E2S_SCAN_RANGE_TILES 8   // tiles per range of the scan where the shard leaves the choice (large shards: n_tiles / E2S_SEGFIX_MAX)

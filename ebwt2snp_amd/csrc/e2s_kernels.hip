@@ -144,7 +144,7 @@ __device__ __forceinline__ u64 wave_first64(u64 v) {
 __device__ unsigned long long g_e2s_stamps[32768 * 4];
 #endif
 template <int X, bool FUSED>
-__global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f) {
+__global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f) {
     static_assert(!FUSED || (X == 1 && SPAN_WORDS == 16), "the fused pre-filter works on 1-byte LCPs, 64 entries per lane");
     constexpr int NR = SPAN_WORDS;
     constexpr int ES = 4 * NR / X;                           // entries per thread span
@@ -152,28 +152,26 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     constexpr int EPW = Swar<X>::EPW;
     constexpr int NW = NR + 2;                               // [word before][span][word after]
     constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
+    // A block is ONE wave: the dispatcher places it wherever a wave slot is free (a four-wave block had to find a slot on every SIMD of one
+    // CU at once -- with it 7 % of the slots stood empty between blocks, profiles/round5_scan_ranges.txt -- and its waves, which end at
+    // different times, shared a histogram and so an ending).
     const u32 lane = threadIdx.x & 63u;
-    const u32 wslot = threadIdx.x >> 6;
-    // the block's histogram replicas (4 per wave: lengths concentrate on a few values), two 64-bit sums
-    __shared__ u32 s_hist[16][E2S_MAX_CLUST_LEN_K + 2];
-    __shared__ u64 s_acc[2];
-    __shared__ u32 s_arrived;                                   // waves of the block that are done
-    for (u32 i = threadIdx.x; i < 16u * (E2S_MAX_CLUST_LEN_K + 2); i += 256u) (&s_hist[0][0])[i] = 0u;
-    if (threadIdx.x < 2) s_acc[threadIdx.x] = 0ull;
-    if (threadIdx.x == 2) s_arrived = 0u;
-    __syncthreads();
+    // the wave's histogram replicas (4: lengths concentrate on a few values)
+    __shared__ u32 s_hist[4][E2S_MAX_CLUST_LEN_K + 2];
+    for (u32 i = lane; i < 4u * (E2S_MAX_CLUST_LEN_K + 2); i += 64u) (&s_hist[0][0])[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // the lane's share of the statistics: records kept and their base count (lengths of disjoint clusters inside a range of < 2^32 entries)
     u32 l_kept = 0, l_nb32 = 0;
     u32 qn = 0;                                                 // (FUSED) flagged clusters queued in LDS: wave state, kept from range to range
-    __shared__ u64 s_q[FUSED ? 4 : 1][FUSED ? F2_Q : 1];
-    u64* const q = s_q[FUSED ? wslot : 0];
+    __shared__ u64 s_q[FUSED ? F2_Q : 1];
+    u64* const q = s_q;
     // Every WAVE takes ONE range of tiles (= segment), and there are several times as many ranges as waves fit on the chip: the hardware's
-    // dispatcher is the work queue -- a block's four waves take four consecutive ranges, and the next block starts where wave slots come
-    // free.  Measured with as many ranges as resident waves, one each (profiles/round5_scan_worker_ends.txt): the four waves of a SIMD do
-    // not share its issue slots evenly -- the oldest ended at 0.55 of the kernel's length, the youngest at 0.92, the slowest few at 1.0 --
-    // and 27 % of the wave slots' time stood empty.
-    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // range (= segment) index
-    const bool working = b < a.n_blocks;                        // (every wave of the block meets at the barrier below)
+    // dispatcher is the work queue -- the next wave starts where a slot comes free.  Measured with as many ranges as resident waves, one each
+    // (profiles/round5_scan_worker_ends.txt): the four waves of a SIMD do not share its issue slots evenly -- the oldest ended at 0.55 of
+    // the kernel's length, the youngest at 0.92, the slowest few at 1.0 -- and 27 % of the wave slots' time stood empty.
+    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)blockIdx.x);   // range (= segment) index
+    const bool working = b < a.n_blocks;
 #ifdef E2S_DIAG_STAMPS
     const u64 diag_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     uint16_t* const seg_lens = a.lens + seg;
     const u32 shift1 = (u32)((t0 - torg) * TILE) + 1u;          // 1 + offset of the range's first entry from the origin of the offsets
     // what append_entry keeps (ebwt2clust.cpp:54-63) and statistics() counts (clust2snp.cpp:889-909), tallied as the records leave
-    u32* const hrow = s_hist[wslot * 4u + (lane & 3u)];
+    u32* const hrow = s_hist[lane & 3u];
     // (which record is the LAST one kept -- the statistics count it twice, H4 -- is found by k_seg_fix in the segment itself: tracked here
     //  it cost two VGPRs for the whole kernel, the two that stood between the pinned class constants and a fourth wave per SIMD)
     auto tally = [&](const u32 len16) {
@@ -260,8 +258,8 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
     // records of a tile are staged in LDS by the lanes that own their ENDs and written out in rank order, 64 per
     // store: a sparse store per record costs ~55 SIMD cycles on this chip whatever the number of active lanes (the
     // per-record stores were 16 of the kernel's 68 us)
-    __shared__ uint64_t s_stage[4][SEG_STAGE + 1];              // (+1: the start of a cluster still open at the tile's end)
-    uint64_t* const st_rec = s_stage[threadIdx.x >> 6];
+    __shared__ uint64_t s_stage[SEG_STAGE + 1];                 // (+1: the start of a cluster still open at the tile's end)
+    uint64_t* const st_rec = s_stage;
     // pre-filter state (FUSED): see k_cluster_filter2
     u32 pf_open1 = 0, cin0 = 0, ccarry = 0;
     auto queue_flush = [&]() {
@@ -622,26 +620,19 @@ __global__ __launch_bounds__(256, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Fil
 #endif
     }
     }
-    // the block's share of the statistics: one flush of the histogram replicas and the two sums
-    u64 l_nrec = (u64)l_kept, l_nb = (u64)l_nb32;              // (a wave is one worker: the records it kept are the records the statistics count)
+    // the wave's share of the statistics: one flush of its histogram replicas and the two sums, into one of E2S_STATS_REPL copies of the
+    // statistics (k_seg_fix adds them up): tens of thousands of waves adding to the same 150 words would queue on them
+    unsigned long long* const gstats = a.stats + (size_t)(b % (u32)E2S_STATS_REPL) * E2S_STATS_STRIDE;
+    u64 l_nrec = (u64)l_kept, l_nb = (u64)l_nb32;              // (a wave is one range: the records it kept are the records the statistics count)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { l_nrec += __shfl_xor((unsigned long long)l_nrec, o); l_nb += __shfl_xor((unsigned long long)l_nb, o); }
-    if (lane == 0 && l_nrec) { atomicAdd((unsigned long long*)&s_acc[0], (unsigned long long)l_nrec); atomicAdd((unsigned long long*)&s_acc[1], (unsigned long long)l_nb); }
-    // No barrier at the end: the four waves' ranges take different times (each wave competes with the other waves of its own SIMD), and a wave
-    // that waited here kept its slot from the next block's waves -- measured, 7 % of the wave slots' time (profiles/round5_scan_worker_ends.txt).
-    // A wave leaves as soon as it has counted itself in; the LAST one of the block flushes the replicas.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    u32 arrived = 0;
-    if (lane == 0) arrived = atomicAdd(&s_arrived, 1u);
-    if ((u32)__builtin_amdgcn_readfirstlane((int)arrived) != 3u) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (u32 i = lane; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 64u) {
-        u32 v = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v += s_hist[r][i];
-        if (v) atomicAdd(&a.stats[i], (unsigned long long)v);
+        const u32 v = s_hist[0][i] + s_hist[1][i] + s_hist[2][i] + s_hist[3][i];
+        if (v) atomicAdd(&gstats[i], (unsigned long long)v);
     }
-    if (lane == 0 && s_acc[0]) { atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 1], (unsigned long long)s_acc[0]); atomicAdd(&a.stats[E2S_MAX_CLUST_LEN_K + 2], (unsigned long long)s_acc[1]); }
+    if (lane == 0 && l_nrec) { atomicAdd(&gstats[E2S_MAX_CLUST_LEN_K + 1], (unsigned long long)l_nrec); atomicAdd(&gstats[E2S_MAX_CLUST_LEN_K + 2], (unsigned long long)l_nb); }
 }
 
 // shard descriptors: begins_inside / open_after / end_before_last and the two last LCP values, evaluated scalar-ly on the
@@ -854,7 +845,9 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
     }
     // the statistics: the scan's sums plus the records finished above
     for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 1024u) {
-        const u64 v = a.stats[i] + (u64)s_hadj[i];
+        u64 v = (u64)s_hadj[i];
+#pragma unroll
+        for (int r = 0; r < E2S_STATS_REPL; ++r) v += a.stats[(size_t)r * E2S_STATS_STRIDE + i];
         stats_out[i] = v;
         if (blob) ((e2s_scan_stats*)(blob + sizeof(e2s_boundary)))->hist.freq[i] = v;
     }
@@ -903,8 +896,11 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         m.img_records = ktotal;
         *out = m;
         // the two sums, and the last record the statistics count (the reference counts it twice, H4) with the place it lives at
-        stats_out[E2S_MAX_CLUST_LEN_K + 1] = a.stats[E2S_MAX_CLUST_LEN_K + 1] + s_nadj[0];
-        stats_out[E2S_MAX_CLUST_LEN_K + 2] = a.stats[E2S_MAX_CLUST_LEN_K + 2] + s_nadj[1];
+        u64 sum_rec = s_nadj[0], sum_bases = s_nadj[1];
+#pragma unroll
+        for (int r = 0; r < E2S_STATS_REPL; ++r) { sum_rec += a.stats[(size_t)r * E2S_STATS_STRIDE + E2S_MAX_CLUST_LEN_K + 1]; sum_bases += a.stats[(size_t)r * E2S_STATS_STRIDE + E2S_MAX_CLUST_LEN_K + 2]; }
+        stats_out[E2S_MAX_CLUST_LEN_K + 1] = sum_rec;
+        stats_out[E2S_MAX_CLUST_LEN_K + 2] = sum_bases;
         u64 last_len = 0, at = NONE;
         if (s_lastk) {
             const u32 bk = s_lastk - 1u;
@@ -2081,17 +2077,17 @@ int e2s_scan_seg_resident_blocks(int xb) {                   // resident WORKERS
     int per_cu = 0, dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    per_cu = resident_blocks(fn, 256, 0) / (cus > 0 ? cus : 1);
-    return 4 * (per_cu < 5 ? per_cu : 5) * cus;
+    per_cu = resident_blocks(fn, 64, 0) / (cus > 0 ? cus : 1);     // one-wave blocks
+    return (per_cu < 20 ? per_cu : 20) * cus;
 }
 #ifdef E2S_DIAG_STAMPS
 extern "C" int e2s_diag_scan_stamps(void* out, size_t bytes) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_e2s_stamps), bytes < sizeof(g_e2s_stamps) ? bytes : sizeof(g_e2s_stamps));
 }
 #endif
-int e2s_scan_seg_fused_resident_blocks() { return 4 * resident_blocks((const void*)k_scan_seg<1, true>, 256, 0); }
+int e2s_scan_seg_fused_resident_blocks() { return resident_blocks((const void*)k_scan_seg<1, true>, 64, 0); }
 void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
-    const dim3 grid((a.n_blocks + 3) / 4), blk(256);           // four ranges (waves) per block
+    const dim3 grid(a.n_blocks), blk(64);                       // a range = a wave = a block
     const FilterArgs f{};
     if (xb == 1) hipLaunchKernelGGL((k_scan_seg<1, false>), grid, blk, 0, st, a, f);
     else if (xb == 2) hipLaunchKernelGGL((k_scan_seg<2, false>), grid, blk, 0, st, a, f);
@@ -2099,7 +2095,7 @@ void e2s_launch_scan_seg(const SegArgs& a, int xb, hipStream_t st) {
 }
 // the scan with the per-cluster pass's pre-filter inside (1-byte LCPs, 16-byte aligned LCP and BWT)
 void e2s_launch_scan_seg_fused(const SegArgs& a, const FilterArgs& f, hipStream_t st) {
-    hipLaunchKernelGGL((k_scan_seg<1, true>), dim3((a.n_blocks + 3) / 4), dim3(256), 0, st, a, f);
+    hipLaunchKernelGGL((k_scan_seg<1, true>), dim3(a.n_blocks), dim3(64), 0, st, a, f);
 }
 // the scan that writes the image itself: g.n_waves waves (a whole number of blocks) taking tickets
 void e2s_launch_seg_fix(const SegArgs& a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err, const uint8_t* bwt, const void* pos,
@@ -2229,7 +2225,7 @@ __global__ void k_phase_init(u64* count, u64 count_value, uint16_t* lens, u32 n_
     if (lens && t < n_lens) lens[t] = 0;
     if (w0 && t < n0) w0[t] = 0;
     if (w1 && t < n1) w1[t] = 0;
-    if (z && t < nz) z[t] = 0ull;
+    if (z) for (u32 i = t; i < nz; i += 256u) z[i] = 0ull;
 }
 // the per-cluster pass's counters cleared and the seed clusters (read from the pinned mailbox) placed into the reserved head
 // of the flagged list, in one launch

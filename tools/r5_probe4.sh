@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5: the scan without its end barrier -- range sizes against time on c3, on one block of it (a rank of eight) and on c2
-root=$(pwd); out=$root/gpurun_out/r5_probe3; mkdir -p $out
+# round 5: the scan as one-wave blocks -- range sizes against time on c3, on one block of it (a rank of eight) and on c2
+root=$(pwd); out=$root/gpurun_out/r5_probe4; mkdir -p $out
 export E2S_DEV=1
 timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "e2c_golden_table or scan_fuzz or fused_streaming_fuzz or sharded_fuzz or resident_job_images" > $out/tests.txt 2>&1 || { tail -30 $out/tests.txt; exit 1; }
 tail -2 $out/tests.txt
