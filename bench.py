@@ -703,7 +703,7 @@ def measure_workload(a, name, world, rank, local, dist, dev, steps, warmup, scal
 
     prim = measure(True, warmup, steps, timing=BENCH_TIMING)
     bare = measure(True, 1, steps, timing=0) if BENCH_TIMING else prim      # the same steps without a single timing event
-    phases = measure(True, 1, max(3, steps // 2), timing=2) if (emul is not None or world > 1) else None     # (per-phase kernel times for the rank report)
+    phases = measure(True, 1, max(3, steps // 2), timing=2) if (emul is not None or world > 1 or os.environ.get("E2S_BENCH_PHASES", "0") == "1") else None     # (per-phase kernel times for the rank report)
     other = measure(False, min(warmup, 2) + 1, max(3, steps // 2), timing=2) if SECOND_LEG and emul is None else None
     host = measure(True, 1, max(2, min(5, steps // 4)), on_host=True, timing=0) if emul is None else None
     info = prim["info"]

@@ -683,29 +683,35 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
         nb = std::min<uint64_t>(nb, (uint64_t)fused_resident);
     } else if (armed) nb = std::min<uint64_t>(nb, 4096);         // leave registers for the pre-filter's waves beside it
     if (nb == 0) nb = 1;
-    // The scan runs over RANGES of tiles, one wave each and several times as many as waves are resident: the dispatcher hands the next block
-    // of four ranges to whatever CU has room (k_scan_seg).  A range is a segment of the output.  Ranges of E2S_SCAN_RANGE_TILES tiles (a
-    // range's start-up -- the carries from the entries before it, its descriptor, its block's share of the histogram -- costs about a third
-    // of a tile), as many as k_seg_fix handles at most, at least one per resident wave.
-    const uint64_t nw = nb;
+    // The scan runs over RANGES of tiles, one wave each, in ROUNDS: several times as many ranges as waves are resident, and the dispatcher hands
+    // the next one to whatever SIMD has a wave slot free (k_scan_seg; one static range per wave left 27 % of the slots' time empty:
+    // profiles/round5_scan_worker_ends.txt).  A range is a segment of the output.  What a range costs to start -- the wave's launch, its
+    // first loads and the carries from the entries before it at the loaded memory system's latency: 7-9 us, a tile and a half -- sets the
+    // other bound: ranges of at least E2S_SCAN_RANGE_TILES tiles, a whole number of rounds (with one to three rounds a partial last round
+    // runs on a part of the chip), as many ranges as k_seg_fix handles at most.  Measured (profiles/round5_scan_ranges.txt): 180 tiles per
+    // slot (c3): 8 rounds 1.22-1.33 ms against 1.37-1.57 as one round; 18 tiles per slot (a rank of eight of c3): one round is best.
+    const uint64_t nw = nb, T = sa.n_tiles;
     static const int range_tiles_env = e2s_env_dev("E2S_SCAN_RANGE_TILES") ? atoi(e2s_env_dev("E2S_SCAN_RANGE_TILES")) : 0;
     const uint64_t range_tiles = range_tiles_env > 0 ? (uint64_t)range_tiles_env : (uint64_t)E2S_SCAN_RANGE_TILES;
-    nb = std::max<uint64_t>(nw, std::min<uint64_t>((uint64_t)E2S_SEGFIX_MAX, (sa.n_tiles + range_tiles - 1) / range_tiles));
-    nb = std::min<uint64_t>(nb, std::max<uint64_t>(sa.n_tiles, 1));
-    sa.tiles_per_block = (uint32_t)(sa.n_tiles / nb);
-    sa.tiles_rem = (uint32_t)(sa.n_tiles % nb);
+    if (T <= nw) nb = std::max<uint64_t>(T, 1);                 // (a tile per range, fewer ranges than wave slots)
+    else {
+        const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>(T / (nw * range_tiles), (uint64_t)E2S_SEGFIX_MAX / nw));
+        nb = std::min<uint64_t>(T, nw * rounds);
+    }
+    sa.tiles_per_block = (uint32_t)(T / nb);
+    sa.tiles_rem = (uint32_t)(T % nb);
     if (nb > (uint64_t)E2S_SEGFIX_MAX) return fail(h, E2S_ERR_STATE, "more scan ranges than k_seg_fix handles");
     sa.n_blocks = (uint32_t)nb;
     if (nb + 1 > h->seg_blocks_cap) {
         dev_free(h->d_seg_desc); dev_free(h->d_seg_off); dev_free(h->d_kept_off); h->d_seg_desc = nullptr; h->d_seg_off = nullptr; h->d_kept_off = nullptr;
         h->seg_blocks_cap = 0;
-        CK(hipMalloc((void**)&h->d_seg_desc, (nb + 1) * sizeof(SegDesc)));
+        CK(hipMalloc((void**)&h->d_seg_desc, (nb + 1) * (sizeof(SegDesc) + sizeof(uint2))));   // descriptors, then the hot words
         CK(hipMalloc((void**)&h->d_seg_off, (nb + 2) * 8));
         CK(hipMalloc((void**)&h->d_kept_off, (nb + 2) * 8));
         h->seg_blocks_cap = (uint32_t)(nb + 1);
     }
     sa.min_len = min_len; sa.stats = (unsigned long long*)h->d_scan_stats;
-    const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 1) * row_entries;
+    const uint64_t range_entries = ((uint64_t)sa.tiles_per_block + 2) * row_entries;    // (+ the tile before the range: the origin of its offsets)
     // (E2S_TEST_SEG_CAP: a testing aid -- the first attempt's segments hold that few records, so that a worker overflows its segment)
     static const int test_seg_cap = e2s_env_dev("E2S_TEST_SEG_CAP") ? atoi(e2s_env_dev("E2S_TEST_SEG_CAP")) : 0;
     if (!seg_cap) seg_cap = test_seg_cap > 0 ? (uint64_t)test_seg_cap : (range_entries / 8 + 256 + 7) & ~7ull;   // typical density is ~0.03 records per entry; 16-byte aligned segments
@@ -713,7 +719,7 @@ static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t 
     seg_cap = (seg_cap + 7) & ~7ull;                                   // (the layout kernel loads four records at once: 16-byte aligned segments)
     if (seg_cap > 0xFFFFFFF0ull) return fail(h, E2S_ERR_ARG, "shard too large");
     if ((rc = ensure_records(h, nb * seg_cap))) return rc;
-    sa.seg_cap = (uint32_t)seg_cap; sa.starts32 = (uint32_t*)h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc;
+    sa.seg_cap = (uint32_t)seg_cap; sa.starts32 = (uint32_t*)h->d_starts; sa.lens = h->d_lens; sa.desc = h->d_seg_desc; sa.hot = (uint2*)(h->d_seg_desc + h->seg_blocks_cap);
     sa.wrap_list = (unsigned long long*)h->d_wrap; sa.wrap_count = h->d_words + 12;
     FilterArgs fa{};
     bool fuse_now = false;
@@ -919,7 +925,10 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 // per-cluster pass (e2s_pack_clusters with async != 0): it is bandwidth bound, that pass latency bound.
 // (Throttling the pack's blocks where it runs beside other kernels was measured in round 3 -- 256 ... 2048 blocks: 3.18 / 2.83 / 2.75 / 2.83 /
 // 2.83 ms per c3 step against 2.82-2.93 unthrottled: what the per-cluster pass gains, the tail loses -- and the switch is gone: one block per segment.)
-static uint32_t pack_blocks_beside() { return 0u; }
+// Round 5: the scan leaves up to 32768 segments where it left 4096: the layout kernel keeps its 4096 blocks, each taking every 4096th segment --
+// tens of thousands of short blocks kept refilling every CU until the kernel's end, and the tail's one 1024-thread block (k_tail_partials)
+// found no CU with sixteen free wave slots before that: 152 us instead of 5 (gpurun_out/r5_timeline).
+static uint32_t pack_blocks_beside() { return 4096u; }
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
     h->img_valid = false; h->img_pending = false; h->img_records = 0; h->img_total_known = false; h->img_prestitch = false; h->img_stream = st;
     const uint64_t n_raw = h->stitched ? h->n_rec : h->n_ends;
@@ -942,7 +951,7 @@ static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
         e2s_launch_pack_segments(h->seg_args, h->seg_row_entries, slot0_b, (const unsigned long long*)h->d_kept_off, h->d_img, h->img_cap, nullptr,
                                  h->stitched ? h->plan.n_tail : 0,
                                  h->plan.tail_start[0], h->plan.tail_len[0], h->plan.tail_start[1], h->plan.tail_len[1], st,
-                                 st == h->stream2 ? pack_blocks_beside() : 0u);
+                                 pack_blocks_beside());
         LCHK("e2s_launch_pack_segments");
         CK(hipEventRecord(h->ev_img, st));
         h->img_records = h->img_scan_records - h->img_skip + nt;
@@ -1419,7 +1428,8 @@ static int cand_seeds(e2s_ctx* h, const CandArgs& a, bool streaming, uint64_t* n
                 uint32_t s32 = 0;
                 CK(hipMemcpy(&s32, (const uint32_t*)h->d_starts + r, 4, hipMemcpyDeviceToHost));
                 const SegArgs& sa = h->seg_args;
-                const uint64_t rb = sa.prov_lo + ((uint64_t)b * sa.tiles_per_block + std::min<uint32_t>(b, sa.tiles_rem)) * (uint64_t)h->seg_row_entries;
+                const uint64_t t0b = e2s_range_tile0(sa, b);
+                const uint64_t rb = sa.prov_lo + (t0b > 0 ? t0b - 1 : t0b) * (uint64_t)h->seg_row_entries;   // (seg_range_base)
                 st = (r % h->seg_cap == 0 && sd.first_unknown) ? sd.first_start : rb + s32;
             } else CK(hipMemcpy(&st, h->d_starts + r, 8, hipMemcpyDeviceToHost));
             seed(st, ln);

@@ -14,7 +14,7 @@
 #define E2S_STATS_REPL 8         // ... E2S_STATS_REPL copies of them that the scan's waves add to (range b: copy b mod 8), summed by k_seg_fix
 #define E2S_SEGFIX_MAX 32768     // segments (= ranges of the scan) k_seg_fix ties together
 #ifndef E2S_SCAN_RANGE_TILES
-#define E2S_SCAN_RANGE_TILES 8   // tiles per range of the scan where the shard leaves the choice (large shards: n_tiles / E2S_SEGFIX_MAX)
+#define E2S_SCAN_RANGE_TILES 16  // a range of the scan holds at least this many tiles where the shard is large enough for several rounds (seg_scan_launch)
 #endif
 
 // device-side error bits
@@ -77,11 +77,17 @@ struct SegArgs {
     uint32_t k_u32, kb, hge;
     uint64_t n_tiles; uint32_t tiles_per_block; uint32_t n_blocks;   // range (= segment) b holds tiles_per_block tiles, +1 for b < tiles_rem; n_blocks ranges
     uint32_t tiles_rem;
-    uint32_t* starts32; uint16_t* lens; uint32_t seg_cap;      // segment b = [b*seg_cap, (b+1)*seg_cap): start - first entry of worker b's range, length
+    uint32_t* starts32; uint16_t* lens; uint32_t seg_cap;      // segment b = [b*seg_cap, (b+1)*seg_cap): start - first entry of the tile before range b, length
     SegDesc* desc;
+    uint2* hot;                                                 // per range: (count | overflow << 31, kept | first_unknown << 31 | open_after << 30)
     int min_len; unsigned long long* stats;                     // [151 freq | n_records | n_bases] of the records append_entry keeps: zero before the launch
     unsigned long long* wrap_list; uint32_t* wrap_count;        // addresses (b*seg_cap + i) of records with true length >= 65536
 };
+
+// first tile of range b (b == n_blocks: the end of the last range = n_tiles)
+static inline __host__ __device__ uint64_t e2s_range_tile0(const SegArgs& a, uint32_t b) {
+    return (uint64_t)b * a.tiles_per_block + (b < a.tiles_rem ? b : a.tiles_rem);
+}
 
 // everything the host needs after a scan, gathered by k_scan_mail so that ONE small download suffices
 struct ScanMail {

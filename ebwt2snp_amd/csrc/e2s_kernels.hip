@@ -88,22 +88,40 @@ __device__ __forceinline__ u32 wave_shr1(u32 x, u32 first) {
 // cluster that matters is at most 150 entries long, so the 192 entries before the range are enough: three entries per lane,
 // ballots and scalar population counts (a whole warm-up tile through the plane code cost 8 % of a 12-tile worker).
 // Offsets count from the tile before the range (open1 = 1 + offset of the last start among the 192 entries, 0: none).
-struct PfCarry { u32 open1, cin0, ccarry; };
+struct PfCarry { u32 open1, cin0, ccarry, cb; };
+// Every byte is loaded FIRST, all sixteen loads in flight together, and only then looked at: written with && / || the compiler evaluated the
+// rules lazily -- a load, a wait, a branch, the next load: thirteen memory round trips one after the other at the head of every range,
+// 10-28 us at the loaded memory system's latency (profiles/round5_scan_ranges.txt).  cb: what range_carry() returns for the same range
+// (the entries r0 - 2 .. r0 are among the bytes read here).
 __device__ __forceinline__ PfCarry prefilter_carry_192(const uint8_t* lcp, const uint8_t* bwt, const int64_t r0, const u32 k_u32, const u32 hge, const u32 lane) {
     auto cls = [](u32 x) -> u32 { x &= 0xDFu; return x == 'C' ? 1u : x == 'G' ? 3u : x == 'T' ? 2u : 0u; };   // bit 0 = C|G, bit 1 = G|T (span_bwt_code_planes)
     u64 Sm[3], Cm[3], Gm[3], Tm[3], Fm[3];
-    PfCarry r{0u, 0u, 0u};
+    PfCarry r{0u, 0u, 0u, 0u};
+    u32 L2[3], L1[3], L0[3], Bc[3], Bp[3];
+    const uint8_t* const pl = lcp + (r0 - 192 + (int64_t)lane);
+    const uint8_t* const pb = bwt + (r0 - 192 + (int64_t)lane);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { L2[p] = pl[64 * p - 2]; L1[p] = pl[64 * p - 1]; L0[p] = pl[64 * p]; Bc[p] = pb[64 * p]; Bp[p] = pb[64 * p - 1]; }
+    u32 lr0 = lcp[r0];                                          // (the range's first entry, the same in every lane)
+    asm volatile("" : "+v"(L2[0]), "+v"(L1[0]), "+v"(L0[0]), "+v"(Bc[0]), "+v"(Bp[0]), "+v"(L2[1]), "+v"(L1[1]), "+v"(L0[1]), "+v"(Bc[1]), "+v"(Bp[1]),
+                      "+v"(L2[2]), "+v"(L1[2]), "+v"(L0[2]), "+v"(Bc[2]), "+v"(Bp[2]), "+v"(lr0));
+    const bool never = hge == 0;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const int64_t e = r0 - 192 + 64 * p + (int64_t)lane;
-        const u32 lm2 = lcp[e - 2], lm1 = lcp[e - 1], l0 = lcp[e];
-        const bool gm1 = hge != 0 && lm1 >= k_u32, g0 = hge != 0 && l0 >= k_u32;
-        const bool endm1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
-        const u32 c = cls(bwt[e]), cp = cls(bwt[e - 1]);
-        Sm[p] = __ballot(g0 && !(gm1 && !endm1));
+        const u32 lm2 = L2[p], lm1 = L1[p], l0 = L0[p];
+        const bool gm1 = !never & (lm1 >= k_u32), g0 = !never & (l0 >= k_u32);
+        const bool endm1 = gm1 & (((lm2 > lm1) & (lm1 <= l0)) | !g0);
+        const u32 c = cls(Bc[p]), cp = cls(Bp[p]);
+        Sm[p] = __ballot(g0 & !(gm1 & !endm1));
         Cm[p] = __ballot(c == 1u); Gm[p] = __ballot(c == 3u); Tm[p] = __ballot(c == 2u);
         Fm[p] = __ballot(c != cp);
         if (p == 2) r.ccarry = (u32)__builtin_amdgcn_readlane((int)c, 63);      // C = 1, G = 3, T = 2: bit 0 = C|G, bit 1 = G|T
+    }
+    {   // range_carry's value: GE / end of entry r0 - 1 (lane 63 of the last pass holds entries r0 - 3 .. r0 - 1)
+        const u32 lm2 = L1[2], lm1 = L0[2], l0 = lr0;
+        const bool gm1 = !never & (lm1 >= k_u32), g0 = !never & (l0 >= k_u32);
+        const bool em1 = gm1 & (((lm2 > lm1) & (lm1 <= l0)) | !g0);
+        r.cb = (u32)__builtin_amdgcn_readlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)), 63);
     }
     int sp = -1;                                                // the last start among the 192 entries
 #pragma unroll
@@ -124,6 +142,41 @@ __device__ __forceinline__ PfCarry prefilter_carry_192(const uint8_t* lcp, const
     return r;
 }
 
+// The scan's own look at the 192 entries before a range (the kernel without the pre-filter; any entry width): x = GE / end of the entry
+// before the range (range_carry's value), y = 1 + the offset of the LAST cluster start among the 192, counted from the first entry of the
+// tile before the range (0: none).  All ten loads first, as above.
+template <int X>
+__device__ __forceinline__ uint2 scan_lookback_192(const uint8_t* base, const int64_t r0, const u32 k_u32, const u32 hge, const u32 lane, const u32 tile_entries) {
+    auto ld = [&](int64_t i) -> u32 { return X == 1 ? (u32)base[i] : X == 2 ? (u32)((const uint16_t*)base)[i] : ((const u32*)base)[i]; };
+    u32 L2[3], L1[3], L0[3];
+    const int64_t e0 = r0 - 192 + (int64_t)lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { L2[p] = ld(e0 + 64 * p - 2); L1[p] = ld(e0 + 64 * p - 1); L0[p] = ld(e0 + 64 * p); }
+    u32 lr0 = ld(r0);
+    asm volatile("" : "+v"(L2[0]), "+v"(L1[0]), "+v"(L0[0]), "+v"(L2[1]), "+v"(L1[1]), "+v"(L0[1]), "+v"(L2[2]), "+v"(L1[2]), "+v"(L0[2]), "+v"(lr0));
+    const bool never = hge == 0;
+    u64 Sm[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const u32 lm2 = L2[p], lm1 = L1[p], l0 = L0[p];
+        const bool gm1 = !never & (lm1 >= k_u32), g0 = !never & (l0 >= k_u32);
+        const bool endm1 = gm1 & (((lm2 > lm1) & (lm1 <= l0)) | !g0);
+        Sm[p] = __ballot(g0 & !(gm1 & !endm1));
+    }
+    uint2 r = make_uint2(0u, 0u);
+    {
+        const u32 lm2 = L1[2], lm1 = L0[2], l0 = lr0;
+        const bool gm1 = !never & (lm1 >= k_u32), g0 = !never & (l0 >= k_u32);
+        const bool em1 = gm1 & (((lm2 > lm1) & (lm1 <= l0)) | !g0);
+        r.x = (u32)__builtin_amdgcn_readlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)), 63);
+    }
+    int sp = -1;
+#pragma unroll
+    for (int p = 2; p >= 0; --p) if (sp < 0 && Sm[p]) sp = 64 * p + 63 - __clzll(Sm[p]);
+    if (sp >= 0) r.y = 1u + (tile_entries - 192u + (u32)sp);
+    return r;
+}
+
 constexpr int F2_Q = 64;                     // flagged clusters a wave queues in LDS between global reservations (pre-filter)
 // packed base counts C | G << 8 | T << 16 (added) and flags << 24 (or-ed)
 __device__ __forceinline__ u32 pf_merge(u32 x, u32 y) { return (((x & 0xFFFFFFu) + (y & 0xFFFFFFu)) & 0xFFFFFFu) | ((x | y) & 0xFF000000u); }
@@ -141,7 +194,7 @@ __device__ __forceinline__ u64 wave_first64(u64 v) {
 #ifdef E2S_DIAG_STAMPS
 // diagnostic build only (tools/scan_stamps.py): when every range of the scan started and ended (s_memrealtime, 100 MHz), and where it ran.
 // The stamps go to a buffer nothing else reads; no result depends on them.
-__device__ unsigned long long g_e2s_stamps[32768 * 4];
+__device__ unsigned long long g_e2s_stamps[32768 * 8];
 #endif
 template <int X, bool FUSED>
 __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, FilterArgs f) {
@@ -152,6 +205,10 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
     constexpr int EPW = Swar<X>::EPW;
     constexpr int NW = NR + 2;                               // [word before][span][word after]
     constexpr u32 LM = (X == 4) ? 0xFFFFFFFFu : ((1u << (8 * (X & 3))) - 1u);
+#ifdef E2S_DIAG_STAMPS
+    const u64 diag_t0 = __builtin_amdgcn_s_memrealtime();
+    u64 diag_tc = 0, diag_tq0 = 0, diag_tq1 = 0;
+#endif
     // A block is ONE wave: the dispatcher places it wherever a wave slot is free (a four-wave block had to find a slot on every SIMD of one
     // CU at once -- with it 7 % of the slots stood empty between blocks, profiles/round5_scan_ranges.txt -- and its waves, which end at
     // different times, shared a histogram and so an ending).
@@ -172,23 +229,24 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
     // the kernel's length, the youngest at 0.92, the slowest few at 1.0 -- and 27 % of the wave slots' time stood empty.
     const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)blockIdx.x);   // range (= segment) index
     const bool working = b < a.n_blocks;
-#ifdef E2S_DIAG_STAMPS
-    const u64 diag_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (working) {
-    const u64 t0 = (u64)b * a.tiles_per_block + min(b, a.tiles_rem);
-    const u64 t1 = min(t0 + (u64)a.tiles_per_block + (b < a.tiles_rem ? 1u : 0u), a.n_tiles);
+    const u64 t0 = e2s_range_tile0(a, b);
+    const u64 t1 = min(e2s_range_tile0(a, b + 1u), a.n_tiles);
     const uint8_t* base = (const uint8_t*)a.lcp;
     const int64_t n_prov = (int64_t)a.n_prov;
     const int64_t own_lo = (int64_t)a.own_lo, end_hi = (int64_t)a.end_hi, start_hi = (int64_t)a.start_hi;
-    const u64 torg = (FUSED && t0 > 0) ? t0 - 1 : t0;           // first tile processed: offsets count from it
+    const u64 torg = t0 > 0 ? t0 - 1 : t0;                      // the tile before the range: offsets count from it (seg_range_base)
     const u64 g_range = a.prov_lo + torg * TILE;                // SA position of offset 0
     const u64 seg = (u64)b * a.seg_cap;
     // a segment holds (start - first entry of the worker's range : u32, length : u16) -- 6 bytes per record instead of the image's 10:
     // the segments are an intermediate, read once more by the kernel that lays the image out
     u32* const seg_starts = a.starts32 + seg;                   // worker-uniform bases: stores use a 32-bit record offset
     uint16_t* const seg_lens = a.lens + seg;
-    const u32 shift1 = (u32)((t0 - torg) * TILE) + 1u;          // 1 + offset of the range's first entry from the origin of the offsets
+    // A record's start is stored as its offset from the first entry of the tile BEFORE the range: the start of a cluster that reaches into
+    // the range from the 192 entries before it is found by the wave itself (start_carry), so that record 0 of a range is as finished as
+    // the others -- what k_seg_fix had to do for four ranges in five (start, length, kept count, statistics) is left for the cluster that
+    // reaches back further.
+    const u32 shift1 = 1u;
     // what append_entry keeps (ebwt2clust.cpp:54-63) and statistics() counts (clust2snp.cpp:889-909), tallied as the records leave
     u32* const hrow = s_hist[lane & 3u];
     // (which record is the LAST one kept -- the statistics count it twice, H4 -- is found by k_seg_fix in the segment itself: tracked here
@@ -573,13 +631,22 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         bool have_cb = false;
         // what the range inherits: the scan's GE / end of the entry before it, and (FUSED) the pre-filter's carries
         auto start_carry = [&]() __attribute__((always_inline)) {
-            cb = range_carry();
-            if constexpr (FUSED) {
-                if (t0 > 0 && t0 < t1) {                        // (t0 >= 1: the 192 entries before the range lie inside the provided range)
+            u32 back1 = 0;                                      // 1 + offset of the last start among the 192 entries before the range (0: none)
+            if (t0 > 0 && t0 < t1) {                            // (t0 >= 1: the 192 entries before the range lie inside the provided range)
+                if constexpr (FUSED) {
                     const PfCarry pc = prefilter_carry_192(base, f.bwt, (int64_t)t0 * TILE, a.k_u32, a.hge, lane);
-                    pf_open1 = pc.open1; cin0 = pc.cin0; ccarry = pc.ccarry;
+                    pf_open1 = pc.open1; cin0 = pc.cin0; ccarry = pc.ccarry; cb = pc.cb; back1 = pc.open1;
+                } else {
+                    const uint2 lb = scan_lookback_192<X>(base, (int64_t)t0 * TILE, a.k_u32, a.hge, lane, (u32)TILE);
+                    cb = lb.x; back1 = lb.y;
                 }
-            }
+            } else cb = range_carry();
+            // (a start before the owned window is not this shard's to use: its record is the stitch's, e2s_stitch_plan)
+            if (back1 != 0u && (int64_t)(torg * TILE) + (int64_t)(back1 - 1u) >= own_lo) open1 = back1;
+#ifdef E2S_DIAG_STAMPS
+            asm volatile("" : "+v"(cb) : "v"(cin0), "v"(ccarry), "v"(pf_open1));
+            diag_tc = __builtin_amdgcn_s_memrealtime();
+#endif
         };
         if constexpr (FUSED) tile = t0;
         if (!have_cb && tile < min(t1, (u64)1)) { start_carry(); have_cb = true; }
@@ -593,7 +660,13 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         }
         if (!have_cb) start_carry();
         slow_run(t1);
+#ifdef E2S_DIAG_STAMPS
+        diag_tq0 = __builtin_amdgcn_s_memrealtime();
+#endif
         if constexpr (FUSED) queue_flush();
+#ifdef E2S_DIAG_STAMPS
+        diag_tq1 = __builtin_amdgcn_s_memrealtime();
+#endif
     }
     // worker descriptor (`unknown` / `first_end`: wave-uniform, set with the range's first end)
     u32 kept_w = l_kept;
@@ -610,12 +683,14 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         else { d.open_after = 1; d.open_start = g_range + (open1 - 1u); }
         d.kept = kept_w; d.last_kept1 = 0u; d.last_kept_len = 0u; d.first_start = ~0ull;      // (last_kept*: no longer filled in -- seg_last_kept)
         a.desc[b] = d;
+        a.hot[b] = make_uint2(d.count | (d.overflow << 31), kept_w | (unknown << 31) | (d.open_after << 30));   // what k_seg_fix reads of every range
 #ifdef E2S_DIAG_STAMPS
         if (b < 32768u) {
-            g_e2s_stamps[4 * b + 0] = diag_t0;
-            g_e2s_stamps[4 * b + 1] = __builtin_amdgcn_s_memrealtime();
-            g_e2s_stamps[4 * b + 2] = ((u64)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
-            g_e2s_stamps[4 * b + 3] = ((u64)run << 32) | (u64)(t1 - t0);
+            g_e2s_stamps[8 * b + 0] = diag_t0;
+            g_e2s_stamps[8 * b + 1] = __builtin_amdgcn_s_memrealtime();
+            g_e2s_stamps[8 * b + 2] = ((u64)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (u64)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
+            g_e2s_stamps[8 * b + 3] = ((u64)run << 32) | (u64)(t1 - t0);
+            g_e2s_stamps[8 * b + 4] = diag_tc; g_e2s_stamps[8 * b + 5] = diag_tq0; g_e2s_stamps[8 * b + 6] = diag_tq1;
         }
 #endif
     }
@@ -633,6 +708,9 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         if (v) atomicAdd(&gstats[i], (unsigned long long)v);
     }
     if (lane == 0 && l_nrec) { atomicAdd(&gstats[E2S_MAX_CLUST_LEN_K + 1], (unsigned long long)l_nrec); atomicAdd(&gstats[E2S_MAX_CLUST_LEN_K + 2], (unsigned long long)l_nb); }
+#ifdef E2S_DIAG_STAMPS
+    if (lane == 0 && b < 32768u && working) g_e2s_stamps[8 * b + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // shard descriptors: begins_inside / open_after / end_before_last and the two last LCP values, evaluated scalar-ly on the
@@ -697,7 +775,8 @@ __device__ void shard_flags_eval(const void* lcp, u64 n_prov, u64 prov_lo, u64 o
 // those shares), and the ScanMail the host downloads.
 constexpr int SEGFIX_MAX = E2S_SEGFIX_MAX;   // segments (= ranges of the scan) one launch ties together: 32 per thread at most
 __device__ __forceinline__ u64 seg_range_base(const SegArgs& a, u32 b, u32 row_entries) {      // SA position of the first entry of worker b's range
-    return a.prov_lo + ((u64)b * a.tiles_per_block + min(b, a.tiles_rem)) * (u64)row_entries;
+    const u64 t0 = e2s_range_tile0(a, b);
+    return a.prov_lo + (t0 > 0 ? t0 - 1 : t0) * (u64)row_entries;     // (offsets count from the tile before the range: k_scan_seg)
 }
 // 1 + index of the LAST record of worker b's segment that append_entry keeps (length >= min_len), among the records whose length the scan
 // knew -- record 0 is left out where its start lay before the range (the caller looks at that one itself); 0: none.  Eight lengths per
@@ -719,17 +798,20 @@ __device__ __forceinline__ u32 seg_last_kept(const SegArgs& a, u32 b, u32 count,
 // blob (the resident job): this rank's share of the first all-gather -- e2s_boundary + e2s_scan_stats exactly as e2s_boundary_desc /
 // e2s_scan_stats_desc hand them out (tail_bwt_arg >= 0: the BWT byte of the shard's last entry given by the caller, e2s_upload_lcp).
 //
-// A thread owns a CONTIGUOUS run of segments (dpt = ceil(n / 1024) of them) and walks it three times -- the descriptors stay in the caches --,
-// with what the run inherits and where it begins taken from scans over the 1024 threads' summaries (wave scans + one LDS round per scan):
-//   1. sums of the counts, the last cluster left open in the run (or "every segment lies inside one cluster": PASS);
-//   2. with the open cluster the run inherits: record 0 of every segment whose cluster began in an earlier one gets its start and length,
-//      its place in the statistics and -- if append_entry keeps it -- in the kept counts;
-//   3. with the run's offsets: the exclusive sums of raw and kept counts per segment.
+// Up to 32768 segments by ONE block, in a few microseconds: it reads 8 bytes per segment (SegArgs::hot: count, kept count, three flags),
+// coalesced -- wave w owns a contiguous run of segments and takes them 64 at a time, segment j * 64 + lane of its run in lane `lane` --, and
+// writes the two exclusive sums the same way: a wave scan per 64 segments, a carry from one 64 to the next, the sixteen waves' totals
+// through LDS.  (Its first scalable form gave every thread a contiguous run and walked the 56-byte descriptors three times: 247 us for
+// 32768 segments, one CU's worth of uncoalesced loads behind one another.)
+// The one thing a segment may still need from its predecessors -- the start of its record 0 where the cluster reaches back further than
+// the 192 entries the scan looks at itself (k_scan_seg, start_carry) -- is rare: the lane walks back through the descriptors until one
+// says where the cluster began.
 __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* tailv, u64* seg_off, u64* kept_off, u32* err,
                                                   const uint8_t* bwt, const void* pos, const void* da, int xb, int yb, int zb, ScanMail* out,
                                                   u64* stats_out, uint8_t* blob, int is_last_rank, int tail_bwt_arg) {
-    __shared__ u64 s_wopen[16];              // per wave: the last open start of its threads' runs | PASS | NONE
-    __shared__ u32 s_wcnt[16], s_wkept[16];
+    constexpr int JMAX = SEGFIX_MAX / 1024;  // 64-segment groups per wave at most
+    static_assert(JMAX <= 32, "a lane's groups: one bit each in adjmask");
+    __shared__ u64 s_wcnt[16], s_wkept[16];
     __shared__ u32 s_first, s_last, s_err, s_lastk;
     __shared__ u32 s_hadj[E2S_MAX_CLUST_LEN_K + 2];
     __shared__ u64 s_nadj[2];
@@ -739,110 +821,105 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
     __shared__ u32 s_flags[4], s_tailv[2];
     if (tid == 0) { s_first = 0xFFFFFFFFu; s_last = 0; s_err = 0; s_lastk = 0; s_nadj[0] = 0; s_nadj[1] = 0; }
     for (u32 i = tid; i < (u32)(E2S_MAX_CLUST_LEN_K + 2); i += 1024u) s_hadj[i] = 0u;
-    // the shard's boundary flags (an otherwise idle thread, while the others fetch descriptors)
+    // the shard's boundary flags (an otherwise idle thread, while the others fetch the hot words)
     if (tid == 1023) shard_flags_eval(a.lcp, a.n_prov, a.prov_lo, a.own_lo, a.start_hi, a.end_hi, a.k_u32, a.hge, (u32)xb, s_flags, s_tailv);
-    static_assert(SEGFIX_MAX <= 32 * 1024, "a thread's run of segments: one bit each in slotmask");
-    const u32 dpt = (nb + 1023u) / 1024u;                       // <= 32
-    const u32 lo = min(nb, tid * dpt), hi = min(nb, lo + dpt);
-    auto open_of = [&](const SegDesc& d) -> u64 { return !d.open_after ? NONE : (d.open_start != NONE ? d.open_start : PASS); };
-    // ---- walk 1
-    u32 sum = 0; u64 run_open = PASS;
-    {
-        u32 fmin = 0xFFFFFFFFu, fmax = 0u, ferr = 0u;
-#pragma unroll 4
-        for (u32 b = lo; b < hi; ++b) {
-            const SegDesc d = a.desc[b];
-            sum += d.count;
-            const u64 o = open_of(d);
-            if (o != PASS) run_open = o;
-            if (d.overflow) ferr = E2S_DEVERR_SEGFULL;
-            if (d.count) { fmin = min(fmin, b); fmax = max(fmax, b); }
-        }
-        // wave-level reduction first: one LDS atomic per wave instead of one per descriptor on a single address
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { fmin = min(fmin, (u32)__shfl_xor((int)fmin, o)); fmax = max(fmax, (u32)__shfl_xor((int)fmax, o)); ferr |= (u32)__shfl_xor((int)ferr, o); }
-        __syncthreads();                                        // (s_first / s_last / s_err are set)
-        if (lane == 0) {
-            if (fmin != 0xFFFFFFFFu) { atomicMin(&s_first, fmin); atomicMax(&s_last, fmax); }
-            if (ferr) atomicOr(&s_err, ferr);
-        }
+    const u32 jn = (nb + 1023u) / 1024u;                        // groups per wave
+    const u32 w0 = wave * jn * 64u;                             // the wave's first segment
+    // what the cluster that is open behind segment q began at: its start | PASS (q lies inside one cluster throughout) | NONE (closed)
+    auto open_of = [&](u32 q) -> u64 {
+        const uint2 hq = a.hot[q];
+        if (!((hq.y >> 30) & 1u)) return NONE;
+        const u64 os = a.desc[q].open_start;
+        return os != NONE ? os : PASS;
+    };
+    auto carry_into = [&](u32 b) -> u64 {                       // the nearest earlier segment that is not inside one cluster throughout
+        for (u32 q = b; q-- > 0;) { const u64 v = open_of(q); if (v != PASS) return v; }
+        return NONE;
+    };
+    // pass 1 over the hot words: the lane's sums, and which of its segments need their record 0 finished here
+    u32 unkmask = 0u, ferr = 0u;
+    u64 lsum = 0, lksum = 0;
+    const u32 nbm1 = nb ? nb - 1u : 0u;
+#pragma unroll 16
+    for (u32 j = 0; j < (u32)JMAX; ++j) {                       // (unconditional loads at clamped addresses: sixteen in flight together)
+        const u32 b = w0 + j * 64u + lane;
+        uint2 hv = a.hot[min(b, nbm1)];
+        if (j >= jn || b >= nb) hv = make_uint2(0u, 0u);
+        if (hv.x >> 31) ferr = E2S_DEVERR_SEGFULL;               // (its segment overflowed)
+        if ((hv.x & 0x7FFFFFFFu) && (hv.y >> 31)) unkmask |= 1u << j;
+        lsum += hv.x & 0x7FFFFFFFu; lksum += hv.y & 0x3FFFFFFFu;
     }
-    // the open start a run inherits: the nearest earlier run that is not inside one cluster throughout (inclusive "last defined" scan
-    // over the wave, then the waves before)
-    u64 incl = run_open;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const u64 v = __shfl_up((unsigned long long)incl, o); if (lane >= (u32)o && incl == PASS) incl = v; }
-    if (lane == 63) s_wopen[wave] = incl;
-    __syncthreads();
-    u64 carry = __shfl_up((unsigned long long)incl, 1);
-    if (lane == 0) carry = PASS;
-    for (u32 w = wave; carry == PASS && w-- > 0;) carry = s_wopen[w];
-    if (carry == PASS) carry = NONE;                            // nothing before the run leaves a cluster open
-    const u64 carry_end_of_all = [&]() -> u64 {                 // what a segment behind the last one would inherit (the shard's open cluster)
-        u64 c = PASS;
-        for (u32 w = 16; c == PASS && w-- > 0;) c = s_wopen[w];
-        return c == PASS ? NONE : c;
-    }();
-    // ---- walk 2: record 0 of a segment whose cluster began in an earlier one: start and length -- and whether append_entry keeps it.  The
-    // one that began in an earlier SHARD stays provisional (e2s_stitch finishes it) and keeps a slot in the image whatever its length.
+    __syncthreads();                                            // (s_first / s_last / s_err / s_hadj are set)
+    // record 0 of a segment whose cluster began before the 192 entries its wave looked at: start and length -- and whether append_entry
+    // keeps it.  The one that began in an earlier SHARD stays provisional (e2s_stitch finishes it) and keeps a slot in the image whatever
+    // its length.  (Rare; a loop over the set bits.)
     u64 t_nadj = 0, t_badj = 0;
-    u32 ksum = 0, slotmask = 0, lastk = 0;
-    {
-        u64 c = carry;
-#pragma unroll 4
-        for (u32 b = lo; b < hi; ++b) {
-            const SegDesc d = a.desc[b];
-            u32 kept = d.kept;
-            if (d.count && d.first_unknown) {
-                const u64 seg = (u64)b * a.seg_cap;
-                u32 len16; bool slot;
-                if (c == NONE) { len16 = (u32)a.lens[seg]; slot = true; }          // begins in an earlier shard: e2s_stitch
-                else {
-                    const u64 true_len = d.first_end_pos - c + 1;
-                    len16 = (u32)(true_len & 0xFFFFull);
-                    a.desc[b].first_start = c;
-                    a.lens[seg] = (uint16_t)len16;
-                    if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
-                    slot = (int)len16 >= a.min_len;
-                }
-                if ((int)len16 >= a.min_len) {                  // what the statistics count: the length as stored
-                    ++t_nadj; t_badj += (u64)len16;
-                    if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&s_hadj[len16], 1u);
-                }
-                if (slot) { kept += 1u; slotmask |= 1u << (b - lo); }
-            }
-            ksum += kept;
-            if (kept) lastk = b + 1u;
-            const u64 o = open_of(d);
-            if (o != PASS) c = o;
+    u32 adjmask = 0u;
+    for (u32 m = unkmask; m; m &= m - 1u) {
+        const u32 j = (u32)__ffs((int)m) - 1u;
+        const u32 b = w0 + j * 64u + lane;
+        const u64 c = carry_into(b);
+        const u64 seg = (u64)b * a.seg_cap;
+        u32 len16; bool slot;
+        if (c == NONE) { len16 = (u32)a.lens[seg]; slot = true; }          // begins in an earlier shard: e2s_stitch
+        else {
+            const u64 true_len = a.desc[b].first_end_pos - c + 1;
+            len16 = (u32)(true_len & 0xFFFFull);
+            a.desc[b].first_start = c;
+            a.lens[seg] = (uint16_t)len16;
+            if (true_len >= 65536ull) { const u32 i = atomicAdd(a.wrap_count, 1u); if (i < E2S_WRAP_CAP) a.wrap_list[i] = seg; }
+            slot = (int)len16 >= a.min_len;
         }
+        if ((int)len16 >= a.min_len) {                          // what the statistics count: the length as stored
+            ++t_nadj; t_badj += (u64)len16;
+            if (len16 <= (u32)E2S_MAX_CLUST_LEN_K) atomicAdd(&s_hadj[len16], 1u);
+        }
+        if (slot) adjmask |= 1u << j;
     }
-    // (one LDS atomic per wave: ~3000 of them on one address were a third of this kernel's time)
+    lksum += (u64)__popc(adjmask);
+    // wave-level reductions first: one LDS atomic per wave instead of one per segment on a single address
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
+        ferr |= (u32)__shfl_xor((int)ferr, o);
         t_nadj += __shfl_xor((unsigned long long)t_nadj, o); t_badj += __shfl_xor((unsigned long long)t_badj, o);
-        lastk = max(lastk, (u32)__shfl_xor((int)lastk, o));
+        lsum += __shfl_xor((unsigned long long)lsum, o); lksum += __shfl_xor((unsigned long long)lksum, o);
     }
     if (lane == 0) {
+        if (ferr) atomicOr(&s_err, ferr);
         if (t_nadj) { atomicAdd((unsigned long long*)&s_nadj[0], (unsigned long long)t_nadj); atomicAdd((unsigned long long*)&s_nadj[1], (unsigned long long)t_badj); }
-        if (lastk) atomicMax(&s_lastk, lastk);
+        s_wcnt[wave] = lsum; s_wkept[wave] = lksum;
     }
-    // ---- walk 3: exclusive sums of the raw and the kept counts
-    const u32 inc = wave_incl_scan(sum), kinc = wave_incl_scan(ksum);
-    if (lane == 63) { s_wcnt[wave] = inc; s_wkept[wave] = kinc; }
     __syncthreads();
     {
-        u64 run = inc - sum, krun = kinc - ksum;
+        // pass 2: exclusive sums of the raw and the kept counts, in segment order: the waves before, the groups before, the lanes before
+        u64 run = 0, krun = 0;
         for (u32 w = 0; w < wave; ++w) { run += s_wcnt[w]; krun += s_wkept[w]; }
-#pragma unroll 4
-        for (u32 b = lo; b < hi; ++b) {
-            const SegDesc d = a.desc[b];
-            seg_off[b] = run; kept_off[b] = krun;
-            run += d.count; krun += d.kept + ((slotmask >> (b - lo)) & 1u);
+        u32 fmin = 0xFFFFFFFFu, fmax = 0u, lastk = 0u;
+#pragma unroll 8
+        for (u32 j = 0; j < (u32)JMAX; ++j) {                   // (a constant trip count: the loop holds wave-level operations)
+            const u32 b = w0 + j * 64u + lane;
+            uint2 hv = a.hot[min(b, nbm1)];                      // (again: out of the caches; unconditional, eight in flight)
+            if (j < jn) {
+                if (b >= nb) hv = make_uint2(0u, 0u);
+                const u32 cnt = hv.x & 0x7FFFFFFFu, kept = (hv.y & 0x3FFFFFFFu) + ((adjmask >> j) & 1u);
+                const u32 inc = wave_incl_scan(cnt), kinc = wave_incl_scan(kept);
+                if (b < nb) { seg_off[b] = run + (inc - cnt); kept_off[b] = krun + (kinc - kept); }
+                run += wave_bcast_last(inc); krun += wave_bcast_last(kinc);
+                if (cnt) { fmin = min(fmin, b); fmax = max(fmax, b); }
+                if (kept) lastk = max(lastk, b + 1u);
+            }
         }
-        if (hi == nb && lo < nb) { seg_off[nb] = run; kept_off[nb] = krun; }
-        if (nb == 0 && tid == 0) { seg_off[0] = 0; kept_off[0] = 0; }
+        if (wave == 15u && lane == 0) { seg_off[nb] = run; kept_off[nb] = krun; }      // (the last wave's run ends at or behind the last segment: the totals)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            fmin = min(fmin, (u32)__shfl_xor((int)fmin, o)); fmax = max(fmax, (u32)__shfl_xor((int)fmax, o)); lastk = max(lastk, (u32)__shfl_xor((int)lastk, o));
+        }
+        if (lane == 0) {
+            if (fmin != 0xFFFFFFFFu) { atomicMin(&s_first, fmin); atomicMax(&s_last, fmax); }
+            if (lastk) atomicMax(&s_lastk, lastk);
+        }
     }
+    const u64 carry_end_of_all = tid == 0 ? carry_into(nb) : NONE;  // what a segment behind the last one would inherit (the shard's open cluster)
     // the statistics: the scan's sums plus the records finished above
     for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 1024u) {
         u64 v = (u64)s_hadj[i];
@@ -1396,15 +1473,17 @@ constexpr int MAXCH = 3;                           // ceil(150/64)
 // the 150-entry maximum).  `alloc(lane)` hands out the memory of the next candidate (wave-uniform).
 // the four columns of a cluster's entries, lane i <-> entry s + i per 64-entry chunk: LOADS ONLY, so that the caller can issue them for the
 // cluster of its next round before it works on the current one (len 0: nothing is loaded)
-struct ClusterCols { u32 text[MAXCH], suff[MAXCH], lcp[MAXCH], bwt[MAXCH]; };
-template <bool DEF>
-__device__ __forceinline__ void cluster_load(const CandArgs& a, const u64 s, const int len, const u32 lane, ClusterCols& k) {
+template <int NCH> struct ClusterColsN { u32 text[NCH], suff[NCH], lcp[NCH], bwt[NCH]; };   // NCH chunks of 64 entries, an entry per lane
+typedef ClusterColsN<MAXCH> ClusterCols;
+// chunks C0 .. C0 + NCH - 1 of the cluster [s, s + len) into k's slots 0 .. NCH - 1
+template <bool DEF, int NCH, int C0 = 0>
+__device__ __forceinline__ void cluster_load(const CandArgs& a, const u64 s, const int len, const u32 lane, ClusterColsN<NCH>& k) {
     const int nch = (len + 63) >> 6;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         k.text[c] = k.suff[c] = k.lcp[c] = k.bwt[c] = 0;
-        if (c < nch) {
-            const int o = c * 64 + (int)lane;
+        if (C0 + c < nch) {
+            const int o = (C0 + c) * 64 + (int)lane;
             if (o < len) {
                 const u64 g = s + (u64)o;
                 if (g == a.n_total) { k.text[c] = a.ph_text; k.suff[c] = a.ph_suff; k.lcp[c] = a.ph_lcp; k.bwt[c] = a.ph_bwt; }
@@ -1418,8 +1497,10 @@ __device__ __forceinline__ void cluster_load(const CandArgs& a, const u64 s, con
         }
     }
 }
-template <bool DEF, typename Alloc>                // DEF: widths (x,y,z) = (1,4,1)
-__device__ __forceinline__ void cluster_record(const CandArgs& a, const ClusterCols& k, const int len, const u64 key, const u32 lane, Alloc alloc) {
+// MAXCH: the chunks the cluster may have (1 for the clusters of <= 64 entries -- most of them: the mode of the lengths is the coverage --,
+// whose code then holds one chunk's registers and none of the chunk loops' branches)
+template <bool DEF, int MAXCH, typename Alloc>     // DEF: widths (x,y,z) = (1,4,1)
+__device__ __forceinline__ void cluster_record(const CandArgs& a, const ClusterColsN<MAXCH>& k, const int len, const u64 key, const u32 lane, Alloc alloc) {
     const int nch = (len + 63) >> 6;
     const u32 (&text)[MAXCH] = k.text; const u32 (&suff)[MAXCH] = k.suff; const u32 (&lcp)[MAXCH] = k.lcp; const u32 (&bwt)[MAXCH] = k.bwt;
     bool valid[MAXCH];
@@ -1820,29 +1901,44 @@ __global__ __launch_bounds__(256, K2B_WAVES) void k_flagged_lists(CandArgs a, co
     };
     u64 s_n2 = 0, k_n2 = 0; int len_n2 = 0;                        // round r + 2's entry
     u64 s_n1 = 0, k_n1 = 0; int len_n1 = 0, kind_n1 = 0;          // round r + 1's entry, its columns on their way
-    ClusterCols c_n1;
+    // Only a cluster's FIRST chunk (its first 64 entries) is fetched ahead: most flagged clusters have no more (the mode of the lengths is the
+    // coverage), the registers of two more chunks per cluster in flight bought nothing for them, and a longer cluster fetches its other
+    // chunks when its round comes (one exposed round trip for the few).
+    ClusterColsN<1> c_n1;
     {
         const u64 r0 = first + (u64)blockIdx.x * 4 + wave;
         if (r0 < n) { s_n1 = a.starts[r0]; len_n1 = (int)a.lens[r0]; k_n1 = a.keys ? a.keys[r0] : s_n1; }
         const u64 r1 = r0 + per_round;
         if (r1 < n) { s_n2 = a.starts[r1]; len_n2 = (int)a.lens[r1]; k_n2 = a.keys ? a.keys[r1] : s_n2; }
         kind_n1 = r0 < n ? entry_kind(s_n1, len_n1) : 0;
-        cluster_load<DEF>(a, s_n1, kind_n1 == 1 ? len_n1 : 0, lane, c_n1);
+        cluster_load<DEF, 1>(a, s_n1, kind_n1 == 1 ? len_n1 : 0, lane, c_n1);
     }
     for (u64 base = first + (u64)blockIdx.x * 4; base < n; base += per_round) {
         // (flushing earlier to start the PCIe stream sooner was tried: chunks of ~8 records ran 25 % slower)
         if (s_nstage > (u32)FW_STAGE - 16u || s_used8 + 16u * max8 > cap8) stage_flush();
         const u64 r = base + wave;
-        const u64 key = k_n1; const int len = len_n1, kind = kind_n1;
-        const ClusterCols cur = c_n1;
+        const u64 key = k_n1, s_cur = s_n1; const int len = len_n1, kind = kind_n1;
+        const ClusterColsN<1> cur = c_n1;
         // round r + 1: its entry arrived a round ago -- its columns leave now; round r + 2: its entry leaves now
         s_n1 = s_n2; len_n1 = len_n2; k_n1 = k_n2;
         kind_n1 = r + per_round < n ? entry_kind(s_n1, len_n1) : 0;
-        cluster_load<DEF>(a, s_n1, kind_n1 == 1 ? len_n1 : 0, lane, c_n1);
+        cluster_load<DEF, 1>(a, s_n1, kind_n1 == 1 ? len_n1 : 0, lane, c_n1);
         { const u64 rn = r + 2 * per_round; if (rn < n) { s_n2 = a.starts[rn]; len_n2 = (int)a.lens[rn]; k_n2 = a.keys ? a.keys[rn] : s_n2; } }
         if (r < n) {
             if (kind == 2) { if (lane == 0) atomicOr(a.err, E2S_DEVERR_REMOTE); }
-            else if (kind == 1) cluster_record<DEF>(a, cur, len, key, lane, StageAlloc{s_stage, cap8, &s_used8, &s_nstage, s_keys, s_offs});
+            else if (kind == 1) {
+                const StageAlloc alloc{s_stage, cap8, &s_used8, &s_nstage, s_keys, s_offs};
+                if (len <= 64) cluster_record<DEF, 1>(a, cur, len, key, lane, alloc);
+                else {
+                    ClusterColsN<MAXCH - 1> rest;
+                    cluster_load<DEF, MAXCH - 1, 1>(a, s_cur, len, lane, rest);
+                    ClusterCols all;
+                    all.text[0] = cur.text[0]; all.suff[0] = cur.suff[0]; all.lcp[0] = cur.lcp[0]; all.bwt[0] = cur.bwt[0];
+#pragma unroll
+                    for (int c = 1; c < MAXCH; ++c) { all.text[c] = rest.text[c - 1]; all.suff[c] = rest.suff[c - 1]; all.lcp[c] = rest.lcp[c - 1]; all.bwt[c] = rest.bwt[c - 1]; }
+                    cluster_record<DEF, MAXCH>(a, all, len, key, lane, alloc);
+                }
+            }
         }
         __syncthreads();
     }

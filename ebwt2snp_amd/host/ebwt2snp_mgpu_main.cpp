@@ -111,6 +111,47 @@ int pwrite_sink(void* user, const void* data, size_t bytes) {
     return 0;
 }
 
+// A rank's piece of the `.clusters` file written from its image in HBM IN THE BACKGROUND, beside the per-cluster pass and the tail: a few
+// threads, each with a stream and two pinned buffers of its own and a contiguous slice of the image -- a chunk comes down (DMA) while the
+// one before it goes into the page cache (pwrite).  One thread's pwrite (~10 GB/s) was the 0.11 s the one-GPU run spent "writing both files"
+// after everything else was done (profiles/round4_c3_end_to_end.txt).  The image must stay as it is until join().
+class ImageWriter {
+  public:
+    void start(int dev, const void* d_img, uint64_t bytes, int fd, uint64_t file_off, int threads) {
+        started_ = true;
+        const uint64_t CH = 4000000;                              // (a whole number of 10-byte records)
+        const uint64_t n_ch = (bytes + CH - 1) / CH;
+        threads = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads, n_ch));
+        rc_.assign((size_t)threads, 0);
+        for (int t = 0; t < threads; ++t) th_.emplace_back([=]() {
+            const uint64_t c0 = n_ch * (uint64_t)t / (uint64_t)threads, c1 = n_ch * (uint64_t)(t + 1) / (uint64_t)threads;
+            hipStream_t st = nullptr; void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr};
+            bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 2 && ok; ++i) ok = hipHostMalloc(&buf[i], CH, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+            auto issue = [&](uint64_t c) {
+                const uint64_t off = c * CH, len = std::min<uint64_t>(CH, bytes - off);
+                return hipMemcpyAsync(buf[c & 1], (const uint8_t*)d_img + off, len, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(ev[c & 1], st) == hipSuccess;
+            };
+            if (ok && c0 < c1) ok = issue(c0);
+            for (uint64_t c = c0; c < c1 && ok; ++c) {
+                ok = hipEventSynchronize(ev[c & 1]) == hipSuccess;
+                if (ok && c + 1 < c1) ok = issue(c + 1);
+                const uint64_t off = c * CH; uint64_t len = std::min<uint64_t>(CH, bytes - off), at = file_off + off;
+                const char* p = (const char*)buf[c & 1];
+                while (ok && len) { const ssize_t w = ::pwrite(fd, p, len, (off_t)at); if (w <= 0) ok = false; else { p += w; len -= (uint64_t)w; at += (uint64_t)w; } }
+            }
+            if (st) (void)hipStreamSynchronize(st);
+            for (int i = 0; i < 2; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+            if (st) (void)hipStreamDestroy(st);
+            rc_[(size_t)t] = ok ? 0 : 1;
+        });
+    }
+    bool started() const { return started_; }
+    int join() { int rc = 0; for (auto& t : th_) t.join(); th_.clear(); for (int v : rc_) rc |= v; return rc; }
+  private:
+    bool started_ = false; std::vector<std::thread> th_; std::vector<int> rc_;
+};
+
 #define STEP(call, what)                                                                                                        \
     do { const int rc_ = (call); if (rc_ && !mine_rc) { std::lock_guard<std::mutex> lk(S.log_m);                                   \
          std::cerr << "rank " << r << ": " << what << " failed (" << rc_ << "): " << (h ? e2s_last_error(h) : "") << std::endl;     \
@@ -236,7 +277,9 @@ void rank_main(Shared& S, int r) {
     rp.o.nr_reads1 = o.nr_reads1; rp.o.k_left = o.k_left; rp.o.k_right = o.k_right; rp.o.mcov_out = o.mcov_out; rp.o.consensus_reads = o.consensus_reads;
     rp.o.max_gap = o.max_gap; rp.o.max_err = o.max_err; rp.o.pval = o.pval;
     if (!mine_rc && !S.slim) { rp.probe_only = 1; S.form[(size_t)r] = e2s_resident_job(h, &rp, job_allgather, nullptr, nullptr) == E2S_OK ? 1 : 0; rp.probe_only = 0; }
+    ImageWriter writer;                                         // (the stepwise path starts it early; it is joined before the handles go)
     auto leave = [&]() {
+        if (writer.started()) (void)writer.join();
         if (d_send) (void)hipFree(d_send);
         if (d_recv) (void)hipFree(d_recv);
         if (xs) (void)hipStreamDestroy(xs);
@@ -320,7 +363,17 @@ void rank_main(Shared& S, int r) {
             else if (rc && !mine_rc) mine_rc = rc;
             if (r == 0) S.mcl = mcl;
         }
-        pc.mark("rank 0: exchange 1, stitch, statistics, image layout started");
+        // the `.clusters` piece of this rank leaves NOW, in the background: the image is being laid out (e2s_clusters_image waits for it: a
+        // millisecond), every rank's record count gives every rank its place in the file
+        uint64_t early_records = 0; const void* early_img = nullptr;
+        if (!mine_rc) STEP(e2s_clusters_image(h, &early_img, &early_records), ".clusters image");
+        S.cl_records[(size_t)r] = mine_rc ? 0 : early_records;
+        if (S.bar->wait() && !mine_rc && early_records) {
+            uint64_t at = 0;
+            for (int q = 0; q < r; ++q) at += S.cl_records[(size_t)q] * 10;
+            writer.start(dev, early_img, early_records * 10, S.cl_fd, at, 4);
+        }
+        pc.mark("rank 0: exchange 1, stitch, statistics, image laid out, its file being written in the background");
         if (!mine_rc && !S.crash.load()) {
             e2s_c2s_params prm{};
             prm.nr_reads1 = o.nr_reads1; prm.k_left = o.k_left; prm.k_right = o.k_right; prm.mcov_out = o.mcov_out;
@@ -400,7 +453,8 @@ void rank_main(Shared& S, int r) {
         if (S.snp_fd < 0) mine_rc = E2S_ERR_IO;
     }
     if (!agree(S, r, mine_rc)) { leave(); return; }
-    if (my_records) { PSink ps{S.cl_fd, cl_at}; uint64_t w = 0; STEP(e2s_stream_clusters(h, pwrite_sink, &ps, &w), "write .clusters"); }
+    if (writer.started()) { if (writer.join() && !mine_rc) { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": writing .clusters failed" << std::endl; mine_rc = E2S_ERR_IO; } }
+    else if (my_records) { PSink ps{S.cl_fd, cl_at}; uint64_t w = 0; STEP(e2s_stream_clusters(h, pwrite_sink, &ps, &w), "write .clusters"); }
     if (S.snp_bytes[(size_t)r]) { PSink ps{S.snp_fd, snp_at}; STEP(e2s_stream_snp(ht, pwrite_sink, &ps), "write .snp"); }
     const bool all_fine = agree(S, r, mine_rc);
     pc.mark("rank 0: both files written");
@@ -425,6 +479,8 @@ void help() {
 
 int main(int argc, char** argv) {
     const double t_main = PhaseClock::now();
+    struct timespec ts_main; clock_gettime(CLOCK_REALTIME, &ts_main);
+    const double epoch_main = ts_main.tv_sec + ts_main.tv_nsec * 1e-9;
     if (argc < 3) help();
     Opts o;
     int opt;
@@ -549,9 +605,12 @@ int main(int argc, char** argv) {
     std::cout << events << " events saved to " << S.snp_path << std::endl;
     if (const char* jp = getenv("E2S_CLI_JSON")) {                  // a perf report in a side file (stdout stays as it is)
         if (FILE* f = *jp ? fopen(jp, "w") : nullptr) {
-            fprintf(f, "{\"tool\": \"ebwt2snp_mgpu\", \"library\": \"%s\", \"entries\": %llu, \"ranks\": %d, \"form\": \"%s\", \"seconds_wall\": %.6f, \"bytes_uploaded_per_rank\": [",
+            // (epoch_*: wall-clock stamps of main()'s first line and of this line, so that whoever started the process can tell the loader's and
+            //  the kernel's share -- before main(), behind _exit: the mappings and the GPU memory go then -- from the job's)
+            struct timespec tsn; clock_gettime(CLOCK_REALTIME, &tsn);
+            fprintf(f, "{\"tool\": \"ebwt2snp_mgpu\", \"library\": \"%s\", \"entries\": %llu, \"ranks\": %d, \"form\": \"%s\", \"seconds_wall\": %.6f, \"epoch_main\": %.6f, \"epoch_report\": %.6f, \"bytes_uploaded_per_rank\": [",
                     e2s_version(), (unsigned long long)F.n, S.nranks, S.slim ? "LCP + BWT uploaded, flagged clusters gathered from the files" : "all four columns resident (e2s_resident_job)",
-                    (PhaseClock::now() - t_main) * 1e-3);
+                    (PhaseClock::now() - t_main) * 1e-3, epoch_main, tsn.tv_sec + tsn.tv_nsec * 1e-9);
             for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.uploaded[(size_t)r]);
             fprintf(f, "], \"entries_gathered_per_rank\": [");
             for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.gathered[(size_t)r]);

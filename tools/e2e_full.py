@@ -90,10 +90,16 @@ try:
             env.update(extra_env or {})
             t1 = time.time()
             rr = subprocess.run(cmd, capture_output=True, text=True, env=env)
-            dt = time.time() - t1
+            t2 = time.time()
+            dt = t2 - t1
             total += dt
             assert rr.returncode == 0, (cmd, rr.stdout[-600:], rr.stderr[-1200:])
-            detail.append((os.path.basename(cmd[0]), dt, [l for l in rr.stderr.splitlines() if l.startswith("[timing]")], json.load(open(jp)) if os.path.exists(jp) else {}))
+            jr = json.load(open(jp)) if os.path.exists(jp) else {}
+            tl = [l for l in rr.stderr.splitlines() if l.startswith("[timing]")]
+            if "epoch_main" in jr:                               # where the time outside the job's own clock goes
+                tl.append("[outside] process start -> main() %.1f ms; main() -> report %.1f ms; report -> process reaped (exit: mappings, GPU memory) %.1f ms"
+                          % ((jr["epoch_main"] - t1) * 1e3, (jr["epoch_report"] - jr["epoch_main"]) * 1e3, (t2 - jr["epoch_report"]) * 1e3))
+            detail.append((os.path.basename(cmd[0]), dt, tl, jr))
         ok = (sha(p + ".clusters"), sha(snp)) == want
         rows.append((tag, total, ok))
         print("== %s: %.3f s wall in all = %.3g entries/s; outputs %s the resident job's images (%.2f GB .clusters, %.1f MB .snp)"
@@ -112,6 +118,12 @@ try:
     for it in range(2):                                            # (the first run of the process that links RCCL pages the library in)
         run("ebwt2snp_mgpu -G 1 (all four columns resident, e2s_resident_job), run %d" % it, [[mg, "-i", p, "-n", str(n1), "-G", "1"]], {"E2S_MGPU_FULL_COLUMNS": "1"})
         run("ebwt2snp_mgpu -G 1 (LCP + BWT uploaded, flagged clusters gathered), run %d" % it, [[mg, "-i", p, "-n", str(n1), "-G", "1"]])
+    # E2E_VARIANTS="tag:K=V,K=V;tag2:K=V": the one-process driver again under other settings (development)
+    for var in [v for v in os.environ.get("E2E_VARIANTS", "").split(";") if v]:
+        vt, _, kv = var.partition(":")
+        envv = dict(x.split("=", 1) for x in kv.split(",") if x)
+        for it in range(2):
+            run("ebwt2snp_mgpu -G 1 [%s], run %d" % (vt, it), [[mg, "-i", p, "-n", str(n1), "-G", "1"]], envv)
     print("summary: %d entries, files %.2f GB" % (n, files_gb))
     for tag, total, ok in rows:
         print("   %-78s %.3f s  %.3g entries/s" % (tag, total, n / total))

@@ -23,7 +23,7 @@ h.set_timing(2)
 h.attach_soa(capi.Handle.desc(n), blk["bwt"].data_ptr(), blk["lcp"].data_ptr(), blk["pos"].data_ptr(), blk["da"].data_ptr())
 lib = C.CDLL(capi.LIB_PATH)
 NW = 32768
-buf = np.zeros(NW * 4, dtype=np.uint64)
+buf = np.zeros(NW * 8, dtype=np.uint64)
 SLOTS = 4096 if fused else 5120          # waves resident at once (4 / 5 per SIMD x 1024 SIMDs)
 
 
@@ -34,7 +34,7 @@ def one():
     ms = h.timing().scan_main_ms
     rc = lib.e2s_diag_scan_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.nbytes))
     assert rc == 0, rc
-    return ms, buf.reshape(NW, 4).copy()
+    return ms, buf.reshape(NW, 8).copy()
 
 
 for _ in range(5):
@@ -63,5 +63,12 @@ for rep in range(3):
     occ = [(np.minimum(e_us, edges[i + 1]) - np.maximum(s_us, edges[i])).clip(min=0).sum() / (edges[i + 1] - edges[i]) for i in range(20)]
     print("  ranges resident, by twentieth of the kernel: " + " ".join("%.0f" % x for x in occ))
     print("  per XCC: " + "  ".join("x%d n=%d last end %.0f" % (x, (xcc == x).sum(), e_us[xcc == x].max()) for x in sorted(set(xcc))))
+    ph = [(st[:, c].astype(np.int64) - base) / 100.0 for c in (4, 5, 6, 7)]       # after the range's carries | tiles done | queue flushed | histogram flushed
+    ok = st[:, 4] != 0
+    if ok.any():
+        seg = [ph[0] - s_us, ph[1] - ph[0], ph[2] - ph[1], e_us - ph[2], ph[3] - e_us]
+        names = ["start -> carries read", "tiles", "flagged list flushed (returning atomic)", "descriptor written", "histogram flushed"]
+        print("  phases of a range, median / mean us: " + "; ".join("%s %.1f / %.1f" % (nm, np.median(x[ok]), x[ok].mean()) for nm, x in zip(names, seg)))
+        print("  per tile: median %.2f us" % np.median((seg[1] / np.maximum(tiles, 1))[ok]))
     order = np.argsort(s_us)
     print("  median life by tenth of the start order: " + " ".join("%.0f" % np.median(life[i]) for i in np.array_split(order, 10)))
