@@ -82,7 +82,7 @@ SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_up
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
            "e2s_candidates_packed", "e2s_snp_from_candidates", "e2s_snp_from_packed", "e2s_last_timing", "e2s_set_timing", "e2s_stream", "e2s_synchronize",
-           "e2s_pack_clusters", "e2s_clusters_image", "e2s_upload_reads", "e2s_share_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_renumber_snp", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp",
+           "e2s_pack_clusters", "e2s_clusters_image", "e2s_upload_reads", "e2s_upload_reads_of_candidates", "e2s_share_reads", "e2s_attach_reads", "e2s_upload_reads_fasta", "e2s_call_variants", "e2s_renumber_snp", "e2s_fetch_snp", "e2s_stream_snp", "e2s_write_snp",
            "e2s_ebwt2clust_chunked", "e2s_clust2snp_chunked", "e2s_ebwt2snp_chunked", "e2s_find_candidates_gathered", "e2s_hist_of_records", "e2s_resident_job", "e2s_fasta_index_open", "e2s_fasta_index_close"]
 
 _lib = None
@@ -136,6 +136,7 @@ def lib():
     L.e2s_pack_clusters.argtypes = [H, C.c_int]
     L.e2s_clusters_image.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.e2s_upload_reads.argtypes = [H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    L.e2s_upload_reads_of_candidates.argtypes = [H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_attach_reads.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
     L.e2s_upload_reads_fasta.argtypes = [H, C.c_char_p, C.POINTER(C.c_uint64)]
     L.e2s_call_variants.argtypes = [H, C.POINTER(TailParams), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -343,6 +344,15 @@ class Handle:
         text = np.ascontiguousarray(text, dtype=np.uint8); start = np.ascontiguousarray(start, dtype=np.uint64)
         length = np.ascontiguousarray(length, dtype=np.uint32)
         self._ck(self.L.e2s_upload_reads(self.h, _ptr(text), text.size, _ptr(start), _ptr(length), start.size, int(length.max()) if length.size else 0))
+
+    def upload_reads_of_candidates(self, text, start, length):
+        """only the reads the handle's candidates name (candidates delivered to the host): (reads gathered, bytes uploaded)"""
+        text = np.ascontiguousarray(text, dtype=np.uint8); start = np.ascontiguousarray(start, dtype=np.uint64)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        ng, nb = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.e2s_upload_reads_of_candidates(self.h, _ptr(text), text.size, _ptr(start), _ptr(length), start.size,
+                                                       int(length.max()) if length.size else 0, C.byref(ng), C.byref(nb)))
+        return ng.value, nb.value
 
     def attach_reads(self, d_text, d_start, d_len, n_reads, max_len, keep=()):
         self._keep_reads = list(keep)

@@ -382,8 +382,9 @@ static int narrow_lcp(e2s_ctx* h) {
 // one thread's memcpy (15-25 GB/s on these hosts) bounds it, below what the link gives.  Cut into slices copied by a few threads, each
 // on a stream of its own, the staging runs on several cores and the DMA engines side by side.  E2S_UPLOAD_THREADS (default 4; 1 = one copy).
 #include <thread>
+#include <atomic>
 static int upload_sliced(e2s_ctx* h, void* dst, const void* src, size_t bytes) {
-    static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 4;
+    static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 8;      // (6 GB out of the page cache: 4 threads 0.34 s, 8 threads 0.28-0.30: profiles/round5_c3_end_to_end.txt)
     const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(T_env, 1), bytes >> 24));     // (slices of at least 16 MB)
     if (T == 1) { CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return E2S_OK; }
     if (h->up_streams.size() < (size_t)T) {
@@ -1775,10 +1776,14 @@ extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src) {
     return E2S_OK;
 }
 
+static int upload_reads_impl(e2s_ctx* h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads, uint32_t max_len);
 extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
                                 uint32_t max_len) {
     dbg_entry("e2s_upload_reads");
     if (!h || !n_reads || !text || !start || !len) return E2S_ERR_ARG;
+    return upload_reads_impl(h, text, text_bytes, start, len, n_reads, max_len);
+}
+static int upload_reads_impl(e2s_ctx* h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads, uint32_t max_len) {
     CK(hipSetDevice(h->device));
     release_reads(h);
     h->reads_owned = true;
@@ -1806,6 +1811,109 @@ extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_by
         h->text_bytes = n_reads * (uint64_t)max_len;
     }
     return pack_reads(h);
+}
+
+// get_reads (clust2snp.cpp:147-212) touches the reads the candidates name and no others (:519-528): a handle whose candidates were
+// delivered to the host -- no reads resident during e2s_find_candidates -- makes exactly THOSE reads resident, as a compact table
+// (a bit per read, a population count per 64 reads: the compact rank of a read), sends the candidates after them with the read ranks
+// rewritten (the host's copy keeps the original ranks: e2s_candidates_packed and the host tail see what they always saw), and
+// e2s_call_variants then runs as with all reads resident.  A rank of a multi-GPU job uploads the reads of ITS candidates instead of all.
+extern "C" int e2s_upload_reads_of_candidates(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len,
+                                              uint64_t n_reads, uint32_t max_len, uint64_t* n_gathered, uint64_t* bytes_uploaded) {
+    dbg_entry("e2s_upload_reads_of_candidates");
+    if (n_gathered) *n_gathered = 0;
+    if (bytes_uploaded) *bytes_uploaded = 0;
+    if (!h || !n_reads || !text || !start || !len) return E2S_ERR_ARG;
+    (void)text_bytes; (void)max_len;
+    if (!h->cand_downloaded || !h->n_cand) return fail(h, E2S_ERR_STATE, "no candidates (e2s_find_candidates has not run, or found none)");
+    if (h->cand_dev) return fail(h, E2S_ERR_STATE, "the candidates are in HBM already: the reads were resident during e2s_find_candidates");
+    if (!h->cand_host_valid || !h->pin_cand || !h->pin_order) return fail(h, E2S_ERR_STATE, "the candidates' host copy is not valid");
+    CK(hipSetDevice(h->device));
+    const uint64_t n = h->n_cand;
+    const uint32_t* ord = h->pin_order;
+    const size_t stream_bytes = (size_t)ord[n] * 8;
+    static const int T_env = getenv("E2S_TAIL_THREADS") ? atoi(getenv("E2S_TAIL_THREADS")) : 8;
+    const unsigned T = (unsigned)std::max(1, std::min(T_env, 64));
+    auto run = [&](auto f) { std::vector<std::thread> th; for (unsigned t = 1; t < T; ++t) th.emplace_back(f, t); f(0u); for (auto& x : th) x.join(); };
+    // 1. which reads are named: a bit each
+    const size_t nw = (size_t)((n_reads + 63) / 64);
+    std::vector<std::atomic<uint64_t>> bits(nw);
+    for (auto& b : bits) b.store(0, std::memory_order_relaxed);
+    auto mark = [&](uint32_t id) { if ((uint64_t)id < n_reads) bits[id >> 6].fetch_or(1ull << (id & 63u), std::memory_order_relaxed); };
+    run([&](unsigned t) {
+        for (uint64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+            const uint32_t* w = (const uint32_t*)(h->pin_cand + (size_t)ord[i] * 8);
+            const uint32_t k = w[0] + w[1];
+            mark(w[2]);
+            for (uint32_t j = 0; j < k; ++j) mark(w[4 + j]);
+        }
+    });
+    // 2. compact ranks: reads named before each 64-read word; the compact table's text offsets: bytes before each word
+    std::vector<uint32_t> before(nw + 1, 0);
+    std::vector<uint64_t> tbefore(T + 1, 0), cbefore(T + 1, 0);
+    run([&](unsigned t) {
+        uint64_t c = 0, bytes = 0;
+        for (size_t w = nw * t / T; w < nw * (t + 1) / T; ++w) {
+            uint64_t m = bits[w].load(std::memory_order_relaxed);
+            c += (uint64_t)__builtin_popcountll(m);
+            for (; m; m &= m - 1) bytes += len[(w << 6) + (size_t)__builtin_ctzll(m)];
+        }
+        cbefore[t + 1] = c; tbefore[t + 1] = bytes;
+    });
+    for (unsigned t = 0; t < T; ++t) { cbefore[t + 1] += cbefore[t]; tbefore[t + 1] += tbefore[t]; }
+    const uint64_t M = cbefore[T], ctext_bytes = tbefore[T];
+    if (M >= 0xFFFFFFFFull) return fail(h, E2S_ERR_CAPACITY, "more than 2^32 reads named by one handle's candidates");
+    std::vector<uint64_t> cstart((size_t)M);
+    std::vector<uint32_t> clen((size_t)M);
+    std::vector<uint8_t> ctext((size_t)ctext_bytes + 64);
+    std::vector<uint32_t> cmax(T, 0);
+    run([&](unsigned t) {
+        uint64_t c = cbefore[t], at = tbefore[t];
+        for (size_t w = nw * t / T; w < nw * (t + 1) / T; ++w) {
+            before[w] = (uint32_t)c;
+            for (uint64_t m = bits[w].load(std::memory_order_relaxed); m; m &= m - 1) {
+                const size_t id = (w << 6) + (size_t)__builtin_ctzll(m);
+                const uint32_t l = len[id];
+                cstart[(size_t)c] = at; clen[(size_t)c] = l;
+                memcpy(ctext.data() + at, (const uint8_t*)text + start[id], l);
+                at += l; ++c; cmax[t] = std::max(cmax[t], l);
+            }
+        }
+    });
+    uint32_t mx = 0;
+    for (uint32_t v : cmax) mx = std::max(mx, v);
+    // 3. the compact table becomes the handle's reads
+    int rc = upload_reads_impl(h, ctext.data(), ctext_bytes, cstart.data(), clen.data(), M, mx);
+    if (rc) return rc;
+    // 4. the candidates with compact ranks (a rank past the last read stays past the last read: 2^32 - 1), into HBM
+    std::vector<uint8_t> remapped(stream_bytes);
+    memcpy(remapped.data(), h->pin_cand, stream_bytes);
+    auto rank_of = [&](uint32_t id) -> uint32_t {
+        if ((uint64_t)id >= n_reads) return 0xFFFFFFFFu;
+        const uint64_t m = bits[id >> 6].load(std::memory_order_relaxed);
+        return before[id >> 6] + (uint32_t)__builtin_popcountll(m & ((1ull << (id & 63u)) - 1ull));
+    };
+    run([&](unsigned t) {
+        for (uint64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+            uint32_t* w = (uint32_t*)(remapped.data() + (size_t)ord[i] * 8);
+            const uint32_t k = w[0] + w[1];
+            w[2] = rank_of(w[2]);
+            for (uint32_t j = 0; j < k; ++j) w[4 + j] = rank_of(w[4 + j]);
+        }
+    });
+    const size_t need = h->stream_ord_off + ((size_t)h->cand_cap + 1) * 4;
+    if (need > h->d_stream_bytes) {
+        dev_free(h->d_stream); h->d_stream = nullptr; h->d_stream_bytes = 0;
+        CK(hipMalloc((void**)&h->d_stream, need + 4096));
+        h->d_stream_bytes = need + 4096;
+    }
+    CK(hipMemcpyAsync(h->d_stream, remapped.data(), stream_bytes, hipMemcpyHostToDevice, h->stream));
+    CK(hipMemcpyAsync(h->d_stream + h->stream_ord_off, ord, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    CK(hipStreamSynchronize(h->stream));
+    h->cand_dev = true;                                         // (cand_host_valid stays: the pinned copy holds the ORIGINAL ranks)
+    if (n_gathered) *n_gathered = M;
+    if (bytes_uploaded) *bytes_uploaded = ctext_bytes + M * 12 + stream_bytes + (n + 1) * 4;
+    return E2S_OK;
 }
 
 // what the GPU tail needs before it can run at all (both e2s_call_variants and the resident job)

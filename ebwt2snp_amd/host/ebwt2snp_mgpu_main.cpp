@@ -91,6 +91,10 @@ struct Shared {
     std::vector<int> verdict;                 // per rank, after the job: 1 done, 2 done (the reference crashes here), 0 redo through the stepwise calls
     std::vector<uint64_t> closed, cands, events, cl_records, snp_bytes, uploaded, gathered; int mcl = 0;
     bool slim = false;                        // ranks upload LCP + BWT only, the flagged clusters' other columns are gathered from the files
+    // ... and of the READS only those its candidates name (e2s_upload_reads_of_candidates: what get_reads touches, clust2snp.cpp:519-528),
+    // once the per-cluster pass has found them.  With several ranks by default (every rank held ALL reads until round 5: 8 x 30 GB through
+    // one host for c5); one rank uploads everything while the scan's columns go up (E2S_MGPU_GATHER_READS=1 / 0 decide otherwise)
+    bool gather_reads = false; std::vector<uint64_t> reads_uploaded, reads_gathered;
     // where only the host tail reproduces the reference (a read rank past the last read, -L outside 1..64, an irregular FASTA): every
     // rank hands over its packed candidates and ONE e2s_snp_from_packed runs at the end
     bool host_tail = false; std::vector<std::vector<uint8_t>> pk_stream; std::vector<std::vector<uint32_t>> pk_off8; uint32_t pk_pw = 4;
@@ -266,9 +270,11 @@ void rank_main(Shared& S, int r) {
         }
     }
     pc.mark("rank 0: handle(s), shard uploaded");
-    // the reads: every rank holds all of them, uploaded from the ONE index the main thread has been building meanwhile
-    (void)latch_wait(S, S.reads_state);
-    if (!mine_rc && S.reads_ok) STEP(e2s_upload_reads(hr_, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads");
+    // the reads, from the ONE index the main thread has been building meanwhile: all of them now -- or, later, those this rank's candidates name
+    if (!S.gather_reads) {
+        (void)latch_wait(S, S.reads_state);
+        if (!mine_rc && S.reads_ok) { STEP(e2s_upload_reads(hr_, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads"); S.reads_uploaded[(size_t)r] = S.rd_bytes; S.reads_gathered[(size_t)r] = S.rd_n; }
+    }
     if (S.use_rccl && latch_wait(S, S.comms_state) < 0 && !mine_rc) mine_rc = E2S_ERR_HIP;       // (ncclCommInitAll failed: said so on stderr)
     pc.mark("rank 0: reads uploaded (waited for the FASTA index and the communicators)");
     if (S.fail_rank == r && S.fail_at == "setup") { std::lock_guard<std::mutex> lk(S.log_m); std::cerr << "rank " << r << ": injected failure (setup)" << std::endl; mine_rc = E2S_ERR_HIP; }
@@ -389,11 +395,21 @@ void rank_main(Shared& S, int r) {
                 int grc = e2s_stitch_plan(allb.data(), S.nranks, r, n, o.k, o.lcp, &plan);
                 uint64_t ng = 0;
                 if (grc == E2S_OK) grc = e2s_find_candidates_gathered(h, hc, &cp, &co, &src, &plan, mcl, &n_cand, &ng);
-                if (grc == E2S_OK) { ht = hc; S.gathered[(size_t)r] = ng; S.uploaded[(size_t)r] += 7 * ng; }
+                if (grc == E2S_OK) {
+                    ht = hc; S.gathered[(size_t)r] = ng; S.uploaded[(size_t)r] += 7 * ng;
+                    if (S.gather_reads && n_cand) {                 // the reads these candidates name, and no others
+                        (void)latch_wait(S, S.reads_state);
+                        uint64_t rg = 0, rb = 0;
+                        if (S.reads_ok) STEP(e2s_upload_reads_of_candidates(hc, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max, &rg, &rb), "upload the candidates' reads");
+                        S.reads_uploaded[(size_t)r] = rb; S.reads_gathered[(size_t)r] = rg;
+                    }
+                }
                 else if (grc == E2S_ERR_STATE) {
                     // (a window too dense for the pre-filter's queue, a cluster of 65536+ entries: this shard needs all four columns after all)
                     STEP(e2s_create(dev, &hf), "e2s_create (full columns)");
-                    if (!mine_rc && S.reads_ok) STEP(e2s_share_reads(hf, hc), "share reads");
+                    if (S.gather_reads) (void)latch_wait(S, S.reads_state);
+                    if (!mine_rc && S.reads_ok && !S.gather_reads) STEP(e2s_share_reads(hf, hc), "share reads");
+                    if (!mine_rc && S.reads_ok && S.gather_reads) { STEP(e2s_upload_reads(hf, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads (all columns)"); S.reads_uploaded[(size_t)r] = S.rd_bytes; S.reads_gathered[(size_t)r] = S.rd_n; }
                     if (!mine_rc) STEP(e2s_upload_bcr(hf, &d, S.F->bwt.p + p0, S.F->lcp.p + p0, S.F->pairsa.p + p0 * 5), "upload (BCR, all columns)");
                     if (!mine_rc) STEP(e2s_prefilter_arm(hf, o.mcov_out), "arm");
                     if (!mine_rc) STEP(e2s_cluster_scan(hf, o.k, o.min_len, 0), "cluster scan (all columns)");
@@ -541,6 +557,9 @@ int main(int argc, char** argv) {
     S.cl_records.assign((size_t)S.nranks, 0); S.snp_bytes.assign((size_t)S.nranks, 0); S.uploaded.assign((size_t)S.nranks, 0); S.gathered.assign((size_t)S.nranks, 0);
     S.slim = !F.gesa && o.lcp == 1 && o.da == 4 && o.pos == 1 && !(getenv("E2S_MGPU_FULL_COLUMNS") && atoi(getenv("E2S_MGPU_FULL_COLUMNS")) != 0); S.status.assign((size_t)S.nranks, 0); S.form.assign((size_t)S.nranks, 0); S.verdict.assign((size_t)S.nranks, 0);
     S.pk_stream.resize((size_t)S.nranks); S.pk_off8.resize((size_t)S.nranks);
+    S.reads_uploaded.assign((size_t)S.nranks, 0); S.reads_gathered.assign((size_t)S.nranks, 0);
+    S.gather_reads = S.slim && S.nranks > 1;
+    if (const char* e = getenv("E2S_MGPU_GATHER_READS")) S.gather_reads = S.slim && atoi(e) != 0;
     if (const char* e = e2s_env_dev("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
     S.fail_at = e2s_env_dev("E2S_MGPU_FAIL_AT") ? e2s_env_dev("E2S_MGPU_FAIL_AT") : "setup";
     e2s_fasta_index* fix = nullptr;
@@ -614,6 +633,10 @@ int main(int argc, char** argv) {
             for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.uploaded[(size_t)r]);
             fprintf(f, "], \"entries_gathered_per_rank\": [");
             for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.gathered[(size_t)r]);
+            fprintf(f, "], \"reads_text_bytes\": %llu, \"reads_bytes_uploaded_per_rank\": [", (unsigned long long)S.rd_bytes);
+            for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.reads_uploaded[(size_t)r]);
+            fprintf(f, "], \"reads_resident_per_rank\": [");
+            for (int r = 0; r < S.nranks; ++r) fprintf(f, "%s%llu", r ? ", " : "", (unsigned long long)S.reads_gathered[(size_t)r]);
             fprintf(f, "], \"clusters_printed\": %llu, \"candidates\": %llu, \"events\": %llu, \"max_clust_length\": %d}\n", (unsigned long long)closed, (unsigned long long)cands,
                     (unsigned long long)events, S.mcl);
             fclose(f);

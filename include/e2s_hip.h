@@ -273,6 +273,13 @@ int e2s_share_reads(e2s_handle dst, e2s_handle src);
 int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
                      uint32_t max_len);
 int e2s_attach_reads(e2s_handle h, const void* d_text, const uint64_t* d_start, const uint32_t* d_len, uint64_t n_reads, uint32_t max_len);
+/* get_reads touches the reads the candidates name and no others (clust2snp.cpp:519-528 -> :147-212).  For a handle whose candidates were
+ * delivered to the HOST (no reads resident during e2s_find_candidates): exactly those reads, from the host-side index (arrays as for
+ * e2s_upload_reads), become resident as a compact table, the candidates follow them into HBM with their read ranks rewritten, and
+ * e2s_call_variants then runs as with all reads resident; e2s_candidates_packed keeps handing out the ORIGINAL ranks (the host tail's).
+ * What a rank of a multi-GPU job uploads instead of every read.  *n_gathered: reads made resident; *bytes_uploaded: text + index + candidates. */
+int e2s_upload_reads_of_candidates(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
+                                   uint32_t max_len, uint64_t* n_gathered, uint64_t* bytes_uploaded);
 int e2s_upload_reads_fasta(e2s_handle h, const char* fasta_path, uint64_t* n_reads);
 /* Host only: the same index built ONCE for several handles to upload from (e2s_upload_reads with the arrays handed out here) -- what a
  * driver of several GPUs does instead of parsing the file once per GPU.  E2S_ERR_INPUT for an irregular file (see above), E2S_ERR_IO. */

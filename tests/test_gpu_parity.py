@@ -1043,8 +1043,11 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
         #  default widths -- a rank uploads LCP + BWT only and gathers the flagged clusters' other columns from the mapped files; the
         #  E2S_CLI_JSON side file says which form ran and how many bytes each rank uploaded)
         slim_ok = (not meta.get("gesa")) and tuple(meta["xyz"]) == (1, 4, 1)
-        for ranks, shared, pieces, tiny, full in ((1, False, 0, 0, 1), (2, True, 0, 0, 1), (3, True, 3, 0, 1), (5, True, 0, 0, 1), (1, False, 8, 0, 1), (3, True, 0, 4, 1),
-                                                  (1, False, 0, 4, 1), (1, False, 0, 0, 0), (2, True, 0, 0, 0), (3, True, 0, 0, 0), (5, True, 0, 0, 0)):
+        # (gather: "" = the driver's default -- a lone rank uploads every read while its columns go up, several ranks upload each the reads ITS
+        #  candidates name, e2s_upload_reads_of_candidates -- "1" / "0" force the one or the other)
+        for ranks, shared, pieces, tiny, full, gather in ((1, False, 0, 0, 1, ""), (2, True, 0, 0, 1, ""), (3, True, 3, 0, 1, ""), (5, True, 0, 0, 1, ""), (1, False, 8, 0, 1, ""),
+                                                          (3, True, 0, 4, 1, ""), (1, False, 0, 4, 1, ""), (1, False, 0, 0, 0, ""), (2, True, 0, 0, 0, ""), (3, True, 0, 0, 0, ""),
+                                                          (5, True, 0, 0, 0, ""), (1, False, 0, 0, 0, "1"), (3, True, 0, 0, 0, "0")):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
@@ -1054,6 +1057,8 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
             force_rccl = ranks == 1 and (full == 1 or meta["name"].endswith("bcr"))
             env = dict(os.environ, E2S_MGPU_SHARED_DEVICE="1" if shared else "0", E2S_MGPU_FULL_COLUMNS=str(full), E2S_CLI_JSON=jpath,
                        E2S_MGPU_FORCE_RCCL="1" if force_rccl else "0")
+            if gather:
+                env["E2S_MGPU_GATHER_READS"] = gather
             if pieces:
                 env["E2S_JOB_PIECES"] = str(pieces)
             if tiny:
@@ -1072,8 +1077,59 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
             n_tot = jr["entries"]
             if slim:                                                # 2 bytes per provided entry + 7 per gathered one: far below the 7 per entry of the resident form
                 assert sum(jr["bytes_uploaded_per_rank"]) <= 2 * (n_tot + 153 * ranks) + 7 * sum(jr["entries_gathered_per_rank"]), jr
+                # the reads: all of them on every rank, or what the rank's candidates name (text + 12 bytes of index per read + the candidates)
+                gathered = (gather == "1") or (gather == "" and ranks > 1)
+                n_reads_all = len(reads) if not hasattr(reads, "shape") else reads.shape[0]
+                if gathered:
+                    assert all(g <= n_reads_all for g in jr["reads_resident_per_rank"]) and sum(jr["reads_resident_per_rank"]) < ranks * n_reads_all, jr
+                else:
+                    assert jr["reads_resident_per_rank"] == [n_reads_all] * ranks and jr["reads_bytes_uploaded_per_rank"] == [jr["reads_text_bytes"]] * ranks, jr
             else:
                 assert sum(jr["bytes_uploaded_per_rank"]) >= sum(meta["xyz"]) * n_tot + n_tot, jr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c1_bcr", "rag_bcr"])
+def test_reads_of_candidates_equal_all_reads(tmp_path, name):
+    """e2s_upload_reads_of_candidates (round 5: what a rank of the multi-GPU driver uploads instead of every read): the per-cluster pass
+    runs WITHOUT reads resident, its candidates arrive on the host, the reads they name -- and only those -- become resident as a compact
+    table, the candidates follow with their ranks rewritten: the GPU tail writes the golden `.snp`, byte for byte, as with all reads
+    resident; e2s_candidates_packed keeps the ORIGINAL ranks (the host tail's input); reads of one length and of different lengths"""
+    meta = [m for m in goldens.e2e_cases() if m["name"] == name][0]
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    rows = [bytes(r) for r in reads] if isinstance(reads, list) else [r.tobytes() for r in reads]
+    text = np.frombuffer(b"".join(rows), dtype=np.uint8)
+    length = np.array([len(r) for r in rows], dtype=np.uint32)
+    start = np.concatenate([[0], np.cumsum(length[:-1], dtype=np.uint64)]).astype(np.uint64)
+    c2s = dict(meta["c2s"])
+    L, Rc, g, e, m = c2s.get("L", 31), c2s.get("R", 30), c2s.get("g", 10), c2s.get("e", 2), c2s.get("m", 5)
+    h = capi.Handle(0)
+    try:
+        tools.ebwt2clust(p, handle=h, **meta["e2c"])
+        tools._open_shard(h, p, 1, 4, 1)
+        recs = np.fromfile(p + ".clusters", dtype=np.uint8)
+        out = {}
+        for form in ("all reads", "the candidates' reads"):
+            h.attach_reads(None, None, None, 0, 0)                  # (forget the reads of the pass before)
+            if form == "all reads":
+                h.upload_reads(text, start, length)
+            h.load_clusters(recs)
+            mcl, _, _ = capi.auto_max_clust_length([h.hist()], m, c2s.get("p", 0.99))
+            nc = h.find_candidates(capi.C2SParams(n1, L, Rc, m, c2s.get("c", 20), mcl, 0))
+            assert nc > 5
+            st, off8, n, pw = h.candidates_packed()
+            packed = (st[:int(off8[n]) * 8].copy(), off8[:n + 1].copy())
+            if form != "all reads":
+                ng, nb = h.upload_reads_of_candidates(text, start, length)
+                assert 0 < ng < len(rows) and nb < text.size + 12 * len(rows) + packed[0].size + 4 * (n + 1)
+                st2, off2, n2, _ = h.candidates_packed()            # ... the host's copy keeps the original ranks
+                assert n2 == n and np.array_equal(st2[:int(off2[n2]) * 8], packed[0]) and np.array_equal(off2[:n2 + 1], packed[1])
+            h.call_variants(L, Rc, g, e)
+            out[form] = (h.fetch_snp().tobytes(), packed)
+        assert out["all reads"][0] == out["the candidates' reads"][0] == goldens.golden_snp(meta)
+    finally:
+        h.close()
 
 
 @pytest.mark.gpu
