@@ -383,6 +383,7 @@ static int narrow_lcp(e2s_ctx* h) {
 // on a stream of its own, the staging runs on several cores and the DMA engines side by side.  E2S_UPLOAD_THREADS (default 4; 1 = one copy).
 #include <thread>
 #include <atomic>
+#include <memory>
 static int upload_sliced(e2s_ctx* h, void* dst, const void* src, size_t bytes) {
     static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 8;      // (6 GB out of the page cache: 4 threads 0.34 s, 8 threads 0.28-0.30: profiles/round5_c3_end_to_end.txt)
     const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(T_env, 1), bytes >> 24));     // (slices of at least 16 MB)
@@ -1851,42 +1852,73 @@ extern "C" int e2s_upload_reads_of_candidates(e2s_handle h, const void* text, ui
     // 2. compact ranks: reads named before each 64-read word; the compact table's text offsets: bytes before each word
     std::vector<uint32_t> before(nw + 1, 0);
     std::vector<uint64_t> tbefore(T + 1, 0), cbefore(T + 1, 0);
+    std::vector<uint32_t> lmin(T, 0xFFFFFFFFu), lmax(T, 0u);
     run([&](unsigned t) {
         uint64_t c = 0, bytes = 0;
         for (size_t w = nw * t / T; w < nw * (t + 1) / T; ++w) {
             uint64_t m = bits[w].load(std::memory_order_relaxed);
             c += (uint64_t)__builtin_popcountll(m);
-            for (; m; m &= m - 1) bytes += len[(w << 6) + (size_t)__builtin_ctzll(m)];
+            for (; m; m &= m - 1) { const uint32_t l = len[(w << 6) + (size_t)__builtin_ctzll(m)]; bytes += l; lmin[t] = std::min(lmin[t], l); lmax[t] = std::max(lmax[t], l); }
         }
         cbefore[t + 1] = c; tbefore[t + 1] = bytes;
     });
     for (unsigned t = 0; t < T; ++t) { cbefore[t + 1] += cbefore[t]; tbefore[t + 1] += tbefore[t]; }
     const uint64_t M = cbefore[T], ctext_bytes = tbefore[T];
     if (M >= 0xFFFFFFFFull) return fail(h, E2S_ERR_CAPACITY, "more than 2^32 reads named by one handle's candidates");
-    std::vector<uint64_t> cstart((size_t)M);
-    std::vector<uint32_t> clen((size_t)M);
-    std::vector<uint8_t> ctext((size_t)ctext_bytes + 64);
-    std::vector<uint32_t> cmax(T, 0);
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (unsigned t = 0; t < T; ++t) { mn = std::min(mn, lmin[t]); mx = std::max(mx, lmax[t]); }
+    const bool uniform = M > 0 && mn == mx && mx > 0;             // reads of ONE length: a dense matrix, read c at c * length, no index arrays
+    // 3. the compact table becomes the handle's reads: every thread gathers its stretch of the table through a small buffer of its own
+    //    (it stays in the caches; a table-sized host buffer cost more in page faults than the copy) and sends it up on a stream of its own
+    release_reads(h);
+    h->reads_owned = true;
+    CK(hipMalloc((void**)&h->d_text, ctext_bytes + 256));
+    if (!uniform) { CK(hipMalloc((void**)&h->d_rstart, M * 8 + 64)); CK(hipMalloc((void**)&h->d_rlen, M * 4 + 64)); }
+    if (h->up_streams.size() < (size_t)T) {
+        const size_t have = h->up_streams.size();
+        h->up_streams.resize((size_t)T, nullptr);
+        for (size_t i = have; i < (size_t)T; ++i) CK(hipStreamCreateWithFlags(&h->up_streams[i], hipStreamNonBlocking));
+    }
+    std::vector<int> trc(T, 0);
+    const int dev = h->device;
     run([&](unsigned t) {
-        uint64_t c = cbefore[t], at = tbefore[t];
-        for (size_t w = nw * t / T; w < nw * (t + 1) / T; ++w) {
+        constexpr size_t CH = 4u << 20;
+        std::unique_ptr<uint8_t[]> buf(new uint8_t[CH]);
+        std::vector<uint64_t> ls; std::vector<uint32_t> ll;
+        if (!uniform) { ls.reserve((size_t)(cbefore[t + 1] - cbefore[t])); ll.reserve((size_t)(cbefore[t + 1] - cbefore[t])); }
+        hipStream_t st = h->up_streams[t];
+        bool ok = hipSetDevice(dev) == hipSuccess;
+        uint64_t c = cbefore[t], at = tbefore[t], flushed = tbefore[t]; size_t fill = 0;
+        auto flush = [&]() { if (fill && ok) ok = hipMemcpyAsync(h->d_text + flushed, buf.get(), fill, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess; flushed += fill; fill = 0; };
+        for (size_t w = nw * t / T; w < nw * (t + 1) / T && ok; ++w) {
             before[w] = (uint32_t)c;
             for (uint64_t m = bits[w].load(std::memory_order_relaxed); m; m &= m - 1) {
                 const size_t id = (w << 6) + (size_t)__builtin_ctzll(m);
                 const uint32_t l = len[id];
-                cstart[(size_t)c] = at; clen[(size_t)c] = l;
-                memcpy(ctext.data() + at, (const uint8_t*)text + start[id], l);
-                at += l; ++c; cmax[t] = std::max(cmax[t], l);
+                if (!uniform) { ls.push_back(at); ll.push_back(l); }
+                const uint8_t* src = (const uint8_t*)text + start[id];
+                for (uint32_t done = 0; done < l;) {              // (a read longer than the buffer goes up in pieces)
+                    const size_t k = std::min<size_t>(l - done, CH - fill);
+                    memcpy(buf.get() + fill, src + done, k);
+                    fill += k; done += (uint32_t)k;
+                    if (fill == CH) flush();
+                }
+                at += l; ++c;
             }
         }
+        flush();
+        if (!uniform && ok && !ls.empty())
+            ok = hipMemcpyAsync(h->d_rstart + cbefore[t], ls.data(), ls.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+                 hipMemcpyAsync(h->d_rlen + cbefore[t], ll.data(), ll.size() * 4, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        trc[t] = ok ? 0 : 1;
     });
-    uint32_t mx = 0;
-    for (uint32_t v : cmax) mx = std::max(mx, v);
-    // 3. the compact table becomes the handle's reads
-    int rc = upload_reads_impl(h, ctext.data(), ctext_bytes, cstart.data(), clen.data(), M, mx);
-    if (rc) return rc;
+    for (int v : trc) if (v) return fail(h, E2S_ERR_HIP, "uploading the candidates' reads failed");
+    h->n_reads = M; h->reads_max_len = mx; h->have_reads = true; h->variants_valid = false;
+    h->text_bytes = ctext_bytes;
+    { int rc = pack_reads(h); if (rc) return rc; }
     // 4. the candidates with compact ranks (a rank past the last read stays past the last read: 2^32 - 1), into HBM
-    std::vector<uint8_t> remapped(stream_bytes);
+    std::unique_ptr<uint8_t[]> remapped_buf(new uint8_t[stream_bytes + 8]);
+    struct { uint8_t* p; uint8_t* data() { return p; } } remapped{remapped_buf.get()};
     memcpy(remapped.data(), h->pin_cand, stream_bytes);
     auto rank_of = [&](uint32_t id) -> uint32_t {
         if ((uint64_t)id >= n_reads) return 0xFFFFFFFFu;
@@ -1912,7 +1944,7 @@ extern "C" int e2s_upload_reads_of_candidates(e2s_handle h, const void* text, ui
     CK(hipStreamSynchronize(h->stream));
     h->cand_dev = true;                                         // (cand_host_valid stays: the pinned copy holds the ORIGINAL ranks)
     if (n_gathered) *n_gathered = M;
-    if (bytes_uploaded) *bytes_uploaded = ctext_bytes + M * 12 + stream_bytes + (n + 1) * 4;
+    if (bytes_uploaded) *bytes_uploaded = ctext_bytes + (uniform ? 0 : M * 12) + stream_bytes + (n + 1) * 4;
     return E2S_OK;
 }
 
