@@ -987,6 +987,69 @@ def test_full_size_outputs_equal_reference(case, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gesa_444_full_size_equals_reference(tmp_path):
+    """the invocation the reference's README documents -- `-x 4 -y 4 -z 4` over `<input>.gesa` (README.md:80,83; 13 bytes per entry,
+    array of structs, include.hpp:126-155) -- at FULL size: a whole block of c3 (3.02x10^8 entries, 3.9 GB of .gesa) through
+    bin/ebwt2clust + bin/clust2snp and through bin/ebwt2snp_mgpu -G 1, `.clusters` and `.snp` byte for byte the reference's own
+    executables' (oracle/_ref with the same options).  The records say which path the input took and what it cost
+    (E2S_REPORT_DIR: a copy of them for profiles/)"""
+    import json
+    import subprocess
+    import sys
+    import time
+    import torch
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    dev = torch.device("cuda", 0)
+    R, L = 1000000, 150
+    reads, n1, blk = bench.build_block(R, L, dev)
+    n = blk["lcp"].numel()
+    p = str(tmp_path / "reads.fasta")
+    IO.write_fasta_fast(p, reads.cpu().numpy())
+    lcp = blk["lcp"].cpu().numpy().copy()
+    lcp[-1] = 0
+    IO.write_gesa(p, blk["da"].cpu().numpy(), blk["pos"].cpu().numpy(), lcp, blk["bwt"].cpu().numpy(), x=4, y=4, z=4)
+    del blk, reads
+    torch.cuda.empty_cache()
+    assert os.path.getsize(p + ".gesa") == 13 * n
+    w = ["-x", "4", "-y", "4", "-z", "4"]
+    t0 = time.time()
+    rc, out = O.ref_ebwt2clust(p, w)
+    assert rc == 0, out[-300:]
+    t1 = time.time()
+    rc, out = O.ref_clust2snp(p, n1, w)
+    assert rc == 0, out[-300:]
+    t2 = time.time()
+    want_cl, want_snp = open(p + ".clusters", "rb").read(), open(IO.snp_out_path(p), "rb").read()
+    assert len(want_cl) > 10 ** 8 and len(want_snp) > 10 ** 6
+    report = {"entries": n, "gesa_bytes": 13 * n, "reference_seconds": {"ebwt2clust": round(t1 - t0, 2), "clust2snp": round(t2 - t1, 2)}, "runs": []}
+    for tag, cmds in (("bin/ebwt2clust + bin/clust2snp", [[os.path.join(root, "bin", "ebwt2clust"), "-i", p] + w, [os.path.join(root, "bin", "clust2snp"), "-i", p, "-n", str(n1)] + w]),
+                      ("bin/ebwt2snp_mgpu -G 1", [[os.path.join(root, "bin", "ebwt2snp_mgpu"), "-i", p, "-n", str(n1), "-G", "1"] + w])):
+        for f in (p + ".clusters", IO.snp_out_path(p)):
+            os.remove(f)
+        wall, timing, forms = 0.0, [], []
+        for i, cmd in enumerate(cmds):
+            jp = str(tmp_path / ("perf_%d.json" % i))
+            t3 = time.time()
+            r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, E2S_CLI_TIMING="1", E2S_CLI_JSON=jp), timeout=600)
+            wall += time.time() - t3
+            assert r.returncode == 0, (cmd, r.stdout[-500:], r.stderr[-800:])
+            timing += [l for l in r.stderr.splitlines() if l.startswith("[timing]")]
+            if os.path.exists(jp):
+                jr = json.load(open(jp))
+                forms.append({k: jr[k] for k in ("tool", "form", "seconds_wall", "seconds_upload", "bytes_uploaded", "bytes_uploaded_per_rank", "chunks") if k in jr})
+        assert open(p + ".clusters", "rb").read() == want_cl, tag
+        assert open(IO.snp_out_path(p), "rb").read() == want_snp, tag
+        report["runs"].append({"what": tag, "seconds_wall": round(wall, 3), "entries_per_s": n / wall, "json": forms, "timing": timing})
+    if os.environ.get("E2S_REPORT_DIR"):
+        with open(os.path.join(os.environ["E2S_REPORT_DIR"], "gesa_444_full_size.json"), "w") as f:
+            json.dump(report, f, indent=1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("chunk", [9973, 20000, 61000])
 def test_chunked_executables_on_goldens(chunk, tmp_path):
     """every end-to-end golden through bin/ebwt2clust + bin/clust2snp with E2S_CHUNK_ENTRIES small enough for 3 to 60 chunks (cuts at

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: SQ / TCC counters of the step's kernels over one bench run, one rocprofv3 --pmc pass per counter group (counters only, never with a trace)
 #   tools/pmc_round4.sh [workload] [tag]
-wl=${1:-c3}; tag=${2:-pmc_r4_$wl}
+wl=${1:-c3}; tag=${2:-pmc_r5_$wl}
 root=$(pwd); out=$root/gpurun_out/$tag; rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --cpu-sample 0 --workload $wl --second-workload none"
