@@ -65,10 +65,15 @@ struct SegDesc {                 // per block, written by k_scan_seg
     uint64_t open_start;         // its start if it lies in this block's range, else ~0
     uint64_t first_end_pos;      // SA position of the block's first end (valid if count > 0)
     uint32_t kept;               // records append_entry keeps (record 0 not counted while its start is unknown: k_seg_fix adds it)
-    uint32_t last_kept1;         // 1 + index of the last of them, and its length
+    // read back by the range's own wave when it ends (its segment's tail is in the caches; k_seg_fix's one thread paid a chain of
+    // dependent round trips for the same values): 1 + index of the LAST record append_entry keeps among those whose length the scan
+    // knew (0: none) and its length; the stored start of the range's last record; the length of its record 0
+    uint32_t last_kept1;
     uint32_t last_kept_len;
-    uint32_t reserved;
+    uint32_t last_start32;
     uint64_t first_start;        // record 0's start where it lies before the block's range (k_seg_fix, e2s_stitch)
+    uint32_t first_len16;
+    uint32_t reserved;
 };
 
 struct SegArgs {

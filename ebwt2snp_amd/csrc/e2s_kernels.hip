@@ -681,7 +681,22 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         if (state == 0u) { d.open_after = (t0 < t1) ? in0 : 0u; d.open_start = ~0ull; }         // no event at all
         else if (state == 1u) { d.open_after = 0; d.open_start = ~0ull; }
         else { d.open_after = 1; d.open_start = g_range + (open1 - 1u); }
-        d.kept = kept_w; d.last_kept1 = 0u; d.last_kept_len = 0u; d.first_start = ~0ull;      // (last_kept*: no longer filled in -- seg_last_kept)
+        d.kept = kept_w; d.first_start = ~0ull;
+        {
+            // the segment's tail read back (past the L1: this wave's stores went through it): eight lengths from the end, the last
+            // record's start, record 0's length -- all in flight together; nearly every record is kept, so the first eight answer
+            const volatile uint16_t* vl = seg_lens; const volatile u32* vs = seg_starts;
+            const u32 cnt = d.count, lo = unknown ? 1u : 0u;
+            u32 lk = 0u, lklen = 0u;
+            u32 v[8];
+#pragma unroll
+            for (u32 q = 0; q < 8u; ++q) v[q] = (q + lo < cnt) ? (u32)vl[cnt - 1u - q] : 0u;
+            const u32 ls32 = cnt ? vs[cnt - 1u] : 0u, fl16 = cnt ? (u32)vl[0] : 0u;
+#pragma unroll
+            for (u32 q = 0; q < 8u; ++q) if (!lk && q + lo < cnt && (int)v[q] >= a.min_len) { lk = cnt - q; lklen = v[q]; }
+            if (!lk) for (u32 hi = cnt > 8u ? cnt - 8u : 0u; hi > lo && !lk; --hi) { const u32 x = (u32)vl[hi - 1u]; if ((int)x >= a.min_len) { lk = hi; lklen = x; } }
+            d.last_kept1 = lk; d.last_kept_len = lklen; d.last_start32 = ls32; d.first_len16 = fl16; d.reserved = 0u;
+        }
         a.desc[b] = d;
         a.hot[b] = make_uint2(d.count | (d.overflow << 31), kept_w | (unknown << 31) | (d.open_after << 30));   // what k_seg_fix reads of every range
 #ifdef E2S_DIAG_STAMPS
@@ -777,23 +792,6 @@ constexpr int SEGFIX_MAX = E2S_SEGFIX_MAX;   // segments (= ranges of the scan) 
 __device__ __forceinline__ u64 seg_range_base(const SegArgs& a, u32 b, u32 row_entries) {      // SA position of the first entry of worker b's range
     const u64 t0 = e2s_range_tile0(a, b);
     return a.prov_lo + (t0 > 0 ? t0 - 1 : t0) * (u64)row_entries;     // (offsets count from the tile before the range: k_scan_seg)
-}
-// 1 + index of the LAST record of worker b's segment that append_entry keeps (length >= min_len), among the records whose length the scan
-// knew -- record 0 is left out where its start lay before the range (the caller looks at that one itself); 0: none.  Eight lengths per
-// round trip, from the segment's end: nearly every record is kept, so the first round answers.
-__device__ __forceinline__ u32 seg_last_kept(const SegArgs& a, u32 b, u32 count, u32 first_unknown) {
-    const volatile uint16_t* lens = a.lens + (u64)b * a.seg_cap;
-    const u32 lo = first_unknown ? 1u : 0u;
-    for (u32 hi = count; hi > lo;) {
-        const u32 n = min(8u, hi - lo);
-        u32 v[8];
-#pragma unroll
-        for (u32 q = 0; q < 8u; ++q) v[q] = q < n ? (u32)lens[hi - 1u - q] : 0u;
-#pragma unroll
-        for (u32 q = 0; q < 8u; ++q) if (q < n && (int)v[q] >= a.min_len) return hi - q;
-        hi -= n;
-    }
-    return 0u;
 }
 // blob (the resident job): this rank's share of the first all-gather -- e2s_boundary + e2s_scan_stats exactly as e2s_boundary_desc /
 // e2s_scan_stats_desc hand them out (tail_bwt_arg >= 0: the BWT byte of the shard's last entry given by the caller, e2s_upload_lcp).
@@ -944,9 +942,11 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         dl.first_start = vdesc[any ? s_last : 0].first_start;
         const u64 last_addr = any ? (u64)s_last * a.seg_cap + dl.count - 1 : NONE;
         const SegDesc dk = a.desc[s_lastk ? s_lastk - 1u : 0u];
-        const u64 v_first_end = a.desc[any ? s_first : 0].first_end_pos;
-        const u32 v_last_st32 = a.starts32[any ? last_addr : 0];
-        const u32 v_first_len = vlens[any ? first_addr : 0];
+        const SegDesc df = a.desc[any ? s_first : 0];
+        const u64 v_first_end = df.first_end_pos;
+        const u32 v_last_st32 = dl.last_start32;
+        // (record 0 of the first segment: its length as its wave wrote it -- unless it was finished above, by another thread of this block)
+        const u32 v_first_len = df.first_unknown ? (u32)vlens[any ? first_addr : 0] : df.first_len16;
         const u32 v_text = da ? (yb == 1 ? (u32)((const uint8_t*)da)[li] : yb == 2 ? (u32)((const uint16_t*)da)[li] : ((const u32*)da)[li]) : 0u;
         const u32 v_suff = pos ? (zb == 1 ? (u32)((const uint8_t*)pos)[li] : zb == 2 ? (u32)((const uint16_t*)pos)[li] : ((const u32*)pos)[li]) : 0u;
         const u32 v_lcp = xb == 1 ? (u32)((const uint8_t*)a.lcp)[li] : xb == 2 ? (u32)((const uint16_t*)a.lcp)[li] : ((const u32*)a.lcp)[li];
@@ -981,16 +981,16 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         u64 last_len = 0, at = NONE;
         if (s_lastk) {
             const u32 bk = s_lastk - 1u;
-            const u32 lk = seg_last_kept(a, bk, dk.count, dk.first_unknown);
-            if (lk) { at = (u64)bk * a.seg_cap + lk - 1u; last_len = vlens[at]; }
+            const u32 lk = dk.last_kept1;
+            if (lk) { at = (u64)bk * a.seg_cap + lk - 1u; last_len = dk.last_kept_len; }
             else { last_len = vlens[(u64)bk * a.seg_cap]; at = (u64)bk * a.seg_cap; }       // only its record 0, finished above
             // (a provisional record 0 that holds a slot without reaching min_len is not what the statistics end with)
             if ((int)last_len < a.min_len) {
                 last_len = 0; at = NONE;
                 for (u32 b2 = bk; b2-- > 0;) {
                     const SegDesc d2 = a.desc[b2];
-                    const u32 lk2 = seg_last_kept(a, b2, d2.count, d2.first_unknown);
-                    if (lk2) { at = (u64)b2 * a.seg_cap + lk2 - 1u; last_len = vlens[at]; break; }
+                    const u32 lk2 = d2.last_kept1;
+                    if (lk2) { at = (u64)b2 * a.seg_cap + lk2 - 1u; last_len = d2.last_kept_len; break; }
                     if (vkept[b2 + 1u] != vkept[b2] && (int)vlens[(u64)b2 * a.seg_cap] >= a.min_len) { last_len = vlens[(u64)b2 * a.seg_cap]; at = (u64)b2 * a.seg_cap; break; }
                 }
             }
