@@ -101,3 +101,17 @@ const void* d_clusters; uint64_t n_rec; e2s_clusters_image(h, &d_clusters, &n_re
 // [end]
     return rc + can + (int)n_rec;
 }
+
+int snippet_reads_of_candidates(e2s_handle h, const std::string& input, int k_left, int k_right, int max_gap, int max_err, uint64_t first_id) {
+    e2s_fasta_index* fix; const void* text; uint64_t text_bytes, n_reads; const uint64_t* start; const uint32_t* len; uint32_t max_len;
+    e2s_tail_params t = {k_left, k_right, max_gap, max_err};
+    uint64_t nv, ne, snp_bytes;
+// [snippet 6: a rank that does not hold every read]
+e2s_fasta_index_open(input.c_str(), &fix, &text, &text_bytes, &start, &len, &n_reads, &max_len);   // once per process, shared by the ranks
+uint64_t n_named, up_bytes;
+e2s_upload_reads_of_candidates(h, text, text_bytes, start, len, n_reads, max_len, &n_named, &up_bytes);   // the named reads as a compact table + the candidates, ranks rewritten
+e2s_call_variants(h, &t, first_id, &nv, &ne, &snp_bytes);        // as with all reads resident; e2s_candidates_packed still hands out the original ranks
+// [end]
+    e2s_fasta_index_close(fix);
+    return (int)(n_named + up_bytes + nv + ne + snp_bytes);
+}
