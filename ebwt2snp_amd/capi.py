@@ -136,7 +136,8 @@ def lib():
     L.e2s_pack_clusters.argtypes = [H, C.c_int]
     L.e2s_clusters_image.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.e2s_upload_reads.argtypes = [H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
-    L.e2s_upload_reads_of_candidates.argtypes = [H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    if hasattr(L, "e2s_upload_reads_of_candidates"):             # (E2S_LIB_PATH may name a build from before round 5: tools/ab_libs.sh)
+        L.e2s_upload_reads_of_candidates.argtypes = [H, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.e2s_attach_reads.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
     L.e2s_upload_reads_fasta.argtypes = [H, C.c_char_p, C.POINTER(C.c_uint64)]
     L.e2s_call_variants.argtypes = [H, C.POINTER(TailParams), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
