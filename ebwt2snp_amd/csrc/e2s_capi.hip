@@ -927,10 +927,14 @@ extern "C" int e2s_cluster_counts(e2s_handle h, uint64_t* n_closed, uint64_t* n_
 // per-cluster pass (e2s_pack_clusters with async != 0): it is bandwidth bound, that pass latency bound.
 // (Throttling the pack's blocks where it runs beside other kernels was measured in round 3 -- 256 ... 2048 blocks: 3.18 / 2.83 / 2.75 / 2.83 /
 // 2.83 ms per c3 step against 2.82-2.93 unthrottled: what the per-cluster pass gains, the tail loses -- and the switch is gone: one block per segment.)
-// Round 5: the scan leaves up to 32768 segments where it left 4096: the layout kernel keeps its 4096 blocks, each taking every 4096th segment --
+// Round 5: the scan leaves up to 32768 segments where it left 4096: the layout kernel runs as 2048 blocks, each taking every 2048th segment --
 // tens of thousands of short blocks kept refilling every CU until the kernel's end, and the tail's one 1024-thread block (k_tail_partials)
-// found no CU with sixteen free wave slots before that: 152 us instead of 5 (gpurun_out/r5_timeline).
-static uint32_t pack_blocks_beside() { return 4096u; }
+// found no CU with sixteen free wave slots before that: 152 us instead of 5 (gpurun_out/r5_timeline).  c3 step, one box, two interleaved
+// sweeps (tools/r5_pack_blocks.sh): 512 blocks 2.308 / 2.316 ms, 1024: 2.178 / 2.216, 2048: 2.178 / 2.183, 4096: 2.201 / 2.203, 8192: 2.222 / 2.199.
+static uint32_t pack_blocks_beside() {
+    static const int env = e2s_env_dev("E2S_PACK_BLOCKS") ? atoi(e2s_env_dev("E2S_PACK_BLOCKS")) : 0;      // (tuning aid)
+    return env > 0 ? (uint32_t)env : 2048u;
+}
 static int pack_image_launch(e2s_ctx* h, hipStream_t st) {
     h->img_valid = false; h->img_pending = false; h->img_records = 0; h->img_total_known = false; h->img_prestitch = false; h->img_stream = st;
     const uint64_t n_raw = h->stitched ? h->n_rec : h->n_ends;
