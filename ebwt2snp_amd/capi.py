@@ -77,7 +77,7 @@ class Timing(C.Structure):
 # every symbol include/e2s_hip.h declares (checked by tests/test_capi_symbols.py)
 BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)     # e2s_byte_sink
 SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
-           "e2s_attach_soa", "e2s_upload_lcp", "e2s_upload_lcp_bwt", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
+           "e2s_attach_soa", "e2s_upload_lcp", "e2s_upload_lcp_bwt", "e2s_upload_bcr_fd", "e2s_upload_gesa_fd", "e2s_upload_lcp_bwt_fd", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_stream_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
@@ -103,6 +103,11 @@ def lib():
     L.e2s_version.restype = C.c_char_p
     L.e2s_upload_bcr.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.e2s_upload_gesa.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p]
+    if hasattr(L, "e2s_upload_bcr_fd"):                          # (absent from older builds: tools/ab_libs.sh loads those too)
+        L.e2s_upload_bcr_fd.argtypes = [H, C.POINTER(ShardDesc), C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_uint64]
+        L.e2s_upload_gesa_fd.argtypes = [H, C.POINTER(ShardDesc), C.c_int, C.c_uint64]
+        L.e2s_upload_lcp_bwt_fd.argtypes = [H, C.POINTER(ShardDesc), C.c_int, C.c_uint64, C.c_int, C.c_uint64]
+    L.e2s_upload_lcp_bwt.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_void_p]
     L.e2s_attach_soa.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.e2s_upload_lcp.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_uint8]
     L.e2s_cluster_scan.argtypes = [H, C.c_int, C.c_int, C.c_int]
@@ -200,6 +205,19 @@ class Handle:
 
     def upload_gesa(self, d, aos):
         self._ck(self.L.e2s_upload_gesa(self.h, C.byref(d), _ptr(aos)))
+
+    def upload_bcr_fd(self, d, bwt_fd, bwt_off, lcp_fd, lcp_off, pairsa_fd, pairsa_off):
+        """the columns from open files (descriptor, byte offset of the first provided entry): pread into pinned buffers"""
+        self._ck(self.L.e2s_upload_bcr_fd(self.h, C.byref(d), bwt_fd, bwt_off, lcp_fd, lcp_off, pairsa_fd, pairsa_off))
+
+    def upload_gesa_fd(self, d, fd, off):
+        self._ck(self.L.e2s_upload_gesa_fd(self.h, C.byref(d), fd, off))
+
+    def upload_lcp_bwt(self, d, lcp, bwt):
+        self._ck(self.L.e2s_upload_lcp_bwt(self.h, C.byref(d), _ptr(lcp), _ptr(bwt)))
+
+    def upload_lcp_bwt_fd(self, d, lcp_fd, lcp_off, bwt_fd, bwt_off):
+        self._ck(self.L.e2s_upload_lcp_bwt_fd(self.h, C.byref(d), lcp_fd, lcp_off, bwt_fd, bwt_off))
 
     def upload_lcp(self, d, lcp, tail_bwt):
         self._ck(self.L.e2s_upload_lcp(self.h, C.byref(d), _ptr(lcp), int(tail_bwt)))

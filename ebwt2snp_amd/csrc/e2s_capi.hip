@@ -93,7 +93,8 @@ struct e2s_ctx {
     uint64_t* d_scan_stats = nullptr;                            // [151 freq | n_records | n_bases] tallied by the scan kernel (in front of d_words)
     std::vector<uint64_t> host_fl_starts; std::vector<uint16_t> host_fl_lens;   // e2s_internal_flagged_list
     uint8_t* d_compact = nullptr; size_t compact_bytes = 0; uint64_t* d_compact_keys = nullptr; uint64_t compact_keys_cap = 0;   // e2s_internal_find_candidates_compact
-    std::vector<hipStream_t> up_streams;                         // upload_sliced
+    std::vector<hipStream_t> up_streams;                         // upload_sliced, upload_from_fd
+    std::vector<uint8_t*> pin_up; std::vector<hipEvent_t> ev_up; uint8_t* pin_up_base = nullptr; size_t pin_up_bytes = 0;   // upload_from_fd: two pinned buffers (pieces of one allocation) and events per thread
     bool ko_clean = false;                                       // the ordering pass's bucket counts are zero (its last kernel leaves them so)
     uint8_t* d_xchg = nullptr; size_t xchg_bytes = 0;            // e2s_resident_job: the two exchanges' send / receive buffers
     uint64_t img_scan_records = 0; uint32_t img_skip = 0;       // records the scan counted for the image; img_skip: the shard's record 0 turned out shorter than min_len
@@ -294,6 +295,8 @@ extern "C" int e2s_destroy(e2s_handle h) {
     if (h->ev_img) ev_destroy(h->ev_img);
     for (auto& e : h->ev_chunk) if (e) ev_destroy(e);
     for (auto st : h->up_streams) stream_destroy(st);
+    pin_free(h->pin_up_base);
+    for (auto e : h->ev_up) ev_destroy(e);
     if (h->stream2) stream_destroy(h->stream2);
     if (h->stream3) stream_destroy(h->stream3);
     dev_free(h->d_pieces);
@@ -409,11 +412,114 @@ static int upload_sliced(e2s_ctx* h, void* dst, const void* src, size_t bytes) {
     return E2S_OK;
 }
 
-extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa) {
-    dbg_entry("e2s_upload_bcr");
-    int rc = check_desc(h, d);
-    if (rc) return rc;
-    if (!bwt || !lcp || !pairsa) return fail(h, E2S_ERR_ARG, "null source pointer");
+// A column that lies in a FILE: every thread reads chunks with pread into two pinned buffers of its own and sends them from there.  No
+// mapping: a page-cache mapping costs a minor fault per 4 KB (with the kernel's fault-around, per 64 KB) on first touch, which is what
+// bounded upload_sliced at ~21 GB/s on these hosts (6 GB of LCP + BWT: 0.28-0.30 s, eight threads), and the pages' entries have to be
+// torn down again when the process ends; and the DMA reads the pinned buffer itself instead of the runtime's staging copy of it.
+// per_chunk (the FASTA: fasta_index.hpp) sees every chunk in the buffer -- bytes [lo, hi) of the file, lo = a - 1 (0 for the first chunk),
+// hi = min(b + read_ahead, end) -- after its copy has been enqueued, on the thread that read it; chunks are handed out in file order.
+#include <unistd.h>
+#include <functional>
+static size_t up_chunk() {                                     // 8 MB; E2S_UP_CHUNK (development tier): the tests cut small files into many chunks
+    const char* e = e2s_env_dev("E2S_UP_CHUNK");                // (read at every call: a test changes it between calls)
+    const long long x = e ? atoll(e) : 0;
+    return x >= 16 ? (size_t)x : (size_t)(8u << 20);
+}
+static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t bytes, size_t read_ahead = 0,
+                          const std::function<void(unsigned, uint64_t, const uint8_t*, uint64_t, size_t, uint64_t, uint64_t)>& per_chunk = nullptr) {
+    if (!bytes) return E2S_OK;
+    static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 8;
+    const size_t UP_CHUNK = up_chunk();
+    const uint64_t n_chunks = (bytes + UP_CHUNK - 1) / UP_CHUNK;
+    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(T_env, 1), n_chunks));
+    // the threads share TWO streams (one reaches the link's rate; every further stream costs ~5 ms when it is first used and at exit)
+    const int NS = std::max(1, std::min(T, e2s_env_dev("E2S_UPLOAD_STREAMS") ? atoi(e2s_env_dev("E2S_UPLOAD_STREAMS")) : 2));
+    if (h->up_streams.size() < (size_t)NS) {
+        const size_t have = h->up_streams.size();
+        h->up_streams.resize((size_t)NS, nullptr);
+        for (size_t i = have; i < (size_t)NS; ++i) CK(hipStreamCreateWithFlags(&h->up_streams[i], hipStreamNonBlocking));
+    }
+    CK(hipStreamSynchronize(h->stream));                        // (whatever was enqueued before must not be overtaken)
+    const bool prof = getenv("E2S_UPLOAD_PROFILE") != nullptr;  // (development: where an upload's time goes, per thread, on stderr)
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    // the pinned buffers (two per thread) and their events stay with the handle: pinning and unpinning 16 x 8 MB costs more than the copy of a GB
+    // (ONE allocation cut into 2 T pieces: a call of hipHostMalloc costs ~5 ms whatever its size, and they do not run side by side)
+    const size_t cap = (UP_CHUNK + read_ahead + 64 + 4095) & ~(size_t)4095;
+    if (h->pin_up_bytes < cap * (size_t)(2 * T)) {
+        pin_free(h->pin_up_base); h->pin_up_base = nullptr; h->pin_up_bytes = 0;
+        CK(hipHostMalloc((void**)&h->pin_up_base, cap * (size_t)(2 * T), hipHostMallocDefault));
+        h->pin_up_bytes = cap * (size_t)(2 * T);
+    }
+    h->pin_up.assign((size_t)(2 * T), nullptr);
+    for (int i = 0; i < 2 * T; ++i) h->pin_up[(size_t)i] = h->pin_up_base + cap * (size_t)i;
+    if (h->ev_up.size() < (size_t)(2 * T)) h->ev_up.resize((size_t)(2 * T), nullptr);
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> bad{0};                                    // 1: HIP, 2: the file
+    const int dev = h->device;
+    const uint64_t end = off + bytes;
+    struct Prof { double alloc = 0, rd = 0, wait = 0, enq = 0, cb = 0, fin = 0; };
+    std::vector<Prof> pf((size_t)T);
+    auto work = [&, dev](int t) {
+        Prof& P = pf[(size_t)t];
+        double t0 = now();
+        if (hipSetDevice(dev) != hipSuccess) { bad = 1; return; }
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t& e = h->ev_up[(size_t)(2 * t + k)];
+            if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { bad = 1; return; }
+        }
+        P.alloc = now() - t0;
+        bool used[2] = {false, false};
+        for (int it = 0;; ++it) {
+            const uint64_t c = next.fetch_add(1);
+            if (c >= n_chunks || bad.load()) break;
+            const int k = it & 1;
+            uint8_t* const buf = h->pin_up[(size_t)(2 * t + k)];
+            t0 = now();
+            if (used[k] && hipEventSynchronize(h->ev_up[(size_t)(2 * t + k)]) != hipSuccess) { bad = 1; break; }
+            double t1 = now(); P.wait += t1 - t0;
+            const uint64_t a = off + c * UP_CHUNK, b = std::min<uint64_t>(a + UP_CHUNK, end);
+            const uint64_t lo = (per_chunk && a > off) ? a - 1 : a, hi = std::min<uint64_t>(b + read_ahead, end);
+            for (uint64_t at = lo; at < hi;) {
+                const ssize_t r = pread(fd, buf + (at - lo), (size_t)(hi - at), (off_t)at);
+                if (r <= 0) { bad = 2; break; }
+                at += (uint64_t)r;
+            }
+            if (bad.load()) break;
+            double t2 = now(); P.rd += t2 - t1;
+            if (hipMemcpyAsync((uint8_t*)dst + (a - off), buf + (a - lo), (size_t)(b - a), hipMemcpyHostToDevice, h->up_streams[(size_t)(t % NS)]) != hipSuccess ||
+                hipEventRecord(h->ev_up[(size_t)(2 * t + k)], h->up_streams[(size_t)(t % NS)]) != hipSuccess) { bad = 1; break; }
+            used[k] = true;
+            double t3 = now(); P.enq += t3 - t2;
+            if (per_chunk) per_chunk((unsigned)t, c, buf, lo, (size_t)(hi - lo), a, b);
+            P.cb += now() - t3;
+        }
+        t0 = now();
+        if (hipStreamSynchronize(h->up_streams[(size_t)(t % NS)]) != hipSuccess) bad = 1;
+        P.fin = now() - t0;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (prof) {
+        Prof m;
+        for (const Prof& P : pf) { m.alloc = std::max(m.alloc, P.alloc); m.rd += P.rd / T; m.wait += P.wait / T; m.enq += P.enq / T; m.cb += P.cb / T; m.fin += P.fin / T; }
+        fprintf(stderr, "[upload] %.2f GB from a file, %d threads, chunks of %zu KB: %.1f ms = %.1f GB/s; per thread: thread start (max) %.1f, pread %.1f, waiting for a buffer %.1f, "
+                        "enqueue %.1f, index %.1f, last copies %.1f ms\n", (double)bytes / 1e9, T, UP_CHUNK >> 10, now() - t_begin, (double)bytes / 1e6 / (now() - t_begin), m.alloc, m.rd, m.wait, m.enq, m.cb, m.fin);
+    }
+    if (bad.load() == 2) return fail(h, E2S_ERR_IO, "reading a column from its file failed (short file or read error)");
+    if (bad.load()) return fail(h, E2S_ERR_HIP, "streamed host-to-device copy failed");
+    return E2S_OK;
+}
+// a column of a shard: in memory, or in an open file at an offset
+struct ColSrc { const void* p; int fd; uint64_t off; };
+static int upload_col(e2s_ctx* h, void* dst, const ColSrc& s, size_t bytes) {
+    return s.p ? upload_sliced(h, dst, s.p, bytes) : upload_from_fd(h, dst, s.fd, s.off, bytes);
+}
+
+static int upload_bcr_impl(e2s_ctx* h, const e2s_shard_desc* d, const ColSrc& bwt, const ColSrc& lcp, const ColSrc& pairsa) {
+    int rc;
     CK(hipSetDevice(h->device));
     release_shard(h);
     set_shard_common(h, d);
@@ -424,17 +530,17 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
     if ((rc = dev_alloc(h, &h->pos, n * h->zb))) return rc;
     if ((rc = dev_alloc(h, &h->da, n * h->yb))) return rc;
-    if ((rc = upload_sliced(h, h->bwt, bwt, n))) return rc;
+    if ((rc = upload_col(h, h->bwt, bwt, n))) return rc;
     DevScratch stage8, stage;
     if (d->lcp_bytes == 8) {
         CK(stage8.alloc(n * 8));
-        if ((rc = upload_sliced(h, stage8.p, lcp, n * 8))) return rc;
+        if ((rc = upload_col(h, stage8.p, lcp, n * 8))) return rc;
         e2s_launch_narrow8((const uint8_t*)stage8.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
-    } else if ((rc = upload_sliced(h, h->lcp, lcp, n * h->xb))) return rc;
+    } else if ((rc = upload_col(h, h->lcp, lcp, n * h->xb))) return rc;
     const size_t rec = (size_t)d->pos_bytes + d->da_bytes;
     CK(stage.alloc(n * rec + 16));
-    if ((rc = upload_sliced(h, stage.p, pairsa, n * rec))) return rc;
+    if ((rc = upload_col(h, stage.p, pairsa, n * rec))) return rc;
     e2s_launch_unpack_pairsa((const uint8_t*)stage.p, n, d->pos_bytes, d->da_bytes, h->pos, h->zb, h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_pairsa");
     TREC(2, 1, h->stream);
@@ -444,12 +550,27 @@ extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void*
     ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
     return narrow_lcp(h);
 }
-
-extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void* aos) {
-    dbg_entry("e2s_upload_gesa");
+extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa) {
+    dbg_entry("e2s_upload_bcr");
     int rc = check_desc(h, d);
     if (rc) return rc;
-    if (!aos) return fail(h, E2S_ERR_ARG, "null source pointer");
+    if (!bwt || !lcp || !pairsa) return fail(h, E2S_ERR_ARG, "null source pointer");
+    return upload_bcr_impl(h, d, ColSrc{bwt, -1, 0}, ColSrc{lcp, -1, 0}, ColSrc{pairsa, -1, 0});
+}
+// The _fd forms: the shard's columns lie in open files (descriptor + byte offset of the shard's first provided entry); they are read with
+// pread into pinned buffers and sent from there (upload_from_fd) -- what a caller that would otherwise map the file and pass the pointer gets
+// without a page fault per 4 KB.  The file must hold the bytes the pointer form would have read.
+static int fd_ok(e2s_handle h, int fd) { return fd >= 0 ? E2S_OK : fail(h, E2S_ERR_ARG, "bad file descriptor"); }
+extern "C" int e2s_upload_bcr_fd(e2s_handle h, const e2s_shard_desc* d, int bwt_fd, uint64_t bwt_off, int lcp_fd, uint64_t lcp_off, int pairsa_fd, uint64_t pairsa_off) {
+    dbg_entry("e2s_upload_bcr_fd");
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if ((rc = fd_ok(h, bwt_fd)) || (rc = fd_ok(h, lcp_fd)) || (rc = fd_ok(h, pairsa_fd))) return rc;
+    return upload_bcr_impl(h, d, ColSrc{nullptr, bwt_fd, bwt_off}, ColSrc{nullptr, lcp_fd, lcp_off}, ColSrc{nullptr, pairsa_fd, pairsa_off});
+}
+
+static int upload_gesa_impl(e2s_ctx* h, const e2s_shard_desc* d, const ColSrc& aos) {
+    int rc;
     CK(hipSetDevice(h->device));
     release_shard(h);
     set_shard_common(h, d);
@@ -463,7 +584,7 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     const size_t rec = (size_t)d->da_bytes + d->pos_bytes + d->lcp_bytes + 1;
     DevScratch stage;
     CK(stage.alloc(n * rec + 16));
-    if ((rc = upload_sliced(h, stage.p, aos, n * rec))) return rc;
+    if ((rc = upload_col(h, stage.p, aos, n * rec))) return rc;
     e2s_launch_unpack_gesa((const uint8_t*)stage.p, n, d->da_bytes, d->pos_bytes, d->lcp_bytes, h->bwt, h->lcp, h->xb, h->pos, h->zb,
                            h->da, h->yb, h->stream);
     LCHK("e2s_launch_unpack_gesa");
@@ -473,6 +594,20 @@ extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void
     CK(hipGetLastError());
     ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
     return narrow_lcp(h);
+}
+extern "C" int e2s_upload_gesa(e2s_handle h, const e2s_shard_desc* d, const void* aos) {
+    dbg_entry("e2s_upload_gesa");
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if (!aos) return fail(h, E2S_ERR_ARG, "null source pointer");
+    return upload_gesa_impl(h, d, ColSrc{aos, -1, 0});
+}
+extern "C" int e2s_upload_gesa_fd(e2s_handle h, const e2s_shard_desc* d, int fd, uint64_t off) {
+    dbg_entry("e2s_upload_gesa_fd");
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if ((rc = fd_ok(h, fd))) return rc;
+    return upload_gesa_impl(h, d, ColSrc{nullptr, fd, off});
 }
 
 extern "C" int e2s_attach_soa(e2s_handle h, const e2s_shard_desc* d, const void* d_bwt, const void* d_lcp, const void* d_pos,
@@ -521,33 +656,51 @@ extern "C" int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void*
     return narrow_lcp(h);
 }
 
-extern "C" int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const void* lcp, const void* bwt) {
-    dbg_entry("e2s_upload_lcp_bwt");
-    int rc = check_desc(h, d);
-    if (rc) return rc;
-    if (!lcp || !bwt) return fail(h, E2S_ERR_ARG, "null source pointer");
+static int upload_lcp_bwt_impl(e2s_ctx* h, const e2s_shard_desc* d, const ColSrc& lcp, const ColSrc& bwt) {
+    int rc;
     CK(hipSetDevice(h->device));
     release_shard(h);
     set_shard_common(h, d);
     h->layout = 0;
     const uint64_t n = h->n_prov;
+    const bool prof = getenv("E2S_UPLOAD_PROFILE") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     TREC(2, 0, h->stream);
     if ((rc = dev_alloc(h, (void**)&h->bwt, n))) return rc;
     if ((rc = dev_alloc(h, &h->lcp, n * h->xb))) return rc;
-    if ((rc = upload_sliced(h, h->bwt, bwt, n))) return rc;
+    const double t1 = now();
+    if ((rc = upload_col(h, h->bwt, bwt, n))) return rc;
     DevScratch stage;
     if (d->lcp_bytes == 8) {
         CK(stage.alloc(n * 8));
-        if ((rc = upload_sliced(h, stage.p, lcp, n * 8))) return rc;
+        if ((rc = upload_col(h, stage.p, lcp, n * 8))) return rc;
         e2s_launch_narrow8((const uint8_t*)stage.p, n, (uint32_t*)h->lcp, h->stream);
         LCHK("e2s_launch_narrow8");
-    } else if ((rc = upload_sliced(h, h->lcp, lcp, n * h->xb))) return rc;
+    } else if ((rc = upload_col(h, h->lcp, lcp, n * h->xb))) return rc;
     TREC(2, 1, h->stream);
     CK(hipStreamSynchronize(h->stream));
     stage.release();
     CK(hipGetLastError());
     ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
-    return narrow_lcp(h);
+    const double t2 = now();
+    rc = narrow_lcp(h);
+    if (prof) fprintf(stderr, "[upload] LCP + BWT of %.2f x 10^9 entries: allocations %.1f ms, the two copies %.1f ms, LCP width check / narrowing %.1f ms\n", (double)n / 1e9, t1 - t0, t2 - t1, now() - t2);
+    return rc;
+}
+extern "C" int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const void* lcp, const void* bwt) {
+    dbg_entry("e2s_upload_lcp_bwt");
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if (!lcp || !bwt) return fail(h, E2S_ERR_ARG, "null source pointer");
+    return upload_lcp_bwt_impl(h, d, ColSrc{lcp, -1, 0}, ColSrc{bwt, -1, 0});
+}
+extern "C" int e2s_upload_lcp_bwt_fd(e2s_handle h, const e2s_shard_desc* d, int lcp_fd, uint64_t lcp_off, int bwt_fd, uint64_t bwt_off) {
+    dbg_entry("e2s_upload_lcp_bwt_fd");
+    int rc = check_desc(h, d);
+    if (rc) return rc;
+    if ((rc = fd_ok(h, lcp_fd)) || (rc = fd_ok(h, bwt_fd))) return rc;
+    return upload_lcp_bwt_impl(h, d, ColSrc{nullptr, lcp_fd, lcp_off}, ColSrc{nullptr, bwt_fd, bwt_off});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1782,6 +1935,7 @@ extern "C" int e2s_share_reads(e2s_handle dst, e2s_handle src) {
 }
 
 static int upload_reads_impl(e2s_ctx* h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads, uint32_t max_len);
+static int reads_resident(e2s_ctx* h, uint64_t text_bytes, uint64_t n_reads, uint32_t max_len, bool uniform);
 extern "C" int e2s_upload_reads(e2s_handle h, const void* text, uint64_t text_bytes, const uint64_t* start, const uint32_t* len, uint64_t n_reads,
                                 uint32_t max_len) {
     dbg_entry("e2s_upload_reads");
@@ -1795,16 +1949,32 @@ static int upload_reads_impl(e2s_ctx* h, const void* text, uint64_t text_bytes, 
     CK(hipMalloc((void**)&h->d_text, text_bytes + 256));
     CK(hipMalloc((void**)&h->d_rstart, n_reads * 8 + 64));
     CK(hipMalloc((void**)&h->d_rlen, n_reads * 4 + 64));
-    CK(hipMemcpyAsync(h->d_text, text, text_bytes, hipMemcpyHostToDevice, h->stream));
-    CK(hipMemcpyAsync(h->d_rstart, start, n_reads * 8, hipMemcpyHostToDevice, h->stream));
+    // the text in slices on several threads (a single copy out of pageable memory is staged by ONE thread: 3 GB in 85 ms against 60)
+    int rc;
+    if ((rc = upload_sliced(h, h->d_text, text, text_bytes))) return rc;
+    if ((rc = upload_sliced(h, h->d_rstart, start, n_reads * 8))) return rc;
     CK(hipMemcpyAsync(h->d_rlen, len, n_reads * 4, hipMemcpyHostToDevice, h->stream));
+    // reads of ONE length?  (looked at while the last copy is under way)
+    bool uniform = max_len > 0;
+    {
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, n_reads >> 16));
+        std::vector<char> ok(T, 1);
+        std::vector<std::thread> th;
+        auto work = [&](unsigned t) { for (uint64_t r = n_reads * t / T, e = n_reads * (t + 1) / T; r < e; ++r) if (len[r] != max_len) { ok[t] = 0; return; } };
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (char c : ok) uniform = uniform && c;
+    }
     CK(hipStreamSynchronize(h->stream));
+    return reads_resident(h, text_bytes, n_reads, max_len, uniform);
+}
+// the text and the index arrays are in HBM (d_text, d_rstart, and d_rlen unless `uniform`): the rest of making the reads resident
+static int reads_resident(e2s_ctx* h, uint64_t text_bytes, uint64_t n_reads, uint32_t max_len, bool uniform) {
     h->n_reads = n_reads; h->reads_max_len = max_len; h->have_reads = true; h->variants_valid = false;
     h->text_bytes = text_bytes;
     // reads of ONE length (what sequencers and the synthetic sets give) become a dense matrix: read r at r * len, no index arrays --
     // every left context then costs one random access instead of three
-    bool uniform = max_len > 0;
-    for (uint64_t r = 0; r < n_reads && uniform; ++r) uniform = len[r] == max_len;
     if (uniform) {
         uint8_t* dense = nullptr;
         CK(hipMalloc((void**)&dense, n_reads * (uint64_t)max_len + 256));
@@ -1816,6 +1986,46 @@ static int upload_reads_impl(e2s_ctx* h, const void* text, uint64_t text_bytes, 
         h->text_bytes = n_reads * (uint64_t)max_len;
     }
     return pack_reads(h);
+}
+
+// (private, ebwt2snp_amd/host/reads_upload.cpp: e2s_upload_reads_fasta) A FASTA of the plain shape -- header, one line of DNA, header, ... --
+// goes to the GPU in ONE pass over the file: chunks read with pread into pinned buffers, sent from there, and indexed in the buffer by the
+// thread that read them (fasta_index.hpp: e2s_fasta_scan_chunk) while the copy is under way; no mapping, no second pass.  The text in HBM is
+// the file's image, as on the mapped path.  Returns 1 for a file of another shape (nothing resident): the caller maps and indexes it whole.
+#include "../host/fasta_index.hpp"
+extern "C" int e2s_internal_upload_reads_fd(e2s_handle h, int fd, uint64_t file_bytes, uint64_t* n_reads) {
+    dbg_entry("e2s_internal_upload_reads_fd");
+    if (!h || fd < 0 || !file_bytes) return E2S_ERR_ARG;
+    CK(hipSetDevice(h->device));
+    const bool prof = getenv("E2S_UPLOAD_PROFILE") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    release_reads(h);
+    h->reads_owned = true;
+    CK(hipMalloc((void**)&h->d_text, file_bytes + 256));
+    const double t1 = now();
+    constexpr size_t READ_AHEAD = 64u << 10;                    // (a line that starts in a chunk and runs further than this beyond it: not this path's)
+    std::vector<FastaChunk> chunks((size_t)((file_bytes + up_chunk() - 1) / up_chunk()));
+    int rc = upload_from_fd(h, h->d_text, fd, 0, file_bytes, READ_AHEAD,
+                            [&](unsigned, uint64_t c, const uint8_t* buf, uint64_t lo, size_t n, uint64_t a, uint64_t b) { e2s_fasta_scan_chunk(buf, lo, n, a, b, file_bytes, chunks[(size_t)c]); });
+    if (rc) { release_reads(h); return rc; }
+    const double t2 = now();
+    FastaJoined ix;
+    if (!e2s_fasta_join_chunks(chunks, ix)) { release_reads(h); return 1; }
+    const bool uniform = ix.uniform;
+    const double t3 = now();
+    const uint64_t n = ix.n;
+    CK(hipMalloc((void**)&h->d_rstart, n * 8 + 64));
+    CK(hipMalloc((void**)&h->d_rlen, n * 4 + 64));
+    if ((rc = upload_sliced(h, h->d_rstart, ix.start.get(), n * 8))) return rc;
+    if (!uniform) CK(hipMemcpyAsync(h->d_rlen, ix.len.get(), n * 4, hipMemcpyHostToDevice, h->stream));   // (reads of one length: the dense matrix needs no lengths)
+    CK(hipStreamSynchronize(h->stream));
+    if (n_reads) *n_reads = n;
+    const double t4 = now();
+    rc = reads_resident(h, file_bytes, n, ix.max_len, uniform);
+    if (prof) fprintf(stderr, "[upload] FASTA of %.2f GB, %.2f x 10^6 reads: allocation %.1f ms, streamed + indexed %.1f ms, index joined %.1f ms, index sent %.1f ms, "
+                              "dense matrix / bit planes on the GPU %.1f ms\n", (double)file_bytes / 1e9, (double)n / 1e6, t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
+    return rc;
 }
 
 // get_reads (clust2snp.cpp:147-212) touches the reads the candidates name and no others (:519-528): a handle whose candidates were

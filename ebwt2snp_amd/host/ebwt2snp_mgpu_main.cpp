@@ -83,6 +83,7 @@ struct Shared {
     // the reads, indexed once
     const void* rd_text = nullptr; uint64_t rd_bytes = 0, rd_n = 0; const uint64_t* rd_start = nullptr; const uint32_t* rd_len = nullptr; uint32_t rd_max = 0;
     bool reads_ok = false;
+    bool mapped = true, stream_reads = false;   // uploads from the mappings, or (E2S_MGPU_PREAD=1) with pread into pinned buffers, a lone rank streaming the FASTA itself
     int cl_fd = -1, snp_fd = -1; std::string snp_path;
     std::atomic<int> rc{0};
     std::atomic<int> crash{0};                // 136 / 139: the reference's clust2snp dies on this input (SIGFPE / SIGSEGV) -- after ebwt2clust wrote its file
@@ -255,23 +256,52 @@ void rank_main(Shared& S, int r) {
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc(&d_send, BLOB) != hipSuccess || hipMalloc(&d_recv, BLOB * (size_t)S.nranks) != hipSuccess) mine_rc = E2S_ERR_HIP;
     }
+    pc.mark("rank 0: first handle (HIP start-up), exchange buffers");
     if (!mine_rc && S.slim) STEP(e2s_create(dev, &hc), "e2s_create (per-cluster pass)");
+    pc.mark("rank 0: second handle");
     e2s_handle const hr_ = S.slim ? hc : h;                     // where the reads live
+    // A lone rank streams the FASTA itself (e2s_upload_reads_fasta: read, sent and indexed chunk by chunk, in one pass).  Where the reads live on a
+    // handle of their own (hc) that goes on in a thread of its own WHILE the shard's columns go up on h: the two share the link and the cores,
+    // and neither waits for the other's allocations and kernels; joined right before the per-cluster pass, which wants the reads resident.
+    std::thread reads_thread; int reads_rc = 0; uint64_t reads_n = 0;
+    auto reads_done = [&]() {
+        if (reads_thread.joinable()) reads_thread.join();
+        if (reads_rc == E2S_OK && reads_n) { S.reads_ok = true; S.rd_n = reads_n; S.reads_uploaded[(size_t)r] = S.rd_bytes; S.reads_gathered[(size_t)r] = reads_n; }
+        else if (!mine_rc && reads_rc != E2S_OK && reads_rc != E2S_ERR_INPUT && reads_rc != E2S_ERR_IO) {      // (an irregular / unreadable FASTA: the host tail decides)
+            std::lock_guard<std::mutex> lk(S.log_m);
+            std::cerr << "rank " << r << ": upload reads (streamed) failed (" << reads_rc << "): " << (hr_ ? e2s_last_error(hr_) : "") << std::endl;
+            mine_rc = reads_rc;
+        }
+    };
+    if (S.stream_reads && !mine_rc && hc) reads_thread = std::thread([&reads_rc, &reads_n, hc, &o]() { reads_rc = e2s_upload_reads_fasta(hc, o.input.c_str(), &reads_n); });
     e2s_shard_desc d{};
     d.global_offset = lo; d.n_entries = hi - lo; d.n_total = n; d.halo_left = hl; d.halo_right = hr;
     d.lcp_bytes = o.lcp; d.da_bytes = o.da; d.pos_bytes = o.pos;
     const uint64_t p0 = lo - hl, n_prov = (hi - lo) + hl + hr;
     if (!mine_rc) {
-        if (S.slim) { STEP(e2s_upload_lcp_bwt(h, &d, S.F->lcp.p + p0, S.F->bwt.p + p0), "upload (LCP + BWT)"); S.uploaded[(size_t)r] = 2 * n_prov; }
-        else {
-            if (S.F->gesa) STEP(e2s_upload_gesa(h, &d, S.F->aos.p + p0 * (uint64_t)(o.lcp + o.da + o.pos + 1)), "upload (.gesa)");
-            else STEP(e2s_upload_bcr(h, &d, S.F->bwt.p + p0, S.F->lcp.p + p0 * (uint64_t)o.lcp, S.F->pairsa.p + p0 * (uint64_t)(o.da + o.pos)), "upload (BCR)");
-            S.uploaded[(size_t)r] = (uint64_t)(o.lcp + o.da + o.pos + 1) * n_prov;
+        // the shard's columns: pointers into the mappings, or (E2S_MGPU_PREAD=1) read from the files with pread into pinned buffers (the _fd forms)
+        if (S.slim) {
+            if (S.mapped) STEP(e2s_upload_lcp_bwt(h, &d, S.F->lcp.p + p0, S.F->bwt.p + p0), "upload (LCP + BWT)");
+            else STEP(e2s_upload_lcp_bwt_fd(h, &d, S.F->lcp.fd, p0, S.F->bwt.fd, p0), "upload (LCP + BWT)");
+            S.uploaded[(size_t)r] = 2 * n_prov;
+        } else {
+            const uint64_t rec = (uint64_t)(o.lcp + o.da + o.pos + 1);
+            if (S.F->gesa) {
+                if (S.mapped) STEP(e2s_upload_gesa(h, &d, S.F->aos.p + p0 * rec), "upload (.gesa)");
+                else STEP(e2s_upload_gesa_fd(h, &d, S.F->aos.fd, p0 * rec), "upload (.gesa)");
+            } else if (S.mapped) STEP(e2s_upload_bcr(h, &d, S.F->bwt.p + p0, S.F->lcp.p + p0 * (uint64_t)o.lcp, S.F->pairsa.p + p0 * (uint64_t)(o.da + o.pos)), "upload (BCR)");
+            else STEP(e2s_upload_bcr_fd(h, &d, S.F->bwt.fd, p0, S.F->lcp.fd, p0 * (uint64_t)o.lcp, S.F->pairsa.fd, p0 * (uint64_t)(o.da + o.pos)), "upload (BCR)");
+            S.uploaded[(size_t)r] = rec * n_prov;
         }
     }
-    pc.mark("rank 0: handle(s), shard uploaded");
-    // the reads, from the ONE index the main thread has been building meanwhile: all of them now -- or, later, those this rank's candidates name
-    if (!S.gather_reads) {
+    pc.mark("rank 0: shard uploaded");
+    // the reads: all of them now -- a lone rank streams the FASTA itself (one pass: read, sent and indexed chunk by chunk); several ranks take
+    // them from the ONE index the main thread has been building meanwhile -- or, later, those this rank's candidates name
+    if (S.stream_reads && !reads_thread.joinable()) {           // (all four columns: the reads live on the shard's own handle, one upload after the other)
+        reads_rc = mine_rc ? mine_rc : e2s_upload_reads_fasta(hr_, o.input.c_str(), &reads_n);
+        reads_done();
+    } else if (S.stream_reads) {
+    } else if (!S.gather_reads) {
         (void)latch_wait(S, S.reads_state);
         if (!mine_rc && S.reads_ok) { STEP(e2s_upload_reads(hr_, S.rd_text, S.rd_bytes, S.rd_start, S.rd_len, S.rd_n, S.rd_max), "upload reads"); S.reads_uploaded[(size_t)r] = S.rd_bytes; S.reads_gathered[(size_t)r] = S.rd_n; }
     }
@@ -285,6 +315,7 @@ void rank_main(Shared& S, int r) {
     if (!mine_rc && !S.slim) { rp.probe_only = 1; S.form[(size_t)r] = e2s_resident_job(h, &rp, job_allgather, nullptr, nullptr) == E2S_OK ? 1 : 0; rp.probe_only = 0; }
     ImageWriter writer;                                         // (the stepwise path starts it early; it is joined before the handles go)
     auto leave = [&]() {
+        if (reads_thread.joinable()) reads_thread.join();
         if (writer.started()) (void)writer.join();
         if (d_send) (void)hipFree(d_send);
         if (d_recv) (void)hipFree(d_recv);
@@ -380,6 +411,7 @@ void rank_main(Shared& S, int r) {
             writer.start(dev, early_img, early_records * 10, S.cl_fd, at, 4);
         }
         pc.mark("rank 0: exchange 1, stitch, statistics, image laid out, its file being written in the background");
+        if (reads_thread.joinable()) { reads_done(); pc.mark("rank 0: waited for the reads (streamed beside the shard)"); }
         if (!mine_rc && !S.crash.load()) {
             e2s_c2s_params prm{};
             prm.nr_reads1 = o.nr_reads1; prm.k_left = o.k_left; prm.k_right = o.k_right; prm.mcov_out = o.mcov_out;
@@ -560,6 +592,11 @@ int main(int argc, char** argv) {
     S.reads_uploaded.assign((size_t)S.nranks, 0); S.reads_gathered.assign((size_t)S.nranks, 0);
     S.gather_reads = S.slim && S.nranks > 1;
     if (const char* e = getenv("E2S_MGPU_GATHER_READS")) S.gather_reads = S.slim && atoi(e) != 0;
+    // E2S_MGPU_PREAD=1: the shard's columns with pread into pinned buffers (the _fd uploads) and, for a lone rank, the FASTA streamed in one pass
+    // beside them, instead of pointers into the files' mappings.  Measured on the pool's boxes (files in the page cache of a tmpfs, whose mappings
+    // fault cheaply): no faster -- the two streams share the link and end later than mapping + index + upload (profiles/round5_c3_end_to_end.txt)
+    S.mapped = !(getenv("E2S_MGPU_PREAD") != nullptr && atoi(getenv("E2S_MGPU_PREAD")) != 0);
+    S.stream_reads = !S.mapped && !S.gather_reads && S.nranks == 1;
     if (const char* e = e2s_env_dev("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
     S.fail_at = e2s_env_dev("E2S_MGPU_FAIL_AT") ? e2s_env_dev("E2S_MGPU_FAIL_AT") : "setup";
     e2s_fasta_index* fix = nullptr;
@@ -571,7 +608,10 @@ int main(int argc, char** argv) {
               << (S.shared_device ? " [rehearsal: all ranks on GPU 0, exchange through host memory]" : (S.use_rccl ? " [RCCL all-gather]" : " [one rank: nothing to exchange]")) << std::endl;
     std::vector<std::thread> th;
     for (int r = 0; r < S.nranks; ++r) th.emplace_back(rank_main, std::ref(S), r);
-    {
+    if (S.stream_reads) {
+        struct stat st{};
+        if (::stat(o.input.c_str(), &st) == 0) S.rd_bytes = (uint64_t)st.st_size;
+    } else {
         // the reads: ONE index of the FASTA for all ranks, built here while the ranks upload their shards (an irregular or unreadable file:
         // no GPU tail, the host tail decides)
         PhaseClock pcm;

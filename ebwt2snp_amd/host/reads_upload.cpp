@@ -13,6 +13,7 @@
 
 #include "../../include/e2s_hip.h"
 #include "fasta_index.hpp"
+#include "../csrc/e2s_env.h"
 
 struct e2s_fasta_index {                                          // the mapped file and its index (e2s_fasta_index_open)
     int fd = -1; void* map = nullptr; size_t n = 0;
@@ -49,9 +50,26 @@ extern "C" int e2s_fasta_index_open(const char* fasta_path, e2s_fasta_index** ou
 }
 extern "C" void e2s_fasta_index_close(e2s_fasta_index* ix) { delete ix; }
 
+extern "C" int e2s_internal_upload_reads_fd(e2s_handle h, int fd, uint64_t file_bytes, uint64_t* n_reads);
 extern "C" int e2s_upload_reads_fasta(e2s_handle h, const char* fasta_path, uint64_t* n_reads) {
     if (!h || !fasta_path) return E2S_ERR_ARG;
     if (n_reads) *n_reads = 0;
+    // a file of the plain shape (header, one line of DNA, ...) streams to the GPU in one pass, indexed on the way (no mapping); E2S_READS_MAPPED=1
+    // keeps to the mapping.  Anything else -- and any file the streamed pass hands back -- is mapped and indexed whole, as before.
+    if (!getenv("E2S_READS_MAPPED")) {
+        const int fd = ::open(fasta_path, O_RDONLY);
+        if (fd < 0) return E2S_ERR_IO;
+        struct stat st{};
+        if (fstat(fd, &st) != 0) { ::close(fd); return E2S_ERR_IO; }
+        if (st.st_size > 0) {
+            uint64_t nr = 0;
+            const int rc = e2s_internal_upload_reads_fd(h, fd, (uint64_t)st.st_size, &nr);
+            ::close(fd);
+            if (rc != 1) { if (rc == E2S_OK && n_reads) *n_reads = nr; return rc; }
+            // (development tier, the tests: a file the streamed pass hands back is an error instead of being mapped -- shows which path ran)
+            if (e2s_env_dev("E2S_READS_STREAM_ONLY")) { e2s_internal_set_error(h, "the streamed pass handed the FASTA back (not of the plain shape)"); return E2S_ERR_STATE; }
+        } else ::close(fd);
+    }
     e2s_fasta_index* f = nullptr;
     const void* text = nullptr; uint64_t tb = 0, nr = 0; const uint64_t* st = nullptr; const uint32_t* ln = nullptr; uint32_t ml = 0;
     int rc = e2s_fasta_index_open(fasta_path, &f, &text, &tb, &st, &ln, &nr, &ml);

@@ -94,6 +94,15 @@ int e2s_upload_lcp(e2s_handle h, const e2s_shard_desc* d, const void* lcp, uint8
  * (e2s_prefilter_arm + e2s_cluster_scan) -- 2 of the 7 bytes per entry.  The document array and the positions are needed only for the
  * clusters the pre-filter lets through (~0.5 % of the entries): the chunked jobs gather those from the host afterwards. */
 int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const void* lcp, const void* bwt);
+/* The same three uploads with the columns in open FILES -- what egsa_stream reads with ifstream (include.hpp:42-81, :126-188): a file
+ * descriptor and the byte offset of the shard's first PROVIDED entry (global_offset - halo_left, times the bytes per entry of that file)
+ * for every pointer of the memory form.  The columns are read with pread into pinned buffers by a few threads (E2S_UPLOAD_THREADS) and
+ * sent from there: a caller that would map the file and pass the pointer pays a page fault per 4 KB of it inside the copy (6 GB of
+ * LCP + BWT out of the page cache: 0.28-0.30 s through a mapping) and again for tearing the mapping down.  E2S_ERR_IO: a file is
+ * shorter than the shard needs.  The descriptors are used with pread only (no seek, not closed). */
+int e2s_upload_bcr_fd(e2s_handle h, const e2s_shard_desc* d, int bwt_fd, uint64_t bwt_off, int lcp_fd, uint64_t lcp_off, int pairsa_fd, uint64_t pairsa_off);
+int e2s_upload_gesa_fd(e2s_handle h, const e2s_shard_desc* d, int fd, uint64_t off);
+int e2s_upload_lcp_bwt_fd(e2s_handle h, const e2s_shard_desc* d, int lcp_fd, uint64_t lcp_off, int bwt_fd, uint64_t bwt_off);
 
 /* ---- ebwt2clust: cluster boundaries ------------------------------------------------------- */
 /* scan_mode: must be 0 (the segmented single-pass scan: every wave a worker over a contiguous range of 4-KiB tiles; the
@@ -264,7 +273,9 @@ int e2s_snp_from_packed(const void* stream, const uint32_t* offsets8, uint64_t n
  * device pointers (the caller keeps ownership; d_start = d_len = NULL: a dense matrix, read r = d_text[r * max_len .. +max_len));
  * e2s_upload_reads_fasta indexes a FASTA file on the host (worker threads) and uploads it -- E2S_ERR_INPUT for a file whose
  * line structure is irregular (a header after a header, no header first, ...), where the reference's line juggling yields
- * text this index cannot express: keep to e2s_snp_from_packed then.
+ * text this index cannot express: keep to e2s_snp_from_packed then.  A file of the plain shape (header, ONE line of DNA, header, ...)
+ * goes up in a single pass: chunks read with pread into pinned buffers, indexed there while their copy is under way; multi-line records
+ * are mapped, joined and indexed whole (E2S_READS_MAPPED=1: always).
  * Make the reads resident BEFORE e2s_find_candidates: the candidates then stay in HBM instead of crossing PCIe.
  * Both calls also keep the text a second time as 2-bit planes (a quarter of its bytes; one pass over it, ~1.7 ms for 3 GB) from which the
  * consensus kernel gathers the left contexts of reads made of "ACGT" alone: attached reads must not change while they are attached. */

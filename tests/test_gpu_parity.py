@@ -1108,9 +1108,12 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
         slim_ok = (not meta.get("gesa")) and tuple(meta["xyz"]) == (1, 4, 1)
         # (gather: "" = the driver's default -- a lone rank uploads every read while its columns go up, several ranks upload each the reads ITS
         #  candidates name, e2s_upload_reads_of_candidates -- "1" / "0" force the one or the other)
-        for ranks, shared, pieces, tiny, full, gather in ((1, False, 0, 0, 1, ""), (2, True, 0, 0, 1, ""), (3, True, 3, 0, 1, ""), (5, True, 0, 0, 1, ""), (1, False, 8, 0, 1, ""),
-                                                          (3, True, 0, 4, 1, ""), (1, False, 0, 4, 1, ""), (1, False, 0, 0, 0, ""), (2, True, 0, 0, 0, ""), (3, True, 0, 0, 0, ""),
-                                                          (5, True, 0, 0, 0, ""), (1, False, 0, 0, 0, "1"), (3, True, 0, 0, 0, "0")):
+        # (pread: "" = the driver's default -- pointers into mappings of the files, the FASTA indexed over its mapping -- "1" = E2S_MGPU_PREAD: the
+        #  shard's columns read from the files with pread into pinned buffers (the _fd uploads), a lone rank streaming the FASTA in one pass beside them)
+        for ranks, shared, pieces, tiny, full, gather, pread in ((1, False, 0, 0, 1, "", ""), (2, True, 0, 0, 1, "", ""), (3, True, 3, 0, 1, "", ""), (5, True, 0, 0, 1, "", ""), (1, False, 8, 0, 1, "", ""),
+                                                                  (3, True, 0, 4, 1, "", ""), (1, False, 0, 4, 1, "", ""), (1, False, 0, 0, 0, "", ""), (2, True, 0, 0, 0, "", ""), (3, True, 0, 0, 0, "", ""),
+                                                                  (5, True, 0, 0, 0, "", ""), (1, False, 0, 0, 0, "1", ""), (3, True, 0, 0, 0, "0", ""),
+                                                                  (1, False, 0, 0, 0, "", "1"), (1, False, 0, 0, 1, "", "1"), (2, True, 0, 0, 0, "", "1")):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
@@ -1122,6 +1125,8 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
                        E2S_MGPU_FORCE_RCCL="1" if force_rccl else "0")
             if gather:
                 env["E2S_MGPU_GATHER_READS"] = gather
+            if pread:
+                env["E2S_MGPU_PREAD"] = pread
             if pieces:
                 env["E2S_JOB_PIECES"] = str(pieces)
             if tiny:
@@ -1675,3 +1680,138 @@ def test_chunked_job_on_goldens(chunk, tmp_path):
         assert rep.n_candidates == meta["n_candidates"] and rep.n_events == meta["n_events"], meta["name"]
         assert hashlib.sha256(bytes(got["cl"])).hexdigest() == meta["clusters_sha256"], meta["name"]
         assert bytes(got["snp"]) == goldens.golden_snp(meta), meta["name"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c1_bcr", "rag_bcr"])
+def test_streamed_fasta_equals_mapped_fasta(tmp_path, name):
+    """e2s_upload_reads_fasta, round 5: a FASTA of the plain shape (header, one line of DNA, ...) goes to the GPU in ONE pass -- chunks read
+    with pread into pinned buffers, sent from there and indexed in the buffer by the thread that read them -- instead of being mapped and
+    indexed whole.  Chunks of 64 / 1000 bytes (lines cross every boundary) and of the default 8 MB, reads of one length and of different
+    lengths: the `.snp` is the golden's, as over the mapping (E2S_READS_MAPPED=1); a file with two-line records is handed back by the
+    streamed pass (an error under E2S_READS_STREAM_ONLY, which is how this test knows which path ran) and indexed over the mapping"""
+    meta = [m for m in goldens.e2e_cases() if m["name"] == name][0]
+    reads, n1, en = goldens.e2e_inputs(meta)
+    p = goldens.write_case_files(meta, reads, en, str(tmp_path))
+    c2s = dict(meta["c2s"])
+    saved = {k: os.environ.get(k) for k in ("E2S_UP_CHUNK", "E2S_READS_MAPPED", "E2S_READS_STREAM_ONLY")}
+    h = capi.Handle(0)
+    try:
+        tools.ebwt2clust(p, handle=h, **meta["e2c"])
+        for chunk, mapped in (("64", False), ("1000", False), ("", False), ("", True)):
+            for k, v in (("E2S_UP_CHUNK", chunk), ("E2S_READS_MAPPED", "1" if mapped else ""), ("E2S_READS_STREAM_ONLY", "" if mapped else "1")):
+                if v:
+                    os.environ[k] = v
+                else:
+                    os.environ.pop(k, None)
+            h.attach_reads(None, None, None, 0, 0)
+            if os.path.exists(IO.snp_out_path(p)):
+                os.remove(IO.snp_out_path(p))
+            r = tools.clust2snp(p, n1, handle=h, **c2s)
+            assert r["n_candidates"] > 5
+            assert open(IO.snp_out_path(p), "rb").read() == goldens.golden_snp(meta), (name, chunk, mapped)
+        # two-line records: not the streamed pass's
+        rows = [bytes(r) for r in reads] if isinstance(reads, list) else [r.tobytes() for r in reads]
+        p2 = str(tmp_path / "two_lines.fasta")
+        with open(p2, "wb") as f:
+            for i, r in enumerate(rows):
+                f.write(b">r%d\n" % i + r[:len(r) // 2] + b"\n" + r[len(r) // 2:] + b"\n")
+        os.environ["E2S_UP_CHUNK"] = "1000"
+        os.environ["E2S_READS_STREAM_ONLY"] = "1"
+        os.environ.pop("E2S_READS_MAPPED", None)
+        with pytest.raises(capi.E2SError):
+            h.upload_reads_fasta(p2)
+        os.environ.pop("E2S_READS_STREAM_ONLY")
+        assert h.upload_reads_fasta(p2) == len(rows)                 # (handed back, then mapped, joined and indexed whole)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["bcr141", "bcr242", "gesa444", "lcp_bwt"])
+def test_uploads_from_files_equal_uploads_from_memory(tmp_path, form):
+    """the _fd uploads (round 5: the shard's columns read from open files with pread into pinned buffers, at a byte offset, by several
+    threads) against the pointer uploads: two shards with halos of one EGSA, chunks of 1000 bytes so that every thread takes many; records,
+    descriptors and candidates (all four columns) must be the same -- for LCP + BWT the records and the pre-filter's flagged list"""
+    reads, n1, e = synth.synth_case(2500, 100, seed=37, tail_lcp0=False)
+    en = synth.egsa_to_numpy(e)
+    n = en["lcp"].size
+    x, y, z = {"bcr141": (1, 4, 1), "bcr242": (2, 4, 2), "gesa444": (4, 4, 4), "lcp_bwt": (1, 4, 1)}[form]
+    p = str(tmp_path / "f.fasta")
+    IO.write_fasta(p, reads.numpy())
+    (IO.write_gesa if form.startswith("gesa") else IO.write_bcr)(p, en["text"], en["suff"], en["lcp"], en["bwt"], x, y, z)
+    saved = os.environ.get("E2S_UP_CHUNK")
+    os.environ["E2S_UP_CHUNK"] = "1000"
+    fds = {}
+    try:
+        for ext in ((".gesa",) if form.startswith("gesa") else (".out", ".out.lcp", ".out.pairSA")):
+            fds[ext] = os.open(p + ext, os.O_RDONLY)
+        files = {ext: np.fromfile(p + ext, dtype=np.uint8) for ext in fds}
+        cut = n // 2 + 17
+        out = {}
+        for how in ("memory", "files"):
+            res = []
+            hs = []
+            for g0, g1 in ((0, cut), (cut, n)):
+                hl, hr = min(g0, 152), min(n - g1, 1)
+                d = capi.Handle.desc(n, offset=g0, n_entries=g1 - g0, halo_left=hl, halo_right=hr, x=x, y=y, z=z)
+                lo, hi = g0 - hl, g1 + hr
+                h = capi.Handle(0)
+                hs.append(h)
+                if form.startswith("gesa"):
+                    rec = x + y + z + 1
+                    if how == "memory":
+                        h.upload_gesa(d, files[".gesa"][lo * rec:hi * rec].copy())
+                    else:
+                        h.upload_gesa_fd(d, fds[".gesa"], lo * rec)
+                elif form == "lcp_bwt":
+                    if how == "memory":
+                        h.upload_lcp_bwt(d, files[".out.lcp"][lo:hi].copy(), files[".out"][lo:hi].copy())
+                    else:
+                        h.upload_lcp_bwt_fd(d, fds[".out.lcp"], lo, fds[".out"], lo)
+                elif how == "memory":
+                    h.upload_bcr(d, files[".out"][lo:hi].copy(), files[".out.lcp"][lo * x:hi * x].copy(), files[".out.pairSA"][lo * (y + z):hi * (y + z)].copy())
+                else:
+                    h.upload_bcr_fd(d, fds[".out"], lo, fds[".out.lcp"], lo * x, fds[".out.pairSA"], lo * (y + z))
+                if form == "lcp_bwt":
+                    h.prefilter_arm(5)
+                h.cluster_scan(16, 2, 0)
+            allb = [h.boundary() for h in hs]
+            for r, h in enumerate(hs):
+                h.stitch(allb, r)
+                res.append(h.fetch_clusters().tobytes())
+                res.append(bytes(allb[r]))
+            for r, h in enumerate(hs):
+                if form != "lcp_bwt":                               # (LCP + BWT end to end: test_multi_gpu_driver_on_goldens, whose default these uploads are)
+                    mcl, _, _ = capi.auto_max_clust_length([q.hist() for q in hs], 5, 0.99)
+                    prm = capi.C2SParams(n1, 31, 30, 5, 20, mcl, 2)
+                    h.find_candidates(prm, r << 40)
+                    buf, nc, cap, stride = h.fetch_candidates(prm)
+                    res.append(repr(capi.parse_candidates(buf, nc, cap, stride)))
+            for h in hs:
+                h.close()
+            out[how] = res
+        assert out["memory"] == out["files"] and len(out["memory"][0]) > 1000
+        # a file shorter than the shard needs: E2S_ERR_IO, not a short upload
+        h = capi.Handle(0)
+        d = capi.Handle.desc(n + 1000, x=x, y=y, z=z)
+        with pytest.raises(capi.E2SError):
+            if form.startswith("gesa"):
+                h.upload_gesa_fd(d, fds[".gesa"], 0)
+            elif form == "lcp_bwt":
+                h.upload_lcp_bwt_fd(d, fds[".out.lcp"], 0, fds[".out"], 0)
+            else:
+                h.upload_bcr_fd(d, fds[".out"], 0, fds[".out.lcp"], 0, fds[".out.pairSA"], 0)
+        h.close()
+    finally:
+        for fd in fds.values():
+            os.close(fd)
+        if saved is None:
+            os.environ.pop("E2S_UP_CHUNK", None)
+        else:
+            os.environ["E2S_UP_CHUNK"] = saved

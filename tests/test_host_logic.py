@@ -45,6 +45,15 @@ def test_swar_stencil_host_build(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_fasta_chunked_index_equals_whole_file_index(tmp_path):
+    """the index built chunk by chunk while the FASTA streams to the GPU against the one over the whole file (sanitizers on)"""
+    exe = str(tmp_path / "fasta_chunks_check")
+    subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "fasta_chunks_check.cpp"),
+                    os.path.join(ROOT, "ebwt2snp_amd", "host", "fasta_index.cpp"), "-lpthread"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def _stitch_all(L, bwt, cuts, k, m, x):
     """records of the whole EGSA assembled from emulated shards + the product's e2s_stitch_plan"""
     n = len(L)

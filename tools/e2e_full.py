@@ -86,7 +86,7 @@ try:
         detail = []
         for i, cmd in enumerate(cmds):
             jp = os.path.join(d, "perf_%s_%d.json" % (tag, i))
-            env = dict(os.environ, E2S_CLI_TIMING="1", E2S_CLI_JSON=jp)
+            env = dict(os.environ, E2S_CLI_TIMING="1", E2S_UPLOAD_PROFILE="1", E2S_CLI_JSON=jp)
             env.update(extra_env or {})
             t1 = time.time()
             rr = subprocess.run(cmd, capture_output=True, text=True, env=env)
@@ -95,7 +95,7 @@ try:
             total += dt
             assert rr.returncode == 0, (cmd, rr.stdout[-600:], rr.stderr[-1200:])
             jr = json.load(open(jp)) if os.path.exists(jp) else {}
-            tl = [l for l in rr.stderr.splitlines() if l.startswith("[timing]")]
+            tl = [l for l in rr.stderr.splitlines() if l.startswith("[timing]") or l.startswith("[upload]")]
             if "epoch_main" in jr:                               # where the time outside the job's own clock goes
                 tl.append("[outside] process start -> main() %.1f ms; main() -> report %.1f ms; report -> process reaped (exit: mappings, GPU memory) %.1f ms"
                           % ((jr["epoch_main"] - t1) * 1e3, (jr["epoch_report"] - jr["epoch_main"]) * 1e3, (t2 - jr["epoch_report"]) * 1e3))
