@@ -2249,7 +2249,15 @@ void e2s_launch_cluster_filter2(FilterArgs a, unsigned long long tile_lo, unsign
     if (tile_hi <= tile_lo) return;
     a.w_tile0 = tile_lo; a.w_tiles = tile_hi - tile_lo;
     const uint64_t cap = (max_workers > 0 && max_workers < resident) ? (uint64_t)max_workers : (uint64_t)resident;
+    // As in the scan (k_scan_seg): several times as many ranges as waves are resident, handed out by the dispatcher as slots come free -- the
+    // SIMD's arbiter serves its oldest wave first, and with one static range per wave the youngest ran on alone for the last fifth of the
+    // kernel.  Ranges of at least 16 tiles (a range's start costs about two), whole rounds, sixteen at most.
+    static const int rounds_env = e2s_env_dev("E2S_FILTER_ROUNDS") ? atoi(e2s_env_dev("E2S_FILTER_ROUNDS")) : 16;
     uint64_t nb = a.w_tiles < cap ? a.w_tiles : cap;
+    if (a.w_tiles > cap && max_workers <= 0) {
+        const uint64_t rounds = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(rounds_env, 1), a.w_tiles / (cap * 16)));
+        nb = cap * rounds;
+    }
     a.w_per = (uint32_t)(a.w_tiles / nb); a.w_rem = (uint32_t)(a.w_tiles % nb); a.w_blocks = (uint32_t)nb;
     hipLaunchKernelGGL(k_cluster_filter2, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, a);
 }
