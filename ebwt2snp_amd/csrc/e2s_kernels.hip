@@ -834,18 +834,25 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         for (u32 q = b; q-- > 0;) { const u64 v = open_of(q); if (v != PASS) return v; }
         return NONE;
     };
+    // the scan's statistics (eight copies): asked for now, by the threads that will add them up after the sums -- a round trip of its own otherwise
+    u64 sr[E2S_STATS_REPL];
+#pragma unroll
+    for (int r = 0; r < E2S_STATS_REPL; ++r) sr[r] = tid <= (u32)E2S_MAX_CLUST_LEN_K ? a.stats[(size_t)r * E2S_STATS_STRIDE + tid] : 0ull;
     // pass 1 over the hot words: the lane's sums, and which of its segments need their record 0 finished here
     u32 unkmask = 0u, ferr = 0u;
     u64 lsum = 0, lksum = 0;
     const u32 nbm1 = nb ? nb - 1u : 0u;
-#pragma unroll 16
-    for (u32 j = 0; j < (u32)JMAX; ++j) {                       // (unconditional loads at clamped addresses: sixteen in flight together)
-        const u32 b = w0 + j * 64u + lane;
-        uint2 hv = a.hot[min(b, nbm1)];
-        if (j >= jn || b >= nb) hv = make_uint2(0u, 0u);
-        if (hv.x >> 31) ferr = E2S_DEVERR_SEGFULL;               // (its segment overflowed)
-        if ((hv.x & 0x7FFFFFFFu) && (hv.y >> 31)) unkmask |= 1u << j;
-        lsum += hv.x & 0x7FFFFFFFu; lksum += hv.y & 0x3FFFFFFFu;
+    for (u32 j0 = 0; j0 < (u32)JMAX && j0 < jn; j0 += 16u) {     // (sixteen groups at a time; a short list -- 4096 segments: four groups -- takes one trip)
+#pragma unroll
+        for (u32 jj = 0; jj < 16u; ++jj) {                      // (unconditional loads at clamped addresses: sixteen in flight together)
+            const u32 j = j0 + jj;
+            const u32 b = w0 + j * 64u + lane;
+            uint2 hv = a.hot[min(b, nbm1)];
+            if (j >= jn || b >= nb) hv = make_uint2(0u, 0u);
+            if (hv.x >> 31) ferr = E2S_DEVERR_SEGFULL;           // (its segment overflowed)
+            if ((hv.x & 0x7FFFFFFFu) && (hv.y >> 31)) unkmask |= 1u << j;
+            lsum += hv.x & 0x7FFFFFFFu; lksum += hv.y & 0x3FFFFFFFu;
+        }
     }
     __syncthreads();                                            // (s_first / s_last / s_err / s_hadj are set)
     // record 0 of a segment whose cluster began before the 192 entries its wave looked at: start and length -- and whether append_entry
@@ -893,18 +900,21 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
         u64 run = 0, krun = 0;
         for (u32 w = 0; w < wave; ++w) { run += s_wcnt[w]; krun += s_wkept[w]; }
         u32 fmin = 0xFFFFFFFFu, fmax = 0u, lastk = 0u;
-#pragma unroll 8
-        for (u32 j = 0; j < (u32)JMAX; ++j) {                   // (a constant trip count: the loop holds wave-level operations)
-            const u32 b = w0 + j * 64u + lane;
-            uint2 hv = a.hot[min(b, nbm1)];                      // (again: out of the caches; unconditional, eight in flight)
-            if (j < jn) {
-                if (b >= nb) hv = make_uint2(0u, 0u);
-                const u32 cnt = hv.x & 0x7FFFFFFFu, kept = (hv.y & 0x3FFFFFFFu) + ((adjmask >> j) & 1u);
-                const u32 inc = wave_incl_scan(cnt), kinc = wave_incl_scan(kept);
-                if (b < nb) { seg_off[b] = run + (inc - cnt); kept_off[b] = krun + (kinc - kept); }
-                run += wave_bcast_last(inc); krun += wave_bcast_last(kinc);
-                if (cnt) { fmin = min(fmin, b); fmax = max(fmax, b); }
-                if (kept) lastk = max(lastk, b + 1u);
+        for (u32 j0 = 0; j0 < (u32)JMAX && j0 < jn; j0 += 8u) {  // (jn is the same in every wave: the trips hold wave-level operations)
+#pragma unroll
+            for (u32 jj = 0; jj < 8u; ++jj) {
+                const u32 j = j0 + jj;
+                const u32 b = w0 + j * 64u + lane;
+                uint2 hv = a.hot[min(b, nbm1)];                  // (again: out of the caches; unconditional, eight in flight)
+                if (j < jn) {
+                    if (b >= nb) hv = make_uint2(0u, 0u);
+                    const u32 cnt = hv.x & 0x7FFFFFFFu, kept = (hv.y & 0x3FFFFFFFu) + ((adjmask >> j) & 1u);
+                    const u32 inc = wave_incl_scan(cnt), kinc = wave_incl_scan(kept);
+                    if (b < nb) { seg_off[b] = run + (inc - cnt); kept_off[b] = krun + (kinc - kept); }
+                    run += wave_bcast_last(inc); krun += wave_bcast_last(kinc);
+                    if (cnt) { fmin = min(fmin, b); fmax = max(fmax, b); }
+                    if (kept) lastk = max(lastk, b + 1u);
+                }
             }
         }
         if (wave == 15u && lane == 0) { seg_off[nb] = run; kept_off[nb] = krun; }      // (the last wave's run ends at or behind the last segment: the totals)
@@ -919,12 +929,12 @@ __global__ __launch_bounds__(1024) void k_seg_fix(SegArgs a, u32* flags, u32* ta
     }
     const u64 carry_end_of_all = tid == 0 ? carry_into(nb) : NONE;  // what a segment behind the last one would inherit (the shard's open cluster)
     // the statistics: the scan's sums plus the records finished above
-    for (u32 i = tid; i <= (u32)E2S_MAX_CLUST_LEN_K; i += 1024u) {
-        u64 v = (u64)s_hadj[i];
+    if (tid <= (u32)E2S_MAX_CLUST_LEN_K) {
+        u64 v = (u64)s_hadj[tid];
 #pragma unroll
-        for (int r = 0; r < E2S_STATS_REPL; ++r) v += a.stats[(size_t)r * E2S_STATS_STRIDE + i];
-        stats_out[i] = v;
-        if (blob) ((e2s_scan_stats*)(blob + sizeof(e2s_boundary)))->hist.freq[i] = v;
+        for (int r = 0; r < E2S_STATS_REPL; ++r) v += sr[r];
+        stats_out[tid] = v;
+        if (blob) ((e2s_scan_stats*)(blob + sizeof(e2s_boundary)))->hist.freq[tid] = v;
     }
     __syncthreads();
     if (tid == 0) {
