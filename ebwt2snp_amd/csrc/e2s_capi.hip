@@ -804,8 +804,9 @@ static void scan_begin(e2s_ctx* h, int k, int min_len) {
 
 // the segmented scan: wave workers over contiguous tile ranges.  seg_cap 0 = the usual estimate; first: the armed pre-filter is taken along.
 // blob != nullptr: k_seg_fix also leaves this rank's share of the job's first all-gather there.
-// prepare_only: every buffer the launch needs is put in place and nothing is enqueued (nor is the handle's state touched) -- the
-// launch proper then cannot fail for want of memory (e2s_resident_job: a rank must not drop out between its enqueue and the exchanges)
+// prepare_only: every buffer the launch needs is put in place and nothing is enqueued -- the launch proper then cannot fail for want of
+// memory (e2s_resident_job: a rank must not drop out between its enqueue and the exchanges).  Buffers may be replaced on the way (segments,
+// descriptors, records): the caller treats whatever an earlier scan left on the handle as gone (e2s_resident_job's probe says so: scan_begin).
 static int seg_scan_launch(e2s_ctx* h, const ScanArgs& a, int min_len, uint64_t seg_cap, bool first, uint8_t* blob, bool copy_mail = true, bool prepare_only = false) {
     int rc;
     const e2s_shard_desc& d = h->d;
@@ -2554,7 +2555,13 @@ extern "C" int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_
     if (!h->ev_wait) CK(hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming));
     void* dev_mail = nullptr;
     CK(hipHostGetDevicePointer(&dev_mail, h->pin_mail, 0));
-    if (p->probe_only) return E2S_OK;
+    if (p->probe_only) {
+        // (the probe may have replaced the segment / record / candidate buffers and their layout words: what an earlier scan or pass left on the
+        //  handle is no longer there to be read -- say so instead of leaving stale results behind)
+        scan_begin(h, p->k, p->min_len);
+        h->variants_valid = false; h->cand_host_valid = false; h->cand_downloaded = false; h->n_cand = 0;
+        return E2S_OK;
+    }
     h->cand_test_done = true;
 
     // ---- ENQUEUE: from here to the second exchange nothing allocates.  Should a HIP call fail all the same, this rank still enqueues the

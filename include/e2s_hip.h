@@ -413,7 +413,8 @@ typedef struct {
     e2s_c2s_options o;                   /* clust2snp's options */
     int32_t want_image;                  /* != 0: the `.clusters` image is laid out on the second stream beside the rest (e2s_clusters_image waits for it) */
     int32_t probe_only;                  /* != 0: only answer whether this form applies (E2S_OK / E2S_ERR_STATE), enqueue nothing -- for drivers whose
-                                            ranks agree on the form before any of them enters an exchange */
+                                            ranks agree on the form before any of them enters an exchange.  The probe puts the step's buffers in place:
+                                            results of an earlier scan / pass on the handle are dropped (as by a new scan) */
 } e2s_resident_params;
 int e2s_resident_job(e2s_handle h, const e2s_resident_params* p, e2s_allgather_fn allgather, void* user, e2s_job_report* rep);
 
