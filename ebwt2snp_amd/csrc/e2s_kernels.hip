@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
     // a lane reads 64 contiguous bytes as 4 x 16 B (neighbouring lanes 64 B apart: the four loads of the wave
     // cover one 4 KiB stretch between them) plus the words just before and after its span
     // interior tile: all of its words, the word before and the word after lie inside the provided range
-    auto load_fast = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
+    auto load_fast_w = [&](u64 tile, u32* W) __attribute__((always_inline)) {
         const int64_t tl = (int64_t)tile * TILE;
 #ifdef E2S_ABL_NOLOAD                                            // diagnostic build: no memory reads, synthetic words (results are wrong)
         {
@@ -277,14 +277,25 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         for (int q = 0; q < NR / 4; ++q) {
             const uint4 v = *(const uint4*)(p + o + 16 * q);
             W[1 + 4 * q + 0] = v.x; W[1 + 4 * q + 1] = v.y; W[1 + 4 * q + 2] = v.z; W[1 + 4 * q + 3] = v.w;
-            if constexpr (FUSED) {
-                const uint4 w = *(const uint4*)(f.bwt + tl + o + 16 * q);
-                B[4 * q + 0] = w.x; B[4 * q + 1] = w.y; B[4 * q + 2] = w.z; B[4 * q + 3] = w.w;
-            }
         }
         W[0] = *(const u32*)(p + o - 4);
         W[NR + 1] = *(const u32*)(p + o + 4 * NR);
     };
+    auto load_fast_b = [&](u64 tile, u32* B) __attribute__((always_inline)) {
+        if constexpr (FUSED) {
+#ifdef E2S_ABL_NOLOAD
+            return;
+#endif
+            const int64_t tl = (int64_t)tile * TILE;
+            const u32 o = lane * (u32)(4 * NR);
+#pragma unroll
+            for (int q = 0; q < NR / 4; ++q) {
+                const uint4 w = *(const uint4*)(f.bwt + tl + o + 16 * q);
+                B[4 * q + 0] = w.x; B[4 * q + 1] = w.y; B[4 * q + 2] = w.z; B[4 * q + 3] = w.w;
+            }
+        }
+    };
+    auto load_fast = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) { load_fast_w(tile, W); load_fast_b(tile, B); };
     // the first tile of the shard and the tiles around its end: byte by byte, zero outside the provided range
     auto load_slow = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
@@ -349,9 +360,11 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         const bool em1 = gm1 && ((lm2 > lm1 && lm1 <= l0) || !g0);
         return (u32)__builtin_amdgcn_readfirstlane((int)((gm1 ? 1u : 0u) | (em1 ? 2u : 0u)));
     };
-    // Two register sets that swap roles from tile to tile (the loop body is instantiated twice): W = the tile
-    // being processed, Wn = the next one, in flight meanwhile.
-    u32 WA[NW], WB[NW], BA[FUSED ? NR : 1], BB[FUSED ? NR : 1];
+    // W / B: the words of the tile being worked on; the next tile's are asked for into the same registers (see below).
+    // ONE set of registers for a tile's words: the NEXT tile's are asked for into the same registers as soon as the planes are built from them --
+    // a fifth of the way into the tile -- and waited for before the record stores.  (Rounds 2-5 kept two sets and asked a whole tile ahead: 34
+    // registers and half of the kernel's code for a distance the other waves of the SIMD cover anyway; without them a FIFTH wave fits.)
+    u32 WA[NW], BA[FUSED ? NR : 1];
     ClassConsts kc = class_consts();                            // (FUSED) held in VGPRs: see e2s_swar.h
     // (The six class constants pinned into VGPRs: v_bitop3 / v_perm issue faster with register operands -- round 2.  Round 4 made room
     //  for them AND a fourth wave per SIMD: 138 -> 123 VGPRs (the statistics' tally on two 32-bit counters, the range's first end and its
@@ -359,10 +372,11 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
 #ifndef E2S_KC_UNPINNED
     if constexpr (FUSED) asm volatile("" : "+v"(kc.m07), "+v"(kc.ehi), "+v"(kc.elo), "+v"(kc.c20), "+v"(kc.one), "+v"(kc.h));
 #endif
-    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
+    auto body = [&](const u64 tile, u32* W, u32* B, auto prefetch) __attribute__((always_inline)) {
         constexpr bool PF = decltype(prefetch)::value;
-        if (PF) load_fast(tile + 1, Wn, Bn);                    // in flight while this tile is processed
+        u32* const Wn = W; u32* const Bn = B;                   // (the next tile's words: the same registers)
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
+        const u32 w1_first = W[1];                              // (the range's first entry, for `in0` below: W is reloaded before that)
         // ---- start / end planes of the span ----
         u64 S, E, GE;                                           // bit e: a cluster starts / ends at entry e of the span
         {
@@ -389,12 +403,14 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
                 GE |= 2ull;                                     // entry 1 belongs to the cluster opened at 0 whatever L[1] is (FUSED: "in a cluster")
             }
         }
+        if constexpr (!FUSED) { if (PF) load_fast_w(tile + 1, Wn); }   // the planes are built: the next tile's words into the same registers
         // ---- pre-filter, part 1: class planes and the lane-to-lane carry of packed base counts (k_cluster_filter2) ----
         const u64 Sa = S, Ea = E;                               // before the window mask: the carries follow every cluster
         u64 C = 0, G = 0, T = 0, F = 0; u32 cin = 0;
         if constexpr (FUSED) {
             u64 c0, c1;                                             // code planes: c0 = C | G, c1 = G | T
             span_bwt_code_planes<NR>(B, kc, c0, c1);
+            if (PF) { load_fast_w(tile + 1, Wn); load_fast_b(tile + 1, Bn); }   // (both sets of planes are built: the registers the class planes' temporaries had are free again)
             C = c0 & ~c1; G = c0 & c1; T = ~c0 & c1;
             const u32 ctop = (u32)(c0 >> 63) | ((u32)(c1 >> 63) << 1);
             const u32 cprev = wave_shr1(ctop, ccarry);
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         }
         if (tile == t0) {
             // does the range begin inside a cluster?  open(first) && !start(first)   (lane 0 holds the first entry)
-            const bool ge0 = a.hge != 0 && (W[1] & LM) >= a.k_u32;
+            const bool ge0 = a.hge != 0 && (w1_first & LM) >= a.k_u32;
             in0 = (u32)__builtin_amdgcn_readfirstlane((ge0 && !(S & 1ull)) ? 1 : 0);
         }
         const u32 cnt = (u32)__popcll(E);
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
                 if (sm2) pf_open1 = max(pf_open1, (u32)__builtin_amdgcn_readlane((int)(base_off + (u32)(64 - __clzll(Sa | 1ull))), 63 - __clzll(sm2)));
             }
         }
-        // Wait for the prefetched words NOW, before the record stores: vmcnt counts loads and stores together and in
+        // Wait for the next tile's words NOW, before the record stores: vmcnt counts loads and stores together and in
         // order, so waiting for the next tile's loads after a data-dependent number of stores would mean waiting for
         // every store to land (vmcnt(0)) once per tile.  The empty asm "uses and redefines" the registers: the compiler
         // places the wait here and the stores drain under the next tile's stencil.  No instruction is emitted.
@@ -618,7 +634,7 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
             }
         }
     };
-    // The hot loop runs over interior tiles only, two per trip (static register roles), and contains nothing but the
+    // The hot loop runs over interior tiles only and contains nothing but the
     // fast loader: with the byte-wise loader of the edge tiles inlined next to it the compiler's wait-count
     // analysis gave up at the join and waited for the prefetch it had just issued (vmcnt(0)) on every other tile.
     {
@@ -627,7 +643,7 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         // interior tiles are [1, tfe): tile 0 has no word before it, the last ones no word after
         const u64 tfe = n_prov >= (int64_t)(TILE + EPW) ? (u64)((n_prov - EPW) / TILE) : 0ull;
         const u64 tf = min(t1, tfe);
-        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, P0); } };
+        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, P0); } };
         bool have_cb = false;
         // what the range inherits: the scan's GE / end of the entry before it, and (FUSED) the pre-filter's carries
         auto start_carry = [&]() __attribute__((always_inline)) {
@@ -654,9 +670,8 @@ __global__ __launch_bounds__(64, E2S_SCAN_WAVES) void k_scan_seg(SegArgs a, Filt
         if (tile < tf) {
             load_fast(tile, WA, BA);
             if (!have_cb) { start_carry(); have_cb = true; }
-            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, P1); body(tile + 1, WB, BB, WA, BA, P1); tile += 2; }
-            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, P1); body(tile + 1, WB, BB, WA, BA, P0); tile += 2; }
-            else { body(tile, WA, BA, WB, BB, P0); tile += 1; }
+            for (; tile + 1 < tf; ++tile) body(tile, WA, BA, P1);
+            body(tile, WA, BA, P0); tile += 1;
         }
         if (!have_cb) start_carry();
         slow_run(t1);
