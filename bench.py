@@ -545,7 +545,7 @@ def pmc_traffic(workload, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE; collected by
     tools/profile.sh in separate --pmc runs of this same command, summarised by tools/profile_summary.py).  None when no
     committed profile covers the workload -- counters cannot be read from inside the timed run."""
-    for rnd in ("round4", "round3", "round2", "round1"):
+    for rnd in ("round5", "round4", "round3", "round2", "round1"):
         for name in ("%s_%s_pmc_traffic.json" % (rnd, workload), "%s_fused_%s_pmc_traffic.json" % (rnd, workload),
                      "%s_fused_pmc_traffic.json" % rnd):
             try:
