@@ -1665,21 +1665,27 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
     const int64_t e_lo = (int64_t)a.own_lo, e_hi = (int64_t)a.end_hi;
     const u64 g_org = a.prov_lo + torg * TILE;                  // SA position of offset 0
 
-    auto load_fast = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
-        const int64_t tl = (int64_t)tile * TILE;
-        const uint8_t* p = base + tl;
-        const uint8_t* pb = bwtb + tl;
+    auto load_fast_w = [&](u64 tile, u32* W) __attribute__((always_inline)) {
+        const uint8_t* p = base + (int64_t)tile * TILE;
         const u32 o = lane * 64u;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const uint4 v = *(const uint4*)(p + o + 16 * qd);
             W[1 + 4 * qd + 0] = v.x; W[1 + 4 * qd + 1] = v.y; W[1 + 4 * qd + 2] = v.z; W[1 + 4 * qd + 3] = v.w;
-            const uint4 w = *(const uint4*)(pb + o + 16 * qd);
-            B[4 * qd + 0] = w.x; B[4 * qd + 1] = w.y; B[4 * qd + 2] = w.z; B[4 * qd + 3] = w.w;
         }
         W[0] = *(const u32*)(p + o - 4);
         W[NR + 1] = *(const u32*)(p + o + 64);
     };
+    auto load_fast_b = [&](u64 tile, u32* B) __attribute__((always_inline)) {
+        const uint8_t* pb = bwtb + (int64_t)tile * TILE;
+        const u32 o = lane * 64u;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const uint4 w = *(const uint4*)(pb + o + 16 * qd);
+            B[4 * qd + 0] = w.x; B[4 * qd + 1] = w.y; B[4 * qd + 2] = w.z; B[4 * qd + 3] = w.w;
+        }
+    };
+    auto load_fast = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) { load_fast_w(tile, W); load_fast_b(tile, B); };
     auto load_slow = [&](u64 tile, u32* W, u32* B) __attribute__((always_inline)) {
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
 #pragma unroll
@@ -1723,12 +1729,12 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
         qn = 0;
     };
 
-    u32 WA[NW], WB[NW], BA[NR], BB[NR];
+    u32 WA[NW], BA[NR];                                         // ONE register set: the next tile's words are asked for into it once the planes are built (k_scan_seg)
     ClassConsts kc = class_consts();                            // held in VGPRs: see e2s_swar.h
     asm volatile("" : "+v"(kc.m07), "+v"(kc.ehi), "+v"(kc.elo), "+v"(kc.c20), "+v"(kc.one), "+v"(kc.h));
-    auto body = [&](const u64 tile, u32* W, u32* B, u32* Wn, u32* Bn, auto prefetch) __attribute__((always_inline)) {
+    auto body = [&](const u64 tile, u32* W, u32* B, auto prefetch) __attribute__((always_inline)) {
         constexpr bool PF = decltype(prefetch)::value;
-        if (PF) load_fast(tile + 1, Wn, Bn);
+        u32* const Wn = W; u32* const Bn = B;
         const int64_t i0 = (int64_t)tile * TILE + (int64_t)lane * ES;
         u64 S, E, GE;
         {
@@ -1754,6 +1760,7 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
         }
         u64 c0, c1;                                             // code planes: c0 = C | G, c1 = G | T (e2s_swar.h)
         span_bwt_code_planes<NR>(B, kc, c0, c1);
+        if (PF) { load_fast_w(tile + 1, Wn); load_fast_b(tile + 1, Bn); }
         const u64 C = c0 & ~c1, G = c0 & c1, T = ~c0 & c1;
         // (LCP >= k_right somewhere in the cluster, clust2snp.cpp:396, is left to K2b's exact test: dropping the plane here lets
         // through only the rare cluster whose LCPs all lie in [k, k_right) and saves 7 % of this kernel's instructions)
@@ -1848,15 +1855,14 @@ __global__ __launch_bounds__(256) void k_cluster_filter2(FilterArgs a) {
         };
         tile = t0;
         bool have_cb = false;
-        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, WB, BB, N); } };
+        auto slow_run = [&](u64 upto) __attribute__((always_inline)) { for (; tile < upto; ++tile) { load_slow(tile, WA, BA); body(tile, WA, BA, N); } };
         if (!have_cb && tile < min(t1, (u64)1)) { start_carry(); have_cb = true; }
         slow_run(min(t1, (u64)1));
         if (tile < tf) {
             load_fast(tile, WA, BA);
             if (!have_cb) { start_carry(); have_cb = true; }
-            while (tile + 3 <= tf) { body(tile, WA, BA, WB, BB, Y); body(tile + 1, WB, BB, WA, BA, Y); tile += 2; }
-            if (tile + 2 == tf) { body(tile, WA, BA, WB, BB, Y); body(tile + 1, WB, BB, WA, BA, N); tile += 2; }
-            else { body(tile, WA, BA, WB, BB, N); tile += 1; }
+            for (; tile + 1 < tf; ++tile) body(tile, WA, BA, Y);
+            body(tile, WA, BA, N); tile += 1;
         }
         if (!have_cb) start_carry();
         slow_run(t1);
