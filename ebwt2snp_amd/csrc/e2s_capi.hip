@@ -387,7 +387,13 @@ static int narrow_lcp(e2s_ctx* h) {
 #include <thread>
 #include <atomic>
 #include <memory>
+#include <functional>
+static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t bytes, size_t read_ahead,
+                          const std::function<void(unsigned, uint64_t, const uint8_t*, uint64_t, size_t, uint64_t, uint64_t)>& per_chunk, const uint8_t* mem);
 static int upload_sliced(e2s_ctx* h, void* dst, const void* src, size_t bytes) {
+    // E2S_UPLOAD_PINNED=1 (development tier): large copies through the handle's own pinned buffers (upload_from_fd with a memory source)
+    static const bool staged = e2s_env_dev("E2S_UPLOAD_PINNED") && atoi(e2s_env_dev("E2S_UPLOAD_PINNED")) != 0;
+    if (staged && bytes >= ((size_t)64 << 20)) return upload_from_fd(h, dst, -1, 0, bytes, 0, nullptr, (const uint8_t*)src);
     static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 8;      // (6 GB out of the page cache: 4 threads 0.34 s, 8 threads 0.28-0.30: profiles/round5_c3_end_to_end.txt)
     const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(T_env, 1), bytes >> 24));     // (slices of at least 16 MB)
     if (T == 1) { CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return E2S_OK; }
@@ -425,8 +431,10 @@ static size_t up_chunk() {                                     // 8 MB; E2S_UP_C
     const long long x = e ? atoll(e) : 0;
     return x >= 16 ? (size_t)x : (size_t)(8u << 20);
 }
-static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t bytes, size_t read_ahead = 0,
-                          const std::function<void(unsigned, uint64_t, const uint8_t*, uint64_t, size_t, uint64_t, uint64_t)>& per_chunk = nullptr) {
+// mem != nullptr: the bytes come from (pageable) memory instead of a file -- copied into the pinned buffers by the threads and sent from there
+// (upload_sliced: the runtime's own staging of a copy out of pageable memory runs on the calling thread, one buffer at a time)
+static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t bytes, size_t read_ahead,
+                          const std::function<void(unsigned, uint64_t, const uint8_t*, uint64_t, size_t, uint64_t, uint64_t)>& per_chunk, const uint8_t* mem) {
     if (!bytes) return E2S_OK;
     static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 8;
     const size_t UP_CHUNK = up_chunk();
@@ -480,7 +488,8 @@ static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t 
             double t1 = now(); P.wait += t1 - t0;
             const uint64_t a = off + c * UP_CHUNK, b = std::min<uint64_t>(a + UP_CHUNK, end);
             const uint64_t lo = (per_chunk && a > off) ? a - 1 : a, hi = std::min<uint64_t>(b + read_ahead, end);
-            for (uint64_t at = lo; at < hi;) {
+            if (mem) memcpy(buf, mem + (lo - off), (size_t)(hi - lo));
+            else for (uint64_t at = lo; at < hi;) {
                 const ssize_t r = pread(fd, buf + (at - lo), (size_t)(hi - at), (off_t)at);
                 if (r <= 0) { bad = 2; break; }
                 at += (uint64_t)r;
@@ -505,8 +514,8 @@ static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t 
     if (prof) {
         Prof m;
         for (const Prof& P : pf) { m.alloc = std::max(m.alloc, P.alloc); m.rd += P.rd / T; m.wait += P.wait / T; m.enq += P.enq / T; m.cb += P.cb / T; m.fin += P.fin / T; }
-        fprintf(stderr, "[upload] %.2f GB from a file, %d threads, chunks of %zu KB: %.1f ms = %.1f GB/s; per thread: thread start (max) %.1f, pread %.1f, waiting for a buffer %.1f, "
-                        "enqueue %.1f, index %.1f, last copies %.1f ms\n", (double)bytes / 1e9, T, UP_CHUNK >> 10, now() - t_begin, (double)bytes / 1e6 / (now() - t_begin), m.alloc, m.rd, m.wait, m.enq, m.cb, m.fin);
+        fprintf(stderr, "[upload] %.2f GB from %s, %d threads, chunks of %zu KB: %.1f ms = %.1f GB/s; per thread: thread start (max) %.1f, pread %.1f, waiting for a buffer %.1f, "
+                        "enqueue %.1f, index %.1f, last copies %.1f ms\n", (double)bytes / 1e9, mem ? "memory through pinned buffers" : "a file", T, UP_CHUNK >> 10, now() - t_begin, (double)bytes / 1e6 / (now() - t_begin), m.alloc, m.rd, m.wait, m.enq, m.cb, m.fin);
     }
     if (bad.load() == 2) return fail(h, E2S_ERR_IO, "reading a column from its file failed (short file or read error)");
     if (bad.load()) return fail(h, E2S_ERR_HIP, "streamed host-to-device copy failed");
@@ -515,7 +524,7 @@ static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t 
 // a column of a shard: in memory, or in an open file at an offset
 struct ColSrc { const void* p; int fd; uint64_t off; };
 static int upload_col(e2s_ctx* h, void* dst, const ColSrc& s, size_t bytes) {
-    return s.p ? upload_sliced(h, dst, s.p, bytes) : upload_from_fd(h, dst, s.fd, s.off, bytes);
+    return s.p ? upload_sliced(h, dst, s.p, bytes) : upload_from_fd(h, dst, s.fd, s.off, bytes, 0, nullptr, nullptr);
 }
 
 static int upload_bcr_impl(e2s_ctx* h, const e2s_shard_desc* d, const ColSrc& bwt, const ColSrc& lcp, const ColSrc& pairsa) {
@@ -2008,7 +2017,8 @@ extern "C" int e2s_internal_upload_reads_fd(e2s_handle h, int fd, uint64_t file_
     constexpr size_t READ_AHEAD = 64u << 10;                    // (a line that starts in a chunk and runs further than this beyond it: not this path's)
     std::vector<FastaChunk> chunks((size_t)((file_bytes + up_chunk() - 1) / up_chunk()));
     int rc = upload_from_fd(h, h->d_text, fd, 0, file_bytes, READ_AHEAD,
-                            [&](unsigned, uint64_t c, const uint8_t* buf, uint64_t lo, size_t n, uint64_t a, uint64_t b) { e2s_fasta_scan_chunk(buf, lo, n, a, b, file_bytes, chunks[(size_t)c]); });
+                            [&](unsigned, uint64_t c, const uint8_t* buf, uint64_t lo, size_t n, uint64_t a, uint64_t b) { e2s_fasta_scan_chunk(buf, lo, n, a, b, file_bytes, chunks[(size_t)c]); },
+                            nullptr);
     if (rc) { release_reads(h); return rc; }
     const double t2 = now();
     FastaJoined ix;

@@ -83,7 +83,7 @@ struct Shared {
     // the reads, indexed once
     const void* rd_text = nullptr; uint64_t rd_bytes = 0, rd_n = 0; const uint64_t* rd_start = nullptr; const uint32_t* rd_len = nullptr; uint32_t rd_max = 0;
     bool reads_ok = false;
-    bool mapped = true, stream_reads = false;   // uploads from the mappings, or (E2S_MGPU_PREAD=1) with pread into pinned buffers, a lone rank streaming the FASTA itself
+    bool mapped = true, stream_reads = false;   // the shard from the files' mappings, or with pread (E2S_MGPU_PREAD=1); a lone rank streaming the FASTA itself (E2S_MGPU_STREAM_READS=1)
     int cl_fd = -1, snp_fd = -1; std::string snp_path;
     std::atomic<int> rc{0};
     std::atomic<int> crash{0};                // 136 / 139: the reference's clust2snp dies on this input (SIGFPE / SIGSEGV) -- after ebwt2clust wrote its file
@@ -592,11 +592,13 @@ int main(int argc, char** argv) {
     S.reads_uploaded.assign((size_t)S.nranks, 0); S.reads_gathered.assign((size_t)S.nranks, 0);
     S.gather_reads = S.slim && S.nranks > 1;
     if (const char* e = getenv("E2S_MGPU_GATHER_READS")) S.gather_reads = S.slim && atoi(e) != 0;
-    // E2S_MGPU_PREAD=1: the shard's columns with pread into pinned buffers (the _fd uploads) and, for a lone rank, the FASTA streamed in one pass
-    // beside them, instead of pointers into the files' mappings.  Measured on the pool's boxes (files in the page cache of a tmpfs, whose mappings
-    // fault cheaply): no faster -- the two streams share the link and end later than mapping + index + upload (profiles/round5_c3_end_to_end.txt)
+    // Where the uploads read from.  The shard's columns: pointers into the files' mappings; E2S_MGPU_PREAD=1: the files themselves, with pread into
+    // pinned buffers (the _fd uploads: 6 GB of LCP + BWT in 0.16-0.21 s against 0.21-0.26).  The reads: ONE index of the FASTA built over its mapping
+    // by the main thread beside the shards' uploads, then uploaded; E2S_MGPU_STREAM_READS=1 (a lone rank): streamed in one pass by a thread of the
+    // rank's beside its shard instead.  Measured on the whole c3 files, box by box (profiles/round5_c3_uploads_from_files.txt): the three forms end
+    // within 5 % of each other -- what the shard's upload gains the FASTA index, now the longer arm, gives back; the mappings stay the default.
     S.mapped = !(getenv("E2S_MGPU_PREAD") != nullptr && atoi(getenv("E2S_MGPU_PREAD")) != 0);
-    S.stream_reads = !S.mapped && !S.gather_reads && S.nranks == 1;
+    S.stream_reads = getenv("E2S_MGPU_STREAM_READS") != nullptr && atoi(getenv("E2S_MGPU_STREAM_READS")) != 0 && !S.gather_reads && S.nranks == 1;
     if (const char* e = e2s_env_dev("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
     S.fail_at = e2s_env_dev("E2S_MGPU_FAIL_AT") ? e2s_env_dev("E2S_MGPU_FAIL_AT") : "setup";
     e2s_fasta_index* fix = nullptr;

@@ -1108,12 +1108,13 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
         slim_ok = (not meta.get("gesa")) and tuple(meta["xyz"]) == (1, 4, 1)
         # (gather: "" = the driver's default -- a lone rank uploads every read while its columns go up, several ranks upload each the reads ITS
         #  candidates name, e2s_upload_reads_of_candidates -- "1" / "0" force the one or the other)
-        # (pread: "" = the driver's default -- pointers into mappings of the files, the FASTA indexed over its mapping -- "1" = E2S_MGPU_PREAD: the
-        #  shard's columns read from the files with pread into pinned buffers (the _fd uploads), a lone rank streaming the FASTA in one pass beside them)
+        # (pread: "" = the driver's default -- pointers into mappings of the files, the FASTA indexed over its mapping -- "p" = E2S_MGPU_PREAD: the shard's
+        #  columns read from the files with pread into pinned buffers (the _fd uploads); "s" = E2S_MGPU_STREAM_READS: a lone rank streams the FASTA in one
+        #  pass beside its shard; "ps": both)
         for ranks, shared, pieces, tiny, full, gather, pread in ((1, False, 0, 0, 1, "", ""), (2, True, 0, 0, 1, "", ""), (3, True, 3, 0, 1, "", ""), (5, True, 0, 0, 1, "", ""), (1, False, 8, 0, 1, "", ""),
                                                                   (3, True, 0, 4, 1, "", ""), (1, False, 0, 4, 1, "", ""), (1, False, 0, 0, 0, "", ""), (2, True, 0, 0, 0, "", ""), (3, True, 0, 0, 0, "", ""),
                                                                   (5, True, 0, 0, 0, "", ""), (1, False, 0, 0, 0, "1", ""), (3, True, 0, 0, 0, "0", ""),
-                                                                  (1, False, 0, 0, 0, "", "1"), (1, False, 0, 0, 1, "", "1"), (2, True, 0, 0, 0, "", "1")):
+                                                                  (1, False, 0, 0, 0, "", "p"), (1, False, 0, 0, 1, "", "p"), (2, True, 0, 0, 0, "", "p"), (1, False, 0, 0, 0, "", "s"), (1, False, 0, 0, 1, "", "ps")):
             for f in (p + ".clusters", IO.snp_out_path(p)):
                 if os.path.exists(f):
                     os.remove(f)
@@ -1125,8 +1126,10 @@ def test_multi_gpu_driver_on_goldens(tmp_path):
                        E2S_MGPU_FORCE_RCCL="1" if force_rccl else "0")
             if gather:
                 env["E2S_MGPU_GATHER_READS"] = gather
-            if pread:
-                env["E2S_MGPU_PREAD"] = pread
+            if "p" in pread:
+                env["E2S_MGPU_PREAD"] = "1"
+            if "s" in pread:
+                env["E2S_MGPU_STREAM_READS"] = "1"
             if pieces:
                 env["E2S_JOB_PIECES"] = str(pieces)
             if tiny:
