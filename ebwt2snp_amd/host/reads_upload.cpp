@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <thread>
+#include <vector>
 
 #include "../../include/e2s_hip.h"
 #include "fasta_index.hpp"
@@ -18,8 +20,30 @@
 struct e2s_fasta_index {                                          // the mapped file and its index (e2s_fasta_index_open)
     int fd = -1; void* map = nullptr; size_t n = 0;
     FastaIndex ix;
+    FastaJoined jx;                                               // (a file of the plain shape: indexed chunk by chunk in ONE pass over the mapping)
     ~e2s_fasta_index() { if (map) munmap(map, n); if (fd >= 0) ::close(fd); }
 };
+// One pass over the mapping for a file of the plain shape (header, one line of DNA, ...): chunks of 8 MB handed to the threads as they come
+// free, every chunk scanned once (e2s_fasta_scan_chunk) -- the two-pass index (count, then fill) touched every page twice.  false: another shape.
+static bool index_plain_one_pass(const uint8_t* p, size_t n, unsigned T, FastaJoined& out) {
+    const size_t CH = (size_t)8 << 20;
+    std::vector<FastaChunk> chunks((n + CH - 1) / CH);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> plain{true};
+    auto work = [&]() {
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= chunks.size() || !plain.load(std::memory_order_relaxed)) return;
+            e2s_fasta_scan_chunk(p, 0, n, (uint64_t)c * CH, std::min<uint64_t>((uint64_t)(c + 1) * CH, n), n, chunks[c]);
+            if (!chunks[c].plain) plain.store(false, std::memory_order_relaxed);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    return plain.load() && e2s_fasta_join_chunks(chunks, out);
+}
 extern "C" void e2s_internal_set_error(e2s_handle h, const char* msg);
 
 extern "C" int e2s_fasta_index_open(const char* fasta_path, e2s_fasta_index** out, const void** text, uint64_t* text_bytes, const uint64_t** start,
@@ -38,6 +62,16 @@ extern "C" int e2s_fasta_index_open(const char* fasta_path, e2s_fasta_index** ou
     madvise(f->map, f->n, MADV_SEQUENTIAL);
     const int env = getenv("E2S_TAIL_THREADS") ? atoi(getenv("E2S_TAIL_THREADS")) : 0;
     const unsigned T = env > 0 ? (unsigned)env : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (((const uint8_t*)f->map)[0] == '>' && !getenv("E2S_FASTA_TWO_PASS") && index_plain_one_pass((const uint8_t*)f->map, f->n, T, f->jx)) {
+        if (text) *text = f->map;
+        if (text_bytes) *text_bytes = f->n;
+        if (start) *start = f->jx.start.get();
+        if (len) *len = f->jx.len.get();
+        if (n_reads) *n_reads = f->jx.n;
+        if (max_len) *max_len = f->jx.max_len;
+        *out = f;
+        return E2S_OK;
+    }
     if (!e2s_index_fasta((const uint8_t*)f->map, f->n, T, f->ix)) { delete f; return E2S_ERR_INPUT; }      // irregular line structure: the host tail decides
     if (text) *text = f->ix.text;
     if (text_bytes) *text_bytes = f->ix.text_bytes;

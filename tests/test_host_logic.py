@@ -54,6 +54,68 @@ def test_fasta_chunked_index_equals_whole_file_index(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_fasta_index_open_one_pass_equals_two_pass(tmp_path):
+    """e2s_fasta_index_open (host only: no GPU): a file of the plain shape is indexed in ONE pass over its mapping, chunk by chunk; every other shape --
+    and every file under E2S_FASTA_TWO_PASS=1 -- by the two-pass index.  Same reads either way; a multi-line file joins its lines; an irregular one is
+    E2S_ERR_INPUT"""
+    import ctypes as C
+    L = C.CDLL(capi.LIB_PATH)
+    L.e2s_fasta_index_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.e2s_fasta_index_close.argtypes = [C.c_void_p]
+
+    def index(path):
+        ix, text, st, ln = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        tb, nr, ml = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        rc = L.e2s_fasta_index_open(path.encode(), C.byref(ix), C.byref(text), C.byref(tb), C.byref(st), C.byref(ln), C.byref(nr), C.byref(ml))
+        if rc:
+            return rc, None
+        n = nr.value
+        starts = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint64)), shape=(n,)).copy()
+        lens = np.ctypeslib.as_array(C.cast(ln, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+        buf = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(tb.value,))
+        reads = [buf[int(a):int(a) + int(b)].tobytes() for a, b in zip(starts, lens)]
+        L.e2s_fasta_index_close(ix)
+        return 0, (reads, ml.value)
+
+    rnd = np.random.RandomState(5)
+    saved = os.environ.get("E2S_FASTA_TWO_PASS")
+    try:
+        for case in range(12):
+            nrec = int(rnd.randint(1, 4000))
+            same = case % 2 == 0
+            seqs = ["".join("ACGTN"[i] for i in rnd.randint(0, 5, 50 if same else rnd.randint(0, 120))) for _ in range(nrec)]
+            multi = case % 4 == 3
+            p = str(tmp_path / ("f%d.fasta" % case))
+            with open(p, "w") as f:
+                for i, q in enumerate(seqs):
+                    f.write(">read_%d some text\n" % i)
+                    if multi and len(q) > 3 and i % 7 == 0:
+                        f.write(q[:len(q) // 2] + "\n" + q[len(q) // 2:] + "\n")
+                    else:
+                        f.write(q + ("\n" if (i + 1 < nrec or case % 3) else ""))
+            got = {}
+            for mode in ("one", "two"):
+                if mode == "two":
+                    os.environ["E2S_FASTA_TWO_PASS"] = "1"
+                else:
+                    os.environ.pop("E2S_FASTA_TWO_PASS", None)
+                rc, res = index(p)
+                assert rc == 0, (case, mode, rc)
+                got[mode] = res
+            want = [q.encode() for q in seqs]
+            assert got["one"][0] == want and got["two"][0] == want and got["one"][1] == got["two"][1] == max(len(q) for q in seqs), case
+        p = str(tmp_path / "bad.fasta")
+        open(p, "w").write(">a\n>b\nACGT\n")
+        os.environ.pop("E2S_FASTA_TWO_PASS", None)
+        assert index(p)[0] == 6                                      # E2S_ERR_INPUT
+    finally:
+        if saved is None:
+            os.environ.pop("E2S_FASTA_TWO_PASS", None)
+        else:
+            os.environ["E2S_FASTA_TWO_PASS"] = saved
+
+
 def _stitch_all(L, bwt, cuts, k, m, x):
     """records of the whole EGSA assembled from emulated shards + the product's e2s_stitch_plan"""
     n = len(L)
