@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <fstream>
 #include <iostream>
+#include <fcntl.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 #include "e2s_hip.h"      // (the snippets' own #include line, at file scope where the reference would have it)
@@ -115,3 +117,17 @@ e2s_call_variants(h, &t, first_id, &nv, &ne, &snp_bytes);        // as with all 
     e2s_fasta_index_close(fix);
     return (int)(n_named + up_bytes + nv + ne + snp_bytes);
 }
+
+int snippet_upload_from_files(e2s_handle h, const std::string& input, uint64_t n, uint64_t g0, uint64_t g1, int k, int min_len) {
+// [snippet 7: a shard's columns straight from the index files]
+int fd_lcp = open((input + ".out.lcp").c_str(), O_RDONLY), fd_bwt = open((input + ".out").c_str(), O_RDONLY);
+e2s_shard_desc d = {g0, g1 - g0, n, (uint32_t)(g0 < 152 ? g0 : 152), (uint32_t)(g1 < n ? 1 : 0), 1, 4, 1, 0};   // SA range [g0, g1) of n entries, halos 152 / 1
+const uint64_t first = g0 - d.halo_left;                          // the first PROVIDED entry: the byte offset in a 1-byte-per-entry file
+e2s_upload_lcp_bwt_fd(h, &d, fd_lcp, first, fd_bwt, first);       // pread into pinned buffers, several threads; no mapping
+e2s_prefilter_arm(h, 5);
+e2s_cluster_scan(h, k, min_len, 0);
+close(fd_lcp); close(fd_bwt);
+// [end]
+    return 0;
+}
+
