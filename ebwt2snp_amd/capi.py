@@ -77,7 +77,7 @@ class Timing(C.Structure):
 # every symbol include/e2s_hip.h declares (checked by tests/test_capi_symbols.py)
 BYTE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)     # e2s_byte_sink
 SYMBOLS = ["e2s_create", "e2s_destroy", "e2s_last_error", "e2s_version", "e2s_upload_bcr", "e2s_upload_gesa",
-           "e2s_attach_soa", "e2s_upload_lcp", "e2s_upload_lcp_bwt", "e2s_upload_bcr_fd", "e2s_upload_gesa_fd", "e2s_upload_lcp_bwt_fd", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
+           "e2s_attach_soa", "e2s_upload_lcp", "e2s_upload_lcp_bwt", "e2s_upload_bcr_fd", "e2s_upload_gesa_fd", "e2s_upload_lcp_bwt_fd", "e2s_set_upload_staging", "e2s_cluster_scan", "e2s_boundary_desc", "e2s_stitch_plan", "e2s_stitch",
            "e2s_cluster_counts", "e2s_fetch_clusters", "e2s_stream_clusters", "e2s_load_clusters", "e2s_cluster_hist", "e2s_scan_stats_desc",
            "e2s_hist_after_stitch", "e2s_auto_max_clust_length_ranks",
            "e2s_auto_max_clust_length", "e2s_prefilter_begin", "e2s_prefilter_arm", "e2s_find_candidates", "e2s_candidate_stride", "e2s_fetch_candidates", "e2s_candidates_view",
@@ -107,6 +107,8 @@ def lib():
         L.e2s_upload_bcr_fd.argtypes = [H, C.POINTER(ShardDesc), C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_uint64]
         L.e2s_upload_gesa_fd.argtypes = [H, C.POINTER(ShardDesc), C.c_int, C.c_uint64]
         L.e2s_upload_lcp_bwt_fd.argtypes = [H, C.POINTER(ShardDesc), C.c_int, C.c_uint64, C.c_int, C.c_uint64]
+    if hasattr(L, "e2s_set_upload_staging"):
+        L.e2s_set_upload_staging.argtypes = [H, C.c_int]
     L.e2s_upload_lcp_bwt.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_void_p]
     L.e2s_attach_soa.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.e2s_upload_lcp.argtypes = [H, C.POINTER(ShardDesc), C.c_void_p, C.c_uint8]
@@ -209,6 +211,9 @@ class Handle:
     def upload_bcr_fd(self, d, bwt_fd, bwt_off, lcp_fd, lcp_off, pairsa_fd, pairsa_off):
         """the columns from open files (descriptor, byte offset of the first provided entry): pread into pinned buffers"""
         self._ck(self.L.e2s_upload_bcr_fd(self.h, C.byref(d), bwt_fd, bwt_off, lcp_fd, lcp_off, pairsa_fd, pairsa_off))
+
+    def set_upload_staging(self, through_pinned_buffers):
+        self._ck(self.L.e2s_set_upload_staging(self.h, 1 if through_pinned_buffers else 0))
 
     def upload_gesa_fd(self, d, fd, off):
         self._ck(self.L.e2s_upload_gesa_fd(self.h, C.byref(d), fd, off))

@@ -93,6 +93,7 @@ struct e2s_ctx {
     uint64_t* d_scan_stats = nullptr;                            // [151 freq | n_records | n_bases] tallied by the scan kernel (in front of d_words)
     std::vector<uint64_t> host_fl_starts; std::vector<uint16_t> host_fl_lens;   // e2s_internal_flagged_list
     uint8_t* d_compact = nullptr; size_t compact_bytes = 0; uint64_t* d_compact_keys = nullptr; uint64_t compact_keys_cap = 0;   // e2s_internal_find_candidates_compact
+    bool up_staged = false;                                      // e2s_set_upload_staging
     std::vector<hipStream_t> up_streams;                         // upload_sliced, upload_from_fd
     std::vector<uint8_t*> pin_up; std::vector<hipEvent_t> ev_up; uint8_t* pin_up_base = nullptr; size_t pin_up_bytes = 0;   // upload_from_fd: two pinned buffers (pieces of one allocation) and events per thread
     bool ko_clean = false;                                       // the ordering pass's bucket counts are zero (its last kernel leaves them so)
@@ -391,9 +392,10 @@ static int narrow_lcp(e2s_ctx* h) {
 static int upload_from_fd(e2s_ctx* h, void* dst, int fd, uint64_t off, uint64_t bytes, size_t read_ahead,
                           const std::function<void(unsigned, uint64_t, const uint8_t*, uint64_t, size_t, uint64_t, uint64_t)>& per_chunk, const uint8_t* mem);
 static int upload_sliced(e2s_ctx* h, void* dst, const void* src, size_t bytes) {
-    // E2S_UPLOAD_PINNED=1 (development tier): large copies through the handle's own pinned buffers (upload_from_fd with a memory source)
-    static const bool staged = e2s_env_dev("E2S_UPLOAD_PINNED") && atoi(e2s_env_dev("E2S_UPLOAD_PINNED")) != 0;
-    if (staged && bytes >= ((size_t)64 << 20)) return upload_from_fd(h, dst, -1, 0, bytes, 0, nullptr, (const uint8_t*)src);
+    // e2s_set_upload_staging(h, 1) (or E2S_UPLOAD_PINNED=1, development tier): large copies through the handle's own pinned buffers (upload_from_fd
+    // with a memory source) -- for sources that are file mappings, whose pages fault inside the runtime's single staging copy
+    static const bool staged_env = e2s_env_dev("E2S_UPLOAD_PINNED") && atoi(e2s_env_dev("E2S_UPLOAD_PINNED")) != 0;
+    if ((staged_env || h->up_staged) && bytes >= ((size_t)64 << 20)) return upload_from_fd(h, dst, -1, 0, bytes, 0, nullptr, (const uint8_t*)src);
     static const int T_env = getenv("E2S_UPLOAD_THREADS") ? atoi(getenv("E2S_UPLOAD_THREADS")) : 8;      // (6 GB out of the page cache: 4 threads 0.34 s, 8 threads 0.28-0.30: profiles/round5_c3_end_to_end.txt)
     const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(T_env, 1), bytes >> 24));     // (slices of at least 16 MB)
     if (T == 1) { CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return E2S_OK; }
@@ -558,6 +560,11 @@ static int upload_bcr_impl(e2s_ctx* h, const e2s_shard_desc* d, const ColSrc& bw
     CK(hipGetLastError());
     ev_ms(&h->tm.upload_ms, h->ev[0], h->ev[1], h->timing >= 2);
     return narrow_lcp(h);
+}
+extern "C" int e2s_set_upload_staging(e2s_handle h, int through_pinned_buffers) {
+    if (!h) return E2S_ERR_ARG;
+    h->up_staged = through_pinned_buffers != 0;
+    return E2S_OK;
 }
 extern "C" int e2s_upload_bcr(e2s_handle h, const e2s_shard_desc* d, const void* bwt, const void* lcp, const void* pairsa) {
     dbg_entry("e2s_upload_bcr");

@@ -83,6 +83,7 @@ struct Shared {
     // the reads, indexed once
     const void* rd_text = nullptr; uint64_t rd_bytes = 0, rd_n = 0; const uint64_t* rd_start = nullptr; const uint32_t* rd_len = nullptr; uint32_t rd_max = 0;
     bool reads_ok = false;
+    bool staged = true;                         // uploads out of the mappings through the handles' pinned buffers (e2s_set_upload_staging)
     bool mapped = true, stream_reads = false;   // the shard from the files' mappings, or with pread (E2S_MGPU_PREAD=1); a lone rank streaming the FASTA itself (E2S_MGPU_STREAM_READS=1)
     int cl_fd = -1, snp_fd = -1; std::string snp_path;
     std::atomic<int> rc{0};
@@ -259,6 +260,8 @@ void rank_main(Shared& S, int r) {
     pc.mark("rank 0: first handle (HIP start-up), exchange buffers");
     if (!mine_rc && S.slim) STEP(e2s_create(dev, &hc), "e2s_create (per-cluster pass)");
     pc.mark("rank 0: second handle");
+    // (the pointers this driver uploads from are file mappings: their copies go through the handles' pinned buffers -- E2S_MGPU_STAGING=0: the runtime's staging)
+    if (S.staged) { if (h) (void)e2s_set_upload_staging(h, 1); if (hc) (void)e2s_set_upload_staging(hc, 1); }
     e2s_handle const hr_ = S.slim ? hc : h;                     // where the reads live
     // A lone rank streams the FASTA itself (e2s_upload_reads_fasta: read, sent and indexed chunk by chunk, in one pass).  Where the reads live on a
     // handle of their own (hc) that goes on in a thread of its own WHILE the shard's columns go up on h: the two share the link and the cores,
@@ -598,6 +601,7 @@ int main(int argc, char** argv) {
     // rank's beside its shard instead.  Measured on the whole c3 files, box by box (profiles/round5_c3_uploads_from_files.txt): the three forms end
     // within 5 % of each other -- what the shard's upload gains the FASTA index, now the longer arm, gives back; the mappings stay the default.
     S.mapped = !(getenv("E2S_MGPU_PREAD") != nullptr && atoi(getenv("E2S_MGPU_PREAD")) != 0);
+    S.staged = !(getenv("E2S_MGPU_STAGING") != nullptr && atoi(getenv("E2S_MGPU_STAGING")) == 0);
     S.stream_reads = getenv("E2S_MGPU_STREAM_READS") != nullptr && atoi(getenv("E2S_MGPU_STREAM_READS")) != 0 && !S.gather_reads && S.nranks == 1;
     if (const char* e = e2s_env_dev("E2S_MGPU_FAIL_RANK")) S.fail_rank = atoi(e);
     S.fail_at = e2s_env_dev("E2S_MGPU_FAIL_AT") ? e2s_env_dev("E2S_MGPU_FAIL_AT") : "setup";

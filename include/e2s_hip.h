@@ -100,6 +100,10 @@ int e2s_upload_lcp_bwt(e2s_handle h, const e2s_shard_desc* d, const void* lcp, c
  * sent from there: a caller that would map the file and pass the pointer pays a page fault per 4 KB of it inside the copy (6 GB of
  * LCP + BWT out of the page cache: 0.28-0.30 s through a mapping) and again for tearing the mapping down.  E2S_ERR_IO: a file is
  * shorter than the shard needs.  The descriptors are used with pread only (no seek, not closed). */
+/* How the uploads out of HOST MEMORY (the pointer forms above, e2s_upload_reads) stage large copies: 0 (default) the runtime's own staging of a
+ * copy out of pageable memory -- best for ordinary memory (48 GB/s from eight threads) --, 1: through the handle's pinned buffers, filled by
+ * those threads -- for pointers into file MAPPINGS, whose pages fault inside the copy (6 GB of LCP + BWT: 0.25 -> 0.16-0.17 s). */
+int e2s_set_upload_staging(e2s_handle h, int through_pinned_buffers);
 int e2s_upload_bcr_fd(e2s_handle h, const e2s_shard_desc* d, int bwt_fd, uint64_t bwt_off, int lcp_fd, uint64_t lcp_off, int pairsa_fd, uint64_t pairsa_off);
 int e2s_upload_gesa_fd(e2s_handle h, const e2s_shard_desc* d, int fd, uint64_t off);
 int e2s_upload_lcp_bwt_fd(e2s_handle h, const e2s_shard_desc* d, int lcp_fd, uint64_t lcp_off, int bwt_fd, uint64_t bwt_off);
