@@ -446,7 +446,7 @@ class EgsaSource(C.Structure):
 EGSA_GET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
 EGSA_RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
-EgsaSource._fields_ = [("get", EGSA_GET), ("release", EGSA_RELEASE), ("user", C.c_void_p), ("gesa", C.c_int32), ("reserved", C.c_int32)]
+EgsaSource._fields_ = [("get", EGSA_GET), ("release", EGSA_RELEASE), ("user", C.c_void_p), ("gesa", C.c_int32), ("flags", C.c_int32)]
 
 
 class ChunkParams(C.Structure):

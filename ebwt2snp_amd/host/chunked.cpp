@@ -68,7 +68,11 @@ class ChunkPipe {
     // the two handles first -- the caller makes the reads resident on them from ITS thread -- and only then the uploader thread, which
     // works on the handles from then on (a handle is one thread's at a time)
     int create() {
-        for (auto& h : h_) if (!h) { int rc = e2s_create(p_.device, &h); if (rc) { err_ = e2s_last_error(nullptr); return rc; } }
+        for (auto& h : h_) if (!h) {
+            int rc = e2s_create(p_.device, &h);
+            if (rc) { err_ = e2s_last_error(nullptr); return rc; }
+            if (src_.flags & 1) (void)e2s_set_upload_staging(h, 1);   // (the source hands out pointers into file mappings)
+        }
         return E2S_OK;
     }
     int start() {
@@ -425,7 +429,7 @@ extern "C" int e2s_ebwt2snp_chunked(const e2s_chunk_params* p, const e2s_c2s_opt
             uint64_t n_cand = 0;
             e2s_handle ht = hc;
             if (flagged[(size_t)r].full) {
-                if (!hf) { RC(e2s_create(p->device, &hf)); RC(e2s_share_reads(hf, hc)); }
+                if (!hf) { RC(e2s_create(p->device, &hf)); RC(e2s_share_reads(hf, hc)); if (src->flags & 1) (void)e2s_set_upload_staging(hf, 1); }
                 const Chunk& c = chunks[(size_t)r];
                 const uint64_t lo = c.lo - c.hl, n = (c.hi - c.lo) + c.hl + c.hr;
                 const void *bwt = nullptr, *lcp = nullptr, *psa = nullptr, *aos = nullptr;

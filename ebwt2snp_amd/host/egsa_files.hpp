@@ -76,7 +76,7 @@ struct FileSource {
         *bwt = s->F->bwt.p + lo; *lcp = s->F->lcp.p + lo * (uint64_t)s->x; *pairsa = s->F->pairsa.p + lo * (uint64_t)(s->y + s->z);
         return 0;
     }
-    e2s_egsa_source source() const { e2s_egsa_source r{}; r.get = &FileSource::get; r.release = nullptr; r.user = (void*)this; r.gesa = F->gesa ? 1 : 0; return r; }
+    e2s_egsa_source source() const { e2s_egsa_source r{}; r.get = &FileSource::get; r.release = nullptr; r.user = (void*)this; r.gesa = F->gesa ? 1 : 0; r.flags = 1; return r; }
 };
 // E2S_CHUNK_ENTRIES: SA positions per chunk (default: the library's, 1.5x10^9); inputs that fit one chunk go through in one piece
 inline uint64_t chunk_entries_env() { const char* e = getenv("E2S_CHUNK_ENTRIES"); return e ? strtoull(e, nullptr, 10) : 0ull; }

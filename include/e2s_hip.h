@@ -340,7 +340,8 @@ typedef struct {
     void (*release)(void* user, int slot);                     /* may be NULL */
     void* user;
     int32_t gesa;
-    int32_t reserved;
+    int32_t flags;                                             /* bit 0: the pointers are into file MAPPINGS (their copies then go through the handles' pinned
+                                                                  buffers, e2s_set_upload_staging); other bits: 0 */
 } e2s_egsa_source;
 typedef struct {
     int32_t device;
