@@ -258,11 +258,25 @@ void rank_main(Shared& S, int r) {
             hipMalloc(&d_send, BLOB) != hipSuccess || hipMalloc(&d_recv, BLOB * (size_t)S.nranks) != hipSuccess) mine_rc = E2S_ERR_HIP;
     }
     pc.mark("rank 0: first handle (HIP start-up), exchange buffers");
-    if (!mine_rc && S.slim) STEP(e2s_create(dev, &hc), "e2s_create (per-cluster pass)");
+    // the second handle (streams, events, a dozen small allocations, a pinned mailbox: 20-45 ms) is made by a thread of its own while the shard goes up
+    // on the first -- unless the FASTA is streamed on it beside the shard, which needs it now
+    std::thread hc_thread; int hc_rc = 0;
+    auto make_hc = [&hc, &hc_rc, dev, &S]() { hc_rc = e2s_create(dev, &hc); if (!hc_rc && S.staged) (void)e2s_set_upload_staging(hc, 1); };
+    if (!mine_rc && S.slim) { if (S.stream_reads) make_hc(); else hc_thread = std::thread(make_hc); }
+    auto hc_ready = [&]() {
+        if (hc_thread.joinable()) hc_thread.join();
+        if (hc_rc && !mine_rc) {
+            std::lock_guard<std::mutex> lk(S.log_m);
+            std::cerr << "rank " << r << ": e2s_create (per-cluster pass) failed (" << hc_rc << "): " << e2s_last_error(nullptr) << std::endl;
+            mine_rc = hc_rc;
+        }
+        hc_rc = 0;
+    };
+    if (S.stream_reads) hc_ready();
     pc.mark("rank 0: second handle");
     // (the pointers this driver uploads from are file mappings: their copies go through the handles' pinned buffers -- E2S_MGPU_STAGING=0: the runtime's staging)
-    if (S.staged) { if (h) (void)e2s_set_upload_staging(h, 1); if (hc) (void)e2s_set_upload_staging(hc, 1); }
-    e2s_handle const hr_ = S.slim ? hc : h;                     // where the reads live
+    if (S.staged && h) (void)e2s_set_upload_staging(h, 1);
+#define hr_ (S.slim ? hc : h)                                    /* where the reads live (hc: once hc_ready() has run) */
     // A lone rank streams the FASTA itself (e2s_upload_reads_fasta: read, sent and indexed chunk by chunk, in one pass).  Where the reads live on a
     // handle of their own (hc) that goes on in a thread of its own WHILE the shard's columns go up on h: the two share the link and the cores,
     // and neither waits for the other's allocations and kernels; joined right before the per-cluster pass, which wants the reads resident.
@@ -297,6 +311,7 @@ void rank_main(Shared& S, int r) {
             S.uploaded[(size_t)r] = rec * n_prov;
         }
     }
+    hc_ready();
     pc.mark("rank 0: shard uploaded");
     // the reads: all of them now -- a lone rank streams the FASTA itself (one pass: read, sent and indexed chunk by chunk); several ranks take
     // them from the ONE index the main thread has been building meanwhile -- or, later, those this rank's candidates name
@@ -318,6 +333,7 @@ void rank_main(Shared& S, int r) {
     if (!mine_rc && !S.slim) { rp.probe_only = 1; S.form[(size_t)r] = e2s_resident_job(h, &rp, job_allgather, nullptr, nullptr) == E2S_OK ? 1 : 0; rp.probe_only = 0; }
     ImageWriter writer;                                         // (the stepwise path starts it early; it is joined before the handles go)
     auto leave = [&]() {
+        if (hc_thread.joinable()) hc_thread.join();
         if (reads_thread.joinable()) reads_thread.join();
         if (writer.started()) (void)writer.join();
         if (d_send) (void)hipFree(d_send);
@@ -513,6 +529,7 @@ void rank_main(Shared& S, int r) {
     //  0.8-s job on the full c3 files; E2S_MGPU_TEARDOWN=1 under E2S_DEV=1 frees everything the slow way)
     if (!all_fine || S.teardown) leave();
 }
+#undef hr_
 
 void help() {
     std::cout << "ebwt2snp_mgpu [options]\nebwt2clust + clust2snp over the GPUs of one node (SA-range shards, RCCL boundary stitch). Options:\n"
